@@ -1,0 +1,130 @@
+/*
+ * nvorbis_hip.h -- C ABI of libnvorbis_hip.so, the MI355X (gfx950) back end for NVorbis'
+ * per-packet synthesis path.
+ *
+ * The reference (NVorbis 0.10.5, managed C#) has no native boundary; its synthesis plug-ins sit
+ * behind the internal interfaces IMdct / IFloor / IResidue / IMapping / IMode created by IFactory
+ * (NVorbis/Contracts/I*.cs, NVorbis/Factory.cs:5-59) and are driven once per packet by
+ * StreamDecoder.DecodeNextPacket (NVorbis/StreamDecoder.cs:497-506).  This header declares what a
+ * P/Invoke binding for that path binds to (see INTEGRATION.md for the C# side):
+ *
+ *   level 1  batched, device-pointer entry points that mirror the interface methods one to one
+ *            (unit parity tests, GpuMdct / GpuFloor / GpuResidue / GpuMapping shims);
+ *   level 2  a stream object that takes raw Vorbis packets exactly as IPacketProvider hands them
+ *            to StreamDecoder (bytes + granule position + end-of-stream / resync flags), parses
+ *            them on the host, synthesises whole batches of frames on the GPU and returns
+ *            interleaved float PCM with VorbisReader.ReadSamples semantics.
+ *
+ * Conventions: every function returns an int status (NVH_OK == 0, negative = error, never throws or
+ * unwinds across the ABI); handles are opaque; `d_` pointers are device (HBM) addresses, all other
+ * pointers are host addresses owned by the caller for the duration of the call.  A handle must not
+ * be used from two threads at once; distinct handles are independent.
+ */
+#ifndef NVORBIS_HIP_H
+#define NVORBIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (C# shim maps them back to the reference's exception types) ---- */
+#define NVH_OK 0
+#define NVH_ERR_INVALID_DATA (-1) /* System.IO.InvalidDataException (Mapping.cs:40-77, Floor1.cs:122, Residue0.cs:64,73, Codebook.cs:63,161, Factory.cs:29,38,56) */
+#define NVH_ERR_ARGUMENT (-2)     /* ArgumentOutOfRangeException / ArgumentException (StreamDecoder.cs:322-325, Floor1.cs:188) */
+#define NVH_ERR_RUNTIME (-3)      /* IndexOutOfRange / NullReference / DivideByZero class faults of the managed code */
+#define NVH_ERR_NOMEM (-4)
+#define NVH_ERR_NOT_VORBIS (-5)   /* header signature mismatch (StreamDecoder.cs:145-155) */
+#define NVH_ERR_DEVICE (-6)       /* HIP runtime error; nvh_last_hip_error() has the code */
+#define NVH_ERR_UNSUPPORTED (-7)  /* legal stream outside the documented limits of this build */
+#define NVH_ERR_NO_GPU (-8)       /* no gfx950 device visible: there is NO CPU fallback */
+
+typedef struct nvh_ctx nvh_ctx;       /* device + HIP stream + per-n IMDCT table cache */
+typedef struct nvh_stream nvh_stream; /* one logical Vorbis stream: setup tables in HBM + overlap state */
+typedef struct nvh_batch nvh_batch;   /* one parsed batch of frames resident in HBM */
+
+/* packet flags, as IPacket exposes them (Contracts/IPacket.cs: IsEndOfStream, IsResync) */
+#define NVH_PKT_EOS 1
+#define NVH_PKT_RESYNC 2
+
+const char *nvh_version(void);
+int nvh_last_hip_error(void);
+int nvh_device_count(void);
+
+/* ---- context ---- */
+int nvh_ctx_create(int device, nvh_ctx **out);
+void nvh_ctx_destroy(nvh_ctx *ctx);
+/* Launch on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int nvh_ctx_set_hip_stream(nvh_ctx *ctx, void *hip_stream);
+int nvh_ctx_synchronize(nvh_ctx *ctx);
+
+/* ---- level 1: batched mirrors of the plug-in interface methods (device pointers) ---- */
+
+/* IMdct.Reverse(float[] samples, int sampleCount) (Contracts/IMdct.cs:5, Mdct.cs:13-21) on `batch`
+ * buffers: buffer b = d_buf + b*stride holds n floats, reads [0,n/2), writes [0,n).  n = 64..8192. */
+int nvh_mdct_reverse(nvh_ctx *ctx, int n, int batch, float *d_buf, int64_t stride);
+
+/* Table builders (host, exact reference typing): Mdct.cs:30-63, Mode.cs:69-117. */
+int nvh_mdct_tables(int n, float *a /*n/2*/, float *b /*n/2*/, float *c /*n/4*/, uint16_t *bitrev /*n/8*/);
+int nvh_calc_window(int prev_block, int block, int next_block, float *out /*block*/);
+int nvh_calc_overlap(int prev_block, int block, int next_block, int *start, int *valid, int *total);
+
+/* ---- level 2: stream ---- */
+
+/* StreamDecoder..ctor -> ProcessHeaderPackets (StreamDecoder.cs:50-127): the three Vorbis header
+ * packets.  Builds every table of LoadBooks (:226-289) and uploads it once.  ctx == NULL creates a
+ * host-only stream that can parse packets but returns NVH_ERR_NO_GPU from every synthesis call. */
+int nvh_stream_open(nvh_ctx *ctx, const uint8_t *id_pkt, int id_len, const uint8_t *comment_pkt, int comment_len,
+                    const uint8_t *setup_pkt, int setup_len, nvh_stream **out);
+void nvh_stream_close(nvh_stream *s);
+int nvh_stream_info(const nvh_stream *s, int *channels, int *sample_rate, int *block0, int *block1);
+/* IStreamDecoder.ClipSamples (StreamDecoder.cs:723, default on) / HasClipped (:728) */
+int nvh_stream_set_clip(nvh_stream *s, int on);
+int nvh_stream_has_clipped(nvh_stream *s, int *clipped);
+/* IStreamDecoder.SamplePosition after everything parsed so far has been read (StreamDecoder.cs:718) */
+int nvh_stream_position(const nvh_stream *s, int64_t *position, int64_t *emitted, int *eos);
+
+/* Host parse of one audio packet into the pending batch (DecodeNextPacket, StreamDecoder.cs:465-530,
+ * bit-consuming half).  granule < 0 = packet carries no granule position. */
+int nvh_stream_push_packet(nvh_stream *s, const uint8_t *data, int len, int64_t granule, int flags);
+/* The packet provider returned null (StreamDecoder.cs:472-475). */
+int nvh_stream_push_end(nvh_stream *s);
+/* Pending (parsed, not yet synthesised) work. */
+/* Frame geometry of the pending batch, 8 int32 per frame: block size, start, valid, total
+ * (Mode.GetPacketInfo, Mode.cs:119-151, valid after the EOS trim of StreamDecoder.cs:429-437),
+ * emit_start, emit_count, overlap source frame (-1 none, -2 carried tail), overlap length. */
+int nvh_stream_pending_geometry(const nvh_stream *s, int32_t *out, int cap_frames);
+int nvh_stream_pending(const nvh_stream *s, int *frames, int64_t *pcm_samples_per_channel);
+
+/* Synthesise the pending batch: H2D descriptors -> kernels -> interleaved PCM.  Exactly one of
+ * pcm_host / d_pcm is non-NULL; capacity is in floats and must hold pending samples * channels.
+ * Advances the overlap state (the last block's tail is carried to the next batch). */
+int nvh_stream_synth(nvh_stream *s, float *pcm_host, float *d_pcm, int64_t capacity, int64_t *written);
+
+/* ---- device-resident batches (benchmarks, pipelined callers) ---- */
+/* Move the pending batch into HBM as an object of its own; the stream's pending batch becomes empty
+ * and its overlap state advances as if the batch had been synthesised. */
+int nvh_batch_upload(nvh_stream *s, nvh_batch **out);
+int nvh_batch_info(const nvh_batch *b, int *frames, int *chan_frames, int64_t *pcm_samples_per_channel,
+                   int64_t *descriptor_bytes);
+/* Launch the synthesis kernels for a resident batch (asynchronous on the context's stream);
+ * may be repeated, results are identical each time.  d_pcm holds samples*channels floats. */
+int nvh_batch_synth(nvh_batch *b, float *d_pcm, int64_t capacity);
+/* Time `iters` repetitions with hipEvents on the launch stream: total milliseconds for the whole
+ * pipeline, and per kernel (residue, couple+floor, imdct+window, overlap+emit). */
+int nvh_batch_time(nvh_batch *b, float *d_pcm, int64_t capacity, int iters, float *total_ms, float *kernel_ms /*[4]*/);
+void nvh_batch_free(nvh_batch *b);
+
+/* ---- container helper (minimal forward-only demux so .ogg files can feed the path) ----
+ * Splits the first logical stream of an Ogg file into packets the way NVorbis' seekable reader
+ * delivers them (Ogg/PageReader.cs:27-93, Ogg/PacketProvider.cs:324-438).  Call with NULL outputs to
+ * size, then again with buffers. */
+int nvh_ogg_demux(const uint8_t *bytes, size_t len, uint8_t *pkt_bytes, int64_t pkt_bytes_cap, int64_t *offsets,
+                  int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets, int64_t *total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVORBIS_HIP_H */

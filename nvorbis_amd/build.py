@@ -1,0 +1,48 @@
+"""Build script for libnvorbis_hip.so (hipcc, gfx950 only, in-tree)."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libnvorbis_hip.so")
+SOURCES = ["nvh_api.hip", "kernels.hip", "host_setup.cpp", "host_parse.cpp", "host_ogg.cpp"]
+# -ffp-contract=off: bit-exact parity with the reference needs separately rounded mul/add (no v_fma_f32);
+# fp32 denormals are preserved by default (no -fgpu-flush-denormals-to-zero).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libnvorbis_hip.so cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    for root, _, files in os.walk(CSRC):
+        for f in files:
+            if os.path.getmtime(os.path.join(root, f)) > t:
+                return True
+    inc = os.path.join(HERE, "..", "include", "nvorbis_hip.h")
+    return os.path.getmtime(inc) > t
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc()] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(OUT)

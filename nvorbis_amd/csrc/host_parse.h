@@ -1,0 +1,74 @@
+// host_parse.h -- audio-packet bit parser + stream geometry state machine (product host code).
+//
+// Splits NVorbis' per-packet work at the only place it can be split: everything that consumes bits
+// (Mode.GetPacketInfo, IFloor.Unpack, the classification / entry decode inside IResidue.Decode) runs
+// here on the host and is recorded as a frame descriptor; everything that touches float vectors
+// (WriteVectors adds, inverse coupling, IFloor.Apply, IMdct.Reverse, windowing, OverlapBuffers,
+// interleave + clip) runs on the GPU from those descriptors.  Bit parsing never depends on a float
+// result, so the parser can run arbitrarily far ahead of synthesis.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "host_setup.h"
+#include "nvh_format.h"
+
+namespace nvh {
+
+struct FrameBatch {
+  std::vector<NvhFrame> frames;
+  std::vector<NvhChan> chans;
+  std::vector<NvhResPass> passes;
+  std::vector<NvhResOp> ops;
+  std::vector<uint16_t> entries;
+  std::vector<uint16_t> posts;
+  std::vector<float> coeffs;
+  int64_t pcm_samples = 0;      // per-channel samples the batch emits
+  bool sequential_ola = false;  // some overlap region reaches into a tail: apply overlaps in order
+  bool clipped_unknown = true;
+  void clear() {
+    frames.clear(); chans.clear(); passes.clear(); ops.clear(); entries.clear(); posts.clear(); coeffs.clear();
+    pcm_samples = 0;
+    sequential_ola = false;
+  }
+};
+
+// packet flags: NVH_PKT_EOS / NVH_PKT_RESYNC of the public C ABI header
+
+// Mirrors the integer half of StreamDecoder.Read / ReadNextPacket / DecodeNextPacket
+// (StreamDecoder.cs:320-530): which samples each packet emits, where the previous tail overlaps,
+// the EOS trim, the drain after a failed packet, SamplePosition bookkeeping.
+class StreamParser {
+ public:
+  explicit StreamParser(const Setup* s) : s_(s) {}
+
+  // Parse one audio packet.  Appends at most one frame (and possibly extends the previous frame's
+  // emission when the packet fails: "drain", StreamDecoder.cs:352-356).  Returns NVH_OK or an error
+  // that corresponds to an exception escaping ReadSamples in the reference.
+  int push_packet(const uint8_t* data, int len, int64_t granule, int flags, FrameBatch& out);
+  // The provider ran out of packets (GetNextPacket()==null, StreamDecoder.cs:472-475).
+  int push_end(FrameBatch& out);
+  // Call after a batch was handed to synthesis: following frames refer to the carried tail.
+  void begin_batch();
+
+  bool eos() const { return eos_found_; }
+  int64_t position() const { return position_; }   // IStreamDecoder.SamplePosition after everything parsed was read
+  int64_t emitted() const { return emitted_; }
+
+ private:
+  int parse_audio(BitReader& p, FrameBatch& out, int* decoded);
+  int decode_floor(int floor_idx, BitReader& p, FrameBatch& out, NvhChan& ch, bool* energy);
+  int decode_residue(int residue_idx, BitReader& p, int block_size, FrameBatch& out, NvhResPass& pass);
+  void drain(FrameBatch& out);
+
+  const Setup* s_;
+  // StreamDecoder.cs:30-39 state, integer part
+  bool has_prev_buf_ = false;   // _prevPacketBuf != null
+  int prev_start_ = 0, prev_end_ = 0, prev_stop_ = 0;
+  int prev_frame_ = -1;         // index of the previous decoded frame in the current batch, -2 = carried
+  bool has_position_ = false, eos_found_ = false;
+  int64_t position_ = 0;        // _currentPosition + bufferedSamples
+  int64_t emitted_ = 0;         // total samples emitted since open (per channel)
+};
+
+}  // namespace nvh

@@ -1,0 +1,621 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels for NVorbis' per-packet synthesis path.
+//
+//   k_residue        IResidue.Decode's vector adds (Residue0.cs:180-201, Residue1.cs:8-26, Residue2.cs:23-47)
+//   k_couple_floor   inverse channel coupling (Mapping.cs:137-182) + IFloor.Apply
+//                    (Floor1.cs:186-341, Floor0.cs:152-212)
+//   k_imdct_window   IMdct.Reverse (Mdct.cs:65-535) + the window multiply of Mode.Decode (Mode.cs:160-166)
+//   k_ola_*          StreamDecoder.OverlapBuffers (:532-541) + ClippingCopyBuffer / CopyBuffer (:391-415)
+//
+// Parity rule: every float expression keeps the reference's operand order and association and is
+// rounded per operation; this file is compiled with -ffp-contract=off (no v_fma_f32 contraction), fp32
+// denormals preserved.  Butterflies of one IMDCT stage touch disjoint elements, so running them in
+// parallel in any order is bit-identical to the reference's sequential loops.
+#include <hip/hip_runtime.h>
+
+#include "kernels_common.h"
+
+#define NVH_THREADS 256
+
+__constant__ float c_inverse_db[256] = {
+#include "floor1_db_table.inc"
+};
+
+// ================================================================================================
+// IMDCT (generic block size n = 64 .. 8192), stage-synchronous over LDS
+// ================================================================================================
+
+// One radix-2 butterfly of "step 3" (Mdct.cs:324-329 and siblings).
+__device__ __forceinline__ void bfly(float* u, int e0, int e2, float a0, float a1) {
+  float k0 = u[e0] - u[e2];
+  float k1 = u[e0 - 1] - u[e2 - 1];
+  u[e0] = u[e0] + u[e2];
+  u[e0 - 1] = u[e0 - 1] + u[e2 - 1];
+  u[e2] = k0 * a0 - k1 * a1;
+  u[e2 - 1] = k1 * a0 + k0 * a1;
+}
+
+// Mdct.cs:509-535
+__device__ __forceinline__ void iter_54(float* e, int z) {
+  float k00 = e[z] - e[z - 4];
+  float y0 = e[z] + e[z - 4];
+  float y2 = e[z - 2] + e[z - 6];
+  float k22 = e[z - 2] - e[z - 6];
+  e[z] = y0 + y2;
+  e[z - 2] = y0 - y2;
+  float k33 = e[z - 3] - e[z - 7];
+  e[z - 4] = k00 + k33;
+  e[z - 6] = k00 - k33;
+  float k11 = e[z - 1] - e[z - 5];
+  float y1 = e[z - 1] + e[z - 5];
+  float y3 = e[z - 3] + e[z - 7];
+  e[z - 1] = y1 + y3;
+  e[z - 3] = y1 - y3;
+  e[z - 5] = k11 - k22;
+  e[z - 7] = k11 + k22;
+}
+
+// u: LDS, n/2 floats holding the spectrum on entry.  v: LDS scratch, n/2 floats (the reference's buf2).
+// On return v holds the result of step 7; step 8 is done by the caller through `emit`.
+template <typename Emit>
+__device__ void imdct_lds(float* u, float* v, int n, const float* __restrict__ A, const float* __restrict__ B,
+                          const float* __restrict__ C, const uint16_t* __restrict__ BR, int tid, int nthreads,
+                          Emit emit) {
+  const int n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+  int ld = 0;
+  for (int t = n; t > 1; t >>= 1) ++ld;  // ilog(n) - 1
+
+  // step 0 (Mdct.cs:74-97): spectrum (u) -> v
+  for (int j = tid; j < n4; j += nthreads) {
+    if (j < n8) {
+      int d = n2 - 2 - 2 * j, e = 4 * j, AA = 2 * j;
+      v[d + 1] = (u[e] * A[AA] - u[e + 2] * A[AA + 1]);
+      v[d] = (u[e] * A[AA + 1] + u[e + 2] * A[AA]);
+    } else {
+      int jj = j - n8;
+      int d = n4 - 2 - 2 * jj, e = n2 - 3 - 4 * jj, AA = n4 + 2 * jj;
+      v[d + 1] = (-u[e + 2] * A[AA] - -u[e] * A[AA + 1]);
+      v[d] = (-u[e + 2] * A[AA + 1] + -u[e] * A[AA]);
+    }
+  }
+  __syncthreads();
+
+  // step 2 (Mdct.cs:105-139): v -> u
+  for (int c = tid; c < n8; c += nthreads) {
+    int lo = 2 * c, hi = n4 + 2 * c, t = n2 - 4 - 4 * c;
+    float d1 = v[hi + 1] - v[lo + 1];
+    float d0 = v[hi] - v[lo];
+    u[hi + 1] = v[hi + 1] + v[lo + 1];
+    u[hi] = v[hi] + v[lo];
+    u[lo + 1] = d1 * A[t] - d0 * A[t + 1];
+    u[lo] = d0 * A[t] + d1 * A[t + 1];
+  }
+  __syncthreads();
+
+  // step 3 generic stages (Mdct.cs:144-183).  Stage l: groups g < 2^(l+1), butterflies m < M_l,
+  // e0 = n2-1 - g*(n>>(l+2)) - 2m, e2 = e0 - (n>>(l+3)), twiddle index m<<(l+3).  The reference runs
+  // stages 0 and 1 unconditionally (:144-151), further ones while l < ld-6.
+  const int L = (ld - 6) > 2 ? (ld - 6) : 2;
+  for (int l = 0; l < L; ++l) {
+    const int M = ((n >> (l + 4)) >> 2) << 2;
+    const int total = M << (l + 1);
+    for (int b = tid; b < total; b += nthreads) {
+      int g = b / M, m = b - g * M;
+      int e0 = n2 - 1 - g * (n >> (l + 2)) - 2 * m;
+      int e2 = e0 - (n >> (l + 3));
+      int t = m << (l + 3);
+      bfly(u, e0, e2, A[t], A[t + 1]);
+    }
+    __syncthreads();
+  }
+
+  // fused last three stages (Mdct.cs:463-507)
+  {
+    const float A2 = A[n >> 3];
+    for (int q = tid; q < (n >> 5); q += nthreads) {
+      int z = n2 - 1 - 16 * q;
+      float k00, k11;
+      k00 = u[z] - u[z - 8];
+      k11 = u[z - 1] - u[z - 9];
+      u[z] = u[z] + u[z - 8];
+      u[z - 1] = u[z - 1] + u[z - 9];
+      u[z - 8] = k00;
+      u[z - 9] = k11;
+
+      k00 = u[z - 2] - u[z - 10];
+      k11 = u[z - 3] - u[z - 11];
+      u[z - 2] = u[z - 2] + u[z - 10];
+      u[z - 3] = u[z - 3] + u[z - 11];
+      u[z - 10] = (k00 + k11) * A2;
+      u[z - 11] = (k11 - k00) * A2;
+
+      k00 = u[z - 12] - u[z - 4];
+      k11 = u[z - 5] - u[z - 13];
+      u[z - 4] = u[z - 4] + u[z - 12];
+      u[z - 5] = u[z - 5] + u[z - 13];
+      u[z - 12] = k11;
+      u[z - 13] = k00;
+
+      k00 = u[z - 14] - u[z - 6];
+      k11 = u[z - 7] - u[z - 15];
+      u[z - 6] = u[z - 6] + u[z - 14];
+      u[z - 7] = u[z - 7] + u[z - 15];
+      u[z - 14] = (k00 + k11) * A2;
+      u[z - 15] = (k00 - k11) * A2;
+
+      iter_54(u, z);
+      iter_54(u, z - 8);
+    }
+  }
+  __syncthreads();
+
+  // steps 4-6: bit reverse u -> v (Mdct.cs:189-214)
+  for (int i = tid; i < (n >> 4); i += nthreads) {
+    int d0 = n4 - 4 - 4 * i, d1 = n2 - 4 - 4 * i;
+    int k4 = BR[2 * i];
+    v[d1 + 3] = u[k4];
+    v[d1 + 2] = u[k4 + 1];
+    v[d0 + 3] = u[k4 + 2];
+    v[d0 + 2] = u[k4 + 3];
+    k4 = BR[2 * i + 1];
+    v[d1 + 1] = u[k4];
+    v[d1] = u[k4 + 1];
+    v[d0 + 1] = u[k4 + 2];
+    v[d0] = u[k4 + 3];
+  }
+  __syncthreads();
+
+  // step 7 (Mdct.cs:217-258), in place on v
+  for (int i = tid; i < (n >> 4); i += nthreads) {
+    int c = 4 * i, d = 4 * i, e = n2 - 4 - 4 * i;
+    float a02, a11, b0, b1, b2, b3;
+    a02 = v[d] - v[e + 2];
+    a11 = v[d + 1] + v[e + 3];
+    b0 = C[c + 1] * a02 + C[c] * a11;
+    b1 = C[c + 1] * a11 - C[c] * a02;
+    b2 = v[d] + v[e + 2];
+    b3 = v[d + 1] - v[e + 3];
+    v[d] = b2 + b0;
+    v[d + 1] = b3 + b1;
+    v[e + 2] = b2 - b0;
+    v[e + 3] = b1 - b3;
+
+    a02 = v[d + 2] - v[e];
+    a11 = v[d + 3] + v[e + 1];
+    b0 = C[c + 3] * a02 + C[c + 2] * a11;
+    b1 = C[c + 3] * a11 - C[c + 2] * a02;
+    b2 = v[d + 2] + v[e];
+    b3 = v[d + 3] - v[e + 1];
+    v[d + 2] = b2 + b0;
+    v[d + 3] = b3 + b1;
+    v[e] = b2 - b0;
+    v[e + 1] = b1 - b3;
+  }
+  __syncthreads();
+
+  // step 8 + decode (Mdct.cs:261-312): v (buf2) -> n outputs
+  for (int i = tid; i < (n >> 4); i += nthreads) {
+    int b = n2 - 8 - 8 * i, e = b;
+    int d0 = 4 * i, d1 = n2 - 4 - 4 * i, d2 = n2 + 4 * i, d3 = n - 4 - 4 * i;
+    float p0, p1, p2, p3;
+    p3 = v[e + 6] * B[b + 7] - v[e + 7] * B[b + 6];
+    p2 = -v[e + 6] * B[b + 6] - v[e + 7] * B[b + 7];
+    emit(d0, p3);
+    emit(d1 + 3, -p3);
+    emit(d2, p2);
+    emit(d3 + 3, p2);
+
+    p1 = v[e + 4] * B[b + 5] - v[e + 5] * B[b + 4];
+    p0 = -v[e + 4] * B[b + 4] - v[e + 5] * B[b + 5];
+    emit(d0 + 1, p1);
+    emit(d1 + 2, -p1);
+    emit(d2 + 1, p0);
+    emit(d3 + 2, p0);
+
+    p3 = v[e + 2] * B[b + 3] - v[e + 3] * B[b + 2];
+    p2 = -v[e + 2] * B[b + 2] - v[e + 3] * B[b + 3];
+    emit(d0 + 2, p3);
+    emit(d1 + 1, -p3);
+    emit(d2 + 2, p2);
+    emit(d3 + 1, p2);
+
+    p1 = v[e] * B[b + 1] - v[e + 1] * B[b];
+    p0 = -v[e] * B[b] - v[e + 1] * B[b + 1];
+    emit(d0 + 3, p1);
+    emit(d1, -p1);
+    emit(d2 + 3, p0);
+    emit(d3, p0);
+  }
+}
+
+// Stand-alone batched IMdct.Reverse: buf[b*stride .. +n) in place, no window (fine-grained ABI).
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_mdct_reverse(float* __restrict__ buf, int n, long long stride, const float* __restrict__ A,
+               const float* __restrict__ B, const float* __restrict__ C, const uint16_t* __restrict__ BR) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* u = lds;
+  float* v = lds + (n >> 1);
+  float* x = buf + (long long)blockIdx.x * stride;
+  for (int i = threadIdx.x; i < (n >> 1); i += NVH_THREADS) u[i] = x[i];
+  __syncthreads();
+  imdct_lds(u, v, n, A, B, C, BR, threadIdx.x, NVH_THREADS, [=](int idx, float val) { x[idx] = val; });
+}
+
+// IMDCT + window of every ch-frame of a batch, in place on the work planes [frame][ch][block1].
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_imdct_window(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int cf = blockIdx.x;
+  const int f = cf / S.channels, c = cf - f * S.channels;
+  const NvhFrame fr = Bt.frames[f];
+  const int n = fr.n;
+  if (n == 0) return;
+  float* x = work + ((long long)f * S.channels + c) * S.block1;
+  const float* __restrict__ w = S.windows + fr.window_off;
+  const NvhChan chn = Bt.chans[fr.chan_off + c];
+  const int tid = threadIdx.x;
+  if (!chn.exec) {
+    // Mapping.cs:192-196 then Mode.cs:160-166: front half keeps the residue, back half is cleared
+    for (int i = tid; i < n; i += NVH_THREADS) {
+      float val = (i < (n >> 1)) ? x[i] : 0.0f;
+      x[i] = val * w[i];
+    }
+    return;
+  }
+  float* u = lds;
+  float* v = lds + (n >> 1);
+  for (int i = tid; i < (n >> 1); i += NVH_THREADS) u[i] = x[i];
+  __syncthreads();
+  const int s = fr.mdct_slot;
+  imdct_lds(u, v, n, S.mdct_a[s], S.mdct_b[s], S.mdct_c[s], S.mdct_br[s], tid, NVH_THREADS,
+            [=](int idx, float val) { x[idx] = val * w[idx]; });
+}
+
+// ================================================================================================
+// Residue vector adds
+// ================================================================================================
+
+__device__ __forceinline__ void residue_apply(const NvhDevSetup& S, const NvhDevBatch& Bt, const NvhDevResidue& R,
+                                              const NvhResOp& op, int i, float* planes, int half) {
+  const NvhDevBook bk = S.books[op.book];
+  const int dims = (int)bk.dim;
+  const int offset = R.begin + (int)op.partition * R.partition_size;
+  int j, comp, ch, x;
+  if (R.type == 0) {
+    // Residue0.cs:193-199: res[offset++] over dim-major order
+    int steps = R.partition_size / dims;
+    if (i >= steps * dims) return;
+    comp = i / steps;
+    j = i - comp * steps;
+    ch = op.channel;
+    x = offset + i;
+  } else if (R.type == 1) {
+    // Residue1.cs:19-22
+    j = i / dims;
+    comp = i - j * dims;
+    ch = op.channel;
+    x = offset + i;
+  } else {
+    // Residue2.cs:25-45: offset /= channels; chPtr restarts at 0 (quirk B-1)
+    j = i / dims;
+    comp = i - j * dims;
+    ch = i % R.real_channels;
+    x = offset / R.real_channels + i / R.real_channels;
+  }
+  unsigned e = Bt.entries[op.ent_off + j];
+  if (e == NVH_ENTRY_SKIP) return;
+  if (x >= half) return;  // lands in [n/2, block1): overwritten by the IMDCT or cleared, never observed
+  float* p = planes + (long long)ch * S.block1 + x;
+  *p = *p + S.vq[bk.tab_off + e * (unsigned)dims + (unsigned)comp];
+}
+
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_residue(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work) {
+  const int f = blockIdx.x;
+  const NvhFrame fr = Bt.frames[f];
+  if (fr.n == 0) return;
+  const int half = fr.n >> 1;
+  const int tid = threadIdx.x;
+  float* planes = work + (long long)f * S.channels * S.block1;
+  // Array.Clear(buffer[i], 0, halfBlockSize) (Mapping.cs:108)
+  for (int c = 0; c < S.channels; ++c)
+    for (int i = tid; i < half; i += NVH_THREADS) planes[(long long)c * S.block1 + i] = 0.0f;
+  __syncthreads();
+
+  for (unsigned ps = fr.pass_begin; ps < fr.pass_end; ++ps) {
+    const NvhResPass* pass = &Bt.passes[ps];
+    const NvhDevResidue R = S.residues[pass->residue];
+    const int psize = R.partition_size;
+    for (int s = 0; s < NVH_MAX_STAGES; ++s) {
+      const unsigned ob = pass->op_begin[s], oe = pass->op_begin[s + 1];
+      if (ob == oe) continue;
+      if (!R.sequential) {
+        const long long total = (long long)(oe - ob) * psize;
+        for (long long idx = tid; idx < total; idx += NVH_THREADS) {
+          unsigned o = (unsigned)(idx / psize);
+          int i = (int)(idx - (long long)o * psize);
+          residue_apply(S, Bt, R, Bt.ops[ob + o], i, planes, half);
+        }
+        __syncthreads();
+      } else {
+        // partitions may alias (quirk B-1 / vector overrun): keep the reference's partition order
+        for (unsigned o = ob; o < oe; ++o) {
+          const NvhResOp op = Bt.ops[o];
+          const int dims = (int)S.books[op.book].dim;
+          const int cnt = ((psize + dims - 1) / dims) * dims;
+          for (int i = tid; i < cnt; i += NVH_THREADS) residue_apply(S, Bt, R, op, i, planes, half);
+          __syncthreads();
+        }
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// Inverse coupling + floor apply
+// ================================================================================================
+
+// Floor1.cs:299-314
+__device__ __forceinline__ int render_point(int x0, int y0, int x1, int y1, int X) {
+  int dy = y1 - y0;
+  int adx = x1 - x0;
+  int ady = dy < 0 ? -dy : dy;
+  int err = ady * (X - x0);
+  int off = err / adx;
+  return dy < 0 ? y0 - off : y0 + off;
+}
+
+// Closed form of Floor1.RenderLineMulti (Floor1.cs:316-341) at abscissa x in [x0, x1):
+// y = y0 + b*t + sy*floor(ady'*t/adx), t = x-x0, b = dy/adx (truncating), ady' = |dy| - |b|*adx.
+__device__ __forceinline__ int line_y(int x0, int y0, int x1, int y1, int x) {
+  int dy = y1 - y0;
+  int adx = x1 - x0;
+  int ady = dy < 0 ? -dy : dy;
+  int sy = dy < 0 ? -1 : 1;
+  int b = dy / adx;
+  int ab = b < 0 ? -b : b;
+  ady -= ab * adx;
+  int t = x - x0;
+  return y0 + b * t + sy * ((ady * t) / adx);
+}
+
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err) {
+  __shared__ int s_x[NVH_MAX_POSTS + 2];
+  __shared__ int s_y[NVH_MAX_POSTS + 2];
+  __shared__ int s_nseg;
+  __shared__ float s_coeff[256];
+  const int f = blockIdx.x;
+  const NvhFrame fr = Bt.frames[f];
+  if (fr.n == 0) return;
+  const int half = fr.n >> 1;
+  const int tid = threadIdx.x;
+  float* planes = work + (long long)f * S.channels * S.block1;
+  const NvhChan* chans = Bt.chans + fr.chan_off;
+
+  // inverse coupling, last step first (Mapping.cs:137-182)
+  const NvhDevMapping mp = S.mappings[fr.mapping];
+  for (int st = mp.coupling_steps - 1; st >= 0; --st) {
+    const int mg = S.coupling[mp.coupling_off + 2 * st], an = S.coupling[mp.coupling_off + 2 * st + 1];
+    if (chans[an].exec || chans[mg].exec) {
+      float* M = planes + (long long)mg * S.block1;
+      float* Aa = planes + (long long)an * S.block1;
+      for (int j = tid; j < half; j += NVH_THREADS) {
+        float oldM = M[j], oldA = Aa[j], newM, newA;
+        if (oldM > 0) {
+          if (oldA > 0) { newM = oldM; newA = oldM - oldA; }
+          else          { newA = oldM; newM = oldM + oldA; }
+        } else {
+          if (oldA > 0) { newM = oldM; newA = oldM + oldA; }
+          else          { newA = oldM; newM = oldM - oldA; }
+        }
+        M[j] = newM;
+        Aa[j] = newA;
+      }
+    }
+    __syncthreads();
+  }
+
+  for (int c = 0; c < S.channels; ++c) {
+    const NvhChan chn = chans[c];
+    if (!chn.exec) continue;  // uniform across the block
+    float* res = planes + (long long)c * S.block1;
+    const NvhDevFloor* fl = &S.floors[chn.floor];
+    if (fl->type == 1) {
+      const NvhDevFloor1* F = &fl->f1;
+      if (chn.post_count == 0) {
+        // Floor1.cs:218-221 (ForceEnergy with no posts): Array.Clear(residue, 0, n)
+        for (int i = tid; i < half; i += NVH_THREADS) res[i] = 0.0f;
+        continue;
+      }
+      __syncthreads();  // previous channel's readers are done with s_x/s_y
+      if (tid == 0) {
+        // UnwrapPosts (Floor1.cs:224-297)
+        int finalY[NVH_MAX_POSTS];
+        bool step[NVH_MAX_POSTS];
+        const uint16_t* posts = Bt.posts + chn.data_off;
+        const int pc = chn.post_count;
+        for (int i = 0; i < pc; ++i) step[i] = false;
+        step[0] = true;
+        step[1] = true;
+        finalY[0] = posts[0];
+        finalY[1] = posts[1];
+        for (int i = 2; i < pc; ++i) {
+          int lo = F->l_neigh[i], hi = F->h_neigh[i];
+          int predicted = render_point(F->x_list[lo], finalY[lo], F->x_list[hi], finalY[hi], F->x_list[i]);
+          int val = posts[i];
+          int highroom = F->range - predicted;
+          int lowroom = predicted;
+          int room = (highroom < lowroom) ? highroom * 2 : lowroom * 2;
+          if (val != 0) {
+            step[lo] = true;
+            step[hi] = true;
+            step[i] = true;
+            if (val >= room) {
+              if (highroom > lowroom) finalY[i] = val - lowroom + predicted;
+              else finalY[i] = predicted - val + highroom - 1;
+            } else {
+              if ((val % 2) == 1) finalY[i] = predicted - ((val + 1) / 2);
+              else finalY[i] = predicted + (val / 2);
+            }
+          } else {
+            step[i] = false;
+            finalY[i] = predicted;
+          }
+        }
+        // Apply's walk over the sorted posts (Floor1.cs:196-216) -> segment list
+        int ns = 0;
+        int lx = 0, ly = finalY[0] * F->multiplier;
+        s_x[0] = lx;
+        s_y[0] = ly;
+        for (int i = 1; i < pc; ++i) {
+          int idx = F->sort_idx[i];
+          if (step[idx]) {
+            int hx = F->x_list[idx];
+            int hy = finalY[idx] * F->multiplier;
+            if (lx < half) {
+              ++ns;
+              s_x[ns] = hx;  // the segment is drawn towards min(hx, n) (quirk B-6)
+              s_y[ns] = hy;
+            }
+            lx = hx;
+            ly = hy;
+          }
+          if (lx >= half) break;
+        }
+        if (lx < half) {
+          ++ns;
+          s_x[ns] = half;
+          s_y[ns] = ly;
+        }
+        s_nseg = ns;
+      }
+      __syncthreads();
+      const int ns = s_nseg;
+      for (int x = tid; x < half; x += NVH_THREADS) {
+        int k = 0;
+        while (k + 1 < ns && s_x[k + 1] <= x) ++k;
+        int x1 = s_x[k + 1] < half ? s_x[k + 1] : half;
+        int y = line_y(s_x[k], s_y[k], x1, s_y[k + 1], x);
+        if (y < 0 || y > 255) {
+          atomicOr(err, NVH_DEVERR_FLOOR1_Y);  // inverse_dB_table[y] would throw (quirk B-7)
+          y = y < 0 ? 0 : 255;
+        }
+        res[x] = res[x] * c_inverse_db[y];
+      }
+    } else {
+      const NvhDevFloor0* F = &fl->f0;
+      if (!(chn.amp > 0.0f)) {
+        for (int i = tid; i < half; i += NVH_THREADS) res[i] = 0.0f;
+        continue;
+      }
+      __syncthreads();
+      // data.Coeff[i] = 2f * (float)Math.Cos(data.Coeff[i]) (Floor0.cs:165-168)
+      for (int i = tid; i < F->order; i += NVH_THREADS) s_coeff[i] = 2.0f * (float)cos((double)Bt.coeffs[chn.data_off + i]);
+      __syncthreads();
+      const int slot = fr.mdct_slot;
+      const int32_t* bark = S.ipool + F->bark_off[slot];
+      const float* wmap = S.fpool + F->wmap_off[slot];
+      for (int i = tid; i < half; i += NVH_THREADS) {
+        int k = bark[i];
+        if (k < 0 || k >= half) {
+          atomicOr(err, NVH_DEVERR_FLOOR0_W);
+          continue;
+        }
+        float p = .5f, q = .5f;
+        float w = wmap[k];
+        int j;
+        for (j = 1; j < F->order; j += 2) {
+          q = q * (w - s_coeff[j - 1]);
+          p = p * (w - s_coeff[j]);
+        }
+        if (j == F->order) {
+          q = q * (w - s_coeff[j - 1]);
+          p = p * (p * (4.0f - w * w));
+          q = q * q;
+        } else {
+          p = p * (p * (2.0f - w));
+          q = q * (q * (2.0f + w));
+        }
+        q = chn.amp / (float)sqrt((double)(p + q)) - (float)F->amp_ofs;
+        q = (float)exp((double)(q * 0.11512925f));
+        res[i] = res[i] * q;
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// Overlap-add + interleave + clip
+// ================================================================================================
+
+__device__ __forceinline__ float clip_value(float v, int* clipped) {  // Utils.cs:30-43
+  if (v > .99999994f) { *clipped = 1; return 0.99999994f; }
+  if (v < -.99999994f) { *clipped = 1; return -0.99999994f; }
+  return v;
+}
+
+// Parallel form: valid when no overlap region reaches into a tail (FrameBatch::sequential_ola == false),
+// i.e. every tail read here is an untouched windowed block.  One workgroup per frame.
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const float* __restrict__ carry,
+           float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag) {
+  const int f = blockIdx.x;
+  const NvhFrame fr = Bt.frames[f];
+  const int ch = S.channels;
+  const int total = fr.emit_count * ch;
+  if (total <= 0) return;
+  const float* cur = work + (long long)f * ch * S.block1;
+  const float* prev = nullptr;
+  if (fr.ov_len > 0) prev = (fr.ov_frame == -2) ? carry : (fr.ov_frame >= 0 ? work + (long long)fr.ov_frame * ch * S.block1 : nullptr);
+  float* out = pcm + fr.out_pos * ch;
+  int clipped = 0;
+  for (int o = threadIdx.x; o < total; o += NVH_THREADS) {
+    int t = o / ch, c = o - t * ch;
+    int idx = fr.emit_start + t;
+    float v;
+    if (fr.n == 0) {
+      v = prev[(long long)c * S.block1 + fr.ov_src + t];  // drained carried tail, emitted as it is
+    } else {
+      v = cur[(long long)c * S.block1 + idx];
+      int j = idx - fr.start;
+      if (prev && j >= 0 && j < fr.ov_len) v = v + prev[(long long)c * S.block1 + fr.ov_src + j];  // OverlapBuffers
+    }
+    if (clip) v = clip_value(v, &clipped);
+    out[o] = v;
+  }
+  if (clipped) atomicOr(clipped_flag, 1);
+}
+
+// Sequential form: one workgroup walks the frames in order and performs the adds in place, exactly
+// like the reference's ping-pong buffers (needed only for streams whose window flags disagree with
+// their neighbours so that an overlap reaches a block's own tail).
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_ola_emit_seq(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, const float* __restrict__ carry,
+               float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag) {
+  const int ch = S.channels;
+  int clipped = 0;
+  for (int f = 0; f < Bt.nframes; ++f) {
+    const NvhFrame fr = Bt.frames[f];
+    float* cur = work + (long long)f * ch * S.block1;
+    const float* prev = nullptr;
+    if (fr.ov_len > 0) prev = (fr.ov_frame == -2) ? carry : (fr.ov_frame >= 0 ? work + (long long)fr.ov_frame * ch * S.block1 : nullptr);
+    if (fr.n != 0 && prev) {
+      for (int o = threadIdx.x; o < fr.ov_len * ch; o += NVH_THREADS) {
+        int c = o / fr.ov_len, j = o - c * fr.ov_len;
+        float* p = cur + (long long)c * S.block1 + fr.start + j;
+        *p = *p + prev[(long long)c * S.block1 + fr.ov_src + j];
+      }
+    }
+    __syncthreads();
+    float* out = pcm + fr.out_pos * ch;
+    const int total = fr.emit_count * ch;
+    for (int o = threadIdx.x; o < total; o += NVH_THREADS) {
+      int t = o / ch, c = o - t * ch;
+      float v = (fr.n == 0) ? prev[(long long)c * S.block1 + fr.ov_src + t] : cur[(long long)c * S.block1 + fr.emit_start + t];
+      if (clip) v = clip_value(v, &clipped);
+      out[o] = v;
+    }
+    __syncthreads();
+  }
+  if (clipped) atomicOr(clipped_flag, 1);
+}

@@ -1,0 +1,39 @@
+// kernels_common.h -- device-side parameter blocks for the gfx950 synthesis kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nvh_format.h"
+
+// Pointers into the per-stream device arena that holds the setup (uploaded once).
+struct NvhDevSetup {
+  int32_t channels, block0, block1, pad;
+  const float* vq;                // VQ lookup tables of every codebook
+  const NvhDevBook* books;
+  const NvhDevFloor* floors;
+  const NvhDevResidue* residues;
+  const NvhDevMapping* mappings;
+  const uint8_t* coupling;        // (magnitude, angle) byte pairs
+  const float* windows;           // window pool (Mode.cs:69-100)
+  const int32_t* ipool;           // Floor0 Bark maps
+  const float* fpool;             // Floor0 wdel maps
+  const float* mdct_a[2];         // Mdct.cs:40-55 tables for block0 / block1
+  const float* mdct_b[2];
+  const float* mdct_c[2];
+  const uint16_t* mdct_br[2];
+};
+
+// One uploaded frame batch.
+struct NvhDevBatch {
+  const NvhFrame* frames;
+  const NvhChan* chans;
+  const NvhResPass* passes;
+  const NvhResOp* ops;
+  const uint16_t* entries;
+  const uint16_t* posts;
+  const float* coeffs;
+  int32_t nframes, pad;
+};
+
+// error word written by kernels when the reference would have thrown (index out of range)
+enum { NVH_DEVERR_FLOOR1_Y = 1, NVH_DEVERR_FLOOR0_W = 2 };

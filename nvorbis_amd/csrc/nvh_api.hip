@@ -1,0 +1,778 @@
+// nvh_api.hip -- C ABI of libnvorbis_hip.so (see include/nvorbis_hip.h): device management, setup
+// upload, batch upload and kernel launches.  There is no CPU fallback anywhere in this file: without a
+// HIP device every compute entry point fails with NVH_ERR_NO_GPU / NVH_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "../../include/nvorbis_hip.h"
+#include "host_ogg.h"
+#include "host_parse.h"
+#include "host_setup.h"
+#include "kernels_common.h"
+
+
+extern "C" {
+__global__ void k_mdct_reverse(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
+                               const uint16_t* BR);
+__global__ void k_imdct_window(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
+__global__ void k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
+                           int* clipped_flag);
+__global__ void k_ola_emit_seq(NvhDevSetup S, NvhDevBatch Bt, float* work, const float* carry, float* pcm, int clip,
+                               int* clipped_flag);
+}
+
+static thread_local int g_last_hip_error = 0;
+
+#define HIP_TRY(expr)                        \
+  do {                                       \
+    hipError_t e_ = (expr);                  \
+    if (e_ != hipSuccess) {                  \
+      g_last_hip_error = (int)e_;            \
+      return NVH_ERR_DEVICE;                 \
+    }                                        \
+  } while (0)
+
+namespace {
+
+struct DevBuf {  // growable device allocation
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return NVH_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return NVH_OK;
+  }
+};
+
+struct MdctDev {
+  int n = 0;
+  float *a = nullptr, *b = nullptr, *c = nullptr;
+  uint16_t* br = nullptr;
+};
+
+}  // namespace
+
+struct nvh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::map<int, MdctDev> mdct_cache;  // Mdct._setupCache (Mdct.cs:11)
+};
+
+struct nvh_batch {
+  nvh_stream* s = nullptr;
+  DevBuf blob;          // all descriptor arrays, one allocation
+  DevBuf work;          // [frames][ch][block1] float planes
+  DevBuf carry_in;      // snapshot of the tail this batch overlaps its first frame with
+  NvhDevBatch dev{};
+  int nframes = 0, chan_frames = 0;
+  int64_t pcm_samples = 0;
+  int64_t descriptor_bytes = 0;
+  bool sequential_ola = false;
+  int last_decoded = -1;  // last frame with n != 0 (its block becomes the next carried tail)
+  bool has_carry_in = false;
+};
+
+struct nvh_stream {
+  nvh_ctx* ctx = nullptr;
+  nvh::Setup setup;
+  std::unique_ptr<nvh::StreamParser> parser;
+  nvh::FrameBatch pending;
+  DevBuf arena;  // setup tables
+  NvhDevSetup dev{};
+  DevBuf carry;  // [ch][block1] windowed block of the last decoded frame
+  bool carry_valid = false;
+  DevBuf flags;  // int[2]: device error word, clipped flag
+  DevBuf pcm;    // staging for host-destination synth
+  int clip = 1;
+  int has_clipped = 0;
+  nvh_batch scratch;  // reused by nvh_stream_synth
+};
+
+// ------------------------------------------------------------------------------------------------
+
+static int ensure_device(int device) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_last_hip_error = (int)e;
+    return NVH_ERR_NO_GPU;
+  }
+  if (device < 0 || device >= count) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(device));
+  return NVH_OK;
+}
+
+extern "C" const char* nvh_version(void) { return "nvorbis_hip 0.1 (gfx950)"; }
+extern "C" int nvh_last_hip_error(void) { return g_last_hip_error; }
+extern "C" int nvh_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+extern "C" int nvh_ctx_create(int device, nvh_ctx** out) {
+  if (!out) return NVH_ERR_ARGUMENT;
+  *out = nullptr;
+  int rc = ensure_device(device);
+  if (rc != NVH_OK) return rc;
+  nvh_ctx* c = new (std::nothrow) nvh_ctx();
+  if (!c) return NVH_ERR_NOMEM;
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    delete c;
+    return NVH_ERR_DEVICE;
+  }
+  c->own_stream = true;
+  *out = c;
+  return NVH_OK;
+}
+
+extern "C" void nvh_ctx_destroy(nvh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (auto& kv : c->mdct_cache) {
+    (void)hipFree(kv.second.a);
+    (void)hipFree(kv.second.b);
+    (void)hipFree(kv.second.c);
+    (void)hipFree(kv.second.br);
+  }
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int nvh_ctx_set_hip_stream(nvh_ctx* c, void* hip_stream) {
+  if (!c) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->own_stream && c->stream) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipStreamDestroy(c->stream);
+    c->own_stream = false;
+    c->stream = nullptr;
+  }
+  if (hip_stream == nullptr) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  } else {
+    c->stream = (hipStream_t)hip_stream;
+  }
+  return NVH_OK;
+}
+
+extern "C" int nvh_ctx_synchronize(nvh_ctx* c) {
+  if (!c) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return NVH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// level 1
+// ------------------------------------------------------------------------------------------------
+
+static bool valid_block(int n) { return n >= 64 && n <= 8192 && (n & (n - 1)) == 0; }
+
+extern "C" int nvh_mdct_tables(int n, float* a, float* b, float* c, uint16_t* bitrev) {
+  if (!valid_block(n) || !a || !b || !c || !bitrev) return NVH_ERR_ARGUMENT;
+  nvh::MdctTables t;
+  nvh::build_mdct_tables(n, t);
+  std::memcpy(a, t.a.data(), t.a.size() * sizeof(float));
+  std::memcpy(b, t.b.data(), t.b.size() * sizeof(float));
+  std::memcpy(c, t.c.data(), t.c.size() * sizeof(float));
+  std::memcpy(bitrev, t.bitrev.data(), t.bitrev.size() * sizeof(uint16_t));
+  return NVH_OK;
+}
+
+extern "C" int nvh_calc_window(int prev_block, int block, int next_block, float* out) {
+  if (!out || block <= 0 || prev_block <= 0 || next_block <= 0 || prev_block > block || next_block > block) return NVH_ERR_ARGUMENT;
+  nvh::calc_window(prev_block, block, next_block, out);
+  return NVH_OK;
+}
+
+extern "C" int nvh_calc_overlap(int prev_block, int block, int next_block, int* start, int* valid, int* total) {
+  if (!start || !valid || !total) return NVH_ERR_ARGUMENT;
+  nvh::calc_overlap(prev_block, block, next_block, start, valid, total);
+  return NVH_OK;
+}
+
+static int get_mdct(nvh_ctx* c, int n, MdctDev** out) {
+  auto it = c->mdct_cache.find(n);
+  if (it != c->mdct_cache.end()) {
+    *out = &it->second;
+    return NVH_OK;
+  }
+  nvh::MdctTables t;
+  nvh::build_mdct_tables(n, t);
+  MdctDev d;
+  d.n = n;
+  HIP_TRY(hipMalloc((void**)&d.a, t.a.size() * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&d.b, t.b.size() * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&d.c, t.c.size() * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&d.br, t.bitrev.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(d.a, t.a.data(), t.a.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d.b, t.b.data(), t.b.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d.c, t.c.data(), t.c.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d.br, t.bitrev.data(), t.bitrev.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  auto ins = c->mdct_cache.emplace(n, d);
+  *out = &ins.first->second;
+  return NVH_OK;
+}
+
+extern "C" int nvh_mdct_reverse(nvh_ctx* c, int n, int batch, float* d_buf, int64_t stride) {
+  if (!c || !d_buf || batch < 0 || !valid_block(n) || stride < n) return NVH_ERR_ARGUMENT;
+  if (batch == 0) return NVH_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  MdctDev* m = nullptr;
+  int rc = get_mdct(c, n, &m);
+  if (rc != NVH_OK) return rc;
+  hipLaunchKernelGGL(k_mdct_reverse, dim3((unsigned)batch), dim3(256), (size_t)n * sizeof(float), c->stream, d_buf, n,
+                     (long long)stride, m->a, m->b, m->c, m->br);
+  HIP_TRY(hipGetLastError());
+  return NVH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream: setup upload
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct ArenaBuilder {
+  std::vector<uint8_t> bytes;
+  size_t add(const void* src, size_t n, size_t align = 16) {
+    size_t off = (bytes.size() + align - 1) / align * align;
+    bytes.resize(off + n);
+    if (n) std::memcpy(bytes.data() + off, src, n);
+    return off;
+  }
+};
+
+}  // namespace
+
+static int upload_setup(nvh_stream* s) {
+  const nvh::Setup& S = s->setup;
+  ArenaBuilder ab;
+  // documented limits of this build
+  if (S.channels > 255) return NVH_ERR_UNSUPPORTED;
+  if (S.books.size() > 256) return NVH_ERR_UNSUPPORTED;
+
+  std::vector<float> vq;
+  std::vector<NvhDevBook> books(S.books.size());
+  for (size_t i = 0; i < S.books.size(); i++) {
+    const nvh::Codebook& b = S.books[i];
+    books[i].entries = (uint32_t)b.entries;
+    books[i].dim = (uint32_t)b.dimensions;
+    books[i].pad = 0;
+    if (b.map_type == 0) {
+      books[i].tab_off = 0xFFFFFFFFu;
+    } else {
+      books[i].tab_off = (uint32_t)vq.size();
+      vq.insert(vq.end(), b.lookup.begin(), b.lookup.end());
+    }
+  }
+
+  std::vector<int32_t> ipool;
+  std::vector<float> fpool;
+  std::vector<NvhDevFloor> floors(S.floors.size());
+  for (size_t i = 0; i < S.floors.size(); i++) {
+    const nvh::Floor& f = S.floors[i];
+    NvhDevFloor& d = floors[i];
+    std::memset(&d, 0, sizeof d);
+    d.type = f.type;
+    if (f.type == 1) {
+      int cnt = (int)f.f1.x_list.size();
+      d.f1.x_count = cnt;
+      d.f1.multiplier = f.f1.multiplier;
+      d.f1.range = f.f1.range;
+      int lim = cnt < NVH_MAX_POSTS ? cnt : NVH_MAX_POSTS;  // more than 64 posts faults at decode time (host parser)
+      int levels = 0;
+      for (int k = 0; k < lim; k++) {
+        if (f.f1.x_list[k] > 0xFFFF) return NVH_ERR_UNSUPPORTED;
+        d.f1.x_list[k] = (uint16_t)f.f1.x_list[k];
+        d.f1.l_neigh[k] = (uint8_t)f.f1.l_neigh[k];
+        d.f1.h_neigh[k] = (uint8_t)f.f1.h_neigh[k];
+        d.f1.sort_idx[k] = (uint8_t)(f.f1.sort_idx[k] < NVH_MAX_POSTS ? f.f1.sort_idx[k] : 0);
+        int lv = 0;
+        if (k >= 2) {
+          int a = d.f1.level[f.f1.l_neigh[k]], b = d.f1.level[f.f1.h_neigh[k]];
+          lv = (a > b ? a : b) + 1;
+        }
+        d.f1.level[k] = (uint8_t)lv;
+        if (lv + 1 > levels) levels = lv + 1;
+      }
+      d.f1.levels = levels;
+    } else {
+      d.f0.order = f.f0.order;
+      d.f0.amp_ofs = f.f0.amp_ofs;
+      d.f0.bark_map_size = f.f0.bark_map_size;
+      if (f.f0.order > 255) return NVH_ERR_UNSUPPORTED;
+      for (int w = 0; w < 2; w++) {
+        d.f0.bark_off[w] = (uint32_t)ipool.size();
+        ipool.insert(ipool.end(), f.f0.bark_map[w].begin(), f.f0.bark_map[w].end());
+        d.f0.wmap_off[w] = (uint32_t)fpool.size();
+        fpool.insert(fpool.end(), f.f0.w_map[w].begin(), f.f0.w_map[w].end());
+      }
+    }
+  }
+
+  std::vector<NvhDevResidue> residues(S.residues.size());
+  for (size_t i = 0; i < S.residues.size(); i++) {
+    const nvh::Residue& r = S.residues[i];
+    NvhDevResidue& d = residues[i];
+    d.type = r.type;
+    d.begin = r.begin;
+    d.end = r.end;
+    d.partition_size = r.partition_size;
+    d.classifications = r.classifications;
+    d.channels = r.channels;
+    d.real_channels = r.real_channels;
+    bool seq = false;
+    if (r.type == 2 && (r.begin % r.real_channels != 0 || r.partition_size % r.real_channels != 0)) seq = true;
+    for (int c = 0; c < r.classifications; c++)
+      for (int k = 0; k < NVH_MAX_STAGES; k++) {
+        int b = r.books[c][k];
+        if (b < 0) continue;
+        const nvh::Codebook& bk = S.books[(size_t)b];
+        if (bk.entries > 0xFFFF) return NVH_ERR_UNSUPPORTED;  // entry stream is 16-bit (0xFFFF = skip)
+        if (bk.dimensions > 0 && r.type != 0 && r.partition_size % bk.dimensions != 0) seq = true;  // vector overrun
+      }
+    d.sequential = seq ? 1 : 0;
+  }
+
+  std::vector<uint8_t> coupling;
+  std::vector<NvhDevMapping> mappings(S.mappings.size());
+  for (size_t i = 0; i < S.mappings.size(); i++) {
+    mappings[i].coupling_steps = (int32_t)S.mappings[i].coupling_angle.size();
+    mappings[i].coupling_off = (uint32_t)coupling.size();
+    for (size_t k = 0; k < S.mappings[i].coupling_angle.size(); k++) {
+      coupling.push_back((uint8_t)S.mappings[i].coupling_magnitude[k]);
+      coupling.push_back((uint8_t)S.mappings[i].coupling_angle[k]);
+    }
+  }
+  if (coupling.empty()) coupling.push_back(0);
+  if (vq.empty()) vq.push_back(0.0f);
+  if (ipool.empty()) ipool.push_back(0);
+  if (fpool.empty()) fpool.push_back(0.0f);
+
+  size_t o_vq = ab.add(vq.data(), vq.size() * sizeof(float));
+  size_t o_books = ab.add(books.data(), books.size() * sizeof(NvhDevBook));
+  size_t o_floors = ab.add(floors.data(), floors.size() * sizeof(NvhDevFloor));
+  size_t o_res = ab.add(residues.data(), residues.size() * sizeof(NvhDevResidue));
+  size_t o_map = ab.add(mappings.data(), mappings.size() * sizeof(NvhDevMapping));
+  size_t o_cpl = ab.add(coupling.data(), coupling.size());
+  size_t o_win = ab.add(S.windows.data(), S.windows.size() * sizeof(float));
+  size_t o_ip = ab.add(ipool.data(), ipool.size() * sizeof(int32_t));
+  size_t o_fp = ab.add(fpool.data(), fpool.size() * sizeof(float));
+  size_t o_a[2], o_b[2], o_c[2], o_br[2];
+  for (int w = 0; w < 2; w++) {
+    o_a[w] = ab.add(S.mdct[w].a.data(), S.mdct[w].a.size() * sizeof(float));
+    o_b[w] = ab.add(S.mdct[w].b.data(), S.mdct[w].b.size() * sizeof(float));
+    o_c[w] = ab.add(S.mdct[w].c.data(), S.mdct[w].c.size() * sizeof(float));
+    o_br[w] = ab.add(S.mdct[w].bitrev.data(), S.mdct[w].bitrev.size() * sizeof(uint16_t));
+  }
+
+  int rc = s->arena.reserve(ab.bytes.size());
+  if (rc != NVH_OK) return rc;
+  HIP_TRY(hipMemcpy(s->arena.p, ab.bytes.data(), ab.bytes.size(), hipMemcpyHostToDevice));
+  const uint8_t* base = (const uint8_t*)s->arena.p;
+  NvhDevSetup& D = s->dev;
+  D.channels = S.channels;
+  D.block0 = S.block0;
+  D.block1 = S.block1;
+  D.pad = 0;
+  D.vq = (const float*)(base + o_vq);
+  D.books = (const NvhDevBook*)(base + o_books);
+  D.floors = (const NvhDevFloor*)(base + o_floors);
+  D.residues = (const NvhDevResidue*)(base + o_res);
+  D.mappings = (const NvhDevMapping*)(base + o_map);
+  D.coupling = base + o_cpl;
+  D.windows = (const float*)(base + o_win);
+  D.ipool = (const int32_t*)(base + o_ip);
+  D.fpool = (const float*)(base + o_fp);
+  for (int w = 0; w < 2; w++) {
+    D.mdct_a[w] = (const float*)(base + o_a[w]);
+    D.mdct_b[w] = (const float*)(base + o_b[w]);
+    D.mdct_c[w] = (const float*)(base + o_c[w]);
+    D.mdct_br[w] = (const uint16_t*)(base + o_br[w]);
+  }
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, const uint8_t* comment_pkt,
+                               int comment_len, const uint8_t* setup_pkt, int setup_len, nvh_stream** out) {
+  // ctx == NULL gives a host-only stream: packets can be parsed (and their frame geometry inspected) but
+  // every synthesis entry point fails with NVH_ERR_NO_GPU -- there is no CPU synthesis path.
+  if (!id_pkt || !setup_pkt || !out) return NVH_ERR_ARGUMENT;
+  *out = nullptr;
+  if (c) HIP_TRY(hipSetDevice(c->device));
+  std::unique_ptr<nvh_stream> s(new (std::nothrow) nvh_stream());
+  if (!s) return NVH_ERR_NOMEM;
+  s->ctx = c;
+  int rc = s->setup.parse_id(id_pkt, id_len);
+  if (rc != NVH_OK) return rc;
+  if (!valid_block(s->setup.block0) || !valid_block(s->setup.block1) || s->setup.block0 > s->setup.block1)
+    return NVH_ERR_UNSUPPORTED;  // Vorbis I allows 64..8192 with block0 <= block1
+  if (comment_pkt) {
+    rc = s->setup.parse_comment_sig(comment_pkt, comment_len);
+    if (rc != NVH_OK) return rc;
+  }
+  rc = s->setup.parse_setup(setup_pkt, setup_len);
+  if (rc != NVH_OK) return rc;
+  s->parser.reset(new nvh::StreamParser(&s->setup));
+  s->scratch.s = s.get();
+  if (!c) {
+    *out = s.release();
+    return NVH_OK;
+  }
+  rc = upload_setup(s.get());
+  if (rc != NVH_OK) return rc;
+  size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
+  if ((rc = s->carry.reserve(plane)) != NVH_OK) return rc;
+  HIP_TRY(hipMemset(s->carry.p, 0, plane));
+  if ((rc = s->flags.reserve(2 * sizeof(int))) != NVH_OK) return rc;
+  HIP_TRY(hipMemset(s->flags.p, 0, 2 * sizeof(int)));
+  s->scratch.s = s.get();
+  *out = s.release();
+  return NVH_OK;
+}
+
+extern "C" void nvh_stream_close(nvh_stream* s) {
+  if (!s) return;
+  if (s->ctx) {
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+  }
+  delete s;
+}
+
+extern "C" int nvh_stream_info(const nvh_stream* s, int* channels, int* sample_rate, int* block0, int* block1) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  if (channels) *channels = s->setup.channels;
+  if (sample_rate) *sample_rate = s->setup.sample_rate;
+  if (block0) *block0 = s->setup.block0;
+  if (block1) *block1 = s->setup.block1;
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_set_clip(nvh_stream* s, int on) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  s->clip = on ? 1 : 0;
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_has_clipped(nvh_stream* s, int* clipped) {
+  if (!s || !clipped) return NVH_ERR_ARGUMENT;
+  *clipped = s->has_clipped;
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_position(const nvh_stream* s, int64_t* position, int64_t* emitted, int* eos) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  if (position) *position = s->parser->position();
+  if (emitted) *emitted = s->parser->emitted();
+  if (eos) *eos = s->parser->eos() ? 1 : 0;
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_push_packet(nvh_stream* s, const uint8_t* data, int len, int64_t granule, int flags) {
+  if (!s || (!data && len > 0) || len < 0) return NVH_ERR_ARGUMENT;
+  static const uint8_t empty = 0;
+  return s->parser->push_packet(data ? data : &empty, len, granule, flags, s->pending);
+}
+
+extern "C" int nvh_stream_push_end(nvh_stream* s) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  return s->parser->push_end(s->pending);
+}
+
+extern "C" int nvh_stream_pending_geometry(const nvh_stream* s, int32_t* out, int cap_frames) {
+  if (!s || !out) return NVH_ERR_ARGUMENT;
+  int n = (int)s->pending.frames.size();
+  if (cap_frames < n) return NVH_ERR_ARGUMENT;
+  for (int i = 0; i < n; i++) {
+    const NvhFrame& f = s->pending.frames[(size_t)i];
+    int32_t* o = out + (size_t)i * 8;
+    o[0] = f.n; o[1] = f.start; o[2] = f.valid; o[3] = f.total;
+    o[4] = f.emit_start; o[5] = f.emit_count; o[6] = f.ov_frame; o[7] = f.ov_len;
+  }
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_pending(const nvh_stream* s, int* frames, int64_t* pcm_samples) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  if (frames) *frames = (int)s->pending.frames.size();
+  if (pcm_samples) *pcm_samples = s->pending.pcm_samples;
+  return NVH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batches
+// ------------------------------------------------------------------------------------------------
+
+// Moves s->pending into `b` (device resident) and advances the stream's batch boundary.
+static int batch_upload(nvh_stream* s, nvh_batch* b) {
+  nvh::FrameBatch& P = s->pending;
+  b->s = s;
+  b->nframes = (int)P.frames.size();
+  b->chan_frames = (int)P.chans.size();
+  b->pcm_samples = P.pcm_samples;
+  b->sequential_ola = P.sequential_ola;
+  b->last_decoded = -1;
+  for (int i = b->nframes - 1; i >= 0; --i)
+    if (P.frames[(size_t)i].n != 0) {
+      b->last_decoded = i;
+      break;
+    }
+
+  ArenaBuilder ab;
+  auto pad1 = [](size_t n) { return n ? n : (size_t)1; };
+  std::vector<uint8_t> dummy(64, 0);
+  size_t o_fr = ab.add(P.frames.empty() ? (const void*)dummy.data() : P.frames.data(), pad1(P.frames.size()) * sizeof(NvhFrame));
+  size_t o_ch = ab.add(P.chans.empty() ? (const void*)dummy.data() : P.chans.data(), pad1(P.chans.size()) * sizeof(NvhChan));
+  size_t o_ps = ab.add(P.passes.empty() ? (const void*)dummy.data() : P.passes.data(), pad1(P.passes.size()) * sizeof(NvhResPass));
+  size_t o_op = ab.add(P.ops.empty() ? (const void*)dummy.data() : P.ops.data(), pad1(P.ops.size()) * sizeof(NvhResOp));
+  size_t o_en = ab.add(P.entries.empty() ? (const void*)dummy.data() : P.entries.data(), pad1(P.entries.size()) * sizeof(uint16_t));
+  size_t o_po = ab.add(P.posts.empty() ? (const void*)dummy.data() : P.posts.data(), pad1(P.posts.size()) * sizeof(uint16_t));
+  size_t o_co = ab.add(P.coeffs.empty() ? (const void*)dummy.data() : P.coeffs.data(), pad1(P.coeffs.size()) * sizeof(float));
+  b->descriptor_bytes = (int64_t)(P.frames.size() * sizeof(NvhFrame) + P.chans.size() * sizeof(NvhChan) +
+                                  P.passes.size() * sizeof(NvhResPass) + P.ops.size() * sizeof(NvhResOp) +
+                                  P.entries.size() * 2 + P.posts.size() * 2 + P.coeffs.size() * 4);
+  int rc = b->blob.reserve(ab.bytes.size());
+  if (rc != NVH_OK) return rc;
+  hipStream_t st = s->ctx->stream;
+  HIP_TRY(hipMemcpyAsync(b->blob.p, ab.bytes.data(), ab.bytes.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));  // `ab` is pageable host memory owned by this frame
+  const uint8_t* base = (const uint8_t*)b->blob.p;
+  b->dev.frames = (const NvhFrame*)(base + o_fr);
+  b->dev.chans = (const NvhChan*)(base + o_ch);
+  b->dev.passes = (const NvhResPass*)(base + o_ps);
+  b->dev.ops = (const NvhResOp*)(base + o_op);
+  b->dev.entries = (const uint16_t*)(base + o_en);
+  b->dev.posts = (const uint16_t*)(base + o_po);
+  b->dev.coeffs = (const float*)(base + o_co);
+  b->dev.nframes = b->nframes;
+  b->dev.pad = 0;
+
+  size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
+  rc = b->work.reserve(pad1((size_t)b->nframes) * plane);
+  if (rc != NVH_OK) return rc;
+  P.clear();
+  s->parser->begin_batch();
+  return NVH_OK;
+}
+
+static int batch_launch(nvh_batch* b, const float* carry, float* d_pcm, bool timing, float* kernel_ms) {
+  nvh_stream* s = b->s;
+  hipStream_t st = s->ctx->stream;
+  if (b->nframes == 0) return NVH_OK;
+  const int ch = s->setup.channels;
+  float* work = (float*)b->work.p;
+  int* flags = (int*)s->flags.p;
+  const size_t lds = (size_t)s->setup.block1 * sizeof(float);
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (timing)
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  if (timing) HIP_TRY(hipEventRecord(ev[0], st));
+  hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work);
+  if (timing) HIP_TRY(hipEventRecord(ev[1], st));
+  hipLaunchKernelGGL(k_couple_floor, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, flags);
+  if (timing) HIP_TRY(hipEventRecord(ev[2], st));
+  hipLaunchKernelGGL(k_imdct_window, dim3((unsigned)(b->nframes * ch)), dim3(256), lds, st, s->dev, b->dev, work);
+  if (timing) HIP_TRY(hipEventRecord(ev[3], st));
+  if (!b->sequential_ola)
+    hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
+                       d_pcm, s->clip, flags + 1);
+  else
+    hipLaunchKernelGGL(k_ola_emit_seq, dim3(1), dim3(256), 0, st, s->dev, b->dev, work, carry, d_pcm, s->clip, flags + 1);
+  if (timing) HIP_TRY(hipEventRecord(ev[4], st));
+  HIP_TRY(hipGetLastError());
+  if (timing) {
+    HIP_TRY(hipEventSynchronize(ev[4]));
+    for (int k = 0; k < 4; k++) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+      kernel_ms[k] += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  return NVH_OK;
+}
+
+// Reads and clears the device error / clipped words; maps device errors to status codes.
+static int collect_flags(nvh_stream* s) {
+  int h[2] = {0, 0};
+  hipStream_t st = s->ctx->stream;
+  HIP_TRY(hipMemcpyAsync(h, s->flags.p, sizeof h, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (h[0] || h[1]) HIP_TRY(hipMemsetAsync(s->flags.p, 0, sizeof h, st));
+  if (h[1]) s->has_clipped = 1;
+  if (h[0]) return NVH_ERR_RUNTIME;  // inverse_dB_table / wMap index out of range in the reference
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, int64_t capacity, int64_t* written) {
+  if (!s || (pcm_host && d_pcm)) return NVH_ERR_ARGUMENT;
+  if (written) *written = 0;
+  if (!s->ctx) return NVH_ERR_NO_GPU;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  const int ch = s->setup.channels;
+  const int64_t need = s->pending.pcm_samples * ch;
+  if (s->pending.frames.empty()) return NVH_OK;
+  if (need > 0 && !pcm_host && !d_pcm) return NVH_ERR_ARGUMENT;
+  if (capacity < need) return NVH_ERR_ARGUMENT;
+  nvh_batch* b = &s->scratch;
+  int rc = batch_upload(s, b);
+  if (rc != NVH_OK) return rc;
+  float* dst = d_pcm;
+  if (!dst) {
+    if ((rc = s->pcm.reserve((size_t)(need > 0 ? need : 1) * sizeof(float))) != NVH_OK) return rc;
+    dst = (float*)s->pcm.p;
+  }
+  rc = batch_launch(b, (const float*)s->carry.p, dst, false, nullptr);
+  if (rc != NVH_OK) return rc;
+  hipStream_t st = s->ctx->stream;
+  // carry the last decoded block to the next batch (StreamDecoder's _prevPacketBuf)
+  if (b->last_decoded >= 0) {
+    size_t plane = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(s->carry.p, (const uint8_t*)b->work.p + (size_t)b->last_decoded * plane, plane,
+                           hipMemcpyDeviceToDevice, st));
+    s->carry_valid = true;
+  }
+  if (pcm_host && need > 0) HIP_TRY(hipMemcpyAsync(pcm_host, dst, (size_t)need * sizeof(float), hipMemcpyDeviceToHost, st));
+  rc = collect_flags(s);  // synchronises the stream
+  if (rc != NVH_OK) return rc;
+  if (written) *written = need;
+  return NVH_OK;
+}
+
+extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
+  if (!s || !out) return NVH_ERR_ARGUMENT;
+  *out = nullptr;
+  if (!s->ctx) return NVH_ERR_NO_GPU;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  std::unique_ptr<nvh_batch> b(new (std::nothrow) nvh_batch());
+  if (!b) return NVH_ERR_NOMEM;
+  // snapshot the tail this batch starts from so that repeated synthesis is idempotent
+  size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
+  int rc = b->carry_in.reserve(plane);
+  if (rc != NVH_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(b->carry_in.p, s->carry.p, plane, hipMemcpyDeviceToDevice, s->ctx->stream));
+  b->has_carry_in = true;
+  rc = batch_upload(s, b.get());
+  if (rc != NVH_OK) return rc;
+  *out = b.release();
+  return NVH_OK;
+}
+
+extern "C" int nvh_batch_info(const nvh_batch* b, int* frames, int* chan_frames, int64_t* pcm_samples,
+                              int64_t* descriptor_bytes) {
+  if (!b) return NVH_ERR_ARGUMENT;
+  if (frames) *frames = b->nframes;
+  if (chan_frames) *chan_frames = b->chan_frames;
+  if (pcm_samples) *pcm_samples = b->pcm_samples;
+  if (descriptor_bytes) *descriptor_bytes = b->descriptor_bytes;
+  return NVH_OK;
+}
+
+extern "C" int nvh_batch_synth(nvh_batch* b, float* d_pcm, int64_t capacity) {
+  if (!b || !b->s) return NVH_ERR_ARGUMENT;
+  nvh_stream* s = b->s;
+  if (capacity < b->pcm_samples * s->setup.channels) return NVH_ERR_ARGUMENT;
+  if (b->pcm_samples > 0 && !d_pcm) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  int rc = batch_launch(b, (const float*)b->carry_in.p, d_pcm, false, nullptr);
+  if (rc != NVH_OK) return rc;
+  // the stream keeps the tail of the newest batch
+  if (b->last_decoded >= 0) {
+    size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(s->carry.p, (const uint8_t*)b->work.p + (size_t)b->last_decoded * plane, plane,
+                           hipMemcpyDeviceToDevice, s->ctx->stream));
+  }
+  return NVH_OK;
+}
+
+extern "C" int nvh_batch_time(nvh_batch* b, float* d_pcm, int64_t capacity, int iters, float* total_ms,
+                              float* kernel_ms) {
+  if (!b || !b->s || iters <= 0) return NVH_ERR_ARGUMENT;
+  nvh_stream* s = b->s;
+  if (capacity < b->pcm_samples * s->setup.channels) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  hipStream_t st = s->ctx->stream;
+  float km[4] = {0, 0, 0, 0};
+  if (kernel_ms) {
+    for (int i = 0; i < iters; i++) {
+      int rc = batch_launch(b, (const float*)b->carry_in.p, d_pcm, true, km);
+      if (rc != NVH_OK) return rc;
+    }
+    for (int k = 0; k < 4; k++) kernel_ms[k] = km[k] / (float)iters;
+  }
+  if (total_ms) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; i++) {
+      int rc = batch_launch(b, (const float*)b->carry_in.p, d_pcm, false, nullptr);
+      if (rc != NVH_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *total_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  return collect_flags(s);
+}
+
+extern "C" void nvh_batch_free(nvh_batch* b) {
+  if (!b) return;
+  if (b->s) {
+    (void)hipSetDevice(b->s->ctx->device);
+    (void)hipStreamSynchronize(b->s->ctx->stream);
+  }
+  delete b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// container helper
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int nvh_ogg_demux(const uint8_t* bytes, size_t len, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
+                             int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
+                             int64_t* total_bytes) {
+  if (!bytes || !npackets || !total_bytes) return NVH_ERR_ARGUMENT;
+  nvh::OggPackets pk;
+  int rc = nvh::ogg_demux(bytes, len, pk);
+  if (rc != NVH_OK) return rc;
+  int n = (int)pk.granule.size();
+  *npackets = n;
+  *total_bytes = (int64_t)pk.bytes.size();
+  if (!pkt_bytes && !offsets && !granules && !flags) return NVH_OK;  // sizing call
+  if (pkt_cap < n || pkt_bytes_cap < (int64_t)pk.bytes.size() || !pkt_bytes || !offsets || !granules || !flags)
+    return NVH_ERR_ARGUMENT;
+  if (!pk.bytes.empty()) std::memcpy(pkt_bytes, pk.bytes.data(), pk.bytes.size());
+  std::memcpy(offsets, pk.offs.data(), sizeof(int64_t) * (size_t)(n + 1));
+  if (n) {
+    std::memcpy(granules, pk.granule.data(), sizeof(int64_t) * (size_t)n);
+    std::memcpy(flags, pk.flags.data(), (size_t)n);
+  }
+  return NVH_OK;
+}

@@ -1,0 +1,111 @@
+// nvh_format.h -- plain-old-data layouts shared by the host bit-parser and the gfx950 kernels.
+//
+// Two kinds of data cross from host to HBM:
+//   * the SETUP (once per stream): codebook VQ tables, floor / residue / mapping / mode parameters,
+//     windows and IMDCT twiddles -- everything NVorbis builds in StreamDecoder.LoadBooks
+//     (StreamDecoder.cs:226-289), Mode.Init (Mode.cs:24-67) and MdctImpl..ctor (Mdct.cs:30-63);
+//   * the FRAME BATCH (per look-ahead batch of audio packets): what the bit-consuming half of
+//     Mapping.DecodePacket (Mapping.cs:95-134) produced for each packet -- floor posts / LSP
+//     coefficients, residue classifications + VQ entry numbers -- plus the integer frame geometry of
+//     Mode.GetPacketInfo (Mode.cs:119-151) and StreamDecoder.ReadNextPacket (StreamDecoder.cs:417-463).
+// No float ever travels host->device per packet except Floor0's amplitude/LSP values.
+#pragma once
+#include <stdint.h>
+
+#define NVH_MAX_POSTS 64        // Floor1.Data.Posts = new int[64] (Floor1.cs:12)
+#define NVH_MAX_STAGES 8        // cascade is 8 bits wide (Residue0.cs:46-58)
+#define NVH_MAX_CLASSES 64      // 6 bits + 1 (Residue0.cs:41)
+#define NVH_ENTRY_SKIP 0xFFFFu  // entry-stream sentinel: "no vector was added here"
+
+// ---- setup -------------------------------------------------------------------------------------
+
+struct NvhDevBook {      // Codebook lookup table (Codebook.cs:222-283, indexer :322)
+  uint32_t tab_off;      // float offset into the VQ pool; 0xFFFFFFFF for map type 0
+  uint32_t entries;
+  uint32_t dim;
+  uint32_t pad;
+};
+
+struct NvhDevFloor1 {    // Floor1.cs:21-25, :93-133
+  int32_t x_count;       // number of posts (<= NVH_MAX_POSTS on the decode path)
+  int32_t multiplier;    // header field + 1 (Floor1.cs:74)
+  int32_t range;
+  int32_t levels;        // number of dependency levels of the unwrap (host-derived, see host_setup.cpp)
+  uint16_t x_list[NVH_MAX_POSTS];
+  uint8_t l_neigh[NVH_MAX_POSTS];
+  uint8_t h_neigh[NVH_MAX_POSTS];
+  uint8_t sort_idx[NVH_MAX_POSTS];
+  uint8_t level[NVH_MAX_POSTS];  // post i can be unwrapped once all posts of lower level are final
+};
+
+struct NvhDevFloor0 {    // Floor0.cs:22-26
+  int32_t order;
+  int32_t amp_ofs;
+  int32_t bark_map_size;
+  int32_t pad;
+  uint32_t bark_off[2];  // int pool offsets of the Bark maps for block0 / block1 (n/2+1 ints each)
+  uint32_t wmap_off[2];  // float pool offsets of the wdel maps for block0 / block1 (n/2 floats each)
+};
+
+struct NvhDevFloor {
+  int32_t type;          // 0 / 1
+  int32_t pad;
+  NvhDevFloor0 f0;
+  NvhDevFloor1 f1;
+};
+
+struct NvhDevResidue {   // Residue0.cs:21-33
+  int32_t type;          // 0, 1, 2
+  int32_t begin, end, partition_size;
+  int32_t classifications;
+  int32_t channels;      // channels seen by the base decode loop (1 for type 2, Residue2.cs:13)
+  int32_t real_channels; // Residue2._channels
+  int32_t sequential;    // 1 => partitions of a stage may alias (quirk B-1): apply ops in order
+};
+
+struct NvhDevMapping {   // Mapping.cs:9-14
+  int32_t coupling_steps;
+  uint32_t coupling_off; // offset into the coupling pool: pairs (magnitude, angle) as uint8
+};
+
+// ---- per-batch frame descriptors -----------------------------------------------------------------
+
+struct NvhResOp {        // one (stage, partition, channel) vector write (Residue0.cs:157-170)
+  uint32_t ent_off;      // offset of its entries in the batch entry stream (uint16 each)
+  uint16_t partition;
+  uint8_t channel;       // channel index inside the residue (always 0 for type 2)
+  uint8_t book;          // codebook index
+};
+
+struct NvhResPass {      // one IResidue.Decode call (Mapping.cs:133): ops grouped by stage
+  int32_t residue;       // residue index
+  uint32_t op_begin[NVH_MAX_STAGES + 1];  // ops of stage s are [op_begin[s], op_begin[s+1])
+};
+
+struct NvhChan {         // one channel of one frame ("ch-frame")
+  uint8_t exec;          // IFloorData.ExecuteChannel after ForceEnergy / ForceNoEnergy (Mapping.cs:104-131)
+  uint8_t floor;         // floor index
+  uint8_t post_count;    // Floor1: Data.PostCount; Floor0: 1 if Amp > 0
+  uint8_t pad;
+  uint32_t data_off;     // Floor1: offset of raw posts (uint16) in the post pool;
+                         // Floor0: offset of coeff[order+1] (float) in the coeff pool
+  float amp;             // Floor0 Data.Amp
+};
+
+struct NvhFrame {
+  int32_t n;             // block size of the packet's mode
+  int32_t mapping;       // mapping index
+  uint32_t window_off;   // float offset of the window (n floats) in the window pool
+  int32_t mdct_slot;     // 0 = block0 tables, 1 = block1 tables
+  // geometry (Mode.cs:102-151, StreamDecoder.cs:417-463)
+  int32_t start, valid, total;  // as returned by Mode.Decode (valid already EOS-trimmed)
+  int32_t emit_start;    // first index of the block that is emitted
+  int32_t emit_count;    // samples per channel this frame contributes to the PCM
+  int32_t ov_frame;      // frame whose tail overlaps into this one: index in batch, -1 none, -2 carried tail
+  int32_t ov_src;        // first index of that tail in the previous block
+  int32_t ov_len;        // number of overlapped samples (added at [start, start+ov_len))
+  int64_t out_pos;       // per-channel sample position of the first emitted sample in the batch PCM
+  uint32_t chan_off;     // first NvhChan of this frame
+  uint32_t pass_begin, pass_end;  // residue passes of this frame (one per submap)
+  uint32_t pad;
+};

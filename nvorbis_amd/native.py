@@ -1,0 +1,94 @@
+"""ctypes binding of libnvorbis_hip.so (include/nvorbis_hip.h).
+
+This is the Python stand-in for the C# P/Invoke shim (no .NET in the build image): the same C ABI,
+the same call sequence.  There is no fallback: if the shared library is missing it is built with
+hipcc, and if that fails the import raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK = 0
+ERR_INVALID_DATA, ERR_ARGUMENT, ERR_RUNTIME, ERR_NOMEM = -1, -2, -3, -4
+ERR_NOT_VORBIS, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NO_GPU = -5, -6, -7, -8
+PKT_EOS, PKT_RESYNC = 1, 2
+
+_ERRNAMES = {
+    ERR_INVALID_DATA: "InvalidDataException", ERR_ARGUMENT: "ArgumentOutOfRangeException",
+    ERR_RUNTIME: "runtime fault (IndexOutOfRange/NullReference class)", ERR_NOMEM: "out of memory",
+    ERR_NOT_VORBIS: "not a Vorbis stream", ERR_DEVICE: "HIP error", ERR_UNSUPPORTED: "unsupported stream",
+    ERR_NO_GPU: "no HIP device (there is no CPU fallback)",
+}
+
+
+class NvhError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        extra = ""
+        if code == ERR_DEVICE:
+            extra = " hipError=%d" % lib().nvh_last_hip_error()
+        super().__init__("%s failed: %d (%s)%s" % (where, code, _ERRNAMES.get(code, "?"), extra))
+
+
+# symbol -> (restype, argtypes); also the list tests check against the header
+_u8p, _f32p, _i64p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+_vp, _vpp, _ip = C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)
+SIGNATURES = {
+    "nvh_version": (C.c_char_p, []),
+    "nvh_last_hip_error": (C.c_int, []),
+    "nvh_device_count": (C.c_int, []),
+    "nvh_ctx_create": (C.c_int, [C.c_int, _vpp]),
+    "nvh_ctx_destroy": (None, [_vp]),
+    "nvh_ctx_set_hip_stream": (C.c_int, [_vp, _vp]),
+    "nvh_ctx_synchronize": (C.c_int, [_vp]),
+    "nvh_mdct_reverse": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int64]),
+    "nvh_mdct_tables": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),
+    "nvh_calc_window": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp]),
+    "nvh_calc_overlap": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]),
+    "nvh_stream_open": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vpp]),
+    "nvh_stream_close": (None, [_vp]),
+    "nvh_stream_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "nvh_stream_set_clip": (C.c_int, [_vp, C.c_int]),
+    "nvh_stream_has_clipped": (C.c_int, [_vp, _ip]),
+    "nvh_stream_position": (C.c_int, [_vp, _i64p, _i64p, _ip]),
+    "nvh_stream_push_packet": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int]),
+    "nvh_stream_push_end": (C.c_int, [_vp]),
+    "nvh_stream_pending": (C.c_int, [_vp, _ip, _i64p]),
+    "nvh_stream_pending_geometry": (C.c_int, [_vp, _vp, C.c_int]),
+    "nvh_stream_synth": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i64p]),
+    "nvh_batch_upload": (C.c_int, [_vp, _vpp]),
+    "nvh_batch_info": (C.c_int, [_vp, _ip, _ip, _i64p, _i64p]),
+    "nvh_batch_synth": (C.c_int, [_vp, _vp, C.c_int64]),
+    "nvh_batch_time": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _f32p, _f32p]),
+    "nvh_batch_free": (None, [_vp]),
+    "nvh_ogg_demux": (C.c_int, [_vp, C.c_size_t, _vp, C.c_int64, _vp, _vp, _vp, C.c_int, _ip, _i64p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnvorbis_hip.so")
+
+
+def lib():
+    """Load (building first if needed) the native library.  Raises if it cannot be had."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            _build.build()
+        handle = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == ABI drift, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, where):
+    if rc != OK:
+        raise NvhError(rc, where)
+    return rc

@@ -1,0 +1,309 @@
+"""Host-side mirror of NVorbis' reader surface over the C ABI.
+
+`VorbisReader.ReadSamples` / `StreamDecoder.Read` keep the reference's semantics
+(VorbisReader.cs:336-363, StreamDecoder.cs:320-389): counts are trimmed to a multiple of the channel
+count, partial reads are allowed, 0 is returned at the end of the stream.  Internally packets are
+parsed a batch ahead on the host and synthesised on the GPU one batch per launch sequence; a PCM ring
+is drained by the reads.  Python stands in for the C# shim of INTEGRATION.md (no .NET in this image).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native
+from .native import check, lib
+
+
+def demux_ogg(data: bytes):
+    """First logical stream of an Ogg file -> (list of packet bytes, granules, flags).
+
+    Delivers packets the way NVorbis' seekable reader does (Ogg/PacketProvider.cs:324-438)."""
+    L = lib()
+    n = C.c_int(0)
+    total = C.c_int64(0)
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    check(L.nvh_ogg_demux(buf, len(data), None, 0, None, None, None, 0, C.byref(n), C.byref(total)), "nvh_ogg_demux")
+    pk = np.zeros(max(total.value, 1), dtype=np.uint8)
+    offs = np.zeros(n.value + 1, dtype=np.int64)
+    gran = np.zeros(max(n.value, 1), dtype=np.int64)
+    flags = np.zeros(max(n.value, 1), dtype=np.uint8)
+    check(L.nvh_ogg_demux(buf, len(data), pk.ctypes.data, pk.size, offs.ctypes.data, gran.ctypes.data,
+                          flags.ctypes.data, n.value, C.byref(n), C.byref(total)), "nvh_ogg_demux")
+    packets = [pk[offs[i]:offs[i + 1]].tobytes() for i in range(n.value)]
+    return packets, gran[:n.value].copy(), flags[:n.value].copy()
+
+
+class Context:
+    """nvh_ctx: one GPU + one HIP stream."""
+
+    def __init__(self, device=0, hip_stream=None):
+        self._h = C.c_void_p()
+        check(lib().nvh_ctx_create(int(device), C.byref(self._h)), "nvh_ctx_create")
+        if hip_stream is not None:
+            self.set_hip_stream(hip_stream)
+
+    def set_hip_stream(self, hip_stream):
+        check(lib().nvh_ctx_set_hip_stream(self._h, C.c_void_p(hip_stream)), "nvh_ctx_set_hip_stream")
+
+    def synchronize(self):
+        check(lib().nvh_ctx_synchronize(self._h), "nvh_ctx_synchronize")
+
+    def mdct_reverse(self, n, batch, d_ptr, stride):
+        """IMdct.Reverse on `batch` device buffers (Contracts/IMdct.cs:5)."""
+        check(lib().nvh_mdct_reverse(self._h, int(n), int(batch), C.c_void_p(d_ptr), int(stride)), "nvh_mdct_reverse")
+
+    def close(self):
+        if self._h:
+            lib().nvh_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """nvh_batch: a parsed batch of frames resident in HBM (descriptors + work planes)."""
+
+    def __init__(self, handle, channels):
+        self._h = handle
+        self.channels = channels
+        fr, cf = C.c_int(0), C.c_int(0)
+        smp, db = C.c_int64(0), C.c_int64(0)
+        check(lib().nvh_batch_info(self._h, C.byref(fr), C.byref(cf), C.byref(smp), C.byref(db)), "nvh_batch_info")
+        self.frames, self.chan_frames, self.samples, self.descriptor_bytes = fr.value, cf.value, smp.value, db.value
+
+    def synth(self, d_pcm_ptr, capacity):
+        check(lib().nvh_batch_synth(self._h, C.c_void_p(d_pcm_ptr), int(capacity)), "nvh_batch_synth")
+
+    def time(self, d_pcm_ptr, capacity, iters, per_kernel=True):
+        total = C.c_float(0)
+        km = (C.c_float * 4)()
+        check(lib().nvh_batch_time(self._h, C.c_void_p(d_pcm_ptr), int(capacity), int(iters), C.byref(total),
+                                   km if per_kernel else None), "nvh_batch_time")
+        return total.value, [km[i] for i in range(4)]
+
+    def free(self):
+        if self._h:
+            lib().nvh_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    """nvh_stream: setup tables in HBM + host parser + overlap state.  ctx=None -> host-only (parse, no synthesis)."""
+
+    def __init__(self, ctx, id_pkt, comment_pkt, setup_pkt):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        check(lib().nvh_stream_open(ctx._h if ctx is not None else None, id_pkt, len(id_pkt), comment_pkt,
+                                    len(comment_pkt) if comment_pkt is not None else 0, setup_pkt, len(setup_pkt),
+                                    C.byref(self._h)), "nvh_stream_open")
+        ch, sr, b0, b1 = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().nvh_stream_info(self._h, C.byref(ch), C.byref(sr), C.byref(b0), C.byref(b1)), "nvh_stream_info")
+        self.channels, self.sample_rate, self.block0, self.block1 = ch.value, sr.value, b0.value, b1.value
+
+    def push_packet(self, data, granule=-1, flags=0):
+        check(lib().nvh_stream_push_packet(self._h, data, len(data), int(granule), int(flags)), "nvh_stream_push_packet")
+
+    def push_end(self):
+        check(lib().nvh_stream_push_end(self._h), "nvh_stream_push_end")
+
+    def pending(self):
+        fr, smp = C.c_int(0), C.c_int64(0)
+        check(lib().nvh_stream_pending(self._h, C.byref(fr), C.byref(smp)), "nvh_stream_pending")
+        return fr.value, smp.value
+
+    def pending_geometry(self):
+        fr, _ = self.pending()
+        out = np.zeros((max(fr, 1), 8), dtype=np.int32)
+        check(lib().nvh_stream_pending_geometry(self._h, out.ctypes.data, max(fr, 1)), "nvh_stream_pending_geometry")
+        return out[:fr]
+
+    def position(self):
+        pos, em, eos = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(lib().nvh_stream_position(self._h, C.byref(pos), C.byref(em), C.byref(eos)), "nvh_stream_position")
+        return pos.value, em.value, bool(eos.value)
+
+    def set_clip(self, on):
+        check(lib().nvh_stream_set_clip(self._h, 1 if on else 0), "nvh_stream_set_clip")
+
+    def has_clipped(self):
+        v = C.c_int(0)
+        check(lib().nvh_stream_has_clipped(self._h, C.byref(v)), "nvh_stream_has_clipped")
+        return bool(v.value)
+
+    def synth_host(self):
+        """Synthesise the pending batch; returns interleaved float32 PCM (numpy)."""
+        _, smp = self.pending()
+        out = np.empty(max(smp * self.channels, 1), dtype=np.float32)
+        wr = C.c_int64(0)
+        check(lib().nvh_stream_synth(self._h, out.ctypes.data, None, out.size, C.byref(wr)), "nvh_stream_synth")
+        return out[:wr.value]
+
+    def synth_device(self, d_ptr, capacity):
+        wr = C.c_int64(0)
+        check(lib().nvh_stream_synth(self._h, None, C.c_void_p(d_ptr), int(capacity), C.byref(wr)), "nvh_stream_synth")
+        return wr.value
+
+    def upload_batch(self):
+        h = C.c_void_p()
+        check(lib().nvh_batch_upload(self._h, C.byref(h)), "nvh_batch_upload")
+        return Batch(h, self.channels)
+
+    def close(self):
+        if self._h:
+            lib().nvh_stream_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StreamDecoder:
+    """IStreamDecoder-shaped object (Contracts/IStreamDecoder.cs:9-105) over a packet list."""
+
+    def __init__(self, ctx, packets, granules=None, flags=None, batch_frames=1024):
+        if len(packets) < 3:
+            raise native.NvhError(native.ERR_NOT_VORBIS, "StreamDecoder")
+        self._stream = Stream(ctx, packets[0], packets[1], packets[2])
+        self._packets = packets
+        self._granules = granules if granules is not None else [-1] * len(packets)
+        self._flags = flags if flags is not None else [0] * len(packets)
+        self._next = 3
+        self._batch_frames = int(batch_frames)
+        self._ring = np.zeros(0, dtype=np.float32)
+        self._ring_pos = 0
+        self._ended = False
+        self._position = 0
+
+    Channels = property(lambda self: self._stream.channels)
+    SampleRate = property(lambda self: self._stream.sample_rate)
+    HasClipped = property(lambda self: self._stream.has_clipped())
+
+    @property
+    def ClipSamples(self):
+        return self._clip if hasattr(self, "_clip") else True
+
+    @ClipSamples.setter
+    def ClipSamples(self, on):
+        self._clip = bool(on)
+        self._stream.set_clip(on)
+
+    @property
+    def IsEndOfStream(self):
+        return self._ended and self._ring_pos >= self._ring.size
+
+    @property
+    def SamplePosition(self):
+        pos, _, _ = self._stream.position()
+        return pos - (self._ring.size - self._ring_pos) // self.Channels
+
+    def _refill(self):
+        """Parse up to batch_frames packets ahead and synthesise them."""
+        while not self._ended:
+            pushed = 0
+            while pushed < self._batch_frames:
+                if self._stream.position()[2]:
+                    self._ended = True  # _eosFound: no more packets are pulled
+                    break
+                if self._next >= len(self._packets):
+                    self._stream.push_end()
+                    self._ended = True
+                    break
+                i = self._next
+                self._next += 1
+                self._stream.push_packet(self._packets[i], self._granules[i], self._flags[i])
+                pushed += 1
+            frames, _ = self._stream.pending()
+            if frames:
+                pcm = self._stream.synth_host()
+                if pcm.size:
+                    self._ring = pcm.copy()
+                    self._ring_pos = 0
+                    return True
+        return False
+
+    def Read(self, buffer, offset, count):
+        """StreamDecoder.Read (StreamDecoder.cs:320-389)."""
+        ch = self.Channels
+        if offset < 0 or offset + count > len(buffer):
+            raise IndexError("offset")  # ArgumentOutOfRangeException
+        if count % ch != 0:
+            raise ValueError("count must be a multiple of Channels")
+        idx, tgt = offset, offset + count
+        while idx < tgt:
+            if self._ring_pos >= self._ring.size:
+                if not self._refill():
+                    break
+            take = min(tgt - idx, self._ring.size - self._ring_pos)
+            buffer[idx:idx + take] = self._ring[self._ring_pos:self._ring_pos + take]
+            self._ring_pos += take
+            idx += take
+        return idx - offset
+
+    def close(self):
+        self._stream.close()
+
+
+class VorbisReader:
+    """VorbisReader-shaped facade (VorbisReader.cs): first logical stream of an .ogg file or byte string."""
+
+    def __init__(self, source, ctx=None, device=0, batch_frames=1024):
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            data = bytes(source)
+        else:
+            with open(source, "rb") as fh:
+                data = fh.read()
+        self._own_ctx = ctx is None
+        self._ctx = ctx if ctx is not None else Context(device)
+        packets, gran, flags = demux_ogg(data)
+        self._dec = StreamDecoder(self._ctx, packets, gran.tolist(), flags.tolist(), batch_frames)
+
+    Channels = property(lambda self: self._dec.Channels)
+    SampleRate = property(lambda self: self._dec.SampleRate)
+    IsEndOfStream = property(lambda self: self._dec.IsEndOfStream)
+    HasClipped = property(lambda self: self._dec.HasClipped)
+    SamplePosition = property(lambda self: self._dec.SamplePosition)
+
+    @property
+    def ClipSamples(self):
+        return self._dec.ClipSamples
+
+    @ClipSamples.setter
+    def ClipSamples(self, on):
+        self._dec.ClipSamples = on
+
+    def ReadSamples(self, buffer, offset=0, count=None):
+        """VorbisReader.ReadSamples(float[], int, int) (VorbisReader.cs:336-345)."""
+        if count is None:
+            count = len(buffer) - offset
+        count -= count % self.Channels
+        if count > 0:
+            return self._dec.Read(buffer, offset, count)
+        return 0
+
+    def read_all(self):
+        chunks = []
+        buf = np.empty(65536 * self.Channels, dtype=np.float32)
+        while True:
+            n = self.ReadSamples(buf, 0, buf.size)
+            if n <= 0:
+                break
+            chunks.append(buf[:n].copy())
+        return np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.float32)
+
+    def close(self):
+        self._dec.close()
+        if self._own_ctx:
+            self._ctx.close()
