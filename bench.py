@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decoded Vorbis frames/s for the synthesis hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): a batch of 4096 stereo 44.1 kHz long-block frames
+(n = 2048, window long/long), Floor1 + Residue2 + coupling, setup and side information taken from the
+254 long/long packets of TestFiles/3test.ogg (tests/golden/3test.ogg) tiled to 4096 ("G-real" of
+SURVEY 8d).  A step is one pass of the whole hot path (residue adds -> inverse coupling + floor ->
+IMDCT + window -> overlap-add + interleave + clip) over that batch, descriptors already resident in
+HBM, PCM written to HBM.  Weak scaling: every rank owns one GPU and one such batch, no collective in
+the data path.
+
+Launch: python bench.py --gpus N --steps K --warmup W   (N > 1 via torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FRAMES = 4096
+BLOCK = 2048
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def ll_packets(nv, path):
+    """Header packets + the long/long audio packets of an .ogg file (classified by the host parser)."""
+    data = open(path, "rb").read()
+    pk, gr, fl = nv.demux_ogg(data)
+    s = nv.Stream(None, pk[0], pk[1], pk[2])
+    ll = []
+    for i in range(3, len(pk)):
+        before = s.pending()[0]
+        s.push_packet(pk[i], -1, 0)
+        if s.pending()[0] == before + 1:
+            g = s.pending_geometry()[-1]
+            if g[0] == BLOCK and g[1] == 0 and g[2] == BLOCK // 2 and g[3] == BLOCK:
+                ll.append(pk[i])
+    s.close()
+    return pk[:3], ll, s.channels
+
+
+def cpu_baseline(headers, ll, seconds=12.0):
+    """The CPU oracle (C restatement of the reference algorithm, 1 thread) on a bounded sample of the same workload."""
+    import numpy as np
+    from tests import oracle_py
+    orc = oracle_py.load()
+    nframes = 2048
+    packets = list(headers) + [ll[i % len(ll)] for i in range(nframes + 1)]
+    gr = [-1] * len(packets)
+    fl = [0] * len(packets)
+    reps, t_total, frames = 0, 0.0, 0
+    orc.decode_packets(packets[:64], gr[:64], fl[:64])  # warm tables
+    while t_total < seconds and reps < 64:
+        t0 = time.perf_counter()
+        pcm, info = orc.decode_packets(packets, gr, fl)
+        t_total += time.perf_counter() - t0
+        frames += nframes
+        reps += 1
+    return {"value": frames / t_total, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d x %d stereo n=2048 LL frames of the bench workload (packets -> PCM incl. bit parse), %.1f s" % (reps, nframes, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import nvorbis_amd as nv
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    headers, ll, ch = ll_packets(nv, os.path.join(ROOT, "tests", "golden", "3test.ogg"))
+    assert ch == 2 and len(ll) > 0
+
+    ctx = nv.Context(local_rank)
+    ctx.set_hip_stream(torch.cuda.current_stream().cuda_stream)
+    stream = nv.Stream(ctx, headers[0], headers[1], headers[2])
+    # priming frame (a first packet emits nothing, StreamDecoder.cs:446-450) goes through a batch of its own
+    stream.push_packet(ll[(rank * 7) % len(ll)], -1, 0)
+    stream.synth_host()
+    for i in range(FRAMES):
+        stream.push_packet(ll[(i + rank * 7 + 1) % len(ll)], -1, 0)
+    batch = stream.upload_batch()
+    assert batch.frames == FRAMES and batch.samples == FRAMES * (BLOCK // 2), (batch.frames, batch.samples)
+    pcm = torch.empty(batch.samples * ch, dtype=torch.float32, device="cuda")
+    cap = pcm.numel()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.synth(pcm.data_ptr(), cap)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.synth(pcm.data_ptr(), cap)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations, hipEvents on the launch stream (rank 0 reports)
+    iters = max(10, min(args.steps, 50))
+    total_ms, km = batch.time(pcm.data_ptr(), cap, iters)
+    checksum = float(pcm.double().abs().sum().item())
+    assert checksum > 0 and bool(torch.isfinite(pcm).all().item())
+
+    if rank == 0:
+        names = ["residue", "couple_floor", "imdct_window", "ola_emit"]
+        dom = max(range(4), key=lambda k: km[k])
+        alg_bytes = FRAMES * ch * 4 * BLOCK  # read n/2*4 B spectrum + write n/2*4 B PCM per ch-frame = 4n B
+        dom_ms = km[dom]
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(names[dom])
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "decoded Vorbis frames/sec (44.1 kHz stereo long-block)",
+            "value": world * FRAMES * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (3test.ogg long/long packets tiled to 4096 frames per GPU, device resident)",
+            "config": {"workload": "C2: 4096 stereo long-block (n=2048) frames, Floor1+Residue2+coupling, IMDCT+window+OLA",
+                       "frames_per_gpu": FRAMES, "channels": ch, "block": BLOCK, "parallelism": "frame-parallel x%d" % world,
+                       "descriptor_bytes_per_frame": batch.descriptor_bytes / FRAMES},
+            "kernels_ms": dict(zip(names, km)),
+            "pipeline_ms_events": total_ms / iters,
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(headers, ll)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,13 @@ def lib():
     """Load (building first if needed) the native library.  Raises if it cannot be had."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7).
+        # Loading torch first makes the dynamic loader bind our NEEDED libamdhip64.so.7 to that copy;
+        # the other order would map a second runtime from /opt/rocm and torch.cuda would see no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = lib_path()
         if not os.path.exists(path):
             _build.build()
