@@ -164,7 +164,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(headers, ll)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    batch.free()
+    stream.close()
+    ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

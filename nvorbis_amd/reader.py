@@ -67,9 +67,10 @@ class Context:
 class Batch:
     """nvh_batch: a parsed batch of frames resident in HBM (descriptors + work planes)."""
 
-    def __init__(self, handle, channels):
+    def __init__(self, handle, stream):
         self._h = handle
-        self.channels = channels
+        self._stream = stream  # keeps the owning nvh_stream (and its nvh_ctx) alive until the batch is freed
+        self.channels = stream.channels
         fr, cf = C.c_int(0), C.c_int(0)
         smp, db = C.c_int64(0), C.c_int64(0)
         check(lib().nvh_batch_info(self._h, C.byref(fr), C.byref(cf), C.byref(smp), C.byref(db)), "nvh_batch_info")
@@ -156,7 +157,7 @@ class Stream:
     def upload_batch(self):
         h = C.c_void_p()
         check(lib().nvh_batch_upload(self._h, C.byref(h)), "nvh_batch_upload")
-        return Batch(h, self.channels)
+        return Batch(h, self)
 
     def close(self):
         if self._h:
