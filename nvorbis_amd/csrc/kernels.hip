@@ -382,7 +382,9 @@ extern "C" __global__ void __launch_bounds__(NVH_THREADS)
 k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err) {
   __shared__ int s_x[NVH_MAX_POSTS + 2];
   __shared__ int s_y[NVH_MAX_POSTS + 2];
-  __shared__ int s_nseg;
+  __shared__ int s_nseg, s_flat;
+  __shared__ int s_fy[NVH_MAX_POSTS];
+  __shared__ int s_step[NVH_MAX_POSTS];
   __shared__ float s_coeff[256];
   const int f = blockIdx.x;
   const NvhFrame fr = Bt.frames[f];
@@ -427,67 +429,78 @@ k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __r
         for (int i = tid; i < half; i += NVH_THREADS) res[i] = 0.0f;
         continue;
       }
-      __syncthreads();  // previous channel's readers are done with s_x/s_y
-      if (tid == 0) {
-        // UnwrapPosts (Floor1.cs:224-297)
-        int finalY[NVH_MAX_POSTS];
-        bool step[NVH_MAX_POSTS];
-        const uint16_t* posts = Bt.posts + chn.data_off;
-        const int pc = chn.post_count;
-        for (int i = 0; i < pc; ++i) step[i] = false;
-        step[0] = true;
-        step[1] = true;
-        finalY[0] = posts[0];
-        finalY[1] = posts[1];
-        for (int i = 2; i < pc; ++i) {
-          int lo = F->l_neigh[i], hi = F->h_neigh[i];
-          int predicted = render_point(F->x_list[lo], finalY[lo], F->x_list[hi], finalY[hi], F->x_list[i]);
-          int val = posts[i];
+      __syncthreads();  // previous channel's readers are done with the shared post state
+      // UnwrapPosts (Floor1.cs:224-297), parallel over dependency levels: post i only needs the final Y of
+      // its two neighbours (both of lower index), so all posts of one level are independent.
+      const int pc = chn.post_count;
+      const uint16_t* posts = Bt.posts + chn.data_off;
+      if (tid < pc) {
+        s_fy[tid] = (tid < 2) ? (int)posts[tid] : 0;
+        s_step[tid] = (tid < 2) ? 1 : 0;
+      }
+      __syncthreads();
+      for (int lv = 1; lv < F->levels; ++lv) {
+        if (tid >= 2 && tid < pc && F->level[tid] == lv) {
+          int lo = F->l_neigh[tid], hi = F->h_neigh[tid];
+          int predicted = render_point(F->x_list[lo], s_fy[lo], F->x_list[hi], s_fy[hi], F->x_list[tid]);
+          int val = posts[tid];
           int highroom = F->range - predicted;
           int lowroom = predicted;
           int room = (highroom < lowroom) ? highroom * 2 : lowroom * 2;
+          int fy;
           if (val != 0) {
-            step[lo] = true;
-            step[hi] = true;
-            step[i] = true;
+            // stepFlags[lowOfs] = stepFlags[highOfs] = stepFlags[i] = true: only ever set, never cleared for a
+            // lower index afterwards, so concurrent stores of 1 are order-free
+            s_step[lo] = 1;
+            s_step[hi] = 1;
+            s_step[tid] = 1;
             if (val >= room) {
-              if (highroom > lowroom) finalY[i] = val - lowroom + predicted;
-              else finalY[i] = predicted - val + highroom - 1;
+              if (highroom > lowroom) fy = val - lowroom + predicted;
+              else fy = predicted - val + highroom - 1;
             } else {
-              if ((val % 2) == 1) finalY[i] = predicted - ((val + 1) / 2);
-              else finalY[i] = predicted + (val / 2);
+              if ((val % 2) == 1) fy = predicted - ((val + 1) / 2);
+              else fy = predicted + (val / 2);
             }
           } else {
-            step[i] = false;
-            finalY[i] = predicted;
+            fy = predicted;
           }
+          s_fy[tid] = fy;
         }
-        // Apply's walk over the sorted posts (Floor1.cs:196-216) -> segment list
-        int ns = 0;
-        int lx = 0, ly = finalY[0] * F->multiplier;
-        s_x[0] = lx;
-        s_y[0] = ly;
-        for (int i = 1; i < pc; ++i) {
-          int idx = F->sort_idx[i];
-          if (step[idx]) {
-            int hx = F->x_list[idx];
-            int hy = finalY[idx] * F->multiplier;
-            if (lx < half) {
-              ++ns;
-              s_x[ns] = hx;  // the segment is drawn towards min(hx, n) (quirk B-6)
-              s_y[ns] = hy;
-            }
-            lx = hx;
-            ly = hy;
+        __syncthreads();
+      }
+      // Apply's walk over the sorted posts (Floor1.cs:196-216) -> compacted list of line end points.
+      // One lane of the first wavefront per sorted position (at most 64 posts).
+      if (tid < 64) {
+        int idx = (tid < pc) ? F->sort_idx[tid] : 0;
+        bool active = (tid < pc) && s_step[idx] != 0;
+        unsigned long long mask = __ballot(active);
+        int rank = __popcll(mask & ((1ull << tid) - 1ull));
+        int px = F->x_list[idx];
+        if (active) {
+          s_x[rank] = px;
+          s_y[rank] = s_fy[idx] * F->multiplier;
+        }
+        // the walk stops at the first end point at or beyond n/2 (`if (lx >= n) break`); the line towards
+        // it is drawn to min(hx, n) (quirk B-6)
+        unsigned long long beyond = __ballot(active && rank >= 1 && px >= half);
+        int nact = __popcll(mask);
+        if (tid == 0) {
+          int ns;
+          if (beyond) {
+            int first_lane = __ffsll((long long)beyond) - 1;
+            ns = __popcll(mask & ((1ull << first_lane) - 1ull));  // rank of that end point
+          } else {
+            ns = nact;  // trailing flat run to n/2 (Floor1.cs:213-216)
           }
-          if (lx >= half) break;
+          s_nseg = ns;
+          s_flat = beyond ? 0 : 1;
         }
-        if (lx < half) {
-          ++ns;
-          s_x[ns] = half;
-          s_y[ns] = ly;
-        }
-        s_nseg = ns;
+      }
+      __syncthreads();
+      if (tid == 0 && s_flat) {
+        int ns = s_nseg;
+        s_x[ns] = half;
+        s_y[ns] = s_y[ns - 1];
       }
       __syncthreads();
       const int ns = s_nseg;
