@@ -1,0 +1,151 @@
+"""CPU tests of the product's host side: C-ABI surface, table builders, packet parser geometry."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    """libnvorbis_hip.so loads and exports every function include/nvorbis_hip.h declares."""
+    import nvorbis_amd as nv
+    from nvorbis_amd import native
+    hdr = open(os.path.join(ROOT, "include", "nvorbis_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nvh_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    handle = C.CDLL(nv.lib_path())
+    for name in sorted(declared):
+        assert hasattr(handle, name), "missing export: " + name
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    assert b"gfx950" in nv.lib().nvh_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the compute entry points fail loudly (NVH_ERR_NO_GPU), they never fall back."""
+    import nvorbis_amd as nv
+    from nvorbis_amd import native
+    L = nv.lib()
+    if L.nvh_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    assert L.nvh_ctx_create(0, C.byref(h)) == native.ERR_NO_GPU
+    with pytest.raises(nv.NvhError):
+        nv.Context(0)
+    data = open(os.path.join(ROOT, "tests", "golden", "1test.ogg"), "rb").read()
+    pk, gr, fl = nv.demux_ogg(data)
+    s = nv.Stream(None, pk[0], pk[1], pk[2])
+    s.push_packet(pk[3], gr[3], fl[3])
+    with pytest.raises(nv.NvhError) as ei:
+        s.synth_host()
+    assert ei.value.code == native.ERR_NO_GPU
+    with pytest.raises(nv.NvhError):
+        s.upload_batch()
+
+
+@pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048, 4096, 8192])
+def test_mdct_tables_match_oracle(oracle, n):
+    """Host table builder (Mdct.cs:30-63 typing rules) == oracle, bit for bit."""
+    import nvorbis_amd as nv
+    a, b = np.zeros(n // 2, np.float32), np.zeros(n // 2, np.float32)
+    c, br = np.zeros(n // 4, np.float32), np.zeros(n // 8, np.uint16)
+    assert nv.lib().nvh_mdct_tables(n, a.ctypes.data, b.ctypes.data, c.ctypes.data, br.ctypes.data) == 0
+    oa, ob, oc, obr = oracle.mdct_tables(n)
+    for x, y in ((a, oa), (b, ob), (c, oc)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert np.array_equal(br, obr)
+
+
+def test_windows_match_oracle(oracle):
+    import nvorbis_amd as nv
+    L = nv.lib()
+    for b0, b1 in ((256, 2048), (64, 8192), (512, 512)):
+        for prev in (b0, b1):
+            for nxt in (b0, b1):
+                w = np.zeros(b1, np.float32)
+                assert L.nvh_calc_window(prev, b1, nxt, w.ctypes.data) == 0
+                assert np.array_equal(w.view(np.uint32), oracle.window(prev, b1, nxt).view(np.uint32))
+                s, v, t = C.c_int(), C.c_int(), C.c_int()
+                L.nvh_calc_overlap(prev, b1, nxt, C.byref(s), C.byref(v), C.byref(t))
+                assert (s.value, v.value, t.value) == oracle.overlap(prev, b1, nxt)
+
+
+def _parse_all(nv, packets, granules, flags):
+    s = nv.Stream(None, packets[0], packets[1], packets[2])
+    err = None
+    try:
+        for i in range(3, len(packets)):
+            s.push_packet(packets[i], granules[i], flags[i])
+        s.push_end()
+    except nv.NvhError as e:
+        err = e.code
+    geo = s.pending_geometry()
+    _, smp = s.pending()
+    pos, emitted, eos = s.position()
+    s.close()
+    return geo, smp, pos, err
+
+
+@pytest.mark.parametrize("name", ["1test", "2test", "3test", "issue6test"])
+def test_parser_geometry_matches_oracle(oracle, ogg_bytes, name):
+    """Frame lengths / positions are bit-exact: host parser geometry == oracle trace on the TestFiles."""
+    import nvorbis_amd as nv
+    pk, gr, fl = nv.demux_ogg(ogg_bytes[name])
+    geo, smp, pos, err = _parse_all(nv, pk, gr.tolist(), fl.tolist())
+    assert err is None
+    pcm, info = oracle.decode_ogg(ogg_bytes[name], trace=True)
+    tr = info["trace"]
+    ok = tr[tr[:, 3] == 1]
+    assert geo.shape[0] == ok.shape[0]
+    assert np.array_equal(geo[:, 0], ok[:, 4])  # block size
+    assert np.array_equal(geo[:, 1], ok[:, 0])  # start
+    assert np.array_equal(geo[:, 3], ok[:, 2])  # total
+    assert smp * info["channels"] == pcm.size
+    assert geo[:, 5].sum() == smp
+    assert pos == info["position"]
+    # first packet emits nothing (StreamDecoder.cs:446-450)
+    assert geo[0, 5] == 0
+
+
+def test_parser_fuzz_truncation_and_bitflips_match_oracle(oracle, ogg_bytes):
+    """Packet-time corruption is silent in the reference: truncated / bit-flipped
+    packets must produce the same number of emitted samples and the same error status in the host
+    parser as in the oracle.  (The PCM itself is compared on the GPU in test_gpu_parity.py.)"""
+    import nvorbis_amd as nv
+    rng = np.random.default_rng(2024)
+    pk, gr, fl = nv.demux_ogg(ogg_bytes["3test"])
+    gr, fl = gr.tolist(), fl.tolist()
+    for trial in range(12):
+        pk2 = list(pk[:3])
+        sel = sorted(rng.choice(np.arange(3, len(pk)), size=60, replace=False).tolist())
+        g2, f2 = gr[:3], fl[:3]
+        for i in sel:
+            p = bytearray(pk[i])
+            mode = rng.integers(0, 4)
+            if mode == 0 and len(p) > 2:
+                p = p[: int(rng.integers(0, len(p)))]
+            elif mode == 1:
+                for _ in range(int(rng.integers(1, 4))):
+                    j = int(rng.integers(0, len(p)))
+                    p[j] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 2:
+                p = bytearray()
+            pk2.append(bytes(p))
+            g2.append(-1)
+            f2.append(0)
+        geo, smp, pos, err = _parse_all(nv, pk2, g2, f2)
+        try:
+            pcm, info = oracle.decode_packets(pk2, g2, f2, trace=True)
+            oerr = None
+        except RuntimeError:
+            oerr = True
+        if oerr:
+            assert err is not None
+            continue
+        assert err is None, (trial, err)
+        assert smp * info["channels"] == pcm.size, trial
+        ok = info["trace"][info["trace"][:, 3] == 1]
+        assert geo[geo[:, 0] != 0].shape[0] == ok.shape[0]

@@ -1,0 +1,174 @@
+"""Pins for the CPU oracle that need neither a GPU nor the (unrunnable, managed C#) reference.
+
+The reference ships no golden vectors, so the oracle is pinned by: sample-count known answers derived
+from the shipped TestFiles (granule positions), the closed-form IMDCT identity, window power
+complementarity, TDAC perfect reconstruction with the reference's window / overlap geometry, and
+integer cross-checks of the floor line renderer.
+"""
+import collections
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# final granule position of each file == number of samples per channel the decoder must emit
+# (SURVEY App. C).  issue6test.ogg ends with an EOS page that carries a single zero-length packet:
+# NVorbis' PageReader rejects a page without packets (Ogg/PageReader.cs:131) before the EOS flag is
+# seen, so the last real packet is never EOS-trimmed (StreamDecoder.cs:429-437 needs isEndOfStream)
+# and the provider running dry drains its tail (:352-356): 548223 + 961 = 549184 by the reference's
+# own rules, not the file's granule.
+EXPECTED_SAMPLES = {"1test": 17318, "2test": 315790, "3test": 288094, "issue6test": 549184}
+EXPECTED_KINDS = {  # (start, valid, total) -> count   (issue6test without the empty packet)
+    "1test": {(0, 128, 256): 8, (448, 1024, 2048): 1, (0, 1024, 2048): 16},
+    "2test": {(0, 128, 256): 1, (448, 1024, 2048): 1, (0, 1024, 2048): 308},
+    "3test": {(0, 128, 256): 95, (448, 1024, 2048): 9, (0, 1024, 2048): 254, (0, 1472, 1600): 8},
+    "issue6test": {(0, 128, 256): 79, (448, 1024, 2048): 16, (0, 1024, 2048): 495, (0, 1472, 1600): 15},
+}
+
+
+@pytest.mark.parametrize("name", list(EXPECTED_SAMPLES))
+def test_testfile_sample_counts(oracle, ogg_bytes, name):
+    pcm, info = oracle.decode_ogg(ogg_bytes[name], trace=True)
+    ch = info["channels"]
+    assert pcm.size == EXPECTED_SAMPLES[name] * ch
+    assert np.isfinite(pcm).all()
+    assert np.abs(pcm).max() <= np.float32(0.99999994)
+    tr = info["trace"]
+    kinds = collections.Counter((int(a), int(b), int(c)) for a, b, c, ok, _, _ in tr if ok)
+    assert dict(kinds) == EXPECTED_KINDS[name]
+    assert info["position"] >= EXPECTED_SAMPLES[name]
+
+
+def test_read_chunking_is_irrelevant(oracle, ogg_bytes):
+    """StreamDecoder.Read partial reads (StreamDecoder.cs:338-379): any chunking gives the same PCM."""
+    a, _ = oracle.decode_ogg(ogg_bytes["3test"], chunk=4096)
+    b, _ = oracle.decode_ogg(ogg_bytes["3test"], chunk=1)
+    c, _ = oracle.decode_ogg(ogg_bytes["3test"], chunk=1000003)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+
+
+def _closed_form_imdct(X, n):
+    i = np.arange(n)[:, None]
+    k = np.arange(n // 2)[None, :]
+    return (np.cos(np.pi / (n / 2) * (i + 0.5 + n / 4) * (k + 0.5)) * X[None, :]).sum(1)
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192])
+def test_imdct_closed_form_identity(oracle, n):
+    """Mdct.CalcReverse == unnormalised IMDCT, scale 1, to fp32 accuracy."""
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-1, 1, n // 2).astype(np.float32)
+    got = oracle.mdct_reverse(X, n).astype(np.float64)
+    want = _closed_form_imdct(X.astype(np.float64), n)
+    assert np.abs(got - want).max() / np.abs(want).max() < 6e-7
+    # structural symmetry of the output (used by the GPU kernels)
+    assert np.array_equal(got[: n // 2], -got[: n // 2][::-1])
+    assert np.array_equal(got[n // 2:], got[n // 2:][::-1])
+
+
+@pytest.mark.parametrize("n", [64, 128])
+def test_imdct_small_blocks_are_not_a_transform(oracle, n):
+    """Quirk A.3 / B-10: for n < 256 the reference's stage loops over-count; mirrored, not fixed."""
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-1, 1, n // 2).astype(np.float32)
+    got = oracle.mdct_reverse(X, n).astype(np.float64)
+    want = _closed_form_imdct(X.astype(np.float64), n)
+    assert np.abs(got - want).max() / np.abs(want).max() > 0.1
+
+
+@pytest.mark.parametrize("b0,b1", [(256, 2048), (512, 4096), (64, 8192), (1024, 1024)])
+def test_window_identities(oracle, b0, b1):
+    """Mode.CalcWindow (Mode.cs:69-100): power complementary slopes, exact 0/1 plateaus, mirror symmetry."""
+    for prev in (b0, b1):
+        for nxt in (b0, b1):
+            w = oracle.window(prev, b1, nxt).astype(np.float64)
+            left, right = prev // 2, nxt // 2
+            lb = b1 // 4 - left // 2
+            rb = b1 - b1 // 4 - right // 2
+            assert (w[:lb] == 0).all() and (w[rb + right:] == 0).all()
+            assert (w[lb + left:rb] == 1).all()
+            sl = w[lb:lb + left]
+            sr = w[rb:rb + right]
+            assert np.abs(sl ** 2 + sl[::-1] ** 2 - 1).max() < 5e-7
+            assert np.abs(sr ** 2 + sr[::-1] ** 2 - 1).max() < 5e-7
+            if left == right:
+                assert np.array_equal(sl, sr[::-1])
+    s, v, t = oracle.overlap(b1, b1, b1)
+    assert (s, v, t) == (0, b1 // 2, b1)
+    s, v, t = oracle.overlap(b0, b1, b0)
+    assert (s, v, t) == (b1 // 4 - b0 // 4, b1 // 4 * 3 - b0 // 4, b1 // 4 * 3 + b0 // 4)
+
+
+def test_tdac_perfect_reconstruction(oracle):
+    """Forward MDCT (numpy, double) -> oracle IMDCT + window + overlap-add with the CalcWindow / CalcOverlap
+    geometry reconstructs the signal.  Block sequence exercises all four long windows."""
+    b0, b1 = 256, 2048
+    seq = "LLLSSSLLSLLL"
+    rng = np.random.default_rng(5)
+    sizes = [b1 if c == "L" else b0 for c in seq]
+    # block centres: consecutive blocks overlap so that centre distance = n_prev/4 + n_cur/4
+    centres = [b1 // 2]
+    for i in range(1, len(sizes)):
+        centres.append(centres[-1] + sizes[i - 1] // 4 + sizes[i] // 4)
+    total_len = centres[-1] + b1
+    x = rng.uniform(-0.5, 0.5, total_len)
+    out = np.zeros(total_len)
+    prev_tail = None
+    emitted = []
+    pos_check = None
+    for i, n in enumerate(sizes):
+        prev = sizes[i - 1] if i > 0 else n
+        nxt = sizes[i + 1] if i + 1 < len(sizes) else n
+        if n == b0:
+            prev = nxt = b0
+        w = oracle.window(min(prev, n) if n == b1 else b0, n, min(nxt, n) if n == b1 else b0).astype(np.float64)
+        s, v, t = oracle.overlap(min(prev, n), n, min(nxt, n)) if n == b1 else (0, n // 2, n)
+        seg = x[centres[i] - n // 2: centres[i] + n // 2]
+        ii = np.arange(n)[:, None]
+        kk = np.arange(n // 2)[None, :]
+        X = (4.0 / n) * ((w * seg)[:, None] * np.cos(np.pi / (n / 2) * (ii + 0.5 + n / 4) * (kk + 0.5))).sum(0)
+        y = oracle.mdct_reverse(X.astype(np.float32), n).astype(np.float64) * w
+        if prev_tail is not None:
+            y[s:s + prev_tail.size] += prev_tail
+            emitted.append((centres[i] - n // 2 + s, y[s:v].copy()))
+        prev_tail = y[v:t].copy()
+    # emitted segments are contiguous and reproduce x
+    pos = emitted[0][0]
+    for p, seg in emitted:
+        assert p == pos
+        assert np.abs(seg - x[p:p + seg.size]).max() < 5e-6
+        pos += seg.size
+
+
+def test_floor1_line_closed_form_matches_incremental(oracle):
+    """The closed form used on the GPU for Floor1.RenderLineMulti (Floor1.cs:316-341) equals the reference's
+    incremental error-term loop for every x, including lines whose end point was clipped to n/2."""
+    rng = np.random.default_rng(11)
+    import ctypes as C
+    for _ in range(3000):
+        x0 = int(rng.integers(0, 1000))
+        x1 = x0 + int(rng.integers(1, 600))
+        y0, y1 = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+        v = np.ones(x1 + 1, np.float32)
+        assert oracle.L.orc_render_line_multi(x0, y0, x1, y1, v.ctypes.data, v.size) == 0
+        dy, adx = y1 - y0, x1 - x0
+        ady, sy = abs(dy), (-1 if dy < 0 else 1)
+        b = int(dy / adx)  # truncation toward zero
+        ady -= abs(b) * adx
+        t = np.arange(0, adx)
+        y = y0 + b * t + sy * ((ady * t) // adx)
+        want = np.array([oracle.L.orc_inverse_db(int(q)) for q in y], np.float32)
+        assert np.array_equal(v[x0:x1], want)
+
+
+def test_db_table_copies_agree(oracle):
+    a = open(os.path.join(ROOT, "oracle", "floor1_db_table.inc")).read()
+    b = open(os.path.join(ROOT, "nvorbis_amd", "csrc", "floor1_db_table.inc")).read()
+    assert a == b
+    vals = np.array([oracle.L.orc_inverse_db(i) for i in range(256)], np.float64)
+    closed = np.exp((np.arange(256) - 255) * 0.546875 * 0.11512925)
+    assert np.abs(vals / closed - 1).max() < 1e-7
+    assert vals[255] == 1.0
