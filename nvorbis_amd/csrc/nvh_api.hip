@@ -21,6 +21,8 @@ extern "C" {
 __global__ void k_mdct_reverse(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
                                const uint16_t* BR);
 __global__ void k_imdct_window(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
 __global__ void k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
@@ -187,6 +189,8 @@ extern "C" int nvh_ctx_synchronize(nvh_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 
 static bool valid_block(int n) { return n >= 64 && n <= 8192 && (n & (n - 1)) == 0; }
+// LDS bytes of the wavefront IMDCT: n/4 complex points + 1/8 padding (kernels_imdct.hip Geo<LD>::LDS_FLOATS)
+static size_t wave_lds_bytes(int n) { return (size_t)2 * ((size_t)(n / 4) + (size_t)(n / 32)) * sizeof(float); }
 
 extern "C" int nvh_mdct_tables(int n, float* a, float* b, float* c, uint16_t* bitrev) {
   if (!valid_block(n) || !a || !b || !c || !bitrev) return NVH_ERR_ARGUMENT;
@@ -241,8 +245,12 @@ extern "C" int nvh_mdct_reverse(nvh_ctx* c, int n, int batch, float* d_buf, int6
   MdctDev* m = nullptr;
   int rc = get_mdct(c, n, &m);
   if (rc != NVH_OK) return rc;
-  hipLaunchKernelGGL(k_mdct_reverse, dim3((unsigned)batch), dim3(256), (size_t)n * sizeof(float), c->stream, d_buf, n,
-                     (long long)stride, m->a, m->b, m->c, m->br);
+  if (n >= 256)  // wavefront-per-buffer radix-8 path
+    hipLaunchKernelGGL(k_mdct_reverse_wave, dim3((unsigned)batch), dim3(64), wave_lds_bytes(n), c->stream, d_buf, n,
+                       (long long)stride, m->a, m->b, m->c);
+  else  // 64 / 128: generic stage-synchronous kernel (the reference's loops over-count there, quirk B-10)
+    hipLaunchKernelGGL(k_mdct_reverse, dim3((unsigned)batch), dim3(256), (size_t)n * sizeof(float), c->stream, d_buf, n,
+                       (long long)stride, m->a, m->b, m->c, m->br);
   HIP_TRY(hipGetLastError());
   return NVH_OK;
 }
@@ -593,7 +601,11 @@ static int batch_launch(nvh_batch* b, const float* carry, float* d_pcm, bool tim
   if (timing) HIP_TRY(hipEventRecord(ev[1], st));
   hipLaunchKernelGGL(k_couple_floor, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, flags);
   if (timing) HIP_TRY(hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL(k_imdct_window, dim3((unsigned)(b->nframes * ch)), dim3(256), lds, st, s->dev, b->dev, work);
+  if (s->setup.block0 >= 256)
+    hipLaunchKernelGGL(k_imdct_wave, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
+                       b->dev, work);
+  else
+    hipLaunchKernelGGL(k_imdct_window, dim3((unsigned)(b->nframes * ch)), dim3(256), lds, st, s->dev, b->dev, work);
   if (timing) HIP_TRY(hipEventRecord(ev[3], st));
   if (!b->sequential_ola)
     hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
