@@ -109,6 +109,9 @@ int nvh_stream_synth(nvh_stream *s, float *pcm_host, float *d_pcm, int64_t capac
 int nvh_batch_upload(nvh_stream *s, nvh_batch **out);
 int nvh_batch_info(const nvh_batch *b, int *frames, int *chan_frames, int64_t *pcm_samples_per_channel,
                    int64_t *descriptor_bytes);
+/* Descriptor element counts: frames, channel-frames, residue passes, residue ops, VQ entries, floor1 posts,
+ * floor0 coefficients, reserved. */
+int nvh_batch_stats(const nvh_batch *b, int64_t *out8);
 /* Launch the synthesis kernels for a resident batch (asynchronous on the context's stream);
  * may be repeated, results are identical each time.  d_pcm holds samples*channels floats. */
 int nvh_batch_synth(nvh_batch *b, float *d_pcm, int64_t capacity);

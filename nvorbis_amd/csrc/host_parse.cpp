@@ -285,6 +285,8 @@ int StreamParser::parse_audio(BitReader& p, FrameBatch& out, int* decoded) {
   f.ov_frame = -1;
   f.chan_off = (uint32_t)out.chans.size();
   f.pass_begin = (uint32_t)out.passes.size();
+  f.op_begin = (uint32_t)out.ops.size();
+  f.ent_begin = (uint32_t)out.entries.size();
 
   std::vector<uint8_t> energy((size_t)nch), force_energy((size_t)nch, 0), force_no_energy((size_t)nch, 0);
   bool any_execute = false;
@@ -321,6 +323,8 @@ int StreamParser::parse_audio(BitReader& p, FrameBatch& out, int* decoded) {
   }
   for (int c = 0; c < nch; c++) out.chans[f.chan_off + (size_t)c].exec = exec(c) ? 1 : 0;
   f.pass_end = (uint32_t)out.passes.size();
+  f.op_count = (uint32_t)out.ops.size() - f.op_begin;
+  f.ent_count = (uint32_t)out.entries.size() - f.ent_begin;
   out.frames.push_back(f);
   *decoded = 1;
   return NVH_OK;

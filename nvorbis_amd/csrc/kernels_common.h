@@ -7,7 +7,7 @@
 
 // Pointers into the per-stream device arena that holds the setup (uploaded once).
 struct NvhDevSetup {
-  int32_t channels, block0, block1, pad;
+  int32_t channels, block0, block1, nbooks;
   const float* vq;                // VQ lookup tables of every codebook
   const NvhDevBook* books;
   const NvhDevFloor* floors;

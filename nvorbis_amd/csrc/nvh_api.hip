@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -22,6 +23,8 @@ __global__ void k_mdct_reverse(float* buf, int n, long long stride, const float*
                                const uint16_t* BR);
 __global__ void k_imdct_window(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
+__global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
@@ -84,8 +87,10 @@ struct nvh_batch {
   int nframes = 0, chan_frames = 0;
   int64_t pcm_samples = 0;
   int64_t descriptor_bytes = 0;
+  int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // frames, chans, passes, ops, entries, posts, coeffs, -
   bool sequential_ola = false;
   int last_decoded = -1;  // last frame with n != 0 (its block becomes the next carried tail)
+  int max_ops = 0, max_ent = 0;  // largest per-frame op / entry slice (LDS staging capacity of k_spectrum)
   bool has_carry_in = false;
 };
 
@@ -286,7 +291,7 @@ static int upload_setup(nvh_stream* s) {
     const nvh::Codebook& b = S.books[i];
     books[i].entries = (uint32_t)b.entries;
     books[i].dim = (uint32_t)b.dimensions;
-    books[i].pad = 0;
+    books[i].dim_magic = b.dimensions > 1 ? (uint32_t)((0x100000000ull + (uint64_t)b.dimensions - 1) / (uint64_t)b.dimensions) : 0u;
     if (b.map_type == 0) {
       books[i].tab_off = 0xFFFFFFFFu;
     } else {
@@ -361,6 +366,21 @@ static int upload_setup(nvh_stream* s) {
         if (bk.dimensions > 0 && r.type != 0 && r.partition_size % bk.dimensions != 0) seq = true;  // vector overrun
       }
     d.sequential = seq ? 1 : 0;
+    d.psize_magic = r.partition_size > 1 ? (uint32_t)((0x100000000ull + (uint64_t)r.partition_size - 1) / (uint64_t)r.partition_size) : 0u;
+    d.rch_magic = r.real_channels > 1 ? (uint32_t)((0x100000000ull + (uint64_t)r.real_channels - 1) / (uint64_t)r.real_channels) : 0u;
+    // reciprocal multiplies are exact while index * divisor < 2^32; indices stay below
+    // (partitions per stage) * channels * partition_size <= block1/2 * channels (+ one partition of overrun)
+    {
+      uint64_t max_index = (uint64_t)(S.block1 / 2 + r.partition_size) * (uint64_t)(r.real_channels > 0 ? r.real_channels : 1);
+      uint64_t max_div = (uint64_t)r.partition_size;
+      if ((uint64_t)r.real_channels > max_div) max_div = (uint64_t)r.real_channels;
+      for (int c = 0; c < r.classifications; c++)
+        for (int k = 0; k < NVH_MAX_STAGES; k++)
+          if (r.books[c][k] >= 0 && (uint64_t)S.books[(size_t)r.books[c][k]].dimensions > max_div)
+            max_div = (uint64_t)S.books[(size_t)r.books[c][k]].dimensions;
+      d.fast = (r.type != 0 && r.partition_size > 1 && max_index * max_div < 0x100000000ull) ? 1 : 0;
+      d.pad = 0;
+    }
   }
 
   std::vector<uint8_t> coupling;
@@ -403,7 +423,7 @@ static int upload_setup(nvh_stream* s) {
   D.channels = S.channels;
   D.block0 = S.block0;
   D.block1 = S.block1;
-  D.pad = 0;
+  D.nbooks = (int32_t)S.books.size();
   D.vq = (const float*)(base + o_vq);
   D.books = (const NvhDevBook*)(base + o_books);
   D.floors = (const NvhDevFloor*)(base + o_floors);
@@ -542,12 +562,20 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->pcm_samples = P.pcm_samples;
   b->sequential_ola = P.sequential_ola;
   b->last_decoded = -1;
+  b->max_ops = b->max_ent = 0;
+  for (const NvhFrame& fr : P.frames) {
+    if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
+    if ((int)fr.ent_count > b->max_ent) b->max_ent = (int)fr.ent_count;
+  }
   for (int i = b->nframes - 1; i >= 0; --i)
     if (P.frames[(size_t)i].n != 0) {
       b->last_decoded = i;
       break;
     }
 
+  b->stats[0] = (int64_t)P.frames.size(); b->stats[1] = (int64_t)P.chans.size(); b->stats[2] = (int64_t)P.passes.size();
+  b->stats[3] = (int64_t)P.ops.size(); b->stats[4] = (int64_t)P.entries.size(); b->stats[5] = (int64_t)P.posts.size();
+  b->stats[6] = (int64_t)P.coeffs.size();
   ArenaBuilder ab;
   auto pad1 = [](size_t n) { return n ? n : (size_t)1; };
   std::vector<uint8_t> dummy(64, 0);
@@ -597,9 +625,33 @@ static int batch_launch(nvh_batch* b, const float* carry, float* d_pcm, bool tim
   if (timing)
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   if (timing) HIP_TRY(hipEventRecord(ev[0], st));
-  hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work);
-  if (timing) HIP_TRY(hipEventRecord(ev[1], st));
-  hipLaunchKernelGGL(k_couple_floor, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, flags);
+  // Fused spectrum kernel when a frame's spectrum (+ staged side information) fits the default 64 KB dynamic
+  // LDS window; LDS map in kernels_spectrum.hip.
+  {
+    static const int phase_mask = getenv("NVH_DEBUG_SPECTRUM_MASK") ? atoi(getenv("NVH_DEBUG_SPECTRUM_MASK")) : 7;  // profiling aid
+    const size_t fixed_words = 512 + 4 * (1840 / 4) + (size_t)s->setup.books.size() * 4 + (size_t)ch * (size_t)(s->setup.block1 / 2);
+    int cap_ops = (b->max_ops + 1) & ~1, cap_ent = (b->max_ent + 7) & ~7;  // keep the spectrum 16-byte aligned
+    size_t words = fixed_words + (size_t)cap_ops * 2 + (size_t)cap_ent / 2;
+    if (words * 4 > 64 * 1024) {  // oversized frames: leave ops / entries in global memory
+      cap_ops = cap_ent = 0;
+      words = fixed_words;
+    }
+    if (words * 4 <= 64 * 1024) {
+      bool has_floor0 = false;
+      for (const auto& fl : s->setup.floors) has_floor0 = has_floor0 || fl.type == 0;
+      if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
+      if (has_floor0)
+        hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
+                           phase_mask, cap_ops, cap_ent);
+      else
+        hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
+                           phase_mask, cap_ops, cap_ent);
+    } else {
+      hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work);
+      if (timing) HIP_TRY(hipEventRecord(ev[1], st));
+      hipLaunchKernelGGL(k_couple_floor, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, flags);
+    }
+  }
   if (timing) HIP_TRY(hipEventRecord(ev[2], st));
   if (s->setup.block0 >= 256)
     hipLaunchKernelGGL(k_imdct_wave, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
@@ -699,6 +751,12 @@ extern "C" int nvh_batch_info(const nvh_batch* b, int* frames, int* chan_frames,
   if (chan_frames) *chan_frames = b->chan_frames;
   if (pcm_samples) *pcm_samples = b->pcm_samples;
   if (descriptor_bytes) *descriptor_bytes = b->descriptor_bytes;
+  return NVH_OK;
+}
+
+extern "C" int nvh_batch_stats(const nvh_batch* b, int64_t* out8) {
+  if (!b || !out8) return NVH_ERR_ARGUMENT;
+  for (int i = 0; i < 8; i++) out8[i] = b->stats[i];
   return NVH_OK;
 }
 

@@ -23,7 +23,7 @@ struct NvhDevBook {      // Codebook lookup table (Codebook.cs:222-283, indexer 
   uint32_t tab_off;      // float offset into the VQ pool; 0xFFFFFFFF for map type 0
   uint32_t entries;
   uint32_t dim;
-  uint32_t pad;
+  uint32_t dim_magic;    // ceil(2^32 / dim): x / dim == __umulhi(x, dim_magic) for x * dim < 2^32 (0 when dim <= 1)
 };
 
 struct NvhDevFloor1 {    // Floor1.cs:21-25, :93-133
@@ -61,6 +61,10 @@ struct NvhDevResidue {   // Residue0.cs:21-33
   int32_t channels;      // channels seen by the base decode loop (1 for type 2, Residue2.cs:13)
   int32_t real_channels; // Residue2._channels
   int32_t sequential;    // 1 => partitions of a stage may alias (quirk B-1): apply ops in order
+  uint32_t psize_magic;  // ceil(2^32 / partition_size)
+  uint32_t rch_magic;    // ceil(2^32 / real_channels) (0 when real_channels == 1)
+  int32_t fast;          // 1 => the reciprocal-multiply index path is exact for every index of this residue
+  int32_t pad;
 };
 
 struct NvhDevMapping {   // Mapping.cs:9-14
@@ -107,5 +111,7 @@ struct NvhFrame {
   int64_t out_pos;       // per-channel sample position of the first emitted sample in the batch PCM
   uint32_t chan_off;     // first NvhChan of this frame
   uint32_t pass_begin, pass_end;  // residue passes of this frame (one per submap)
+  uint32_t op_begin, op_count;    // this frame's slice of the op list (contiguous, stage-major)
+  uint32_t ent_begin, ent_count;  // this frame's slice of the entry stream (contiguous)
   uint32_t pad;
 };

@@ -76,6 +76,12 @@ class Batch:
         check(lib().nvh_batch_info(self._h, C.byref(fr), C.byref(cf), C.byref(smp), C.byref(db)), "nvh_batch_info")
         self.frames, self.chan_frames, self.samples, self.descriptor_bytes = fr.value, cf.value, smp.value, db.value
 
+    def stats(self):
+        out = (C.c_int64 * 8)()
+        check(lib().nvh_batch_stats(self._h, out), "nvh_batch_stats")
+        keys = ["frames", "chan_frames", "passes", "ops", "entries", "posts", "coeffs"]
+        return {k: out[i] for i, k in enumerate(keys)}
+
     def synth(self, d_pcm_ptr, capacity):
         check(lib().nvh_batch_synth(self._h, C.c_void_p(d_pcm_ptr), int(capacity)), "nvh_batch_synth")
 
