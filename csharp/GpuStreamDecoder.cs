@@ -1,0 +1,119 @@
+// GpuStreamDecoder.cs -- IStreamDecoder over libnvorbis_hip.so.
+//
+// Shape: NVorbis.StreamDecoder (NVorbis/StreamDecoder.cs) with the synthesis plug-ins (IMode -> IMapping ->
+// IFloor / IResidue / IMdct, created by IFactory) replaced by one native stream object.  The reference's own
+// container layer keeps feeding it: packets come from Contracts.IPacketProvider exactly as before.
+// Plug it in through the seam the reference already has (VorbisReader.cs:15):
+//
+//     VorbisReader.CreateStreamDecoder = pp => new NVorbis.Hip.GpuStreamDecoder(pp, device: 0);
+//
+// Source-only here (no .NET toolchain in the build image); the same call sequence is exercised by the
+// Python mirror nvorbis_amd/reader.py::StreamDecoder against the identical C ABI.
+using System;
+using NVorbis.Contracts;
+
+namespace NVorbis.Hip
+{
+    public sealed unsafe class GpuStreamDecoder : IStreamDecoder
+    {
+        readonly Contracts.IPacketProvider _packetProvider;
+        IntPtr _ctx, _stream;
+        int _channels, _sampleRate, _block0, _block1;
+        readonly int _batchPackets;
+        float[] _ring = Array.Empty<float>();
+        int _ringPos, _ringLen;
+        bool _ended, _clip = true;
+
+        public GpuStreamDecoder(Contracts.IPacketProvider packetProvider, int device = 0, int batchPackets = 1024)
+        {
+            _packetProvider = packetProvider ?? throw new ArgumentNullException(nameof(packetProvider));
+            _batchPackets = batchPackets;
+            NativeMethods.Check(NativeMethods.nvh_ctx_create(device, out _ctx));
+            // ProcessHeaderPackets (StreamDecoder.cs:107-127): id, comment, setup
+            byte[] id = ReadAll(_packetProvider.GetNextPacket());
+            byte[] comment = ReadAll(_packetProvider.GetNextPacket());
+            byte[] setup = ReadAll(_packetProvider.GetNextPacket());
+            fixed (byte* pi = id, pc = comment, ps = setup)
+                NativeMethods.Check(NativeMethods.nvh_stream_open(_ctx, pi, id.Length, pc, comment.Length, ps, setup.Length, out _stream));
+            NativeMethods.Check(NativeMethods.nvh_stream_info(_stream, out _channels, out _sampleRate, out _block0, out _block1));
+        }
+
+        static byte[] ReadAll(IPacket packet)
+        {
+            if (packet == null) throw new System.IO.InvalidDataException("missing Vorbis header packet");
+            var buf = new byte[(packet.BitsRemaining + 7) / 8];
+            int n = packet.Read(buf, 0, buf.Length);   // Extensions.cs:19
+            packet.Done();
+            if (n != buf.Length) Array.Resize(ref buf, n);
+            return buf;
+        }
+
+        public int Channels => _channels;
+        public int SampleRate => _sampleRate;
+        public bool ClipSamples { get => _clip; set { _clip = value; NativeMethods.Check(NativeMethods.nvh_stream_set_clip(_stream, value ? 1 : 0)); } }
+        public bool HasClipped { get { NativeMethods.Check(NativeMethods.nvh_stream_has_clipped(_stream, out int c)); return c != 0; } }
+        public bool IsEndOfStream => _ended && _ringPos >= _ringLen;
+        public long SamplePosition
+        {
+            get { NativeMethods.Check(NativeMethods.nvh_stream_position(_stream, out long pos, out _, out _)); return pos - (_ringLen - _ringPos) / _channels; }
+            set => throw new NotSupportedException("seeking is outside the accelerated path (SURVEY 8 f3)");
+        }
+
+        // Parse up to _batchPackets packets ahead on the host, synthesise them on the GPU in one go.
+        bool Refill()
+        {
+            while (!_ended)
+            {
+                for (int pushed = 0; pushed < _batchPackets; pushed++)
+                {
+                    NativeMethods.Check(NativeMethods.nvh_stream_position(_stream, out _, out _, out int eos));
+                    if (eos != 0) { _ended = true; break; }                    // _eosFound (StreamDecoder.cs:343-350)
+                    var packet = _packetProvider.GetNextPacket();
+                    if (packet == null) { NativeMethods.Check(NativeMethods.nvh_stream_push_end(_stream)); _ended = true; break; }
+                    int flags = (packet.IsEndOfStream ? NativeMethods.NVH_PKT_EOS : 0) | (packet.IsResync ? NativeMethods.NVH_PKT_RESYNC : 0);
+                    long granule = packet.GranulePosition ?? -1;
+                    byte[] data = ReadAll(packet);
+                    fixed (byte* p = data)
+                        NativeMethods.Check(NativeMethods.nvh_stream_push_packet(_stream, p, data.Length, granule, flags));
+                }
+                NativeMethods.Check(NativeMethods.nvh_stream_pending(_stream, out int frames, out long samples));
+                if (frames == 0) continue;
+                long need = samples * _channels;
+                if (_ring.Length < need) _ring = new float[need];
+                long written;
+                fixed (float* dst = _ring)
+                    NativeMethods.Check(NativeMethods.nvh_stream_synth(_stream, dst, IntPtr.Zero, _ring.Length, out written));
+                _ringPos = 0; _ringLen = (int)written;
+                if (written > 0) return true;
+            }
+            return false;
+        }
+
+        // StreamDecoder.Read (StreamDecoder.cs:320-389): same argument checks, partial reads, 0 at end of stream.
+        public int Read(Span<float> buffer, int offset, int count)
+        {
+            if (offset < 0 || offset + count > buffer.Length) throw new ArgumentOutOfRangeException(nameof(offset));
+            if (count % _channels != 0) throw new ArgumentOutOfRangeException(nameof(count), "Must be a multiple of Channels!");
+            if (_stream == IntPtr.Zero) throw new ObjectDisposedException(nameof(GpuStreamDecoder));
+            int idx = offset, tgt = offset + count;
+            while (idx < tgt)
+            {
+                if (_ringPos >= _ringLen && !Refill()) break;
+                int take = Math.Min(tgt - idx, _ringLen - _ringPos);
+                new Span<float>(_ring, _ringPos, take).CopyTo(buffer.Slice(idx, take));
+                _ringPos += take; idx += take;
+            }
+            return idx - offset;
+        }
+
+        public void Dispose()
+        {
+            if (_stream != IntPtr.Zero) { NativeMethods.nvh_stream_close(_stream); _stream = IntPtr.Zero; }
+            if (_ctx != IntPtr.Zero) { NativeMethods.nvh_ctx_destroy(_ctx); _ctx = IntPtr.Zero; }
+        }
+
+        // members of IStreamDecoder that sit outside the accelerated path
+        public void SeekTo(long samplePosition, System.IO.SeekOrigin seekOrigin = System.IO.SeekOrigin.Begin) => throw new NotSupportedException();
+        public void SeekTo(TimeSpan timePosition, System.IO.SeekOrigin seekOrigin = System.IO.SeekOrigin.Begin) => throw new NotSupportedException();
+    }
+}

@@ -1,0 +1,56 @@
+// NativeMethods.cs -- P/Invoke declarations for libnvorbis_hip.so (include/nvorbis_hip.h).
+// Source-only in this repository: the build image has no .NET toolchain.  The Python ctypes binding
+// (nvorbis_amd/native.py) declares exactly the same entry points and is what the test suite drives.
+using System;
+using System.Runtime.InteropServices;
+
+namespace NVorbis.Hip
+{
+    internal static class NativeMethods
+    {
+        const string Lib = "nvorbis_hip"; // resolves libnvorbis_hip.so
+
+        public const int NVH_OK = 0;
+        public const int NVH_ERR_INVALID_DATA = -1, NVH_ERR_ARGUMENT = -2, NVH_ERR_RUNTIME = -3, NVH_ERR_NOMEM = -4;
+        public const int NVH_ERR_NOT_VORBIS = -5, NVH_ERR_DEVICE = -6, NVH_ERR_UNSUPPORTED = -7, NVH_ERR_NO_GPU = -8;
+        public const int NVH_PKT_EOS = 1, NVH_PKT_RESYNC = 2;
+
+        [DllImport(Lib)] public static extern int nvh_device_count();
+        [DllImport(Lib)] public static extern int nvh_last_hip_error();
+        [DllImport(Lib)] public static extern int nvh_ctx_create(int device, out IntPtr ctx);
+        [DllImport(Lib)] public static extern void nvh_ctx_destroy(IntPtr ctx);
+        [DllImport(Lib)] public static extern int nvh_ctx_synchronize(IntPtr ctx);
+
+        [DllImport(Lib)] public static extern int nvh_mdct_reverse(IntPtr ctx, int n, int batch, IntPtr dBuf, long stride);
+        [DllImport(Lib)] public static extern int nvh_calc_window(int prevBlock, int block, int nextBlock, [Out] float[] window);
+        [DllImport(Lib)] public static extern int nvh_calc_overlap(int prevBlock, int block, int nextBlock, out int start, out int valid, out int total);
+
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_open(IntPtr ctx, byte* id, int idLen, byte* comment, int commentLen,
+                                                                       byte* setup, int setupLen, out IntPtr stream);
+        [DllImport(Lib)] public static extern void nvh_stream_close(IntPtr stream);
+        [DllImport(Lib)] public static extern int nvh_stream_info(IntPtr stream, out int channels, out int sampleRate, out int block0, out int block1);
+        [DllImport(Lib)] public static extern int nvh_stream_set_clip(IntPtr stream, int on);
+        [DllImport(Lib)] public static extern int nvh_stream_has_clipped(IntPtr stream, out int clipped);
+        [DllImport(Lib)] public static extern int nvh_stream_position(IntPtr stream, out long position, out long emitted, out int eos);
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_push_packet(IntPtr stream, byte* data, int len, long granule, int flags);
+        [DllImport(Lib)] public static extern int nvh_stream_push_end(IntPtr stream);
+        [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_synth(IntPtr stream, float* pcmHost, IntPtr dPcm, long capacity, out long written);
+
+        internal static void Check(int rc)
+        {
+            switch (rc)
+            {
+                case NVH_OK: return;
+                case NVH_ERR_INVALID_DATA:
+                case NVH_ERR_NOT_VORBIS: throw new System.IO.InvalidDataException("nvorbis_hip: invalid Vorbis data (" + rc + ")");
+                case NVH_ERR_ARGUMENT: throw new ArgumentOutOfRangeException("nvorbis_hip argument");
+                case NVH_ERR_RUNTIME: throw new IndexOutOfRangeException("nvorbis_hip: the managed decoder would have faulted here");
+                case NVH_ERR_NOMEM: throw new OutOfMemoryException();
+                case NVH_ERR_UNSUPPORTED: throw new NotSupportedException("nvorbis_hip: stream outside documented limits");
+                case NVH_ERR_NO_GPU: throw new PlatformNotSupportedException("nvorbis_hip: no HIP device (there is no CPU fallback)");
+                default: throw new InvalidOperationException("nvorbis_hip: HIP error " + nvh_last_hip_error());
+            }
+        }
+    }
+}
