@@ -533,6 +533,38 @@ void build_mdct_tables(int n, MdctTables& t) {  // Mdct.cs:30-63
     t.c[k2 + 1] = (float)-std::sin((double)arg_c);
   }
   for (int i = 0; i < n8; ++i) t.bitrev[i] = (uint16_t)(bit_reverse((uint32_t)i, ld - 3) << 2);
+
+  // Lane-ordered twiddles.  The (ld-5) radix-2 stages with distances N/2 .. 8 (N = n/4 complex points) are run
+  // in passes of up to three stages; pass (R, S) handles distances S<<(R-1) .. S on sets base + S*k, set index
+  // s = blk*S + r.  The butterfly (c_lo, c_lo + D) uses _a[t], _a[t+1], t = (D-1-(c_lo mod D)) * (n2/D), and
+  // c_lo mod D = r + S*kk with kk = k mod 2^st.  Pair index: stages from the largest distance down, kk ascending.
+  t.tw.clear();
+  if (n >= 256) {
+    const int N = n >> 2;
+    int remain = ld - 5;
+    while (remain > 0) {
+      const int R = remain >= 3 ? 3 : remain;
+      const int S = 8 << (remain - R);
+      const int nsets = N >> R;
+      const int pairs = (1 << R) - 1;
+      size_t base = t.tw.size();
+      t.tw.resize(base + (size_t)2 * pairs * nsets);
+      for (int s = 0; s < nsets; ++s) {
+        const int r = s & (S - 1);
+        int pi = 0;
+        for (int st = R - 1; st >= 0; --st) {
+          const int D = S << st;
+          for (int kk = 0; kk < (1 << st); ++kk, ++pi) {
+            const int m = D - 1 - (r + S * kk);
+            const int ti = m * (n2 / D);
+            t.tw[base + (size_t)(2 * pi) * nsets + s] = t.a[(size_t)ti];
+            t.tw[base + (size_t)(2 * pi + 1) * nsets + s] = t.a[(size_t)ti + 1];
+          }
+        }
+      }
+      remain -= R;
+    }
+  }
 }
 
 static int mode_init(Mode& m, BitReader& p, Setup& s) {  // Mode.cs:24-67

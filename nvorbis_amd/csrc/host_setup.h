@@ -92,6 +92,10 @@ struct MdctTables {                // Mdct.cs:30-63
   int n = 0;
   std::vector<float> a, b, c;
   std::vector<uint16_t> bitrev;
+  // _a re-ordered for the wavefront IMDCT kernel (kernels_imdct.hip): for every radix pass, the twiddle pairs a
+  // lane needs, laid out [pair component][set] so that the 64 lanes of a wave read consecutive floats.
+  // Same float values as `a` (bit copies); empty for n < 256.
+  std::vector<float> tw;
 };
 
 struct Setup {

@@ -21,6 +21,7 @@ struct NvhDevSetup {
   const float* mdct_b[2];
   const float* mdct_c[2];
   const uint16_t* mdct_br[2];
+  const float* mdct_tw[2];        // lane-ordered copies of _a for the wavefront IMDCT (host_setup.cpp)
 };
 
 // One uploaded frame batch.

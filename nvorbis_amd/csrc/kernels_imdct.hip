@@ -41,8 +41,9 @@ struct Geo {
 };
 
 // One register pass over R radix-2 stages whose smallest distance is S complex points.
+// TW: this pass's lane-ordered twiddles, [pair component][set] (host_setup.cpp build_mdct_tables).
 template <int LD, int R, int S>
-__device__ __forceinline__ void radix_pass(float2* __restrict__ l2, const float* __restrict__ A, int lane) {
+__device__ __forceinline__ void radix_pass(float2* __restrict__ l2, const float* __restrict__ TW, int lane) {
   using G = Geo<LD>;
   constexpr int K = 1 << R;
   constexpr int NSETS = G::N >> R;
@@ -51,22 +52,23 @@ __device__ __forceinline__ void radix_pass(float2* __restrict__ l2, const float*
     const int r = s & (S - 1);
     const int blk = s / S;
     const int base = blk * (S << R) + r;
+    (void)r;
+    // twiddles of this set: coalesced across the wave (consecutive sets = consecutive floats)
+    float tw[2 * (K - 1)];
+#pragma unroll
+    for (int j = 0; j < 2 * (K - 1); ++j) tw[j] = TW[j * NSETS + s];
     float2 v[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = l2[phys(base + S * k)];
 #pragma unroll
     for (int st = R - 1; st >= 0; --st) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int D = S << st;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         if (k & (1 << st)) continue;
         const int lo = k, hi = k | (1 << st);
-        // c_lo & (D-1) = r + S * (k & ((1<<st)-1))
-        const int m = D - 1 - (r + S * (k & ((1 << st) - 1)));
-        const int t = m * (G::n2 / D);
-        const float a0 = A[t], a1 = A[t + 1];
+        // pair index: stages from the largest distance down, kk = k mod 2^st ascending
+        const int pi = (K - (2 << st)) + (k & ((1 << st) - 1));
+        const float a0 = tw[2 * pi], a1 = tw[2 * pi + 1];
         // Mdct.cs:324-329: k00 = e[ee0]-e[ee2] (odd slot), k01 = e[ee0-1]-e[ee2-1] (even slot)
         const float d1 = v[hi].y - v[lo].y;
         const float d0 = v[hi].x - v[lo].x;
@@ -158,12 +160,12 @@ __device__ __forceinline__ void ld654_pass(float2* __restrict__ l2, const float*
 template <int LD, int REMAIN>
 struct Passes {
   // REMAIN = number of radix-2 stages still to run whose distances are 8<<(REMAIN-1) ... 8
-  static __device__ __forceinline__ void run(float2* l2, const float* A, int lane) {
+  static __device__ __forceinline__ void run(float2* l2, const float* TW, int lane) {
     constexpr int R = REMAIN >= 3 ? 3 : REMAIN;
     constexpr int S = 8 << (REMAIN - R);
-    radix_pass<LD, R, S>(l2, A, lane);
+    radix_pass<LD, R, S>(l2, TW, lane);
     __syncthreads();
-    Passes<LD, REMAIN - R>::run(l2, A, lane);
+    Passes<LD, REMAIN - R>::run(l2, TW + 2 * ((1 << R) - 1) * (Geo<LD>::N >> R), lane);
   }
 };
 template <int LD>
@@ -176,7 +178,7 @@ struct Passes<LD, 0> {
 template <int LD, bool WIN>
 __device__ __forceinline__ void imdct_wave(const float* X, float* out, const float* __restrict__ w,
                                            float* lds, const float* __restrict__ A, const float* __restrict__ B,
-                                           const float* __restrict__ C, int lane) {
+                                           const float* __restrict__ C, const float* __restrict__ TW, int lane) {
   using G = Geo<LD>;
   float2* l2 = reinterpret_cast<float2*>(lds);
 
@@ -198,7 +200,7 @@ __device__ __forceinline__ void imdct_wave(const float* X, float* out, const flo
   __syncthreads();
 
   // radix-2 stages D = N/2 ... 8, three per register pass
-  Passes<LD, LD - 5>::run(l2, A, lane);
+  Passes<LD, LD - 5>::run(l2, TW, lane);
 
   // D = 4, 2, 1
   ld654_pass<LD>(l2, A, lane);
@@ -314,13 +316,14 @@ k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work) {
   const float* A = S.mdct_a[s];
   const float* B = S.mdct_b[s];
   const float* C = S.mdct_c[s];
+  const float* TW = S.mdct_tw[s];
   switch (n) {
-    case 256: imdct_wave<8, true>(x, x, w, lds, A, B, C, lane); break;
-    case 512: imdct_wave<9, true>(x, x, w, lds, A, B, C, lane); break;
-    case 1024: imdct_wave<10, true>(x, x, w, lds, A, B, C, lane); break;
-    case 2048: imdct_wave<11, true>(x, x, w, lds, A, B, C, lane); break;
-    case 4096: imdct_wave<12, true>(x, x, w, lds, A, B, C, lane); break;
-    case 8192: imdct_wave<13, true>(x, x, w, lds, A, B, C, lane); break;
+    case 256: imdct_wave<8, true>(x, x, w, lds, A, B, C, TW, lane); break;
+    case 512: imdct_wave<9, true>(x, x, w, lds, A, B, C, TW, lane); break;
+    case 1024: imdct_wave<10, true>(x, x, w, lds, A, B, C, TW, lane); break;
+    case 2048: imdct_wave<11, true>(x, x, w, lds, A, B, C, TW, lane); break;
+    case 4096: imdct_wave<12, true>(x, x, w, lds, A, B, C, TW, lane); break;
+    case 8192: imdct_wave<13, true>(x, x, w, lds, A, B, C, TW, lane); break;
     default: break;  // 64 / 128: handled by the generic kernel (host never launches this one for them)
   }
 }
@@ -328,17 +331,17 @@ k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work) {
 // Stand-alone batched IMdct.Reverse on the wave path (fine-grained ABI, n >= 256).
 extern "C" __global__ void __launch_bounds__(64)
 k_mdct_reverse_wave(float* __restrict__ buf, int n, long long stride, const float* __restrict__ A,
-                    const float* __restrict__ B, const float* __restrict__ C) {
+                    const float* __restrict__ B, const float* __restrict__ C, const float* __restrict__ TW) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* x = buf + (long long)blockIdx.x * stride;
   const int lane = threadIdx.x;
   switch (n) {
-    case 256: imdct_wave<8, false>(x, x, nullptr, lds, A, B, C, lane); break;
-    case 512: imdct_wave<9, false>(x, x, nullptr, lds, A, B, C, lane); break;
-    case 1024: imdct_wave<10, false>(x, x, nullptr, lds, A, B, C, lane); break;
-    case 2048: imdct_wave<11, false>(x, x, nullptr, lds, A, B, C, lane); break;
-    case 4096: imdct_wave<12, false>(x, x, nullptr, lds, A, B, C, lane); break;
-    case 8192: imdct_wave<13, false>(x, x, nullptr, lds, A, B, C, lane); break;
+    case 256: imdct_wave<8, false>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 512: imdct_wave<9, false>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 1024: imdct_wave<10, false>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 2048: imdct_wave<11, false>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 4096: imdct_wave<12, false>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 8192: imdct_wave<13, false>(x, x, nullptr, lds, A, B, C, TW, lane); break;
     default: break;
   }
 }

@@ -25,7 +25,8 @@ __global__ void k_imdct_window(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
-__global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C);
+__global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
+                                    const float* TW);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
 __global__ void k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
@@ -65,7 +66,7 @@ struct DevBuf {  // growable device allocation
 
 struct MdctDev {
   int n = 0;
-  float *a = nullptr, *b = nullptr, *c = nullptr;
+  float *a = nullptr, *b = nullptr, *c = nullptr, *tw = nullptr;
   uint16_t* br = nullptr;
 };
 
@@ -159,6 +160,7 @@ extern "C" void nvh_ctx_destroy(nvh_ctx* c) {
     (void)hipFree(kv.second.b);
     (void)hipFree(kv.second.c);
     (void)hipFree(kv.second.br);
+    (void)hipFree(kv.second.tw);
   }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -238,6 +240,10 @@ static int get_mdct(nvh_ctx* c, int n, MdctDev** out) {
   HIP_TRY(hipMemcpy(d.b, t.b.data(), t.b.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d.c, t.c.data(), t.c.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d.br, t.bitrev.data(), t.bitrev.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  if (!t.tw.empty()) {
+    HIP_TRY(hipMalloc((void**)&d.tw, t.tw.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(d.tw, t.tw.data(), t.tw.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   auto ins = c->mdct_cache.emplace(n, d);
   *out = &ins.first->second;
   return NVH_OK;
@@ -252,7 +258,7 @@ extern "C" int nvh_mdct_reverse(nvh_ctx* c, int n, int batch, float* d_buf, int6
   if (rc != NVH_OK) return rc;
   if (n >= 256)  // wavefront-per-buffer radix-8 path
     hipLaunchKernelGGL(k_mdct_reverse_wave, dim3((unsigned)batch), dim3(64), wave_lds_bytes(n), c->stream, d_buf, n,
-                       (long long)stride, m->a, m->b, m->c);
+                       (long long)stride, m->a, m->b, m->c, m->tw);
   else  // 64 / 128: generic stage-synchronous kernel (the reference's loops over-count there, quirk B-10)
     hipLaunchKernelGGL(k_mdct_reverse, dim3((unsigned)batch), dim3(256), (size_t)n * sizeof(float), c->stream, d_buf, n,
                        (long long)stride, m->a, m->b, m->c, m->br);
@@ -407,12 +413,13 @@ static int upload_setup(nvh_stream* s) {
   size_t o_win = ab.add(S.windows.data(), S.windows.size() * sizeof(float));
   size_t o_ip = ab.add(ipool.data(), ipool.size() * sizeof(int32_t));
   size_t o_fp = ab.add(fpool.data(), fpool.size() * sizeof(float));
-  size_t o_a[2], o_b[2], o_c[2], o_br[2];
+  size_t o_a[2], o_b[2], o_c[2], o_br[2], o_tw[2];
   for (int w = 0; w < 2; w++) {
     o_a[w] = ab.add(S.mdct[w].a.data(), S.mdct[w].a.size() * sizeof(float));
     o_b[w] = ab.add(S.mdct[w].b.data(), S.mdct[w].b.size() * sizeof(float));
     o_c[w] = ab.add(S.mdct[w].c.data(), S.mdct[w].c.size() * sizeof(float));
     o_br[w] = ab.add(S.mdct[w].bitrev.data(), S.mdct[w].bitrev.size() * sizeof(uint16_t));
+    o_tw[w] = ab.add(S.mdct[w].tw.data(), S.mdct[w].tw.size() * sizeof(float));
   }
 
   int rc = s->arena.reserve(ab.bytes.size());
@@ -438,6 +445,7 @@ static int upload_setup(nvh_stream* s) {
     D.mdct_b[w] = (const float*)(base + o_b[w]);
     D.mdct_c[w] = (const float*)(base + o_c[w]);
     D.mdct_br[w] = (const uint16_t*)(base + o_br[w]);
+    D.mdct_tw[w] = (const float*)(base + o_tw[w]);
   }
   return NVH_OK;
 }
