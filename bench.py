@@ -130,7 +130,7 @@ def main():
 
     if rank == 0:
         # slot 0 is the fused spectrum kernel (residue + coupling + floor) when slot 1 is empty
-        names = ["residue", "spectrum" if km[0] < 2e-3 else "couple_floor", "imdct_window", "ola_emit"]
+        names = ["residue", "spectrum" if km[0] < 2e-3 else "couple_floor", "imdct_ola" if km[3] < 2e-3 else "imdct_window", "ola_emit"]
         dom = max(range(4), key=lambda k: km[k])
         alg_bytes = FRAMES * ch * 4 * BLOCK  # read n/2*4 B spectrum + write n/2*4 B PCM per ch-frame = 4n B
         dom_ms = km[dom]

@@ -348,6 +348,7 @@ void StreamParser::drain(FrameBatch& out) {
       f.ov_frame = -2;
       f.ov_src = prev_start_;
       f.ov_len = cnt;
+      f.ov_n = prev_n_;
       f.emit_start = 0;
       f.emit_count = cnt;
       f.out_pos = out.pcm_samples;
@@ -423,6 +424,7 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
       f.ov_frame = prev_frame_;
       f.ov_src = prev_start_;
       f.ov_len = ov_len;
+      f.ov_n = prev_n_;
       if (start + ov_len > valid) out.sequential_ola = true;  // the overlap reaches this block's own tail
     }
     prev_start_ = start;
@@ -453,6 +455,7 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
   emitted_ += cnt;
   prev_start_ = prev_end_;
   prev_frame_ = idx;
+  prev_n_ = f.n;
   return NVH_OK;
 }
 

@@ -26,6 +26,16 @@
 
 namespace {
 
+// A wavefront's LDS slice is private to it: ordering between its own DS writes and reads only needs the
+// compiler not to reorder them (the hardware executes one wave's DS instructions in order).
+// The fences are scoped to the LDS address space ("local") so that independent global loads (twiddles, window,
+// the next tables) may still be scheduled across them.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // LDS layout: complex point c (float2) lives at float2 slot c + 8*(c>>6): the pad keeps the stride-8 and
 // stride-64 set patterns of the radix passes off each other's banks.
 __device__ __forceinline__ int phys(int c) { return c + ((c >> 6) << 3); }
@@ -164,7 +174,7 @@ struct Passes {
     constexpr int R = REMAIN >= 3 ? 3 : REMAIN;
     constexpr int S = 8 << (REMAIN - R);
     radix_pass<LD, R, S>(l2, TW, lane);
-    __syncthreads();
+    wave_sync();
     Passes<LD, REMAIN - R>::run(l2, TW + 2 * ((1 << R) - 1) * (Geo<LD>::N >> R), lane);
   }
 };
@@ -175,10 +185,13 @@ struct Passes<LD, 0> {
 
 // Full IMDCT of one channel-frame by one wavefront.  X: n/2 spectrum floats (global), out: n floats (global),
 // w: window (n floats) applied on the way out (Mode.cs:160-166).
-template <int LD, bool WIN>
-__device__ __forceinline__ void imdct_wave(const float* X, float* out, const float* __restrict__ w,
-                                           float* lds, const float* __restrict__ A, const float* __restrict__ B,
-                                           const float* __restrict__ C, const float* __restrict__ TW, int lane) {
+// sink(slot, idx, v): receives the 8 float4 output chunks a lane produces per pair index (slot 0..7 is a
+// compile-time constant after unrolling), idx = position of the chunk inside the n-sample block.
+template <int LD, bool WIN, typename Sink>
+__device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __restrict__ w, float* lds,
+                                                const float* __restrict__ A, const float* __restrict__ B,
+                                                const float* __restrict__ C, const float* __restrict__ TW, int lane,
+                                                Sink sink) {
   using G = Geo<LD>;
   float2* l2 = reinterpret_cast<float2*>(lds);
 
@@ -197,14 +210,14 @@ __device__ __forceinline__ void imdct_wave(const float* X, float* out, const flo
     l2[phys(G::N - 1 - j)] = hi;
     l2[phys(j)] = lo;
   }
-  __syncthreads();
+  wave_sync();
 
   // radix-2 stages D = N/2 ... 8, three per register pass
   Passes<LD, LD - 5>::run(l2, TW, lane);
 
   // D = 4, 2, 1
   ld654_pass<LD>(l2, A, lane);
-  __syncthreads();
+  wave_sync();
 
   // steps 4-6 (bit reversal), 7 and 8 fused.  Pair index p covers step-7 iterations 2p and 2p+1, whose
   // results are exactly the inputs of step-8 iterations p and n/16-1-p.
@@ -281,12 +294,256 @@ __device__ __forceinline__ void imdct_wave(const float* X, float* out, const flo
         o2 = make_float4(o2.x * w2.x, o2.y * w2.y, o2.z * w2.z, o2.w * w2.w);
         o3 = make_float4(o3.x * w3.x, o3.y * w3.y, o3.z * w3.z, o3.w * w3.w);
       }
-      *reinterpret_cast<float4*>(out + d0) = o0;
-      *reinterpret_cast<float4*>(out + d1) = o1;
-      *reinterpret_cast<float4*>(out + d2) = o2;
-      *reinterpret_cast<float4*>(out + d3) = o3;
+      sink(4 * h + 0, d0, o0);
+      sink(4 * h + 1, d1, o1);
+      sink(4 * h + 2, d2, o2);
+      sink(4 * h + 3, d3, o3);
     }
   }
+}
+
+// ---- latency-optimised form for n <= 2048 ---------------------------------------------------------------
+// For N <= 512 complex points every pass has at most one set per lane, so the transform is straight-line code
+// per lane.  A wave spends most of its life parked on memory round trips (rocprof: SQ_WAIT_ANY ~63 % of wave
+// cycles in the looped form, each phase fetching its own tables right before use); here every table access
+// whose address depends only on the lane -- step-0 twiddles, the radix-pass twiddles, _c, _b and the window --
+// is issued up front, next to the spectrum load, so that one memory latency covers all of them.
+template <int LD>
+struct PassPlan {  // stages D = N/2 .. 8 are LD-5 radix-2 stages: first pass takes 3 (or all), second the rest
+  static constexpr int TOTAL = LD - 5;
+  static constexpr int R1 = TOTAL >= 3 ? 3 : TOTAL;
+  static constexpr int S1 = 8 << (TOTAL - R1);
+  static constexpr int R2 = TOTAL - R1;  // 0..3 (LD <= 11)
+  static constexpr int S2 = 8;
+  static constexpr int NSETS1 = (1 << (LD - 2)) >> R1;
+  static constexpr int NSETS2 = R2 > 0 ? ((1 << (LD - 2)) >> R2) : 1;
+  static constexpr int TW1 = 2 * ((1 << R1) - 1);
+  static constexpr int TW2 = R2 > 0 ? 2 * ((1 << R2) - 1) : 0;
+};
+
+template <int LD, int R, int S, int NT>
+__device__ __forceinline__ void radix_pass_regs(float2* __restrict__ l2, const float (&tw)[NT], int s, bool on) {
+  using G = Geo<LD>;
+  constexpr int K = 1 << R;
+  if (!on) return;
+  const int r = s & (S - 1);
+  const int blk = s / S;
+  const int base = blk * (S << R) + r;
+  float2 v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = l2[phys(base + S * k)];
+#pragma unroll
+  for (int st = R - 1; st >= 0; --st) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k & (1 << st)) continue;
+      const int lo = k, hi = k | (1 << st);
+      const int pi = (K - (2 << st)) + (k & ((1 << st) - 1));
+      const float a0 = tw[2 * pi], a1 = tw[2 * pi + 1];
+      const float d1 = v[hi].y - v[lo].y;
+      const float d0 = v[hi].x - v[lo].x;
+      v[hi].y = v[hi].y + v[lo].y;
+      v[hi].x = v[hi].x + v[lo].x;
+      v[lo].y = d1 * a0 - d0 * a1;
+      v[lo].x = d0 * a0 + d1 * a1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) l2[phys(base + S * k)] = v[k];
+  (void)G::n;
+}
+
+template <int LD, bool WIN, typename Sink>
+__device__ __forceinline__ void imdct_wave_fast(const float* X, const float* __restrict__ w, float* lds,
+                                                const float* __restrict__ A, const float* __restrict__ B,
+                                                const float* __restrict__ C, const float* __restrict__ TW, int lane,
+                                                Sink sink) {
+  static_assert(LD >= 8 && LD <= 11, "single-set-per-lane form");
+  using G = Geo<LD>;
+  using P = PassPlan<LD>;
+  float2* l2 = reinterpret_cast<float2*>(lds);
+  constexpr int J = (G::n8 + 63) / 64;  // step-0 items per lane
+
+  // ---- every global load whose address is known now ----
+  float4 x[J];
+  float2 a_lo[J], a_hi[J];
+#pragma unroll
+  for (int r = 0; r < J; ++r) {
+    const int j = lane + 64 * r;
+    const int jc = j < G::n8 ? j : G::n8 - 1;
+    x[r] = reinterpret_cast<const float4*>(X)[jc];
+    a_lo[r] = reinterpret_cast<const float2*>(A)[jc];
+    a_hi[r] = reinterpret_cast<const float2*>(A)[G::n4 - 1 - jc];
+  }
+  float tw1[P::TW1];
+  const int s1 = lane < P::NSETS1 ? lane : P::NSETS1 - 1;
+#pragma unroll
+  for (int j = 0; j < P::TW1; ++j) tw1[j] = TW[j * P::NSETS1 + s1];
+  float tw2[P::TW2 > 0 ? P::TW2 : 1];
+  const int s2 = lane < P::NSETS2 ? lane : P::NSETS2 - 1;
+  if (P::R2 > 0) {
+    const float* TW2p = TW + P::TW1 * P::NSETS1;
+#pragma unroll
+    for (int j = 0; j < P::TW2; ++j) tw2[j] = TW2p[j * P::NSETS2 + s2];
+  }
+  // ---- step 0 (Mdct.cs:74-97) ----
+#pragma unroll
+  for (int r = 0; r < J; ++r) {
+    const int j = lane + 64 * r;
+    if (j < G::n8) {
+      float2 hi, lo;
+      hi.y = (x[r].x * a_lo[r].x - x[r].z * a_lo[r].y);
+      hi.x = (x[r].x * a_lo[r].y + x[r].z * a_lo[r].x);
+      lo.y = (-x[r].w * a_hi[r].x - -x[r].y * a_hi[r].y);
+      lo.x = (-x[r].w * a_hi[r].y + -x[r].y * a_hi[r].x);
+      l2[phys(G::N - 1 - j)] = hi;
+      l2[phys(j)] = lo;
+    }
+  }
+  // second wave of table loads: one phase of lead time is enough, and the step-0 registers are free now
+  const float A2 = A[G::n >> 3];
+  const bool pon = lane < (G::n >> 5);
+  const int p = pon ? lane : (G::n >> 5) - 1;
+  const float4 cc0 = reinterpret_cast<const float4*>(C)[2 * p];
+  const float4 cc1 = reinterpret_cast<const float4*>(C)[2 * p + 1];
+  const int i8a = p, i8b = (G::n >> 4) - 1 - p;
+  const int ba = G::n2 - 8 - 8 * i8a, bb = G::n2 - 8 - 8 * i8b;
+  const float4 ba_lo = *reinterpret_cast<const float4*>(B + ba), ba_hi = *reinterpret_cast<const float4*>(B + ba + 4);
+  const float4 bb_lo = *reinterpret_cast<const float4*>(B + bb), bb_hi = *reinterpret_cast<const float4*>(B + bb + 4);
+  const int da[4] = {4 * i8a, G::n2 - 4 - 4 * i8a, G::n2 + 4 * i8a, G::n - 4 - 4 * i8a};
+  const int db[4] = {4 * i8b, G::n2 - 4 - 4 * i8b, G::n2 + 4 * i8b, G::n - 4 - 4 * i8b};
+  wave_sync();
+  radix_pass_regs<LD, P::R1, P::S1>(l2, tw1, s1, lane < P::NSETS1);
+  float4 wa[4], wb[4];
+  if (WIN) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wa[q] = *reinterpret_cast<const float4*>(w + da[q]);
+      wb[q] = *reinterpret_cast<const float4*>(w + db[q]);
+    }
+  }
+
+  wave_sync();
+  if (P::R2 > 0) {
+    radix_pass_regs<LD, (P::R2 > 0 ? P::R2 : 1), P::S2>(l2, tw2, s2, lane < P::NSETS2);
+    wave_sync();
+  }
+
+  // ---- D = 4, 2, 1 (Mdct.cs:463-535) ----
+  if (lane < (G::N >> 3)) {
+    const int q = lane;
+    const int c0 = G::N - 8 - 8 * q;
+    float e[16];
+    float4* p4 = reinterpret_cast<float4*>(l2 + phys(c0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 t = p4[j];
+      e[4 * j] = t.x; e[4 * j + 1] = t.y; e[4 * j + 2] = t.z; e[4 * j + 3] = t.w;
+    }
+#define U(k) e[15 - (k)]
+    float k00, k11;
+    k00 = U(0) - U(8);  k11 = U(1) - U(9);
+    U(0) = U(0) + U(8); U(1) = U(1) + U(9);
+    U(8) = k00;         U(9) = k11;
+    k00 = U(2) - U(10); k11 = U(3) - U(11);
+    U(2) = U(2) + U(10); U(3) = U(3) + U(11);
+    U(10) = (k00 + k11) * A2; U(11) = (k11 - k00) * A2;
+    k00 = U(12) - U(4); k11 = U(5) - U(13);
+    U(4) = U(4) + U(12); U(5) = U(5) + U(13);
+    U(12) = k11;        U(13) = k00;
+    k00 = U(14) - U(6); k11 = U(7) - U(15);
+    U(6) = U(6) + U(14); U(7) = U(7) + U(15);
+    U(14) = (k00 + k11) * A2; U(15) = (k00 - k11) * A2;
+#undef U
+    iter_54_regs(e, 15);
+    iter_54_regs(e, 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p4[j] = make_float4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+  }
+  wave_sync();
+
+  // ---- steps 4-6 (bit reversal), 7, 8 (Mdct.cs:189-312) ----
+  if (pon) {
+    const float* lf = lds;
+    float vd[8], ve[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = 2 * p + h;
+      const int ir = (G::n >> 4) - 1 - i;
+      const int kE0 = (int)(__brev((unsigned)(2 * i)) >> (32 - (LD - 3))) << 2;
+      const int kE1 = (int)(__brev((unsigned)(2 * i + 1)) >> (32 - (LD - 3))) << 2;
+      const int kD0 = (int)(__brev((unsigned)(2 * ir)) >> (32 - (LD - 3))) << 2;
+      const int kD1 = (int)(__brev((unsigned)(2 * ir + 1)) >> (32 - (LD - 3))) << 2;
+      const float2 e0 = *reinterpret_cast<const float2*>(lf + 2 * phys(kE0 >> 1));
+      const float2 e1 = *reinterpret_cast<const float2*>(lf + 2 * phys(kE1 >> 1));
+      const float2 g0 = *reinterpret_cast<const float2*>(lf + 2 * phys((kD0 >> 1) + 1));
+      const float2 g1 = *reinterpret_cast<const float2*>(lf + 2 * phys((kD1 >> 1) + 1));
+      float vD0 = g1.y, vD1 = g1.x, vD2 = g0.y, vD3 = g0.x;
+      float vE0 = e1.y, vE1 = e1.x, vE2 = e0.y, vE3 = e0.x;
+      const float4 cc = h == 0 ? cc0 : cc1;
+      float a02, a11, b0, b1, b2, b3;
+      a02 = vD0 - vE2;
+      a11 = vD1 + vE3;
+      b0 = cc.y * a02 + cc.x * a11;
+      b1 = cc.y * a11 - cc.x * a02;
+      b2 = vD0 + vE2;
+      b3 = vD1 - vE3;
+      const float nD0 = b2 + b0, nD1 = b3 + b1, nE2 = b2 - b0, nE3 = b1 - b3;
+      a02 = vD2 - vE0;
+      a11 = vD3 + vE1;
+      b0 = cc.w * a02 + cc.z * a11;
+      b1 = cc.w * a11 - cc.z * a02;
+      b2 = vD2 + vE0;
+      b3 = vD3 - vE1;
+      const float nD2 = b2 + b0, nD3 = b3 + b1, nE0 = b2 - b0, nE1 = b1 - b3;
+      vd[4 * h] = nD0; vd[4 * h + 1] = nD1; vd[4 * h + 2] = nD2; vd[4 * h + 3] = nD3;
+      ve[4 * (1 - h)] = nE0; ve[4 * (1 - h) + 1] = nE1; ve[4 * (1 - h) + 2] = nE2; ve[4 * (1 - h) + 3] = nE3;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* vv = h == 0 ? ve : vd;
+      const float4 b_lo = h == 0 ? ba_lo : bb_lo;
+      const float4 b_hi = h == 0 ? ba_hi : bb_hi;
+      float p0, p1, p2, p3;
+      float4 o0, o1, o2, o3;
+      p3 = vv[6] * b_hi.w - vv[7] * b_hi.z;
+      p2 = -vv[6] * b_hi.z - vv[7] * b_hi.w;
+      o0.x = p3; o1.w = -p3; o2.x = p2; o3.w = p2;
+      p1 = vv[4] * b_hi.y - vv[5] * b_hi.x;
+      p0 = -vv[4] * b_hi.x - vv[5] * b_hi.y;
+      o0.y = p1; o1.z = -p1; o2.y = p0; o3.z = p0;
+      p3 = vv[2] * b_lo.w - vv[3] * b_lo.z;
+      p2 = -vv[2] * b_lo.z - vv[3] * b_lo.w;
+      o0.z = p3; o1.y = -p3; o2.z = p2; o3.y = p2;
+      p1 = vv[0] * b_lo.y - vv[1] * b_lo.x;
+      p0 = -vv[0] * b_lo.x - vv[1] * b_lo.y;
+      o0.w = p1; o1.x = -p1; o2.w = p0; o3.x = p0;
+      if (WIN) {
+        const float4 w0 = h == 0 ? wa[0] : wb[0], w1 = h == 0 ? wa[1] : wb[1];
+        const float4 w2 = h == 0 ? wa[2] : wb[2], w3 = h == 0 ? wa[3] : wb[3];
+        o0 = make_float4(o0.x * w0.x, o0.y * w0.y, o0.z * w0.z, o0.w * w0.w);
+        o1 = make_float4(o1.x * w1.x, o1.y * w1.y, o1.z * w1.z, o1.w * w1.w);
+        o2 = make_float4(o2.x * w2.x, o2.y * w2.y, o2.z * w2.z, o2.w * w2.w);
+        o3 = make_float4(o3.x * w3.x, o3.y * w3.y, o3.z * w3.z, o3.w * w3.w);
+      }
+      const int* dd = h == 0 ? da : db;
+      sink(4 * h + 0, dd[0], o0);
+      sink(4 * h + 1, dd[1], o1);
+      sink(4 * h + 2, dd[2], o2);
+      sink(4 * h + 3, dd[3], o3);
+    }
+  }
+}
+
+// In-place form: out may alias X (all of X is consumed by step 0 before anything is stored).
+template <int LD, bool WIN>
+__device__ __forceinline__ void imdct_wave(const float* X, float* out, const float* __restrict__ w, float* lds,
+                                           const float* __restrict__ A, const float* __restrict__ B,
+                                           const float* __restrict__ C, const float* __restrict__ TW, int lane) {
+  if constexpr (LD <= 11)
+    imdct_wave_fast<LD, WIN>(X, w, lds, A, B, C, TW, lane, [=](int, int idx, float4 v) { *reinterpret_cast<float4*>(out + idx) = v; });
+  else
+    imdct_wave_sink<LD, WIN>(X, w, lds, A, B, C, TW, lane, [=](int, int idx, float4 v) { *reinterpret_cast<float4*>(out + idx) = v; });
 }
 
 }  // namespace
@@ -344,4 +601,242 @@ k_mdct_reverse_wave(float* __restrict__ buf, int n, long long stride, const floa
     case 8192: imdct_wave<13, false>(x, x, nullptr, lds, A, B, C, TW, lane); break;
     default: break;
   }
+}
+
+// ================================================================================================
+// Fused IMDCT + window + overlap-add + interleave + clip  (block sizes 256 .. 2048, up to 4 channels)
+// ================================================================================================
+//
+//   IMdct.Reverse + window          Mdct.cs:65-313, Mode.cs:160-166
+//   OverlapBuffers                  StreamDecoder.cs:532-541
+//   ClippingCopyBuffer / CopyBuffer StreamDecoder.cs:391-415, Utils.cs:30-43
+//
+// One workgroup = one RUN of consecutive frames, one wavefront per channel.  A wave walks its channel through
+// the run keeping the previous block's windowed second half (the only part a later frame can overlap with) in
+// its LDS slice, so the windowed blocks never travel through HBM: the kernel reads n/2 spectrum floats and
+// writes (valid - start) PCM floats per channel-frame -- exactly the algorithmic traffic of SURVEY 8d -- plus
+// one recomputed "halo" frame per run (the frame before the run's first, needed for its tail; the same trick
+// as the reference's one-packet pre-roll after a seek, StreamDecoder.cs:602-623).
+// Interleaving: each wave stages its channel's emitted samples planar in LDS (its IMDCT scratch is free by
+// then), the workgroup then writes [t][c] with 16-byte stores.
+//
+// Host-checked preconditions (nvh_api.hip, otherwise the unfused kernels run): every overlap lands inside the
+// first half of its block and comes from the second half of the previous one; block sizes 256..2048.
+
+namespace {
+
+template <int LD>
+__device__ __forceinline__ void block_chunks(const NvhDevSetup& S, const NvhFrame& fr, bool exec, const float* X, float* buf,
+                                             int lane, float4 (&ov)[8], int (&oi)[8]) {
+  using G = Geo<LD>;
+  const float* __restrict__ w = S.windows + fr.window_off;
+  const int sl = fr.mdct_slot;
+  if (exec) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) oi[k] = -1;
+    imdct_wave_fast<LD, true>(X, w, buf, S.mdct_a[sl], S.mdct_b[sl], S.mdct_c[sl], S.mdct_tw[sl], lane,
+                              [&](int slot, int idx, float4 v) { ov[slot] = v; oi[slot] = idx; });
+  } else {
+    // Mapping.cs:192-196 + Mode.cs:160-166: front half keeps the residue, back half is cleared, all windowed
+    const int p = lane;
+    const bool on = p < (G::n >> 5);
+    const int i8[2] = {p, (G::n >> 4) - 1 - p};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int d[4] = {4 * i8[h], G::n2 - 4 - 4 * i8[h], G::n2 + 4 * i8[h], G::n - 4 - 4 * i8[h]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        oi[4 * h + q] = on ? d[q] : -1;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on && d[q] < G::n2) x = *reinterpret_cast<const float4*>(X + d[q]);
+        float4 ww = on ? *reinterpret_cast<const float4*>(w + d[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ov[4 * h + q] = make_float4(x.x * ww.x, x.y * ww.y, x.z * ww.z, x.w * ww.w);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float clip1(float v, int& clipped) {  // Utils.cs:30-43
+  if (v > .99999994f) { clipped = 1; return 0.99999994f; }
+  if (v < -.99999994f) { clipped = 1; return -0.99999994f; }
+  return v;
+}
+
+}  // namespace
+
+namespace {
+
+// One frame of one channel inside a run: block synthesis, overlap-add with the tail left by the previous
+// frame, new tail, staging + interleaved emission.  emit == false: halo frame (only its tail is produced).
+// Kept out of line per block size so that the kernel's register allocation is that of one instance, not
+// the union of all of them.
+template <int LD>
+__device__ __attribute__((noinline)) int ola_frame(const NvhDevSetup& S, const NvhDevBatch& Bt, int f, bool emit,
+                                                   const float* __restrict__ work, float* __restrict__ carry_out,
+                                                   float* __restrict__ pcm, int clip, int last_decoded, float* lds,
+                                                   int stride, int BUF) {
+  const int nch = S.channels;
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x, nthr = nch * 64;
+  float* buf = lds + c * stride;
+  float* tail = buf + BUF;
+  const NvhFrame fr = Bt.frames[f];
+  const bool exec = Bt.chans[fr.chan_off + c].exec != 0;
+  const float* X = work + ((long long)f * nch + c) * S.block1;
+  int clipped = 0;
+  float4 ov[8];
+  int oi[8];
+  block_chunks<LD>(S, fr, exec, X, buf, lane, ov, oi);
+  const int h2 = fr.n >> 1;
+  if (!emit) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (oi[k] >= h2) *reinterpret_cast<float4*>(tail + (oi[k] - h2)) = ov[k];
+    wave_sync();
+    return 0;
+  }
+  float* out = pcm + fr.out_pos * nch;
+  // phase 1: OverlapBuffers -- next[start + j] += previous[prevStart + j]; reads the old tail only
+  if (fr.ov_len > 0) {
+    const int toff = fr.ov_src - (fr.ov_n >> 1) - fr.start;  // tail index = idx + toff
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = oi[k];
+      if (idx < 0 || idx >= h2) continue;
+      const int j = idx - fr.start;
+      if (j >= 0 && j + 3 < fr.ov_len && (toff & 3) == 0) {
+        const float4 t4 = *reinterpret_cast<const float4*>(tail + idx + toff);
+        ov[k].x = ov[k].x + t4.x; ov[k].y = ov[k].y + t4.y; ov[k].z = ov[k].z + t4.z; ov[k].w = ov[k].w + t4.w;
+      } else if (j + 3 >= 0 && j < fr.ov_len) {
+        if (j >= 0 && j < fr.ov_len) ov[k].x = ov[k].x + tail[idx + toff];
+        if (j + 1 >= 0 && j + 1 < fr.ov_len) ov[k].y = ov[k].y + tail[idx + 1 + toff];
+        if (j + 2 >= 0 && j + 2 < fr.ov_len) ov[k].z = ov[k].z + tail[idx + 2 + toff];
+        if (j + 3 >= 0 && j + 3 < fr.ov_len) ov[k].w = ov[k].w + tail[idx + 3 + toff];
+      }
+    }
+  }
+  wave_sync();
+  // phase 2: new tail, staging of the emitted range (or direct stores when it does not fit the scratch)
+  const bool direct = fr.emit_count > BUF;
+  const bool aligned = ((fr.emit_start | fr.emit_count) & 3) == 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = oi[k];
+    if (idx < 0) continue;
+    if (idx >= h2) {
+      *reinterpret_cast<float4*>(tail + (idx - h2)) = ov[k];
+      if (f == last_decoded) *reinterpret_cast<float4*>(carry_out + (long long)c * S.block1 + idx) = ov[k];
+    }
+    const int t = idx - fr.emit_start;
+    if (t + 3 < 0 || t >= fr.emit_count) continue;
+    const float e4[4] = {ov[k].x, ov[k].y, ov[k].z, ov[k].w};
+    if (!direct && aligned && t >= 0 && t + 3 < fr.emit_count) {
+      *reinterpret_cast<float4*>(buf + t) = ov[k];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int te = t + e;
+        if (te < 0 || te >= fr.emit_count) continue;
+        if (direct) {
+          float v = e4[e];
+          if (clip) v = clip1(v, clipped);
+          out[(long long)te * nch + c] = v;
+        } else {
+          buf[te] = e4[e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // interleave + clip: [t][c], 16-byte stores when the geometry allows
+  if (!direct) {
+    const bool vec = aligned && ((fr.out_pos * nch) & 3) == 0;
+    if (vec && nch == 2) {
+      const float* s0 = lds;
+      const float* s1 = lds + stride;
+      for (int g = tid; g < (fr.emit_count >> 2); g += nthr) {
+        float4 a = reinterpret_cast<const float4*>(s0)[g], b = reinterpret_cast<const float4*>(s1)[g];
+        if (clip) {
+          a.x = clip1(a.x, clipped); a.y = clip1(a.y, clipped); a.z = clip1(a.z, clipped); a.w = clip1(a.w, clipped);
+          b.x = clip1(b.x, clipped); b.y = clip1(b.y, clipped); b.z = clip1(b.z, clipped); b.w = clip1(b.w, clipped);
+        }
+        reinterpret_cast<float4*>(out)[2 * g] = make_float4(a.x, b.x, a.y, b.y);
+        reinterpret_cast<float4*>(out)[2 * g + 1] = make_float4(a.z, b.z, a.w, b.w);
+      }
+    } else if (vec && nch == 1) {
+      for (int g = tid; g < (fr.emit_count >> 2); g += nthr) {
+        float4 a = reinterpret_cast<const float4*>(lds)[g];
+        if (clip) { a.x = clip1(a.x, clipped); a.y = clip1(a.y, clipped); a.z = clip1(a.z, clipped); a.w = clip1(a.w, clipped); }
+        reinterpret_cast<float4*>(out)[g] = a;
+      }
+    } else {
+      for (int o = tid; o < fr.emit_count * nch; o += nthr) {
+        int t = o / nch, cc = o - t * nch;
+        float v = lds[cc * stride + t];
+        if (clip) v = clip1(v, clipped);
+        out[o] = v;
+      }
+    }
+  }
+  __syncthreads();
+  return clipped;
+}
+
+__device__ __forceinline__ int ola_frame_any(int n, const NvhDevSetup& S, const NvhDevBatch& Bt, int f, bool emit,
+                                             const float* work, float* carry_out, float* pcm, int clip, int last_decoded,
+                                             float* lds, int stride, int BUF) {
+  switch (n) {
+    case 256: return ola_frame<8>(S, Bt, f, emit, work, carry_out, pcm, clip, last_decoded, lds, stride, BUF);
+    case 512: return ola_frame<9>(S, Bt, f, emit, work, carry_out, pcm, clip, last_decoded, lds, stride, BUF);
+    case 1024: return ola_frame<10>(S, Bt, f, emit, work, carry_out, pcm, clip, last_decoded, lds, stride, BUF);
+    default: return ola_frame<11>(S, Bt, f, emit, work, carry_out, pcm, clip, last_decoded, lds, stride, BUF);
+  }
+}
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(256)
+k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const float* __restrict__ carry_in,
+            float* __restrict__ carry_out, float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag, int run_len,
+            int last_decoded) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nch = S.channels;
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x, nthr = nch * 64;
+  const int BUF = 2 * ((S.block1 >> 2) + (S.block1 >> 5));  // Geo<>::LDS_FLOATS of the largest block
+  const int stride = BUF + (S.block1 >> 1);
+  float* tail = lds + c * stride + BUF;  // previous block's windowed second half
+  const int f0 = blockIdx.x * run_len;
+  const int f1 = (f0 + run_len) < Bt.nframes ? (f0 + run_len) : Bt.nframes;
+  int clipped = 0;
+
+  // ---- tail of the frame before the run ----
+  {
+    const NvhFrame fr0 = Bt.frames[f0];
+    if (fr0.n != 0 && fr0.ov_len > 0) {
+      if (fr0.ov_frame == -2) {
+        const float* src = carry_in + (long long)c * S.block1 + (fr0.ov_n >> 1);
+        for (int j = lane; j < (fr0.ov_n >> 3); j += 64) reinterpret_cast<float4*>(tail)[j] = reinterpret_cast<const float4*>(src)[j];
+        wave_sync();
+      } else if (fr0.ov_frame >= 0) {
+        ola_frame_any(fr0.ov_n, S, Bt, fr0.ov_frame, false, work, carry_out, pcm, clip, last_decoded, lds, stride, BUF);
+      }
+    }
+  }
+
+  for (int f = f0; f < f1; ++f) {
+    const int n = Bt.frames[f].n;
+    if (n == 0) {
+      // drained carried tail (StreamDecoder.cs:352-356): emitted as it is
+      const NvhFrame fr = Bt.frames[f];
+      float* out = pcm + fr.out_pos * nch;
+      for (int o = tid; o < fr.emit_count * nch; o += nthr) {
+        int t = o / nch, cc = o - t * nch;
+        float v = carry_in[(long long)cc * S.block1 + fr.ov_src + t];
+        if (clip) v = clip1(v, clipped);
+        out[o] = v;
+      }
+      continue;
+    }
+    clipped |= ola_frame_any(n, S, Bt, f, true, work, carry_out, pcm, clip, last_decoded, lds, stride, BUF);
+  }
+  if (clipped) atomicOr(clipped_flag, 1);
 }

@@ -36,6 +36,14 @@ __device__ __forceinline__ int sp_render_point(int x0, int y0, int x1, int y1, i
   return dy < 0 ? y0 - off : y0 + off;
 }
 
+// A wavefront's floor scratch block is private to it (wave w prepares channel c0 + w): LDS ordering inside the
+// wave only needs the compiler to keep program order.
+__device__ __forceinline__ void sp_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct FloorScratch {
   int fy[NVH_MAX_POSTS];
   int step[NVH_MAX_POSTS];
@@ -111,6 +119,45 @@ __device__ __forceinline__ void residue_apply_fast(const NvhDevBook bk, const fl
   *p = *p + vq[bk.tab_off + e * dims + comp];
 }
 
+// Everything lane i of a wavefront needs to unwrap post i of its channel: fetched with independent loads so that
+// one memory latency covers the lot (static post geometry from the setup, the raw post value from the batch).
+struct FloorLane {
+  int mode;  // 0 skip, 1 floor1 curve, 2 clear, 3 floor0
+  int pc, levels, level, lo, hi, x, x_lo, x_hi, val, sorted, x_sorted, range, mult;
+};
+
+__device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const NvhDevBatch& Bt, const NvhChan* chans, int c,
+                                                     int nch, int lane) {
+  FloorLane L;
+  L.mode = 0; L.pc = 0; L.levels = 0; L.level = 0; L.lo = 0; L.hi = 1; L.x = 0; L.x_lo = 0; L.x_hi = 1; L.val = 0;
+  L.sorted = 0; L.x_sorted = 0; L.range = 0; L.mult = 0;
+  if (c >= nch) return L;
+  const NvhChan chn = chans[c];
+  const NvhDevFloor* fl = &S.floors[chn.floor];
+  if (chn.exec) {
+    if (fl->type == 1) L.mode = chn.post_count > 0 ? 1 : 2;
+    else L.mode = chn.amp > 0.0f ? 3 : 2;
+  }
+  if (L.mode != 1) return L;
+  const NvhDevFloor1* F = &fl->f1;
+  L.pc = chn.post_count;
+  L.levels = F->levels;
+  L.range = F->range;
+  L.mult = F->multiplier;
+  if (lane < L.pc) {
+    L.lo = F->l_neigh[lane];
+    L.hi = F->h_neigh[lane];
+    L.level = F->level[lane];
+    L.x = F->x_list[lane];
+    L.val = Bt.posts[chn.data_off + lane];
+    L.sorted = F->sort_idx[lane];
+    L.x_lo = F->x_list[L.lo];
+    L.x_hi = F->x_list[L.hi];
+    L.x_sorted = F->x_list[L.sorted];
+  }
+  return L;
+}
+
 }  // namespace
 
 // LDS map (dynamic, 4-byte words): [ s_db 256 | s_coeff 256 | FloorScratch x SP_GROUP | books nbooks*4 |
@@ -136,6 +183,11 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   const int tid = threadIdx.x;
   const int nch = S.channels;
   const NvhChan* chans = Bt.chans + fr.chan_off;
+
+  // floor lane data of the first channel group: independent of the residue, so fetch it now and let the
+  // latency hide behind the residue and coupling phases
+  const int wv = tid >> 6, lane = tid & 63;
+  const FloorLane first_lane = load_floor_lane(S, Bt, chans, wv, nch, lane);
 
   // ---- stage the frame's side information (one coalesced burst) and clear the spectrum ----
   const bool staged = (int)fr.op_count <= cap_ops && (int)fr.ent_count <= cap_ent;
@@ -217,66 +269,30 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   }
 
   // ---- floors, SP_GROUP channels at a time: wavefront w prepares channel c0 + w ----
-  const int wv = tid >> 6, lane = tid & 63;
   for (int c0 = 0; (phase_mask & 4) && c0 < nch; c0 += SP_GROUP) {
-    const int c = c0 + wv;
-    const bool mine = c < nch;
-    NvhChan chn;
-    chn.exec = 0; chn.floor = 0; chn.post_count = 0; chn.pad = 0; chn.data_off = 0; chn.amp = 0.0f;
-    const NvhDevFloor* fl = nullptr;
-    int mode = 0, levels = 0;
-    if (mine) {
-      chn = chans[c];
-      fl = &S.floors[chn.floor];
-      if (chn.exec) {
-        if (fl->type == 1) mode = chn.post_count > 0 ? 1 : 2;
-        else mode = chn.amp > 0.0f ? 3 : 2;
-      }
-      if (mode == 1) levels = fl->f1.levels;
-      if (lane == 0) fs[wv].mode = mode;
-    }
-    // the level loop is block-uniform: take the deepest floor of the group
-    int max_levels = 0;
-    for (int k = 0; k < SP_GROUP && c0 + k < nch; ++k) {
-      const NvhChan ck = chans[c0 + k];
-      const NvhDevFloor* fk = &S.floors[ck.floor];
-      if (ck.exec && fk->type == 1 && ck.post_count > 0 && fk->f1.levels > max_levels) max_levels = fk->f1.levels;
-    }
-
-    // UnwrapPosts (Floor1.cs:224-297).  Lane i owns post i.  Everything that does not depend on another post's
-    // final Y is fetched here, before the level loop, so that the loop only touches LDS.
-    const NvhDevFloor1* F = (mode == 1) ? &fl->f1 : nullptr;
-    const int pc = (mode == 1) ? chn.post_count : 0;
-    int my_lo = 0, my_hi = 1, my_level = 0, my_x = 0, x_lo = 0, x_hi = 1, my_val = 0, my_sorted = 0, x_sorted = 0;
-    int f_range = 0, f_mult = 0;
+    FloorLane fl_lane = (c0 == 0) ? first_lane : load_floor_lane(S, Bt, chans, c0 + wv, nch, lane);
+    const int mode = fl_lane.mode;
+    const int pc = fl_lane.pc;
+    if (lane == 0) fs[wv].mode = mode;
+    // UnwrapPosts (Floor1.cs:224-297).  Lane i owns post i; posts of one dependency level are independent, and the
+    // scratch block belongs to this wavefront alone, so the levels are separated by wave-local ordering only.
     if (lane < pc) {
-      my_lo = F->l_neigh[lane];
-      my_hi = F->h_neigh[lane];
-      my_level = F->level[lane];
-      my_x = F->x_list[lane];
-      my_val = Bt.posts[chn.data_off + lane];
-      my_sorted = F->sort_idx[lane];
-      f_range = F->range;
-      f_mult = F->multiplier;
-      x_lo = F->x_list[my_lo];
-      x_hi = F->x_list[my_hi];
-      x_sorted = F->x_list[my_sorted];
-      fs[wv].fy[lane] = (lane < 2) ? my_val : 0;
+      fs[wv].fy[lane] = (lane < 2) ? fl_lane.val : 0;
       fs[wv].step[lane] = (lane < 2) ? 1 : 0;
     }
-    __syncthreads();
-    for (int lv = 1; lv < max_levels; ++lv) {
-      if (lane >= 2 && lane < pc && lv < levels && my_level == lv) {
-        int predicted = sp_render_point(x_lo, fs[wv].fy[my_lo], x_hi, fs[wv].fy[my_hi], my_x);
-        int val = my_val;
-        int highroom = f_range - predicted;
+    sp_wave_sync();
+    for (int lv = 1; lv < fl_lane.levels; ++lv) {
+      if (lane >= 2 && lane < pc && fl_lane.level == lv) {
+        int predicted = sp_render_point(fl_lane.x_lo, fs[wv].fy[fl_lane.lo], fl_lane.x_hi, fs[wv].fy[fl_lane.hi], fl_lane.x);
+        int val = fl_lane.val;
+        int highroom = fl_lane.range - predicted;
         int lowroom = predicted;
         int room = (highroom < lowroom) ? highroom * 2 : lowroom * 2;
         int fy;
         if (val != 0) {
           // stepFlags are only ever set for lower-indexed posts, never cleared afterwards: order-free
-          fs[wv].step[my_lo] = 1;
-          fs[wv].step[my_hi] = 1;
+          fs[wv].step[fl_lane.lo] = 1;
+          fs[wv].step[fl_lane.hi] = 1;
           fs[wv].step[lane] = 1;
           if (val >= room) {
             if (highroom > lowroom) fy = val - lowroom + predicted;
@@ -290,8 +306,9 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         }
         fs[wv].fy[lane] = fy;
       }
-      __syncthreads();
+      sp_wave_sync();
     }
+    const int my_sorted = fl_lane.sorted, x_sorted = fl_lane.x_sorted, f_mult = fl_lane.mult;
     // Apply's walk over the sorted posts (Floor1.cs:196-216): compact the flagged posts in X order
     if (mode == 1) {
       bool active = (lane < pc) && fs[wv].step[my_sorted] != 0;
@@ -306,13 +323,12 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       int nact = __popcll(mask);
       int ns;
       if (beyond) {
-        int first_lane = __ffsll((long long)beyond) - 1;
-        ns = __popcll(mask & ((1ull << first_lane) - 1ull));
+        int fl0 = __ffsll((long long)beyond) - 1;
+        ns = __popcll(mask & ((1ull << fl0) - 1ull));
       } else {
         ns = nact;  // trailing flat run to n/2 (Floor1.cs:213-216)
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+      sp_wave_sync();
       if (lane == 0) {
         if (!beyond) {
           fs[wv].x[ns] = half;
@@ -320,8 +336,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         }
         fs[wv].nseg = ns;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+      sp_wave_sync();
       // per-segment line parameters (Floor1.cs:316-326): one lane per segment
       if (lane < ns) {
         int x0 = fs[wv].x[lane], y0 = fs[wv].y[lane];

@@ -25,6 +25,8 @@ __global__ void k_imdct_window(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
+__global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
+                            int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
                                     const float* TW);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
@@ -92,6 +94,7 @@ struct nvh_batch {
   bool sequential_ola = false;
   int last_decoded = -1;  // last frame with n != 0 (its block becomes the next carried tail)
   int max_ops = 0, max_ent = 0;  // largest per-frame op / entry slice (LDS staging capacity of k_spectrum)
+  bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
   bool has_carry_in = false;
 };
 
@@ -102,8 +105,8 @@ struct nvh_stream {
   nvh::FrameBatch pending;
   DevBuf arena;  // setup tables
   NvhDevSetup dev{};
-  DevBuf carry;  // [ch][block1] windowed block of the last decoded frame
-  bool carry_valid = false;
+  DevBuf carry[2];  // [ch][block1] windowed block of the last decoded frame (ping-pong: read one, write the other)
+  int carry_cur = 0;
   DevBuf flags;  // int[2]: device error word, clipped flag
   DevBuf pcm;    // staging for host-destination synth
   int clip = 1;
@@ -479,8 +482,10 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
   rc = upload_setup(s.get());
   if (rc != NVH_OK) return rc;
   size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
-  if ((rc = s->carry.reserve(plane)) != NVH_OK) return rc;
-  HIP_TRY(hipMemset(s->carry.p, 0, plane));
+  for (int k = 0; k < 2; k++) {
+    if ((rc = s->carry[k].reserve(plane)) != NVH_OK) return rc;
+    HIP_TRY(hipMemset(s->carry[k].p, 0, plane));
+  }
   if ((rc = s->flags.reserve(2 * sizeof(int))) != NVH_OK) return rc;
   HIP_TRY(hipMemset(s->flags.p, 0, 2 * sizeof(int)));
   s->scratch.s = s.get();
@@ -575,6 +580,23 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
     if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
     if ((int)fr.ent_count > b->max_ent) b->max_ent = (int)fr.ent_count;
   }
+  {
+    // preconditions of the fused IMDCT + overlap-add kernel (kernels_imdct.hip, k_imdct_ola)
+    bool ok = !P.sequential_ola && s->setup.block0 >= 256 && s->setup.block1 <= 2048 && s->setup.channels <= 4;
+    for (size_t i = 0; ok && i < P.frames.size(); i++) {
+      const NvhFrame& fr = P.frames[i];
+      if (fr.n == 0) {
+        ok = fr.ov_frame == -2;
+        continue;
+      }
+      if (fr.ov_len > 0) {
+        const bool src_ok = fr.ov_frame == -2 || (fr.ov_frame == (int)i - 1 && P.frames[i - 1].n != 0);
+        ok = src_ok && fr.start + fr.ov_len <= fr.n / 2 && fr.ov_src >= fr.ov_n / 2 && fr.ov_src + fr.ov_len <= fr.ov_n &&
+             fr.ov_n >= 256 && fr.ov_n <= 2048;
+      }
+    }
+    b->fused_ola = ok;
+  }
   for (int i = b->nframes - 1; i >= 0; --i)
     if (P.frames[(size_t)i].n != 0) {
       b->last_decoded = i;
@@ -621,7 +643,7 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   return NVH_OK;
 }
 
-static int batch_launch(nvh_batch* b, const float* carry, float* d_pcm, bool timing, float* kernel_ms) {
+static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms) {
   nvh_stream* s = b->s;
   hipStream_t st = s->ctx->stream;
   if (b->nframes == 0) return NVH_OK;
@@ -661,17 +683,35 @@ static int batch_launch(nvh_batch* b, const float* carry, float* d_pcm, bool tim
     }
   }
   if (timing) HIP_TRY(hipEventRecord(ev[2], st));
-  if (s->setup.block0 >= 256)
-    hipLaunchKernelGGL(k_imdct_wave, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
-                       b->dev, work);
-  else
-    hipLaunchKernelGGL(k_imdct_window, dim3((unsigned)(b->nframes * ch)), dim3(256), lds, st, s->dev, b->dev, work);
-  if (timing) HIP_TRY(hipEventRecord(ev[3], st));
-  if (!b->sequential_ola)
-    hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
-                       d_pcm, s->clip, flags + 1);
-  else
-    hipLaunchKernelGGL(k_ola_emit_seq, dim3(1), dim3(256), 0, st, s->dev, b->dev, work, carry, d_pcm, s->clip, flags + 1);
+  static const int run_len_env = getenv("NVH_RUN_LEN") ? atoi(getenv("NVH_RUN_LEN")) : 0;
+  static const int no_fused_ola = getenv("NVH_NO_FUSED_OLA") ? 1 : 0;
+  const size_t plane_bytes = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
+  if (b->fused_ola && !no_fused_ola) {
+    // one workgroup per run of frames, one wavefront per channel; keep >= ~2048 waves in flight
+    int run_len = run_len_env > 0 ? run_len_env : 4;
+    while (run_len > 1 && (long long)(b->nframes / run_len) * ch < 2048) run_len >>= 1;
+    const int runs = (b->nframes + run_len - 1) / run_len;
+    const size_t ola_lds = (size_t)ch * (wave_lds_bytes(s->setup.block1) + (size_t)(s->setup.block1 / 2) * sizeof(float));
+    hipLaunchKernelGGL(k_imdct_ola, dim3((unsigned)runs), dim3((unsigned)(64 * ch)), ola_lds, st, s->dev, b->dev, (const float*)work,
+                       carry, carry_out, d_pcm, s->clip, flags + 1, run_len, b->last_decoded);
+    if (timing) HIP_TRY(hipEventRecord(ev[3], st));  // slot 2 = fused IMDCT+OLA, slot 3 empty
+  } else {
+    if (s->setup.block0 >= 256)
+      hipLaunchKernelGGL(k_imdct_wave, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
+                         b->dev, work);
+    else
+      hipLaunchKernelGGL(k_imdct_window, dim3((unsigned)(b->nframes * ch)), dim3(256), lds, st, s->dev, b->dev, work);
+    if (timing) HIP_TRY(hipEventRecord(ev[3], st));
+    if (!b->sequential_ola)
+      hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
+                         d_pcm, s->clip, flags + 1);
+    else
+      hipLaunchKernelGGL(k_ola_emit_seq, dim3(1), dim3(256), 0, st, s->dev, b->dev, work, carry, d_pcm, s->clip, flags + 1);
+    // the last decoded block becomes the carried tail (StreamDecoder's _prevPacketBuf)
+    if (b->last_decoded >= 0 && carry_out)
+      HIP_TRY(hipMemcpyAsync(carry_out, (const uint8_t*)b->work.p + (size_t)b->last_decoded * plane_bytes, plane_bytes,
+                             hipMemcpyDeviceToDevice, st));
+  }
   if (timing) HIP_TRY(hipEventRecord(ev[4], st));
   HIP_TRY(hipGetLastError());
   if (timing) {
@@ -716,16 +756,10 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
     if ((rc = s->pcm.reserve((size_t)(need > 0 ? need : 1) * sizeof(float))) != NVH_OK) return rc;
     dst = (float*)s->pcm.p;
   }
-  rc = batch_launch(b, (const float*)s->carry.p, dst, false, nullptr);
+  rc = batch_launch(b, (const float*)s->carry[s->carry_cur].p, (float*)s->carry[s->carry_cur ^ 1].p, dst, false, nullptr);
   if (rc != NVH_OK) return rc;
   hipStream_t st = s->ctx->stream;
-  // carry the last decoded block to the next batch (StreamDecoder's _prevPacketBuf)
-  if (b->last_decoded >= 0) {
-    size_t plane = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(s->carry.p, (const uint8_t*)b->work.p + (size_t)b->last_decoded * plane, plane,
-                           hipMemcpyDeviceToDevice, st));
-    s->carry_valid = true;
-  }
+  if (b->last_decoded >= 0) s->carry_cur ^= 1;  // the batch wrote its last block's tail into the other buffer
   if (pcm_host && need > 0) HIP_TRY(hipMemcpyAsync(pcm_host, dst, (size_t)need * sizeof(float), hipMemcpyDeviceToHost, st));
   rc = collect_flags(s);  // synchronises the stream
   if (rc != NVH_OK) return rc;
@@ -744,7 +778,7 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
   size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
   int rc = b->carry_in.reserve(plane);
   if (rc != NVH_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(b->carry_in.p, s->carry.p, plane, hipMemcpyDeviceToDevice, s->ctx->stream));
+  HIP_TRY(hipMemcpyAsync(b->carry_in.p, s->carry[s->carry_cur].p, plane, hipMemcpyDeviceToDevice, s->ctx->stream));
   b->has_carry_in = true;
   rc = batch_upload(s, b.get());
   if (rc != NVH_OK) return rc;
@@ -774,15 +808,8 @@ extern "C" int nvh_batch_synth(nvh_batch* b, float* d_pcm, int64_t capacity) {
   if (capacity < b->pcm_samples * s->setup.channels) return NVH_ERR_ARGUMENT;
   if (b->pcm_samples > 0 && !d_pcm) return NVH_ERR_ARGUMENT;
   HIP_TRY(hipSetDevice(s->ctx->device));
-  int rc = batch_launch(b, (const float*)b->carry_in.p, d_pcm, false, nullptr);
-  if (rc != NVH_OK) return rc;
-  // the stream keeps the tail of the newest batch
-  if (b->last_decoded >= 0) {
-    size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(s->carry.p, (const uint8_t*)b->work.p + (size_t)b->last_decoded * plane, plane,
-                           hipMemcpyDeviceToDevice, s->ctx->stream));
-  }
-  return NVH_OK;
+  // the stream keeps the tail of the newest batch (written to its current carry buffer; the batch reads its own snapshot)
+  return batch_launch(b, (const float*)b->carry_in.p, (float*)s->carry[s->carry_cur].p, d_pcm, false, nullptr);
 }
 
 extern "C" int nvh_batch_time(nvh_batch* b, float* d_pcm, int64_t capacity, int iters, float* total_ms,
@@ -795,7 +822,7 @@ extern "C" int nvh_batch_time(nvh_batch* b, float* d_pcm, int64_t capacity, int 
   float km[4] = {0, 0, 0, 0};
   if (kernel_ms) {
     for (int i = 0; i < iters; i++) {
-      int rc = batch_launch(b, (const float*)b->carry_in.p, d_pcm, true, km);
+      int rc = batch_launch(b, (const float*)b->carry_in.p, (float*)s->carry[s->carry_cur].p, d_pcm, true, km);
       if (rc != NVH_OK) return rc;
     }
     for (int k = 0; k < 4; k++) kernel_ms[k] = km[k] / (float)iters;
@@ -806,7 +833,7 @@ extern "C" int nvh_batch_time(nvh_batch* b, float* d_pcm, int64_t capacity, int 
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; i++) {
-      int rc = batch_launch(b, (const float*)b->carry_in.p, d_pcm, false, nullptr);
+      int rc = batch_launch(b, (const float*)b->carry_in.p, (float*)s->carry[s->carry_cur].p, d_pcm, false, nullptr);
       if (rc != NVH_OK) return rc;
     }
     HIP_TRY(hipEventRecord(e1, st));

@@ -113,5 +113,5 @@ struct NvhFrame {
   uint32_t pass_begin, pass_end;  // residue passes of this frame (one per submap)
   uint32_t op_begin, op_count;    // this frame's slice of the op list (contiguous, stage-major)
   uint32_t ent_begin, ent_count;  // this frame's slice of the entry stream (contiguous)
-  uint32_t pad;
+  int32_t ov_n;                   // block size of the frame the overlapped tail comes from (0 if none)
 };
