@@ -321,7 +321,10 @@ int StreamParser::parse_audio(BitReader& p, FrameBatch& out, int* decoded) {
       out.passes.push_back(pass);
     }
   }
-  for (int c = 0; c < nch; c++) out.chans[f.chan_off + (size_t)c].exec = exec(c) ? 1 : 0;
+  for (int c = 0; c < nch; c++) {
+    out.chans[f.chan_off + (size_t)c].exec = exec(c) ? 1 : 0;
+    if (c < 32 && exec(c)) f.exec_mask |= 1u << c;
+  }
   f.pass_end = (uint32_t)out.passes.size();
   f.op_count = (uint32_t)out.ops.size() - f.op_begin;
   f.ent_count = (uint32_t)out.entries.size() - f.ent_begin;
@@ -349,11 +352,19 @@ void StreamParser::drain(FrameBatch& out) {
       f.ov_src = prev_start_;
       f.ov_len = cnt;
       f.ov_n = prev_n_;
+      f.ov_window_off = prev_window_off_;
       f.emit_start = 0;
       f.emit_count = cnt;
       f.out_pos = out.pcm_samples;
       f.chan_off = (uint32_t)out.chans.size();
       f.pass_begin = f.pass_end = (uint32_t)out.passes.size();
+      for (size_t c = 0; c < (size_t)s_->channels; c++) {
+        NvhChan ch;
+        std::memset(&ch, 0, sizeof ch);
+        ch.ov_exec = c < prev_exec_.size() ? prev_exec_[c] : 0;
+        if (c < 32 && ch.ov_exec) f.ov_exec_mask |= 1u << c;
+        out.chans.push_back(ch);  // the pseudo-frame carries the source frame's exec flags in its own channel records
+      }
       out.frames.push_back(f);
     }
     out.pcm_samples += cnt;
@@ -425,6 +436,11 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
       f.ov_src = prev_start_;
       f.ov_len = ov_len;
       f.ov_n = prev_n_;
+      f.ov_window_off = prev_window_off_;
+      for (size_t c = 0; c < prev_exec_.size() && c < (size_t)s_->channels; c++) {
+        out.chans[f.chan_off + c].ov_exec = prev_exec_[c];
+        if (c < 32 && prev_exec_[c]) f.ov_exec_mask |= 1u << c;
+      }
       if (start + ov_len > valid) out.sequential_ola = true;  // the overlap reaches this block's own tail
     }
     prev_start_ = start;
@@ -456,6 +472,9 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
   prev_start_ = prev_end_;
   prev_frame_ = idx;
   prev_n_ = f.n;
+  prev_window_off_ = f.window_off;
+  prev_exec_.resize((size_t)s_->channels);
+  for (int c = 0; c < s_->channels; c++) prev_exec_[(size_t)c] = out.chans[f.chan_off + (size_t)c].exec;
   return NVH_OK;
 }
 

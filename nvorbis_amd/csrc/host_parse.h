@@ -67,6 +67,8 @@ class StreamParser {
   int prev_start_ = 0, prev_end_ = 0, prev_stop_ = 0;
   int prev_frame_ = -1;         // index of the previous decoded frame in the current batch, -2 = carried
   int prev_n_ = 0;              // block size of the previous decoded frame
+  uint32_t prev_window_off_ = 0;
+  std::vector<uint8_t> prev_exec_;  // per channel, of the previous decoded frame
   bool has_position_ = false, eos_found_ = false;
   int64_t position_ = 0;        // _currentPosition + bufferedSamples
   int64_t emitted_ = 0;         // total samples emitted since open (per channel)

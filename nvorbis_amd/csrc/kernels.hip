@@ -632,3 +632,156 @@ k_ola_emit_seq(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, const fl
   }
   if (clipped) atomicOr(clipped_flag, 1);
 }
+
+
+// ================================================================================================
+// Overlap-add + interleave + clip from the COMPACT block layout written by k_imdct_compact
+// ================================================================================================
+//
+// plane[0, n/4) = y[0, n/4) and plane[n/2, 3n/4) = y[n/2, 3n/4) of the un-windowed IMDCT output y; the rest follows
+// from y[n/2-1-x] = -y[x] and y[n-1-x] = y[n/2+x] (Mdct.cs:275-303).  A channel that did not execute keeps its
+// residue in plane[0, n/2) and has a zero tail (Mapping.cs:192-196).  The window multiply of Mode.cs:160-166
+// happens here, on both operands of the overlap add, as separately rounded products.
+__device__ __forceinline__ float compact_value(const float* __restrict__ plane, const float* __restrict__ w, int n,
+                                               int exec, int idx) {
+  const int n2 = n >> 1, n4 = n >> 2;
+  float y;
+  if (exec) {
+    if (idx < n4) y = plane[idx];
+    else if (idx < n2) y = -plane[n2 - 1 - idx];
+    else if (idx < n2 + n4) y = plane[idx];
+    else y = plane[n + n2 - 1 - idx];
+  } else {
+    y = idx < n2 ? plane[idx] : 0.0f;
+  }
+  return y * w[idx];
+}
+
+// Four consecutive block positions idx0 .. idx0+3 (idx0 a multiple of 4: a group never straddles a quarter).
+__device__ __forceinline__ float4 compact_value4(const float* __restrict__ plane, const float* __restrict__ w, int n,
+                                                 int exec, int idx0) {
+  const int n2 = n >> 1, n4 = n >> 2;
+  float4 y;
+  if (exec) {
+    if (idx0 < n4 || (idx0 >= n2 && idx0 < n2 + n4)) {
+      y = *reinterpret_cast<const float4*>(plane + idx0);
+    } else if (idx0 < n2) {
+      const float4 r = *reinterpret_cast<const float4*>(plane + (n2 - 4 - idx0));
+      y = make_float4(-r.w, -r.z, -r.y, -r.x);
+    } else {
+      const float4 r = *reinterpret_cast<const float4*>(plane + (n + n2 - 4 - idx0));
+      y = make_float4(r.w, r.z, r.y, r.x);
+    }
+  } else {
+    y = idx0 < n2 ? *reinterpret_cast<const float4*>(plane + idx0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float4 ww = *reinterpret_cast<const float4*>(w + idx0);
+  return make_float4(y.x * ww.x, y.y * ww.y, y.z * ww.z, y.w * ww.w);
+}
+
+#ifndef NVH_OLA_THREADS
+#define NVH_OLA_THREADS 64
+#endif
+extern "C" __global__ void __launch_bounds__(NVH_OLA_THREADS)
+k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const float* __restrict__ carry,
+              float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag, float* __restrict__ carry_out, int last_decoded) {
+  const int f = blockIdx.x;
+  const NvhFrame fr = Bt.frames[f];
+  const int ch = S.channels;
+  if (f == last_decoded && carry_out) {
+    // this block becomes the carried tail of the next batch (StreamDecoder's _prevPacketBuf), stored fully windowed
+    const float* __restrict__ wl = S.windows + fr.window_off;
+    for (int o = threadIdx.x; o < (fr.n >> 2) * ch; o += NVH_OLA_THREADS) {
+      int c = o / (fr.n >> 2), g = o - c * (fr.n >> 2);
+      const float* plane = work + ((long long)f * ch + c) * S.block1;
+      *reinterpret_cast<float4*>(carry_out + (long long)c * S.block1 + 4 * g) =
+          compact_value4(plane, wl, fr.n, Bt.chans[fr.chan_off + c].exec, 4 * g);
+    }
+  }
+  const int total = fr.emit_count * ch;
+  if (total <= 0) return;
+  const float* cur = work + (long long)f * ch * S.block1;
+  const float* prev = nullptr;
+  if (fr.ov_len > 0) prev = (fr.ov_frame == -2) ? carry : (fr.ov_frame >= 0 ? work + (long long)fr.ov_frame * ch * S.block1 : nullptr);
+  const float* __restrict__ w = S.windows + fr.window_off;
+  const float* __restrict__ wp = S.windows + fr.ov_window_off;
+  const NvhChan* chans = Bt.chans + fr.chan_off;
+  float* out = pcm + fr.out_pos * ch;
+  int clipped = 0;
+  // the carried block (ov_frame == -2) is always stored fully windowed (k_expand_carry); blocks of this batch are compact
+  const bool prev_full = fr.ov_frame == -2;
+
+  // fast path: everything in units of four samples (true for every frame of a well-formed stream except an
+  // EOS-trimmed last one)
+  const bool vec = fr.n != 0 && ch <= 2 && ((fr.emit_start | fr.emit_count | fr.start | fr.ov_src | fr.ov_len) & 3) == 0 &&
+                   ((fr.out_pos * ch) & 3) == 0;
+  if (vec) {
+    const int groups = fr.emit_count >> 2;
+    const int e0 = fr.exec_mask & 1, e1 = (fr.exec_mask >> 1) & 1;  // mirrors of NvhChan::exec / ov_exec: no dependent load
+    const int p0 = fr.ov_exec_mask & 1, p1 = (fr.ov_exec_mask >> 1) & 1;
+    for (int g = threadIdx.x; g < groups; g += NVH_OLA_THREADS) {
+      const int idx0 = fr.emit_start + 4 * g;
+      const int j0 = idx0 - fr.start;
+      const bool ov = prev && j0 >= 0 && j0 < fr.ov_len;  // whole group inside or outside (all multiples of 4)
+      float4 v[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c >= ch) break;
+        v[c] = compact_value4(cur + (long long)c * S.block1, w, fr.n, c == 0 ? e0 : e1, idx0);
+        if (ov) {
+          const float* pp = prev + (long long)c * S.block1;
+          float4 t4 = prev_full ? *reinterpret_cast<const float4*>(pp + fr.ov_src + j0)
+                                : compact_value4(pp, wp, fr.ov_n, c == 0 ? p0 : p1, fr.ov_src + j0);
+          v[c].x = v[c].x + t4.x; v[c].y = v[c].y + t4.y; v[c].z = v[c].z + t4.z; v[c].w = v[c].w + t4.w;
+        }
+        if (clip) {
+          v[c].x = clip_value(v[c].x, &clipped); v[c].y = clip_value(v[c].y, &clipped);
+          v[c].z = clip_value(v[c].z, &clipped); v[c].w = clip_value(v[c].w, &clipped);
+        }
+      }
+      if (ch == 2) {
+        reinterpret_cast<float4*>(out)[2 * g] = make_float4(v[0].x, v[1].x, v[0].y, v[1].y);
+        reinterpret_cast<float4*>(out)[2 * g + 1] = make_float4(v[0].z, v[1].z, v[0].w, v[1].w);
+      } else {
+        reinterpret_cast<float4*>(out)[g] = v[0];
+      }
+    }
+    if (clipped) atomicOr(clipped_flag, 1);
+    return;
+  }
+
+  for (int o = threadIdx.x; o < total; o += NVH_OLA_THREADS) {
+    int t = o / ch, c = o - t * ch;
+    int idx = fr.emit_start + t;
+    const NvhChan cn = chans[c];
+    float v;
+    if (fr.n == 0) {
+      // drained carried tail (StreamDecoder.cs:352-356): the previous block's windowed samples as they are
+      v = prev[(long long)c * S.block1 + fr.ov_src + t];
+    } else {
+      v = compact_value(cur + (long long)c * S.block1, w, fr.n, cn.exec, idx);
+      int j = idx - fr.start;
+      if (prev && j >= 0 && j < fr.ov_len) {  // OverlapBuffers: next[start + j] += previous[prevStart + j]
+        const float* pp = prev + (long long)c * S.block1;
+        v = v + (prev_full ? pp[fr.ov_src + j] : compact_value(pp, wp, fr.ov_n, cn.ov_exec, fr.ov_src + j));
+      }
+    }
+    if (clip) v = clip_value(v, &clipped);
+    out[o] = v;
+  }
+  if (clipped) atomicOr(clipped_flag, 1);
+}
+
+// Expands the compact planes of one frame into the fully windowed block (the carried tail format shared by all
+// overlap kernels).  One workgroup, launched once per batch for its last decoded frame.
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, float* __restrict__ carry_out, int f) {
+  const NvhFrame fr = Bt.frames[f];
+  const int ch = S.channels;
+  const float* __restrict__ w = S.windows + fr.window_off;
+  for (int o = threadIdx.x; o < fr.n * ch; o += NVH_THREADS) {
+    int c = o / fr.n, i = o - c * fr.n;
+    const float* plane = work + ((long long)f * ch + c) * S.block1;
+    carry_out[(long long)c * S.block1 + i] = compact_value(plane, w, fr.n, Bt.chans[fr.chan_off + c].exec, i);
+  }
+}

@@ -536,14 +536,20 @@ __device__ __forceinline__ void imdct_wave_fast(const float* X, const float* __r
 }
 
 // In-place form: out may alias X (all of X is consumed by step 0 before anything is stored).
-template <int LD, bool WIN>
+// COMPACT: store only the two independent quarters of the (un-windowed) result -- out[0, n/4) and
+// out[n/2, 3n/4); the other two follow from out[n/2-1-x] = -out[x] and out[n-1-x] = out[n/2+x] (Mdct.cs:275-303)
+// and are rebuilt, windowed, by k_ola_compact.  Halves the bytes this kernel writes and the next one reads.
+template <int LD, bool WIN, bool COMPACT = false>
 __device__ __forceinline__ void imdct_wave(const float* X, float* out, const float* __restrict__ w, float* lds,
                                            const float* __restrict__ A, const float* __restrict__ B,
                                            const float* __restrict__ C, const float* __restrict__ TW, int lane) {
+  auto sink = [=](int slot, int idx, float4 v) {
+    if (!COMPACT || (slot & 1) == 0) *reinterpret_cast<float4*>(out + idx) = v;
+  };
   if constexpr (LD <= 11)
-    imdct_wave_fast<LD, WIN>(X, w, lds, A, B, C, TW, lane, [=](int, int idx, float4 v) { *reinterpret_cast<float4*>(out + idx) = v; });
+    imdct_wave_fast<LD, WIN>(X, w, lds, A, B, C, TW, lane, sink);
   else
-    imdct_wave_sink<LD, WIN>(X, w, lds, A, B, C, TW, lane, [=](int, int idx, float4 v) { *reinterpret_cast<float4*>(out + idx) = v; });
+    imdct_wave_sink<LD, WIN>(X, w, lds, A, B, C, TW, lane, sink);
 }
 
 }  // namespace
@@ -582,6 +588,40 @@ k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work) {
     case 4096: imdct_wave<12, true>(x, x, w, lds, A, B, C, TW, lane); break;
     case 8192: imdct_wave<13, true>(x, x, w, lds, A, B, C, TW, lane); break;
     default: break;  // 64 / 128: handled by the generic kernel (host never launches this one for them)
+  }
+}
+
+// Compact variant: plane[0, n/4) and plane[n/2, 3n/4) receive the un-windowed independent quarters
+// (see imdct_wave<.., COMPACT>); consumed by k_ola_compact.
+extern "C" __global__ void __launch_bounds__(64)
+k_imdct_compact(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int cf = blockIdx.x;
+  const int f = cf / S.channels, c = cf - f * S.channels;
+  const NvhFrame fr = Bt.frames[f];
+  const int n = fr.n;
+  if (n == 0) return;
+  float* x = work + ((long long)f * S.channels + c) * S.block1;
+  const NvhChan chn = Bt.chans[fr.chan_off + c];
+  const int lane = threadIdx.x;
+  if (!chn.exec) {
+    // the residue stays in [0, n/2) (nothing to exploit; k_ola_compact windows it); its tail quarter is zero
+    for (int i = lane; i < (n >> 2); i += 64) x[(n >> 1) + i] = 0.0f;
+    return;
+  }
+  const int s = fr.mdct_slot;
+  const float* A = S.mdct_a[s];
+  const float* B = S.mdct_b[s];
+  const float* C = S.mdct_c[s];
+  const float* TW = S.mdct_tw[s];
+  switch (n) {
+    case 256: imdct_wave<8, false, true>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 512: imdct_wave<9, false, true>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 1024: imdct_wave<10, false, true>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 2048: imdct_wave<11, false, true>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 4096: imdct_wave<12, false, true>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    case 8192: imdct_wave<13, false, true>(x, x, nullptr, lds, A, B, C, TW, lane); break;
+    default: break;
   }
 }
 

@@ -23,6 +23,10 @@ __global__ void k_mdct_reverse(float* buf, int n, long long stride, const float*
                                const uint16_t* BR);
 __global__ void k_imdct_window(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_imdct_compact(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* work, float* carry_out, int f);
+__global__ void k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
+                              int* clipped_flag, float* carry_out, int last_decoded);
 __global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
 __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
@@ -684,7 +688,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   }
   if (timing) HIP_TRY(hipEventRecord(ev[2], st));
   static const int run_len_env = getenv("NVH_RUN_LEN") ? atoi(getenv("NVH_RUN_LEN")) : 0;
-  static const int no_fused_ola = getenv("NVH_NO_FUSED_OLA") ? 1 : 0;
+  static const int no_fused_ola = getenv("NVH_FUSED_OLA") ? 0 : 1;  // experimental run-based kernel: opt-in
   const size_t plane_bytes = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
   if (b->fused_ola && !no_fused_ola) {
     // one workgroup per run of frames, one wavefront per channel; keep >= ~2048 waves in flight
@@ -696,19 +700,29 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                        carry, carry_out, d_pcm, s->clip, flags + 1, run_len, b->last_decoded);
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));  // slot 2 = fused IMDCT+OLA, slot 3 empty
   } else {
-    if (s->setup.block0 >= 256)
+    // compact hand-over (two independent quarters per block, windowed in the overlap kernel) whenever no overlap
+    // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
+    static const int no_compact = getenv("NVH_NO_COMPACT") ? 1 : 0;
+    const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact;
+    if (compact)
+      hipLaunchKernelGGL(k_imdct_compact, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
+                         b->dev, work);
+    else if (s->setup.block0 >= 256)
       hipLaunchKernelGGL(k_imdct_wave, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
                          b->dev, work);
     else
       hipLaunchKernelGGL(k_imdct_window, dim3((unsigned)(b->nframes * ch)), dim3(256), lds, st, s->dev, b->dev, work);
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));
-    if (!b->sequential_ola)
+    if (compact)
+      hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes), dim3(64), 0, st, s->dev, b->dev, (const float*)work, carry,
+                         d_pcm, s->clip, flags + 1, carry_out, b->last_decoded);
+    else if (!b->sequential_ola)
       hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
                          d_pcm, s->clip, flags + 1);
     else
       hipLaunchKernelGGL(k_ola_emit_seq, dim3(1), dim3(256), 0, st, s->dev, b->dev, work, carry, d_pcm, s->clip, flags + 1);
-    // the last decoded block becomes the carried tail (StreamDecoder's _prevPacketBuf)
-    if (b->last_decoded >= 0 && carry_out)
+    // the last decoded block becomes the carried tail (StreamDecoder's _prevPacketBuf), always fully windowed
+    if (!compact && b->last_decoded >= 0 && carry_out)
       HIP_TRY(hipMemcpyAsync(carry_out, (const uint8_t*)b->work.p + (size_t)b->last_decoded * plane_bytes, plane_bytes,
                              hipMemcpyDeviceToDevice, st));
   }

@@ -90,7 +90,7 @@ struct NvhChan {         // one channel of one frame ("ch-frame")
   uint8_t exec;          // IFloorData.ExecuteChannel after ForceEnergy / ForceNoEnergy (Mapping.cs:104-131)
   uint8_t floor;         // floor index
   uint8_t post_count;    // Floor1: Data.PostCount; Floor0: 1 if Amp > 0
-  uint8_t pad;
+  uint8_t ov_exec;       // exec flag of this channel in the frame the overlapped tail comes from
   uint32_t data_off;     // Floor1: offset of raw posts (uint16) in the post pool;
                          // Floor0: offset of coeff[order+1] (float) in the coeff pool
   float amp;             // Floor0 Data.Amp
@@ -114,4 +114,8 @@ struct NvhFrame {
   uint32_t op_begin, op_count;    // this frame's slice of the op list (contiguous, stage-major)
   uint32_t ent_begin, ent_count;  // this frame's slice of the entry stream (contiguous)
   int32_t ov_n;                   // block size of the frame the overlapped tail comes from (0 if none)
+  uint32_t ov_window_off;         // window of that frame (its tail is stored un-windowed in the compact layout)
+  uint32_t exec_mask;             // bit c = channel c executes (first 32 channels; mirrors NvhChan::exec)
+  uint32_t ov_exec_mask;          // same for the overlap source frame (mirrors NvhChan::ov_exec)
+  uint32_t pad;
 };
