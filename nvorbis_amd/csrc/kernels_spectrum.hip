@@ -92,7 +92,7 @@ __device__ __forceinline__ void residue_apply_lds(const NvhDevBook bk, const flo
 // Residue types 1 and 2 with every division replaced by an exact reciprocal multiply (NvhDevResidue::fast).
 __device__ __forceinline__ void residue_apply_fast(const NvhDevBook bk, const float* __restrict__ vq, const NvhDevResidue& R,
                                                    const NvhResOp op, const uint16_t* __restrict__ ent, unsigned ent_begin, int i,
-                                                   float* spec, int half) {
+                                                   float* spec, int half, int fake = 0) {
   const unsigned dims = bk.dim;
   const unsigned j = dims > 1 ? __umulhi((unsigned)i, bk.dim_magic) : (unsigned)i;
   const unsigned comp = (unsigned)i - j * dims;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void residue_apply_fast(const NvhDevBook bk, const fl
   }
   if (x >= half) return;
   float* p = spec + ch * half + x;
-  *p = *p + vq[bk.tab_off + e * dims + comp];
+  *p = *p + vq[fake ? (comp + (e & 7u)) : (bk.tab_off + e * dims + comp)];  // fake: profiling aid (gather locality ablation)
 }
 
 // Everything lane i of a wavefront needs to unwrap post i of its channel: fetched with independent loads so that
@@ -166,7 +166,7 @@ __device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const
 template <bool FLOOR0>
 __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDevBatch& Bt, float* __restrict__ work,
                                               int* __restrict__ err, int phase_mask, int cap_ops, int cap_ent,
-                                              float* smem) {
+                                              float* smem, long long* dbg = nullptr) {
   float* s_db = smem;
   float* s_coeff = smem + 256;
   FloorScratch* fs = reinterpret_cast<FloorScratch*>(smem + 512);
@@ -177,12 +177,16 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   float* spec = reinterpret_cast<float*>(s_ent) + ((cap_ent + 7) >> 3) * 4;  // [ch][half], 16-byte aligned
 
   const int f = blockIdx.x;
+#define DBG_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 8 + (k)] = clock64(); } while (0)
+  DBG_T(0);
   const NvhFrame fr = Bt.frames[f];
   if (fr.n == 0) return;
   const int half = fr.n >> 1;
   const int tid = threadIdx.x;
   const int nch = S.channels;
   const NvhChan* chans = Bt.chans + fr.chan_off;
+  if (dbg && fr.n == 12345) dbg[0] = 0;
+  DBG_T(1);
 
   // floor lane data of the first channel group: independent of the residue, so fetch it now and let the
   // latency hide behind the residue and coupling phases
@@ -201,6 +205,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   }
   for (int i = tid; i < nch * half; i += SP_THREADS) spec[i] = 0.0f;  // Mapping.cs:108
   __syncthreads();
+  DBG_T(2);
   // both sources are indexed relative to the frame's slice (op.ent_off and pass->op_begin[] are batch offsets)
   const NvhResOp* ops = staged ? s_ops : Bt.ops + fr.op_begin;
   const uint16_t* ent = staged ? s_ent : Bt.entries + fr.ent_begin;
@@ -219,7 +224,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           unsigned o = __umulhi((unsigned)idx, R.psize_magic);
           int i = idx - (int)o * psize;
           const NvhResOp op = ops[ob + o];
-          residue_apply_fast(s_books[op.book], S.vq, R, op, ent, fr.ent_begin, i, spec, half);
+          residue_apply_fast(s_books[op.book], S.vq, R, op, ent, fr.ent_begin, i, spec, half, phase_mask & 8);
         }
         __syncthreads();
       } else if (!R.sequential) {
@@ -245,6 +250,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     }
   }
 
+  DBG_T(3);
   // ---- inverse coupling, last step first (Mapping.cs:137-182) ----
   const NvhDevMapping mp = S.mappings[fr.mapping];
   for (int st = mp.coupling_steps - 1; (phase_mask & 2) && st >= 0; --st) {
@@ -268,6 +274,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     __syncthreads();
   }
 
+  DBG_T(4);
   // ---- floors, SP_GROUP channels at a time: wavefront w prepares channel c0 + w ----
   for (int c0 = 0; (phase_mask & 4) && c0 < nch; c0 += SP_GROUP) {
     FloorLane fl_lane = (c0 == 0) ? first_lane : load_floor_lane(S, Bt, chans, c0 + wv, nch, lane);
@@ -457,6 +464,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     __syncthreads();
   }
 
+  DBG_T(5);
   // ---- spectrum -> work planes ----
   float* planes = work + (long long)f * nch * S.block1;
   const int q4 = half >> 2;
@@ -464,13 +472,14 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     int c = i / q4, k = i - c * q4;
     reinterpret_cast<float4*>(planes + (long long)c * S.block1)[k] = reinterpret_cast<const float4*>(spec + c * half)[k];
   }
+  DBG_T(6);
 }
 
 extern "C" __global__ void __launch_bounds__(SP_THREADS)
 k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int phase_mask, int cap_ops,
-           int cap_ent) {
+           int cap_ent, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<false>(S, Bt, work, err, phase_mask, cap_ops, cap_ent, smem);
+  spectrum_body<false>(S, Bt, work, err, phase_mask, cap_ops, cap_ent, smem, dbg);
 }
 
 // Variant for setups that contain a Floor0 (double-precision cos / sqrt / exp: costs registers, kept apart).

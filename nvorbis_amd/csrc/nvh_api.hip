@@ -27,7 +27,12 @@ __global__ void k_imdct_compact(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* work, float* carry_out, int f);
 __global__ void k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
                               int* clipped_flag, float* carry_out, int last_decoded);
-__global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
+__global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent,
+                           long long* dbg);
+__global__ void k_spectrum2_c1(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
+__global__ void k_spectrum2_c2(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
+__global__ void k_spectrum2_c1_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
+__global__ void k_spectrum2_c2_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
 __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
                             int clip, int* clipped_flag, int run_len, int last_decoded);
@@ -42,6 +47,8 @@ __global__ void k_ola_emit_seq(NvhDevSetup S, NvhDevBatch Bt, float* work, const
 }
 
 static thread_local int g_last_hip_error = 0;
+static void* g_dbg_buf = nullptr;  // profiling aid: per-workgroup phase timestamps of k_spectrum (nvh_debug_set_buffer)
+extern "C" void nvh_debug_set_buffer(void* d_buf) { g_dbg_buf = d_buf; }
 
 #define HIP_TRY(expr)                        \
   do {                                       \
@@ -115,6 +122,9 @@ struct nvh_stream {
   DevBuf pcm;    // staging for host-destination synth
   int clip = 1;
   int has_clipped = 0;
+  bool gather_ok = false;  // stream shape admits k_spectrum2 (kernels_spectrum2.hip)
+  int gather_idx_cap = 0;  // entries of its (stage, partition[, channel]) -> op index
+  bool has_floor0 = false;
   nvh_batch scratch;  // reused by nvh_stream_synth
 };
 
@@ -429,6 +439,26 @@ static int upload_setup(nvh_stream* s) {
     o_tw[w] = ab.add(S.mdct[w].tw.data(), S.mdct[w].tw.size() * sizeof(float));
   }
 
+  {
+    // k_spectrum2 preconditions: 1-2 channels, a single submap per mapping, residues of type 1/2 without aliasing
+    bool ok = S.channels <= 2;
+    for (const auto& m : S.mappings) ok = ok && m.submap_floor.size() == 1;
+    int max_parts = 0;
+    for (size_t i = 0; i < S.residues.size(); i++) {
+      const nvh::Residue& r = S.residues[i];
+      ok = ok && r.type != 0 && residues[i].fast && !residues[i].sequential;
+      const int bs = r.type == 2 ? S.block1 * S.channels : S.block1;
+      const int end = r.end < bs / 2 ? r.end : bs / 2;
+      const int parts = end > r.begin ? (end - r.begin) / r.partition_size : 0;
+      const int mul = r.type == 2 ? 1 : S.channels;
+      if (parts * mul > max_parts) max_parts = parts * mul;
+      if (parts > 0xFFFE) ok = false;
+    }
+    s->has_floor0 = false;
+    for (const auto& fl : S.floors) s->has_floor0 = s->has_floor0 || fl.type == 0;
+    s->gather_ok = ok;
+    s->gather_idx_cap = (NVH_MAX_STAGES * max_parts + 7) & ~7;
+  }
   int rc = s->arena.reserve(ab.bytes.size());
   if (rc != NVH_OK) return rc;
   HIP_TRY(hipMemcpy(s->arena.p, ab.bytes.data(), ab.bytes.size(), hipMemcpyHostToDevice));
@@ -670,16 +700,26 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
       cap_ops = cap_ent = 0;
       words = fixed_words;
     }
-    if (words * 4 <= 64 * 1024) {
-      bool has_floor0 = false;
-      for (const auto& fl : s->setup.floors) has_floor0 = has_floor0 || fl.type == 0;
+    static const int no_gather = getenv("NVH_NO_GATHER") ? 1 : 0;
+    const bool has_floor0 = s->has_floor0;
+    // gather form (kernels_spectrum2.hip): needs the op / entry slices staged (op indices are 16-bit)
+    size_t g_words = (size_t)(has_floor0 ? 512 : 256) + (size_t)ch * (1840 / 4) + (size_t)s->setup.books.size() * 4 +
+                     (size_t)((b->max_ops + 1) & ~1) * 2 + (size_t)((b->max_ent + 7) & ~7) / 2 + (size_t)s->gather_idx_cap / 2 +
+                     (size_t)ch * (size_t)(s->setup.block1 / 8) + (has_floor0 ? (size_t)ch * (size_t)(s->setup.block1 / 2) : 0);
+    if (s->gather_ok && !no_gather && b->max_ops < 0xFFFF && g_words * 4 <= 64 * 1024) {
+      const int g_ops = (b->max_ops + 1) & ~1, g_ent = (b->max_ent + 7) & ~7;
+      if (timing) HIP_TRY(hipEventRecord(ev[1], st));
+      auto kern = ch == 1 ? (has_floor0 ? k_spectrum2_c1_f0 : k_spectrum2_c1) : (has_floor0 ? k_spectrum2_c2_f0 : k_spectrum2_c2);
+      hipLaunchKernelGGL(kern, dim3((unsigned)b->nframes), dim3(128), g_words * 4, st, s->dev, b->dev, work, flags, g_ops, g_ent,
+                         s->gather_idx_cap);
+    } else if (words * 4 <= 64 * 1024) {
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
       if (has_floor0)
         hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            phase_mask, cap_ops, cap_ent);
       else
         hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
-                           phase_mask, cap_ops, cap_ent);
+                           phase_mask, cap_ops, cap_ent, (long long*)g_dbg_buf);
     } else {
       hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work);
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));
