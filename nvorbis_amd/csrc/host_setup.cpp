@@ -199,6 +199,19 @@ int Codebook::init(BitReader& p) {
   std::vector<uint32_t> mult((size_t)std::max(lookup_value_count, 0));
   for (int i = 0; i < lookup_value_count; i++) mult[i] = (uint32_t)p.read(value_bits);
   lookup.assign((size_t)table_len, 0.0f);
+  lattice_values = 0;
+  lattice.clear();
+  if (map_type == 1 && !sequence_p) {
+    // every component is (float)mult[digit] * delta + min, widened to double, + 0.0, narrowed again: only
+    // lookup_value_count distinct results, built here with the very expression of the table loop below
+    lattice_values = lookup_value_count;
+    for (int k = 0; k < lookup_value_count; k++) {
+      float fv = (float)mult[k] * delta_value;
+      fv = fv + min_value;
+      double value = (double)fv + 0.0;
+      lattice.push_back((float)value);
+    }
+  }
   if (map_type == 1) {
     for (int idx = 0; idx < entries; idx++) {
       double last = 0.0;

@@ -27,6 +27,8 @@ struct Codebook {
   int dimensions = 0, entries = 0, map_type = 0;
   std::vector<int> lengths;
   std::vector<float> lookup;      // entries * dimensions (map type != 0)
+  int lattice_values = 0;         // map type 1 without sequence_p: number of distinct component values, else 0
+  std::vector<float> lattice;     // those values: lookup[e*dim+i] == lattice[(e / lattice_values^i) % lattice_values]
   std::vector<HuffNode> prefix;   // 1 << prefix_bits
   std::vector<HuffNode> overflow;
   bool has_overflow = false;      // C# `_overflowList != null`

@@ -9,6 +9,8 @@
 struct NvhDevSetup {
   int32_t channels, block0, block1, nbooks;
   const float* vq;                // VQ lookup tables of every codebook
+  const uint32_t* lattice;        // lattice pool (NvhDevBook::lat_off), lattice_words entries
+  int32_t lattice_words, pad2;
   const NvhDevBook* books;
   const NvhDevFloor* floors;
   const NvhDevResidue* residues;

@@ -90,14 +90,18 @@ __device__ __forceinline__ void residue_apply_lds(const NvhDevBook bk, const flo
 }
 
 // Residue types 1 and 2 with every division replaced by an exact reciprocal multiply (NvhDevResidue::fast).
-__device__ __forceinline__ void residue_apply_fast(const NvhDevBook bk, const float* __restrict__ vq, const NvhDevResidue& R,
-                                                   const NvhResOp op, const uint16_t* __restrict__ ent, unsigned ent_begin, int i,
-                                                   float* spec, int half, int fake = 0) {
+// Split in two so that the caller can have several independent element chains (op -> book -> entry -> value) in
+// flight before it commits the adds: returns the target (nullptr: nothing to add) and the value.
+__device__ __forceinline__ float* residue_fetch_fast(const NvhDevBook* __restrict__ s_books, const float* __restrict__ vq,
+                                                     const NvhDevResidue& R, const NvhResOp op,
+                                                     const uint16_t* __restrict__ ent, unsigned ent_begin, int i, float* spec,
+                                                     int half, const uint32_t* __restrict__ s_lat, float* val) {
+  const NvhDevBook bk = s_books[op.book];
   const unsigned dims = bk.dim;
   const unsigned j = dims > 1 ? __umulhi((unsigned)i, bk.dim_magic) : (unsigned)i;
   const unsigned comp = (unsigned)i - j * dims;
   const unsigned e = ent[op.ent_off - ent_begin + j];
-  if (e == NVH_ENTRY_SKIP) return;
+  if (e == NVH_ENTRY_SKIP) return nullptr;
   const int offset = R.begin + (int)op.partition * R.partition_size;
   int ch, x;
   if (R.type == 1) {
@@ -114,9 +118,17 @@ __device__ __forceinline__ void residue_apply_fast(const NvhDevBook bk, const fl
       x = offset + i;
     }
   }
-  if (x >= half) return;
-  float* p = spec + ch * half + x;
-  *p = *p + vq[fake ? (comp + (e & 7u)) : (bk.tab_off + e * dims + comp)];  // fake: profiling aid (gather locality ablation)
+  if (x >= half) return nullptr;
+  if (bk.lat_values) {
+    // lattice book: component = distinct[(e / lat_values^comp) % lat_values], all in LDS, no table gather
+    const uint32_t pm = s_lat[bk.lat_off + bk.lat_values + comp];
+    const unsigned q = pm ? __umulhi(e, pm) : e;
+    const unsigned digit = bk.lat_values > 1 ? q - __umulhi(q, bk.lat_magic) * bk.lat_values : 0u;
+    *val = __uint_as_float(s_lat[bk.lat_off + digit]);
+  } else {
+    *val = vq[bk.tab_off + e * dims + comp];
+  }
+  return spec + ch * half + x;
 }
 
 // Everything lane i of a wavefront needs to unwrap post i of its channel: fetched with independent loads so that
@@ -160,7 +172,7 @@ __device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const
 
 }  // namespace
 
-// LDS map (dynamic, 4-byte words): [ s_db 256 | s_coeff 256 | FloorScratch x SP_GROUP | books nbooks*4 |
+// LDS map (dynamic, 4-byte words): [ s_db 256 | s_coeff 256 | FloorScratch x SP_GROUP | books nbooks*8 | lattice pool |
 //                                   ops cap_ops*2 | entries cap_ent/2 | spectrum ch*half ]
 // cap_ops / cap_ent == 0: the frame's ops / entries are read from global memory instead (oversized frames).
 template <bool FLOOR0>
@@ -172,12 +184,13 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   FloorScratch* fs = reinterpret_cast<FloorScratch*>(smem + 512);
   static_assert(sizeof(FloorScratch) % 16 == 0, "keep the spectrum 16-byte aligned");
   NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(smem + 512 + SP_GROUP * (sizeof(FloorScratch) / 4));
-  NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(reinterpret_cast<float*>(s_books) + S.nbooks * 4);
+  uint32_t* s_lat = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(s_books) + S.nbooks * 8);
+  NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(s_lat + ((S.lattice_words + 3) & ~3));
   uint16_t* s_ent = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(s_ops) + cap_ops * 2);
   float* spec = reinterpret_cast<float*>(s_ent) + ((cap_ent + 7) >> 3) * 4;  // [ch][half], 16-byte aligned
 
   const int f = blockIdx.x;
-#define DBG_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 8 + (k)] = clock64(); } while (0)
+#define DBG_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + (k)] = clock64(); } while (0)
   DBG_T(0);
   const NvhFrame fr = Bt.frames[f];
   if (fr.n == 0) return;
@@ -197,6 +210,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   const bool staged = (int)fr.op_count <= cap_ops && (int)fr.ent_count <= cap_ent;
   s_db[tid] = k_inverse_db[tid];
   for (int i = tid; i < S.nbooks; i += SP_THREADS) s_books[i] = S.books[i];
+  for (int i = tid; i < S.lattice_words; i += SP_THREADS) s_lat[i] = S.lattice[i];
   if (staged) {
     const uint2* go = reinterpret_cast<const uint2*>(Bt.ops + fr.op_begin);
     for (int i = tid; i < (int)fr.op_count; i += SP_THREADS) reinterpret_cast<uint2*>(s_ops)[i] = go[i];
@@ -212,21 +226,49 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
 
   // ---- residue ----  (phase_mask: profiling aid, all bits set in production)
   for (unsigned ps = fr.pass_begin; (phase_mask & 1) && ps < fr.pass_end; ++ps) {
-    const NvhResPass* pass = &Bt.passes[ps];
-    const NvhDevResidue R = S.residues[pass->residue];
+    // by value: the stage loop below is full of barriers, across which loads through a pointer are not hoisted --
+    // every stage (empty ones included) would pay a scalar-load round trip for its op range
+    const NvhResPass pass = Bt.passes[ps];
+    const NvhDevResidue R = S.residues[pass.residue];
     const int psize = R.partition_size;
+    if (dbg && psize == 123456) dbg[1] = 0;
+    long long t_prev = dbg ? clock64() : 0;
+    if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 7] = t_prev;
+#pragma unroll
     for (int s = 0; s < NVH_MAX_STAGES; ++s) {
-      const unsigned ob = pass->op_begin[s] - fr.op_begin, oe = pass->op_begin[s + 1] - fr.op_begin;
+      const unsigned ob = pass.op_begin[s] - fr.op_begin, oe = pass.op_begin[s + 1] - fr.op_begin;
       if (ob == oe) continue;
       if (!R.sequential && R.fast) {
+        // elements of one stage never alias (that is what !sequential means), so four of them are fetched as
+        // independent dependency chains before their adds are committed
         const int total = (int)(oe - ob) * psize;
-        for (int idx = tid; idx < total; idx += SP_THREADS) {
-          unsigned o = __umulhi((unsigned)idx, R.psize_magic);
-          int i = idx - (int)o * psize;
-          const NvhResOp op = ops[ob + o];
-          residue_apply_fast(s_books[op.book], S.vq, R, op, ent, fr.ent_begin, i, spec, half, phase_mask & 8);
+        for (int base = tid; base < total; base += 4 * SP_THREADS) {
+          float* tp[4];
+          float tv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * SP_THREADS;
+            tp[u] = nullptr;
+            tv[u] = 0.0f;
+            if (idx < total) {
+              unsigned o = __umulhi((unsigned)idx, R.psize_magic);
+              int i = idx - (int)o * psize;
+              tp[u] = residue_fetch_fast(s_books, S.vq, R, ops[ob + o], ent, fr.ent_begin, i, spec, half, s_lat, &tv[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (tp[u]) *tp[u] = *tp[u] + tv[u];
         }
         __syncthreads();
+        if (dbg) {
+          long long t_now = clock64();
+          if (threadIdx.x == 0) {
+            dbg[(long long)blockIdx.x * 24 + 8 + s] = t_now - t_prev;
+            dbg[(long long)blockIdx.x * 24 + 16 + s] = (long long)(oe - ob);
+          }
+          t_prev = t_now;
+        }
       } else if (!R.sequential) {
         const int total = (int)(oe - ob) * psize;
         for (int idx = tid; idx < total; idx += SP_THREADS) {

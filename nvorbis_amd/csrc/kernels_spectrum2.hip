@@ -71,7 +71,7 @@ __device__ __forceinline__ void spectrum2_body(const NvhDevSetup& S, const NvhDe
   S2Floor* fs = reinterpret_cast<S2Floor*>(smem + HEAD);
   static_assert(sizeof(S2Floor) % 16 == 0, "alignment of what follows");
   NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(smem + HEAD + NCH * (sizeof(S2Floor) / 4));
-  NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(reinterpret_cast<float*>(s_books) + S.nbooks * 4);
+  NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(reinterpret_cast<float*>(s_books) + S.nbooks * 8);
   uint16_t* s_ent = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(s_ops) + cap_ops * 2);
   uint16_t* s_idx = s_ent + cap_ent;
   // floor curves: Floor1 keeps the inverse_dB_table index of every bin (one byte), Floor0 a float multiplier

@@ -309,9 +309,48 @@ static int upload_setup(nvh_stream* s) {
   if (S.books.size() > 256) return NVH_ERR_UNSUPPORTED;
 
   std::vector<float> vq;
+  std::vector<uint32_t> lattice;
   std::vector<NvhDevBook> books(S.books.size());
   for (size_t i = 0; i < S.books.size(); i++) {
     const nvh::Codebook& b = S.books[i];
+    books[i].lat_values = 0;
+    books[i].lat_magic = 0;
+    books[i].lat_off = 0;
+    books[i].pad = 0;
+    // lattice fast path: digits via exact reciprocal multiplies (entry < 2^16, powers <= entries)
+    if (b.lattice_values >= 1 && b.dimensions >= 1 && b.dimensions <= 16 && b.entries <= 0xFFFF) {
+      bool ok = true;
+      std::vector<uint32_t> magics;
+      uint64_t pw = 1;
+      for (int d = 0; d < b.dimensions && ok; d++) {
+        if (pw > 0xFFFF) { ok = false; break; }
+        magics.push_back(pw > 1 ? (uint32_t)((0x100000000ull + pw - 1) / pw) : 0u);  // 0: divisor 1
+        pw *= (uint64_t)b.lattice_values;
+      }
+      // self-check against the table the reference algorithm builds
+      for (int e = 0; ok && e < b.entries; e++) {
+        int q = e;
+        for (int d = 0; d < b.dimensions; d++) {
+          uint32_t bits_t, bits_l;
+          float tv = b.lookup[(size_t)e * b.dimensions + d], lv = b.lattice[(size_t)(q % b.lattice_values)];
+          std::memcpy(&bits_t, &tv, 4);
+          std::memcpy(&bits_l, &lv, 4);
+          if (bits_t != bits_l) { ok = false; break; }
+          q /= b.lattice_values;
+        }
+      }
+      if (ok) {
+        books[i].lat_values = (uint32_t)b.lattice_values;
+        books[i].lat_magic = b.lattice_values > 1 ? (uint32_t)((0x100000000ull + (uint64_t)b.lattice_values - 1) / (uint64_t)b.lattice_values) : 0u;
+        books[i].lat_off = (uint32_t)lattice.size();
+        for (float v : b.lattice) {
+          uint32_t bits;
+          std::memcpy(&bits, &v, 4);
+          lattice.push_back(bits);
+        }
+        lattice.insert(lattice.end(), magics.begin(), magics.end());
+      }
+    }
     books[i].entries = (uint32_t)b.entries;
     books[i].dim = (uint32_t)b.dimensions;
     books[i].dim_magic = b.dimensions > 1 ? (uint32_t)((0x100000000ull + (uint64_t)b.dimensions - 1) / (uint64_t)b.dimensions) : 0u;
@@ -418,10 +457,12 @@ static int upload_setup(nvh_stream* s) {
   }
   if (coupling.empty()) coupling.push_back(0);
   if (vq.empty()) vq.push_back(0.0f);
+  if (lattice.empty()) lattice.push_back(0u);
   if (ipool.empty()) ipool.push_back(0);
   if (fpool.empty()) fpool.push_back(0.0f);
 
   size_t o_vq = ab.add(vq.data(), vq.size() * sizeof(float));
+  size_t o_lat = ab.add(lattice.data(), lattice.size() * sizeof(uint32_t));
   size_t o_books = ab.add(books.data(), books.size() * sizeof(NvhDevBook));
   size_t o_floors = ab.add(floors.data(), floors.size() * sizeof(NvhDevFloor));
   size_t o_res = ab.add(residues.data(), residues.size() * sizeof(NvhDevResidue));
@@ -469,6 +510,9 @@ static int upload_setup(nvh_stream* s) {
   D.block1 = S.block1;
   D.nbooks = (int32_t)S.books.size();
   D.vq = (const float*)(base + o_vq);
+  D.lattice = (const uint32_t*)(base + o_lat);
+  D.lattice_words = (int32_t)lattice.size();
+  D.pad2 = 0;
   D.books = (const NvhDevBook*)(base + o_books);
   D.floors = (const NvhDevFloor*)(base + o_floors);
   D.residues = (const NvhDevResidue*)(base + o_res);
@@ -693,17 +737,18 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   // LDS window; LDS map in kernels_spectrum.hip.
   {
     static const int phase_mask = getenv("NVH_DEBUG_SPECTRUM_MASK") ? atoi(getenv("NVH_DEBUG_SPECTRUM_MASK")) : 7;  // profiling aid
-    const size_t fixed_words = 512 + 4 * (1840 / 4) + (size_t)s->setup.books.size() * 4 + (size_t)ch * (size_t)(s->setup.block1 / 2);
+    const size_t fixed_words = 512 + 4 * (1840 / 4) + (size_t)s->setup.books.size() * 8 + (size_t)((s->dev.lattice_words + 3) & ~3) +
+                               (size_t)ch * (size_t)(s->setup.block1 / 2);
     int cap_ops = (b->max_ops + 1) & ~1, cap_ent = (b->max_ent + 7) & ~7;  // keep the spectrum 16-byte aligned
     size_t words = fixed_words + (size_t)cap_ops * 2 + (size_t)cap_ent / 2;
     if (words * 4 > 64 * 1024) {  // oversized frames: leave ops / entries in global memory
       cap_ops = cap_ent = 0;
       words = fixed_words;
     }
-    static const int no_gather = getenv("NVH_NO_GATHER") ? 1 : 0;
+    static const int no_gather = getenv("NVH_GATHER") ? 0 : 1;  // gather-form kernel (kernels_spectrum2.hip): bit-exact but not faster, opt-in
     const bool has_floor0 = s->has_floor0;
     // gather form (kernels_spectrum2.hip): needs the op / entry slices staged (op indices are 16-bit)
-    size_t g_words = (size_t)(has_floor0 ? 512 : 256) + (size_t)ch * (1840 / 4) + (size_t)s->setup.books.size() * 4 +
+    size_t g_words = (size_t)(has_floor0 ? 512 : 256) + (size_t)ch * (1840 / 4) + (size_t)s->setup.books.size() * 8 +
                      (size_t)((b->max_ops + 1) & ~1) * 2 + (size_t)((b->max_ent + 7) & ~7) / 2 + (size_t)s->gather_idx_cap / 2 +
                      (size_t)ch * (size_t)(s->setup.block1 / 8) + (has_floor0 ? (size_t)ch * (size_t)(s->setup.block1 / 2) : 0);
     if (s->gather_ok && !no_gather && b->max_ops < 0xFFFF && g_words * 4 <= 64 * 1024) {

@@ -24,6 +24,13 @@ struct NvhDevBook {      // Codebook lookup table (Codebook.cs:222-283, indexer 
   uint32_t entries;
   uint32_t dim;
   uint32_t dim_magic;    // ceil(2^32 / dim): x / dim == __umulhi(x, dim_magic) for x * dim < 2^32 (0 when dim <= 1)
+  // Lattice books (Codebook.cs:242-260, map type 1 without sequence_p): component i of entry e is one of only
+  // `lat_values` distinct floats, selected by digit (e / lat_values^i) % lat_values.  lat_off points into the
+  // lattice pool: [lat_values floats][dim reciprocal magics of lat_values^i].  lat_values == 0: use the table.
+  uint32_t lat_values;
+  uint32_t lat_magic;    // ceil(2^32 / lat_values)
+  uint32_t lat_off;
+  uint32_t pad;
 };
 
 struct NvhDevFloor1 {    // Floor1.cs:21-25, :93-133

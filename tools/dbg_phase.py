@@ -1,6 +1,5 @@
 import os, sys, ctypes
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-os.environ["NVH_NO_GATHER"] = "1"
 import torch, numpy as np
 import nvorbis_amd as nv, bench
 headers, ll, ch = bench.ll_packets(nv, os.path.join(bench.ROOT, "tests", "golden", "3test.ogg"))
@@ -9,16 +8,20 @@ st.push_packet(ll[0], -1, 0); st.synth_host()
 for i in range(4096): st.push_packet(ll[(i+1) % len(ll)], -1, 0)
 b = st.upload_batch(); print(b.stats())
 pcm = torch.empty(b.samples*ch, dtype=torch.float32, device="cuda")
-dbg = torch.zeros(4096*8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(4096*24, dtype=torch.int64, device="cuda")
 L = nv.lib(); L.nvh_debug_set_buffer.argtypes=[ctypes.c_void_p]; L.nvh_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
 for _ in range(3): b.synth(pcm.data_ptr(), pcm.numel())
 ctx.synchronize(); torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(4096, 8)
+d = dbg.cpu().numpy().reshape(4096, 24)
 t0 = d[:,0].min()
 names = ["frame-load", "stage+zero+barrier", "residue", "coupling", "floor", "writeout"]
 for k in range(6):
     dt = d[:,k+1]-d[:,k]
     print("%-22s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (names[k], dt.mean(), np.median(dt), np.percentile(dt,90)))
+print("residue detail: pass/R load %.0f cycles; per-stage mean cycles (0 = stage empty): %s; frames with stage: %s" % (
+    (d[:,7]-d[:,2]).mean(), [round(float(d[:,8+k][d[:,8+k]>0].mean())) if (d[:,8+k]>0).any() else 0 for k in range(8)],
+    [int((d[:,8+k]>0).sum()) for k in range(8)]))
+print('ops per stage (mean over frames):', [round(float(d[:,16+k].mean()),1) for k in range(8)])
 life = d[:,6]-d[:,0]
 print("WG lifetime mean %.0f p50 %.0f ; kernel span %.0f cycles; start spread p50 %.0f p99 %.0f" % (life.mean(), np.median(life), d[:,6].max()-t0, np.median(d[:,0]-t0), np.percentile(d[:,0]-t0, 99)))
 L.nvh_debug_set_buffer(None)
