@@ -168,3 +168,52 @@ def test_bench_workload_prefix_vs_oracle(oracle, gpu_ctx):
     assert n == ref.size == (600 * 1024 + 1024) * ch
     assert np.array_equal(buf[:n].view(np.uint32), ref.view(np.uint32))
     dec.close()
+
+
+def _decode_gpu(nv, ctx, pk, gr, fl, clip, batch_frames):
+    dec = nv.StreamDecoder(ctx, pk, gr, fl, batch_frames=batch_frames)
+    dec.ClipSamples = clip
+    chunks = []
+    buf = np.zeros(1 << 20, np.float32)
+    buf = buf[: buf.size - buf.size % dec.Channels]
+    while True:
+        n = dec.Read(buf, 0, buf.size)
+        if n == 0:
+            break
+        chunks.append(buf[:n].copy())
+    dec.close()
+    return np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+
+
+@pytest.mark.parametrize("name", ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
+                                  "two_submaps", "equal_blocks_overrun", "mono_8192"])
+@pytest.mark.parametrize("consistent", [True, False])
+def test_synthetic_configs_bit_exact(oracle, gpu_ctx, name, consistent):
+    """Paths no shipped file reaches -- Residue0, Residue1 with coupling, 3 and 6 channels (incl. the Residue2
+    offset quirk B-1 and BASELINE config C4's shape), several submaps (quirk B-3), block sizes 64/128 and 8192,
+    codebook dimensions that do not divide the partition size, inconsistent window flags (sequential overlap
+    path) -- bit-exact against the oracle on random-bit packets."""
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    pk, gr, fl = ss.filtered_stream(oracle, name, 150, 11 + int(consistent), consistent_windows=consistent)
+    for clip in (True, False):
+        ref, info = oracle.decode_packets(pk, gr, fl, clip=clip)
+        for bf in (1024, 13):
+            got = _decode_gpu(nv, gpu_ctx, pk, gr, fl, clip, bf)
+            assert got.size == ref.size, (name, clip, bf)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, clip, bf, float(np.abs(got - ref).max()))
+
+
+def test_floor0_within_tolerance(oracle, gpu_ctx):
+    """Floor0 evaluates cos / sqrt / exp in double precision (Floor0.cs:167,198,201); the GPU uses the device
+    math library, the oracle glibc, so parity is the stated 1e-6 absolute rather than bit-exact."""
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    pk, gr, fl = ss.filtered_stream(oracle, "floor0_stereo", 200, 5)
+    ref, info = oracle.decode_packets(pk, gr, fl, clip=True)
+    got = _decode_gpu(nv, gpu_ctx, pk, gr, fl, True, 64)
+    assert got.size == ref.size
+    assert np.isfinite(got).all()
+    assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) <= 1e-6
+    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    assert exact > 0.99, exact

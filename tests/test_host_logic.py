@@ -149,3 +149,21 @@ def test_parser_fuzz_truncation_and_bitflips_match_oracle(oracle, ogg_bytes):
         assert smp * info["channels"] == pcm.size, trial
         ok = info["trace"][info["trace"][:, 3] == 1]
         assert geo[geo[:, 0] != 0].shape[0] == ok.shape[0]
+
+
+@pytest.mark.parametrize("name", __import__("tests.synth_stream", fromlist=["CONFIG_NAMES"]).CONFIG_NAMES)
+def test_parser_geometry_synthetic_configs(oracle, name):
+    """Floor0, Residue0, 3/6 channels, several submaps, 64..8192 blocks (no shipped file has them): the host
+    parser emits the same frame geometry / sample count as the oracle on random-bit packets."""
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    for consistent in (True, False):
+        pk, gr, fl = ss.filtered_stream(oracle, name, 60, 7, consistent_windows=consistent)
+        geo, smp, pos, err = _parse_all(nv, pk, gr, fl)
+        pcm, info = oracle.decode_packets(pk, gr, fl, trace=True)
+        assert err is None
+        assert smp * info["channels"] == pcm.size
+        ok = info["trace"][info["trace"][:, 3] == 1]
+        dec = geo[geo[:, 0] != 0]
+        assert dec.shape[0] == ok.shape[0]
+        assert np.array_equal(dec[:, 0], ok[:, 4]) and np.array_equal(dec[:, 1], ok[:, 0]) and np.array_equal(dec[:, 3], ok[:, 2])
