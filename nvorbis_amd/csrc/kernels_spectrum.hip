@@ -8,10 +8,16 @@
 // Output: work[frame][ch][0, n/2) = the vector IMdct.Reverse consumes (or, for a channel that does not
 // execute, the raw residue -- quirk B-4).  The IMDCT kernel (kernels_imdct.hip) picks it up from there.
 //
-// The kernel is latency-, not bandwidth-bound (a frame's side information is ~2 KB), so its structure is
-// about short dependency chains: the frame's op list, entry stream and the codebook directory are staged
-// into LDS with one coalesced burst, every lane of the floor unwrap fetches its static post geometry up
-// front, and all index divisions are exact reciprocal multiplies prepared by the host.
+// The kernel moves ~2 KB of side information per frame and is bound by instruction issue, not by HBM: with
+// 7+ workgroups resident per CU the SIMDs' VALU ports are ~80 % busy (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES).
+// Its structure therefore aims at few instructions and a small LDS footprint (occupancy):
+//   * side information (ops, entries, codebook directory, lattice pool, stage ranges) is staged into LDS with
+//     16-byte copies; all index divisions are exact reciprocal multiplies prepared by the host;
+//   * lattice codebooks (every book libvorbis writes) never touch their VQ table: a lane peels two base-
+//     lat_values digits off the entry number and adds two bins ("pair path");
+//   * for mono / stereo Floor1 streams coupling, floor render and the store to the work planes are one pass:
+//     a lane owns 4 consecutive bins of every channel in registers ("fused tail"); the floor posts are unwrapped
+//     by one wavefront per channel while the staging loads are in flight.
 // Bit-exactness: residue adds replay the reference's stage order (one barrier per stage); all float
 // expressions are single operations; -ffp-contract=off.
 #include <hip/hip_runtime.h>
@@ -44,18 +50,30 @@ __device__ __forceinline__ void sp_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// One line segment of a rendered Floor1 curve: from (x, y) towards the next flagged post, drawn up to xend.
+struct FloorSeg {
+  uint32_t x_xend;   // x | xend << 16  (xend = start of the next segment, or n/2 / the first post beyond it)
+  int32_t y;         // curve value at x (post value * multiplier)
+  int32_t b;         // dy / adx                                   (Floor1.cs:316-326)
+  uint32_t ady_adx;  // (|dy| - |b|*adx) | (dy < 0 ? -adx : adx) << 16
+};
+
+// Per-channel floor scratch.  The unwrap state (fy, step) is dead once the flagged posts have been compacted
+// into segments, so both views share the block.
 struct FloorScratch {
-  int fy[NVH_MAX_POSTS];
-  int step[NVH_MAX_POSTS];
-  // line segments k = 0 .. nseg-1: from (x[k], y[k]) towards (x[k+1], y[k+1]), drawn up to min(x[k+1], n/2)
-  int x[NVH_MAX_POSTS + 2];
-  int y[NVH_MAX_POSTS + 2];
-  int b[NVH_MAX_POSTS + 2];     // dy / adx
-  int ady[NVH_MAX_POSTS + 2];   // |dy| - |b|*adx
-  int adx[NVH_MAX_POSTS + 2];   // x1 - x0, negated when dy < 0
+  union {
+    struct {
+      int fy[NVH_MAX_POSTS + 2];
+      int step[NVH_MAX_POSTS + 2];
+    } u;
+    FloorSeg seg[NVH_MAX_POSTS + 2];
+  };
   int nseg;
   int mode;  // 0 = skip, 1 = floor1 curve, 2 = clear (exec without energy), 3 = floor0
+  int pad[2];
 };
+static_assert(sizeof(FloorScratch) % 16 == 0, "keep the LDS map 16-byte aligned");
+static_assert(sizeof(FloorScratch) == NVH_SP_FLOOR_SCRATCH_WORDS * 4, "host-side LDS sizing (nvh_api.hip) follows this");
 
 // General (division-based) form of one residue element, all residue types.
 __device__ __forceinline__ void residue_apply_lds(const NvhDevBook bk, const float* __restrict__ vq, const NvhDevResidue& R,
@@ -170,24 +188,179 @@ __device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const
   return L;
 }
 
+// One wavefront turns the posts of one channel into the segment list of its curve.
+//   UnwrapPosts (Floor1.cs:224-297): lane i owns post i; posts of one dependency level are independent.
+//   Apply's walk over the sorted posts (Floor1.cs:196-216): the flagged posts compacted in X order; the walk
+//   stops at the first end point at or beyond n/2, else a flat run to n/2 closes the curve (:213-216).
+__device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& L, int lane, int half) {
+  const int mode = L.mode, pc = L.pc;
+  if (lane == 0) Q->mode = mode;
+  if (mode != 1) return;  // wave-uniform
+  if (lane < pc) {
+    Q->u.fy[lane] = (lane < 2) ? L.val : 0;
+    Q->u.step[lane] = (lane < 2) ? 1 : 0;
+  }
+  sp_wave_sync();
+  for (int lv = 1; lv < L.levels; ++lv) {
+    if (lane >= 2 && lane < pc && L.level == lv) {
+      int predicted = sp_render_point(L.x_lo, Q->u.fy[L.lo], L.x_hi, Q->u.fy[L.hi], L.x);
+      int val = L.val;
+      int highroom = L.range - predicted;
+      int lowroom = predicted;
+      int room = (highroom < lowroom) ? highroom * 2 : lowroom * 2;
+      int fy;
+      if (val != 0) {
+        // stepFlags are only ever set, never cleared: order-free
+        Q->u.step[L.lo] = 1;
+        Q->u.step[L.hi] = 1;
+        Q->u.step[lane] = 1;
+        if (val >= room) {
+          if (highroom > lowroom) fy = val - lowroom + predicted;
+          else fy = predicted - val + highroom - 1;
+        } else {
+          if ((val % 2) == 1) fy = predicted - ((val + 1) / 2);
+          else fy = predicted + (val / 2);
+        }
+      } else {
+        fy = predicted;
+      }
+      Q->u.fy[lane] = fy;
+    }
+    sp_wave_sync();
+  }
+  // compact the flagged posts in X order; the unwrap state is read into registers before the segment view
+  // (which shares its storage) is written
+  const bool active = (lane < pc) && Q->u.step[L.sorted] != 0;
+  const int ys = (lane < pc) ? Q->u.fy[L.sorted] * L.mult : 0;
+  const unsigned long long mask = __ballot(active);
+  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  const unsigned long long beyond = __ballot(active && rank >= 1 && L.x_sorted >= half);
+  int ns;
+  if (beyond) {
+    const int fl0 = __ffsll((long long)beyond) - 1;
+    ns = __popcll(mask & ((1ull << fl0) - 1ull));
+  } else {
+    ns = __popcll(mask);  // trailing flat run to n/2
+  }
+  sp_wave_sync();
+  if (active) {
+    Q->seg[rank].x_xend = (uint32_t)L.x_sorted;
+    Q->seg[rank].y = ys;
+  }
+  sp_wave_sync();
+  if (lane == 0) {
+    if (!beyond) {
+      Q->seg[ns].x_xend = (uint32_t)half;
+      Q->seg[ns].y = Q->seg[ns - 1].y;
+    }
+    Q->nseg = ns;
+  }
+  sp_wave_sync();
+  int x0 = 0, x1n = 0, y0 = 0, y1 = 0;
+  if (lane < ns) {
+    x0 = (int)Q->seg[lane].x_xend;
+    y0 = Q->seg[lane].y;
+    x1n = (int)Q->seg[lane + 1].x_xend;
+    y1 = Q->seg[lane + 1].y;
+  }
+  sp_wave_sync();  // every lane has read its successor's plain x before the packed form goes in
+  if (lane < ns) {
+    const int x1 = x1n < half ? x1n : half;  // Math.Min(hx, n) (quirk B-6)
+    const int dy = y1 - y0;
+    const int adx = x1 - x0;
+    const int ady = dy < 0 ? -dy : dy;
+    const int b = dy / adx;
+    const int ab = b < 0 ? -b : b;
+    FloorSeg sgm;
+    sgm.x_xend = (uint32_t)x0 | ((uint32_t)x1n << 16);
+    sgm.y = y0;
+    sgm.b = b;
+    sgm.ady_adx = ((uint32_t)(ady - ab * adx) & 0xFFFFu) | ((uint32_t)((dy < 0) ? -adx : adx) << 16);
+    Q->seg[lane] = sgm;
+  }
+}
+
+// Curve values of 4 consecutive bins starting at x0 (a multiple of 4): locate the segment once, restart the
+// reference's error-term recurrence (Floor1.cs:328-340) from its closed form, then step it, hopping segments
+// as they end.  Returns the 4 inverse-dB multipliers.
+__device__ __forceinline__ void floor_walk4(const FloorScratch* Q, const float* __restrict__ s_db, int x0, int* __restrict__ err,
+                                            float m[4]) {
+  const int ns = __builtin_amdgcn_readfirstlane(Q->nseg);
+  int lo = 0, hi = ns - 1;
+  while (lo < hi) {  // last segment whose start is <= x0
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)(Q->seg[mid].x_xend & 0xFFFFu) <= x0) lo = mid; else hi = mid - 1;
+  }
+  int sg = lo;
+  FloorSeg s = Q->seg[sg];
+  int sadx = (int)s.ady_adx >> 16, sady = (int)(s.ady_adx & 0xFFFFu), sb = s.b;
+  int adx = sadx < 0 ? -sadx : sadx, sy = sadx < 0 ? -1 : 1;
+  const int t = x0 - (int)(s.x_xend & 0xFFFFu);
+  const int wq = (sady * t) / adx;
+  int y = s.y + sb * t + sy * wq;
+  int e = -adx + sady * t - adx * wq;  // the reference's `err` after t steps
+  int xend = (int)(s.x_xend >> 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int x = x0 + q;
+    if (x >= xend && sg + 1 < ns) {  // the next segment starts exactly here
+      ++sg;
+      s = Q->seg[sg];
+      sadx = (int)s.ady_adx >> 16; sady = (int)(s.ady_adx & 0xFFFFu); sb = s.b;
+      adx = sadx < 0 ? -sadx : sadx; sy = sadx < 0 ? -1 : 1;
+      y = s.y;
+      e = -adx;
+      xend = (int)(s.x_xend >> 16);
+    }
+    int yy = y;
+    if (yy < 0 || yy > 255) {
+      atomicOr(err, NVH_DEVERR_FLOOR1_Y);  // inverse_dB_table[y] would throw (quirk B-7)
+      yy = yy < 0 ? 0 : 255;
+    }
+    m[q] = s_db[yy];
+    y += sb;  // advance to x+1 inside the segment
+    e += sady;
+    if (e >= 0) {
+      e -= adx;
+      y += sy;
+    }
+  }
+}
+
+__device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150-178
+  const float oldM = M, oldA = A;
+  float newM, newA;
+  if (oldM > 0) {
+    if (oldA > 0) { newM = oldM; newA = oldM - oldA; }
+    else          { newA = oldM; newM = oldM + oldA; }
+  } else {
+    if (oldA > 0) { newM = oldM; newA = oldM + oldA; }
+    else          { newA = oldM; newM = oldM - oldA; }
+  }
+  M = newM;
+  A = newA;
+}
+
 }  // namespace
 
-// LDS map (dynamic, 4-byte words): [ s_db 256 | s_coeff 256 | FloorScratch x SP_GROUP | books nbooks*8 | lattice pool |
-//                                   ops cap_ops*2 | entries cap_ent/2 | spectrum ch*half ]
-// cap_ops / cap_ent == 0: the frame's ops / entries are read from global memory instead (oversized frames).
+// LDS map (dynamic, 4-byte words):
+//   [ s_db 256 | (FLOOR0: s_coeff 256) | FloorScratch x min(channels, SP_GROUP) | stage ranges cap_pass*12 |
+//     books nbooks*8 | lattice pool | ops cap_ops*2 | entries cap_ent/2 | spectrum ch*half ]
 template <bool FLOOR0>
 __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDevBatch& Bt, float* __restrict__ work,
-                                              int* __restrict__ err, int phase_mask, int cap_ops, int cap_ent,
-                                              float* smem, long long* dbg = nullptr) {
+                                              int* __restrict__ err, int cap_pass, int cap_ops, int cap_ent, float* smem,
+                                              long long* dbg = nullptr) {
+  const int nch = S.channels;
+  const int ngrp_lds = nch < SP_GROUP ? nch : SP_GROUP;
   float* s_db = smem;
-  float* s_coeff = smem + 256;
-  FloorScratch* fs = reinterpret_cast<FloorScratch*>(smem + 512);
-  static_assert(sizeof(FloorScratch) % 16 == 0, "keep the spectrum 16-byte aligned");
-  NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(smem + 512 + SP_GROUP * (sizeof(FloorScratch) / 4));
+  float* s_coeff = smem + 256;  // FLOOR0 only
+  FloorScratch* fs = reinterpret_cast<FloorScratch*>(smem + (FLOOR0 ? 512 : 256));
+  uint32_t* s_pass = reinterpret_cast<uint32_t*>(fs + ngrp_lds);  // per pass: residue, op_begin[0..8] (frame relative), pad
+  NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(s_pass + cap_pass * 12);
   uint32_t* s_lat = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(s_books) + S.nbooks * 8);
   NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(s_lat + ((S.lattice_words + 3) & ~3));
   uint16_t* s_ent = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(s_ops) + cap_ops * 2);
-  float* spec = reinterpret_cast<float*>(s_ent) + ((cap_ent + 7) >> 3) * 4;  // [ch][half], 16-byte aligned
+  float* spec = reinterpret_cast<float*>(s_ent) + (cap_ent >> 1);  // [ch][half], 16-byte aligned (cap_ent % 8 == 0)
 
   const int f = blockIdx.x;
 #define DBG_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + (k)] = clock64(); } while (0)
@@ -196,49 +369,123 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   if (fr.n == 0) return;
   const int half = fr.n >> 1;
   const int tid = threadIdx.x;
-  const int nch = S.channels;
   const NvhChan* chans = Bt.chans + fr.chan_off;
-  if (dbg && fr.n == 12345) dbg[0] = 0;
+  const NvhDevMapping mp = S.mappings[fr.mapping];
   DBG_T(1);
 
-  // floor lane data of the first channel group: independent of the residue, so fetch it now and let the
-  // latency hide behind the residue and coupling phases
+  // floor lane data of the first channel group: independent of the residue, so fetch it first
   const int wv = tid >> 6, lane = tid & 63;
   const FloorLane first_lane = load_floor_lane(S, Bt, chans, wv, nch, lane);
 
-  // ---- stage the frame's side information (one coalesced burst) and clear the spectrum ----
-  const bool staged = (int)fr.op_count <= cap_ops && (int)fr.ent_count <= cap_ent;
+  // ---- stage the frame's side information (16-byte copies) and clear the spectrum ----
+  const int npass = (int)(fr.pass_end - fr.pass_begin);
+  // the host sizes the three capacities from the batch's largest frame (nvh_api.hip) and launches the unfused
+  // kernels instead when that does not fit; a frame beyond them would be a host bug
+  if ((int)fr.op_count > cap_ops || (int)fr.ent_count + 7 > cap_ent || npass > cap_pass) __builtin_trap();
+  // the entry slice starts at any 2-byte offset: copy from the enclosing 16-byte boundary
+  const unsigned ent_shift = fr.ent_begin & 7u;
   s_db[tid] = k_inverse_db[tid];
-  for (int i = tid; i < S.nbooks; i += SP_THREADS) s_books[i] = S.books[i];
-  for (int i = tid; i < S.lattice_words; i += SP_THREADS) s_lat[i] = S.lattice[i];
-  if (staged) {
+  {
+    const uint4* gb = reinterpret_cast<const uint4*>(S.books);
+    for (int i = tid; i < S.nbooks * 2; i += SP_THREADS) reinterpret_cast<uint4*>(s_books)[i] = gb[i];
+    for (int i = tid; i < S.lattice_words; i += SP_THREADS) s_lat[i] = S.lattice[i];
+  }
+  {
     const uint2* go = reinterpret_cast<const uint2*>(Bt.ops + fr.op_begin);
     for (int i = tid; i < (int)fr.op_count; i += SP_THREADS) reinterpret_cast<uint2*>(s_ops)[i] = go[i];
-    const uint16_t* ge = Bt.entries + fr.ent_begin;
-    for (int i = tid; i < (int)fr.ent_count; i += SP_THREADS) s_ent[i] = ge[i];
+    const uint4* ge = reinterpret_cast<const uint4*>(Bt.entries + (fr.ent_begin - ent_shift));
+    const int nvec = (int)((ent_shift + fr.ent_count + 7u) >> 3);
+    for (int i = tid; i < nvec; i += SP_THREADS) reinterpret_cast<uint4*>(s_ent)[i] = ge[i];
+    for (int i = tid; i < npass * 10; i += SP_THREADS) {
+      const int p = i / 10, k = i - p * 10;
+      const NvhResPass* gp = Bt.passes + fr.pass_begin + p;
+      s_pass[p * 12 + k] = k == 0 ? (uint32_t)gp->residue : gp->op_begin[k - 1] - fr.op_begin;
+    }
   }
-  for (int i = tid; i < nch * half; i += SP_THREADS) spec[i] = 0.0f;  // Mapping.cs:108
+  {
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = tid; i < (nch * half) >> 2; i += SP_THREADS) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
+  }
+  // mono / stereo Floor1 streams take the fused tail; their posts are unwrapped now, one wavefront per
+  // channel, while the staging loads are in flight
+  const bool fused_tail = !FLOOR0 && nch <= 2 && mp.coupling_steps <= 1;
+  if (fused_tail && wv < nch) floor_prepare(&fs[wv], first_lane, lane, half);
   __syncthreads();
   DBG_T(2);
   // both sources are indexed relative to the frame's slice (op.ent_off and pass->op_begin[] are batch offsets)
-  const NvhResOp* ops = staged ? s_ops : Bt.ops + fr.op_begin;
-  const uint16_t* ent = staged ? s_ent : Bt.entries + fr.ent_begin;
+  const NvhResOp* ops = s_ops;
+  const uint16_t* ent = s_ent + ent_shift;
 
-  // ---- residue ----  (phase_mask: profiling aid, all bits set in production)
-  for (unsigned ps = fr.pass_begin; (phase_mask & 1) && ps < fr.pass_end; ++ps) {
-    // by value: the stage loop below is full of barriers, across which loads through a pointer are not hoisted --
-    // every stage (empty ones included) would pay a scalar-load round trip for its op range
-    const NvhResPass pass = Bt.passes[ps];
-    const NvhDevResidue R = S.residues[pass.residue];
+  // ---- residue ----
+  for (int ps = 0; ps < npass; ++ps) {
+    // values read back from LDS are wave-uniform: say so, or every use downstream turns into vector code
+    const NvhDevResidue R = S.residues[__builtin_amdgcn_readfirstlane((int)s_pass[ps * 12])];
     const int psize = R.partition_size;
-    if (dbg && psize == 123456) dbg[1] = 0;
     long long t_prev = dbg ? clock64() : 0;
     if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 7] = t_prev;
-#pragma unroll
+#pragma unroll 1
     for (int s = 0; s < NVH_MAX_STAGES; ++s) {
-      const unsigned ob = pass.op_begin[s] - fr.op_begin, oe = pass.op_begin[s + 1] - fr.op_begin;
+      const unsigned ob = __builtin_amdgcn_readfirstlane(s_pass[ps * 12 + 1 + s]);
+      const unsigned oe = __builtin_amdgcn_readfirstlane(s_pass[ps * 12 + 2 + s]);
       if (ob == oe) continue;
-      if (!R.sequential && R.fast) {
+      if (R.pair_path) {
+        // every book of this residue is a lattice of even dimension: one lane adds two consecutive components of
+        // one codebook entry (for stereo type 2 that is one bin of both channels).  The VQ lookup is two base-
+        // lat_values digits of the entry number, peeled with exact reciprocal multiplies; nothing leaves LDS.
+        const unsigned hp = (unsigned)psize >> 1;
+        const unsigned hp_magic = R.hp_magic;
+        const unsigned rch = (unsigned)R.real_channels;
+        const unsigned total = (oe - ob) * hp;
+        for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
+          const unsigned o = hp > 1 ? __umulhi(idx, hp_magic) : idx;
+          const unsigned i = (idx - o * hp) << 1;  // first component index inside the partition
+          const NvhResOp op = ops[ob + o];
+          const NvhDevBook bk = s_books[op.book];
+          const unsigned dims = bk.dim, lv = bk.lat_values;
+          const unsigned j = dims > 2 ? __umulhi(i, bk.dim_magic) : i >> 1;
+          const unsigned comp = i - j * dims;
+          unsigned q = ent[op.ent_off - fr.ent_begin + j];
+          if (q == NVH_ENTRY_SKIP) continue;
+          const uint32_t* lat = s_lat + bk.lat_off;
+          if (comp) q = __umulhi(q, lat[lv + comp]);  // e / lv^comp
+          unsigned d0 = 0, d1 = 0;
+          if (lv > 1) {
+            const unsigned q1 = __umulhi(q, bk.lat_magic);
+            d0 = q - q1 * lv;
+            d1 = q1 - __umulhi(q1, bk.lat_magic) * lv;
+          }
+          const float v0 = __uint_as_float(lat[d0]), v1 = __uint_as_float(lat[d1]);
+          const unsigned offset = (unsigned)(R.begin + (int)op.partition * psize);
+          unsigned c0, x0, c1, x1;
+          if (R.type == 1) {
+            c0 = c1 = op.channel;
+            x0 = offset + i;
+            x1 = x0 + 1;
+          } else if (rch == 2) {
+            c0 = 0; c1 = 1;
+            x0 = x1 = (offset >> 1) + (i >> 1);
+          } else if (rch > 1) {
+            const unsigned qi = __umulhi(i, R.rch_magic);
+            c0 = i - qi * rch;
+            x0 = __umulhi(offset, R.rch_magic) + qi;
+            c1 = c0 + 1; x1 = x0;
+            if (c1 == rch) { c1 = 0; ++x1; }
+          } else {
+            c0 = c1 = 0;
+            x0 = offset + i;
+            x1 = x0 + 1;
+          }
+          if (x0 < (unsigned)half) {
+            float* p = spec + c0 * (unsigned)half + x0;
+            *p = *p + v0;
+          }
+          if (x1 < (unsigned)half) {
+            float* p = spec + c1 * (unsigned)half + x1;
+            *p = *p + v1;
+          }
+        }
+        __syncthreads();
+      } else if (!R.sequential && R.fast) {
         // elements of one stage never alias (that is what !sequential means), so four of them are fetched as
         // independent dependency chains before their adds are committed
         const int total = (int)(oe - ob) * psize;
@@ -261,14 +508,6 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
             if (tp[u]) *tp[u] = *tp[u] + tv[u];
         }
         __syncthreads();
-        if (dbg) {
-          long long t_now = clock64();
-          if (threadIdx.x == 0) {
-            dbg[(long long)blockIdx.x * 24 + 8 + s] = t_now - t_prev;
-            dbg[(long long)blockIdx.x * 24 + 16 + s] = (long long)(oe - ob);
-          }
-          t_prev = t_now;
-        }
       } else if (!R.sequential) {
         const int total = (int)(oe - ob) * psize;
         for (int idx = tid; idx < total; idx += SP_THREADS) {
@@ -289,125 +528,92 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           __syncthreads();
         }
       }
+      if (dbg) {
+        long long t_now = clock64();
+        if (threadIdx.x == 0) {
+          dbg[(long long)blockIdx.x * 24 + 8 + s] = t_now - t_prev;
+          dbg[(long long)blockIdx.x * 24 + 16 + s] = (long long)(oe - ob);
+        }
+        t_prev = t_now;
+      }
     }
   }
 
   DBG_T(3);
-  // ---- inverse coupling, last step first (Mapping.cs:137-182) ----
-  const NvhDevMapping mp = S.mappings[fr.mapping];
-  for (int st = mp.coupling_steps - 1; (phase_mask & 2) && st >= 0; --st) {
+  float* planes = work + (long long)f * nch * S.block1;
+
+  if (fused_tail) {
+    // ---- fused tail: inverse coupling (Mapping.cs:137-182), floor apply and the store, 4 bins per lane ----
+    int mg = 0;
+    bool couple = false;
+    if (nch == 2 && mp.coupling_steps == 1) {
+      mg = S.coupling[mp.coupling_off];  // the angle channel is the other one
+      couple = chans[0].exec || chans[1].exec;
+    }
+    const int md0 = __builtin_amdgcn_readfirstlane(fs[0].mode), md1 = nch == 2 ? __builtin_amdgcn_readfirstlane(fs[1].mode) : 0;
+    for (int x0 = tid * 4; x0 < half; x0 += SP_THREADS * 4) {
+      float4 r0 = *reinterpret_cast<const float4*>(spec + x0);
+      float4 r1 = nch == 2 ? *reinterpret_cast<const float4*>(spec + half + x0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (couple) {
+        if (mg == 0) {
+          couple1(r0.x, r1.x); couple1(r0.y, r1.y); couple1(r0.z, r1.z); couple1(r0.w, r1.w);
+        } else {
+          couple1(r1.x, r0.x); couple1(r1.y, r0.y); couple1(r1.z, r0.z); couple1(r1.w, r0.w);
+        }
+      }
+      float m[4];
+      if (md0 == 1) {
+        floor_walk4(&fs[0], s_db, x0, err, m);
+        r0.x = r0.x * m[0]; r0.y = r0.y * m[1]; r0.z = r0.z * m[2]; r0.w = r0.w * m[3];
+      } else if (md0 == 2) {
+        r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // Floor1.cs:218-221
+      }
+      *reinterpret_cast<float4*>(planes + x0) = r0;
+      if (nch == 2) {
+        if (md1 == 1) {
+          floor_walk4(&fs[1], s_db, x0, err, m);
+          r1.x = r1.x * m[0]; r1.y = r1.y * m[1]; r1.z = r1.z * m[2]; r1.w = r1.w * m[3];
+        } else if (md1 == 2) {
+          r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        *reinterpret_cast<float4*>(planes + S.block1 + x0) = r1;
+      }
+    }
+    DBG_T(4);
+    DBG_T(5);
+    DBG_T(6);
+    return;
+  }
+
+  // ---- general tail: any channel count, any number of coupling steps, Floor0 ----
+  // inverse coupling, last step first (Mapping.cs:137-182)
+  for (int st = mp.coupling_steps - 1; st >= 0; --st) {
     const int mg = S.coupling[mp.coupling_off + 2 * st], an = S.coupling[mp.coupling_off + 2 * st + 1];
     if (chans[an].exec || chans[mg].exec) {
       float* M = spec + mg * half;
       float* Aa = spec + an * half;
       for (int j = tid; j < half; j += SP_THREADS) {
-        float oldM = M[j], oldA = Aa[j], newM, newA;
-        if (oldM > 0) {
-          if (oldA > 0) { newM = oldM; newA = oldM - oldA; }
-          else          { newA = oldM; newM = oldM + oldA; }
-        } else {
-          if (oldA > 0) { newM = oldM; newA = oldM + oldA; }
-          else          { newA = oldM; newM = oldM - oldA; }
-        }
-        M[j] = newM;
-        Aa[j] = newA;
+        float vm = M[j], va = Aa[j];
+        couple1(vm, va);
+        M[j] = vm;
+        Aa[j] = va;
       }
     }
     __syncthreads();
   }
 
   DBG_T(4);
-  // ---- floors, SP_GROUP channels at a time: wavefront w prepares channel c0 + w ----
-  for (int c0 = 0; (phase_mask & 4) && c0 < nch; c0 += SP_GROUP) {
-    FloorLane fl_lane = (c0 == 0) ? first_lane : load_floor_lane(S, Bt, chans, c0 + wv, nch, lane);
-    const int mode = fl_lane.mode;
-    const int pc = fl_lane.pc;
-    if (lane == 0) fs[wv].mode = mode;
-    // UnwrapPosts (Floor1.cs:224-297).  Lane i owns post i; posts of one dependency level are independent, and the
-    // scratch block belongs to this wavefront alone, so the levels are separated by wave-local ordering only.
-    if (lane < pc) {
-      fs[wv].fy[lane] = (lane < 2) ? fl_lane.val : 0;
-      fs[wv].step[lane] = (lane < 2) ? 1 : 0;
-    }
-    sp_wave_sync();
-    for (int lv = 1; lv < fl_lane.levels; ++lv) {
-      if (lane >= 2 && lane < pc && fl_lane.level == lv) {
-        int predicted = sp_render_point(fl_lane.x_lo, fs[wv].fy[fl_lane.lo], fl_lane.x_hi, fs[wv].fy[fl_lane.hi], fl_lane.x);
-        int val = fl_lane.val;
-        int highroom = fl_lane.range - predicted;
-        int lowroom = predicted;
-        int room = (highroom < lowroom) ? highroom * 2 : lowroom * 2;
-        int fy;
-        if (val != 0) {
-          // stepFlags are only ever set for lower-indexed posts, never cleared afterwards: order-free
-          fs[wv].step[fl_lane.lo] = 1;
-          fs[wv].step[fl_lane.hi] = 1;
-          fs[wv].step[lane] = 1;
-          if (val >= room) {
-            if (highroom > lowroom) fy = val - lowroom + predicted;
-            else fy = predicted - val + highroom - 1;
-          } else {
-            if ((val % 2) == 1) fy = predicted - ((val + 1) / 2);
-            else fy = predicted + (val / 2);
-          }
-        } else {
-          fy = predicted;
-        }
-        fs[wv].fy[lane] = fy;
-      }
-      sp_wave_sync();
-    }
-    const int my_sorted = fl_lane.sorted, x_sorted = fl_lane.x_sorted, f_mult = fl_lane.mult;
-    // Apply's walk over the sorted posts (Floor1.cs:196-216): compact the flagged posts in X order
-    if (mode == 1) {
-      bool active = (lane < pc) && fs[wv].step[my_sorted] != 0;
-      unsigned long long mask = __ballot(active);
-      int rank = __popcll(mask & ((1ull << lane) - 1ull));
-      if (active) {
-        fs[wv].x[rank] = x_sorted;
-        fs[wv].y[rank] = fs[wv].fy[my_sorted] * f_mult;
-      }
-      // the walk stops at the first end point at or beyond n/2 (`if (lx >= n) break`)
-      unsigned long long beyond = __ballot(active && rank >= 1 && x_sorted >= half);
-      int nact = __popcll(mask);
-      int ns;
-      if (beyond) {
-        int fl0 = __ffsll((long long)beyond) - 1;
-        ns = __popcll(mask & ((1ull << fl0) - 1ull));
-      } else {
-        ns = nact;  // trailing flat run to n/2 (Floor1.cs:213-216)
-      }
-      sp_wave_sync();
-      if (lane == 0) {
-        if (!beyond) {
-          fs[wv].x[ns] = half;
-          fs[wv].y[ns] = fs[wv].y[ns - 1];
-        }
-        fs[wv].nseg = ns;
-      }
-      sp_wave_sync();
-      // per-segment line parameters (Floor1.cs:316-326): one lane per segment
-      if (lane < ns) {
-        int x0 = fs[wv].x[lane], y0 = fs[wv].y[lane];
-        int x1 = fs[wv].x[lane + 1] < half ? fs[wv].x[lane + 1] : half;  // Math.Min(hx, n) (quirk B-6)
-        int y1 = fs[wv].y[lane + 1];
-        int dy = y1 - y0;
-        int adx = x1 - x0;
-        int ady = dy < 0 ? -dy : dy;
-        int b = dy / adx;
-        int ab = b < 0 ? -b : b;
-        fs[wv].b[lane] = b;
-        fs[wv].ady[lane] = ady - ab * adx;
-        fs[wv].adx[lane] = (dy < 0) ? -adx : adx;
-      }
-    }
+  // floors, SP_GROUP channels at a time: wavefront w prepares channel c0 + w
+  for (int c0 = 0; c0 < nch; c0 += SP_GROUP) {
+    const FloorLane fl_lane = (c0 == 0) ? first_lane : load_floor_lane(S, Bt, chans, c0 + wv, nch, lane);
+    if (c0 + wv < nch) floor_prepare(&fs[wv], fl_lane, lane, half);
     __syncthreads();
 
-    // ---- render / apply: all threads over the group's channels ----
+    // render / apply: all threads over the group's channels
     const int ngrp = (nch - c0) < SP_GROUP ? (nch - c0) : SP_GROUP;
     for (int k = 0; k < ngrp; ++k) {
       const int cc = c0 + k;
-      const int md = fs[k].mode;
+      const int md = __builtin_amdgcn_readfirstlane(fs[k].mode);
       float* res = spec + cc * half;
       if (md == 0) continue;
       if (md == 2) {
@@ -415,50 +621,10 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         continue;
       }
       if (md == 1) {
-        const FloorScratch* Q = &fs[k];
-        const int ns = Q->nseg;
-        // chunks of 4 consecutive bins per thread: locate the segment once, then step the reference's
-        // error-term recurrence (Floor1.cs:328-340) forward, hopping segments as they end
         for (int x0 = tid * 4; x0 < half; x0 += SP_THREADS * 4) {
-          int lo = 0, hi = ns - 1;
-          while (lo < hi) {  // last segment whose start is <= x0
-            int mid = (lo + hi + 1) >> 1;
-            if (Q->x[mid] <= x0) lo = mid; else hi = mid - 1;
-          }
-          int sg = lo;
-          int sx = Q->x[sg], sadx = Q->adx[sg], sb = Q->b[sg], sady = Q->ady[sg];
-          int adx = sadx < 0 ? -sadx : sadx, sy = sadx < 0 ? -1 : 1;
-          int t = x0 - sx;
-          int wq = (sady * t) / adx;
-          int y = Q->y[sg] + sb * t + sy * wq;
-          int e = -adx + sady * t - adx * wq;  // the reference's `err` after t steps
-          int xend = Q->x[sg + 1];
-          float4 v = *reinterpret_cast<float4*>(res + x0);
           float m[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            int x = x0 + q;
-            if (x >= xend && sg + 1 < ns) {  // the next segment starts exactly here
-              ++sg;
-              sadx = Q->adx[sg]; sb = Q->b[sg]; sady = Q->ady[sg];
-              adx = sadx < 0 ? -sadx : sadx; sy = sadx < 0 ? -1 : 1;
-              y = Q->y[sg];
-              e = -adx;
-              xend = Q->x[sg + 1];
-            }
-            int yy = y;
-            if (yy < 0 || yy > 255) {
-              atomicOr(err, NVH_DEVERR_FLOOR1_Y);  // inverse_dB_table[y] would throw (quirk B-7)
-              yy = yy < 0 ? 0 : 255;
-            }
-            m[q] = s_db[yy];
-            y += sb;  // advance to x+1 inside the segment
-            e += sady;
-            if (e >= 0) {
-              e -= adx;
-              y += sy;
-            }
-          }
+          floor_walk4(&fs[k], s_db, x0, err, m);
+          float4 v = *reinterpret_cast<float4*>(res + x0);
           v.x = v.x * m[0];
           v.y = v.y * m[1];
           v.z = v.z * m[2];
@@ -507,8 +673,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   }
 
   DBG_T(5);
-  // ---- spectrum -> work planes ----
-  float* planes = work + (long long)f * nch * S.block1;
+  // spectrum -> work planes
   const int q4 = half >> 2;
   for (int i = tid; i < nch * q4; i += SP_THREADS) {
     int c = i / q4, k = i - c * q4;
@@ -518,16 +683,16 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
 }
 
 extern "C" __global__ void __launch_bounds__(SP_THREADS)
-k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int phase_mask, int cap_ops,
+k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
            int cap_ent, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<false>(S, Bt, work, err, phase_mask, cap_ops, cap_ent, smem, dbg);
+  spectrum_body<false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg);
 }
 
 // Variant for setups that contain a Floor0 (double-precision cos / sqrt / exp: costs registers, kept apart).
 extern "C" __global__ void __launch_bounds__(SP_THREADS)
-k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int phase_mask, int cap_ops,
+k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
               int cap_ent) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<true>(S, Bt, work, err, phase_mask, cap_ops, cap_ent, smem);
+  spectrum_body<true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem);
 }

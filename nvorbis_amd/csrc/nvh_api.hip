@@ -27,13 +27,13 @@ __global__ void k_imdct_compact(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* work, float* carry_out, int f);
 __global__ void k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
                               int* clipped_flag, float* carry_out, int last_decoded);
-__global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent,
+__global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent,
                            long long* dbg);
 __global__ void k_spectrum2_c1(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum2_c2(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum2_c1_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum2_c2_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
-__global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int phase_mask, int cap_ops, int cap_ent);
+__global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
                             int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
@@ -104,7 +104,7 @@ struct nvh_batch {
   int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // frames, chans, passes, ops, entries, posts, coeffs, -
   bool sequential_ola = false;
   int last_decoded = -1;  // last frame with n != 0 (its block becomes the next carried tail)
-  int max_ops = 0, max_ent = 0;  // largest per-frame op / entry slice (LDS staging capacity of k_spectrum)
+  int max_ops = 0, max_ent = 0, max_pass = 0;  // largest per-frame op / entry / pass slice (LDS staging capacity of k_spectrum)
   bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
   bool has_carry_in = false;
 };
@@ -441,7 +441,14 @@ static int upload_setup(nvh_stream* s) {
           if (r.books[c][k] >= 0 && (uint64_t)S.books[(size_t)r.books[c][k]].dimensions > max_div)
             max_div = (uint64_t)S.books[(size_t)r.books[c][k]].dimensions;
       d.fast = (r.type != 0 && r.partition_size > 1 && max_index * max_div < 0x100000000ull) ? 1 : 0;
-      d.pad = 0;
+      bool pairs = d.fast != 0 && !seq && (r.partition_size % 2) == 0;
+      for (int c = 0; c < r.classifications; c++)
+        for (int k = 0; k < NVH_MAX_STAGES; k++)
+          if (r.books[c][k] >= 0 && (books[(size_t)r.books[c][k]].lat_values == 0 || (books[(size_t)r.books[c][k]].dim & 1u))) pairs = false;
+      if (std::getenv("NVH_NO_PAIR")) pairs = false;  // A/B aid
+      d.pair_path = pairs ? 1 : 0;
+      d.hp_magic = r.partition_size / 2 > 1 ? (uint32_t)((0x100000000ull + (uint64_t)(r.partition_size / 2) - 1) / (uint64_t)(r.partition_size / 2)) : 0u;
+      d.pad[0] = d.pad[1] = d.pad[2] = 0;
     }
   }
 
@@ -653,10 +660,11 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->pcm_samples = P.pcm_samples;
   b->sequential_ola = P.sequential_ola;
   b->last_decoded = -1;
-  b->max_ops = b->max_ent = 0;
+  b->max_ops = b->max_ent = b->max_pass = 0;
   for (const NvhFrame& fr : P.frames) {
     if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
     if ((int)fr.ent_count > b->max_ent) b->max_ent = (int)fr.ent_count;
+    if ((int)(fr.pass_end - fr.pass_begin) > b->max_pass) b->max_pass = (int)(fr.pass_end - fr.pass_begin);
   }
   {
     // preconditions of the fused IMDCT + overlap-add kernel (kernels_imdct.hip, k_imdct_ola)
@@ -694,6 +702,7 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   size_t o_en = ab.add(P.entries.empty() ? (const void*)dummy.data() : P.entries.data(), pad1(P.entries.size()) * sizeof(uint16_t));
   size_t o_po = ab.add(P.posts.empty() ? (const void*)dummy.data() : P.posts.data(), pad1(P.posts.size()) * sizeof(uint16_t));
   size_t o_co = ab.add(P.coeffs.empty() ? (const void*)dummy.data() : P.coeffs.data(), pad1(P.coeffs.size()) * sizeof(float));
+  ab.bytes.resize(ab.bytes.size() + 64);  // k_spectrum copies entry slices in whole 16-byte vectors
   b->descriptor_bytes = (int64_t)(P.frames.size() * sizeof(NvhFrame) + P.chans.size() * sizeof(NvhChan) +
                                   P.passes.size() * sizeof(NvhResPass) + P.ops.size() * sizeof(NvhResOp) +
                                   P.entries.size() * 2 + P.posts.size() * 2 + P.coeffs.size() * 4);
@@ -736,17 +745,16 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   // Fused spectrum kernel when a frame's spectrum (+ staged side information) fits the default 64 KB dynamic
   // LDS window; LDS map in kernels_spectrum.hip.
   {
-    static const int phase_mask = getenv("NVH_DEBUG_SPECTRUM_MASK") ? atoi(getenv("NVH_DEBUG_SPECTRUM_MASK")) : 7;  // profiling aid
-    const size_t fixed_words = 512 + 4 * (1840 / 4) + (size_t)s->setup.books.size() * 8 + (size_t)((s->dev.lattice_words + 3) & ~3) +
-                               (size_t)ch * (size_t)(s->setup.block1 / 2);
-    int cap_ops = (b->max_ops + 1) & ~1, cap_ent = (b->max_ent + 7) & ~7;  // keep the spectrum 16-byte aligned
-    size_t words = fixed_words + (size_t)cap_ops * 2 + (size_t)cap_ent / 2;
-    if (words * 4 > 64 * 1024) {  // oversized frames: leave ops / entries in global memory
-      cap_ops = cap_ent = 0;
-      words = fixed_words;
-    }
-    static const int no_gather = getenv("NVH_GATHER") ? 0 : 1;  // gather-form kernel (kernels_spectrum2.hip): bit-exact but not faster, opt-in
     const bool has_floor0 = s->has_floor0;
+    const size_t fixed_words = (size_t)(has_floor0 ? 512 : 256) + (size_t)(ch < 4 ? ch : 4) * NVH_SP_FLOOR_SCRATCH_WORDS +
+                               (size_t)s->setup.books.size() * 8 + (size_t)((s->dev.lattice_words + 3) & ~3) +
+                               (size_t)ch * (size_t)(s->setup.block1 / 2);
+    // staging capacities; the entry slice is copied from its enclosing 16-byte boundary (up to 7 entries of slack)
+    int cap_pass = b->max_pass, cap_ops = (b->max_ops + 1) & ~1, cap_ent = (b->max_ent + 14) & ~7;
+    size_t words = fixed_words + (size_t)cap_pass * 12 + (size_t)cap_ops * 2 + (size_t)cap_ent / 2;
+    if (getenv("NVH_UNFUSED")) words = 1u << 20;  // test aid: force the unfused kernels below
+    static const size_t lds_pad = getenv("NVH_LDS_PAD") ? (size_t)atoi(getenv("NVH_LDS_PAD")) : 0;  // occupancy experiments
+    static const int no_gather = getenv("NVH_GATHER") ? 0 : 1;  // gather-form kernel (kernels_spectrum2.hip): bit-exact but not faster, opt-in
     // gather form (kernels_spectrum2.hip): needs the op / entry slices staged (op indices are 16-bit)
     size_t g_words = (size_t)(has_floor0 ? 512 : 256) + (size_t)ch * (1840 / 4) + (size_t)s->setup.books.size() * 8 +
                      (size_t)((b->max_ops + 1) & ~1) * 2 + (size_t)((b->max_ent + 7) & ~7) / 2 + (size_t)s->gather_idx_cap / 2 +
@@ -761,10 +769,10 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
       if (has_floor0)
         hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
-                           phase_mask, cap_ops, cap_ent);
+                           cap_pass, cap_ops, cap_ent);
       else
-        hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
-                           phase_mask, cap_ops, cap_ent, (long long*)g_dbg_buf);
+        hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4 + lds_pad, st, s->dev, b->dev, work, flags,
+                           cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf);
     } else {
       hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work);
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));

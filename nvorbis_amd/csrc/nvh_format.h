@@ -71,7 +71,9 @@ struct NvhDevResidue {   // Residue0.cs:21-33
   uint32_t psize_magic;  // ceil(2^32 / partition_size)
   uint32_t rch_magic;    // ceil(2^32 / real_channels) (0 when real_channels == 1)
   int32_t fast;          // 1 => the reciprocal-multiply index path is exact for every index of this residue
-  int32_t pad;
+  int32_t pair_path;     // 1 => fast, not sequential, every book a lattice book of even dimension: two bins per lane
+  uint32_t hp_magic;     // ceil(2^32 / (partition_size / 2)) for the pair path, 0 when partition_size / 2 <= 1
+  int32_t pad[3];
 };
 
 struct NvhDevMapping {   // Mapping.cs:9-14
