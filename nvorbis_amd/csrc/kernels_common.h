@@ -39,7 +39,7 @@ struct NvhDevBatch {
 };
 
 // LDS words of one per-channel floor scratch block of k_spectrum (kernels_spectrum.hip: FloorScratch)
-#define NVH_SP_FLOOR_SCRATCH_WORDS 268
+#define NVH_SP_FLOOR_SCRATCH_WORDS 332
 
 // error word written by kernels when the reference would have thrown (index out of range)
 enum { NVH_DEVERR_FLOOR1_Y = 1, NVH_DEVERR_FLOOR0_W = 2 };

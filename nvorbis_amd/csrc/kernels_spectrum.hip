@@ -68,12 +68,18 @@ struct FloorScratch {
     } u;
     FloorSeg seg[NVH_MAX_POSTS + 2];
   };
+  uint32_t magic[NVH_MAX_POSTS + 2];  // floor((2^32 - 1) / adx) of each segment: restart of the error recurrence
   int nseg;
   int mode;  // 0 = skip, 1 = floor1 curve, 2 = clear (exec without energy), 3 = floor0
-  int pad[2];
 };
 static_assert(sizeof(FloorScratch) % 16 == 0, "keep the LDS map 16-byte aligned");
 static_assert(sizeof(FloorScratch) == NVH_SP_FLOOR_SCRATCH_WORDS * 4, "host-side LDS sizing (nvh_api.hip) follows this");
+
+// floor(n / d) for 0 <= n < 2^28 from m = floor((2^32 - 1) / d): the estimate is at most one short.
+__device__ __forceinline__ unsigned sp_div_magic(unsigned n, unsigned d, unsigned m) {
+  unsigned q = __umulhi(n, m);
+  return (n - q * d >= d) ? q + 1 : q;
+}
 
 // General (division-based) form of one residue element, all residue types.
 __device__ __forceinline__ void residue_apply_lds(const NvhDevBook bk, const float* __restrict__ vq, const NvhDevResidue& R,
@@ -154,13 +160,14 @@ __device__ __forceinline__ float* residue_fetch_fast(const NvhDevBook* __restric
 struct FloorLane {
   int mode;  // 0 skip, 1 floor1 curve, 2 clear, 3 floor0
   int pc, levels, level, lo, hi, x, x_lo, x_hi, val, sorted, x_sorted, range, mult;
+  unsigned adx_magic;
 };
 
 __device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const NvhDevBatch& Bt, const NvhChan* chans, int c,
                                                      int nch, int lane) {
   FloorLane L;
   L.mode = 0; L.pc = 0; L.levels = 0; L.level = 0; L.lo = 0; L.hi = 1; L.x = 0; L.x_lo = 0; L.x_hi = 1; L.val = 0;
-  L.sorted = 0; L.x_sorted = 0; L.range = 0; L.mult = 0;
+  L.sorted = 0; L.x_sorted = 0; L.range = 0; L.mult = 0; L.adx_magic = 0;
   if (c >= nch) return L;
   const NvhChan chn = chans[c];
   const NvhDevFloor* fl = &S.floors[chn.floor];
@@ -181,9 +188,10 @@ __device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const
     L.x = F->x_list[lane];
     L.val = Bt.posts[chn.data_off + lane];
     L.sorted = F->sort_idx[lane];
-    L.x_lo = F->x_list[L.lo];
-    L.x_hi = F->x_list[L.hi];
-    L.x_sorted = F->x_list[L.sorted];
+    L.x_lo = F->x_lo[lane];
+    L.x_hi = F->x_hi[lane];
+    L.x_sorted = F->x_sorted[lane];
+    L.adx_magic = F->adx_magic[lane];
   }
   return L;
 }
@@ -192,7 +200,7 @@ __device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const
 //   UnwrapPosts (Floor1.cs:224-297): lane i owns post i; posts of one dependency level are independent.
 //   Apply's walk over the sorted posts (Floor1.cs:196-216): the flagged posts compacted in X order; the walk
 //   stops at the first end point at or beyond n/2, else a flat run to n/2 closes the curve (:213-216).
-__device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& L, int lane, int half) {
+__device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& L, int lane, int half, int* __restrict__ err) {
   const int mode = L.mode, pc = L.pc;
   if (lane == 0) Q->mode = mode;
   if (mode != 1) return;  // wave-uniform
@@ -203,7 +211,17 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
   sp_wave_sync();
   for (int lv = 1; lv < L.levels; ++lv) {
     if (lane >= 2 && lane < pc && L.level == lv) {
-      int predicted = sp_render_point(L.x_lo, Q->u.fy[L.lo], L.x_hi, Q->u.fy[L.hi], L.x);
+      // RenderPoint (Floor1.cs:299-314) with the static divisor's reciprocal; anything unusual (a corrupt
+      // stream's huge or wrapped err) takes the plain division
+      int predicted;
+      {
+        const int y0 = Q->u.fy[L.lo], y1 = Q->u.fy[L.hi];
+        const int dy = y1 - y0, adx = L.x_hi - L.x_lo;
+        const int ady = dy < 0 ? -dy : dy;
+        const int er = ady * (L.x - L.x_lo);
+        const int off = ((unsigned)er < (1u << 28)) ? (int)sp_div_magic((unsigned)er, (unsigned)adx, L.adx_magic) : er / adx;
+        predicted = dy < 0 ? y0 - off : y0 + off;
+      }
       int val = L.val;
       int highroom = L.range - predicted;
       int lowroom = predicted;
@@ -271,20 +289,28 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
     const int ady = dy < 0 ? -dy : dy;
     const int b = dy / adx;
     const int ab = b < 0 ? -b : b;
+    const int ady2 = ady - ab * adx;
     FloorSeg sgm;
     sgm.x_xend = (uint32_t)x0 | ((uint32_t)x1n << 16);
     sgm.y = y0;
     sgm.b = b;
-    sgm.ady_adx = ((uint32_t)(ady - ab * adx) & 0xFFFFu) | ((uint32_t)((dy < 0) ? -adx : adx) << 16);
+    sgm.ady_adx = ((uint32_t)ady2 & 0xFFFFu) | ((uint32_t)((dy < 0) ? -adx : adx) << 16);
     Q->seg[lane] = sgm;
+    const unsigned mg = 0xFFFFFFFFu / (unsigned)adx;
+    Q->magic[lane] = mg;
+    // inverse_dB_table[y] throws for y outside 0..255 (quirk B-7).  The curve is monotone inside a segment, so
+    // its first and last drawn values decide; the render loop itself then only clamps.
+    const int tl = adx - 1;
+    const int yl = y0 + b * tl + (dy < 0 ? -1 : 1) * (int)sp_div_magic((unsigned)(ady2 * tl), (unsigned)adx, mg);
+    if (y0 < 0 || y0 > 255 || yl < 0 || yl > 255) atomicOr(err, NVH_DEVERR_FLOOR1_Y);
   }
 }
 
-// Curve values of 4 consecutive bins starting at x0 (a multiple of 4): locate the segment once, restart the
+// Curve values of NB consecutive bins starting at x0 (a multiple of NB): locate the segment once, restart the
 // reference's error-term recurrence (Floor1.cs:328-340) from its closed form, then step it, hopping segments
-// as they end.  Returns the 4 inverse-dB multipliers.
-__device__ __forceinline__ void floor_walk4(const FloorScratch* Q, const float* __restrict__ s_db, int x0, int* __restrict__ err,
-                                            float m[4]) {
+// as they end.  Returns the NB inverse-dB multipliers.
+template <int NB>
+__device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* __restrict__ s_db, int x0, float m[NB]) {
   const int ns = __builtin_amdgcn_readfirstlane(Q->nseg);
   int lo = 0, hi = ns - 1;
   while (lo < hi) {  // last segment whose start is <= x0
@@ -296,12 +322,12 @@ __device__ __forceinline__ void floor_walk4(const FloorScratch* Q, const float* 
   int sadx = (int)s.ady_adx >> 16, sady = (int)(s.ady_adx & 0xFFFFu), sb = s.b;
   int adx = sadx < 0 ? -sadx : sadx, sy = sadx < 0 ? -1 : 1;
   const int t = x0 - (int)(s.x_xend & 0xFFFFu);
-  const int wq = (sady * t) / adx;
+  const int wq = (int)sp_div_magic((unsigned)(sady * t), (unsigned)adx, Q->magic[sg]);  // sady, t < adx <= 2^13
   int y = s.y + sb * t + sy * wq;
   int e = -adx + sady * t - adx * wq;  // the reference's `err` after t steps
   int xend = (int)(s.x_xend >> 16);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NB; ++q) {
     const int x = x0 + q;
     if (x >= xend && sg + 1 < ns) {  // the next segment starts exactly here
       ++sg;
@@ -312,11 +338,7 @@ __device__ __forceinline__ void floor_walk4(const FloorScratch* Q, const float* 
       e = -adx;
       xend = (int)(s.x_xend >> 16);
     }
-    int yy = y;
-    if (yy < 0 || yy > 255) {
-      atomicOr(err, NVH_DEVERR_FLOOR1_Y);  // inverse_dB_table[y] would throw (quirk B-7)
-      yy = yy < 0 ? 0 : 255;
-    }
+    const int yy = y < 0 ? 0 : (y > 255 ? 255 : y);  // out-of-range values were reported by floor_prepare
     m[q] = s_db[yy];
     y += sb;  // advance to x+1 inside the segment
     e += sady;
@@ -345,7 +367,7 @@ __device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150
 
 // LDS map (dynamic, 4-byte words):
 //   [ s_db 256 | (FLOOR0: s_coeff 256) | FloorScratch x min(channels, SP_GROUP) | stage ranges cap_pass*12 |
-//     books nbooks*8 | lattice pool | ops cap_ops*2 | entries cap_ent/2 | spectrum ch*half ]
+//     books nbooks*8 | lattice pool | ops cap_ops*2 | pair records cap_ops*4 | entries cap_ent/2 | spectrum ch*half ]
 template <bool FLOOR0>
 __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDevBatch& Bt, float* __restrict__ work,
                                               int* __restrict__ err, int cap_pass, int cap_ops, int cap_ent, float* smem,
@@ -359,23 +381,26 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(s_pass + cap_pass * 12);
   uint32_t* s_lat = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(s_books) + S.nbooks * 8);
   NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(s_lat + ((S.lattice_words + 3) & ~3));
-  uint16_t* s_ent = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(s_ops) + cap_ops * 2);
+  uint4* s_oprec = reinterpret_cast<uint4*>(reinterpret_cast<float*>(s_ops) + cap_ops * 2);  // pair-path op records
+  uint16_t* s_ent = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(s_oprec) + cap_ops * 4);
   float* spec = reinterpret_cast<float*>(s_ent) + (cap_ent >> 1);  // [ch][half], 16-byte aligned (cap_ent % 8 == 0)
 
   const int f = blockIdx.x;
 #define DBG_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + (k)] = clock64(); } while (0)
   DBG_T(0);
+  if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 22] = wall_clock64();
+  // Every frame (drain pseudo-frames included) owns exactly `channels` channel records (host_parse.cpp), so the
+  // channel records and the floor data behind them do not have to wait for the frame record.
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63;
+  const NvhChan* chans = Bt.chans + (long long)f * nch;  // == fr.chan_off
   const NvhFrame fr = Bt.frames[f];
+  // floor lane data of the first channel group: independent of the residue, so fetch it first
+  const FloorLane first_lane = load_floor_lane(S, Bt, chans, wv, nch, lane);
   if (fr.n == 0) return;
   const int half = fr.n >> 1;
-  const int tid = threadIdx.x;
-  const NvhChan* chans = Bt.chans + fr.chan_off;
   const NvhDevMapping mp = S.mappings[fr.mapping];
   DBG_T(1);
-
-  // floor lane data of the first channel group: independent of the residue, so fetch it first
-  const int wv = tid >> 6, lane = tid & 63;
-  const FloorLane first_lane = load_floor_lane(S, Bt, chans, wv, nch, lane);
 
   // ---- stage the frame's side information (16-byte copies) and clear the spectrum ----
   const int npass = (int)(fr.pass_end - fr.pass_begin);
@@ -401,6 +426,28 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       const NvhResPass* gp = Bt.passes + fr.pass_begin + p;
       s_pass[p * 12 + k] = k == 0 ? (uint32_t)gp->residue : gp->op_begin[k - 1] - fr.op_begin;
     }
+    // pair path: everything a lane needs about an op and its codebook in one 16-byte record, resolved once per
+    // op here instead of once per element in the stage loops
+    //   x: entry slice offset | first bin << 16      y: lattice pool offset | lat_values << 16
+    //   z: ceil(2^32 / lat_values)                   w: dim | channel << 8 | ceil(2^16 / dim) << 16
+    for (int p = 0; p < npass; ++p) {
+      const NvhResPass* gp = Bt.passes + fr.pass_begin + p;
+      const NvhDevResidue* Rp = &S.residues[gp->residue];
+      if (!Rp->pair_path) continue;
+      const int o_end = (int)(gp->op_begin[NVH_MAX_STAGES] - fr.op_begin);
+      for (int o = (int)(gp->op_begin[0] - fr.op_begin) + tid; o < o_end; o += SP_THREADS) {
+        const NvhResOp op = Bt.ops[fr.op_begin + o];
+        const NvhDevBook bk = S.books[op.book];
+        const unsigned offset = (unsigned)(Rp->begin + (int)op.partition * Rp->partition_size);
+        const unsigned xbase = (Rp->type == 2 && Rp->real_channels > 1) ? __umulhi(offset, Rp->rch_magic) : offset;
+        uint4 rec;
+        rec.x = (op.ent_off - fr.ent_begin) | (xbase << 16);
+        rec.y = bk.lat_off | (bk.lat_values << 16);
+        rec.z = bk.lat_magic;
+        rec.w = bk.dim | ((unsigned)op.channel << 8) | (((65536u + bk.dim - 1u) / bk.dim) << 16);
+        s_oprec[o] = rec;
+      }
+    }
   }
   {
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -409,7 +456,9 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   // mono / stereo Floor1 streams take the fused tail; their posts are unwrapped now, one wavefront per
   // channel, while the staging loads are in flight
   const bool fused_tail = !FLOOR0 && nch <= 2 && mp.coupling_steps <= 1;
-  if (fused_tail && wv < nch) floor_prepare(&fs[wv], first_lane, lane, half);
+  DBG_T(20);
+  if (fused_tail && wv < nch) floor_prepare(&fs[wv], first_lane, lane, half, err);
+  DBG_T(21);
   __syncthreads();
   DBG_T(2);
   // both sources are indexed relative to the frame's slice (op.ent_off and pass->op_begin[] are batch offsets)
@@ -438,42 +487,35 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         const unsigned total = (oe - ob) * hp;
         for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
           const unsigned o = hp > 1 ? __umulhi(idx, hp_magic) : idx;
-          const unsigned i = (idx - o * hp) << 1;  // first component index inside the partition
-          const NvhResOp op = ops[ob + o];
-          const NvhDevBook bk = s_books[op.book];
-          const unsigned dims = bk.dim, lv = bk.lat_values;
-          const unsigned j = dims > 2 ? __umulhi(i, bk.dim_magic) : i >> 1;
+          const unsigned i2 = idx - o * hp, i = i2 << 1;  // pair / first component index inside the partition
+          const uint4 rec = s_oprec[ob + o];
+          const unsigned dims = rec.w & 0xFFu, lv = rec.y >> 16;
+          const unsigned j = (i * (rec.w >> 16)) >> 16;  // i / dims (i < 4096, dims <= 16: exact)
           const unsigned comp = i - j * dims;
-          unsigned q = ent[op.ent_off - fr.ent_begin + j];
+          unsigned q = ent[(rec.x & 0xFFFFu) + j];
           if (q == NVH_ENTRY_SKIP) continue;
-          const uint32_t* lat = s_lat + bk.lat_off;
+          const uint32_t* lat = s_lat + (rec.y & 0xFFFFu);
           if (comp) q = __umulhi(q, lat[lv + comp]);  // e / lv^comp
-          unsigned d0 = 0, d1 = 0;
-          if (lv > 1) {
-            const unsigned q1 = __umulhi(q, bk.lat_magic);
-            d0 = q - q1 * lv;
-            d1 = q1 - __umulhi(q1, bk.lat_magic) * lv;
-          }
+          // two base-lv digits (lv == 1: the magic is 0 and so are q and both digits)
+          const unsigned q1 = __umulhi(q, rec.z);
+          const unsigned d0 = q - q1 * lv;
+          const unsigned d1 = q1 - __umulhi(q1, rec.z) * lv;
           const float v0 = __uint_as_float(lat[d0]), v1 = __uint_as_float(lat[d1]);
-          const unsigned offset = (unsigned)(R.begin + (int)op.partition * psize);
+          const unsigned xbase = rec.x >> 16;
           unsigned c0, x0, c1, x1;
-          if (R.type == 1) {
-            c0 = c1 = op.channel;
-            x0 = offset + i;
+          if (R.type == 1 || rch == 1) {
+            c0 = c1 = (rec.w >> 8) & 0xFFu;
+            x0 = xbase + i;
             x1 = x0 + 1;
           } else if (rch == 2) {
             c0 = 0; c1 = 1;
-            x0 = x1 = (offset >> 1) + (i >> 1);
-          } else if (rch > 1) {
+            x0 = x1 = xbase + i2;
+          } else {
             const unsigned qi = __umulhi(i, R.rch_magic);
             c0 = i - qi * rch;
-            x0 = __umulhi(offset, R.rch_magic) + qi;
+            x0 = xbase + qi;
             c1 = c0 + 1; x1 = x0;
             if (c1 == rch) { c1 = 0; ++x1; }
-          } else {
-            c0 = c1 = 0;
-            x0 = offset + i;
-            x1 = x0 + 1;
           }
           if (x0 < (unsigned)half) {
             float* p = spec + c0 * (unsigned)half + x0;
@@ -551,37 +593,49 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       couple = chans[0].exec || chans[1].exec;
     }
     const int md0 = __builtin_amdgcn_readfirstlane(fs[0].mode), md1 = nch == 2 ? __builtin_amdgcn_readfirstlane(fs[1].mode) : 0;
-    for (int x0 = tid * 4; x0 < half; x0 += SP_THREADS * 4) {
-      float4 r0 = *reinterpret_cast<const float4*>(spec + x0);
-      float4 r1 = nch == 2 ? *reinterpret_cast<const float4*>(spec + half + x0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // 8 bins per lane: the segment search and the recurrence restart are paid once per 8 bins and channel
+    for (int x0 = tid * 8; x0 < half; x0 += SP_THREADS * 8) {
+      float r0[8], r1[8];
+      *reinterpret_cast<float4*>(r0) = *reinterpret_cast<const float4*>(spec + x0);
+      *reinterpret_cast<float4*>(r0 + 4) = *reinterpret_cast<const float4*>(spec + x0 + 4);
+      if (nch == 2) {
+        *reinterpret_cast<float4*>(r1) = *reinterpret_cast<const float4*>(spec + half + x0);
+        *reinterpret_cast<float4*>(r1 + 4) = *reinterpret_cast<const float4*>(spec + half + x0 + 4);
+      }
       if (couple) {
-        if (mg == 0) {
-          couple1(r0.x, r1.x); couple1(r0.y, r1.y); couple1(r0.z, r1.z); couple1(r0.w, r1.w);
-        } else {
-          couple1(r1.x, r0.x); couple1(r1.y, r0.y); couple1(r1.z, r0.z); couple1(r1.w, r0.w);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (mg == 0) couple1(r0[q], r1[q]); else couple1(r1[q], r0[q]);
         }
       }
-      float m[4];
+      float m[8];
       if (md0 == 1) {
-        floor_walk4(&fs[0], s_db, x0, err, m);
-        r0.x = r0.x * m[0]; r0.y = r0.y * m[1]; r0.z = r0.z * m[2]; r0.w = r0.w * m[3];
+        floor_walk<8>(&fs[0], s_db, x0, m);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r0[q] = r0[q] * m[q];
       } else if (md0 == 2) {
-        r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // Floor1.cs:218-221
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r0[q] = 0.0f;  // Floor1.cs:218-221
       }
-      *reinterpret_cast<float4*>(planes + x0) = r0;
+      *reinterpret_cast<float4*>(planes + x0) = *reinterpret_cast<float4*>(r0);
+      *reinterpret_cast<float4*>(planes + x0 + 4) = *reinterpret_cast<float4*>(r0 + 4);
       if (nch == 2) {
         if (md1 == 1) {
-          floor_walk4(&fs[1], s_db, x0, err, m);
-          r1.x = r1.x * m[0]; r1.y = r1.y * m[1]; r1.z = r1.z * m[2]; r1.w = r1.w * m[3];
+          floor_walk<8>(&fs[1], s_db, x0, m);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r1[q] = r1[q] * m[q];
         } else if (md1 == 2) {
-          r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r1[q] = 0.0f;
         }
-        *reinterpret_cast<float4*>(planes + S.block1 + x0) = r1;
+        *reinterpret_cast<float4*>(planes + S.block1 + x0) = *reinterpret_cast<float4*>(r1);
+        *reinterpret_cast<float4*>(planes + S.block1 + x0 + 4) = *reinterpret_cast<float4*>(r1 + 4);
       }
     }
     DBG_T(4);
     DBG_T(5);
     DBG_T(6);
+    if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 23] = wall_clock64();
     return;
   }
 
@@ -606,7 +660,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   // floors, SP_GROUP channels at a time: wavefront w prepares channel c0 + w
   for (int c0 = 0; c0 < nch; c0 += SP_GROUP) {
     const FloorLane fl_lane = (c0 == 0) ? first_lane : load_floor_lane(S, Bt, chans, c0 + wv, nch, lane);
-    if (c0 + wv < nch) floor_prepare(&fs[wv], fl_lane, lane, half);
+    if (c0 + wv < nch) floor_prepare(&fs[wv], fl_lane, lane, half, err);
     __syncthreads();
 
     // render / apply: all threads over the group's channels
@@ -623,7 +677,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       if (md == 1) {
         for (int x0 = tid * 4; x0 < half; x0 += SP_THREADS * 4) {
           float m[4];
-          floor_walk4(&fs[k], s_db, x0, err, m);
+          floor_walk<4>(&fs[k], s_db, x0, m);
           float4 v = *reinterpret_cast<float4*>(res + x0);
           v.x = v.x * m[0];
           v.y = v.y * m[1];
@@ -682,7 +736,8 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   DBG_T(6);
 }
 
-extern "C" __global__ void __launch_bounds__(SP_THREADS)
+// 8 waves per SIMD = 8 resident workgroups per CU: the register budget (64 VGPRs, 96 SGPRs) is part of the design
+extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
            int cap_ent, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

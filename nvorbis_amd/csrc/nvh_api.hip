@@ -391,6 +391,14 @@ static int upload_setup(nvh_stream* s) {
         d.f1.level[k] = (uint8_t)lv;
         if (lv + 1 > levels) levels = lv + 1;
       }
+      for (int k = 0; k < lim; k++) {
+        const int lo = d.f1.l_neigh[k], hi = d.f1.h_neigh[k];
+        d.f1.x_lo[k] = d.f1.x_list[lo < lim ? lo : 0];
+        d.f1.x_hi[k] = d.f1.x_list[hi < lim ? hi : 0];
+        d.f1.x_sorted[k] = d.f1.x_list[d.f1.sort_idx[k]];
+        const int adx = (int)d.f1.x_hi[k] - (int)d.f1.x_lo[k];
+        d.f1.adx_magic[k] = (k >= 2 && adx > 0) ? 0xFFFFFFFFu / (uint32_t)adx : 0u;
+      }
       d.f1.levels = levels;
     } else {
       d.f0.order = f.f0.order;
@@ -441,7 +449,8 @@ static int upload_setup(nvh_stream* s) {
           if (r.books[c][k] >= 0 && (uint64_t)S.books[(size_t)r.books[c][k]].dimensions > max_div)
             max_div = (uint64_t)S.books[(size_t)r.books[c][k]].dimensions;
       d.fast = (r.type != 0 && r.partition_size > 1 && max_index * max_div < 0x100000000ull) ? 1 : 0;
-      bool pairs = d.fast != 0 && !seq && (r.partition_size % 2) == 0;
+      // pair records pack LDS offsets / bin indices into 16 bits and use a 16-bit reciprocal of the book dimension
+      bool pairs = d.fast != 0 && !seq && (r.partition_size % 2) == 0 && r.partition_size <= 4096 && lattice.size() <= 0xFFFFu;
       for (int c = 0; c < r.classifications; c++)
         for (int k = 0; k < NVH_MAX_STAGES; k++)
           if (r.books[c][k] >= 0 && (books[(size_t)r.books[c][k]].lat_values == 0 || (books[(size_t)r.books[c][k]].dim & 1u))) pairs = false;
@@ -665,6 +674,8 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
     if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
     if ((int)fr.ent_count > b->max_ent) b->max_ent = (int)fr.ent_count;
     if ((int)(fr.pass_end - fr.pass_begin) > b->max_pass) b->max_pass = (int)(fr.pass_end - fr.pass_begin);
+    // kernels index channel records by frame: every frame owns exactly `channels` of them (host_parse.cpp)
+    if (fr.chan_off != (uint32_t)((size_t)(&fr - P.frames.data()) * (size_t)s->setup.channels)) return NVH_ERR_RUNTIME;
   }
   {
     // preconditions of the fused IMDCT + overlap-add kernel (kernels_imdct.hip, k_imdct_ola)
@@ -751,7 +762,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                                (size_t)ch * (size_t)(s->setup.block1 / 2);
     // staging capacities; the entry slice is copied from its enclosing 16-byte boundary (up to 7 entries of slack)
     int cap_pass = b->max_pass, cap_ops = (b->max_ops + 1) & ~1, cap_ent = (b->max_ent + 14) & ~7;
-    size_t words = fixed_words + (size_t)cap_pass * 12 + (size_t)cap_ops * 2 + (size_t)cap_ent / 2;
+    size_t words = fixed_words + (size_t)cap_pass * 12 + (size_t)cap_ops * 6 + (size_t)cap_ent / 2;
     if (getenv("NVH_UNFUSED")) words = 1u << 20;  // test aid: force the unfused kernels below
     static const size_t lds_pad = getenv("NVH_LDS_PAD") ? (size_t)atoi(getenv("NVH_LDS_PAD")) : 0;  // occupancy experiments
     static const int no_gather = getenv("NVH_GATHER") ? 0 : 1;  // gather-form kernel (kernels_spectrum2.hip): bit-exact but not faster, opt-in
@@ -770,9 +781,18 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
       if (has_floor0)
         hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent);
-      else
+      else {
+        if (getenv("NVH_DEBUG_OCC")) {
+          int nb = -1;
+          hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_spectrum, 256, words * 4 + lds_pad);
+          hipFuncAttributes fa;
+          (void)hipFuncGetAttributes(&fa, (const void*)k_spectrum);
+          fprintf(stderr, "k_spectrum: lds %zu B, occupancy %d WG/CU (err %d), regs %d, static lds %zu, max dyn lds %d\n", words * 4 + lds_pad, nb,
+                  (int)oe, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+        }
         hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4 + lds_pad, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf);
+      }
     } else {
       hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work);
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));

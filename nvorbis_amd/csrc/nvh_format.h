@@ -43,6 +43,11 @@ struct NvhDevFloor1 {    // Floor1.cs:21-25, :93-133
   uint8_t h_neigh[NVH_MAX_POSTS];
   uint8_t sort_idx[NVH_MAX_POSTS];
   uint8_t level[NVH_MAX_POSTS];  // post i can be unwrapped once all posts of lower level are final
+  // derived per-post constants of the unwrap (one load level instead of two on the device)
+  uint16_t x_lo[NVH_MAX_POSTS];      // x_list[l_neigh[i]]
+  uint16_t x_hi[NVH_MAX_POSTS];      // x_list[h_neigh[i]]
+  uint16_t x_sorted[NVH_MAX_POSTS];  // x_list[sort_idx[i]]
+  uint32_t adx_magic[NVH_MAX_POSTS]; // floor((2^32 - 1) / (x_hi - x_lo)): quotient estimate, one fix-up step (i >= 2)
 };
 
 struct NvhDevFloor0 {    // Floor0.cs:22-26

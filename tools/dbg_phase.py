@@ -24,4 +24,15 @@ print("residue detail: pass/R load %.0f cycles; per-stage mean cycles (0 = stage
 print('ops per stage (mean over frames):', [round(float(d[:,16+k].mean()),1) for k in range(8)])
 life = d[:,6]-d[:,0]
 print("WG lifetime mean %.0f p50 %.0f ; kernel span %.0f cycles; start spread p50 %.0f p99 %.0f" % (life.mean(), np.median(life), d[:,6].max()-t0, np.median(d[:,0]-t0), np.percentile(d[:,0]-t0, 99)))
+pre = d[:,20]-d[:,1]; prep = d[:,21]-d[:,20]; post = d[:,2]-d[:,21]
+print('staging split: loads+copies before prep %.0f, floor_prepare %.0f, barrier wait after %.0f cycles' % (pre.mean(), prep.mean(), post.mean()))
+w0, w1 = d[:,22], d[:,23]
+ok = w1 > w0
+if ok.any():
+    span_us = (w1[ok].max() - w0[ok].min()) / 100.0
+    mhz = (life[ok] / ((w1[ok] - w0[ok]) / 100.0)).mean()
+    order = np.argsort(w0)
+    print("wall clock: kernel span %.1f us; shader clock ~%.0f MHz; WG lifetime %.2f us mean; WGs in flight at mid-kernel: %d" % (
+        span_us, mhz, ((w1[ok]-w0[ok])/100.0).mean(), int(((w0 <= (w0.min()+w1.max())//2) & (w1 >= (w0.min()+w1.max())//2)).sum())))
+    print("start times (us) percentiles 10/50/90/99: %s" % [round(float(np.percentile((w0-w0.min())/100.0, q)),1) for q in (10,50,90,99)])
 L.nvh_debug_set_buffer(None)
