@@ -10,7 +10,8 @@ struct NvhDevSetup {
   int32_t channels, block0, block1, nbooks;
   const float* vq;                // VQ lookup tables of every codebook
   const uint32_t* lattice;        // lattice pool (NvhDevBook::lat_off), lattice_words entries
-  int32_t lattice_words, pad2;
+  int32_t lattice_words;
+  int32_t fused_tail_ok;          // <= 2 channels, Floor1 only, every mapping has <= 1 coupling step (k_spectrum's fused tail)
   const NvhDevBook* books;
   const NvhDevFloor* floors;
   const NvhDevResidue* residues;

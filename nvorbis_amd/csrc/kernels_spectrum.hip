@@ -26,6 +26,9 @@
 
 #define SP_THREADS 256
 #define SP_GROUP 4  // channels whose floors are prepared concurrently (one wavefront each)
+#ifndef SP_TAIL_BINS
+#define SP_TAIL_BINS 4  // bins per lane in the fused tail
+#endif
 
 namespace {
 
@@ -402,26 +405,32 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   const NvhDevMapping mp = S.mappings[fr.mapping];
   DBG_T(1);
 
-  // ---- stage the frame's side information (16-byte copies) and clear the spectrum ----
+  // ---- stage the frame's side information (16-byte copies), clear the spectrum, prepare the floors ----
+  // Mono / stereo Floor1 streams take the fused tail: their posts are unwrapped here, one wavefront per channel,
+  // while the remaining wavefronts do the staging -- two dependent-load chains side by side instead of in series.
+  const bool fused_tail = !FLOOR0 && S.fused_tail_ok;
+  const int nprep = fused_tail ? nch : 0;  // wavefronts [0, nprep) prepare floors, the others stage
   const int npass = (int)(fr.pass_end - fr.pass_begin);
   // the host sizes the three capacities from the batch's largest frame (nvh_api.hip) and launches the unfused
   // kernels instead when that does not fit; a frame beyond them would be a host bug
   if ((int)fr.op_count > cap_ops || (int)fr.ent_count + 7 > cap_ent || npass > cap_pass) __builtin_trap();
   // the entry slice starts at any 2-byte offset: copy from the enclosing 16-byte boundary
   const unsigned ent_shift = fr.ent_begin & 7u;
-  s_db[tid] = k_inverse_db[tid];
-  {
+  DBG_T(20);
+  if (wv < nprep) {
+    floor_prepare(&fs[wv], first_lane, lane, half, err);
+  } else {
+    const int st = tid - nprep * 64, sn = SP_THREADS - nprep * 64;
+    for (int i = st; i < 256; i += sn) s_db[i] = k_inverse_db[i];
     const uint4* gb = reinterpret_cast<const uint4*>(S.books);
-    for (int i = tid; i < S.nbooks * 2; i += SP_THREADS) reinterpret_cast<uint4*>(s_books)[i] = gb[i];
-    for (int i = tid; i < S.lattice_words; i += SP_THREADS) s_lat[i] = S.lattice[i];
-  }
-  {
+    for (int i = st; i < S.nbooks * 2; i += sn) reinterpret_cast<uint4*>(s_books)[i] = gb[i];
+    for (int i = st; i < S.lattice_words; i += sn) s_lat[i] = S.lattice[i];
     const uint2* go = reinterpret_cast<const uint2*>(Bt.ops + fr.op_begin);
-    for (int i = tid; i < (int)fr.op_count; i += SP_THREADS) reinterpret_cast<uint2*>(s_ops)[i] = go[i];
+    for (int i = st; i < (int)fr.op_count; i += sn) reinterpret_cast<uint2*>(s_ops)[i] = go[i];
     const uint4* ge = reinterpret_cast<const uint4*>(Bt.entries + (fr.ent_begin - ent_shift));
     const int nvec = (int)((ent_shift + fr.ent_count + 7u) >> 3);
-    for (int i = tid; i < nvec; i += SP_THREADS) reinterpret_cast<uint4*>(s_ent)[i] = ge[i];
-    for (int i = tid; i < npass * 10; i += SP_THREADS) {
+    for (int i = st; i < nvec; i += sn) reinterpret_cast<uint4*>(s_ent)[i] = ge[i];
+    for (int i = st; i < npass * 10; i += sn) {
       const int p = i / 10, k = i - p * 10;
       const NvhResPass* gp = Bt.passes + fr.pass_begin + p;
       s_pass[p * 12 + k] = k == 0 ? (uint32_t)gp->residue : gp->op_begin[k - 1] - fr.op_begin;
@@ -435,7 +444,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       const NvhDevResidue* Rp = &S.residues[gp->residue];
       if (!Rp->pair_path) continue;
       const int o_end = (int)(gp->op_begin[NVH_MAX_STAGES] - fr.op_begin);
-      for (int o = (int)(gp->op_begin[0] - fr.op_begin) + tid; o < o_end; o += SP_THREADS) {
+      for (int o = (int)(gp->op_begin[0] - fr.op_begin) + st; o < o_end; o += sn) {
         const NvhResOp op = Bt.ops[fr.op_begin + o];
         const NvhDevBook bk = S.books[op.book];
         const unsigned offset = (unsigned)(Rp->begin + (int)op.partition * Rp->partition_size);
@@ -448,16 +457,9 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         s_oprec[o] = rec;
       }
     }
-  }
-  {
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int i = tid; i < (nch * half) >> 2; i += SP_THREADS) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
+    for (int i = st; i < (nch * half) >> 2; i += sn) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
   }
-  // mono / stereo Floor1 streams take the fused tail; their posts are unwrapped now, one wavefront per
-  // channel, while the staging loads are in flight
-  const bool fused_tail = !FLOOR0 && nch <= 2 && mp.coupling_steps <= 1;
-  DBG_T(20);
-  if (fused_tail && wv < nch) floor_prepare(&fs[wv], first_lane, lane, half, err);
   DBG_T(21);
   __syncthreads();
   DBG_T(2);
@@ -593,43 +595,43 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       couple = chans[0].exec || chans[1].exec;
     }
     const int md0 = __builtin_amdgcn_readfirstlane(fs[0].mode), md1 = nch == 2 ? __builtin_amdgcn_readfirstlane(fs[1].mode) : 0;
-    // 8 bins per lane: the segment search and the recurrence restart are paid once per 8 bins and channel
-    for (int x0 = tid * 8; x0 < half; x0 += SP_THREADS * 8) {
-      float r0[8], r1[8];
-      *reinterpret_cast<float4*>(r0) = *reinterpret_cast<const float4*>(spec + x0);
-      *reinterpret_cast<float4*>(r0 + 4) = *reinterpret_cast<const float4*>(spec + x0 + 4);
-      if (nch == 2) {
-        *reinterpret_cast<float4*>(r1) = *reinterpret_cast<const float4*>(spec + half + x0);
-        *reinterpret_cast<float4*>(r1 + 4) = *reinterpret_cast<const float4*>(spec + half + x0 + 4);
+    // TB bins per lane: the segment search and the recurrence restart are paid once per TB bins and channel
+    constexpr int TB = SP_TAIL_BINS;
+    for (int x0 = tid * TB; x0 < half; x0 += SP_THREADS * TB) {
+      float r0[TB], r1[TB];
+#pragma unroll
+      for (int q = 0; q < TB; q += 4) {
+        *reinterpret_cast<float4*>(r0 + q) = *reinterpret_cast<const float4*>(spec + x0 + q);
+        if (nch == 2) *reinterpret_cast<float4*>(r1 + q) = *reinterpret_cast<const float4*>(spec + half + x0 + q);
       }
       if (couple) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < TB; ++q) {
           if (mg == 0) couple1(r0[q], r1[q]); else couple1(r1[q], r0[q]);
         }
       }
-      float m[8];
+      float m[TB];
       if (md0 == 1) {
-        floor_walk<8>(&fs[0], s_db, x0, m);
+        floor_walk<TB>(&fs[0], s_db, x0, m);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r0[q] = r0[q] * m[q];
+        for (int q = 0; q < TB; ++q) r0[q] = r0[q] * m[q];
       } else if (md0 == 2) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r0[q] = 0.0f;  // Floor1.cs:218-221
+        for (int q = 0; q < TB; ++q) r0[q] = 0.0f;  // Floor1.cs:218-221
       }
-      *reinterpret_cast<float4*>(planes + x0) = *reinterpret_cast<float4*>(r0);
-      *reinterpret_cast<float4*>(planes + x0 + 4) = *reinterpret_cast<float4*>(r0 + 4);
+#pragma unroll
+      for (int q = 0; q < TB; q += 4) *reinterpret_cast<float4*>(planes + x0 + q) = *reinterpret_cast<float4*>(r0 + q);
       if (nch == 2) {
         if (md1 == 1) {
-          floor_walk<8>(&fs[1], s_db, x0, m);
+          floor_walk<TB>(&fs[1], s_db, x0, m);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) r1[q] = r1[q] * m[q];
+          for (int q = 0; q < TB; ++q) r1[q] = r1[q] * m[q];
         } else if (md1 == 2) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) r1[q] = 0.0f;
+          for (int q = 0; q < TB; ++q) r1[q] = 0.0f;
         }
-        *reinterpret_cast<float4*>(planes + S.block1 + x0) = *reinterpret_cast<float4*>(r1);
-        *reinterpret_cast<float4*>(planes + S.block1 + x0 + 4) = *reinterpret_cast<float4*>(r1 + 4);
+#pragma unroll
+        for (int q = 0; q < TB; q += 4) *reinterpret_cast<float4*>(planes + S.block1 + x0 + q) = *reinterpret_cast<float4*>(r1 + q);
       }
     }
     DBG_T(4);

@@ -528,7 +528,11 @@ static int upload_setup(nvh_stream* s) {
   D.vq = (const float*)(base + o_vq);
   D.lattice = (const uint32_t*)(base + o_lat);
   D.lattice_words = (int32_t)lattice.size();
-  D.pad2 = 0;
+  {
+    bool ok = S.channels <= 2 && !s->has_floor0;
+    for (const nvh::Mapping& m : S.mappings) ok = ok && m.coupling_angle.size() <= 1;
+    D.fused_tail_ok = ok ? 1 : 0;
+  }
   D.books = (const NvhDevBook*)(base + o_books);
   D.floors = (const NvhDevFloor*)(base + o_floors);
   D.residues = (const NvhDevResidue*)(base + o_res);
