@@ -67,8 +67,8 @@ def cpu_baseline(headers, ll, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,17 +129,22 @@ def main():
         assert checksum > 0 and bool(torch.isfinite(pcm).all().item())
 
     if rank == 0:
-        # slot 0 is the fused spectrum kernel (residue + coupling + floor) when slot 1 is empty
-        names = ["residue", "spectrum" if km[0] < 2e-3 else "couple_floor", "imdct_ola" if km[3] < 2e-3 else "imdct_window", "ola_emit"]
-        dom = max(range(4), key=lambda k: km[k])
-        alg_bytes = FRAMES * ch * 4 * BLOCK  # read n/2*4 B spectrum + write n/2*4 B PCM per ch-frame = 4n B
+        # the library says which kernel variant sits behind each timing slot ("-" = empty: only event overhead)
+        names = batch.kernels()
+        live = [k for k in range(4) if names[k] != "-"]
+        dom = max(live, key=lambda k: km[k])
+        # SURVEY 8d / DESIGN.md: algorithmic bytes of one ch-frame = n/2*4 B spectrum in + n/2*4 B PCM out = 4n B ... per
+        # pipeline stage that means: every kernel of the chain moves one n/2-float vector in and one out per ch-frame
+        alg_bytes = FRAMES * ch * 4 * BLOCK
         dom_ms = km[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh);
+        # null when the committed profile does not cover the kernel that ran
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(names[dom])
+                traffic = json.load(open(tfile)).get("kernels", {}).get(names[dom], {}).get("hbm_bytes")
             except Exception:
                 traffic = None
         out = {
@@ -158,7 +163,7 @@ def main():
             "config": {"workload": "C2: 4096 stereo long-block (n=2048) frames, Floor1+Residue2+coupling, IMDCT+window+OLA",
                        "frames_per_gpu": FRAMES, "channels": ch, "block": BLOCK, "parallelism": "frame-parallel x%d" % world,
                        "descriptor_bytes_per_frame": batch.descriptor_bytes / FRAMES},
-            "kernels_ms": dict(zip(names, km)),
+            "kernels_ms": {names[k]: km[k] for k in live},
             "pipeline_ms_events": total_ms / iters,
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -112,11 +112,15 @@ int nvh_batch_info(const nvh_batch *b, int *frames, int *chan_frames, int64_t *p
 /* Descriptor element counts: frames, channel-frames, residue passes, residue ops, VQ entries, floor1 posts,
  * floor0 coefficients, reserved. */
 int nvh_batch_stats(const nvh_batch *b, int64_t *out8);
+/* Names of the kernels behind the four timing slots of nvh_batch_time, as launched last (comma separated,
+ * "-" = empty slot): which of the kernel variants ran depends on the stream shape. */
+int nvh_batch_kernels(const nvh_batch *b, char *buf, int cap);
 /* Launch the synthesis kernels for a resident batch (asynchronous on the context's stream);
  * may be repeated, results are identical each time.  d_pcm holds samples*channels floats. */
 int nvh_batch_synth(nvh_batch *b, float *d_pcm, int64_t capacity);
 /* Time `iters` repetitions with hipEvents on the launch stream: total milliseconds for the whole
- * pipeline, and per kernel (residue, couple+floor, imdct+window, overlap+emit). */
+ * pipeline, and per timing slot (spectrum: residue | couple+floor, or fused in slot 1; imdct+window; overlap+emit;
+ * see nvh_batch_kernels).  A slot brackets its launches with event records, which costs ~2 us per slot. */
 int nvh_batch_time(nvh_batch *b, float *d_pcm, int64_t capacity, int iters, float *total_ms, float *kernel_ms /*[4]*/);
 void nvh_batch_free(nvh_batch *b);
 

@@ -369,7 +369,7 @@ __device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150
 }  // namespace
 
 // LDS map (dynamic, 4-byte words):
-//   [ s_db 256 | (FLOOR0: s_coeff 256) | FloorScratch x min(channels, SP_GROUP) | stage ranges cap_pass*12 |
+//   [ s_db 256 | (FLOOR0: s_coeff 256) | FloorScratch x min(channels, SP_GROUP) | pass records cap_pass*16 |
 //     books nbooks*8 | lattice pool | ops cap_ops*2 | pair records cap_ops*4 | entries cap_ent/2 | spectrum ch*half ]
 template <bool FLOOR0>
 __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDevBatch& Bt, float* __restrict__ work,
@@ -380,8 +380,8 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   float* s_db = smem;
   float* s_coeff = smem + 256;  // FLOOR0 only
   FloorScratch* fs = reinterpret_cast<FloorScratch*>(smem + (FLOOR0 ? 512 : 256));
-  uint32_t* s_pass = reinterpret_cast<uint32_t*>(fs + ngrp_lds);  // per pass: residue, op_begin[0..8] (frame relative), pad
-  NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(s_pass + cap_pass * 12);
+  uint32_t* s_pass = reinterpret_cast<uint32_t*>(fs + ngrp_lds);  // per pass, 16 words: residue, op_begin[0..8] (frame relative), residue geometry (below)
+  NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(s_pass + cap_pass * 16);
   uint32_t* s_lat = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(s_books) + S.nbooks * 8);
   NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(s_lat + ((S.lattice_words + 3) & ~3));
   uint4* s_oprec = reinterpret_cast<uint4*>(reinterpret_cast<float*>(s_ops) + cap_ops * 2);  // pair-path op records
@@ -391,7 +391,10 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   const int f = blockIdx.x;
 #define DBG_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + (k)] = clock64(); } while (0)
   DBG_T(0);
-  if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 22] = wall_clock64();
+  if (dbg && threadIdx.x == 0) {
+    dbg[(long long)blockIdx.x * 24 + 22] = wall_clock64();
+    dbg[(long long)blockIdx.x * 24 + 19] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);  // XCC_ID, HW_ID
+  }
   // Every frame (drain pseudo-frames included) owns exactly `channels` channel records (host_parse.cpp), so the
   // channel records and the floor data behind them do not have to wait for the frame record.
   const int tid = threadIdx.x;
@@ -430,62 +433,78 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     const uint4* ge = reinterpret_cast<const uint4*>(Bt.entries + (fr.ent_begin - ent_shift));
     const int nvec = (int)((ent_shift + fr.ent_count + 7u) >> 3);
     for (int i = st; i < nvec; i += sn) reinterpret_cast<uint4*>(s_ent)[i] = ge[i];
-    for (int i = st; i < npass * 10; i += sn) {
-      const int p = i / 10, k = i - p * 10;
-      const NvhResPass* gp = Bt.passes + fr.pass_begin + p;
-      s_pass[p * 12 + k] = k == 0 ? (uint32_t)gp->residue : gp->op_begin[k - 1] - fr.op_begin;
-    }
-    // pair path: everything a lane needs about an op and its codebook in one 16-byte record, resolved once per
-    // op here instead of once per element in the stage loops
-    //   x: entry slice offset | first bin << 16      y: lattice pool offset | lat_values << 16
-    //   z: ceil(2^32 / lat_values)                   w: dim | channel << 8 | ceil(2^16 / dim) << 16
-    for (int p = 0; p < npass; ++p) {
+    // pass records: op ranges per stage plus the residue geometry the stage loops need, so that those do not
+    // start with another global round trip (frame -> pass -> residue)
+    for (int p = st; p < npass; p += sn) {
       const NvhResPass* gp = Bt.passes + fr.pass_begin + p;
       const NvhDevResidue* Rp = &S.residues[gp->residue];
-      if (!Rp->pair_path) continue;
-      const int o_end = (int)(gp->op_begin[NVH_MAX_STAGES] - fr.op_begin);
-      for (int o = (int)(gp->op_begin[0] - fr.op_begin) + st; o < o_end; o += sn) {
-        const NvhResOp op = Bt.ops[fr.op_begin + o];
-        const NvhDevBook bk = S.books[op.book];
-        const unsigned offset = (unsigned)(Rp->begin + (int)op.partition * Rp->partition_size);
-        const unsigned xbase = (Rp->type == 2 && Rp->real_channels > 1) ? __umulhi(offset, Rp->rch_magic) : offset;
-        uint4 rec;
-        rec.x = (op.ent_off - fr.ent_begin) | (xbase << 16);
-        rec.y = bk.lat_off | (bk.lat_values << 16);
-        rec.z = bk.lat_magic;
-        rec.w = bk.dim | ((unsigned)op.channel << 8) | (((65536u + bk.dim - 1u) / bk.dim) << 16);
-        s_oprec[o] = rec;
-      }
+      uint32_t* P = s_pass + p * 16;
+      P[0] = (uint32_t)gp->residue;
+      for (int k = 0; k <= NVH_MAX_STAGES; ++k) P[1 + k] = gp->op_begin[k] - fr.op_begin;
+      P[10] = (uint32_t)Rp->type | (Rp->pair_path ? 0x100u : 0u) | (Rp->sequential ? 0x200u : 0u) | (Rp->fast ? 0x400u : 0u);
+      P[11] = (uint32_t)Rp->real_channels;
+      P[12] = (uint32_t)Rp->partition_size;
+      P[13] = Rp->hp_magic;
+      P[14] = Rp->rch_magic;
+      P[15] = (uint32_t)Rp->begin;
     }
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int i = st; i < (nch * half) >> 2; i += sn) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
   }
   DBG_T(21);
   __syncthreads();
-  DBG_T(2);
   // both sources are indexed relative to the frame's slice (op.ent_off and pass->op_begin[] are batch offsets)
   const NvhResOp* ops = s_ops;
   const uint16_t* ent = s_ent + ent_shift;
+  // pair path: everything a lane needs about an op and its codebook in one 16-byte record, resolved once per op
+  // (from the staged copies) instead of once per element in the stage loops
+  //   x: entry slice offset | first bin << 16      y: lattice pool offset | lat_values << 16
+  //   z: ceil(2^32 / lat_values)                   w: dim | channel << 8 | ceil(2^16 / dim) << 16
+  for (int ps = 0; ps < npass; ++ps) {
+    const uint32_t* P = s_pass + ps * 16;
+    const unsigned rflags = __builtin_amdgcn_readfirstlane(P[10]);
+    if (!(rflags & 0x100u)) continue;
+    const int o_end = __builtin_amdgcn_readfirstlane((int)P[1 + NVH_MAX_STAGES]);
+    const unsigned rch = __builtin_amdgcn_readfirstlane(P[11]), psz = __builtin_amdgcn_readfirstlane(P[12]);
+    const unsigned rch_magic = __builtin_amdgcn_readfirstlane(P[14]), rbegin = __builtin_amdgcn_readfirstlane(P[15]);
+    for (int o = __builtin_amdgcn_readfirstlane((int)P[1]) + tid; o < o_end; o += SP_THREADS) {
+      const NvhResOp op = ops[o];
+      const NvhDevBook bk = s_books[op.book];
+      const unsigned offset = rbegin + (unsigned)op.partition * psz;
+      const unsigned xbase = ((rflags & 0xFFu) == 2 && rch > 1) ? __umulhi(offset, rch_magic) : offset;
+      uint4 rec;
+      rec.x = (op.ent_off - fr.ent_begin) | (xbase << 16);
+      rec.y = bk.lat_off | (bk.lat_values << 16);
+      rec.z = bk.lat_magic;
+      rec.w = bk.dim | ((unsigned)op.channel << 8) | (((65536u + bk.dim - 1u) / bk.dim) << 16);
+      s_oprec[o] = rec;
+    }
+  }
+  __syncthreads();
+  DBG_T(2);
 
   // ---- residue ----
   for (int ps = 0; ps < npass; ++ps) {
     // values read back from LDS are wave-uniform: say so, or every use downstream turns into vector code
-    const NvhDevResidue R = S.residues[__builtin_amdgcn_readfirstlane((int)s_pass[ps * 12])];
-    const int psize = R.partition_size;
+    const uint32_t* P = s_pass + ps * 16;
+    const unsigned rflags = __builtin_amdgcn_readfirstlane(P[10]);
+    const int rtype = (int)(rflags & 0xFFu);
+    const int psize = __builtin_amdgcn_readfirstlane((int)P[12]);
+    const unsigned rch = __builtin_amdgcn_readfirstlane(P[11]);
+    const unsigned hp_magic = __builtin_amdgcn_readfirstlane(P[13]), rch_magic = __builtin_amdgcn_readfirstlane(P[14]);
+    const NvhDevResidue* Rg = &S.residues[__builtin_amdgcn_readfirstlane((int)P[0])];  // general paths only
     long long t_prev = dbg ? clock64() : 0;
     if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 7] = t_prev;
 #pragma unroll 1
     for (int s = 0; s < NVH_MAX_STAGES; ++s) {
-      const unsigned ob = __builtin_amdgcn_readfirstlane(s_pass[ps * 12 + 1 + s]);
-      const unsigned oe = __builtin_amdgcn_readfirstlane(s_pass[ps * 12 + 2 + s]);
+      const unsigned ob = __builtin_amdgcn_readfirstlane(P[1 + s]);
+      const unsigned oe = __builtin_amdgcn_readfirstlane(P[2 + s]);
       if (ob == oe) continue;
-      if (R.pair_path) {
+      if (rflags & 0x100u) {
         // every book of this residue is a lattice of even dimension: one lane adds two consecutive components of
         // one codebook entry (for stereo type 2 that is one bin of both channels).  The VQ lookup is two base-
         // lat_values digits of the entry number, peeled with exact reciprocal multiplies; nothing leaves LDS.
         const unsigned hp = (unsigned)psize >> 1;
-        const unsigned hp_magic = R.hp_magic;
-        const unsigned rch = (unsigned)R.real_channels;
         const unsigned total = (oe - ob) * hp;
         for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
           const unsigned o = hp > 1 ? __umulhi(idx, hp_magic) : idx;
@@ -505,7 +524,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           const float v0 = __uint_as_float(lat[d0]), v1 = __uint_as_float(lat[d1]);
           const unsigned xbase = rec.x >> 16;
           unsigned c0, x0, c1, x1;
-          if (R.type == 1 || rch == 1) {
+          if (rtype == 1 || rch == 1) {
             c0 = c1 = (rec.w >> 8) & 0xFFu;
             x0 = xbase + i;
             x1 = x0 + 1;
@@ -513,7 +532,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
             c0 = 0; c1 = 1;
             x0 = x1 = xbase + i2;
           } else {
-            const unsigned qi = __umulhi(i, R.rch_magic);
+            const unsigned qi = __umulhi(i, rch_magic);
             c0 = i - qi * rch;
             x0 = xbase + qi;
             c1 = c0 + 1; x1 = x0;
@@ -529,7 +548,8 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           }
         }
         __syncthreads();
-      } else if (!R.sequential && R.fast) {
+      } else if ((rflags & 0x600u) == 0x400u) {  // fast, not sequential
+        const NvhDevResidue R = *Rg;
         // elements of one stage never alias (that is what !sequential means), so four of them are fetched as
         // independent dependency chains before their adds are committed
         const int total = (int)(oe - ob) * psize;
@@ -552,7 +572,8 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
             if (tp[u]) *tp[u] = *tp[u] + tv[u];
         }
         __syncthreads();
-      } else if (!R.sequential) {
+      } else if (!(rflags & 0x200u)) {
+        const NvhDevResidue R = *Rg;
         const int total = (int)(oe - ob) * psize;
         for (int idx = tid; idx < total; idx += SP_THREADS) {
           unsigned o = (unsigned)idx / (unsigned)psize;
@@ -563,6 +584,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         __syncthreads();
       } else {
         // partitions may alias (quirk B-1 / vector overrun): keep the reference's partition order
+        const NvhDevResidue R = *Rg;
         for (unsigned o = ob; o < oe; ++o) {
           const NvhResOp op = ops[o];
           const NvhDevBook bk = s_books[op.book];

@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/nvorbis_hip.h"
@@ -104,6 +105,7 @@ struct nvh_batch {
   int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // frames, chans, passes, ops, entries, posts, coeffs, -
   bool sequential_ola = false;
   int last_decoded = -1;  // last frame with n != 0 (its block becomes the next carried tail)
+  const char* slot_name[4] = {"-", "-", "-", "-"};  // kernels behind the four timing slots of the last launch
   int max_ops = 0, max_ent = 0, max_pass = 0;  // largest per-frame op / entry / pass slice (LDS staging capacity of k_spectrum)
   bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
   bool has_carry_in = false;
@@ -766,7 +768,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                                (size_t)ch * (size_t)(s->setup.block1 / 2);
     // staging capacities; the entry slice is copied from its enclosing 16-byte boundary (up to 7 entries of slack)
     int cap_pass = b->max_pass, cap_ops = (b->max_ops + 1) & ~1, cap_ent = (b->max_ent + 14) & ~7;
-    size_t words = fixed_words + (size_t)cap_pass * 12 + (size_t)cap_ops * 6 + (size_t)cap_ent / 2;
+    size_t words = fixed_words + (size_t)cap_pass * 16 + (size_t)cap_ops * 6 + (size_t)cap_ent / 2;
     if (getenv("NVH_UNFUSED")) words = 1u << 20;  // test aid: force the unfused kernels below
     static const size_t lds_pad = getenv("NVH_LDS_PAD") ? (size_t)atoi(getenv("NVH_LDS_PAD")) : 0;  // occupancy experiments
     static const int no_gather = getenv("NVH_GATHER") ? 0 : 1;  // gather-form kernel (kernels_spectrum2.hip): bit-exact but not faster, opt-in
@@ -777,11 +779,13 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     if (s->gather_ok && !no_gather && b->max_ops < 0xFFFF && g_words * 4 <= 64 * 1024) {
       const int g_ops = (b->max_ops + 1) & ~1, g_ent = (b->max_ent + 7) & ~7;
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));
+      b->slot_name[0] = "-"; b->slot_name[1] = "k_spectrum2";
       auto kern = ch == 1 ? (has_floor0 ? k_spectrum2_c1_f0 : k_spectrum2_c1) : (has_floor0 ? k_spectrum2_c2_f0 : k_spectrum2_c2);
       hipLaunchKernelGGL(kern, dim3((unsigned)b->nframes), dim3(128), g_words * 4, st, s->dev, b->dev, work, flags, g_ops, g_ent,
                          s->gather_idx_cap);
     } else if (words * 4 <= 64 * 1024) {
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
+      b->slot_name[0] = "-"; b->slot_name[1] = has_floor0 ? "k_spectrum_f0" : "k_spectrum";
       if (has_floor0)
         hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent);
@@ -798,6 +802,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                            cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf);
       }
     } else {
+      b->slot_name[0] = "k_residue"; b->slot_name[1] = "k_couple_floor";
       hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work);
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));
       hipLaunchKernelGGL(k_couple_floor, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, flags);
@@ -813,6 +818,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     while (run_len > 1 && (long long)(b->nframes / run_len) * ch < 2048) run_len >>= 1;
     const int runs = (b->nframes + run_len - 1) / run_len;
     const size_t ola_lds = (size_t)ch * (wave_lds_bytes(s->setup.block1) + (size_t)(s->setup.block1 / 2) * sizeof(float));
+    b->slot_name[2] = "k_imdct_ola"; b->slot_name[3] = "-";
     hipLaunchKernelGGL(k_imdct_ola, dim3((unsigned)runs), dim3((unsigned)(64 * ch)), ola_lds, st, s->dev, b->dev, (const float*)work,
                        carry, carry_out, d_pcm, s->clip, flags + 1, run_len, b->last_decoded);
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));  // slot 2 = fused IMDCT+OLA, slot 3 empty
@@ -821,6 +827,8 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
     static const int no_compact = getenv("NVH_NO_COMPACT") ? 1 : 0;
     const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact;
+    b->slot_name[2] = compact ? "k_imdct_compact" : (s->setup.block0 >= 256 ? "k_imdct_wave" : "k_imdct_window");
+    b->slot_name[3] = compact ? "k_ola_compact" : (!b->sequential_ola ? "k_ola_emit" : "k_ola_emit_seq");
     if (compact)
       hipLaunchKernelGGL(k_imdct_compact, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
                          b->dev, work);
@@ -930,6 +938,18 @@ extern "C" int nvh_batch_info(const nvh_batch* b, int* frames, int* chan_frames,
 extern "C" int nvh_batch_stats(const nvh_batch* b, int64_t* out8) {
   if (!b || !out8) return NVH_ERR_ARGUMENT;
   for (int i = 0; i < 8; i++) out8[i] = b->stats[i];
+  return NVH_OK;
+}
+
+extern "C" int nvh_batch_kernels(const nvh_batch* b, char* buf, int cap) {
+  if (!b || !buf || cap <= 0) return NVH_ERR_ARGUMENT;
+  std::string t;
+  for (int k = 0; k < 4; k++) {
+    if (k) t += ",";
+    t += b->slot_name[k];
+  }
+  if ((int)t.size() + 1 > cap) return NVH_ERR_ARGUMENT;
+  std::memcpy(buf, t.c_str(), t.size() + 1);
   return NVH_OK;
 }
 

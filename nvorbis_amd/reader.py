@@ -82,6 +82,12 @@ class Batch:
         keys = ["frames", "chan_frames", "passes", "ops", "entries", "posts", "coeffs"]
         return {k: out[i] for i, k in enumerate(keys)}
 
+    def kernels(self):
+        """Kernel names behind the four timing slots of the last launch ("-" = empty slot)."""
+        buf = C.create_string_buffer(256)
+        check(lib().nvh_batch_kernels(self._h, buf, 256), "nvh_batch_kernels")
+        return buf.value.decode().split(",")
+
     def synth(self, d_pcm_ptr, capacity):
         check(lib().nvh_batch_synth(self._h, C.c_void_p(d_pcm_ptr), int(capacity)), "nvh_batch_synth")
 

@@ -35,4 +35,21 @@ if ok.any():
     print("wall clock: kernel span %.1f us; shader clock ~%.0f MHz; WG lifetime %.2f us mean; WGs in flight at mid-kernel: %d" % (
         span_us, mhz, ((w1[ok]-w0[ok])/100.0).mean(), int(((w0 <= (w0.min()+w1.max())//2) & (w1 >= (w0.min()+w1.max())//2)).sum())))
     print("start times (us) percentiles 10/50/90/99: %s" % [round(float(np.percentile((w0-w0.min())/100.0, q)),1) for q in (10,50,90,99)])
+hw = d[:,19]; hwid = hw & 0xffffffff; xcc = (hw >> 32) & 0xf
+cu = (hwid >> 8) & 0xf; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 0x7
+key = xcc * 1000 + se * 100 + sh * 20 + cu
+t = (w0 - w0.min()) / 100.0
+print("distinct (xcc,se,sh,cu):", len(np.unique(key)), "xcc values", np.unique(xcc), "se", np.unique(se), "sh", np.unique(sh), "cu", np.unique(cu))
+hist, edges = np.histogram(t, bins=np.arange(0, t.max() + 1.0, 1.0))
+print("WG starts per us:", hist.tolist())
+blk = np.arange(4096)
+print("start time by blockIdx (us) for blocks 0,8,64,512,1024,2047,2048,3000,4095:", [round(float(t[i]),1) for i in (0,8,64,512,1024,2047,2048,3000,4095)])
+first = {}
+for k in np.unique(key):
+    sel = np.sort(t[key == k]); first[k] = sel
+cnt = np.array([len(v) for v in first.values()])
+print("WGs per CU: min %d max %d mean %.1f" % (cnt.min(), cnt.max(), cnt.mean()))
+n_at = lambda T: np.array([(v <= T).sum() for v in first.values()])
+for T in (0.3, 1, 2, 4, 6, 8):
+    a = n_at(T); print("  by %.1f us: WGs started per CU min %d max %d mean %.2f" % (T, a.min(), a.max(), a.mean()))
 L.nvh_debug_set_buffer(None)

@@ -15,9 +15,11 @@ import sqlite3
 
 def kernels_from_trace(path):
     cur = sqlite3.connect(path).cursor()
+    # only the full-size launches of each kernel (bench.py also runs a one-frame priming batch)
     rows = cur.execute("select name, count(*), avg(duration), min(duration), max(duration), max(vgpr_count), "
                        "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) "
-                       "from kernels group by name order by sum(duration) desc").fetchall()
+                       "from kernels k where grid_x = (select max(grid_x) from kernels k2 where k2.name = k.name) "
+                       "group by name order by sum(duration) desc").fetchall()
     out = {}
     for r in rows:
         out[r[0]] = dict(calls=r[1], avg_us=r[2] / 1e3, min_us=r[3] / 1e3, max_us=r[4] / 1e3, vgpr=r[5], agpr=r[6], sgpr=r[7],
@@ -27,7 +29,8 @@ def kernels_from_trace(path):
 
 def counter_avg(path, counter):
     cur = sqlite3.connect(path).cursor()
-    rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? "
+    rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection c where counter_name=? and "
+                       "grid_size_x = (select max(grid_size_x) from counters_collection c2 where c2.kernel_name = c.kernel_name) "
                        "group by kernel_name", (counter,)).fetchall()
     return {r[0]: (r[1], r[2]) for r in rows}
 
@@ -37,6 +40,7 @@ def main():
     ap.add_argument("--trace", required=True)
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--insts", help="pmc pass with SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES")
     ap.add_argument("--out", required=True)
     ap.add_argument("--prefix", default="k_", help="only kernels whose name starts with this prefix")
     ap.add_argument("--note", default="")
@@ -53,6 +57,11 @@ def main():
             v["hbm_write_bytes"] = write[k][0] * 1024
         if "hbm_read_bytes" in v and "hbm_write_bytes" in v:
             v["hbm_bytes"] = v["hbm_read_bytes"] + v["hbm_write_bytes"]
+    if a.insts:
+        for cname in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAVES"):
+            for k, (val, _) in counter_avg(a.insts, cname).items():
+                if k in ks:
+                    ks[k][cname.lower()] = val
     lines = ["# rocprofv3 summary  " + a.note,
              "%-22s %6s %10s %10s %10s %5s %5s %7s %8s %14s %14s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "vgpr", "sgpr",
                                                                       "lds_B", "grid", "hbm_read_B", "hbm_write_B")]
@@ -61,6 +70,12 @@ def main():
             k, v["calls"], v["avg_us"], v["min_us"], v["max_us"], v["vgpr"], v["sgpr"], v["lds"], v["grid"],
             ("%.0f" % v["hbm_read_bytes"]) if "hbm_read_bytes" in v else "-",
             ("%.0f" % v["hbm_write_bytes"]) if "hbm_write_bytes" in v else "-"))
+    if a.insts:
+        lines.append("")
+        lines.append("%-22s %14s %14s %14s %16s" % ("kernel", "insts_valu", "insts_salu", "insts_lds", "wave_cycles(x4)"))
+        for k, v in ks.items():
+            lines.append("%-22s %14.0f %14.0f %14.0f %16.0f" % (k, v.get("sq_insts_valu", 0), v.get("sq_insts_salu", 0),
+                                                                 v.get("sq_insts_lds", 0), v.get("sq_wave_cycles", 0)))
     open(a.out + ".txt", "w").write("\n".join(lines) + "\n")
     json.dump(ks, open(a.out + ".json", "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
