@@ -1,0 +1,27 @@
+"""PCIe-inclusive rate of the boundary (host buffers in, host PCM out): packets -> host parse -> H2D of the
+descriptors -> kernels -> D2H of the PCM through nvh_stream_synth, on the bench workload.
+This is NOT bench.py's `value` (which starts with the descriptors resident in HBM)."""
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+import nvorbis_amd as nv, bench
+
+headers, ll, ch = bench.ll_packets(nv, os.path.join(bench.ROOT, "tests", "golden", "3test.ogg"))
+ctx = nv.Context(0)
+st = nv.Stream(ctx, *headers)
+st.push_packet(ll[0], -1, 0); st.synth_host()
+N = 4096
+best = None
+for rep in range(5):
+    t0 = time.perf_counter()
+    for i in range(N):
+        st.push_packet(ll[(i + 1) % len(ll)], -1, 0)
+    t1 = time.perf_counter()
+    pcm = st.synth_host()
+    t2 = time.perf_counter()
+    r = (t1 - t0, t2 - t1)
+    if best is None or sum(r) < sum(best):
+        best = r
+parse, rest = best
+print("frames %d: host parse %.2f ms (%.0f frames/s, 1 core), upload+kernels+D2H %.2f ms, end to end %.0f frames/s; pcm %d floats" % (
+    N, parse * 1e3, N / parse, rest * 1e3, N / (parse + rest), len(pcm)))
