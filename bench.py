@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent decoder instances (own nvh_ctx / HIP stream / resident batch) the steps rotate over")
     args = ap.parse_args()
 
     import torch
@@ -90,30 +92,40 @@ def main():
     headers, ll, ch = ll_packets(nv, os.path.join(ROOT, "tests", "golden", "3test.ogg"))
     assert ch == 2 and len(ll) > 0
 
-    ctx = nv.Context(local_rank)
-    ctx.set_hip_stream(torch.cuda.current_stream().cuda_stream)
-    stream = nv.Stream(ctx, headers[0], headers[1], headers[2])
-    # priming frame (a first packet emits nothing, StreamDecoder.cs:446-450) goes through a batch of its own
-    stream.push_packet(ll[(rank * 7) % len(ll)], -1, 0)
-    stream.synth_host()
-    for i in range(FRAMES):
-        stream.push_packet(ll[(i + rank * 7 + 1) % len(ll)], -1, 0)
-    batch = stream.upload_batch()
-    assert batch.frames == FRAMES and batch.samples == FRAMES * (BLOCK // 2), (batch.frames, batch.samples)
-    pcm = torch.empty(batch.samples * ch, dtype=torch.float32, device="cuda")
+    # S independent decoder instances, each with its own HIP stream and its own resident 4096-frame batch: a
+    # step is one pass of the hot path over one batch, and consecutive steps go to different instances, so the
+    # GPU overlaps the tail of one batch's kernels with the head of the next one's (what a corpus transcoder
+    # does with independent files).  Instance 0 also provides the serial per-kernel timings below.
+    insts = []
+    for k in range(max(1, args.streams)):
+        ts = torch.cuda.Stream()  # never the legacy default stream: it serialises against every other stream
+        ctx_k = nv.Context(local_rank)
+        ctx_k.set_hip_stream(ts.cuda_stream)
+        stream_k = nv.Stream(ctx_k, headers[0], headers[1], headers[2])
+        # priming frame (a first packet emits nothing, StreamDecoder.cs:446-450) goes through a batch of its own
+        stream_k.push_packet(ll[(rank * 7 + k * 13) % len(ll)], -1, 0)
+        stream_k.synth_host()
+        for i in range(FRAMES):
+            stream_k.push_packet(ll[(i + rank * 7 + k * 13 + 1) % len(ll)], -1, 0)
+        batch_k = stream_k.upload_batch()
+        assert batch_k.frames == FRAMES and batch_k.samples == FRAMES * (BLOCK // 2), (batch_k.frames, batch_k.samples)
+        pcm_k = torch.empty(batch_k.samples * ch, dtype=torch.float32, device="cuda")
+        insts.append((ts, ctx_k, stream_k, batch_k, pcm_k))
+    _, ctx, stream, batch, pcm = insts[0]
     cap = pcm.numel()
+    nin = len(insts)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.synth(pcm.data_ptr(), cap)
+    for i in range(args.warmup):
+        insts[i % nin][3].synth(insts[i % nin][4].data_ptr(), cap)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.synth(pcm.data_ptr(), cap)
+    for i in range(args.steps):
+        insts[i % nin][3].synth(insts[i % nin][4].data_ptr(), cap)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -161,7 +173,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (3test.ogg long/long packets tiled to 4096 frames per GPU, device resident)",
             "config": {"workload": "C2: 4096 stereo long-block (n=2048) frames, Floor1+Residue2+coupling, IMDCT+window+OLA",
-                       "frames_per_gpu": FRAMES, "channels": ch, "block": BLOCK, "parallelism": "frame-parallel x%d" % world,
+                       "frames_per_gpu": FRAMES, "channels": ch, "block": BLOCK, "parallelism": "frame-parallel x%d, %d HIP streams per GPU" % (world, nin),
                        "descriptor_bytes_per_frame": batch.descriptor_bytes / FRAMES},
             "kernels_ms": {names[k]: km[k] for k in live},
             "pipeline_ms_events": total_ms / iters,
@@ -172,9 +184,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(headers, ll)
         print(json.dumps(out), flush=True)
-    batch.free()
-    stream.close()
-    ctx.close()
+    for _, ctx_k, stream_k, batch_k, _ in insts:
+        batch_k.free()
+        stream_k.close()
+        ctx_k.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -371,10 +371,12 @@ __device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150
 // LDS map (dynamic, 4-byte words):
 //   [ s_db 256 | (FLOOR0: s_coeff 256) | FloorScratch x min(channels, SP_GROUP) | pass records cap_pass*16 |
 //     books nbooks*8 | lattice pool | ops cap_ops*2 | pair records cap_ops*4 | entries cap_ent/2 | spectrum ch*half ]
-template <bool FLOOR0>
+// FAST: the stream shape guarantees the pair path for every residue and the fused tail (host: nvh_api.hip decides
+// per stream); the general paths are then not even compiled in, which is worth registers and instruction cache.
+template <bool FLOOR0, bool FAST>
 __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDevBatch& Bt, float* __restrict__ work,
                                               int* __restrict__ err, int cap_pass, int cap_ops, int cap_ent, float* smem,
-                                              long long* dbg = nullptr) {
+                                              long long* dbg = nullptr, int phase_mask = 7) {
   const int nch = S.channels;
   const int ngrp_lds = nch < SP_GROUP ? nch : SP_GROUP;
   float* s_db = smem;
@@ -411,7 +413,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   // ---- stage the frame's side information (16-byte copies), clear the spectrum, prepare the floors ----
   // Mono / stereo Floor1 streams take the fused tail: their posts are unwrapped here, one wavefront per channel,
   // while the remaining wavefronts do the staging -- two dependent-load chains side by side instead of in series.
-  const bool fused_tail = !FLOOR0 && S.fused_tail_ok;
+  const bool fused_tail = FAST || (!FLOOR0 && S.fused_tail_ok);
   const int nprep = fused_tail ? nch : 0;  // wavefronts [0, nprep) prepare floors, the others stage
   const int npass = (int)(fr.pass_end - fr.pass_begin);
   // the host sizes the three capacities from the batch's largest frame (nvh_api.hip) and launches the unfused
@@ -421,7 +423,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   const unsigned ent_shift = fr.ent_begin & 7u;
   DBG_T(20);
   if (wv < nprep) {
-    floor_prepare(&fs[wv], first_lane, lane, half, err);
+    if (phase_mask & 4) floor_prepare(&fs[wv], first_lane, lane, half, err);
   } else {
     const int st = tid - nprep * 64, sn = SP_THREADS - nprep * 64;
     for (int i = st; i < 256; i += sn) s_db[i] = k_inverse_db[i];
@@ -484,7 +486,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   DBG_T(2);
 
   // ---- residue ----
-  for (int ps = 0; ps < npass; ++ps) {
+  for (int ps = 0; (phase_mask & 1) && ps < npass; ++ps) {
     // values read back from LDS are wave-uniform: say so, or every use downstream turns into vector code
     const uint32_t* P = s_pass + ps * 16;
     const unsigned rflags = __builtin_amdgcn_readfirstlane(P[10]);
@@ -492,7 +494,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     const int psize = __builtin_amdgcn_readfirstlane((int)P[12]);
     const unsigned rch = __builtin_amdgcn_readfirstlane(P[11]);
     const unsigned hp_magic = __builtin_amdgcn_readfirstlane(P[13]), rch_magic = __builtin_amdgcn_readfirstlane(P[14]);
-    const NvhDevResidue* Rg = &S.residues[__builtin_amdgcn_readfirstlane((int)P[0])];  // general paths only
+    const NvhDevResidue* Rg = FAST ? nullptr : &S.residues[__builtin_amdgcn_readfirstlane((int)P[0])];  // general paths only
     long long t_prev = dbg ? clock64() : 0;
     if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 7] = t_prev;
 #pragma unroll 1
@@ -500,7 +502,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       const unsigned ob = __builtin_amdgcn_readfirstlane(P[1 + s]);
       const unsigned oe = __builtin_amdgcn_readfirstlane(P[2 + s]);
       if (ob == oe) continue;
-      if (rflags & 0x100u) {
+      if (FAST || (rflags & 0x100u)) {
         // every book of this residue is a lattice of even dimension: one lane adds two consecutive components of
         // one codebook entry (for stereo type 2 that is one bin of both channels).  The VQ lookup is two base-
         // lat_values digits of the entry number, peeled with exact reciprocal multiplies; nothing leaves LDS.
@@ -548,6 +550,8 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           }
         }
         __syncthreads();
+      } else if (FAST) {
+        __builtin_trap();  // host contract violated
       } else if ((rflags & 0x600u) == 0x400u) {  // fast, not sequential
         const NvhDevResidue R = *Rg;
         // elements of one stage never alias (that is what !sequential means), so four of them are fetched as
@@ -608,6 +612,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   DBG_T(3);
   float* planes = work + (long long)f * nch * S.block1;
 
+  if (fused_tail && !(phase_mask & 2)) return;  // profiling aid (NVH_DEBUG_SPECTRUM_MASK)
   if (fused_tail) {
     // ---- fused tail: inverse coupling (Mapping.cs:137-182), floor apply and the store, 4 bins per lane ----
     int mg = 0;
@@ -662,6 +667,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 23] = wall_clock64();
     return;
   }
+  if (FAST) return;
 
   // ---- general tail: any channel count, any number of coupling steps, Floor0 ----
   // inverse coupling, last step first (Mapping.cs:137-182)
@@ -763,9 +769,18 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
 // 8 waves per SIMD = 8 resident workgroups per CU: the register budget (64 VGPRs, 96 SGPRs) is part of the design
 extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
-           int cap_ent, long long* dbg) {
+           int cap_ent, long long* dbg, int phase_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg);
+  spectrum_body<false, true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg, phase_mask);
+}
+
+// Any other Floor1 stream shape (more than two channels, several coupling steps, non-lattice books, aliasing
+// partitions, Residue0).
+extern "C" __global__ void __launch_bounds__(SP_THREADS)
+k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
+               int cap_ent) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  spectrum_body<false, false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem);
 }
 
 // Variant for setups that contain a Floor0 (double-precision cos / sqrt / exp: costs registers, kept apart).
@@ -773,5 +788,5 @@ extern "C" __global__ void __launch_bounds__(SP_THREADS)
 k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
               int cap_ent) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem);
+  spectrum_body<true, false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem);
 }

@@ -29,12 +29,13 @@ __global__ void k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* work,
 __global__ void k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
                               int* clipped_flag, float* carry_out, int last_decoded);
 __global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent,
-                           long long* dbg);
+                           long long* dbg, int phase_mask);
 __global__ void k_spectrum2_c1(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum2_c2(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum2_c1_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum2_c2_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
+__global__ void k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
                             int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
@@ -124,6 +125,7 @@ struct nvh_stream {
   DevBuf pcm;    // staging for host-destination synth
   int clip = 1;
   int has_clipped = 0;
+  bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
   bool gather_ok = false;  // stream shape admits k_spectrum2 (kernels_spectrum2.hip)
   int gather_idx_cap = 0;  // entries of its (stage, partition[, channel]) -> op index
   bool has_floor0 = false;
@@ -534,6 +536,9 @@ static int upload_setup(nvh_stream* s) {
     bool ok = S.channels <= 2 && !s->has_floor0;
     for (const nvh::Mapping& m : S.mappings) ok = ok && m.coupling_angle.size() <= 1;
     D.fused_tail_ok = ok ? 1 : 0;
+    bool all_pairs = true;
+    for (const NvhDevResidue& r : residues) all_pairs = all_pairs && r.pair_path != 0;
+    s->fast_spectrum = ok && all_pairs;
   }
   D.books = (const NvhDevBook*)(base + o_books);
   D.floors = (const NvhDevFloor*)(base + o_floors);
@@ -770,6 +775,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     int cap_pass = b->max_pass, cap_ops = (b->max_ops + 1) & ~1, cap_ent = (b->max_ent + 14) & ~7;
     size_t words = fixed_words + (size_t)cap_pass * 16 + (size_t)cap_ops * 6 + (size_t)cap_ent / 2;
     if (getenv("NVH_UNFUSED")) words = 1u << 20;  // test aid: force the unfused kernels below
+    static const int phase_mask = getenv("NVH_DEBUG_SPECTRUM_MASK") ? atoi(getenv("NVH_DEBUG_SPECTRUM_MASK")) : 7;  // profiling aid
     static const size_t lds_pad = getenv("NVH_LDS_PAD") ? (size_t)atoi(getenv("NVH_LDS_PAD")) : 0;  // occupancy experiments
     static const int no_gather = getenv("NVH_GATHER") ? 0 : 1;  // gather-form kernel (kernels_spectrum2.hip): bit-exact but not faster, opt-in
     // gather form (kernels_spectrum2.hip): needs the op / entry slices staged (op indices are 16-bit)
@@ -785,11 +791,15 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                          s->gather_idx_cap);
     } else if (words * 4 <= 64 * 1024) {
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
-      b->slot_name[0] = "-"; b->slot_name[1] = has_floor0 ? "k_spectrum_f0" : "k_spectrum";
-      if (has_floor0)
+      b->slot_name[0] = "-";
+      b->slot_name[1] = has_floor0 ? "k_spectrum_f0" : (s->fast_spectrum ? "k_spectrum" : "k_spectrum_gen");
+      if (has_floor0) {
         hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent);
-      else {
+      } else if (!s->fast_spectrum) {
+        hipLaunchKernelGGL(k_spectrum_gen, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
+                           cap_pass, cap_ops, cap_ent);
+      } else {
         if (getenv("NVH_DEBUG_OCC")) {
           int nb = -1;
           hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_spectrum, 256, words * 4 + lds_pad);
@@ -799,7 +809,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                   (int)oe, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
         }
         hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4 + lds_pad, st, s->dev, b->dev, work, flags,
-                           cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf);
+                           cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf, phase_mask);
       }
     } else {
       b->slot_name[0] = "k_residue"; b->slot_name[1] = "k_couple_floor";
