@@ -22,6 +22,7 @@
 // expressions are single operations; -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include "imdct_wave.h"
 #include "kernels_common.h"
 
 #define SP_THREADS 256
@@ -373,7 +374,10 @@ __device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150
 //     books nbooks*8 | lattice pool | ops cap_ops*2 | pair records cap_ops*4 | entries cap_ent/2 | spectrum ch*half ]
 // FAST: the stream shape guarantees the pair path for every residue and the fused tail (host: nvh_api.hip decides
 // per stream); the general paths are then not even compiled in, which is worth registers and instruction cache.
-template <bool FLOOR0, bool FAST>
+// IMDCT (FAST only, block1 <= 2048): the inverse MDCT runs in the same workgroup, one wavefront per channel, straight
+// from the LDS spectrum, and the work planes receive the compact IMDCT output k_ola_compact expects -- the
+// spectrum never travels through HBM.
+template <bool FLOOR0, bool FAST, bool IMDCT = false>
 __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDevBatch& Bt, float* __restrict__ work,
                                               int* __restrict__ err, int cap_pass, int cap_ops, int cap_ent, float* smem,
                                               long long* dbg = nullptr, int phase_mask = 7) {
@@ -647,7 +651,10 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         for (int q = 0; q < TB; ++q) r0[q] = 0.0f;  // Floor1.cs:218-221
       }
 #pragma unroll
-      for (int q = 0; q < TB; q += 4) *reinterpret_cast<float4*>(planes + x0 + q) = *reinterpret_cast<float4*>(r0 + q);
+      for (int q = 0; q < TB; q += 4) {
+        if (IMDCT) *reinterpret_cast<float4*>(spec + x0 + q) = *reinterpret_cast<float4*>(r0 + q);
+        else *reinterpret_cast<float4*>(planes + x0 + q) = *reinterpret_cast<float4*>(r0 + q);
+      }
       if (nch == 2) {
         if (md1 == 1) {
           floor_walk<TB>(&fs[1], s_db, x0, m);
@@ -658,10 +665,44 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           for (int q = 0; q < TB; ++q) r1[q] = 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < TB; q += 4) *reinterpret_cast<float4*>(planes + S.block1 + x0 + q) = *reinterpret_cast<float4*>(r1 + q);
+        for (int q = 0; q < TB; q += 4) {
+          if (IMDCT) *reinterpret_cast<float4*>(spec + half + x0 + q) = *reinterpret_cast<float4*>(r1 + q);
+          else *reinterpret_cast<float4*>(planes + S.block1 + x0 + q) = *reinterpret_cast<float4*>(r1 + q);
+        }
       }
     }
     DBG_T(4);
+    if (IMDCT) {
+      // ---- inverse MDCT (Mdct.cs:65-313), one wavefront per channel ----
+      // The transform's LDS slice (n/2 floats + n/16 of padding) overlays the channel's own spectrum, which the
+      // wavefront has fully in registers before its first store (imdct_wave_fast loads everything up front):
+      // channel nch-1 spills its padding past the end of the spectrum area, the one before it into the (dead)
+      // staging area in front of it.
+      __syncthreads();
+      if (wv < nch) {
+        const float* X = spec + wv * half;
+        float* out = planes + (long long)wv * S.block1;
+        if (!((fr.exec_mask >> wv) & 1u)) {
+          // Mapping.cs:192-196: the residue stays in [0, n/2) (k_ola_compact windows it); its tail quarter is zero
+          for (int i = lane * 4; i < half; i += 256) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(X + i);
+          for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+          float* scratch = spec + wv * half - (nch - 1 - wv) * (fr.n >> 4);
+          const int sl = fr.mdct_slot;
+          const float* A = S.mdct_a[sl];
+          const float* B = S.mdct_b[sl];
+          const float* C = S.mdct_c[sl];
+          const float* TW = S.mdct_tw[sl];
+          switch (fr.n) {
+            case 256: imdct_wave<8, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+            case 512: imdct_wave<9, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+            case 1024: imdct_wave<10, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+            case 2048: imdct_wave<11, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+            default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
+          }
+        }
+      }
+    }
     DBG_T(5);
     DBG_T(6);
     if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 23] = wall_clock64();
@@ -772,6 +813,14 @@ k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restr
            int cap_ent, long long* dbg, int phase_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   spectrum_body<false, true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg, phase_mask);
+}
+
+// k_spectrum with the inverse MDCT behind it (block sizes 256..2048): writes the compact IMDCT output.
+extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
+                 int cap_ent, long long* dbg, int phase_mask) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  spectrum_body<false, true, true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg, phase_mask);
 }
 
 // Any other Floor1 stream shape (more than two channels, several coupling steps, non-lattice books, aliasing

@@ -35,6 +35,8 @@ __global__ void k_spectrum2_c2(NvhDevSetup S, NvhDevBatch Bt, float* work, int* 
 __global__ void k_spectrum2_c1_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum2_c2_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
+__global__ void k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent,
+                                 long long* dbg, int phase_mask);
 __global__ void k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
                             int clip, int* clipped_flag, int run_len, int last_decoded);
@@ -764,6 +766,15 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   if (timing)
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   if (timing) HIP_TRY(hipEventRecord(ev[0], st));
+  // compact hand-over (two independent quarters per block, windowed in the overlap kernel) whenever no overlap
+  // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
+  static const int no_compact = getenv("NVH_NO_COMPACT") ? 1 : 0;
+  static const int no_fused_ola = getenv("NVH_FUSED_OLA") ? 0 : 1;  // experimental run-based kernel: opt-in
+  static const int no_fused_imdct = getenv("NVH_NO_FUSED_IMDCT") ? 1 : 0;
+  const bool use_fused_ola = b->fused_ola && !no_fused_ola;
+  const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola;
+  // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers
+  const bool fuse_imdct = compact && s->fast_spectrum && s->setup.block1 <= 2048 && !no_fused_imdct;
   // Fused spectrum kernel when a frame's spectrum (+ staged side information) fits the default 64 KB dynamic
   // LDS window; LDS map in kernels_spectrum.hip.
   {
@@ -808,8 +819,15 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
           fprintf(stderr, "k_spectrum: lds %zu B, occupancy %d WG/CU (err %d), regs %d, static lds %zu, max dyn lds %d\n", words * 4 + lds_pad, nb,
                   (int)oe, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
         }
-        hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4 + lds_pad, st, s->dev, b->dev, work, flags,
-                           cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf, phase_mask);
+        if (fuse_imdct) {
+          // + the IMDCT padding of the last channel (n/16 floats past the spectrum area)
+          b->slot_name[1] = "k_spectrum_imdct";
+          hipLaunchKernelGGL(k_spectrum_imdct, dim3((unsigned)b->nframes), dim3(256), words * 4 + (size_t)(s->setup.block1 / 16) * 4 + lds_pad,
+                             st, s->dev, b->dev, work, flags, cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf, phase_mask);
+        } else {
+          hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4 + lds_pad, st, s->dev, b->dev, work, flags,
+                             cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf, phase_mask);
+        }
       }
     } else {
       b->slot_name[0] = "k_residue"; b->slot_name[1] = "k_couple_floor";
@@ -820,9 +838,8 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   }
   if (timing) HIP_TRY(hipEventRecord(ev[2], st));
   static const int run_len_env = getenv("NVH_RUN_LEN") ? atoi(getenv("NVH_RUN_LEN")) : 0;
-  static const int no_fused_ola = getenv("NVH_FUSED_OLA") ? 0 : 1;  // experimental run-based kernel: opt-in
   const size_t plane_bytes = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
-  if (b->fused_ola && !no_fused_ola) {
+  if (use_fused_ola) {
     // one workgroup per run of frames, one wavefront per channel; keep >= ~2048 waves in flight
     int run_len = run_len_env > 0 ? run_len_env : 4;
     while (run_len > 1 && (long long)(b->nframes / run_len) * ch < 2048) run_len >>= 1;
@@ -833,13 +850,11 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                        carry, carry_out, d_pcm, s->clip, flags + 1, run_len, b->last_decoded);
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));  // slot 2 = fused IMDCT+OLA, slot 3 empty
   } else {
-    // compact hand-over (two independent quarters per block, windowed in the overlap kernel) whenever no overlap
-    // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
-    static const int no_compact = getenv("NVH_NO_COMPACT") ? 1 : 0;
-    const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact;
-    b->slot_name[2] = compact ? "k_imdct_compact" : (s->setup.block0 >= 256 ? "k_imdct_wave" : "k_imdct_window");
+    b->slot_name[2] = fuse_imdct ? "-" : compact ? "k_imdct_compact" : (s->setup.block0 >= 256 ? "k_imdct_wave" : "k_imdct_window");
     b->slot_name[3] = compact ? "k_ola_compact" : (!b->sequential_ola ? "k_ola_emit" : "k_ola_emit_seq");
-    if (compact)
+    if (fuse_imdct)
+      ;  // done inside k_spectrum_imdct
+    else if (compact)
       hipLaunchKernelGGL(k_imdct_compact, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
                          b->dev, work);
     else if (s->setup.block0 >= 256)
