@@ -120,7 +120,8 @@ int StreamParser::decode_floor(int floor_idx, BitReader& p, FrameBatch& out, Nvh
 // residues
 // ---------------------------------------------------------------------------------------------
 
-int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, FrameBatch& out, NvhResPass& pass) {
+int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, FrameBatch& out, NvhResPass& pass,
+                                 uint32_t frame_op_begin) {
   const Residue& r = s_->residues[(size_t)residue_idx];
   const Codebook& class_book = s_->books[(size_t)r.class_book];
   pass.residue = residue_idx;
@@ -138,6 +139,21 @@ int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, 
   std::vector<int> part_word((size_t)r.channels * (size_t)std::max(partition_words, 1), -1);
   const int buflen = s_->block1;  // float[ch][block1Size] (StreamDecoder.cs:498-505)
   bool stop = false;
+  // op_link chains: the last op emitted for each (partition, channel) of this pass
+  std::vector<int32_t> last_op((size_t)r.channels * (size_t)std::max(partition_count, 1), -1);
+  auto link_op = [&](int partition_idx, int ch) {
+    const size_t idx = out.ops.size() - 1;
+    out.op_link.resize(out.ops.size(), (uint16_t)NVH_LINK_NONE);
+    out.op_link[idx] = (uint16_t)NVH_LINK_NONE;
+    const size_t rel = idx - (size_t)frame_op_begin;
+    if (rel >= (size_t)NVH_LINK_NONE) out.links_ok = false;
+    int32_t& last = last_op[(size_t)partition_idx * (size_t)r.channels + (size_t)ch];
+    if (last >= 0 && rel < (size_t)NVH_LINK_NONE) {
+      out.op_link[(size_t)last] = (uint16_t)((out.op_link[(size_t)last] & 0x8000u) | (uint16_t)rel);
+      out.op_link[idx] |= 0x8000u;
+    }
+    last = (int32_t)idx;
+  };
 
   int stage = 0;
   for (; stage < r.max_stages && !stop; stage++) {
@@ -198,6 +214,7 @@ int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, 
             }
             if (offset + steps * dims > buflen) return NVH_ERR_RUNTIME;
             out.ops.push_back(op);
+            link_op(partition_idx, ch);
           } else {
             // Residue1.WriteVectors (Residue1.cs:8-26) / Residue2.WriteVectors (Residue2.cs:23-47):
             // vectors are added as they are decoded; a failed decode keeps what was added so far
@@ -225,6 +242,7 @@ int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, 
             }
             for (int i = done; i < slots; i++) out.entries.push_back((uint16_t)NVH_ENTRY_SKIP);
             out.ops.push_back(op);
+            link_op(partition_idx, ch);
             if (bad) {
               stop = true;
               break;
@@ -316,7 +334,7 @@ int StreamParser::parse_audio(BitReader& p, FrameBatch& out, int* decoded) {
     }
     if (any_execute) {  // Array.IndexOf(doNotDecodeChannel, false) != -1 (Residue0.cs:125)
       NvhResPass pass;
-      int rc = decode_residue(map.submap_residue[i], p, bs, out, pass);
+      int rc = decode_residue(map.submap_residue[i], p, bs, out, pass, f.op_begin);
       if (rc != NVH_OK) return rc;
       out.passes.push_back(pass);
     }
@@ -397,7 +415,7 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
                m_ops = out.ops.size(), m_entries = out.entries.size(), m_posts = out.posts.size(),
                m_coeffs = out.coeffs.size();
   auto rollback = [&]() {
-    out.frames.resize(m_frames); out.chans.resize(m_chans); out.passes.resize(m_passes); out.ops.resize(m_ops);
+    out.frames.resize(m_frames); out.chans.resize(m_chans); out.passes.resize(m_passes); out.ops.resize(m_ops); out.op_link.resize(m_ops);
     out.entries.resize(m_entries); out.posts.resize(m_posts); out.coeffs.resize(m_coeffs);
   };
 

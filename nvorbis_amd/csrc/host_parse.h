@@ -20,6 +20,11 @@ struct FrameBatch {
   std::vector<NvhChan> chans;
   std::vector<NvhResPass> passes;
   std::vector<NvhResOp> ops;
+  // per op: bits 0-14 = the next op (frame-relative index) that adds to the same partition/channel in a later
+  // stage (NVH_LINK_NONE: none), bit 15 = this op has such a predecessor.  Lets a kernel lane walk all stages
+  // of one partition in order without a barrier per stage (kernels_spectrum.hip).
+  std::vector<uint16_t> op_link;
+  bool links_ok = true;         // false: some frame has too many ops for the 15-bit links
   std::vector<uint16_t> entries;
   std::vector<uint16_t> posts;
   std::vector<float> coeffs;
@@ -27,7 +32,8 @@ struct FrameBatch {
   bool sequential_ola = false;  // some overlap region reaches into a tail: apply overlaps in order
   bool clipped_unknown = true;
   void clear() {
-    frames.clear(); chans.clear(); passes.clear(); ops.clear(); entries.clear(); posts.clear(); coeffs.clear();
+    frames.clear(); chans.clear(); passes.clear(); ops.clear(); op_link.clear(); entries.clear(); posts.clear(); coeffs.clear();
+    links_ok = true;
     pcm_samples = 0;
     sequential_ola = false;
   }
@@ -58,7 +64,7 @@ class StreamParser {
  private:
   int parse_audio(BitReader& p, FrameBatch& out, int* decoded);
   int decode_floor(int floor_idx, BitReader& p, FrameBatch& out, NvhChan& ch, bool* energy);
-  int decode_residue(int residue_idx, BitReader& p, int block_size, FrameBatch& out, NvhResPass& pass);
+  int decode_residue(int residue_idx, BitReader& p, int block_size, FrameBatch& out, NvhResPass& pass, uint32_t frame_op_begin);
   void drain(FrameBatch& out);
 
   const Setup* s_;

@@ -33,6 +33,7 @@ struct NvhDevBatch {
   const NvhChan* chans;
   const NvhResPass* passes;
   const NvhResOp* ops;
+  const uint16_t* op_link;        // per op: next op of the same partition/channel (host_parse.h FrameBatch::op_link)
   const uint16_t* entries;
   const uint16_t* posts;
   const float* coeffs;

@@ -371,7 +371,7 @@ __device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150
 
 // LDS map (dynamic, 4-byte words):
 //   [ s_db 256 | (FLOOR0: s_coeff 256) | FloorScratch x min(channels, SP_GROUP) | pass records cap_pass*16 |
-//     books nbooks*8 | lattice pool | ops cap_ops*2 | pair records cap_ops*4 | entries cap_ent/2 | spectrum ch*half ]
+//     books nbooks*8 | lattice pool | ops cap_ops*2 | pair records cap_ops*4 | op links cap_ops/2 | entries cap_ent/2 | spectrum ch*half ]
 // FAST: the stream shape guarantees the pair path for every residue and the fused tail (host: nvh_api.hip decides
 // per stream); the general paths are then not even compiled in, which is worth registers and instruction cache.
 // IMDCT (FAST only, block1 <= 2048): the inverse MDCT runs in the same workgroup, one wavefront per channel, straight
@@ -391,7 +391,8 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   uint32_t* s_lat = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(s_books) + S.nbooks * 8);
   NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(s_lat + ((S.lattice_words + 3) & ~3));
   uint4* s_oprec = reinterpret_cast<uint4*>(reinterpret_cast<float*>(s_ops) + cap_ops * 2);  // pair-path op records
-  uint16_t* s_ent = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(s_oprec) + cap_ops * 4);
+  uint16_t* s_link = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(s_oprec) + cap_ops * 4);  // cap_ops % 8 == 0
+  uint16_t* s_ent = s_link + cap_ops;
   float* spec = reinterpret_cast<float*>(s_ent) + (cap_ent >> 1);  // [ch][half], 16-byte aligned (cap_ent % 8 == 0)
 
   const int f = blockIdx.x;
@@ -436,6 +437,10 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     for (int i = st; i < S.lattice_words; i += sn) s_lat[i] = S.lattice[i];
     const uint2* go = reinterpret_cast<const uint2*>(Bt.ops + fr.op_begin);
     for (int i = st; i < (int)fr.op_count; i += sn) reinterpret_cast<uint2*>(s_ops)[i] = go[i];
+    if (FAST) {
+      const uint16_t* gl = Bt.op_link + fr.op_begin;
+      for (int i = st; i < (int)fr.op_count; i += sn) s_link[i] = gl[i];
+    }
     const uint4* ge = reinterpret_cast<const uint4*>(Bt.entries + (fr.ent_begin - ent_shift));
     const int nvec = (int)((ent_shift + fr.ent_count + 7u) >> 3);
     for (int i = st; i < nvec; i += sn) reinterpret_cast<uint4*>(s_ent)[i] = ge[i];
@@ -501,12 +506,74 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     const NvhDevResidue* Rg = FAST ? nullptr : &S.residues[__builtin_amdgcn_readfirstlane((int)P[0])];  // general paths only
     long long t_prev = dbg ? clock64() : 0;
     if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 7] = t_prev;
+    if (FAST) {
+      // All stages of the pass in one sweep.  The host links the ops that add to the same partition/channel across
+      // stages (op_link); a lane takes one pair of bins of one chain *head*, walks the chain in stage order with
+      // the running sums in registers, and writes once.  Same additions in the same order as the reference's
+      // stage loop, without a barrier and an LDS read-modify-write per stage.
+      const unsigned hp = (unsigned)psize >> 1;
+      const unsigned o0 = __builtin_amdgcn_readfirstlane(P[1]), o1 = __builtin_amdgcn_readfirstlane(P[1 + NVH_MAX_STAGES]);
+      const unsigned total = (o1 - o0) * hp;
+      for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
+        const unsigned oq = hp > 1 ? __umulhi(idx, hp_magic) : idx;
+        const unsigned i2 = idx - oq * hp, i = i2 << 1;  // pair / first component index inside the partition
+        unsigned o = o0 + oq;
+        unsigned link = s_link[o];
+        if (link & 0x8000u) continue;  // not a chain head: an earlier-stage op owns these bins
+        uint4 rec = s_oprec[o];
+        const unsigned xbase = rec.x >> 16;
+        unsigned c0, x0, c1, x1;
+        if (rtype == 1 || rch == 1) {
+          c0 = c1 = (rec.w >> 8) & 0xFFu;
+          x0 = xbase + i;
+          x1 = x0 + 1;
+        } else if (rch == 2) {
+          c0 = 0; c1 = 1;
+          x0 = x1 = xbase + i2;
+        } else {
+          const unsigned qi = __umulhi(i, rch_magic);
+          c0 = i - qi * rch;
+          x0 = xbase + qi;
+          c1 = c0 + 1; x1 = x0;
+          if (c1 == rch) { c1 = 0; ++x1; }
+        }
+        const bool in0 = x0 < (unsigned)half, in1 = x1 < (unsigned)half;
+        float* p0 = spec + c0 * (unsigned)half + x0;
+        float* p1 = spec + c1 * (unsigned)half + x1;
+        float a0 = in0 ? *p0 : 0.0f, a1 = in1 ? *p1 : 0.0f;
+        for (;;) {
+          const unsigned dims = rec.w & 0xFFu, lv = rec.y >> 16;
+          const unsigned j = (i * (rec.w >> 16)) >> 16;  // i / dims (i < 4096, dims <= 16: exact)
+          const unsigned comp = i - j * dims;
+          unsigned q = ent[(rec.x & 0xFFFFu) + j];
+          if (q != NVH_ENTRY_SKIP) {
+            const uint32_t* lat = s_lat + (rec.y & 0xFFFFu);
+            if (comp) q = __umulhi(q, lat[lv + comp]);  // e / lv^comp
+            // two base-lv digits (lv == 1: the magic is 0 and so are q and both digits)
+            const unsigned q1 = __umulhi(q, rec.z);
+            const unsigned d0 = q - q1 * lv;
+            const unsigned d1 = q1 - __umulhi(q1, rec.z) * lv;
+            a0 = a0 + __uint_as_float(lat[d0]);
+            a1 = a1 + __uint_as_float(lat[d1]);
+          }
+          link &= 0x7FFFu;
+          if (link == NVH_LINK_NONE) break;
+          o = link;
+          rec = s_oprec[o];
+          link = s_link[o];
+        }
+        if (in0) *p0 = a0;
+        if (in1) *p1 = a1;
+      }
+      __syncthreads();
+      continue;
+    }
 #pragma unroll 1
     for (int s = 0; s < NVH_MAX_STAGES; ++s) {
       const unsigned ob = __builtin_amdgcn_readfirstlane(P[1 + s]);
       const unsigned oe = __builtin_amdgcn_readfirstlane(P[2 + s]);
       if (ob == oe) continue;
-      if (FAST || (rflags & 0x100u)) {
+      if (rflags & 0x100u) {
         // every book of this residue is a lattice of even dimension: one lane adds two consecutive components of
         // one codebook entry (for stereo type 2 that is one bin of both channels).  The VQ lookup is two base-
         // lat_values digits of the entry number, peeled with exact reciprocal multiplies; nothing leaves LDS.
@@ -554,8 +621,6 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           }
         }
         __syncthreads();
-      } else if (FAST) {
-        __builtin_trap();  // host contract violated
       } else if ((rflags & 0x600u) == 0x400u) {  // fast, not sequential
         const NvhDevResidue R = *Rg;
         // elements of one stage never alias (that is what !sequential means), so four of them are fetched as

@@ -109,6 +109,7 @@ struct nvh_batch {
   bool sequential_ola = false;
   int last_decoded = -1;  // last frame with n != 0 (its block becomes the next carried tail)
   const char* slot_name[4] = {"-", "-", "-", "-"};  // kernels behind the four timing slots of the last launch
+  bool links_ok = false;  // op_link chains usable (every frame has < 32767 ops): k_spectrum's chain walk
   int max_ops = 0, max_ent = 0, max_pass = 0;  // largest per-frame op / entry / pass slice (LDS staging capacity of k_spectrum)
   bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
   bool has_carry_in = false;
@@ -683,6 +684,7 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->sequential_ola = P.sequential_ola;
   b->last_decoded = -1;
   b->max_ops = b->max_ent = b->max_pass = 0;
+  b->links_ok = P.links_ok && P.op_link.size() == P.ops.size();
   for (const NvhFrame& fr : P.frames) {
     if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
     if ((int)fr.ent_count > b->max_ent) b->max_ent = (int)fr.ent_count;
@@ -723,12 +725,13 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   size_t o_ch = ab.add(P.chans.empty() ? (const void*)dummy.data() : P.chans.data(), pad1(P.chans.size()) * sizeof(NvhChan));
   size_t o_ps = ab.add(P.passes.empty() ? (const void*)dummy.data() : P.passes.data(), pad1(P.passes.size()) * sizeof(NvhResPass));
   size_t o_op = ab.add(P.ops.empty() ? (const void*)dummy.data() : P.ops.data(), pad1(P.ops.size()) * sizeof(NvhResOp));
+  size_t o_lk = ab.add(P.op_link.empty() ? (const void*)dummy.data() : P.op_link.data(), pad1(P.op_link.size()) * sizeof(uint16_t));
   size_t o_en = ab.add(P.entries.empty() ? (const void*)dummy.data() : P.entries.data(), pad1(P.entries.size()) * sizeof(uint16_t));
   size_t o_po = ab.add(P.posts.empty() ? (const void*)dummy.data() : P.posts.data(), pad1(P.posts.size()) * sizeof(uint16_t));
   size_t o_co = ab.add(P.coeffs.empty() ? (const void*)dummy.data() : P.coeffs.data(), pad1(P.coeffs.size()) * sizeof(float));
   ab.bytes.resize(ab.bytes.size() + 64);  // k_spectrum copies entry slices in whole 16-byte vectors
   b->descriptor_bytes = (int64_t)(P.frames.size() * sizeof(NvhFrame) + P.chans.size() * sizeof(NvhChan) +
-                                  P.passes.size() * sizeof(NvhResPass) + P.ops.size() * sizeof(NvhResOp) +
+                                  P.passes.size() * sizeof(NvhResPass) + P.ops.size() * (sizeof(NvhResOp) + sizeof(uint16_t)) +
                                   P.entries.size() * 2 + P.posts.size() * 2 + P.coeffs.size() * 4);
   int rc = b->blob.reserve(ab.bytes.size());
   if (rc != NVH_OK) return rc;
@@ -740,6 +743,7 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->dev.chans = (const NvhChan*)(base + o_ch);
   b->dev.passes = (const NvhResPass*)(base + o_ps);
   b->dev.ops = (const NvhResOp*)(base + o_op);
+  b->dev.op_link = (const uint16_t*)(base + o_lk);
   b->dev.entries = (const uint16_t*)(base + o_en);
   b->dev.posts = (const uint16_t*)(base + o_po);
   b->dev.coeffs = (const float*)(base + o_co);
@@ -774,7 +778,8 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   const bool use_fused_ola = b->fused_ola && !no_fused_ola;
   const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola;
   // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers
-  const bool fuse_imdct = compact && s->fast_spectrum && s->setup.block1 <= 2048 && !no_fused_imdct;
+  const bool fast = s->fast_spectrum && b->links_ok;  // k_spectrum proper (pair path by chain walk, fused tail)
+  const bool fuse_imdct = compact && fast && s->setup.block1 <= 2048 && !no_fused_imdct;
   // Fused spectrum kernel when a frame's spectrum (+ staged side information) fits the default 64 KB dynamic
   // LDS window; LDS map in kernels_spectrum.hip.
   {
@@ -783,8 +788,8 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                                (size_t)s->setup.books.size() * 8 + (size_t)((s->dev.lattice_words + 3) & ~3) +
                                (size_t)ch * (size_t)(s->setup.block1 / 2);
     // staging capacities; the entry slice is copied from its enclosing 16-byte boundary (up to 7 entries of slack)
-    int cap_pass = b->max_pass, cap_ops = (b->max_ops + 1) & ~1, cap_ent = (b->max_ent + 14) & ~7;
-    size_t words = fixed_words + (size_t)cap_pass * 16 + (size_t)cap_ops * 6 + (size_t)cap_ent / 2;
+    int cap_pass = b->max_pass, cap_ops = (b->max_ops + 7) & ~7, cap_ent = (b->max_ent + 14) & ~7;
+    size_t words = fixed_words + (size_t)cap_pass * 16 + (size_t)cap_ops * 6 + (size_t)cap_ops / 2 + (size_t)cap_ent / 2;  // ops 2 + pair records 4 + links 1/2 words per op
     if (getenv("NVH_UNFUSED")) words = 1u << 20;  // test aid: force the unfused kernels below
     static const int phase_mask = getenv("NVH_DEBUG_SPECTRUM_MASK") ? atoi(getenv("NVH_DEBUG_SPECTRUM_MASK")) : 7;  // profiling aid
     static const size_t lds_pad = getenv("NVH_LDS_PAD") ? (size_t)atoi(getenv("NVH_LDS_PAD")) : 0;  // occupancy experiments
@@ -803,11 +808,11 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     } else if (words * 4 <= 64 * 1024) {
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
       b->slot_name[0] = "-";
-      b->slot_name[1] = has_floor0 ? "k_spectrum_f0" : (s->fast_spectrum ? "k_spectrum" : "k_spectrum_gen");
+      b->slot_name[1] = has_floor0 ? "k_spectrum_f0" : (fast ? "k_spectrum" : "k_spectrum_gen");
       if (has_floor0) {
         hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent);
-      } else if (!s->fast_spectrum) {
+      } else if (!fast) {
         hipLaunchKernelGGL(k_spectrum_gen, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent);
       } else {

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #define NVH_MAX_POSTS 64        // Floor1.Data.Posts = new int[64] (Floor1.cs:12)
+#define NVH_LINK_NONE 0x7FFF     // NvhDevBatch::op_link: no later-stage op for this partition/channel
 #define NVH_MAX_STAGES 8        // cascade is 8 bits wide (Residue0.cs:46-58)
 #define NVH_MAX_CLASSES 64      // 6 bits + 1 (Residue0.cs:41)
 #define NVH_ENTRY_SKIP 0xFFFFu  // entry-stream sentinel: "no vector was added here"

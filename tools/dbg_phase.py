@@ -53,3 +53,10 @@ n_at = lambda T: np.array([(v <= T).sum() for v in first.values()])
 for T in (0.3, 1, 2, 4, 6, 8):
     a = n_at(T); print("  by %.1f us: WGs started per CU min %d max %d mean %.2f" % (T, a.min(), a.max(), a.mean()))
 L.nvh_debug_set_buffer(None)
+# which SIMD does hardware wave 0 of each workgroup land on, and how do blockIdx residues spread over one CU?
+simd = (hwid >> 4) & 3
+print("SIMD of hw wave 0: counts", np.bincount(simd, minlength=4).tolist())
+for k in list(np.unique(key))[:3]:
+    sel = np.nonzero(key == k)[0]
+    o = sel[np.argsort(t[sel])]
+    print(" CU", int(k), "blockIdx in start order:", o.tolist())
