@@ -30,10 +30,6 @@ __global__ void k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* work, 
                               int* clipped_flag, float* carry_out, int last_decoded);
 __global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent,
                            long long* dbg, int phase_mask);
-__global__ void k_spectrum2_c1(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
-__global__ void k_spectrum2_c2(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
-__global__ void k_spectrum2_c1_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
-__global__ void k_spectrum2_c2_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_ops, int cap_ent, int cap_idx);
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent,
                                  long long* dbg, int phase_mask);
@@ -129,8 +125,6 @@ struct nvh_stream {
   int clip = 1;
   int has_clipped = 0;
   bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
-  bool gather_ok = false;  // stream shape admits k_spectrum2 (kernels_spectrum2.hip)
-  int gather_idx_cap = 0;  // entries of its (stage, partition[, channel]) -> op index
   bool has_floor0 = false;
   nvh_batch scratch;  // reused by nvh_stream_synth
 };
@@ -503,26 +497,8 @@ static int upload_setup(nvh_stream* s) {
     o_tw[w] = ab.add(S.mdct[w].tw.data(), S.mdct[w].tw.size() * sizeof(float));
   }
 
-  {
-    // k_spectrum2 preconditions: 1-2 channels, a single submap per mapping, residues of type 1/2 without aliasing
-    bool ok = S.channels <= 2;
-    for (const auto& m : S.mappings) ok = ok && m.submap_floor.size() == 1;
-    int max_parts = 0;
-    for (size_t i = 0; i < S.residues.size(); i++) {
-      const nvh::Residue& r = S.residues[i];
-      ok = ok && r.type != 0 && residues[i].fast && !residues[i].sequential;
-      const int bs = r.type == 2 ? S.block1 * S.channels : S.block1;
-      const int end = r.end < bs / 2 ? r.end : bs / 2;
-      const int parts = end > r.begin ? (end - r.begin) / r.partition_size : 0;
-      const int mul = r.type == 2 ? 1 : S.channels;
-      if (parts * mul > max_parts) max_parts = parts * mul;
-      if (parts > 0xFFFE) ok = false;
-    }
-    s->has_floor0 = false;
-    for (const auto& fl : S.floors) s->has_floor0 = s->has_floor0 || fl.type == 0;
-    s->gather_ok = ok;
-    s->gather_idx_cap = (NVH_MAX_STAGES * max_parts + 7) & ~7;
-  }
+  s->has_floor0 = false;
+  for (const auto& fl : S.floors) s->has_floor0 = s->has_floor0 || fl.type == 0;
   int rc = s->arena.reserve(ab.bytes.size());
   if (rc != NVH_OK) return rc;
   HIP_TRY(hipMemcpy(s->arena.p, ab.bytes.data(), ab.bytes.size(), hipMemcpyHostToDevice));
@@ -779,7 +755,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola;
   // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers
   const bool fast = s->fast_spectrum && b->links_ok;  // k_spectrum proper (pair path by chain walk, fused tail)
-  const bool fuse_imdct = compact && fast && s->setup.block1 <= 2048 && !no_fused_imdct;
+  bool fuse_imdct = compact && fast && s->setup.block1 <= 2048 && !no_fused_imdct;  // and the LDS-resident path is taken (below)
   // Fused spectrum kernel when a frame's spectrum (+ staged side information) fits the default 64 KB dynamic
   // LDS window; LDS map in kernels_spectrum.hip.
   {
@@ -791,21 +767,10 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     int cap_pass = b->max_pass, cap_ops = (b->max_ops + 7) & ~7, cap_ent = (b->max_ent + 14) & ~7;
     size_t words = fixed_words + (size_t)cap_pass * 16 + (size_t)cap_ops * 6 + (size_t)cap_ops / 2 + (size_t)cap_ent / 2;  // ops 2 + pair records 4 + links 1/2 words per op
     if (getenv("NVH_UNFUSED")) words = 1u << 20;  // test aid: force the unfused kernels below
+    if ((words + (size_t)(s->setup.block1 / 16)) * 4 > 64 * 1024) fuse_imdct = false;
     static const int phase_mask = getenv("NVH_DEBUG_SPECTRUM_MASK") ? atoi(getenv("NVH_DEBUG_SPECTRUM_MASK")) : 7;  // profiling aid
     static const size_t lds_pad = getenv("NVH_LDS_PAD") ? (size_t)atoi(getenv("NVH_LDS_PAD")) : 0;  // occupancy experiments
-    static const int no_gather = getenv("NVH_GATHER") ? 0 : 1;  // gather-form kernel (kernels_spectrum2.hip): bit-exact but not faster, opt-in
-    // gather form (kernels_spectrum2.hip): needs the op / entry slices staged (op indices are 16-bit)
-    size_t g_words = (size_t)(has_floor0 ? 512 : 256) + (size_t)ch * (1840 / 4) + (size_t)s->setup.books.size() * 8 +
-                     (size_t)((b->max_ops + 1) & ~1) * 2 + (size_t)((b->max_ent + 7) & ~7) / 2 + (size_t)s->gather_idx_cap / 2 +
-                     (size_t)ch * (size_t)(s->setup.block1 / 8) + (has_floor0 ? (size_t)ch * (size_t)(s->setup.block1 / 2) : 0);
-    if (s->gather_ok && !no_gather && b->max_ops < 0xFFFF && g_words * 4 <= 64 * 1024) {
-      const int g_ops = (b->max_ops + 1) & ~1, g_ent = (b->max_ent + 7) & ~7;
-      if (timing) HIP_TRY(hipEventRecord(ev[1], st));
-      b->slot_name[0] = "-"; b->slot_name[1] = "k_spectrum2";
-      auto kern = ch == 1 ? (has_floor0 ? k_spectrum2_c1_f0 : k_spectrum2_c1) : (has_floor0 ? k_spectrum2_c2_f0 : k_spectrum2_c2);
-      hipLaunchKernelGGL(kern, dim3((unsigned)b->nframes), dim3(128), g_words * 4, st, s->dev, b->dev, work, flags, g_ops, g_ent,
-                         s->gather_idx_cap);
-    } else if (words * 4 <= 64 * 1024) {
+    if (words * 4 <= 64 * 1024) {
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
       b->slot_name[0] = "-";
       b->slot_name[1] = has_floor0 ? "k_spectrum_f0" : (fast ? "k_spectrum" : "k_spectrum_gen");

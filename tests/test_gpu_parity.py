@@ -217,3 +217,24 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
     assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) <= 1e-6
     exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
     assert exact > 0.99, exact
+
+
+@pytest.mark.parametrize("toggle", ["NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT"])
+def test_fallback_kernel_paths_bit_exact(toggle):
+    """The library picks kernel variants by stream shape.  Each environment toggle disables one
+    level of fusion, so the whole parity suite above is replayed through the general kernels in a child process:
+    NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact,
+    NVH_NO_COMPACT -> k_imdct_wave + k_ola_emit."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NVH_TEST_CHILD"):
+        pytest.skip("already inside a fallback-path run")
+    env = dict(os.environ)
+    env[toggle] = "1"
+    env["NVH_TEST_CHILD"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 NAME=${1:-r01}
 OUT=gpurun_out/prof_$NAME
 rm -rf $OUT; mkdir -p $OUT
-B="python bench.py --no-cpu-baseline --steps 20 --warmup 5"
+B="python bench.py --no-cpu-baseline --steps 20 --warmup 5 --streams 1"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- $B > $OUT/write.log 2>&1
