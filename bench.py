@@ -54,7 +54,7 @@ def cpu_baseline(headers, ll, seconds=12.0):
     fl = [0] * len(packets)
     reps, t_total, frames = 0, 0.0, 0
     orc.decode_packets(packets[:64], gr[:64], fl[:64])  # warm tables
-    while t_total < seconds and reps < 64:
+    while t_total < seconds and reps < 1024:
         t0 = time.perf_counter()
         pcm, info = orc.decode_packets(packets, gr, fl)
         t_total += time.perf_counter() - t0
