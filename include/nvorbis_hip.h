@@ -89,6 +89,11 @@ int nvh_stream_position(const nvh_stream *s, int64_t *position, int64_t *emitted
 /* Host parse of one audio packet into the pending batch (DecodeNextPacket, StreamDecoder.cs:465-530,
  * bit-consuming half).  granule < 0 = packet carries no granule position. */
 int nvh_stream_push_packet(nvh_stream *s, const uint8_t *data, int len, int64_t granule, int flags);
+/* nvh_stream_push_packet over a packet array in one call (packet i = bytes[offsets[i], offsets[i+1]); granules / flags
+ * may be NULL): the look-ahead loop of a batched caller without one FFI transition per packet.  Stops after
+ * max_packets, at the first error, or once the stream has seen its end-of-stream packet; *consumed = packets taken. */
+int nvh_stream_push_packets(nvh_stream *s, const uint8_t *bytes, const int64_t *offsets, const int64_t *granules,
+                            const uint8_t *flags, int n, int max_packets, int *consumed);
 /* The packet provider returned null (StreamDecoder.cs:472-475). */
 int nvh_stream_push_end(nvh_stream *s);
 /* Pending (parsed, not yet synthesised) work. */

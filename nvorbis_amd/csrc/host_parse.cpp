@@ -438,10 +438,14 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
   const int idx = (int)out.frames.size() - 1;
   NvhFrame& f = out.frames[(size_t)idx];
   int start = f.start, valid = f.valid, total = f.total;
+  bool trimmed_eos = false;
   if (granule >= 0 && is_eos) {
     int64_t actual_end = position_ + valid - start;
     int diff = (int)(granule - actual_end);
-    if (diff < 0) valid += diff;
+    if (diff < 0) {
+      valid += diff;
+      trimmed_eos = true;
+    }
   }
   if (prev_end_ > 0) {
     int ov_len = prev_stop_ - prev_start_;
@@ -459,7 +463,11 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
         out.chans[f.chan_off + c].ov_exec = prev_exec_[c];
         if (c < 32 && prev_exec_[c]) f.ov_exec_mask |= 1u << c;
       }
-      if (start + ov_len > valid) out.sequential_ola = true;  // the overlap reaches this block's own tail
+      // The overlap reaches this block's own tail: a later overlap (or drain) would read samples this one has
+      // modified, so the batch must apply its overlaps in order.  Measured against the untrimmed `valid`: an
+      // end-of-stream trim moves `valid` into the overlapped region, but nothing is pulled after that packet
+      // (StreamDecoder.cs:343-350), so its tail is never read.
+      if (start + ov_len > (trimmed_eos ? f.valid : valid)) out.sequential_ola = true;
     }
     prev_start_ = start;
   } else if (!has_prev_buf_) {

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <iterator>
 #include <new>
 #include <string>
 #include <vector>
@@ -61,17 +62,69 @@ extern "C" void nvh_debug_set_buffer(void* d_buf) { g_dbg_buf = d_buf; }
 
 namespace {
 
-struct DevBuf {  // growable device allocation
+// Device allocations are recycled through a per-context pool: hipMalloc / hipFree cost 0.1-1 ms each and
+// serialise inside the runtime, which is what a file-parallel transcoder (many short streams per context, many
+// contexts per GPU) would otherwise spend its time on.  Every buffer of a context is used on that context's HIP
+// stream only, so handing a block from a closed stream to the next one is ordered by the stream itself.
+struct BufPool {
+  bool host = false;  // true: pinned host memory (hipHostMalloc), staging for asynchronous copies
+  std::multimap<size_t, void*> free_;
+  size_t bytes_ = 0;
+  void raw_free(void* p) const { (void)(host ? hipHostFree(p) : hipFree(p)); }
+  static constexpr size_t kKeepBytes = (size_t)2 << 30;  // beyond this, returned blocks go back to the runtime
+  // size classes with two mantissa bits (<= 25 % slack) so that blocks are interchangeable between streams
+  static size_t size_class(size_t bytes) {
+    size_t v = bytes < 4096 ? 4096 : bytes;
+    size_t p = 1;
+    while ((p << 1) <= v) p <<= 1;
+    size_t step = p >> 2;
+    return (v + step - 1) / step * step;
+  }
+  void* take(size_t cls) {
+    auto it = free_.find(cls);
+    if (it == free_.end()) return nullptr;
+    void* p = it->second;
+    free_.erase(it);
+    bytes_ -= cls;
+    return p;
+  }
+  void give(void* p, size_t cls) {
+    if (bytes_ + cls > kKeepBytes) {
+      raw_free(p);
+      return;
+    }
+    free_.emplace(cls, p);
+    bytes_ += cls;
+  }
+  void clear() {
+    for (auto& kv : free_) raw_free(kv.second);
+    free_.clear();
+    bytes_ = 0;
+  }
+};
+
+struct DevBuf {  // growable device (or pinned host) allocation, optionally backed by a context's pool
   void* p = nullptr;
   size_t cap = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int reserve(size_t bytes) {
-    if (bytes <= cap) return NVH_OK;
-    if (p) (void)hipFree(p);
+  BufPool* pool = nullptr;
+  bool host = false;  // pinned host memory; must match pool->host
+  ~DevBuf() { release(); }
+  void release() {
+    if (!p) return;
+    if (pool) pool->give(p, cap);
+    else (void)(host ? hipHostFree(p) : hipFree(p));
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
-    HIP_TRY(hipMalloc(&p, want));
+  }
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return NVH_OK;
+    release();
+    const size_t want = BufPool::size_class(bytes + 256);
+    if (pool) p = pool->take(want);
+    if (!p) {
+      if (host) HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+      else HIP_TRY(hipMalloc(&p, want));
+    }
     cap = want;
     return NVH_OK;
   }
@@ -85,16 +138,31 @@ struct MdctDev {
 
 }  // namespace
 
+// Everything derived from a stream's headers: parsed tables on the host, their device image, kernel-selection
+// flags.  Immutable once built, so streams with byte-identical identification + setup packets (the normal case
+// inside one corpus: same encoder, same settings) share one entry per context.
+struct SharedSetup {
+  nvh::Setup setup;
+  DevBuf arena;  // setup tables
+  NvhDevSetup dev{};
+  bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
+  bool has_floor0 = false;
+};
+
 struct nvh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::map<int, MdctDev> mdct_cache;  // Mdct._setupCache (Mdct.cs:11)
+  BufPool pool;
+  BufPool hpool;  // pinned staging blocks
+  std::map<std::string, std::shared_ptr<SharedSetup>> setup_cache;  // key: identification packet + setup packet bytes
 };
 
 struct nvh_batch {
   nvh_stream* s = nullptr;
   DevBuf blob;          // all descriptor arrays, one allocation
+  DevBuf h_blob;        // pinned staging image of it (the upload is asynchronous)
   DevBuf work;          // [frames][ch][block1] float planes
   DevBuf carry_in;      // snapshot of the tail this batch overlaps its first frame with
   NvhDevBatch dev{};
@@ -113,20 +181,33 @@ struct nvh_batch {
 
 struct nvh_stream {
   nvh_ctx* ctx = nullptr;
-  nvh::Setup setup;
+  std::shared_ptr<SharedSetup> shared;
+  nvh::Setup& setup;
+  DevBuf& arena;
+  NvhDevSetup& dev;
+  bool& fast_spectrum;
+  bool& has_floor0;
   std::unique_ptr<nvh::StreamParser> parser;
   nvh::FrameBatch pending;
-  DevBuf arena;  // setup tables
-  NvhDevSetup dev{};
   DevBuf carry[2];  // [ch][block1] windowed block of the last decoded frame (ping-pong: read one, write the other)
   int carry_cur = 0;
   DevBuf flags;  // int[2]: device error word, clipped flag
   DevBuf pcm;    // staging for host-destination synth
+  DevBuf h_pcm;  // pinned bounce buffer behind it (+ 2 ints: the flag words), read back asynchronously
   int clip = 1;
   int has_clipped = 0;
-  bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
-  bool has_floor0 = false;
   nvh_batch scratch;  // reused by nvh_stream_synth
+
+  nvh_stream(nvh_ctx* c, std::shared_ptr<SharedSetup> sh)
+      : ctx(c), shared(std::move(sh)), setup(shared->setup), arena(shared->arena), dev(shared->dev),
+        fast_spectrum(shared->fast_spectrum), has_floor0(shared->has_floor0) {
+    BufPool* pool = c ? &c->pool : nullptr;
+    carry[0].pool = carry[1].pool = flags.pool = pcm.pool = pool;
+    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = pool;
+    h_pcm.host = scratch.h_blob.host = true;
+    h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;
+    scratch.s = this;
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -159,6 +240,7 @@ extern "C" int nvh_ctx_create(int device, nvh_ctx** out) {
   nvh_ctx* c = new (std::nothrow) nvh_ctx();
   if (!c) return NVH_ERR_NOMEM;
   c->device = device;
+  c->hpool.host = true;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
@@ -180,6 +262,9 @@ extern "C" void nvh_ctx_destroy(nvh_ctx* c) {
     (void)hipFree(kv.second.br);
     (void)hipFree(kv.second.tw);
   }
+  c->setup_cache.clear();  // streams must have been closed: they share these entries and return their buffers here
+  c->pool.clear();
+  c->hpool.clear();
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -543,36 +628,57 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
   // every synthesis entry point fails with NVH_ERR_NO_GPU -- there is no CPU synthesis path.
   if (!id_pkt || !setup_pkt || !out) return NVH_ERR_ARGUMENT;
   *out = nullptr;
+  if (id_len < 0 || setup_len < 0) return NVH_ERR_ARGUMENT;
   if (c) HIP_TRY(hipSetDevice(c->device));
-  std::unique_ptr<nvh_stream> s(new (std::nothrow) nvh_stream());
-  if (!s) return NVH_ERR_NOMEM;
-  s->ctx = c;
-  int rc = s->setup.parse_id(id_pkt, id_len);
-  if (rc != NVH_OK) return rc;
-  if (!valid_block(s->setup.block0) || !valid_block(s->setup.block1) || s->setup.block0 > s->setup.block1)
-    return NVH_ERR_UNSUPPORTED;  // Vorbis I allows 64..8192 with block0 <= block1
-  if (comment_pkt) {
-    rc = s->setup.parse_comment_sig(comment_pkt, comment_len);
+  int rc;
+  if (comment_pkt) {  // signature check only (StreamDecoder.cs:157-175), independent of the other two headers
+    nvh::Setup probe;
+    rc = probe.parse_comment_sig(comment_pkt, comment_len);
     if (rc != NVH_OK) return rc;
   }
-  rc = s->setup.parse_setup(setup_pkt, setup_len);
-  if (rc != NVH_OK) return rc;
+  std::string key;
+  std::shared_ptr<SharedSetup> sh;
+  if (c) {
+    key.assign((const char*)id_pkt, (size_t)id_len);
+    key.append((const char*)setup_pkt, (size_t)setup_len);
+    auto it = c->setup_cache.find(key);
+    if (it != c->setup_cache.end()) sh = it->second;
+  }
+  const bool cached = (bool)sh;
+  if (!cached) {
+    sh.reset(new (std::nothrow) SharedSetup());
+    if (!sh) return NVH_ERR_NOMEM;
+    sh->arena.pool = c ? &c->pool : nullptr;
+    rc = sh->setup.parse_id(id_pkt, id_len);
+    if (rc != NVH_OK) return rc;
+    if (!valid_block(sh->setup.block0) || !valid_block(sh->setup.block1) || sh->setup.block0 > sh->setup.block1)
+      return NVH_ERR_UNSUPPORTED;  // Vorbis I allows 64..8192 with block0 <= block1
+    rc = sh->setup.parse_setup(setup_pkt, setup_len);
+    if (rc != NVH_OK) return rc;
+  }
+  std::unique_ptr<nvh_stream> s(new (std::nothrow) nvh_stream(c, sh));
+  if (!s) return NVH_ERR_NOMEM;
   s->parser.reset(new nvh::StreamParser(&s->setup));
-  s->scratch.s = s.get();
   if (!c) {
     *out = s.release();
     return NVH_OK;
   }
-  rc = upload_setup(s.get());
-  if (rc != NVH_OK) return rc;
+  if (!cached) {
+    rc = upload_setup(s.get());
+    if (rc != NVH_OK) return rc;
+    if (c->setup_cache.size() >= 64) {  // bounded: drop entries no open stream uses
+      for (auto it = c->setup_cache.begin(); it != c->setup_cache.end();)
+        it = it->second.use_count() == 1 ? c->setup_cache.erase(it) : std::next(it);
+    }
+    c->setup_cache.emplace(std::move(key), sh);
+  }
   size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
   for (int k = 0; k < 2; k++) {
     if ((rc = s->carry[k].reserve(plane)) != NVH_OK) return rc;
-    HIP_TRY(hipMemset(s->carry[k].p, 0, plane));
+    HIP_TRY(hipMemsetAsync(s->carry[k].p, 0, plane, c->stream));
   }
   if ((rc = s->flags.reserve(2 * sizeof(int))) != NVH_OK) return rc;
-  HIP_TRY(hipMemset(s->flags.p, 0, 2 * sizeof(int)));
-  s->scratch.s = s.get();
+  HIP_TRY(hipMemsetAsync(s->flags.p, 0, 2 * sizeof(int), c->stream));
   *out = s.release();
   return NVH_OK;
 }
@@ -619,6 +725,27 @@ extern "C" int nvh_stream_push_packet(nvh_stream* s, const uint8_t* data, int le
   if (!s || (!data && len > 0) || len < 0) return NVH_ERR_ARGUMENT;
   static const uint8_t empty = 0;
   return s->parser->push_packet(data ? data : &empty, len, granule, flags, s->pending);
+}
+
+extern "C" int nvh_stream_push_packets(nvh_stream* s, const uint8_t* bytes, const int64_t* offsets, const int64_t* granules,
+                                       const uint8_t* flags, int n, int max_packets, int* consumed) {
+  if (!s || !bytes || !offsets || !consumed || n < 0) return NVH_ERR_ARGUMENT;
+  static const uint8_t empty = 0;
+  int i = 0;
+  // the look-ahead loop of a batched caller: stop when the quota is used up or once the stream has seen its
+  // end-of-stream packet (StreamDecoder.cs:343-350: no more packets are pulled after _eosFound)
+  for (; i < n && i < max_packets && !s->parser->eos(); i++) {
+    const int64_t len = offsets[i + 1] - offsets[i];
+    if (len < 0 || len > 0x7FFFFFFF) return NVH_ERR_ARGUMENT;
+    int rc = s->parser->push_packet(len ? bytes + offsets[i] : &empty, (int)len, granules ? granules[i] : -1,
+                                    flags ? (int)flags[i] : 0, s->pending);
+    if (rc != NVH_OK) {
+      *consumed = i;
+      return rc;
+    }
+  }
+  *consumed = i;
+  return NVH_OK;
 }
 
 extern "C" int nvh_stream_push_end(nvh_stream* s) {
@@ -694,26 +821,38 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->stats[0] = (int64_t)P.frames.size(); b->stats[1] = (int64_t)P.chans.size(); b->stats[2] = (int64_t)P.passes.size();
   b->stats[3] = (int64_t)P.ops.size(); b->stats[4] = (int64_t)P.entries.size(); b->stats[5] = (int64_t)P.posts.size();
   b->stats[6] = (int64_t)P.coeffs.size();
-  ArenaBuilder ab;
+  // the descriptor arrays are laid out back to back (16-byte aligned) in one pinned staging block and go to the
+  // device with one asynchronous copy; the caller decides when the stream is synchronised
   auto pad1 = [](size_t n) { return n ? n : (size_t)1; };
-  std::vector<uint8_t> dummy(64, 0);
-  size_t o_fr = ab.add(P.frames.empty() ? (const void*)dummy.data() : P.frames.data(), pad1(P.frames.size()) * sizeof(NvhFrame));
-  size_t o_ch = ab.add(P.chans.empty() ? (const void*)dummy.data() : P.chans.data(), pad1(P.chans.size()) * sizeof(NvhChan));
-  size_t o_ps = ab.add(P.passes.empty() ? (const void*)dummy.data() : P.passes.data(), pad1(P.passes.size()) * sizeof(NvhResPass));
-  size_t o_op = ab.add(P.ops.empty() ? (const void*)dummy.data() : P.ops.data(), pad1(P.ops.size()) * sizeof(NvhResOp));
-  size_t o_lk = ab.add(P.op_link.empty() ? (const void*)dummy.data() : P.op_link.data(), pad1(P.op_link.size()) * sizeof(uint16_t));
-  size_t o_en = ab.add(P.entries.empty() ? (const void*)dummy.data() : P.entries.data(), pad1(P.entries.size()) * sizeof(uint16_t));
-  size_t o_po = ab.add(P.posts.empty() ? (const void*)dummy.data() : P.posts.data(), pad1(P.posts.size()) * sizeof(uint16_t));
-  size_t o_co = ab.add(P.coeffs.empty() ? (const void*)dummy.data() : P.coeffs.data(), pad1(P.coeffs.size()) * sizeof(float));
-  ab.bytes.resize(ab.bytes.size() + 64);  // k_spectrum copies entry slices in whole 16-byte vectors
+  static const uint8_t dummy[64] = {0};
+  struct Piece { const void* src; size_t n, off; };
+  std::vector<Piece> pieces;
+  size_t total = 0;
+  auto add = [&](const void* src, size_t count, size_t elem) {
+    const size_t n = pad1(count) * elem;
+    total = (total + 15) / 16 * 16;
+    pieces.push_back({count ? src : (const void*)dummy, count ? n : (n < sizeof dummy ? n : sizeof dummy), total});
+    total += n;
+    return pieces.back().off;
+  };
+  size_t o_fr = add(P.frames.data(), P.frames.size(), sizeof(NvhFrame));
+  size_t o_ch = add(P.chans.data(), P.chans.size(), sizeof(NvhChan));
+  size_t o_ps = add(P.passes.data(), P.passes.size(), sizeof(NvhResPass));
+  size_t o_op = add(P.ops.data(), P.ops.size(), sizeof(NvhResOp));
+  size_t o_lk = add(P.op_link.data(), P.op_link.size(), sizeof(uint16_t));
+  size_t o_en = add(P.entries.data(), P.entries.size(), sizeof(uint16_t));
+  size_t o_po = add(P.posts.data(), P.posts.size(), sizeof(uint16_t));
+  size_t o_co = add(P.coeffs.data(), P.coeffs.size(), sizeof(float));
+  total += 64;  // k_spectrum copies entry slices in whole 16-byte vectors
   b->descriptor_bytes = (int64_t)(P.frames.size() * sizeof(NvhFrame) + P.chans.size() * sizeof(NvhChan) +
                                   P.passes.size() * sizeof(NvhResPass) + P.ops.size() * (sizeof(NvhResOp) + sizeof(uint16_t)) +
                                   P.entries.size() * 2 + P.posts.size() * 2 + P.coeffs.size() * 4);
-  int rc = b->blob.reserve(ab.bytes.size());
+  int rc = b->blob.reserve(total);
   if (rc != NVH_OK) return rc;
+  if ((rc = b->h_blob.reserve(total)) != NVH_OK) return rc;
+  for (const Piece& pc : pieces) std::memcpy((uint8_t*)b->h_blob.p + pc.off, pc.src, pc.n);
   hipStream_t st = s->ctx->stream;
-  HIP_TRY(hipMemcpyAsync(b->blob.p, ab.bytes.data(), ab.bytes.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));  // `ab` is pageable host memory owned by this frame
+  HIP_TRY(hipMemcpyAsync(b->blob.p, b->h_blob.p, total, hipMemcpyHostToDevice, st));
   const uint8_t* base = (const uint8_t*)b->blob.p;
   b->dev.frames = (const NvhFrame*)(base + o_fr);
   b->dev.chans = (const NvhChan*)(base + o_ch);
@@ -894,9 +1033,17 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
   if (rc != NVH_OK) return rc;
   hipStream_t st = s->ctx->stream;
   if (b->last_decoded >= 0) s->carry_cur ^= 1;  // the batch wrote its last block's tail into the other buffer
-  if (pcm_host && need > 0) HIP_TRY(hipMemcpyAsync(pcm_host, dst, (size_t)need * sizeof(float), hipMemcpyDeviceToHost, st));
-  rc = collect_flags(s);  // synchronises the stream
-  if (rc != NVH_OK) return rc;
+  // one read-back, one synchronisation: PCM and the two flag words land in a pinned bounce buffer
+  const size_t pcm_bytes = pcm_host ? (size_t)need * sizeof(float) : 0;
+  if ((rc = s->h_pcm.reserve(pcm_bytes + 2 * sizeof(int))) != NVH_OK) return rc;
+  int* h_flags = (int*)((uint8_t*)s->h_pcm.p + pcm_bytes);
+  if (pcm_bytes) HIP_TRY(hipMemcpyAsync(s->h_pcm.p, dst, pcm_bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_flags, s->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (pcm_bytes) std::memcpy(pcm_host, s->h_pcm.p, pcm_bytes);
+  if (h_flags[0] || h_flags[1]) HIP_TRY(hipMemsetAsync(s->flags.p, 0, 2 * sizeof(int), st));
+  if (h_flags[1]) s->has_clipped = 1;
+  if (h_flags[0]) return NVH_ERR_RUNTIME;  // inverse_dB_table / wMap index out of range in the reference
   if (written) *written = need;
   return NVH_OK;
 }
@@ -907,6 +1054,11 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
   if (!s->ctx) return NVH_ERR_NO_GPU;
   HIP_TRY(hipSetDevice(s->ctx->device));
   std::unique_ptr<nvh_batch> b(new (std::nothrow) nvh_batch());
+  if (b && s && s->ctx) {
+    b->blob.pool = b->work.pool = b->carry_in.pool = &s->ctx->pool;
+    b->h_blob.host = true;
+    b->h_blob.pool = &s->ctx->hpool;
+  }
   if (!b) return NVH_ERR_NOMEM;
   // snapshot the tail this batch starts from so that repeated synthesis is idempotent
   size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);

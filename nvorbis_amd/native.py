@@ -53,6 +53,7 @@ SIGNATURES = {
     "nvh_stream_has_clipped": (C.c_int, [_vp, _ip]),
     "nvh_stream_position": (C.c_int, [_vp, _i64p, _i64p, _ip]),
     "nvh_stream_push_packet": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int]),
+    "nvh_stream_push_packets": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "nvh_stream_push_end": (C.c_int, [_vp]),
     "nvh_stream_pending": (C.c_int, [_vp, _ip, _i64p]),
     "nvh_stream_pending_geometry": (C.c_int, [_vp, _vp, C.c_int]),

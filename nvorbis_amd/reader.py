@@ -14,8 +14,29 @@ from . import native
 from .native import check, lib
 
 
-def demux_ogg(data: bytes):
-    """First logical stream of an Ogg file -> (list of packet bytes, granules, flags).
+class PacketArray:
+    """Packets of one logical stream in one contiguous buffer (what nvh_ogg_demux produces): packet i is
+    bytes[offsets[i]:offsets[i+1]].  Feeds nvh_stream_push_packets without one FFI call per packet."""
+
+    def __init__(self, data, offsets, granules, flags):
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = self.offsets.size - 1
+        self.granules = np.ascontiguousarray(granules[:n], dtype=np.int64) if n else np.zeros(1, np.int64)
+        self.flags = np.ascontiguousarray(flags[:n], dtype=np.uint8) if n else np.zeros(1, np.uint8)
+        self._n = n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if i < 0 or i >= self._n:
+            raise IndexError(i)
+        return self.data[self.offsets[i]:self.offsets[i + 1]].tobytes()
+
+
+def demux_ogg_array(data: bytes):
+    """First logical stream of an Ogg file as a PacketArray.
 
     Delivers packets the way NVorbis' seekable reader does (Ogg/PacketProvider.cs:324-438)."""
     L = lib()
@@ -29,8 +50,14 @@ def demux_ogg(data: bytes):
     flags = np.zeros(max(n.value, 1), dtype=np.uint8)
     check(L.nvh_ogg_demux(buf, len(data), pk.ctypes.data, pk.size, offs.ctypes.data, gran.ctypes.data,
                           flags.ctypes.data, n.value, C.byref(n), C.byref(total)), "nvh_ogg_demux")
-    packets = [pk[offs[i]:offs[i + 1]].tobytes() for i in range(n.value)]
-    return packets, gran[:n.value].copy(), flags[:n.value].copy()
+    return PacketArray(pk, offs[:n.value + 1], gran, flags)
+
+
+def demux_ogg(data: bytes):
+    """First logical stream of an Ogg file -> (list of packet bytes, granules, flags)."""
+    pa = demux_ogg_array(data)
+    n = len(pa)
+    return [pa[i] for i in range(n)], pa.granules[:n].copy(), pa.flags[:n].copy()
 
 
 class Context:
@@ -126,6 +153,16 @@ class Stream:
     def push_packet(self, data, granule=-1, flags=0):
         check(lib().nvh_stream_push_packet(self._h, data, len(data), int(granule), int(flags)), "nvh_stream_push_packet")
 
+    def push_packets(self, pa, first, max_packets):
+        """Push packets pa[first:] (a PacketArray) until max_packets were taken or the stream saw its EOS packet;
+        returns the number consumed."""
+        took = C.c_int(0)
+        n = len(pa) - first
+        check(lib().nvh_stream_push_packets(self._h, pa.data.ctypes.data, pa.offsets[first:].ctypes.data,
+                                            pa.granules[first:].ctypes.data, pa.flags[first:].ctypes.data, int(n),
+                                            int(max_packets), C.byref(took)), "nvh_stream_push_packets")
+        return took.value
+
     def push_end(self):
         check(lib().nvh_stream_push_end(self._h), "nvh_stream_push_end")
 
@@ -191,6 +228,7 @@ class StreamDecoder:
             raise native.NvhError(native.ERR_NOT_VORBIS, "StreamDecoder")
         self._stream = Stream(ctx, packets[0], packets[1], packets[2])
         self._packets = packets
+        self._array = packets if isinstance(packets, PacketArray) else None  # batched push, no per-packet FFI call
         self._granules = granules if granules is not None else [-1] * len(packets)
         self._flags = flags if flags is not None else [0] * len(packets)
         self._next = 3
@@ -226,6 +264,18 @@ class StreamDecoder:
         """Parse up to batch_frames packets ahead and synthesise them."""
         while not self._ended:
             pushed = 0
+            if self._array is not None:
+                if self._stream.position()[2]:
+                    self._ended = True
+                elif self._next >= len(self._array):
+                    self._stream.push_end()
+                    self._ended = True
+                else:
+                    took = self._stream.push_packets(self._array, self._next, self._batch_frames)
+                    self._next += took
+                    if took < self._batch_frames and self._next < len(self._array):
+                        self._ended = True  # stopped early: _eosFound
+                pushed = self._batch_frames
             while pushed < self._batch_frames:
                 if self._stream.position()[2]:
                     self._ended = True  # _eosFound: no more packets are pulled
@@ -280,8 +330,7 @@ class VorbisReader:
                 data = fh.read()
         self._own_ctx = ctx is None
         self._ctx = ctx if ctx is not None else Context(device)
-        packets, gran, flags = demux_ogg(data)
-        self._dec = StreamDecoder(self._ctx, packets, gran.tolist(), flags.tolist(), batch_frames)
+        self._dec = StreamDecoder(self._ctx, demux_ogg_array(data), None, None, batch_frames)
 
     Channels = property(lambda self: self._dec.Channels)
     SampleRate = property(lambda self: self._dec.SampleRate)

@@ -238,3 +238,15 @@ def test_fallback_kernel_paths_bit_exact(toggle):
                         "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_threaded_corpus_decode_matches_serial(oracle, ogg_bytes):
+    """File-parallel decode with a pool of host threads on one GPU (corpus.decode_files_threaded) returns, per file,
+    exactly the oracle's PCM: concurrent contexts / HIP streams do not interfere."""
+    from nvorbis_amd import corpus
+    names = ["1test", "2test", "3test", "issue6test"] * 3
+    files = [ogg_bytes[n] for n in names]
+    out = corpus.decode_files_threaded(files, device=0, workers=6, batch_frames=512)
+    refs = {n: oracle.decode_ogg(ogg_bytes[n])[0] for n in set(names)}
+    for n, o in zip(names, out):
+        assert o.size == refs[n].size and (o == refs[n]).all(), n

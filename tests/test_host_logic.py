@@ -167,3 +167,27 @@ def test_parser_geometry_synthetic_configs(oracle, name):
         dec = geo[geo[:, 0] != 0]
         assert dec.shape[0] == ok.shape[0]
         assert np.array_equal(dec[:, 0], ok[:, 4]) and np.array_equal(dec[:, 1], ok[:, 0]) and np.array_equal(dec[:, 3], ok[:, 2])
+
+
+def test_push_packets_equals_per_packet_push(ogg_bytes):
+    """nvh_stream_push_packets (one FFI call per batch) leaves the parser in the same state as the per-packet loop,
+    including the stop at the end-of-stream packet."""
+    import nvorbis_amd as nv
+    for name in ("1test", "issue6test"):
+        pa = nv.demux_ogg_array(ogg_bytes[name])
+        a = nv.Stream(None, pa[0], pa[1], pa[2])
+        b = nv.Stream(None, pa[0], pa[1], pa[2])
+        for i in range(3, len(pa)):
+            if a.position()[2]:
+                break
+            a.push_packet(pa[i], int(pa.granules[i]), int(pa.flags[i]))
+        nxt = 3
+        while nxt < len(pa) and not b.position()[2]:
+            took = b.push_packets(pa, nxt, 37)
+            assert 0 < took <= 37
+            nxt += took
+        assert a.pending() == b.pending()
+        assert a.position() == b.position()
+        assert (a.pending_geometry() == b.pending_geometry()).all()
+        a.close()
+        b.close()
