@@ -83,12 +83,18 @@ def gather_pcm(local, nfiles, rank, world, dist=None, device="cpu"):
     return out
 
 
-def transcode(files, decode_fn, rank=0, world=1, dist=None, device="cpu"):
+def transcode(files, decode_fn=None, rank=0, world=1, dist=None, device="cpu", gpu=0, workers=16):
     """Decode `files` (list of bytes) file-parallel; rank 0 returns the list of PCM arrays in file order.
 
-    decode_fn(bytes) -> float32 numpy PCM.  Gathered PCM is byte-identical to a single-rank run."""
+    decode_fn(bytes) -> float32 numpy PCM decodes one file; None = this package's GPU path with a pool of `workers`
+    host threads on HIP device `gpu` (decode_files_threaded).  Gathered PCM is byte-identical to a single-rank run."""
     shards = lpt_shards([len(f) for f in files], world)
-    local = {i: np.ascontiguousarray(decode_fn(files[i]), dtype=np.float32) for i in shards[rank]}
+    mine = shards[rank]
+    if decode_fn is None:
+        pcm = decode_files_threaded([files[i] for i in mine], device=gpu, workers=workers)
+        local = {i: np.ascontiguousarray(a, dtype=np.float32) for i, a in zip(mine, pcm)}
+    else:
+        local = {i: np.ascontiguousarray(decode_fn(files[i]), dtype=np.float32) for i in mine}
     return gather_pcm(local, len(files), rank, world, dist, device)
 
 

@@ -6,6 +6,7 @@
 // (:150-160).  Implemented as a bit cursor over the packet bytes (no bucket refill state).
 #pragma once
 #include <cstdint>
+#include <cstring>
 
 namespace nvh {
 
@@ -23,8 +24,14 @@ struct BitReader {
     if (count > 64) count = 64;
     int remaining = total_bits - pos;
     int n = count < remaining ? count : remaining;
-    uint64_t v = 0;
     int byte = pos >> 3, sh = pos & 7, filled = 0;
+    if (n <= 57 && byte + 8 <= (total_bits >> 3)) {  // common case: one unaligned 64-bit load (little endian host)
+      uint64_t w;
+      std::memcpy(&w, data + byte, 8);
+      *got = n;
+      return n == 0 ? 0 : (w >> sh) & ((~0ull) >> (64 - n));
+    }
+    uint64_t v = 0;
     while (filled < n) {
       uint64_t b = (uint64_t)(data[byte++] >> sh);
       v |= b << filled;
