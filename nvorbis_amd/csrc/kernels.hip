@@ -679,6 +679,44 @@ __device__ __forceinline__ float4 compact_value4(const float* __restrict__ plane
   return make_float4(y.x * ww.x, y.y * ww.y, y.z * ww.z, y.w * ww.w);
 }
 
+// Overlap-add of one frame, CH channels, everything in units of four samples: a lane produces four consecutive
+// sample times of every channel and writes them as CH 16-byte stores (its 4*CH interleaved floats are contiguous).
+template <int CH>
+__device__ __forceinline__ int ola_vec(const NvhDevSetup& S, const NvhFrame& fr, const float* cur, const float* prev, bool prev_full,
+                                       const float* __restrict__ w, const float* __restrict__ wp, float* out, int clip, int threads) {
+  int clipped = 0;
+  const int groups = fr.emit_count >> 2;
+  for (int g = threadIdx.x; g < groups; g += threads) {
+    const int idx0 = fr.emit_start + 4 * g;
+    const int j0 = idx0 - fr.start;
+    const bool ov = prev && j0 >= 0 && j0 < fr.ov_len;  // whole group inside or outside (all multiples of 4)
+    float flat[4 * CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      // exec_mask / ov_exec_mask mirror NvhChan::exec / ov_exec: no dependent load
+      float4 v = compact_value4(cur + (long long)c * S.block1, w, fr.n, (fr.exec_mask >> c) & 1, idx0);
+      if (ov) {
+        const float* pp = prev + (long long)c * S.block1;
+        const float4 t4 = prev_full ? *reinterpret_cast<const float4*>(pp + fr.ov_src + j0)
+                                    : compact_value4(pp, wp, fr.ov_n, (fr.ov_exec_mask >> c) & 1, fr.ov_src + j0);
+        v.x = v.x + t4.x; v.y = v.y + t4.y; v.z = v.z + t4.z; v.w = v.w + t4.w;
+      }
+      if (clip) {
+        v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
+        v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
+      }
+      flat[0 * CH + c] = v.x;
+      flat[1 * CH + c] = v.y;
+      flat[2 * CH + c] = v.z;
+      flat[3 * CH + c] = v.w;
+    }
+    float4* o4 = reinterpret_cast<float4*>(out) + (long long)g * CH;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) o4[k] = make_float4(flat[4 * k], flat[4 * k + 1], flat[4 * k + 2], flat[4 * k + 3]);
+  }
+  return clipped;
+}
+
 #ifndef NVH_OLA_THREADS
 #define NVH_OLA_THREADS 64
 #endif
@@ -712,39 +750,19 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
   const bool prev_full = fr.ov_frame == -2;
 
   // fast path: everything in units of four samples (true for every frame of a well-formed stream except an
-  // EOS-trimmed last one)
-  const bool vec = fr.n != 0 && ch <= 2 && ((fr.emit_start | fr.emit_count | fr.start | fr.ov_src | fr.ov_len) & 3) == 0 &&
+  // EOS-trimmed last one), up to 8 channels
+  const bool vec = fr.n != 0 && ch <= 8 && ((fr.emit_start | fr.emit_count | fr.start | fr.ov_src | fr.ov_len) & 3) == 0 &&
                    ((fr.out_pos * ch) & 3) == 0;
   if (vec) {
-    const int groups = fr.emit_count >> 2;
-    const int e0 = fr.exec_mask & 1, e1 = (fr.exec_mask >> 1) & 1;  // mirrors of NvhChan::exec / ov_exec: no dependent load
-    const int p0 = fr.ov_exec_mask & 1, p1 = (fr.ov_exec_mask >> 1) & 1;
-    for (int g = threadIdx.x; g < groups; g += NVH_OLA_THREADS) {
-      const int idx0 = fr.emit_start + 4 * g;
-      const int j0 = idx0 - fr.start;
-      const bool ov = prev && j0 >= 0 && j0 < fr.ov_len;  // whole group inside or outside (all multiples of 4)
-      float4 v[2];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (c >= ch) break;
-        v[c] = compact_value4(cur + (long long)c * S.block1, w, fr.n, c == 0 ? e0 : e1, idx0);
-        if (ov) {
-          const float* pp = prev + (long long)c * S.block1;
-          float4 t4 = prev_full ? *reinterpret_cast<const float4*>(pp + fr.ov_src + j0)
-                                : compact_value4(pp, wp, fr.ov_n, c == 0 ? p0 : p1, fr.ov_src + j0);
-          v[c].x = v[c].x + t4.x; v[c].y = v[c].y + t4.y; v[c].z = v[c].z + t4.z; v[c].w = v[c].w + t4.w;
-        }
-        if (clip) {
-          v[c].x = clip_value(v[c].x, &clipped); v[c].y = clip_value(v[c].y, &clipped);
-          v[c].z = clip_value(v[c].z, &clipped); v[c].w = clip_value(v[c].w, &clipped);
-        }
-      }
-      if (ch == 2) {
-        reinterpret_cast<float4*>(out)[2 * g] = make_float4(v[0].x, v[1].x, v[0].y, v[1].y);
-        reinterpret_cast<float4*>(out)[2 * g + 1] = make_float4(v[0].z, v[1].z, v[0].w, v[1].w);
-      } else {
-        reinterpret_cast<float4*>(out)[g] = v[0];
-      }
+    switch (ch) {
+      case 1: clipped = ola_vec<1>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
+      case 2: clipped = ola_vec<2>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
+      case 3: clipped = ola_vec<3>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
+      case 4: clipped = ola_vec<4>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
+      case 5: clipped = ola_vec<5>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
+      case 6: clipped = ola_vec<6>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
+      case 7: clipped = ola_vec<7>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
+      default: clipped = ola_vec<8>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
     }
     if (clipped) atomicOr(clipped_flag, 1);
     return;
