@@ -82,6 +82,13 @@ void nvh_stream_close(nvh_stream *s);
 int nvh_stream_info(const nvh_stream *s, int *channels, int *sample_rate, int *block0, int *block1);
 /* IStreamDecoder.ClipSamples (StreamDecoder.cs:723, default on) / HasClipped (:728) */
 int nvh_stream_set_clip(nvh_stream *s, int on);
+/* Parse audio packets on the GPU (kernels_parse.hip: floors, residue classification and VQ entry decode, one lane per
+ * packet) instead of on the calling thread; the host then only reads each packet's mode number and window flags.
+ * Same PCM.  Difference in error behaviour: a packet the managed decoder would have thrown on (NVH_ERR_RUNTIME) is
+ * reported by nvh_stream_synth for the whole look-ahead batch instead of by nvh_stream_push_packet for that packet.
+ * NVH_ERR_UNSUPPORTED for stream shapes outside the GPU parser's limits (Floor0, > 8 channels); call between batches.
+ * The environment variable NVH_GPU_PARSE=1 turns it on for every eligible stream. */
+int nvh_stream_set_gpu_parse(nvh_stream *s, int on);
 int nvh_stream_has_clipped(nvh_stream *s, int *clipped);
 /* IStreamDecoder.SamplePosition after everything parsed so far has been read (StreamDecoder.cs:718) */
 int nvh_stream_position(const nvh_stream *s, int64_t *position, int64_t *emitted, int *eos);

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnvorbis_hip.so")
-SOURCES = ["nvh_api.hip", "kernels.hip", "kernels_imdct.hip", "kernels_spectrum.hip", "host_setup.cpp", "host_parse.cpp", "host_ogg.cpp"]
+SOURCES = ["nvh_api.hip", "kernels.hip", "kernels_imdct.hip", "kernels_spectrum.hip", "kernels_parse.hip", "host_setup.cpp", "host_parse.cpp", "host_ogg.cpp"]
 # -ffp-contract=off: bit-exact parity with the reference needs separately rounded mul/add (no v_fma_f32);
 # fp32 denormals are preserved by default (no -fgpu-flush-denormals-to-zero).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",

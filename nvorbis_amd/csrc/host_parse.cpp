@@ -306,6 +306,30 @@ int StreamParser::parse_audio(BitReader& p, FrameBatch& out, int* decoded) {
   f.op_begin = (uint32_t)out.ops.size();
   f.ent_begin = (uint32_t)out.entries.size();
 
+  if (light_) {
+    // GPU-parse mode: the rest of the packet is decoded by kernels_parse.hip.  Keep the packet (word aligned, zero
+    // padded: the device bit reader loads whole words) and where the device should continue reading.
+    if (nch > NVH_PARSE_MAX_CH) return NVH_ERR_UNSUPPORTED;
+    out.pkt_refs.resize(out.frames.size());  // pseudo-frames carry empty references
+    NvhPacketRef ref;
+    ref.byte_off = (uint32_t)out.pkt_pool.size();
+    ref.bit_len = (uint32_t)p.total_bits;
+    ref.bit_pos = (uint32_t)p.pos;
+    ref.pad = 0;
+    const size_t nbytes = (size_t)(p.total_bits >> 3);
+    out.pkt_pool.insert(out.pkt_pool.end(), p.data, p.data + nbytes);
+    out.pkt_pool.resize((out.pkt_pool.size() + 7) & ~(size_t)3, 0);  // >= 4 bytes of zeros behind every packet
+    out.pkt_refs.push_back(ref);
+    for (int i = 0; i < nch; i++) {
+      NvhChan ch;
+      std::memset(&ch, 0, sizeof ch);
+      out.chans.push_back(ch);
+    }
+    f.pass_end = f.pass_begin;
+    out.frames.push_back(f);
+    *decoded = 1;
+    return NVH_OK;
+  }
   std::vector<uint8_t> energy((size_t)nch), force_energy((size_t)nch, 0), force_no_energy((size_t)nch, 0);
   bool any_execute = false;
   for (int i = 0; i < nch; i++) {
@@ -413,10 +437,11 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
   // transactional append: a packet that makes the reference throw leaves the batch untouched
   const size_t m_frames = out.frames.size(), m_chans = out.chans.size(), m_passes = out.passes.size(),
                m_ops = out.ops.size(), m_entries = out.entries.size(), m_posts = out.posts.size(),
-               m_coeffs = out.coeffs.size();
+               m_coeffs = out.coeffs.size(), m_pool = out.pkt_pool.size(), m_refs = out.pkt_refs.size();
   auto rollback = [&]() {
     out.frames.resize(m_frames); out.chans.resize(m_chans); out.passes.resize(m_passes); out.ops.resize(m_ops); out.op_link.resize(m_ops);
     out.entries.resize(m_entries); out.posts.resize(m_posts); out.coeffs.resize(m_coeffs);
+    out.pkt_pool.resize(m_pool); out.pkt_refs.resize(m_refs);
   };
 
   int decoded = 0;
@@ -500,7 +525,7 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
   prev_n_ = f.n;
   prev_window_off_ = f.window_off;
   prev_exec_.resize((size_t)s_->channels);
-  for (int c = 0; c < s_->channels; c++) prev_exec_[(size_t)c] = out.chans[f.chan_off + (size_t)c].exec;
+  for (int c = 0; c < s_->channels; c++) prev_exec_[(size_t)c] = out.chans[f.chan_off + (size_t)c].exec;  // light mode: fixed up on the device (k_parse_links)
   return NVH_OK;
 }
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "host_setup.h"
+#include "nvh_parse_format.h"
 #include "nvh_format.h"
 
 namespace nvh {
@@ -28,11 +29,15 @@ struct FrameBatch {
   std::vector<uint16_t> entries;
   std::vector<uint16_t> posts;
   std::vector<float> coeffs;
+  // GPU-parse mode (StreamParser::set_light): the packets themselves, word aligned and zero padded, and where each
+  // frame's packet lies (parallel to `frames`; pseudo-frames carry an empty reference)
+  std::vector<uint8_t> pkt_pool;
+  std::vector<NvhPacketRef> pkt_refs;
   int64_t pcm_samples = 0;      // per-channel samples the batch emits
   bool sequential_ola = false;  // some overlap region reaches into a tail: apply overlaps in order
   bool clipped_unknown = true;
   void clear() {
-    frames.clear(); chans.clear(); passes.clear(); ops.clear(); op_link.clear(); entries.clear(); posts.clear(); coeffs.clear();
+    frames.clear(); chans.clear(); passes.clear(); ops.clear(); op_link.clear(); entries.clear(); posts.clear(); coeffs.clear(); pkt_pool.clear(); pkt_refs.clear();
     links_ok = true;
     pcm_samples = 0;
     sequential_ola = false;
@@ -57,6 +62,10 @@ class StreamParser {
   // Call after a batch was handed to synthesis: following frames refer to the carried tail.
   void begin_batch();
 
+  // Light mode: only the packet type, mode number and window flags are read here (frame geometry, overlap and
+  // position bookkeeping); floors and residues are left to kernels_parse.hip, which receives the packet bytes.
+  void set_light(bool on) { light_ = on; }
+  bool light() const { return light_; }
   bool eos() const { return eos_found_; }
   int64_t position() const { return position_; }   // IStreamDecoder.SamplePosition after everything parsed was read
   int64_t emitted() const { return emitted_; }
@@ -68,6 +77,7 @@ class StreamParser {
   void drain(FrameBatch& out);
 
   const Setup* s_;
+  bool light_ = false;
   // StreamDecoder.cs:30-39 state, integer part
   bool has_prev_buf_ = false;   // _prevPacketBuf != null
   int prev_start_ = 0, prev_end_ = 0, prev_stop_ = 0;

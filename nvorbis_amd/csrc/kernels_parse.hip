@@ -1,0 +1,451 @@
+// kernels_parse.hip -- the bit-consuming half of the decoder on the GPU: one lane per
+// audio packet turns the packet's bits into the same frame descriptors host_parse.cpp produces (channel records,
+// raw Floor1 posts, residue passes / ops / op links / VQ entry numbers), so that the synthesis kernels can follow
+// without the packet ever being parsed on a host core.
+//
+// Reference behaviour followed (file:line under /root/reference/NVorbis/); the structure mirrors host_parse.cpp,
+// which stays the definition (tests/test_gpu_parse.py compares the two descriptor streams field by field):
+//   DataPacket.cs:150-283 (bit reader: zero-extended peeks, parked skips), Codebook.cs:294-320 (DecodeScalar),
+//   Floor1.cs:135-184 (Unpack), Mapping.cs:95-134 (bit half of DecodePacket, ForceEnergy / ForceNoEnergy),
+//   Residue0.cs:119-201, Residue1.cs:8-26, Residue2.cs:16-47 (classification + entry decode).
+// What stays on the host in this mode is the per-stream integer state machine (Mode.GetPacketInfo, overlap
+// geometry, sample positions): it needs the packet type, the mode number and the two window flags only.
+//
+// Huffman decoding is sequential inside a packet, so the parallelism is across packets (64 per wavefront, all
+// divergent).  Per-lane state is a 64-bit bit buffer refilled by aligned word loads (the host aligns and zero-pads
+// every packet), the tables come through L2.  Output goes to fixed-capacity per-frame slabs.
+#include <hip/hip_runtime.h>
+
+#include "kernels_common.h"
+#include "nvh_parse_format.h"
+
+namespace {
+
+// status codes of include/nvorbis_hip.h used here
+constexpr int kErrRuntime = -3;      // NVH_ERR_RUNTIME: the managed code would have thrown
+constexpr int kErrUnsupported = -7;  // NVH_ERR_UNSUPPORTED
+
+struct BitR {
+  const uint32_t* w;
+  uint32_t nwords, next;
+  uint32_t total, pos;
+  uint64_t buf;
+  uint32_t avail;
+  bool is_short;
+};
+
+__device__ __forceinline__ void br_fill(BitR& b) {
+  while (b.avail <= 32 && b.next < b.nwords) {
+    b.buf |= (uint64_t)b.w[b.next++] << b.avail;
+    b.avail += 32;
+  }
+}
+
+__device__ __forceinline__ void br_init(BitR& b, const uint32_t* words, uint32_t total_bits, uint32_t start) {
+  b.w = words;
+  b.total = total_bits;
+  b.nwords = (total_bits + 31u) >> 5;
+  b.pos = start < total_bits ? start : total_bits;
+  b.is_short = false;
+  b.next = b.pos >> 5;
+  b.buf = 0;
+  b.avail = 0;
+  br_fill(b);
+  const uint32_t s = b.pos & 31u;
+  if (s) {
+    b.buf >>= s;
+    b.avail = b.avail >= s ? b.avail - s : 0;
+    br_fill(b);
+  }
+}
+
+// DataPacket.TryPeekBits (:168-205): the remaining bits zero-extended, `got` = how many were really there
+__device__ __forceinline__ uint32_t br_peek(const BitR& b, int count, int* got) {
+  if (count <= 0) { *got = 0; return 0; }
+  const uint32_t remaining = b.total - b.pos;
+  const uint32_t n = (uint32_t)count < remaining ? (uint32_t)count : remaining;
+  *got = (int)n;
+  if (n == 0) return 0;
+  return (uint32_t)(b.buf & ((~0ull) >> (64 - n)));
+}
+
+// DataPacket.SkipBits (:247-280): past the end parks the cursor there and raises IsShort
+__device__ __forceinline__ void br_skip(BitR& b, int count) {
+  if (count <= 0) return;
+  if (b.total - b.pos >= (uint32_t)count) {
+    b.buf >>= count;
+    b.avail -= (uint32_t)count;
+    b.pos += (uint32_t)count;
+    br_fill(b);
+  } else {
+    b.pos = b.total;
+    b.is_short = true;
+    b.buf = 0;
+    b.avail = 0;
+    b.next = b.nwords;
+  }
+}
+
+__device__ __forceinline__ uint32_t br_read(BitR& b, int count) {
+  if (count == 0) return 0;
+  int got;
+  const uint32_t v = br_peek(b, count, &got);
+  br_skip(b, count);
+  return v;
+}
+
+// Codebook.DecodeScalar (Codebook.cs:294-320).  -1 = no symbol; -2 = the reference would fault (null list)
+__device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const NvhPBook& bk, BitR& p) {
+  int got;
+  uint32_t data = br_peek(p, bk.prefix_bits, &got);
+  if (got == 0) return -1;
+  if (!bk.has_tree) return -2;
+  const uint32_t node = T.prefix[bk.prefix_off + data];
+  if (node & 0x80u) {
+    br_skip(p, (int)(node & 0x7Fu));
+    return (int)(node >> 8);
+  }
+  data = br_peek(p, bk.max_bits, &got);
+  if (!bk.has_overflow) return -2;
+  const NvhPOverflow* ov = T.overflow + bk.ovf_off;
+  for (uint32_t k = 0; k < bk.ovf_count; ++k) {
+    if (ov[k].bits == (data & ov[k].mask)) {
+      br_skip(p, (int)ov[k].length);
+      return (int)ov[k].value;
+    }
+  }
+  return -1;
+}
+
+// Floor1.Unpack (Floor1.cs:135-184).  Writes the raw posts of one channel; returns 0 or an error code.
+__device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const NvhPFloor1& f, BitR& p, uint16_t* __restrict__ posts,
+                                             int* post_count_out) {
+  int post_count = 0;
+  int first_big = NVH_MAX_POSTS + 1;  // first post whose raw value does not fit 16 bits (documented limit)
+  if (br_read(p, 1) == 1) {
+    post_count = 2;
+    const uint32_t y0 = br_read(p, f.y_bits), y1 = br_read(p, f.y_bits);
+    posts[0] = (uint16_t)y0;
+    posts[1] = (uint16_t)y1;
+    for (int i = 0; i < f.partition_count; i++) {
+      const int cls = f.partition_class[i];
+      const int cdim = f.class_dims[cls];
+      const int cbits = f.class_sub_bits[cls];
+      const uint32_t csub = (1u << cbits) - 1u;
+      uint32_t cval = 0;
+      if (cbits > 0) {
+        const int r = decode_scalar(T, T.books[f.class_master[cls]], p);
+        if (r == -2) return kErrRuntime;
+        cval = (uint32_t)r;
+        if (cval == 0xFFFFFFFFu) {
+          post_count = 0;
+          break;
+        }
+      }
+      bool stop = false;
+      for (int j = 0; j < cdim; j++) {
+        const int book = f.sub_book[cls][cval & csub];
+        cval >>= cbits;
+        if (book >= 0) {
+          if (post_count >= NVH_MAX_POSTS) return kErrRuntime;  // Posts = new int[64]
+          const int r = decode_scalar(T, T.books[book], p);
+          if (r == -2) return kErrRuntime;
+          if (r == -1) {
+            post_count = 0;
+            stop = true;
+            break;
+          }
+          if (r > 0xFFFF && post_count < first_big) first_big = post_count;
+          posts[post_count] = (uint16_t)r;
+        } else if (post_count < NVH_MAX_POSTS) {
+          posts[post_count] = 0;  // Posts[] is zero-initialised and never written for a null book
+        }
+        ++post_count;
+      }
+      if (stop) break;
+    }
+  }
+  if (post_count > NVH_MAX_POSTS) return kErrRuntime;  // UnwrapPosts would index past finalY[64]
+  if (first_big < post_count) return kErrUnsupported;
+  *post_count_out = post_count;
+  return 0;
+}
+
+}  // namespace
+
+// One lane per frame of the batch.  Frames with n == 0 (drain pseudo-frames) have no packet.
+// Slab layout: frame f owns passes [f*cap_pass, +cap_pass), ops / op_link [f*cap_ops, +cap_ops), entries
+// [f*cap_ent, +cap_ent), posts [(f*channels + c) * NVH_MAX_POSTS, +NVH_MAX_POSTS), and two int scratch rows of cap_parts.
+extern "C" __global__ void __launch_bounds__(64)
+k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
+        NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
+        uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
+        NvhParseResult* __restrict__ result) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f >= nframes) return;
+  NvhFrame fr = frames[f];
+  const int nch = T.channels;
+  NvhChan* ch_out = chans + (long long)f * nch;
+  const uint32_t op_base = (uint32_t)f * (uint32_t)T.cap_ops, ent_base = (uint32_t)f * (uint32_t)T.cap_ent;
+  const uint32_t pass_base = (uint32_t)f * (uint32_t)T.cap_pass;
+  int err = 0;
+  uint32_t nops = 0, nent = 0, npass = 0;
+  uint32_t exec_mask = 0;
+  bool links_ok = true;
+
+  if (fr.n != 0) {
+    const NvhPacketRef ref = refs[f];
+    BitR p;
+    br_init(p, reinterpret_cast<const uint32_t*>(pkt_pool + ref.byte_off), ref.bit_len, ref.bit_pos);
+    const NvhPMapping& map = T.mappings[fr.mapping];
+
+    // ---- floors (Mapping.cs:95-111) ----
+    uint32_t energy = 0;
+    for (int c = 0; c < nch && !err; c++) {
+      const int fl = map.chan_floor[c];
+      int pc = 0;
+      uint16_t* my_posts = posts + ((long long)f * nch + c) * NVH_MAX_POSTS;
+      err = decode_floor1(T, T.floors[fl], p, my_posts, &pc);
+      NvhChan cn;
+      cn.exec = 0;
+      cn.floor = (uint8_t)fl;
+      cn.post_count = (uint8_t)pc;
+      cn.ov_exec = 0;
+      cn.data_off = (uint32_t)(((long long)f * nch + c) * NVH_MAX_POSTS);
+      cn.amp = 0.0f;
+      ch_out[c] = cn;
+      if (pc > 0) energy |= 1u << c;
+    }
+    const bool any_execute = energy != 0;  // computed before ForceEnergy (quirk B-5)
+    uint32_t force_e = 0, force_no = 0;
+    if (!err) {
+      for (int i = 0; i < map.coupling_steps; i++) {  // Mapping.cs:112-119
+        const uint32_t a = 1u << map.coupling_ang[i], m = 1u << map.coupling_mag[i];
+        if (((force_e | energy) & ~force_no) & (a | m)) force_e |= a | m;
+      }
+    }
+    // ---- residues (Mapping.cs:122-134; Residue0.Decode :119-178) ----
+    for (int sm = 0; sm < map.submaps && !err; sm++) {
+      for (int j = 0; j < nch; j++)
+        if (map.submap_floor[sm] != map.chan_floor[j] || map.submap_residue[sm] != map.chan_residue[j]) force_no |= 1u << j;
+      if (!any_execute) continue;
+      const int residue_idx = map.submap_residue[sm];
+      const NvhPResidue& r = T.residues[residue_idx];
+      const NvhPBook& class_book = T.books[r.class_book];
+      NvhResPass pass;
+      pass.residue = residue_idx;
+      for (int s = 0; s <= NVH_MAX_STAGES; s++) pass.op_begin[s] = op_base + nops;
+      int block_size = fr.n;
+      if (r.type == 2) block_size *= r.real_channels;  // Residue2.cs:16-21
+      const int end = r.end < block_size / 2 ? r.end : block_size / 2;
+      const int n = end - r.begin;
+      bool ran = false;
+      int stage = 0;
+      if (n > 0) {
+        ran = true;
+        const int partition_count = n / r.partition_size;
+        const int cdim = r.class_dims;
+        if (cdim == 0) {
+          err = kErrRuntime;
+          break;
+        }
+        const int partition_words = (partition_count + cdim - 1) / cdim;
+        int* part_word = scratch + (long long)f * 2 * T.cap_parts;  // [channel][word]
+        int* last_op = part_word + T.cap_parts;                      // [partition][channel]
+        const int pw_stride = partition_words > 0 ? partition_words : 1;
+        for (int i = 0; i < r.channels * pw_stride; i++) part_word[i] = -1;
+        for (int i = 0; i < r.channels * (partition_count > 0 ? partition_count : 1); i++) last_op[i] = -1;
+        const int buflen = T.block1;  // float[ch][block1Size] (StreamDecoder.cs:498-505)
+        bool stop = false;
+        for (; stage < r.max_stages && !stop && !err; stage++) {
+          pass.op_begin[stage] = op_base + nops;
+          for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count && !stop && !err; entry_idx++) {
+            if (stage == 0) {
+              for (int c = 0; c < r.channels; c++) {
+                const int idx = decode_scalar(T, class_book, p);
+                if (idx == -2) {
+                  err = kErrRuntime;
+                  break;
+                }
+                if (idx >= 0 && idx < r.partvals) {
+                  part_word[c * pw_stride + entry_idx] = idx;
+                } else {
+                  stop = true;
+                  break;
+                }
+              }
+              if (stop || err) break;
+            }
+            for (int dimension_idx = 0; partition_idx < partition_count && dimension_idx < cdim && !stop && !err;
+                 dimension_idx++, partition_idx++) {
+              const int offset = r.begin + partition_idx * r.partition_size;
+              for (int c = 0; c < r.channels; c++) {
+                const int word = part_word[c * pw_stride + entry_idx];
+                if (word < 0) {
+                  err = kErrRuntime;  // NullReferenceException on partWordCache
+                  break;
+                }
+                const int cls = T.ipool[r.decode_map_off + (uint32_t)(word * cdim + dimension_idx)];
+                if ((r.cascade[cls] & (1 << stage)) == 0) continue;
+                const int book_idx = r.books[cls][stage];
+                if (book_idx < 0) continue;
+                const NvhPBook& book = T.books[book_idx];
+                const int dims = book.dims;
+                if (dims == 0) {
+                  err = kErrRuntime;
+                  break;
+                }
+                if (partition_idx > 0xFFFF) {
+                  err = kErrUnsupported;
+                  break;
+                }
+                NvhResOp op;
+                op.ent_off = ent_base + nent;
+                op.partition = (uint16_t)partition_idx;
+                op.channel = (uint8_t)c;
+                op.book = (uint8_t)book_idx;
+                bool push = false, bad = false;
+                if (r.type == 0) {
+                  // Residue0.WriteVectors (:180-201): decode all entries first, add only if all decoded
+                  const int steps = r.partition_size / dims;
+                  const uint32_t mark = nent;
+                  if (nent + (uint32_t)steps > (uint32_t)T.cap_ent) {
+                    err = kErrRuntime;
+                    break;
+                  }
+                  for (int i = 0; i < steps; i++) {
+                    const int e = decode_scalar(T, book, p);
+                    if (e == -2) {
+                      err = kErrRuntime;
+                      break;
+                    }
+                    if (e == -1) {
+                      bad = true;
+                      break;
+                    }
+                    entries[ent_base + nent++] = (uint16_t)e;
+                  }
+                  if (err) break;
+                  if (bad) {
+                    nent = mark;
+                    stop = true;
+                    break;
+                  }
+                  if (offset + steps * dims > buflen) {
+                    err = kErrRuntime;
+                    break;
+                  }
+                  push = true;
+                } else {
+                  // Residue1.WriteVectors (Residue1.cs:8-26) / Residue2.WriteVectors (Residue2.cs:23-47):
+                  // vectors are added as they are decoded; a failed decode keeps what was added so far
+                  const int slots = (r.partition_size + dims - 1) / dims;
+                  if (nent + (uint32_t)slots > (uint32_t)T.cap_ent) {
+                    err = kErrRuntime;
+                    break;
+                  }
+                  int done = 0;
+                  for (int i = 0; i < r.partition_size; i += dims) {
+                    const int e = decode_scalar(T, book, p);
+                    if (e == -2) {
+                      err = kErrRuntime;
+                      break;
+                    }
+                    if (e == -1) {
+                      bad = true;
+                      break;
+                    }
+                    entries[ent_base + nent++] = (uint16_t)e;
+                    ++done;
+                  }
+                  if (err) break;
+                  if (done > 0) {  // bounds of the adds the reference performed
+                    const int last = done * dims - 1;
+                    if (r.type == 1) {
+                      if (offset + last >= buflen) err = kErrRuntime;
+                    } else {
+                      if (offset / r.real_channels + last / r.real_channels >= buflen) err = kErrRuntime;
+                    }
+                    if (err) break;
+                  }
+                  for (int i = done; i < slots; i++) entries[ent_base + nent++] = (uint16_t)NVH_ENTRY_SKIP;
+                  push = true;
+                }
+                if (push) {
+                  if (nops >= (uint32_t)T.cap_ops) {
+                    err = kErrRuntime;
+                    break;
+                  }
+                  const uint32_t rel = nops;
+                  ops[op_base + rel] = op;
+                  uint16_t lk = (uint16_t)NVH_LINK_NONE;
+                  if (rel >= (uint32_t)NVH_LINK_NONE) links_ok = false;
+                  int* last = &last_op[partition_idx * r.channels + c];
+                  if (*last >= 0 && rel < (uint32_t)NVH_LINK_NONE) {
+                    op_link[op_base + (uint32_t)*last] = (uint16_t)((op_link[op_base + (uint32_t)*last] & 0x8000u) | (uint16_t)rel);
+                    lk |= 0x8000u;
+                  }
+                  op_link[op_base + rel] = lk;
+                  *last = (int)rel;
+                  ++nops;
+                }
+                if (bad) {
+                  stop = true;
+                  break;
+                }
+              }
+            }
+          }
+        }
+      }
+      // stages not reached keep empty ranges
+      if (!err) {
+        for (int s = ran ? stage : 0; s <= NVH_MAX_STAGES; s++) pass.op_begin[s] = op_base + nops;
+        if (npass >= (uint32_t)T.cap_pass) {
+          err = kErrRuntime;
+        } else {
+          passes[pass_base + npass++] = pass;
+        }
+      }
+    }
+    if (!err) {
+      exec_mask = (force_e | energy) & ~force_no;
+      for (int c = 0; c < nch; c++) ch_out[c].exec = (exec_mask >> c) & 1u;
+    }
+  }
+
+  frames[f].pass_begin = pass_base;
+  frames[f].pass_end = pass_base + npass;
+  frames[f].op_begin = op_base;
+  frames[f].op_count = nops;
+  frames[f].ent_begin = ent_base;
+  frames[f].ent_count = nent;
+  frames[f].exec_mask = exec_mask;
+  atomicMax(&result->max_ops, (int)nops);
+  atomicMax(&result->max_ent, (int)nent);
+  atomicMax(&result->max_pass, (int)npass);
+  if (!links_ok) atomicAnd(&result->links_ok, 0);
+  if (err) {
+    const int prev = atomicMin(&result->err_frame, f);
+    if (f < prev) result->err_code = err;  // benign race between several failing frames: the host re-checks the minimum
+  }
+}
+
+// Second pass: what a frame needs from its overlap source (known only after every lane has parsed its packet):
+// the source frame's execute flags (NvhChan::ov_exec / NvhFrame::ov_exec_mask).  carry_exec_in: flags of the block
+// carried in from the previous batch; the last decoded frame's flags go out for the next one.
+extern "C" __global__ void __launch_bounds__(64)
+k_parse_links(int nframes, int channels, NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans,
+              const uint32_t* __restrict__ carry_exec_in, uint32_t* __restrict__ carry_exec_out, int last_decoded) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f >= nframes) return;
+  const NvhFrame fr = frames[f];
+  uint32_t m = 0;
+  if (fr.ov_frame == -2) m = carry_exec_in[0];
+  else if (fr.ov_frame >= 0) m = frames[fr.ov_frame].exec_mask;
+  if (fr.ov_frame == -2 || fr.ov_frame >= 0) {
+    frames[f].ov_exec_mask = m;
+    for (int c = 0; c < channels; c++) chans[(long long)f * channels + c].ov_exec = (m >> c) & 1u;
+  }
+  if (f == last_decoded) carry_exec_out[0] = fr.exec_mask;  // ping-pong with the carried block itself (nvh_api.hip)
+}

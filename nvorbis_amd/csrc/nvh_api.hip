@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -18,6 +19,7 @@
 #include "host_parse.h"
 #include "host_setup.h"
 #include "kernels_common.h"
+#include "nvh_parse_format.h"
 
 
 extern "C" {
@@ -39,6 +41,11 @@ __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, co
                             int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
                                     const float* TW);
+__global__ void k_parse(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
+                        NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
+                        NvhParseResult* result);
+__global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
+                              uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
 __global__ void k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
@@ -147,6 +154,10 @@ struct SharedSetup {
   NvhDevSetup dev{};
   bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
   bool has_floor0 = false;
+  // GPU packet parser (kernels_parse.hip): its tables, and whether this stream shape is inside its limits
+  DevBuf parse_arena;
+  NvhDevParse parse{};
+  bool gpu_parse_ok = false;
 };
 
 struct nvh_ctx {
@@ -163,6 +174,7 @@ struct nvh_batch {
   nvh_stream* s = nullptr;
   DevBuf blob;          // all descriptor arrays, one allocation
   DevBuf h_blob;        // pinned staging image of it (the upload is asynchronous)
+  DevBuf slabs;         // GPU-parse mode: per-frame output slabs of k_parse + its scratch + result block
   DevBuf work;          // [frames][ch][block1] float planes
   DevBuf carry_in;      // snapshot of the tail this batch overlaps its first frame with
   NvhDevBatch dev{};
@@ -196,14 +208,16 @@ struct nvh_stream {
   DevBuf h_pcm;  // pinned bounce buffer behind it (+ 2 ints: the flag words), read back asynchronously
   int clip = 1;
   int has_clipped = 0;
+  bool gpu_parse = false;  // packets are parsed by k_parse; the host parser runs in light mode
+  DevBuf carry_exec;       // uint32[2], ping-pong with carry[]: execute flags of the carried block (GPU-parse mode)
   nvh_batch scratch;  // reused by nvh_stream_synth
 
   nvh_stream(nvh_ctx* c, std::shared_ptr<SharedSetup> sh)
       : ctx(c), shared(std::move(sh)), setup(shared->setup), arena(shared->arena), dev(shared->dev),
         fast_spectrum(shared->fast_spectrum), has_floor0(shared->has_floor0) {
     BufPool* pool = c ? &c->pool : nullptr;
-    carry[0].pool = carry[1].pool = flags.pool = pcm.pool = pool;
-    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = pool;
+    carry[0].pool = carry[1].pool = flags.pool = pcm.pool = carry_exec.pool = pool;
+    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = pool;
     h_pcm.host = scratch.h_blob.host = true;
     h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;
     scratch.s = this;
@@ -386,6 +400,8 @@ struct ArenaBuilder {
 };
 
 }  // namespace
+
+static int upload_parse_tables(nvh_stream* s);
 
 static int upload_setup(nvh_stream* s) {
   const nvh::Setup& S = s->setup;
@@ -666,6 +682,8 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
   if (!cached) {
     rc = upload_setup(s.get());
     if (rc != NVH_OK) return rc;
+    rc = upload_parse_tables(s.get());
+    if (rc != NVH_OK) return rc;
     if (c->setup_cache.size() >= 64) {  // bounded: drop entries no open stream uses
       for (auto it = c->setup_cache.begin(); it != c->setup_cache.end();)
         it = it->second.use_count() == 1 ? c->setup_cache.erase(it) : std::next(it);
@@ -679,6 +697,12 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
   }
   if ((rc = s->flags.reserve(2 * sizeof(int))) != NVH_OK) return rc;
   HIP_TRY(hipMemsetAsync(s->flags.p, 0, 2 * sizeof(int), c->stream));
+  if ((rc = s->carry_exec.reserve(2 * sizeof(uint32_t))) != NVH_OK) return rc;
+  HIP_TRY(hipMemsetAsync(s->carry_exec.p, 0, 2 * sizeof(uint32_t), c->stream));
+  if (getenv("NVH_GPU_PARSE") && s->shared->gpu_parse_ok) {  // opt-in default for whole test runs
+    s->gpu_parse = true;
+    s->parser->set_light(true);
+  }
   *out = s.release();
   return NVH_OK;
 }
@@ -698,6 +722,16 @@ extern "C" int nvh_stream_info(const nvh_stream* s, int* channels, int* sample_r
   if (sample_rate) *sample_rate = s->setup.sample_rate;
   if (block0) *block0 = s->setup.block0;
   if (block1) *block1 = s->setup.block1;
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_set_gpu_parse(nvh_stream* s, int on) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  if (!s->ctx) return NVH_ERR_NO_GPU;
+  if (!s->pending.frames.empty()) return NVH_ERR_ARGUMENT;  // switch between batches only
+  if (on && !s->shared->gpu_parse_ok) return NVH_ERR_UNSUPPORTED;
+  s->gpu_parse = on != 0;
+  s->parser->set_light(s->gpu_parse);
   return NVH_OK;
 }
 
@@ -778,6 +812,268 @@ extern "C" int nvh_stream_pending(const nvh_stream* s, int* frames, int64_t* pcm
 // ------------------------------------------------------------------------------------------------
 
 // Moves s->pending into `b` (device resident) and advances the stream's batch boundary.
+// Device tables of the GPU packet parser (kernels_parse.hip) and the worst-case slab capacities of this setup.
+// Streams outside its limits (Floor0, > 8 channels, ...) simply keep the host parser.
+static int upload_parse_tables(nvh_stream* s) {
+  const nvh::Setup& S = s->setup;
+  SharedSetup& sh = *s->shared;
+  sh.gpu_parse_ok = false;
+  if (S.channels > NVH_PARSE_MAX_CH || S.books.size() > 256) return NVH_OK;
+  for (const nvh::Floor& f : S.floors)
+    if (f.type != 1) return NVH_OK;
+  for (const nvh::Mapping& m : S.mappings)
+    if (m.submap_floor.size() > NVH_PARSE_MAX_SUBMAPS || m.coupling_angle.size() > NVH_PARSE_MAX_COUPLING) return NVH_OK;
+
+  std::vector<NvhPBook> books(S.books.size());
+  std::vector<uint32_t> prefix;
+  std::vector<NvhPOverflow> overflow;
+  for (size_t i = 0; i < S.books.size(); i++) {
+    const nvh::Codebook& b = S.books[i];
+    NvhPBook& d = books[i];
+    std::memset(&d, 0, sizeof d);
+    if (b.entries > 0xFFFFFF || b.prefix_bits > 16 || b.max_bits > 32 || b.dimensions > 0xFFFF) return NVH_OK;
+    d.prefix_off = (uint32_t)prefix.size();
+    d.ovf_off = (uint32_t)overflow.size();
+    d.entries = (uint32_t)b.entries;
+    d.dims = (uint16_t)b.dimensions;
+    d.prefix_bits = (uint8_t)b.prefix_bits;
+    d.max_bits = (uint8_t)b.max_bits;
+    d.has_tree = b.has_tree ? 1 : 0;
+    d.has_overflow = b.has_overflow ? 1 : 0;
+    for (const nvh::HuffNode& n : b.prefix) {
+      if (n.present && (n.length < 0 || n.length > 0x7F || n.value < 0 || n.value > 0xFFFFFF)) return NVH_OK;
+      prefix.push_back(n.present ? (((uint32_t)n.value << 8) | 0x80u | (uint32_t)n.length) : 0u);
+    }
+    if (b.prefix.empty()) prefix.push_back(0u);  // has_tree == false: never indexed, keeps offsets valid
+    for (const nvh::HuffNode& n : b.overflow) {
+      NvhPOverflow o;
+      o.bits = (uint32_t)n.bits;
+      o.mask = (uint32_t)n.mask;
+      o.value = (uint32_t)n.value;
+      o.length = (uint32_t)n.length;
+      overflow.push_back(o);
+    }
+    d.ovf_count = (uint32_t)b.overflow.size();
+  }
+  std::vector<NvhPFloor1> floors(S.floors.size());
+  for (size_t i = 0; i < S.floors.size(); i++) {
+    const nvh::Floor1& f = S.floors[i].f1;
+    NvhPFloor1& d = floors[i];
+    std::memset(&d, 0, sizeof d);
+    d.type = 1;
+    d.partition_count = f.partition_count;
+    d.y_bits = f.y_bits;
+    for (int k = 0; k < 32; k++) d.partition_class[k] = (uint8_t)f.partition_class[k];
+    for (int k = 0; k < 16; k++) {
+      d.class_dims[k] = (uint8_t)f.class_dimensions[k];
+      d.class_sub_bits[k] = (uint8_t)f.class_subclasses[k];
+      d.class_master[k] = (int16_t)f.class_masterbook[k];
+      for (int j = 0; j < 8; j++) d.sub_book[k][j] = (int16_t)f.subclass_book[k][j];
+    }
+  }
+  std::vector<int32_t> ipool;
+  std::vector<NvhPResidue> residues(S.residues.size());
+  std::vector<int> r_parts(S.residues.size()), r_ops(S.residues.size()), r_ent(S.residues.size());
+  int cap_parts = 1;
+  for (size_t i = 0; i < S.residues.size(); i++) {
+    const nvh::Residue& r = S.residues[i];
+    NvhPResidue& d = residues[i];
+    std::memset(&d, 0, sizeof d);
+    d.type = r.type; d.begin = r.begin; d.end = r.end; d.partition_size = r.partition_size;
+    d.classifications = r.classifications; d.class_book = r.class_book; d.channels = r.channels;
+    d.real_channels = r.real_channels; d.max_stages = r.max_stages; d.partvals = r.partvals;
+    d.class_dims = S.books[(size_t)r.class_book].dimensions;
+    d.decode_map_off = (uint32_t)ipool.size();
+    ipool.insert(ipool.end(), r.decode_map.begin(), r.decode_map.end());
+    int min_dims = 1 << 30;
+    for (int c = 0; c < NVH_MAX_CLASSES; c++) {
+      d.cascade[c] = (uint8_t)r.cascade[c];
+      for (int k = 0; k < NVH_MAX_STAGES; k++) {
+        d.books[c][k] = (int16_t)r.books[c][k];
+        if (c < r.classifications && r.books[c][k] >= 0) {
+          const int dm = S.books[(size_t)r.books[c][k]].dimensions;
+          if (dm > 0 && dm < min_dims) min_dims = dm;
+        }
+      }
+    }
+    if (min_dims == (1 << 30)) min_dims = 1;
+    // worst case over this setup's largest block: every partition of every channel has a book in every stage
+    const int bs = r.type == 2 ? S.block1 * r.real_channels : S.block1;
+    const int end = r.end < bs / 2 ? r.end : bs / 2;
+    const int n = end - r.begin;
+    const int parts = (n > 0 && r.partition_size > 0) ? n / r.partition_size : 0;
+    const int cdim = d.class_dims > 0 ? d.class_dims : 1;
+    const int words = (parts + cdim - 1) / cdim;
+    r_parts[i] = parts;
+    r_ops[i] = r.max_stages * parts * r.channels;
+    r_ent[i] = r_ops[i] * ((r.partition_size + min_dims - 1) / min_dims);
+    const int need = r.channels * std::max(std::max(parts, words), 1);
+    if (need > cap_parts) cap_parts = need;
+  }
+  if (ipool.empty()) ipool.push_back(0);
+  std::vector<NvhPMapping> mappings(S.mappings.size());
+  int cap_ops = 1, cap_ent = 8, cap_pass = 1;
+  for (size_t i = 0; i < S.mappings.size(); i++) {
+    const nvh::Mapping& m = S.mappings[i];
+    NvhPMapping& d = mappings[i];
+    std::memset(&d, 0, sizeof d);
+    d.submaps = (int32_t)m.submap_floor.size();
+    d.coupling_steps = (int32_t)m.coupling_angle.size();
+    int ops = 0, ent = 0;
+    for (size_t k = 0; k < m.submap_floor.size(); k++) {
+      d.submap_floor[k] = (uint8_t)m.submap_floor[k];
+      d.submap_residue[k] = (uint8_t)m.submap_residue[k];
+      ops += r_ops[(size_t)m.submap_residue[k]];
+      ent += r_ent[(size_t)m.submap_residue[k]];
+    }
+    for (int c = 0; c < S.channels; c++) {
+      d.chan_floor[c] = (uint8_t)m.channel_floor[(size_t)c];
+      d.chan_residue[c] = (uint8_t)m.channel_residue[(size_t)c];
+    }
+    for (size_t k = 0; k < m.coupling_angle.size(); k++) {
+      d.coupling_ang[k] = (uint8_t)m.coupling_angle[k];
+      d.coupling_mag[k] = (uint8_t)m.coupling_magnitude[k];
+    }
+    if (ops > cap_ops) cap_ops = ops;
+    if (ent > cap_ent) cap_ent = ent;
+    if (d.submaps > cap_pass) cap_pass = d.submaps;
+  }
+  cap_ops = (cap_ops + 7) & ~7;
+  cap_ent = (cap_ent + 15) & ~7;
+  // keep a frame's slabs within reason (and op indices within the 15-bit links where possible)
+  if ((size_t)cap_ops * 10 + (size_t)cap_ent * 2 + (size_t)cap_parts * 8 > ((size_t)1 << 20)) return NVH_OK;
+
+  ArenaBuilder ab;
+  size_t o_bk = ab.add(books.data(), books.size() * sizeof(NvhPBook));
+  size_t o_px = ab.add(prefix.data(), prefix.size() * sizeof(uint32_t));
+  NvhPOverflow none{};
+  size_t o_ov = ab.add(overflow.empty() ? &none : overflow.data(), (overflow.empty() ? 1 : overflow.size()) * sizeof(NvhPOverflow));
+  size_t o_fl = ab.add(floors.data(), floors.size() * sizeof(NvhPFloor1));
+  size_t o_rs = ab.add(residues.data(), residues.size() * sizeof(NvhPResidue));
+  size_t o_mp = ab.add(mappings.data(), mappings.size() * sizeof(NvhPMapping));
+  size_t o_ip = ab.add(ipool.data(), ipool.size() * sizeof(int32_t));
+  sh.parse_arena.pool = &s->ctx->pool;
+  int rc = sh.parse_arena.reserve(ab.bytes.size());
+  if (rc != NVH_OK) return rc;
+  HIP_TRY(hipMemcpy(sh.parse_arena.p, ab.bytes.data(), ab.bytes.size(), hipMemcpyHostToDevice));
+  const uint8_t* base = (const uint8_t*)sh.parse_arena.p;
+  NvhDevParse& P = sh.parse;
+  P.channels = S.channels;
+  P.block1 = S.block1;
+  P.cap_pass = cap_pass;
+  P.cap_ops = cap_ops;
+  P.cap_ent = cap_ent;
+  P.cap_parts = cap_parts;
+  P.books = (const NvhPBook*)(base + o_bk);
+  P.prefix = (const uint32_t*)(base + o_px);
+  P.overflow = (const NvhPOverflow*)(base + o_ov);
+  P.floors = (const NvhPFloor1*)(base + o_fl);
+  P.residues = (const NvhPResidue*)(base + o_rs);
+  P.mappings = (const NvhPMapping*)(base + o_mp);
+  P.ipool = (const int32_t*)(base + o_ip);
+  sh.gpu_parse_ok = true;
+  return NVH_OK;
+}
+
+static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResult* d_res);
+
+// GPU-parse mode: upload frame geometry + packets, let k_parse produce the descriptors into per-frame slabs.
+static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
+  nvh::FrameBatch& P = s->pending;
+  const NvhDevParse& T = s->shared->parse;
+  const int ch = s->setup.channels;
+  const size_t nf = P.frames.size();
+  P.pkt_refs.resize(nf);  // trailing pseudo-frames
+  if (P.pkt_pool.empty()) P.pkt_pool.resize(8, 0);
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  // host-written prefix of the blob ...
+  const size_t o_fr = 0;
+  const size_t o_ch = al(o_fr + std::max<size_t>(nf, 1) * sizeof(NvhFrame));
+  const size_t o_rf = al(o_ch + std::max<size_t>(nf * ch, 1) * sizeof(NvhChan));
+  const size_t o_pk = al(o_rf + std::max<size_t>(nf, 1) * sizeof(NvhPacketRef));
+  const size_t host_bytes = al(o_pk + P.pkt_pool.size() + 8);
+  // ... and the device-only slabs behind it
+  const size_t o_ps = host_bytes;
+  const size_t o_op = al(o_ps + nf * (size_t)T.cap_pass * sizeof(NvhResPass));
+  const size_t o_lk = al(o_op + nf * (size_t)T.cap_ops * sizeof(NvhResOp));
+  const size_t o_en = al(o_lk + nf * (size_t)T.cap_ops * sizeof(uint16_t));
+  const size_t o_po = al(o_en + nf * (size_t)T.cap_ent * sizeof(uint16_t) + 64);
+  const size_t o_sc = al(o_po + nf * (size_t)ch * NVH_MAX_POSTS * sizeof(uint16_t));
+  const size_t o_rs = al(o_sc + nf * 2 * (size_t)T.cap_parts * sizeof(int));
+  const size_t total = al(o_rs + sizeof(NvhParseResult));
+  int rc = b->blob.reserve(total);
+  if (rc != NVH_OK) return rc;
+  if ((rc = b->h_blob.reserve(host_bytes)) != NVH_OK) return rc;
+  uint8_t* h = (uint8_t*)b->h_blob.p;
+  if (nf) std::memcpy(h + o_fr, P.frames.data(), nf * sizeof(NvhFrame));
+  if (nf) std::memcpy(h + o_ch, P.chans.data(), std::min(P.chans.size(), nf * (size_t)ch) * sizeof(NvhChan));
+  if (nf) std::memcpy(h + o_rf, P.pkt_refs.data(), nf * sizeof(NvhPacketRef));
+  std::memcpy(h + o_pk, P.pkt_pool.data(), P.pkt_pool.size());
+  std::memset(h + o_pk + P.pkt_pool.size(), 0, 8);
+  b->descriptor_bytes = (int64_t)(nf * (sizeof(NvhFrame) + sizeof(NvhPacketRef)) + P.pkt_pool.size());
+  hipStream_t st = s->ctx->stream;
+  uint8_t* base = (uint8_t*)b->blob.p;
+  HIP_TRY(hipMemcpyAsync(base, h, host_bytes, hipMemcpyHostToDevice, st));
+  NvhParseResult init{};
+  init.err_frame = 0x7FFFFFFF;
+  init.links_ok = 1;
+  // (a 32-byte pageable source: staged by the runtime before the call returns)
+  HIP_TRY(hipMemcpyAsync(base + o_rs, &init, sizeof init, hipMemcpyHostToDevice, st));
+  b->dev.frames = (const NvhFrame*)(base + o_fr);
+  b->dev.chans = (const NvhChan*)(base + o_ch);
+  b->dev.passes = (const NvhResPass*)(base + o_ps);
+  b->dev.ops = (const NvhResOp*)(base + o_op);
+  b->dev.op_link = (const uint16_t*)(base + o_lk);
+  b->dev.entries = (const uint16_t*)(base + o_en);
+  b->dev.posts = (const uint16_t*)(base + o_po);
+  b->dev.coeffs = (const float*)(base + o_po);  // no Floor0 in this mode
+  b->dev.nframes = b->nframes;
+  b->dev.pad = 0;
+  if (nf) {
+    const unsigned blocks = (unsigned)((nf + 63) / 64);
+    hipLaunchKernelGGL(k_parse, dim3(blocks), dim3(64), 0, st, T, (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
+                       (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
+                       (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
+                       (NvhParseResult*)(base + o_rs));
+    // the carried block's execute flags ping-pong together with the carried block (nvh_stream_synth flips carry_cur)
+    uint32_t* ce = (uint32_t*)s->carry_exec.p;
+    hipLaunchKernelGGL(k_parse_links, dim3(blocks), dim3(64), 0, st, (int)nf, ch, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch),
+                       (const uint32_t*)(ce + s->carry_cur), ce + (s->carry_cur ^ 1), b->last_decoded);
+    HIP_TRY(hipGetLastError());
+  }
+  rc = collect_parse_result(s, b, (const NvhParseResult*)(base + o_rs));
+  if (rc != NVH_OK) return rc;
+  size_t plane = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
+  rc = b->work.reserve(std::max<size_t>((size_t)b->nframes, 1) * plane);
+  if (rc != NVH_OK) return rc;
+  P.clear();
+  s->parser->begin_batch();
+  return NVH_OK;
+}
+
+// Reads k_parse's batch-level result back (one small copy + synchronisation): sizes the LDS staging of the
+// spectrum kernel and reports the first packet the reference would have thrown on.
+static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResult* d_res) {
+  hipStream_t st = s->ctx->stream;
+  int rc = s->h_pcm.reserve(sizeof(NvhParseResult));
+  if (rc != NVH_OK) return rc;
+  NvhParseResult* r = (NvhParseResult*)s->h_pcm.p;
+  HIP_TRY(hipMemcpyAsync(r, d_res, sizeof *r, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  b->max_ops = r->max_ops;
+  b->max_ent = r->max_ent;
+  b->max_pass = r->max_pass;
+  b->links_ok = r->links_ok != 0;
+  if (r->err_frame != 0x7FFFFFFF) {
+    // some packet of the batch would have made the managed decoder throw (host parser: the same code from
+    // nvh_stream_push_packet); the whole look-ahead batch is dropped
+    s->pending.clear();
+    s->parser->begin_batch();
+    return r->err_code < 0 ? r->err_code : NVH_ERR_RUNTIME;
+  }
+  return NVH_OK;
+}
+
 static int batch_upload(nvh_stream* s, nvh_batch* b) {
   nvh::FrameBatch& P = s->pending;
   b->s = s;
@@ -821,6 +1117,7 @@ static int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->stats[0] = (int64_t)P.frames.size(); b->stats[1] = (int64_t)P.chans.size(); b->stats[2] = (int64_t)P.passes.size();
   b->stats[3] = (int64_t)P.ops.size(); b->stats[4] = (int64_t)P.entries.size(); b->stats[5] = (int64_t)P.posts.size();
   b->stats[6] = (int64_t)P.coeffs.size();
+  if (s->gpu_parse) return batch_upload_gpu(s, b);
   // the descriptor arrays are laid out back to back (16-byte aligned) in one pinned staging block and go to the
   // device with one asynchronous copy; the caller decides when the stream is synchronised
   auto pad1 = [](size_t n) { return n ? n : (size_t)1; };
@@ -1055,7 +1352,7 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
   HIP_TRY(hipSetDevice(s->ctx->device));
   std::unique_ptr<nvh_batch> b(new (std::nothrow) nvh_batch());
   if (b && s && s->ctx) {
-    b->blob.pool = b->work.pool = b->carry_in.pool = &s->ctx->pool;
+    b->blob.pool = b->work.pool = b->carry_in.pool = b->slabs.pool = &s->ctx->pool;
     b->h_blob.host = true;
     b->h_blob.pool = &s->ctx->hpool;
   }

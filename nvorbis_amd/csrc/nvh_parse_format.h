@@ -1,0 +1,94 @@
+// nvh_parse_format.h -- device-side tables for the GPU packet parser (kernels_parse.hip): the bit-consuming half
+// of the decoder.  Plain-old-data mirrors of the host structures in host_setup.h,
+// built once per setup by nvh_api.hip:upload_parse_tables.
+//
+// Reference behaviour these tables serve (file:line under /root/reference/NVorbis/):
+//   Huffman.cs:15-76 (prefix table + overflow list), Codebook.cs:294-320 (DecodeScalar),
+//   Floor1.cs:135-184 (Unpack), Residue0.cs:119-201 (Decode), Mapping.cs:95-134 (DecodePacket, bit half).
+#pragma once
+#include <stdint.h>
+
+#include "nvh_format.h"
+
+#define NVH_PARSE_MAX_CH 8        // channels the GPU parser handles (per-channel state lives in register bit masks)
+#define NVH_PARSE_MAX_SUBMAPS 16  // Mapping.cs:45
+#define NVH_PARSE_MAX_COUPLING 16
+
+// Huffman decode tables of one codebook.
+//   prefix[i] (1 << prefix_bits entries): (value << 8) | 0x80 | length for a code of at most prefix_bits bits, else 0
+//   overflow[k]: the longer codes in (length, bits) order
+struct NvhPBook {
+  uint32_t prefix_off;    // into the uint32 prefix pool
+  uint32_t ovf_off;       // into the NvhPOverflow pool
+  uint32_t ovf_count;
+  uint32_t entries;
+  uint16_t dims;
+  uint8_t prefix_bits, max_bits;
+  uint8_t has_tree, has_overflow;  // Codebook.cs:294-320: `_prefixList != null`, `_overflowList != null`
+  uint8_t pad[2];
+};
+
+struct NvhPOverflow {
+  uint32_t bits, mask;
+  uint32_t value;
+  uint32_t length;
+};
+
+struct NvhPFloor1 {  // Floor1.cs:21-25 as Unpack uses it
+  int32_t type;      // 1; anything else makes the stream ineligible for the GPU parser
+  int32_t partition_count;
+  int32_t y_bits;
+  int32_t pad;
+  uint8_t partition_class[32];
+  uint8_t class_dims[16];
+  uint8_t class_sub_bits[16];
+  int16_t class_master[16];
+  int16_t sub_book[16][8];
+};
+
+struct NvhPResidue {  // Residue0.cs:21-33
+  int32_t type, begin, end, partition_size;
+  int32_t classifications, class_book, channels, real_channels;
+  int32_t max_stages, partvals, class_dims, pad;
+  uint32_t decode_map_off;  // into the int pool: partvals * class_dims class numbers
+  uint32_t pad2[3];
+  uint8_t cascade[NVH_MAX_CLASSES];
+  int16_t books[NVH_MAX_CLASSES][NVH_MAX_STAGES];
+};
+
+struct NvhPMapping {  // Mapping.cs:16-78
+  int32_t submaps, coupling_steps;
+  uint8_t submap_floor[NVH_PARSE_MAX_SUBMAPS], submap_residue[NVH_PARSE_MAX_SUBMAPS];
+  uint8_t chan_floor[NVH_PARSE_MAX_CH], chan_residue[NVH_PARSE_MAX_CH];
+  uint8_t coupling_mag[NVH_PARSE_MAX_COUPLING], coupling_ang[NVH_PARSE_MAX_COUPLING];
+};
+
+struct NvhDevParse {
+  int32_t channels, block1;
+  int32_t cap_pass, cap_ops, cap_ent;  // per-frame slab capacities (worst case of the setup)
+  int32_t cap_parts;                   // per-frame scratch: partitions * channels of the largest residue
+  const NvhPBook* books;
+  const uint32_t* prefix;
+  const NvhPOverflow* overflow;
+  const NvhPFloor1* floors;
+  const NvhPResidue* residues;
+  const NvhPMapping* mappings;
+  const int32_t* ipool;
+};
+
+// One packet's location for k_parse (its frame record carries the geometry).
+struct NvhPacketRef {
+  uint32_t byte_off;   // 4-byte aligned offset into the packet pool; the packet is zero-padded to a word boundary
+  uint32_t bit_len;    // packet length in bits
+  uint32_t bit_pos;    // bits the host already consumed (packet type, mode number, window flags)
+  uint32_t pad;
+};
+
+// Batch-level results of k_parse, read back before the synthesis kernels are sized.
+struct NvhParseResult {
+  int32_t max_ops, max_ent, max_pass;
+  int32_t err_frame;   // first frame (lowest index) whose packet would have made the reference throw, or 0x7FFFFFFF
+  int32_t err_code;    // its NVH_ERR_* code
+  int32_t links_ok;
+  int32_t pad[2];
+};

@@ -50,6 +50,7 @@ SIGNATURES = {
     "nvh_stream_close": (None, [_vp]),
     "nvh_stream_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "nvh_stream_set_clip": (C.c_int, [_vp, C.c_int]),
+    "nvh_stream_set_gpu_parse": (C.c_int, [_vp, C.c_int]),
     "nvh_stream_has_clipped": (C.c_int, [_vp, _ip]),
     "nvh_stream_position": (C.c_int, [_vp, _i64p, _i64p, _ip]),
     "nvh_stream_push_packet": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int]),

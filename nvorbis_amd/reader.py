@@ -182,6 +182,10 @@ class Stream:
         check(lib().nvh_stream_position(self._h, C.byref(pos), C.byref(em), C.byref(eos)), "nvh_stream_position")
         return pos.value, em.value, bool(eos.value)
 
+    def set_gpu_parse(self, on):
+        """Parse packets on the GPU (kernels_parse.hip); raises NvhError(UNSUPPORTED) for ineligible stream shapes."""
+        check(lib().nvh_stream_set_gpu_parse(self._h, 1 if on else 0), "nvh_stream_set_gpu_parse")
+
     def set_clip(self, on):
         check(lib().nvh_stream_set_clip(self._h, 1 if on else 0), "nvh_stream_set_clip")
 
