@@ -81,6 +81,10 @@ int nvh_stream_open(nvh_ctx *ctx, const uint8_t *id_pkt, int id_len, const uint8
 void nvh_stream_close(nvh_stream *s);
 int nvh_stream_info(const nvh_stream *s, int *channels, int *sample_rate, int *block0, int *block1);
 /* IStreamDecoder.ClipSamples (StreamDecoder.cs:723, default on) / HasClipped (:728) */
+/* Page-locked host memory for PCM destinations: nvh_stream_synth writes a pinned pcm_host directly with the copy
+ * engine (no bounce buffer, no memcpy on the calling thread).  Any other pinned allocation works as well. */
+int nvh_pinned_alloc(size_t bytes, void **out);
+void nvh_pinned_free(void *p);
 int nvh_stream_set_clip(nvh_stream *s, int on);
 /* Parse audio packets on the GPU (kernels_parse.hip: floors, residue classification and VQ entry decode, one lane per
  * packet) instead of on the calling thread; the host then only reads each packet's mode number and window flags.

@@ -77,6 +77,25 @@ static void generate_table(Codebook& cb, const int* values, const int* length_li
   }
   cb.prefix_bits = table_bits;
   cb.has_tree = true;
+  // group the overflow list by prefix slot (stable)
+  cb.overflow_grouped.clear();
+  cb.slot_group.assign(cb.prefix.size(), 0u);
+  if (cb.has_overflow) {
+    const uint32_t slot_mask = (uint32_t)cb.prefix.size() - 1u;
+    std::vector<uint32_t> count(cb.prefix.size(), 0u), begin(cb.prefix.size(), 0u);
+    for (const HuffNode& nd : cb.overflow) count[(uint32_t)nd.bits & slot_mask]++;
+    uint32_t run = 0;
+    for (size_t k = 0; k < count.size(); k++) {
+      begin[k] = run;
+      run += count[k];
+    }
+    cb.overflow_grouped.resize(cb.overflow.size());
+    std::vector<uint32_t> fill(begin);
+    for (const HuffNode& nd : cb.overflow) cb.overflow_grouped[fill[(uint32_t)nd.bits & slot_mask]++] = nd;
+    bool wide = false;  // a code of 32+ bits has a wrapped mask (Huffman.cs:29) and could match any slot: keep the plain scan
+    for (const HuffNode& nd : cb.overflow) wide = wide || nd.length >= 32 || nd.length <= table_bits;
+    for (size_t k = 0; k < count.size(); k++) cb.slot_group[k] = (begin[k] << 8) | ((count[k] < 0xFFu && !wide) ? count[k] : 0xFFu);
+  }
 }
 
 // Codebook.cs:172-220.  1 ok, 0 over-subscribed, -1 runtime fault (32-bit lengths)
@@ -254,12 +273,23 @@ int Codebook::decode_scalar(BitReader& p) const {
     p.skip(node.length);
     return node.value;
   }
+  const uint32_t group = has_overflow ? slot_group[(size_t)data] : 0u;
   data = (int)p.peek(max_bits, &got);
   if (!has_overflow) return -2;
-  for (const HuffNode& n : overflow) {
-    if (n.bits == (data & n.mask)) {
-      p.skip(n.length);
-      return n.value;
+  if ((group & 0xFFu) == 0xFFu) {  // oversized group: the plain scan
+    for (const HuffNode& n : overflow) {
+      if (n.bits == (data & n.mask)) {
+        p.skip(n.length);
+        return n.value;
+      }
+    }
+    return -1;
+  }
+  const HuffNode* g = overflow_grouped.data() + (group >> 8);
+  for (uint32_t k = 0; k < (group & 0xFFu); k++) {
+    if (g[k].bits == (data & g[k].mask)) {
+      p.skip(g[k].length);
+      return g[k].value;
     }
   }
   return -1;

@@ -31,6 +31,11 @@ struct Codebook {
   std::vector<float> lattice;     // those values: lookup[e*dim+i] == lattice[(e / lattice_values^i) % lattice_values]
   std::vector<HuffNode> prefix;   // 1 << prefix_bits
   std::vector<HuffNode> overflow;
+  // the overflow list regrouped by the first prefix_bits bits of each code (same relative order inside a group): a
+  // code can only match a peek whose low bits select its group, so the reference's first-match scan over the whole
+  // list (Codebook.cs:306-318) and a scan over the group return the same node.  slot_group[slot] = begin << 8 | count.
+  std::vector<HuffNode> overflow_grouped;
+  std::vector<uint32_t> slot_group;
   bool has_overflow = false;      // C# `_overflowList != null`
   bool has_tree = false;
   int prefix_bits = 0, max_bits = 0;

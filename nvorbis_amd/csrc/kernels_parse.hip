@@ -95,30 +95,40 @@ __device__ __forceinline__ uint32_t br_read(BitR& b, int count) {
 }
 
 // Codebook.DecodeScalar (Codebook.cs:294-320).  -1 = no symbol; -2 = the reference would fault (null list)
-__device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const NvhPBook& bk, BitR& p) {
+__device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const NvhPBook& bk, BitR& p) {
   int got;
   uint32_t data = br_peek(p, bk.prefix_bits, &got);
   if (got == 0) return -1;
   if (!bk.has_tree) return -2;
-  const uint32_t node = T.prefix[bk.prefix_off + data];
+  const uint32_t node = bk.lds_off != 0xFFFFFFFFu ? s_prefix[bk.lds_off + data] : T.prefix[bk.prefix_off + data];
   if (node & 0x80u) {
     br_skip(p, (int)(node & 0x7Fu));
     return (int)(node >> 8);
   }
   data = br_peek(p, bk.max_bits, &got);
   if (!bk.has_overflow) return -2;
+  // the longer codes: the reference scans its whole overflow list for the first match; a code can only match a
+  // peek whose low prefix_bits select its slot, so scanning that slot's group (same relative order) finds the same node
   const NvhPOverflow* ov = T.overflow + bk.ovf_off;
-  for (uint32_t k = 0; k < bk.ovf_count; ++k) {
-    if (ov[k].bits == (data & ov[k].mask)) {
-      br_skip(p, (int)ov[k].length);
-      return (int)ov[k].value;
+  uint32_t cnt = node & 0x7Fu;
+  if (cnt == 0x7Fu) {
+    cnt = bk.ovf_count;
+  } else {
+    ov += bk.ovf_count + (node >> 8);
+  }
+  for (uint32_t k = 0; k < cnt; ++k) {
+    const NvhPOverflow o = ov[k];
+    if (o.bits == (data & o.mask)) {
+      br_skip(p, (int)o.length);
+      return (int)o.value;
     }
   }
   return -1;
 }
 
 // Floor1.Unpack (Floor1.cs:135-184).  Writes the raw posts of one channel; returns 0 or an error code.
-__device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const NvhPFloor1& f, BitR& p, uint16_t* __restrict__ posts,
+__device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const NvhPBook* books,
+                                             const NvhPFloor1& f, BitR& p, uint16_t* __restrict__ posts,
                                              int* post_count_out) {
   int post_count = 0;
   int first_big = NVH_MAX_POSTS + 1;  // first post whose raw value does not fit 16 bits (documented limit)
@@ -134,7 +144,7 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const NvhPFlo
       const uint32_t csub = (1u << cbits) - 1u;
       uint32_t cval = 0;
       if (cbits > 0) {
-        const int r = decode_scalar(T, T.books[f.class_master[cls]], p);
+        const int r = decode_scalar(T, s_prefix, books[f.class_master[cls]], p);
         if (r == -2) return kErrRuntime;
         cval = (uint32_t)r;
         if (cval == 0xFFFFFFFFu) {
@@ -148,7 +158,7 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const NvhPFlo
         cval >>= cbits;
         if (book >= 0) {
           if (post_count >= NVH_MAX_POSTS) return kErrRuntime;  // Posts = new int[64]
-          const int r = decode_scalar(T, T.books[book], p);
+          const int r = decode_scalar(T, s_prefix, books[book], p);
           if (r == -2) return kErrRuntime;
           if (r == -1) {
             post_count = 0;
@@ -181,6 +191,19 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
         NvhParseResult* __restrict__ result) {
+  // hot Huffman tables into LDS (every lane of the wavefront helps, then lanes without a frame leave)
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_prefix[];
+  uint32_t* s_meta = s_prefix + T.lds_words;  // books | floors | residues | mappings, as in the arena
+  for (int i = threadIdx.x; i < T.lds_words; i += 64) s_prefix[i] = T.lds_image[i];
+  {
+    const uint32_t* gm = reinterpret_cast<const uint32_t*>(T.books);
+    for (int i = threadIdx.x; i < T.meta_words; i += 64) s_meta[i] = gm[i];
+  }
+  __syncthreads();
+  const NvhPBook* books = reinterpret_cast<const NvhPBook*>(s_meta);
+  const NvhPFloor1* floors = reinterpret_cast<const NvhPFloor1*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_floors_off);
+  const NvhPResidue* residues = reinterpret_cast<const NvhPResidue*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_residues_off);
+  const NvhPMapping* mappings = reinterpret_cast<const NvhPMapping*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_mappings_off);
   const int f = blockIdx.x * 64 + threadIdx.x;
   if (f >= nframes) return;
   NvhFrame fr = frames[f];
@@ -197,7 +220,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
     const NvhPacketRef ref = refs[f];
     BitR p;
     br_init(p, reinterpret_cast<const uint32_t*>(pkt_pool + ref.byte_off), ref.bit_len, ref.bit_pos);
-    const NvhPMapping& map = T.mappings[fr.mapping];
+    const NvhPMapping& map = mappings[fr.mapping];
 
     // ---- floors (Mapping.cs:95-111) ----
     uint32_t energy = 0;
@@ -205,7 +228,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
       const int fl = map.chan_floor[c];
       int pc = 0;
       uint16_t* my_posts = posts + ((long long)f * nch + c) * NVH_MAX_POSTS;
-      err = decode_floor1(T, T.floors[fl], p, my_posts, &pc);
+      err = decode_floor1(T, s_prefix, books, floors[fl], p, my_posts, &pc);
       NvhChan cn;
       cn.exec = 0;
       cn.floor = (uint8_t)fl;
@@ -230,8 +253,8 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
         if (map.submap_floor[sm] != map.chan_floor[j] || map.submap_residue[sm] != map.chan_residue[j]) force_no |= 1u << j;
       if (!any_execute) continue;
       const int residue_idx = map.submap_residue[sm];
-      const NvhPResidue& r = T.residues[residue_idx];
-      const NvhPBook& class_book = T.books[r.class_book];
+      const NvhPResidue& r = residues[residue_idx];
+      const NvhPBook& class_book = books[r.class_book];
       NvhResPass pass;
       pass.residue = residue_idx;
       for (int s = 0; s <= NVH_MAX_STAGES; s++) pass.op_begin[s] = op_base + nops;
@@ -262,7 +285,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
           for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count && !stop && !err; entry_idx++) {
             if (stage == 0) {
               for (int c = 0; c < r.channels; c++) {
-                const int idx = decode_scalar(T, class_book, p);
+                const int idx = decode_scalar(T, s_prefix, class_book, p);
                 if (idx == -2) {
                   err = kErrRuntime;
                   break;
@@ -289,7 +312,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
                 if ((r.cascade[cls] & (1 << stage)) == 0) continue;
                 const int book_idx = r.books[cls][stage];
                 if (book_idx < 0) continue;
-                const NvhPBook& book = T.books[book_idx];
+                const NvhPBook& book = books[book_idx];
                 const int dims = book.dims;
                 if (dims == 0) {
                   err = kErrRuntime;
@@ -314,7 +337,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
                     break;
                   }
                   for (int i = 0; i < steps; i++) {
-                    const int e = decode_scalar(T, book, p);
+                    const int e = decode_scalar(T, s_prefix, book, p);
                     if (e == -2) {
                       err = kErrRuntime;
                       break;
@@ -346,7 +369,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
                   }
                   int done = 0;
                   for (int i = 0; i < r.partition_size; i += dims) {
-                    const int e = decode_scalar(T, book, p);
+                    const int e = decode_scalar(T, s_prefix, book, p);
                     if (e == -2) {
                       err = kErrRuntime;
                       break;

@@ -725,6 +725,17 @@ extern "C" int nvh_stream_info(const nvh_stream* s, int* channels, int* sample_r
   return NVH_OK;
 }
 
+extern "C" int nvh_pinned_alloc(size_t bytes, void** out) {
+  if (!out) return NVH_ERR_ARGUMENT;
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return NVH_OK;
+}
+
+extern "C" void nvh_pinned_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 extern "C" int nvh_stream_set_gpu_parse(nvh_stream* s, int on) {
   if (!s) return NVH_ERR_ARGUMENT;
   if (!s->ctx) return NVH_ERR_NO_GPU;
@@ -840,20 +851,66 @@ static int upload_parse_tables(nvh_stream* s) {
     d.max_bits = (uint8_t)b.max_bits;
     d.has_tree = b.has_tree ? 1 : 0;
     d.has_overflow = b.has_overflow ? 1 : 0;
-    for (const nvh::HuffNode& n : b.prefix) {
-      if (n.present && (n.length < 0 || n.length > 0x7F || n.value < 0 || n.value > 0xFFFFFF)) return NVH_OK;
-      prefix.push_back(n.present ? (((uint32_t)n.value << 8) | 0x80u | (uint32_t)n.length) : 0u);
+    // prefix[slot]: a short code, or (for slots only longer codes start with) that slot's group of overflow nodes
+    //   present: (value << 8) | 0x80 | length        absent: (group begin << 8) | group count (0x7F = scan the whole list)
+    for (size_t k = 0; k < b.prefix.size(); k++) {
+      const nvh::HuffNode& n = b.prefix[k];
+      if (n.present) {
+        if (n.length < 0 || n.length > 0x7F || n.value < 0 || n.value > 0xFFFFFF) return NVH_OK;
+        prefix.push_back(((uint32_t)n.value << 8) | 0x80u | (uint32_t)n.length);
+      } else {
+        uint32_t g = b.has_overflow && k < b.slot_group.size() ? b.slot_group[k] : 0u;
+        uint32_t cnt = g & 0xFFu, beg = g >> 8;
+        if (cnt >= 0x7Fu || beg > 0xFFFFFFu) {  // oversized group (or the host's own fallback marker): plain scan
+          cnt = 0x7Fu;
+          beg = 0;
+        }
+        prefix.push_back((beg << 8) | cnt);
+      }
     }
     if (b.prefix.empty()) prefix.push_back(0u);  // has_tree == false: never indexed, keeps offsets valid
-    for (const nvh::HuffNode& n : b.overflow) {
+    // overflow pool of this book: the whole list in the reference's order, then the same nodes grouped by slot
+    auto put = [&](const nvh::HuffNode& n) {
       NvhPOverflow o;
       o.bits = (uint32_t)n.bits;
       o.mask = (uint32_t)n.mask;
       o.value = (uint32_t)n.value;
       o.length = (uint32_t)n.length;
       overflow.push_back(o);
-    }
+    };
+    for (const nvh::HuffNode& n : b.overflow) put(n);
+    for (const nvh::HuffNode& n : b.overflow_grouped) put(n);
     d.ovf_count = (uint32_t)b.overflow.size();
+  }
+  // LDS image: residue VQ books first (most symbols of a packet), then class books, then floor books, while they fit
+  std::vector<uint32_t> lds_image;
+  {
+    const size_t budget = 13 * 1024;  // words (52 KB; + <= 8 KB of book / floor / residue / mapping records): two workgroups per CU
+    for (auto& d : books) d.lds_off = 0xFFFFFFFFu;
+    std::vector<int> order;
+    std::vector<char> seen(S.books.size(), 0);
+    auto want = [&](int b) {
+      if (b >= 0 && b < (int)S.books.size() && !seen[(size_t)b]) {
+        seen[(size_t)b] = 1;
+        order.push_back(b);
+      }
+    };
+    for (const nvh::Residue& r : S.residues)
+      for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++)
+        for (int k = 0; k < NVH_MAX_STAGES; k++) want(r.books[c][k]);
+    for (const nvh::Residue& r : S.residues) want(r.class_book);
+    for (const nvh::Floor& fl : S.floors)
+      for (int k = 0; k < 16; k++) {
+        want(fl.f1.class_masterbook[k]);
+        for (int j = 0; j < 8; j++) want(fl.f1.subclass_book[k][j]);
+      }
+    for (int b : order) {
+      const size_t n = S.books[(size_t)b].prefix.size();
+      if (n == 0 || lds_image.size() + n > budget) continue;
+      books[(size_t)b].lds_off = (uint32_t)lds_image.size();
+      lds_image.insert(lds_image.end(), prefix.begin() + books[(size_t)b].prefix_off, prefix.begin() + books[(size_t)b].prefix_off + n);
+    }
+    if (lds_image.empty()) lds_image.push_back(0u);
   }
   std::vector<NvhPFloor1> floors(S.floors.size());
   for (size_t i = 0; i < S.floors.size(); i++) {
@@ -944,14 +1001,18 @@ static int upload_parse_tables(nvh_stream* s) {
   if ((size_t)cap_ops * 10 + (size_t)cap_ent * 2 + (size_t)cap_parts * 8 > ((size_t)1 << 20)) return NVH_OK;
 
   ArenaBuilder ab;
+  // books | floors | residues | mappings back to back: k_parse copies this block into LDS
   size_t o_bk = ab.add(books.data(), books.size() * sizeof(NvhPBook));
-  size_t o_px = ab.add(prefix.data(), prefix.size() * sizeof(uint32_t));
-  NvhPOverflow none{};
-  size_t o_ov = ab.add(overflow.empty() ? &none : overflow.data(), (overflow.empty() ? 1 : overflow.size()) * sizeof(NvhPOverflow));
   size_t o_fl = ab.add(floors.data(), floors.size() * sizeof(NvhPFloor1));
   size_t o_rs = ab.add(residues.data(), residues.size() * sizeof(NvhPResidue));
   size_t o_mp = ab.add(mappings.data(), mappings.size() * sizeof(NvhPMapping));
+  const size_t meta_end = (ab.bytes.size() + 15) / 16 * 16;
+  size_t o_px = ab.add(prefix.data(), prefix.size() * sizeof(uint32_t));
+  NvhPOverflow none{};
+  size_t o_ov = ab.add(overflow.empty() ? &none : overflow.data(), (overflow.empty() ? 1 : overflow.size()) * sizeof(NvhPOverflow));
   size_t o_ip = ab.add(ipool.data(), ipool.size() * sizeof(int32_t));
+  size_t o_li = ab.add(lds_image.data(), lds_image.size() * sizeof(uint32_t));
+  if (meta_end - o_bk > 8 * 1024) return NVH_OK;  // unusually large setup: keep the host parser
   sh.parse_arena.pool = &s->ctx->pool;
   int rc = sh.parse_arena.reserve(ab.bytes.size());
   if (rc != NVH_OK) return rc;
@@ -971,6 +1032,13 @@ static int upload_parse_tables(nvh_stream* s) {
   P.residues = (const NvhPResidue*)(base + o_rs);
   P.mappings = (const NvhPMapping*)(base + o_mp);
   P.ipool = (const int32_t*)(base + o_ip);
+  P.lds_image = (const uint32_t*)(base + o_li);
+  P.lds_words = (int32_t)lds_image.size();
+  P.meta_words = (int32_t)((meta_end - o_bk) / 4);
+  P.meta_floors_off = (int32_t)(o_fl - o_bk);
+  P.meta_residues_off = (int32_t)(o_rs - o_bk);
+  P.meta_mappings_off = (int32_t)(o_mp - o_bk);
+  P.pad = 0;
   sh.gpu_parse_ok = true;
   return NVH_OK;
 }
@@ -1031,7 +1099,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   b->dev.pad = 0;
   if (nf) {
     const unsigned blocks = (unsigned)((nf + 63) / 64);
-    hipLaunchKernelGGL(k_parse, dim3(blocks), dim3(64), 0, st, T, (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
+    hipLaunchKernelGGL(k_parse, dim3(blocks), dim3(64), (size_t)(T.lds_words + T.meta_words) * sizeof(uint32_t), st, T, (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
                        (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
                        (NvhParseResult*)(base + o_rs));
@@ -1331,13 +1399,22 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
   hipStream_t st = s->ctx->stream;
   if (b->last_decoded >= 0) s->carry_cur ^= 1;  // the batch wrote its last block's tail into the other buffer
   // one read-back, one synchronisation: PCM and the two flag words land in a pinned bounce buffer
-  const size_t pcm_bytes = pcm_host ? (size_t)need * sizeof(float) : 0;
-  if ((rc = s->h_pcm.reserve(pcm_bytes + 2 * sizeof(int))) != NVH_OK) return rc;
-  int* h_flags = (int*)((uint8_t*)s->h_pcm.p + pcm_bytes);
-  if (pcm_bytes) HIP_TRY(hipMemcpyAsync(s->h_pcm.p, dst, pcm_bytes, hipMemcpyDeviceToHost, st));
+  size_t pcm_bytes = pcm_host ? (size_t)need * sizeof(float) : 0;
+  // a destination in pinned host memory (nvh_pinned_alloc, hipHostMalloc, hipHostRegister) is written by the copy
+  // engine directly; anything else goes through the bounce buffer and one memcpy on this thread
+  bool direct = false;
+  if (pcm_bytes) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, pcm_host) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();  // plain pageable memory: not an error
+  }
+  const size_t bounce = direct ? 0 : pcm_bytes;
+  if ((rc = s->h_pcm.reserve(bounce + 2 * sizeof(int))) != NVH_OK) return rc;
+  int* h_flags = (int*)((uint8_t*)s->h_pcm.p + bounce);
+  if (pcm_bytes) HIP_TRY(hipMemcpyAsync(direct ? (void*)pcm_host : s->h_pcm.p, dst, pcm_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_flags, s->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (pcm_bytes) std::memcpy(pcm_host, s->h_pcm.p, pcm_bytes);
+  if (bounce) std::memcpy(pcm_host, s->h_pcm.p, bounce);
   if (h_flags[0] || h_flags[1]) HIP_TRY(hipMemsetAsync(s->flags.p, 0, 2 * sizeof(int), st));
   if (h_flags[1]) s->has_clipped = 1;
   if (h_flags[0]) return NVH_ERR_RUNTIME;  // inverse_dB_table / wMap index out of range in the reference

@@ -15,8 +15,9 @@
 #define NVH_PARSE_MAX_COUPLING 16
 
 // Huffman decode tables of one codebook.
-//   prefix[i] (1 << prefix_bits entries): (value << 8) | 0x80 | length for a code of at most prefix_bits bits, else 0
-//   overflow[k]: the longer codes in (length, bits) order
+//   prefix[i] (1 << prefix_bits entries): (value << 8) | 0x80 | length for a code of at most prefix_bits bits, else
+//     (group begin << 8) | group count: the longer codes that start with these prefix_bits (count 0x7F: scan all)
+//   overflow: ovf_count nodes in the reference's (length, bits) order, then the same nodes grouped by prefix slot
 struct NvhPBook {
   uint32_t prefix_off;    // into the uint32 prefix pool
   uint32_t ovf_off;       // into the NvhPOverflow pool
@@ -26,6 +27,8 @@ struct NvhPBook {
   uint8_t prefix_bits, max_bits;
   uint8_t has_tree, has_overflow;  // Codebook.cs:294-320: `_prefixList != null`, `_overflowList != null`
   uint8_t pad[2];
+  uint32_t lds_off;       // word offset of this book's prefix table inside the LDS image, 0xFFFFFFFF: read it from global memory
+  uint32_t pad2[3];
 };
 
 struct NvhPOverflow {
@@ -74,6 +77,12 @@ struct NvhDevParse {
   const NvhPResidue* residues;
   const NvhPMapping* mappings;
   const int32_t* ipool;
+  const uint32_t* lds_image;  // prefix tables of the hottest books (residue VQ books first), copied into LDS by every workgroup
+  int32_t lds_words;
+  // books, floors, residues and mappings are contiguous in the arena (in that order): `meta_words` words from `books`
+  // are copied into LDS too, the three offsets locate the other arrays inside that copy
+  int32_t meta_words;
+  int32_t meta_floors_off, meta_residues_off, meta_mappings_off, pad;  // byte offsets from `books`
 };
 
 // One packet's location for k_parse (its frame record carries the geometry).

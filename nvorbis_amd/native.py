@@ -50,6 +50,8 @@ SIGNATURES = {
     "nvh_stream_close": (None, [_vp]),
     "nvh_stream_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "nvh_stream_set_clip": (C.c_int, [_vp, C.c_int]),
+    "nvh_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "nvh_pinned_free": (None, [_vp]),
     "nvh_stream_set_gpu_parse": (C.c_int, [_vp, C.c_int]),
     "nvh_stream_has_clipped": (C.c_int, [_vp, _ip]),
     "nvh_stream_position": (C.c_int, [_vp, _i64p, _i64p, _ip]),

@@ -194,12 +194,27 @@ class Stream:
         check(lib().nvh_stream_has_clipped(self._h, C.byref(v)), "nvh_stream_has_clipped")
         return bool(v.value)
 
-    def synth_host(self):
-        """Synthesise the pending batch; returns interleaved float32 PCM (numpy)."""
+    def synth_host(self, pinned=False):
+        """Synthesise the pending batch; returns interleaved float32 PCM (numpy).
+
+        pinned=True: the result is a view of a page-locked buffer owned by this stream (written by the copy engine
+        directly, no extra copy) and stays valid until the next call."""
         _, smp = self.pending()
-        out = np.empty(max(smp * self.channels, 1), dtype=np.float32)
+        n = max(smp * self.channels, 1)
         wr = C.c_int64(0)
-        check(lib().nvh_stream_synth(self._h, out.ctypes.data, None, out.size, C.byref(wr)), "nvh_stream_synth")
+        if pinned:
+            if getattr(self, "_pin_cap", 0) < n:
+                if getattr(self, "_pin_ptr", None):
+                    lib().nvh_pinned_free(self._pin_ptr)
+                p = C.c_void_p()
+                cap = max(n, 2 * getattr(self, "_pin_cap", 0))
+                check(lib().nvh_pinned_alloc(cap * 4, C.byref(p)), "nvh_pinned_alloc")
+                self._pin_ptr, self._pin_cap = p, cap
+                self._pin_arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(cap,))
+            out = self._pin_arr
+        else:
+            out = np.empty(n, dtype=np.float32)
+        check(lib().nvh_stream_synth(self._h, out.ctypes.data, None, n, C.byref(wr)), "nvh_stream_synth")
         return out[:wr.value]
 
     def synth_device(self, d_ptr, capacity):
@@ -216,6 +231,10 @@ class Stream:
         if self._h:
             lib().nvh_stream_close(self._h)
             self._h = C.c_void_p()
+        if getattr(self, "_pin_ptr", None):
+            self._pin_arr = None
+            lib().nvh_pinned_free(self._pin_ptr)
+            self._pin_ptr, self._pin_cap = None, 0
 
     def __del__(self):
         try:

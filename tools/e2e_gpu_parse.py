@@ -10,20 +10,20 @@ pk = [ll[(i + 1) % len(ll)] for i in range(N)]
 offs = np.zeros(N + 1, np.int64); offs[1:] = np.cumsum([len(p) for p in pk])
 pa = nv.PacketArray(np.frombuffer(b"".join(pk), np.uint8), offs, np.full(N, -1, np.int64), np.zeros(N, np.uint8))
 res = {}
-for mode in ("host", "gpu"):
+for mode in ("host", "gpu", "gpu+pinned"):
     st = nv.Stream(ctx, *headers)
-    st.set_gpu_parse(mode == "gpu")
+    st.set_gpu_parse(mode != "host")
     st.push_packet(ll[0], -1, 0); st.synth_host()
     best = None
     for rep in range(6):
         t0 = time.perf_counter()
         took = st.push_packets(pa, 0, N); assert took == N
         t1 = time.perf_counter()
-        pcm = st.synth_host()
+        pcm = st.synth_host(pinned=mode.endswith("pinned"))
         t2 = time.perf_counter()
         if best is None or (t2 - t0) < sum(best): best = (t1 - t0, t2 - t1)
     res[mode] = pcm.copy()
-    print("%-4s parse: host side %.2f ms, synth (upload + [k_parse] + kernels + D2H) %.2f ms -> %.0f k frames/s end to end" % (
+    print("%-10s parse: host side %.2f ms, synth (upload + [k_parse] + kernels + D2H) %.2f ms -> %.0f k frames/s end to end" % (
         mode, best[0] * 1e3, best[1] * 1e3, N / sum(best) / 1e3), flush=True)
     st.close()
-print("PCM identical:", bool((res["host"] == res["gpu"]).all()), res["host"].size)
+print("PCM identical:", bool((res["host"] == res["gpu"]).all() and (res["host"] == res["gpu+pinned"]).all()), res["host"].size)
