@@ -246,10 +246,16 @@ class Stream:
 class StreamDecoder:
     """IStreamDecoder-shaped object (Contracts/IStreamDecoder.cs:9-105) over a packet list."""
 
-    def __init__(self, ctx, packets, granules=None, flags=None, batch_frames=1024):
+    def __init__(self, ctx, packets, granules=None, flags=None, batch_frames=1024, gpu_parse=False):
         if len(packets) < 3:
             raise native.NvhError(native.ERR_NOT_VORBIS, "StreamDecoder")
         self._stream = Stream(ctx, packets[0], packets[1], packets[2])
+        if gpu_parse:  # packets parsed by k_parse; stream shapes outside its limits silently keep the host parser
+            try:
+                self._stream.set_gpu_parse(True)
+            except native.NvhError as e:
+                if e.code != native.ERR_UNSUPPORTED:
+                    raise
         self._packets = packets
         self._array = packets if isinstance(packets, PacketArray) else None  # batched push, no per-packet FFI call
         self._granules = granules if granules is not None else [-1] * len(packets)
@@ -313,9 +319,10 @@ class StreamDecoder:
                 pushed += 1
             frames, _ = self._stream.pending()
             if frames:
-                pcm = self._stream.synth_host()
+                # the ring is only replaced once it has been read out, so the stream's pinned buffer can be it
+                pcm = self._stream.synth_host(pinned=True)
                 if pcm.size:
-                    self._ring = pcm.copy()
+                    self._ring = pcm
                     self._ring_pos = 0
                     return True
         return False
@@ -345,7 +352,7 @@ class StreamDecoder:
 class VorbisReader:
     """VorbisReader-shaped facade (VorbisReader.cs): first logical stream of an .ogg file or byte string."""
 
-    def __init__(self, source, ctx=None, device=0, batch_frames=1024):
+    def __init__(self, source, ctx=None, device=0, batch_frames=1024, gpu_parse=False):
         if isinstance(source, (bytes, bytearray, memoryview)):
             data = bytes(source)
         else:
@@ -353,7 +360,7 @@ class VorbisReader:
                 data = fh.read()
         self._own_ctx = ctx is None
         self._ctx = ctx if ctx is not None else Context(device)
-        self._dec = StreamDecoder(self._ctx, demux_ogg_array(data), None, None, batch_frames)
+        self._dec = StreamDecoder(self._ctx, demux_ogg_array(data), None, None, batch_frames, gpu_parse)
 
     Channels = property(lambda self: self._dec.Channels)
     SampleRate = property(lambda self: self._dec.SampleRate)

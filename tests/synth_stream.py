@@ -96,6 +96,34 @@ class Book:
             w.write(int(m), self.value_bits)
 
 
+class IncompleteBook(Book):
+    """Like Book, but written sparse with its last entry unused: the all-ones code is unassigned, and a packet that
+    contains it makes the reference fault (no overflow list to consult, Codebook.cs:306 -> NullReferenceException)."""
+
+    def write(self, w, rng):
+        w.write(0x564342, 24)
+        w.write(self.dims, 16)
+        w.write(self.entries, 24)
+        w.write(0, 1)  # not ordered
+        w.write(1, 1)  # sparse
+        for i in range(self.entries):
+            used = i != self.entries - 1
+            w.write(1 if used else 0, 1)
+            if used:
+                w.write(self.bits - 1, 5)
+        w.write(self.lookup, 4)
+        if self.lookup == 0:
+            return
+        w.write(vorbis_float(*self.min_me), 32)
+        w.write(vorbis_float(*self.delta_me), 32)
+        w.write(self.value_bits - 1, 4)
+        w.write(self.sequence_p, 1)
+        count = self.lookup1_values() if self.lookup == 1 else self.entries * self.dims
+        mults = self.mults if self.mults is not None else rng.integers(0, 1 << self.value_bits, count).tolist()
+        for m in mults:
+            w.write(int(m), self.value_bits)
+
+
 def write_floor1(w, partition_classes, class_dims, class_subclass_bits, masterbooks, subclass_books, multiplier, rangebits, xs):
     """Floor1.Init layout (Floor1.cs:30-92).  xs: the X values after the two implicit ones."""
     w.write(1, 16)
