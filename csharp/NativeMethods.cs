@@ -30,9 +30,15 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern void nvh_stream_close(IntPtr stream);
         [DllImport(Lib)] public static extern int nvh_stream_info(IntPtr stream, out int channels, out int sampleRate, out int block0, out int block1);
         [DllImport(Lib)] public static extern int nvh_stream_set_clip(IntPtr stream, int on);
+        /// <summary>Parse audio packets on the GPU (kernels_parse.hip); NVH_ERR_UNSUPPORTED (-7) for stream shapes outside its limits.</summary>
+        [DllImport(Lib)] public static extern int nvh_stream_set_gpu_parse(IntPtr stream, int on);
+        /// <summary>Page-locked host memory: a pinned pcmHost is written by the copy engine directly.</summary>
+        [DllImport(Lib)] public static extern int nvh_pinned_alloc(UIntPtr bytes, out IntPtr p);
+        [DllImport(Lib)] public static extern void nvh_pinned_free(IntPtr p);
         [DllImport(Lib)] public static extern int nvh_stream_has_clipped(IntPtr stream, out int clipped);
         [DllImport(Lib)] public static extern int nvh_stream_position(IntPtr stream, out long position, out long emitted, out int eos);
         [DllImport(Lib)] public static extern unsafe int nvh_stream_push_packet(IntPtr stream, byte* data, int len, long granule, int flags);
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_push_packets(IntPtr stream, byte* bytes, long* offsets, long* granules, byte* flags, int n, int maxPackets, out int consumed);
         [DllImport(Lib)] public static extern int nvh_stream_push_end(IntPtr stream);
         [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);
         [DllImport(Lib)] public static extern unsafe int nvh_stream_synth(IntPtr stream, float* pcmHost, IntPtr dPcm, long capacity, out long written);
