@@ -75,7 +75,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnvorbis_hip.so")
+    # NVH_LIB: load another build of the library (development aid: same-box A/B runs, tools/ab_git.sh)
+    return os.environ.get("NVH_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnvorbis_hip.so")
 
 
 def lib():
