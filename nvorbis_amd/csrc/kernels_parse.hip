@@ -190,7 +190,7 @@ extern "C" __global__ void __launch_bounds__(64)
 k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
-        NvhParseResult* __restrict__ result) {
+        NvhParseResult* __restrict__ result, int lanes) {
   // hot Huffman tables into LDS (every lane of the wavefront helps, then lanes without a frame leave)
   extern __shared__ __attribute__((aligned(16))) uint32_t s_prefix[];
   uint32_t* s_meta = s_prefix + T.lds_words;  // books | floors | residues | mappings, as in the arena
@@ -204,7 +204,11 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
   const NvhPFloor1* floors = reinterpret_cast<const NvhPFloor1*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_floors_off);
   const NvhPResidue* residues = reinterpret_cast<const NvhPResidue*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_residues_off);
   const NvhPMapping* mappings = reinterpret_cast<const NvhPMapping*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_mappings_off);
-  const int f = blockIdx.x * 64 + threadIdx.x;
+  // `lanes` packets per wavefront (host: as few as keeps every workgroup resident at once): the 64 lanes of a wavefront diverge, so its instruction stream is the union
+  // of its packets' paths -- fewer packets per wavefront means a shorter union, and the chip has SIMDs to spare
+  // (a 4096-packet batch at 64 per wavefront would occupy 64 of 1024)
+  if ((int)threadIdx.x >= lanes) return;
+  const int f = blockIdx.x * lanes + threadIdx.x;
   if (f >= nframes) return;
   NvhFrame fr = frames[f];
   const int nch = T.channels;

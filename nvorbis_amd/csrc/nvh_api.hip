@@ -43,7 +43,7 @@ __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const f
                                     const float* TW);
 __global__ void k_parse(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
                         NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
-                        NvhParseResult* result);
+                        NvhParseResult* result, int lanes);
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
                               uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
@@ -1099,10 +1099,17 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   b->dev.pad = 0;
   if (nf) {
     const unsigned blocks = (unsigned)((nf + 63) / 64);
-    hipLaunchKernelGGL(k_parse, dim3(blocks), dim3(64), (size_t)(T.lds_words + T.meta_words) * sizeof(uint32_t), st, T, (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
+    // packets per wavefront: as few as keeps all workgroups resident at once (2 per CU with ~58 KB of LDS each); a
+    // wavefront's instruction stream is the union of its packets' paths, so fewer packets per wavefront run faster
+    static const int lanes_env = getenv("NVH_PARSE_LANES") ? atoi(getenv("NVH_PARSE_LANES")) : 0;
+    int lanes = 64;
+    while (lanes > 8 && (nf + (size_t)(lanes / 2) - 1) / (size_t)(lanes / 2) <= 512) lanes /= 2;
+    if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
+    const unsigned pblocks = (unsigned)((nf + (size_t)lanes - 1) / (size_t)lanes);
+    hipLaunchKernelGGL(k_parse, dim3(pblocks), dim3(64), (size_t)(T.lds_words + T.meta_words) * sizeof(uint32_t), st, T, (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
                        (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
-                       (NvhParseResult*)(base + o_rs));
+                       (NvhParseResult*)(base + o_rs), lanes);
     // the carried block's execute flags ping-pong together with the carried block (nvh_stream_synth flips carry_cur)
     uint32_t* ce = (uint32_t*)s->carry_exec.p;
     hipLaunchKernelGGL(k_parse_links, dim3(blocks), dim3(64), 0, st, (int)nf, ch, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch),
