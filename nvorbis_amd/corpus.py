@@ -98,7 +98,7 @@ def transcode(files, decode_fn=None, rank=0, world=1, dist=None, device="cpu", g
     return gather_pcm(local, len(files), rank, world, dist, device)
 
 
-def decode_files_threaded(files, device=0, workers=16, batch_frames=4096):
+def decode_files_threaded(files, device=0, workers=16, batch_frames=4096, gpu_parse=False):
     """Decode a list of .ogg byte strings on ONE GPU with `workers` host threads; returns PCM arrays in file order.
 
     The bit-serial half of the decoder (Huffman / floor / residue side information, nvorbis_amd/csrc/host_parse.cpp)
@@ -106,7 +106,9 @@ def decode_files_threaded(files, device=0, workers=16, batch_frames=4096):
     synthesises; files are independent, so a worker pool parses them side by side.  Each worker owns one nvh_ctx
     (= one HIP stream), so uploads, kernels and read-backs of different files overlap on the device.  ctypes
     releases the GIL for the duration of every library call and packets are pushed a batch per call
-    (nvh_stream_push_packets), so the pool scales with cores.  Results are byte-identical to a serial decode."""
+    (nvh_stream_push_packets), so the pool scales with cores.  gpu_parse=True moves the packet parse to the GPU as well
+    (kernels_parse.hip): less host work per file, at ~0.8 ms of kernel latency per batch.  Results are byte-identical
+    to a serial decode either way."""
     import queue
     import threading
 
@@ -118,6 +120,11 @@ def decode_files_threaded(files, device=0, workers=16, batch_frames=4096):
         pa = demux_ogg_array(data)
         st = Stream(ctx, pa[0], pa[1], pa[2])
         try:
+            if gpu_parse:  # packets parsed by k_parse; shapes outside its limits keep the host parser
+                try:
+                    st.set_gpu_parse(True)
+                except Exception:
+                    pass
             chunks, nxt = [], 3
             while True:
                 if nxt < len(pa) and not st.position()[2]:

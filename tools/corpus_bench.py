@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--files", type=int, default=1000)
 ap.add_argument("--workers", type=str, default="1,4,16,32,64")
 ap.add_argument("--batch-frames", type=int, default=4096)
+ap.add_argument("--gpu-parse", action="store_true")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = [open(os.path.join(root, "tests", "golden", n + ".ogg"), "rb").read() for n in ("1test", "2test", "3test", "issue6test")]
@@ -21,7 +22,7 @@ files = [base[i % len(base)] for i in range(a.files)]
 ref = None
 for w in [int(x) for x in a.workers.split(",")]:
     t0 = time.perf_counter()
-    out = corpus.decode_files_threaded(files, device=0, workers=w, batch_frames=a.batch_frames)
+    out = corpus.decode_files_threaded(files, device=0, workers=w, batch_frames=a.batch_frames, gpu_parse=a.gpu_parse)
     dt = time.perf_counter() - t0
     samples = sum(o.size for o in out) // 2
     if ref is None:
