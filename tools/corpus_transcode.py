@@ -1,0 +1,55 @@
+"""BASELINE.json configs[4]: offline transcode of an .ogg corpus, file-parallel across the GPUs of one node.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         tools/corpus_transcode.py --files 1000 [--dir DIR] [--workers 16]
+
+One process per GPU.  Files are sharded LPT-greedy by compressed size (no data-path collective), each rank decodes its
+shard with a pool of host threads (nvorbis_amd.corpus.decode_files_threaded), and the only exchange is the final gather
+of the PCM to rank 0 over RCCL / xGMI (all_gather of sample counts + point-to-point payloads, nvorbis_amd.corpus.gather_pcm).
+Without --dir the corpus is the four shipped test files cycled to --files entries.  Rank 0 prints one JSON line."""
+import argparse, glob, json, os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+from nvorbis_amd import corpus
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--files", type=int, default=1000)
+ap.add_argument("--dir", type=str, default=None)
+ap.add_argument("--workers", type=int, default=16)
+ap.add_argument("--gpu-parse", action="store_true")
+a = ap.parse_args()
+rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+torch.cuda.set_device(local)
+dist = None
+if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if a.dir:
+    names = sorted(glob.glob(os.path.join(a.dir, "*.ogg")))
+    files = [open(n, "rb").read() for n in names]
+else:
+    base = [open(os.path.join(root, "tests", "golden", n + ".ogg"), "rb").read() for n in ("1test", "2test", "3test", "issue6test")]
+    files = [base[i % len(base)] for i in range(a.files)]
+if dist is not None:
+    dist.barrier()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+shards = corpus.lpt_shards([len(f) for f in files], world)
+mine = shards[rank]
+pcm = corpus.decode_files_threaded([files[i] for i in mine], device=local, workers=a.workers, gpu_parse=a.gpu_parse)
+t1 = time.perf_counter()
+local_map = {i: np.ascontiguousarray(p, dtype=np.float32) for i, p in zip(mine, pcm)}
+out = corpus.gather_pcm(local_map, len(files), rank, world, dist, "cuda:%d" % local)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+if rank == 0:
+    samples = sum(o.size for o in out)
+    print(json.dumps({"files": len(files), "n_gpus": world, "workers_per_gpu": a.workers, "decode_s": t1 - t0, "gather_s": t2 - t1,
+                      "files_per_s": len(files) / (t2 - t0), "pcm_floats": int(samples),
+                      "long_frame_equivalents_per_s": samples / 2 / 1024 / (t2 - t0)}), flush=True)
+if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
