@@ -62,6 +62,9 @@ int nvh_ctx_synchronize(nvh_ctx *ctx);
 
 /* ---- level 1: batched mirrors of the plug-in interface methods (device pointers) ---- */
 
+/* One inverse square-polar coupling step over two device vectors of `count` floats, in place (Mapping.cs:150-178). */
+int nvh_inverse_couple(nvh_ctx *c, float *d_magnitude, float *d_angle, int count);
+
 /* IMdct.Reverse(float[] samples, int sampleCount) (Contracts/IMdct.cs:5, Mdct.cs:13-21) on `batch`
  * buffers: buffer b = d_buf + b*stride holds n floats, reads [0,n/2), writes [0,n).  n = 64..8192. */
 int nvh_mdct_reverse(nvh_ctx *ctx, int n, int batch, float *d_buf, int64_t stride);
@@ -122,6 +125,13 @@ int nvh_stream_synth(nvh_stream *s, float *pcm_host, float *d_pcm, int64_t capac
 /* ---- device-resident batches (benchmarks, pipelined callers) ---- */
 /* Move the pending batch into HBM as an object of its own; the stream's pending batch becomes empty
  * and its overlap state advances as if the batch had been synthesised. */
+/* IMode.Decode (Mode.cs:153-170) on ONE audio packet: the bit-consuming half on the host, then floors, residue adds, inverse
+ * coupling, floor apply, IMDCT and window on the GPU -- the windowed block before any overlap -- into d_block
+ * [channels][block1] (device).  Independent of the stream's decode state (needs an empty pending batch); *decoded = 0
+ * when the reference returns without decoding the packet.  Geometry as Mode.GetPacketInfo reports it. */
+int nvh_mode_decode(nvh_stream *s, const uint8_t *pkt, int len, float *d_block, int *decoded, int *block_size, int *start,
+                    int *valid, int *total);
+
 int nvh_batch_upload(nvh_stream *s, nvh_batch **out);
 int nvh_batch_info(const nvh_batch *b, int *frames, int *chan_frames, int64_t *pcm_samples_per_channel,
                    int64_t *descriptor_bytes);

@@ -228,6 +228,24 @@ __device__ void imdct_lds(float* u, float* v, int n, const float* __restrict__ A
 }
 
 // Stand-alone batched IMdct.Reverse: buf[b*stride .. +n) in place, no window (fine-grained ABI).
+// One inverse square-polar coupling step over a pair of vectors (Mapping.cs:150-178), stand-alone (fine-grained ABI).
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_inverse_couple(float* __restrict__ magnitude, float* __restrict__ angle, int cnt) {
+  for (int j = blockIdx.x * NVH_THREADS + threadIdx.x; j < cnt; j += gridDim.x * NVH_THREADS) {
+    const float oldM = magnitude[j], oldA = angle[j];
+    float newM, newA;
+    if (oldM > 0) {
+      if (oldA > 0) { newM = oldM; newA = oldM - oldA; }
+      else          { newA = oldM; newM = oldM + oldA; }
+    } else {
+      if (oldA > 0) { newM = oldM; newA = oldM + oldA; }
+      else          { newA = oldM; newM = oldM - oldA; }
+    }
+    magnitude[j] = newM;
+    angle[j] = newA;
+  }
+}
+
 extern "C" __global__ void __launch_bounds__(NVH_THREADS)
 k_mdct_reverse(float* __restrict__ buf, int n, long long stride, const float* __restrict__ A,
                const float* __restrict__ B, const float* __restrict__ C, const uint16_t* __restrict__ BR) {

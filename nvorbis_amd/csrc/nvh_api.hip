@@ -46,6 +46,7 @@ __global__ void k_parse(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketR
                         NvhParseResult* result, int lanes);
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
                               uint32_t* carry_exec_out, int last_decoded);
+__global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
 __global__ void k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
@@ -188,6 +189,7 @@ struct nvh_batch {
   bool links_ok = false;  // op_link chains usable (every frame has < 32767 ops): k_spectrum's chain walk
   int max_ops = 0, max_ent = 0, max_pass = 0;  // largest per-frame op / entry / pass slice (LDS staging capacity of k_spectrum)
   bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
+  bool block_only = false;       // nvh_mode_decode: stop after the windowed IMDCT (full blocks in the work planes, no overlap-add)
   bool has_carry_in = false;
 };
 
@@ -363,6 +365,17 @@ static int get_mdct(nvh_ctx* c, int n, MdctDev** out) {
   }
   auto ins = c->mdct_cache.emplace(n, d);
   *out = &ins.first->second;
+  return NVH_OK;
+}
+
+extern "C" int nvh_inverse_couple(nvh_ctx* c, float* d_magnitude, float* d_angle, int count) {
+  if (!c || !d_magnitude || !d_angle || count < 0) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  if (count == 0) return NVH_OK;
+  int blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_inverse_couple, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_magnitude, d_angle, count);
+  HIP_TRY(hipGetLastError());
   return NVH_OK;
 }
 
@@ -1262,8 +1275,8 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   static const int no_compact = getenv("NVH_NO_COMPACT") ? 1 : 0;
   static const int no_fused_ola = getenv("NVH_FUSED_OLA") ? 0 : 1;  // experimental run-based kernel: opt-in
   static const int no_fused_imdct = getenv("NVH_NO_FUSED_IMDCT") ? 1 : 0;
-  const bool use_fused_ola = b->fused_ola && !no_fused_ola;
-  const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola;
+  const bool use_fused_ola = b->fused_ola && !no_fused_ola && !b->block_only;
+  const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola && !b->block_only;
   // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers
   const bool fast = s->fast_spectrum && b->links_ok;  // k_spectrum proper (pair path by chain walk, fused tail)
   bool fuse_imdct = compact && fast && s->setup.block1 <= 2048 && !no_fused_imdct;  // and the LDS-resident path is taken (below)
@@ -1344,7 +1357,9 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     else
       hipLaunchKernelGGL(k_imdct_window, dim3((unsigned)(b->nframes * ch)), dim3(256), lds, st, s->dev, b->dev, work);
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));
-    if (compact)
+    if (b->block_only) {
+      b->slot_name[3] = "-";  // nvh_mode_decode: the caller wants the windowed blocks themselves
+    } else if (compact)
       hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes), dim3(64), 0, st, s->dev, b->dev, (const float*)work, carry,
                          d_pcm, s->clip, flags + 1, carry_out, b->last_decoded);
     else if (!b->sequential_ola)
@@ -1353,7 +1368,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     else
       hipLaunchKernelGGL(k_ola_emit_seq, dim3(1), dim3(256), 0, st, s->dev, b->dev, work, carry, d_pcm, s->clip, flags + 1);
     // the last decoded block becomes the carried tail (StreamDecoder's _prevPacketBuf), always fully windowed
-    if (!compact && b->last_decoded >= 0 && carry_out)
+    if (!compact && !b->block_only && b->last_decoded >= 0 && carry_out)
       HIP_TRY(hipMemcpyAsync(carry_out, (const uint8_t*)b->work.p + (size_t)b->last_decoded * plane_bytes, plane_bytes,
                              hipMemcpyDeviceToDevice, st));
   }
@@ -1426,6 +1441,52 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
   if (h_flags[1]) s->has_clipped = 1;
   if (h_flags[0]) return NVH_ERR_RUNTIME;  // inverse_dB_table / wMap index out of range in the reference
   if (written) *written = need;
+  return NVH_OK;
+}
+
+// IMode.Decode on one packet (Mode.cs:153-170): floors, residue, coupling, floor apply, IMDCT and window of that packet
+// alone -- the windowed block, before any overlap -- into d_block [channels][block1] (device memory).  Does not
+// touch the stream's decode state; the stream must have nothing pending.  *decoded = 0 when the reference would have
+// returned without decoding (short packet).
+extern "C" int nvh_mode_decode(nvh_stream* s, const uint8_t* pkt, int len, float* d_block, int* decoded, int* block_size,
+                               int* start, int* valid, int* total) {
+  if (!s || (!pkt && len > 0) || len < 0 || !d_block) return NVH_ERR_ARGUMENT;
+  if (!s->ctx) return NVH_ERR_NO_GPU;
+  if (!s->pending.frames.empty()) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  if (decoded) *decoded = 0;
+  static const uint8_t empty = 0;
+  nvh::StreamParser one(&s->setup);  // a fresh parser: Mode.Decode does not depend on what came before
+  nvh::FrameBatch fb;
+  int rc = one.push_packet(pkt ? pkt : &empty, len, -1, 0, fb);
+  if (rc != NVH_OK) return rc;
+  if (fb.frames.empty() || fb.frames[0].n == 0) return NVH_OK;
+  const NvhFrame f0 = fb.frames[0];
+  nvh_batch b;
+  b.blob.pool = b.work.pool = b.carry_in.pool = b.slabs.pool = &s->ctx->pool;
+  b.h_blob.host = true;
+  b.h_blob.pool = &s->ctx->hpool;
+  b.block_only = true;
+  const bool was_gpu = s->gpu_parse;
+  s->gpu_parse = false;
+  std::swap(s->pending, fb);
+  rc = batch_upload(s, &b);
+  std::swap(s->pending, fb);
+  s->pending.clear();
+  s->gpu_parse = was_gpu;
+  if (rc != NVH_OK) return rc;
+  rc = batch_launch(&b, (const float*)s->carry[s->carry_cur].p, nullptr, nullptr, false, nullptr);
+  if (rc != NVH_OK) return rc;
+  hipStream_t st = s->ctx->stream;
+  const size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(d_block, b.work.p, plane, hipMemcpyDeviceToDevice, st));
+  rc = collect_flags(s);  // synchronises; a floor curve outside the dB table is NVH_ERR_RUNTIME here as well
+  if (rc != NVH_OK) return rc;
+  if (decoded) *decoded = 1;
+  if (block_size) *block_size = f0.n;
+  if (start) *start = f0.start;
+  if (valid) *valid = f0.valid;
+  if (total) *total = f0.total;
   return NVH_OK;
 }
 

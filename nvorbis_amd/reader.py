@@ -79,6 +79,10 @@ class Context:
         """IMdct.Reverse on `batch` device buffers (Contracts/IMdct.cs:5)."""
         check(lib().nvh_mdct_reverse(self._h, int(n), int(batch), C.c_void_p(d_ptr), int(stride)), "nvh_mdct_reverse")
 
+    def inverse_couple(self, d_magnitude, d_angle, count):
+        """One inverse square-polar coupling step over two device vectors, in place (Mapping.cs:150-178)."""
+        check(lib().nvh_inverse_couple(self._h, C.c_void_p(d_magnitude), C.c_void_p(d_angle), int(count)), "nvh_inverse_couple")
+
     def close(self):
         if self._h:
             lib().nvh_ctx_destroy(self._h)
@@ -181,6 +185,14 @@ class Stream:
         pos, em, eos = C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(lib().nvh_stream_position(self._h, C.byref(pos), C.byref(em), C.byref(eos)), "nvh_stream_position")
         return pos.value, em.value, bool(eos.value)
+
+    def mode_decode(self, packet, d_block):
+        """IMode.Decode on one packet: the windowed block before overlap into d_block [channels][block1] (device pointer).
+        Returns None if the packet is not decoded, else (block_size, start, valid, total)."""
+        dec, bs, a, b, c = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().nvh_mode_decode(self._h, packet, len(packet), C.c_void_p(d_block), C.byref(dec), C.byref(bs), C.byref(a),
+                                    C.byref(b), C.byref(c)), "nvh_mode_decode")
+        return (bs.value, a.value, b.value, c.value) if dec.value else None
 
     def set_gpu_parse(self, on):
         """Parse packets on the GPU (kernels_parse.hip); raises NvhError(UNSUPPORTED) for ineligible stream shapes."""

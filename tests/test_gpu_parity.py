@@ -250,3 +250,63 @@ def test_threaded_corpus_decode_matches_serial(oracle, ogg_bytes):
     refs = {n: oracle.decode_ogg(ogg_bytes[n])[0] for n in set(names)}
     for n, o in zip(names, out):
         assert o.size == refs[n].size and (o == refs[n]).all(), n
+
+
+def test_inverse_couple_bit_exact(oracle, gpu_ctx):
+    """Fine-grained ABI: one inverse coupling step (Mapping.cs:150-178) on device vectors == the oracle's, every bit."""
+    import ctypes as C
+    torch = _torch()
+    rng = np.random.default_rng(5)
+    n = 4099
+    m = rng.normal(0, 1, n).astype(np.float32)
+    a = rng.normal(0, 1, n).astype(np.float32)
+    m[:8] = [0.0, -0.0, 1.0, -1.0, 0.0, 1e-41, -1e-41, 3.0]
+    a[:8] = [0.0, 1.0, 0.0, -0.0, -2.0, 1e-41, 1e-41, -3.0]
+    rm, ra = m.copy(), a.copy()
+    oracle.L.orc_inverse_couple(rm.ctypes.data, ra.ctypes.data, n)
+    dm, da = torch.from_numpy(m.copy()).cuda(), torch.from_numpy(a.copy()).cuda()
+    gpu_ctx.inverse_couple(dm.data_ptr(), da.data_ptr(), n)
+    gpu_ctx.synchronize()
+    assert np.array_equal(dm.cpu().numpy().view(np.uint32), rm.view(np.uint32))
+    assert np.array_equal(da.cpu().numpy().view(np.uint32), ra.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["2test", "3test"])
+def test_mode_decode_blocks_bit_exact(oracle, gpu_ctx, ogg_bytes, name):
+    """Fine-grained ABI: IMode.Decode of single packets (windowed blocks before overlap, Mode.cs:153-170) == the oracle's
+    orc_decode_packet_block, for long, short and transition windows."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    torch = _torch()
+    pk, gr, fl = nv.demux_ogg(ogg_bytes[name])
+    hdr = pk[:3]
+    blob = np.frombuffer(b"".join(hdr), dtype=np.uint8)
+    offs = np.zeros(4, np.int64)
+    offs[1:] = np.cumsum([len(p) for p in hdr])
+    g3, f3, err = np.full(3, -1, np.int64), np.zeros(3, np.uint8), C.c_int(0)
+    d = oracle.L.orc_open_packets(blob.ctypes.data, offs.ctypes.data, g3.ctypes.data, f3.ctypes.data, 3, C.byref(err))
+    assert d
+    st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+    try:
+        ch, b1 = st.channels, st.block1
+        ref = np.zeros(ch * b1, np.float32)
+        got = torch.zeros(ch * b1, dtype=torch.float32, device="cuda")
+        kinds = set()
+        step = max(1, (len(pk) - 3) // 60)
+        for i in list(range(3, min(len(pk), 40))) + list(range(40, len(pk), step)):
+            a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            rc = oracle.L.orc_decode_packet_block(d, pk[i], len(pk[i]), ref.ctypes.data, C.byref(a), C.byref(b), C.byref(c), C.byref(e))
+            geo = st.mode_decode(pk[i], got.data_ptr())
+            assert (rc == 1) == (geo is not None), i
+            if geo is None:
+                continue
+            assert geo == (e.value, a.value, b.value, c.value), (i, geo)
+            n = e.value
+            kinds.add((n, a.value, c.value))
+            g = got.cpu().numpy().reshape(ch, b1)[:, :n]
+            r = ref.reshape(ch, b1)[:, :n]
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), (i, float(np.abs(g - r).max()))
+        assert len(kinds) >= 2  # more than one window shape was exercised
+    finally:
+        st.close()
+        oracle.L.orc_close(d)
