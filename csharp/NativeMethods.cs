@@ -40,6 +40,10 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern unsafe int nvh_stream_push_packet(IntPtr stream, byte* data, int len, long granule, int flags);
         [DllImport(Lib)] public static extern unsafe int nvh_stream_push_packets(IntPtr stream, byte* bytes, long* offsets, long* granules, byte* flags, int n, int maxPackets, out int consumed);
         [DllImport(Lib)] public static extern int nvh_stream_push_end(IntPtr stream);
+        /// <summary>IMode.Decode of one packet: windowed block [channels][block1] before overlap, into device memory.</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_mode_decode(IntPtr stream, byte* packet, int len, IntPtr dBlock, out int decoded, out int blockSize, out int start, out int valid, out int total);
+        /// <summary>One inverse coupling step (Mapping.cs:150-178) over two device vectors.</summary>
+        [DllImport(Lib)] public static extern int nvh_inverse_couple(IntPtr ctx, IntPtr dMagnitude, IntPtr dAngle, int count);
         [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);
         [DllImport(Lib)] public static extern unsafe int nvh_stream_synth(IntPtr stream, float* pcmHost, IntPtr dPcm, long capacity, out long written);
 
