@@ -310,3 +310,47 @@ def test_mode_decode_blocks_bit_exact(oracle, gpu_ctx, ogg_bytes, name):
     finally:
         st.close()
         oracle.L.orc_close(d)
+
+
+@pytest.mark.parametrize("name", ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
+                                  "two_submaps", "equal_blocks_overrun", "mono_8192", "floor0_stereo"])
+def test_mode_decode_synthetic_shapes(oracle, gpu_ctx, name):
+    """IMode.Decode per packet for the stream shapes no shipped file has (Residue0/1, 3 and 6 channels, submaps, 64..8192
+    blocks): bit-exact, Floor0 within the stated 1e-6."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    torch = _torch()
+    pk, gr, fl = ss.filtered_stream(oracle, name, 40, 21)
+    hdr = pk[:3]
+    blob = np.frombuffer(b"".join(hdr), dtype=np.uint8)
+    offs = np.zeros(4, np.int64)
+    offs[1:] = np.cumsum([len(p) for p in hdr])
+    g3, f3, err = np.full(3, -1, np.int64), np.zeros(3, np.uint8), C.c_int(0)
+    d = oracle.L.orc_open_packets(blob.ctypes.data, offs.ctypes.data, g3.ctypes.data, f3.ctypes.data, 3, C.byref(err))
+    assert d
+    st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+    try:
+        ch, b1 = st.channels, st.block1
+        ref = np.zeros(ch * b1, np.float32)
+        got = torch.zeros(ch * b1, dtype=torch.float32, device="cuda")
+        seen = 0
+        for i in range(3, len(pk)):
+            a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            rc = oracle.L.orc_decode_packet_block(d, pk[i], len(pk[i]), ref.ctypes.data, C.byref(a), C.byref(b), C.byref(c), C.byref(e))
+            geo = st.mode_decode(pk[i], got.data_ptr())
+            assert (rc == 1) == (geo is not None), i
+            if geo is None:
+                continue
+            seen += 1
+            n = e.value
+            g = got.cpu().numpy().reshape(ch, b1)[:, :n]
+            r = ref.reshape(ch, b1)[:, :n]
+            if name == "floor0_stereo":
+                assert float(np.abs(g.astype(np.float64) - r.astype(np.float64)).max()) <= 1e-6, i
+            else:
+                assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), (i, float(np.abs(g - r).max()))
+        assert seen > 10
+    finally:
+        st.close()
+        oracle.L.orc_close(d)
