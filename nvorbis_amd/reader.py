@@ -364,7 +364,7 @@ class StreamDecoder:
 class VorbisReader:
     """VorbisReader-shaped facade (VorbisReader.cs): first logical stream of an .ogg file or byte string."""
 
-    def __init__(self, source, ctx=None, device=0, batch_frames=4096, gpu_parse=True):
+    def __init__(self, source, ctx=None, device=0, batch_frames=8192, gpu_parse=True):
         # gpu_parse: parse the packets on the GPU too when the stream shape allows it (StreamDecoder falls back silently)
         if isinstance(source, (bytes, bytearray, memoryview)):
             data = bytes(source)
