@@ -36,6 +36,10 @@ namespace NVorbis.Hip
             fixed (byte* pi = id, pc = comment, ps = setup)
                 NativeMethods.Check(NativeMethods.nvh_stream_open(_ctx, pi, id.Length, pc, comment.Length, ps, setup.Length, out _stream));
             NativeMethods.Check(NativeMethods.nvh_stream_info(_stream, out _channels, out _sampleRate, out _block0, out _block1));
+            // Parse the packets on the GPU as well when the stream shape allows it (-7 = outside the GPU parser's limits:
+            // the host parser stays in charge).  Same PCM either way.
+            int rc = NativeMethods.nvh_stream_set_gpu_parse(_stream, 1);
+            if (rc != 0 && rc != -7) NativeMethods.Check(rc);
         }
 
         static byte[] ReadAll(IPacket packet)
