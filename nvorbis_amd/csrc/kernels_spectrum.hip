@@ -5,21 +5,28 @@
 //   inverse square-polar coupling         Mapping.cs:137-182
 //   IFloor.Apply                          Floor1.cs:186-341 (UnwrapPosts :224-297), Floor0.cs:152-212
 //
-// Output: work[frame][ch][0, n/2) = the vector IMdct.Reverse consumes (or, for a channel that does not
-// execute, the raw residue -- quirk B-4).  The IMDCT kernel (kernels_imdct.hip) picks it up from there.
+//   IMdct.Reverse (k_spectrum_imdct)       Mdct.cs:65-313, via imdct_wave.h
 //
-// The kernel moves ~2 KB of side information per frame and is bound by instruction issue, not by HBM: with
-// 7+ workgroups resident per CU the SIMDs' VALU ports are ~80 % busy (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES).
-// Its structure therefore aims at few instructions and a small LDS footprint (occupancy):
-//   * side information (ops, entries, codebook directory, lattice pool, stage ranges) is staged into LDS with
-//     16-byte copies; all index divisions are exact reciprocal multiplies prepared by the host;
+// Kernels: k_spectrum_imdct / k_spectrum (pair-path + fused-tail stream shapes: <= 2 channels, Floor1, lattice books;
+// with / without the inverse MDCT behind it), k_spectrum_gen (any other Floor1 shape), k_spectrum_f0 (Floor0).
+// Output: work[frame][ch] = the vector IMdct.Reverse consumes in [0, n/2) (or, for a channel that does not execute,
+// the raw residue -- quirk B-4); k_spectrum_imdct writes the compact IMDCT output k_ola_compact expects instead.
+//
+// The kernel moves ~2 KB of side information per frame and is bound by instruction issue and LDS / L2 latency, not
+// by HBM (DESIGN.md section 6 has the counters).  Its structure aims at few instructions, a small LDS footprint
+// (8 workgroups per CU) and short dependent chains:
+//   * side information (ops, op links, entries, codebook directory, lattice pool, pass records) is staged into LDS
+//     with 16-byte copies by two wavefronts while the other two unwrap the floor posts; all index divisions are
+//     exact reciprocal multiplies prepared by the host;
 //   * lattice codebooks (every book libvorbis writes) never touch their VQ table: a lane peels two base-
-//     lat_values digits off the entry number and adds two bins ("pair path");
-//   * for mono / stereo Floor1 streams coupling, floor render and the store to the work planes are one pass:
-//     a lane owns 4 consecutive bins of every channel in registers ("fused tail"); the floor posts are unwrapped
-//     by one wavefront per channel while the staging loads are in flight.
-// Bit-exactness: residue adds replay the reference's stage order (one barrier per stage); all float
-// expressions are single operations; -ffp-contract=off.
+//     lat_values digits off the entry number and adds two bins ("pair path"); in the fast kernels it walks the
+//     host-linked chain of ops of one partition through all cascade stages with the sums in registers;
+//   * for mono / stereo Floor1 streams coupling, floor render and the store are one pass: a lane owns 4 consecutive
+//     bins of every channel in registers ("fused tail");
+//   * k_spectrum_imdct then runs the wavefront IMDCT in place on the LDS spectrum, one wavefront per channel.
+// Bit-exactness: residue adds happen in the reference's stage order per element (general kernels: one barrier per
+// stage; chain walk: program order inside the owning lane); all float expressions are single operations;
+// -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
 #include "imdct_wave.h"
