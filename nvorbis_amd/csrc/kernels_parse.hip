@@ -190,7 +190,7 @@ extern "C" __global__ void __launch_bounds__(64)
 k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
-        NvhParseResult* __restrict__ result, int lanes) {
+        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words) {
   // hot Huffman tables into LDS (every lane of the wavefront helps, then lanes without a frame leave)
   extern __shared__ __attribute__((aligned(16))) uint32_t s_prefix[];
   uint32_t* s_meta = s_prefix + T.lds_words;  // books | floors | residues | mappings, as in the arena
@@ -204,6 +204,10 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
   const NvhPFloor1* floors = reinterpret_cast<const NvhPFloor1*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_floors_off);
   const NvhPResidue* residues = reinterpret_cast<const NvhPResidue*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_residues_off);
   const NvhPMapping* mappings = reinterpret_cast<const NvhPMapping*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_mappings_off);
+  // per-lane LDS (when the host found room): the residue walk's two scratch rows, and the packet itself -- the bit
+  // reader and the class words are on every symbol's dependency chain, and a global round trip costs ~10x an LDS one
+  int* s_lane = reinterpret_cast<int*>(s_meta + T.meta_words);          // [lanes][scratch_words]
+  uint32_t* s_pkt = reinterpret_cast<uint32_t*>(s_lane + lanes * scratch_words);  // [lanes][pkt_words]
   // `lanes` packets per wavefront (host: as few as keeps every workgroup resident at once): the 64 lanes of a wavefront diverge, so its instruction stream is the union
   // of its packets' paths -- fewer packets per wavefront means a shorter union, and the chip has SIMDs to spare
   // (a 4096-packet batch at 64 per wavefront would occupy 64 of 1024)
@@ -223,7 +227,14 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
   if (fr.n != 0) {
     const NvhPacketRef ref = refs[f];
     BitR p;
-    br_init(p, reinterpret_cast<const uint32_t*>(pkt_pool + ref.byte_off), ref.bit_len, ref.bit_pos);
+    const uint32_t* pw = reinterpret_cast<const uint32_t*>(pkt_pool + ref.byte_off);
+    const int pkt_nwords = (int)((ref.bit_len + 31u) >> 5);
+    if (pkt_words > 0 && pkt_nwords <= pkt_words) {
+      uint32_t* mine = s_pkt + (int)threadIdx.x * pkt_words;
+      for (int i = 0; i < pkt_nwords; i++) mine[i] = pw[i];  // independent loads: one latency for the lot
+      pw = mine;
+    }
+    br_init(p, pw, ref.bit_len, ref.bit_pos);
     const NvhPMapping& map = mappings[fr.mapping];
 
     // ---- floors (Mapping.cs:95-111) ----
@@ -277,7 +288,8 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
           break;
         }
         const int partition_words = (partition_count + cdim - 1) / cdim;
-        int* part_word = scratch + (long long)f * 2 * T.cap_parts;  // [channel][word]
+        int* part_word = scratch_words >= 2 * T.cap_parts ? s_lane + (int)threadIdx.x * scratch_words
+                                                          : scratch + (long long)f * 2 * T.cap_parts;  // [channel][word]
         int* last_op = part_word + T.cap_parts;                      // [partition][channel]
         const int pw_stride = partition_words > 0 ? partition_words : 1;
         for (int i = 0; i < r.channels * pw_stride; i++) part_word[i] = -1;

@@ -43,7 +43,7 @@ __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const f
                                     const float* TW);
 __global__ void k_parse(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
                         NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
-                        NvhParseResult* result, int lanes);
+                        NvhParseResult* result, int lanes, int scratch_words, int pkt_words);
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
                               uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
@@ -1119,10 +1119,26 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
     while (lanes > 8 && (nf + (size_t)(lanes / 2) - 1) / (size_t)(lanes / 2) <= 512) lanes /= 2;
     if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
     const unsigned pblocks = (unsigned)((nf + (size_t)lanes - 1) / (size_t)lanes);
-    hipLaunchKernelGGL(k_parse, dim3(pblocks), dim3(64), (size_t)(T.lds_words + T.meta_words) * sizeof(uint32_t), st, T, (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
+    // per-lane LDS next to the tables, while two workgroups still fit a CU (2 x 80 KB): the residue scratch rows first,
+    // then the packets (sized for the longest packet of the batch)
+    size_t max_pkt_words = 1;
+    for (size_t i = 0; i < nf; i++) max_pkt_words = std::max<size_t>(max_pkt_words, ((size_t)P.pkt_refs[i].bit_len + 31) / 32 + 1);
+    const size_t table_words = (size_t)(T.lds_words + T.meta_words);
+    const size_t lds_cap_words = 80 * 1024 / 4;
+    int scratch_words = 2 * T.cap_parts, pkt_words = (int)max_pkt_words;
+    if (table_words + (size_t)lanes * (size_t)(scratch_words + pkt_words) > lds_cap_words) pkt_words = 0;
+    if (table_words + (size_t)lanes * (size_t)scratch_words > lds_cap_words) scratch_words = 0;
+    const size_t parse_lds = (table_words + (size_t)lanes * (size_t)(scratch_words + pkt_words)) * sizeof(uint32_t);
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(k_parse, dim3(pblocks), dim3(64), parse_lds, st, T,
+                       (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
                        (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
-                       (NvhParseResult*)(base + o_rs), lanes);
+                       (NvhParseResult*)(base + o_rs), lanes, scratch_words, pkt_words);
     // the carried block's execute flags ping-pong together with the carried block (nvh_stream_synth flips carry_cur)
     uint32_t* ce = (uint32_t*)s->carry_exec.p;
     hipLaunchKernelGGL(k_parse_links, dim3(blocks), dim3(64), 0, st, (int)nf, ch, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch),
