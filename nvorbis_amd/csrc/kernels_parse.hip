@@ -25,8 +25,12 @@ namespace {
 constexpr int kErrRuntime = -3;      // NVH_ERR_RUNTIME: the managed code would have thrown
 constexpr int kErrUnsupported = -7;  // NVH_ERR_UNSUPPORTED
 
+// Address spaces are kept apart by hand everywhere in this file: a pointer that may point to LDS *or* global memory
+// compiles to FLAT loads, which cost a global-memory round trip even when they hit LDS and wait for every store in
+// flight -- that alone made a symbol cost ~2500 cycles.
 struct BitR {
-  const uint32_t* w;
+  const uint32_t* w;   // packet words in global memory ...
+  int lds_word;        // ... or (>= 0) their word offset inside the workgroup's LDS packet area
   uint32_t nwords, next;
   uint32_t total, pos;
   uint64_t buf;
@@ -34,15 +38,23 @@ struct BitR {
   bool is_short;
 };
 
-__device__ __forceinline__ void br_fill(BitR& b) {
+template <bool LDS>
+__device__ __forceinline__ void br_fill(BitR& b, const uint32_t* __restrict__ s_pkt) {
   while (b.avail <= 32 && b.next < b.nwords) {
-    b.buf |= (uint64_t)b.w[b.next++] << b.avail;
+    uint32_t word;
+    if (LDS) word = s_pkt[b.lds_word + (int)b.next];  // compile-time choice: never a generic pointer
+    else word = b.w[b.next];
+    b.next++;
+    b.buf |= (uint64_t)word << b.avail;
     b.avail += 32;
   }
 }
 
-__device__ __forceinline__ void br_init(BitR& b, const uint32_t* words, uint32_t total_bits, uint32_t start) {
+template <bool LDS>
+__device__ __forceinline__ void br_init(BitR& b, const uint32_t* words, int lds_word, const uint32_t* __restrict__ s_pkt,
+                                        uint32_t total_bits, uint32_t start) {
   b.w = words;
+  b.lds_word = lds_word;
   b.total = total_bits;
   b.nwords = (total_bits + 31u) >> 5;
   b.pos = start < total_bits ? start : total_bits;
@@ -50,12 +62,12 @@ __device__ __forceinline__ void br_init(BitR& b, const uint32_t* words, uint32_t
   b.next = b.pos >> 5;
   b.buf = 0;
   b.avail = 0;
-  br_fill(b);
+  br_fill<LDS>(b, s_pkt);
   const uint32_t s = b.pos & 31u;
   if (s) {
     b.buf >>= s;
     b.avail = b.avail >= s ? b.avail - s : 0;
-    br_fill(b);
+    br_fill<LDS>(b, s_pkt);
   }
 }
 
@@ -70,13 +82,14 @@ __device__ __forceinline__ uint32_t br_peek(const BitR& b, int count, int* got) 
 }
 
 // DataPacket.SkipBits (:247-280): past the end parks the cursor there and raises IsShort
-__device__ __forceinline__ void br_skip(BitR& b, int count) {
+template <bool LDS>
+__device__ __forceinline__ void br_skip(BitR& b, int count, const uint32_t* __restrict__ s_pkt) {
   if (count <= 0) return;
   if (b.total - b.pos >= (uint32_t)count) {
     b.buf >>= count;
     b.avail -= (uint32_t)count;
     b.pos += (uint32_t)count;
-    br_fill(b);
+    br_fill<LDS>(b, s_pkt);
   } else {
     b.pos = b.total;
     b.is_short = true;
@@ -86,23 +99,34 @@ __device__ __forceinline__ void br_skip(BitR& b, int count) {
   }
 }
 
-__device__ __forceinline__ uint32_t br_read(BitR& b, int count) {
+template <bool LDS>
+__device__ __forceinline__ uint32_t br_read(BitR& b, int count, const uint32_t* __restrict__ s_pkt) {
   if (count == 0) return 0;
   int got;
   const uint32_t v = br_peek(b, count, &got);
-  br_skip(b, count);
+  br_skip<LDS>(b, count, s_pkt);
   return v;
 }
 
+// Prefix-table entry of a book that did not make it into the LDS image.  Not inlined on purpose: next to the LDS read
+// of the same table the optimiser would fold both into one FLAT load through a selected pointer.
+__device__ __attribute__((noinline)) uint32_t prefix_from_global(const uint32_t* __restrict__ prefix, uint32_t index) {
+  return prefix[index];
+}
+
 // Codebook.DecodeScalar (Codebook.cs:294-320).  -1 = no symbol; -2 = the reference would fault (null list)
-__device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const NvhPBook& bk, BitR& p) {
+template <bool LDS>
+__device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const uint32_t* __restrict__ s_pkt,
+                                             const NvhPBook bk, BitR& p) {
   int got;
   uint32_t data = br_peek(p, bk.prefix_bits, &got);
   if (got == 0) return -1;
   if (!bk.has_tree) return -2;
-  const uint32_t node = bk.lds_off != 0xFFFFFFFFu ? s_prefix[bk.lds_off + data] : T.prefix[bk.prefix_off + data];
+  uint32_t node;
+  if (bk.lds_off != 0xFFFFFFFFu) node = s_prefix[bk.lds_off + data];  // ds_read
+  else node = prefix_from_global(T.prefix, bk.prefix_off + data);
   if (node & 0x80u) {
-    br_skip(p, (int)(node & 0x7Fu));
+    br_skip<LDS>(p, (int)(node & 0x7Fu), s_pkt);
     return (int)(node >> 8);
   }
   data = br_peek(p, bk.max_bits, &got);
@@ -119,7 +143,7 @@ __device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_
   for (uint32_t k = 0; k < cnt; ++k) {
     const NvhPOverflow o = ov[k];
     if (o.bits == (data & o.mask)) {
-      br_skip(p, (int)o.length);
+      br_skip<LDS>(p, (int)o.length, s_pkt);
       return (int)o.value;
     }
   }
@@ -127,14 +151,16 @@ __device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_
 }
 
 // Floor1.Unpack (Floor1.cs:135-184).  Writes the raw posts of one channel; returns 0 or an error code.
-__device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const NvhPBook* books,
+template <bool LDS>
+__device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const uint32_t* __restrict__ s_pkt,
+                                             const NvhPBook* books,
                                              const NvhPFloor1& f, BitR& p, uint16_t* __restrict__ posts,
                                              int* post_count_out) {
   int post_count = 0;
   int first_big = NVH_MAX_POSTS + 1;  // first post whose raw value does not fit 16 bits (documented limit)
-  if (br_read(p, 1) == 1) {
+  if (br_read<LDS>(p, 1, s_pkt) == 1) {
     post_count = 2;
-    const uint32_t y0 = br_read(p, f.y_bits), y1 = br_read(p, f.y_bits);
+    const uint32_t y0 = br_read<LDS>(p, f.y_bits, s_pkt), y1 = br_read<LDS>(p, f.y_bits, s_pkt);
     posts[0] = (uint16_t)y0;
     posts[1] = (uint16_t)y1;
     for (int i = 0; i < f.partition_count; i++) {
@@ -144,7 +170,7 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_
       const uint32_t csub = (1u << cbits) - 1u;
       uint32_t cval = 0;
       if (cbits > 0) {
-        const int r = decode_scalar(T, s_prefix, books[f.class_master[cls]], p);
+        const int r = decode_scalar<LDS>(T, s_prefix, s_pkt, books[f.class_master[cls]], p);
         if (r == -2) return kErrRuntime;
         cval = (uint32_t)r;
         if (cval == 0xFFFFFFFFu) {
@@ -158,7 +184,7 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_
         cval >>= cbits;
         if (book >= 0) {
           if (post_count >= NVH_MAX_POSTS) return kErrRuntime;  // Posts = new int[64]
-          const int r = decode_scalar(T, s_prefix, books[book], p);
+          const int r = decode_scalar<LDS>(T, s_prefix, s_pkt, books[book], p);
           if (r == -2) return kErrRuntime;
           if (r == -1) {
             post_count = 0;
@@ -186,18 +212,21 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_
 // One lane per frame of the batch.  Frames with n == 0 (drain pseudo-frames) have no packet.
 // Slab layout: frame f owns passes [f*cap_pass, +cap_pass), ops / op_link [f*cap_ops, +cap_ops), entries
 // [f*cap_ent, +cap_ent), posts [(f*channels + c) * NVH_MAX_POSTS, +NVH_MAX_POSTS), and two int scratch rows of cap_parts.
-extern "C" __global__ void __launch_bounds__(64)
-k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
+#define NVH_PARSE_MAX_WAVES 16  // wavefronts per k_parse workgroup (they share the LDS tables): blockDim.x / 64
+// LDS: the packets and the residue walk's scratch rows of this workgroup live in LDS (k_parse), else in global memory
+// (k_parse_g: batches with a packet too long for that).  A compile-time switch, so that no pointer is ever generic.
+template <bool LDS>
+__device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
         NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words) {
   // hot Huffman tables into LDS (every lane of the wavefront helps, then lanes without a frame leave)
   extern __shared__ __attribute__((aligned(16))) uint32_t s_prefix[];
   uint32_t* s_meta = s_prefix + T.lds_words;  // books | floors | residues | mappings, as in the arena
-  for (int i = threadIdx.x; i < T.lds_words; i += 64) s_prefix[i] = T.lds_image[i];
+  for (int i = threadIdx.x; i < T.lds_words; i += (int)blockDim.x) s_prefix[i] = T.lds_image[i];
   {
     const uint32_t* gm = reinterpret_cast<const uint32_t*>(T.books);
-    for (int i = threadIdx.x; i < T.meta_words; i += 64) s_meta[i] = gm[i];
+    for (int i = threadIdx.x; i < T.meta_words; i += (int)blockDim.x) s_meta[i] = gm[i];
   }
   __syncthreads();
   const NvhPBook* books = reinterpret_cast<const NvhPBook*>(s_meta);
@@ -206,13 +235,16 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
   const NvhPMapping* mappings = reinterpret_cast<const NvhPMapping*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_mappings_off);
   // per-lane LDS (when the host found room): the residue walk's two scratch rows, and the packet itself -- the bit
   // reader and the class words are on every symbol's dependency chain, and a global round trip costs ~10x an LDS one
-  int* s_lane = reinterpret_cast<int*>(s_meta + T.meta_words);          // [lanes][scratch_words]
-  uint32_t* s_pkt = reinterpret_cast<uint32_t*>(s_lane + lanes * scratch_words);  // [lanes][pkt_words]
-  // `lanes` packets per wavefront (host: as few as keeps every workgroup resident at once): the 64 lanes of a wavefront diverge, so its instruction stream is the union
-  // of its packets' paths -- fewer packets per wavefront means a shorter union, and the chip has SIMDs to spare
-  // (a 4096-packet batch at 64 per wavefront would occupy 64 of 1024)
-  if ((int)threadIdx.x >= lanes) return;
-  const int f = blockIdx.x * lanes + threadIdx.x;
+  int* s_lane = reinterpret_cast<int*>(s_meta + T.meta_words);          // [packets per workgroup][scratch_words]
+  uint32_t* s_pkt = reinterpret_cast<uint32_t*>(s_lane + (int)(blockDim.x >> 6) * lanes * scratch_words);  // [packets per workgroup][pkt_words]
+  // `lanes` packets per wavefront, blockDim.x / 64 wavefronts per workgroup.  Packets follow different paths through
+  // this code, so the lanes of a wavefront run mostly one after the other, and a lone wavefront issues an instruction
+  // every ~5 cycles at best: the host picks few packets per wavefront and ~2 wavefronts per SIMD for small batches
+  // (a 4096-packet batch at 64 per wavefront would sit on 64 of 1024 SIMDs) and fills wavefronts up for large ones.
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  if (lane >= lanes) return;
+  const int slot = wave * lanes + lane;  // packet of this workgroup
+  const int f = blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot;
   if (f >= nframes) return;
   NvhFrame fr = frames[f];
   const int nch = T.channels;
@@ -229,12 +261,12 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
     BitR p;
     const uint32_t* pw = reinterpret_cast<const uint32_t*>(pkt_pool + ref.byte_off);
     const int pkt_nwords = (int)((ref.bit_len + 31u) >> 5);
-    if (pkt_words > 0 && pkt_nwords <= pkt_words) {
-      uint32_t* mine = s_pkt + (int)threadIdx.x * pkt_words;
-      for (int i = 0; i < pkt_nwords; i++) mine[i] = pw[i];  // independent loads: one latency for the lot
-      pw = mine;
+    int lds_word = -1;
+    if (LDS) {
+      lds_word = slot * pkt_words;
+      for (int i = 0; i < pkt_nwords; i++) s_pkt[lds_word + i] = pw[i];  // independent loads: one latency for the lot
     }
-    br_init(p, pw, ref.bit_len, ref.bit_pos);
+    br_init<LDS>(p, pw, lds_word, s_pkt, ref.bit_len, ref.bit_pos);
     const NvhPMapping& map = mappings[fr.mapping];
 
     // ---- floors (Mapping.cs:95-111) ----
@@ -243,7 +275,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
       const int fl = map.chan_floor[c];
       int pc = 0;
       uint16_t* my_posts = posts + ((long long)f * nch + c) * NVH_MAX_POSTS;
-      err = decode_floor1(T, s_prefix, books, floors[fl], p, my_posts, &pc);
+      err = decode_floor1<LDS>(T, s_prefix, s_pkt, books, floors[fl], p, my_posts, &pc);
       NvhChan cn;
       cn.exec = 0;
       cn.floor = (uint8_t)fl;
@@ -269,7 +301,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
       if (!any_execute) continue;
       const int residue_idx = map.submap_residue[sm];
       const NvhPResidue& r = residues[residue_idx];
-      const NvhPBook& class_book = books[r.class_book];
+      const NvhPBook class_book = books[r.class_book];  // by value: registers, not an LDS reload per symbol
       NvhResPass pass;
       pass.residue = residue_idx;
       for (int s = 0; s <= NVH_MAX_STAGES; s++) pass.op_begin[s] = op_base + nops;
@@ -288,12 +320,15 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
           break;
         }
         const int partition_words = (partition_count + cdim - 1) / cdim;
-        int* part_word = scratch_words >= 2 * T.cap_parts ? s_lane + (int)threadIdx.x * scratch_words
-                                                          : scratch + (long long)f * 2 * T.cap_parts;  // [channel][word]
-        int* last_op = part_word + T.cap_parts;                      // [partition][channel]
+        // the two scratch rows of the walk: class word per [channel][word], last op per [partition][channel]
+        int* g_rows = scratch + (long long)f * 2 * T.cap_parts;
+        int* l_rows = s_lane + slot * scratch_words;
+        auto row_get = [&](int i) { return LDS ? l_rows[i] : g_rows[i]; };
+        auto row_set = [&](int i, int v) { if (LDS) l_rows[i] = v; else g_rows[i] = v; };
+        const int last_base = T.cap_parts;  // last_op row behind the part_word row
         const int pw_stride = partition_words > 0 ? partition_words : 1;
-        for (int i = 0; i < r.channels * pw_stride; i++) part_word[i] = -1;
-        for (int i = 0; i < r.channels * (partition_count > 0 ? partition_count : 1); i++) last_op[i] = -1;
+        for (int i = 0; i < r.channels * pw_stride; i++) row_set(i, -1);
+        for (int i = 0; i < r.channels * (partition_count > 0 ? partition_count : 1); i++) row_set(last_base + i, -1);
         const int buflen = T.block1;  // float[ch][block1Size] (StreamDecoder.cs:498-505)
         bool stop = false;
         for (; stage < r.max_stages && !stop && !err; stage++) {
@@ -301,13 +336,13 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
           for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count && !stop && !err; entry_idx++) {
             if (stage == 0) {
               for (int c = 0; c < r.channels; c++) {
-                const int idx = decode_scalar(T, s_prefix, class_book, p);
+                const int idx = decode_scalar<LDS>(T, s_prefix, s_pkt, class_book, p);
                 if (idx == -2) {
                   err = kErrRuntime;
                   break;
                 }
                 if (idx >= 0 && idx < r.partvals) {
-                  part_word[c * pw_stride + entry_idx] = idx;
+                  row_set(c * pw_stride + entry_idx, idx);
                 } else {
                   stop = true;
                   break;
@@ -319,7 +354,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
                  dimension_idx++, partition_idx++) {
               const int offset = r.begin + partition_idx * r.partition_size;
               for (int c = 0; c < r.channels; c++) {
-                const int word = part_word[c * pw_stride + entry_idx];
+                const int word = row_get(c * pw_stride + entry_idx);
                 if (word < 0) {
                   err = kErrRuntime;  // NullReferenceException on partWordCache
                   break;
@@ -328,7 +363,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
                 if ((r.cascade[cls] & (1 << stage)) == 0) continue;
                 const int book_idx = r.books[cls][stage];
                 if (book_idx < 0) continue;
-                const NvhPBook& book = books[book_idx];
+                const NvhPBook book = books[book_idx];  // by value (see class_book)
                 const int dims = book.dims;
                 if (dims == 0) {
                   err = kErrRuntime;
@@ -353,7 +388,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
                     break;
                   }
                   for (int i = 0; i < steps; i++) {
-                    const int e = decode_scalar(T, s_prefix, book, p);
+                    const int e = decode_scalar<LDS>(T, s_prefix, s_pkt, book, p);
                     if (e == -2) {
                       err = kErrRuntime;
                       break;
@@ -385,7 +420,7 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
                   }
                   int done = 0;
                   for (int i = 0; i < r.partition_size; i += dims) {
-                    const int e = decode_scalar(T, s_prefix, book, p);
+                    const int e = decode_scalar<LDS>(T, s_prefix, s_pkt, book, p);
                     if (e == -2) {
                       err = kErrRuntime;
                       break;
@@ -419,13 +454,14 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
                   ops[op_base + rel] = op;
                   uint16_t lk = (uint16_t)NVH_LINK_NONE;
                   if (rel >= (uint32_t)NVH_LINK_NONE) links_ok = false;
-                  int* last = &last_op[partition_idx * r.channels + c];
-                  if (*last >= 0 && rel < (uint32_t)NVH_LINK_NONE) {
-                    op_link[op_base + (uint32_t)*last] = (uint16_t)((op_link[op_base + (uint32_t)*last] & 0x8000u) | (uint16_t)rel);
+                  const int last_i = last_base + partition_idx * r.channels + c;
+                  const int last = row_get(last_i);
+                  if (last >= 0 && rel < (uint32_t)NVH_LINK_NONE) {
+                    op_link[op_base + (uint32_t)last] = (uint16_t)((op_link[op_base + (uint32_t)last] & 0x8000u) | (uint16_t)rel);
                     lk |= 0x8000u;
                   }
                   op_link[op_base + rel] = lk;
-                  *last = (int)rel;
+                  row_set(last_i, (int)rel);
                   ++nops;
                 }
                 if (bad) {
@@ -468,6 +504,24 @@ k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef*
     const int prev = atomicMin(&result->err_frame, f);
     if (f < prev) result->err_code = err;  // benign race between several failing frames: the host re-checks the minimum
   }
+}
+
+extern "C" __global__ void __launch_bounds__(64 * NVH_PARSE_MAX_WAVES)
+k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
+        NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
+        uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
+        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words) {
+  parse_body<true>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,
+                   scratch_words, pkt_words);
+}
+
+extern "C" __global__ void __launch_bounds__(64 * NVH_PARSE_MAX_WAVES)
+k_parse_g(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
+          NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
+          uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
+          NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words) {
+  parse_body<false>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,
+                    scratch_words, pkt_words);
 }
 
 // Second pass: what a frame needs from its overlap source (known only after every lane has parsed its packet):

@@ -44,6 +44,9 @@ __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const f
 __global__ void k_parse(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
                         NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
                         NvhParseResult* result, int lanes, int scratch_words, int pkt_words);
+__global__ void k_parse_g(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
+                          NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
+                          NvhParseResult* result, int lanes, int scratch_words, int pkt_words);
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
                               uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
@@ -1112,13 +1115,17 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   b->dev.pad = 0;
   if (nf) {
     const unsigned blocks = (unsigned)((nf + 63) / 64);
-    // packets per wavefront: as few as keeps all workgroups resident at once (2 per CU with ~58 KB of LDS each); a
-    // wavefront's instruction stream is the union of its packets' paths, so fewer packets per wavefront run faster
+    // Launch shape.  Packets take different paths through the parser, so the lanes of a wavefront mostly run one after
+    // the other, and one wavefront alone issues an instruction every ~5 cycles at best: aim at ~2 wavefronts per SIMD
+    // (2048 in all) with as few packets each as that allows; workgroups of 4 wavefronts, two per CU (LDS tables).
     static const int lanes_env = getenv("NVH_PARSE_LANES") ? atoi(getenv("NVH_PARSE_LANES")) : 0;
-    int lanes = 64;
-    while (lanes > 8 && (nf + (size_t)(lanes / 2) - 1) / (size_t)(lanes / 2) <= 512) lanes /= 2;
+    static const int waves_env = getenv("NVH_PARSE_WAVES") ? atoi(getenv("NVH_PARSE_WAVES")) : 0;
+    const int kParseWaves = (waves_env >= 1 && waves_env <= 16) ? waves_env : 4;
+    int lanes = 1;
+    while (lanes < 64 && (nf + (size_t)lanes - 1) / (size_t)lanes > 2048) lanes *= 2;
     if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
-    const unsigned pblocks = (unsigned)((nf + (size_t)lanes - 1) / (size_t)lanes);
+    const size_t per_wg = (size_t)kParseWaves * (size_t)lanes;
+    const unsigned pblocks = (unsigned)((nf + per_wg - 1) / per_wg);
     // per-lane LDS next to the tables, while two workgroups still fit a CU (2 x 80 KB): the residue scratch rows first,
     // then the packets (sized for the longest packet of the batch)
     size_t max_pkt_words = 1;
@@ -1126,15 +1133,18 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
     const size_t table_words = (size_t)(T.lds_words + T.meta_words);
     const size_t lds_cap_words = 80 * 1024 / 4;
     int scratch_words = 2 * T.cap_parts, pkt_words = (int)max_pkt_words;
-    if (table_words + (size_t)lanes * (size_t)(scratch_words + pkt_words) > lds_cap_words) pkt_words = 0;
-    if (table_words + (size_t)lanes * (size_t)scratch_words > lds_cap_words) scratch_words = 0;
-    const size_t parse_lds = (table_words + (size_t)lanes * (size_t)(scratch_words + pkt_words)) * sizeof(uint32_t);
+    // LDS variant only when both the rows and the longest packet of the batch fit for every lane; else everything per-lane
+    // stays in global memory (k_parse_g)
+    const bool in_lds = table_words + per_wg * (size_t)(scratch_words + pkt_words) <= lds_cap_words;
+    if (!in_lds) scratch_words = pkt_words = 0;
+    const size_t parse_lds = (table_words + per_wg * (size_t)(scratch_words + pkt_words)) * sizeof(uint32_t);
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_g, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       lds_attr_set = true;
     }
-    hipLaunchKernelGGL(k_parse, dim3(pblocks), dim3(64), parse_lds, st, T,
+    hipLaunchKernelGGL(in_lds ? k_parse : k_parse_g, dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
                        (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
                        (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
