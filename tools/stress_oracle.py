@@ -1,0 +1,30 @@
+"""Stress: GPU path (host parser and GPU parser alternating) vs the CPU oracle on many random synthetic streams, random batch
+sizes, clip on/off, consistent and inconsistent window flags; PCM must be identical bit for bit (Floor0: 1e-6)."""
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+import nvorbis_amd as nv
+from tests import synth_stream as ss, oracle_py
+from tests.test_gpu_parse import _decode
+orc = oracle_py.load()
+ctx = nv.Context(0)
+rng = np.random.default_rng(77)
+names = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096", "two_submaps",
+         "equal_blocks_overrun", "mono_8192", "floor0_stereo"]
+t0 = time.time(); n = 0; pkts = 0
+seeds = int(os.environ.get("SEEDS", "10"))
+for name in names:
+    for seed in range(500, 500 + seeds):
+        pk, gr, fl = ss.filtered_stream(orc, name, int(rng.integers(10, 90)), seed, bool(seed & 1))
+        clip = bool(seed & 2)
+        ref, _ = orc.decode_packets(pk, gr, fl, clip=clip)
+        bf = int(rng.choice([1, 2, 5, 13, 64, 1000]))
+        gp = bool(seed & 4) and name != "floor0_stereo"
+        got = _decode(nv, ctx, pk, gr, fl, gp, bf, clip)
+        assert got.size == ref.size, (name, seed)
+        if name == "floor0_stereo":
+            assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) <= 1e-6, (name, seed)
+        else:
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, seed, bf, gp)
+        n += 1; pkts += len(pk) - 3
+print("GPU == oracle on %d random streams (%d packets), %.0f s" % (n, pkts, time.time() - t0))
