@@ -44,6 +44,9 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern unsafe int nvh_mode_decode(IntPtr stream, byte* packet, int len, IntPtr dBlock, out int decoded, out int blockSize, out int start, out int valid, out int total);
         /// <summary>One inverse coupling step (Mapping.cs:150-178) over two device vectors.</summary>
         [DllImport(Lib)] public static extern int nvh_inverse_couple(IntPtr ctx, IntPtr dMagnitude, IntPtr dAngle, int count);
+        /// <summary>IFloor.Apply for a Floor1 (Floor1.cs:186-341) on a batch of device vectors; posts is [batch][64] raw Unpack values.</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_floor1_apply(IntPtr stream, int floorIndex, int blockSize, int batch, int* posts, int* postCounts, IntPtr dResidue, long stride, int* status);
+        [DllImport(Lib)] public static extern int nvh_stream_floor_info(IntPtr stream, int floorIndex, out int type, out int postCount, out int range);
         [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);
         [DllImport(Lib)] public static extern unsafe int nvh_stream_synth(IntPtr stream, float* pcmHost, IntPtr dPcm, long capacity, out long written);
 

@@ -65,6 +65,19 @@ int nvh_ctx_synchronize(nvh_ctx *ctx);
 /* One inverse square-polar coupling step over two device vectors of `count` floats, in place (Mapping.cs:150-178). */
 int nvh_inverse_couple(nvh_ctx *c, float *d_magnitude, float *d_angle, int count);
 
+/* IFloor.Apply(IFloorData, int blockSize, float[] residue) for a Floor1 (Contracts/IFloor.cs, Floor1.cs:186-341:
+ * UnwrapPosts, the walk over the sorted posts, RenderLineMulti) of stream `s`, on `batch` device vectors:
+ * item b multiplies d_residue[b*stride .. +block_size/2) by the curve its posts describe, or clears it when
+ * post_counts[b] == 0 (:218-221).  posts: host, [batch][64] raw values as Floor1.Unpack leaves them in
+ * Data.Posts (:135-184), each 0..65535; post_counts[b] is 0 or the floor's post count (nvh_stream_floor_info).
+ * status (host, [batch], may be NULL): NVH_OK, or NVH_ERR_RUNTIME where the reference would index
+ * inverse_dB_table out of range (the item's vector is then unspecified, as after the managed exception);
+ * with status == NULL the first such code is the return value.  Synchronous. */
+int nvh_floor1_apply(nvh_stream *s, int floor_index, int block_size, int batch, const int32_t *posts,
+                     const int32_t *post_counts, float *d_residue, int64_t stride, int32_t *status);
+/* type (0/1), number of posts (Floor1: _xList.Length, Floor1.cs:93-107) and _range (:76) of floor `floor_index`. */
+int nvh_stream_floor_info(const nvh_stream *s, int floor_index, int *type, int *post_count, int *range);
+
 /* IMdct.Reverse(float[] samples, int sampleCount) (Contracts/IMdct.cs:5, Mdct.cs:13-21) on `batch`
  * buffers: buffer b = d_buf + b*stride holds n floats, reads [0,n/2), writes [0,n).  n = 64..8192. */
 int nvh_mdct_reverse(nvh_ctx *ctx, int n, int batch, float *d_buf, int64_t stride);

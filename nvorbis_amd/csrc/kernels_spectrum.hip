@@ -911,3 +911,53 @@ k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __re
   extern __shared__ __attribute__((aligned(16))) float smem[];
   spectrum_body<true, false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem);
 }
+
+// IFloor.Apply for Floor1 (Floor1.cs:186-222) as an operator on its own: one wavefront per item unwraps the raw
+// posts an Unpack call produced and multiplies the item's n/2 residue values by the curve (or clears them when
+// the floor carried no energy, :218-221).  Same device functions as the fused tail of the spectrum kernels.
+// status[item] receives the NVH_DEVERR_* bits of that item alone.
+extern "C" __global__ void __launch_bounds__(64)
+k_floor1_apply(NvhDevSetup S, int floor_idx, const uint16_t* __restrict__ posts, const int32_t* __restrict__ counts, int n,
+               float* __restrict__ data, long long stride, int* __restrict__ status) {
+  __shared__ FloorScratch Q;
+  __shared__ float s_db[256];
+  const int item = (int)blockIdx.x, lane = (int)threadIdx.x, half = n >> 1;
+  for (int i = lane; i < 256; i += 64) s_db[i] = k_inverse_db[i];
+  const NvhDevFloor1* F = &S.floors[floor_idx].f1;
+  FloorLane L;
+  L.pc = counts[item];
+  L.mode = L.pc > 0 ? 1 : 2;
+  L.levels = F->levels;
+  L.range = F->range;
+  L.mult = F->multiplier;
+  L.level = 0; L.lo = 0; L.hi = 1; L.x = 0; L.x_lo = 0; L.x_hi = 1; L.val = 0; L.sorted = 0; L.x_sorted = 0; L.adx_magic = 0;
+  if (lane < L.pc) {
+    L.lo = F->l_neigh[lane];
+    L.hi = F->h_neigh[lane];
+    L.level = F->level[lane];
+    L.x = F->x_list[lane];
+    L.val = posts[(long long)item * NVH_MAX_POSTS + lane];
+    L.sorted = F->sort_idx[lane];
+    L.x_lo = F->x_lo[lane];
+    L.x_hi = F->x_hi[lane];
+    L.x_sorted = F->x_sorted[lane];
+    L.adx_magic = F->adx_magic[lane];
+  }
+  floor_prepare(&Q, L, lane, half, status + item);
+  __syncthreads();
+  float* res = data + (long long)item * stride;
+  if (L.mode == 2) {
+    for (int i = lane; i < half; i += 64) res[i] = 0.0f;
+    return;
+  }
+  for (int x0 = lane * 4; x0 < half; x0 += 64 * 4) {
+    float m[4];
+    floor_walk<4>(&Q, s_db, x0, m);
+    float4 v = *reinterpret_cast<float4*>(res + x0);
+    v.x = v.x * m[0];
+    v.y = v.y * m[1];
+    v.z = v.z * m[2];
+    v.w = v.w * m[3];
+    *reinterpret_cast<float4*>(res + x0) = v;
+  }
+}

@@ -50,6 +50,8 @@ __global__ void k_parse_g(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacke
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
                               uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
+__global__ void k_floor1_apply(NvhDevSetup S, int floor_idx, const uint16_t* posts, const int32_t* counts, int n, float* data,
+                               long long stride, int* status);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
 __global__ void k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
@@ -1410,6 +1412,64 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
     for (auto& e : ev) (void)hipEventDestroy(e);
   }
   return NVH_OK;
+}
+
+// IFloor.Apply for the stream's floor `floor_index` on `batch` device vectors (see include/nvorbis_hip.h).
+extern "C" int nvh_stream_floor_info(const nvh_stream* s, int floor_index, int* type, int* post_count, int* range) {
+  if (!s || floor_index < 0 || floor_index >= (int)s->setup.floors.size()) return NVH_ERR_ARGUMENT;
+  const nvh::Floor& f = s->setup.floors[(size_t)floor_index];
+  if (type) *type = f.type;
+  if (post_count) *post_count = f.type == 1 ? (int)f.f1.x_list.size() : 0;
+  if (range) *range = f.type == 1 ? f.f1.range : 0;
+  return NVH_OK;
+}
+
+extern "C" int nvh_floor1_apply(nvh_stream* s, int floor_index, int block_size, int batch, const int32_t* posts,
+                                const int32_t* post_counts, float* d_residue, int64_t stride, int32_t* status) {
+  if (!s || batch < 0 || (batch > 0 && (!posts || !post_counts || !d_residue))) return NVH_ERR_ARGUMENT;
+  if (floor_index < 0 || floor_index >= (int)s->setup.floors.size()) return NVH_ERR_ARGUMENT;
+  const nvh::Floor& f = s->setup.floors[(size_t)floor_index];
+  if (f.type != 1) return NVH_ERR_ARGUMENT;
+  if (block_size != s->setup.block0 && block_size != s->setup.block1) return NVH_ERR_ARGUMENT;
+  if (stride < block_size / 2) return NVH_ERR_ARGUMENT;
+  if (!s->ctx) return NVH_ERR_NO_GPU;
+  if (batch == 0) return NVH_OK;
+  const int pc = (int)f.f1.x_list.size();
+  // Unpack leaves either no posts or all of them (Floor1.cs:135-184); the values are sums of codebook entries
+  std::vector<uint16_t> h_posts((size_t)batch * NVH_MAX_POSTS, 0);
+  for (int b = 0; b < batch; ++b) {
+    if (post_counts[b] != 0 && post_counts[b] != pc) return NVH_ERR_ARGUMENT;
+    for (int i = 0; i < post_counts[b]; ++i) {
+      const int32_t v = posts[(size_t)b * NVH_MAX_POSTS + i];
+      if (v < 0 || v > 0xFFFF) return NVH_ERR_ARGUMENT;
+      h_posts[(size_t)b * NVH_MAX_POSTS + i] = (uint16_t)v;
+    }
+  }
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  hipStream_t st = s->ctx->stream;
+  DevBuf d_posts, d_counts, d_status;
+  d_posts.pool = d_counts.pool = d_status.pool = &s->ctx->pool;
+  int rc;
+  if ((rc = d_posts.reserve(h_posts.size() * sizeof(uint16_t))) != NVH_OK) return rc;
+  if ((rc = d_counts.reserve((size_t)batch * sizeof(int32_t))) != NVH_OK) return rc;
+  if ((rc = d_status.reserve((size_t)batch * sizeof(int32_t))) != NVH_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(d_posts.p, h_posts.data(), h_posts.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_counts.p, post_counts, (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_status.p, 0, (size_t)batch * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_floor1_apply, dim3((unsigned)batch), dim3(64), 0, st, s->dev, floor_index, (const uint16_t*)d_posts.p,
+                     (const int32_t*)d_counts.p, block_size, d_residue, (long long)stride, (int*)d_status.p);
+  HIP_TRY(hipGetLastError());
+  std::vector<int32_t> h_status((size_t)batch, 0);
+  HIP_TRY(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  int any = NVH_OK;
+  for (int b = 0; b < batch; ++b) {
+    // inverse_dB_table index out of range: IndexOutOfRangeException in the reference (quirk B-7)
+    const int code = h_status[(size_t)b] ? NVH_ERR_RUNTIME : NVH_OK;
+    if (status) status[b] = code;
+    if (code != NVH_OK && any == NVH_OK) any = code;
+  }
+  return status ? NVH_OK : any;
 }
 
 // Reads and clears the device error / clipped words; maps device errors to status codes.

@@ -45,6 +45,8 @@ SIGNATURES = {
     "nvh_mdct_reverse": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int64]),
     "nvh_inverse_couple": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "nvh_mode_decode": (C.c_int, [_vp, _vp, C.c_int, _vp] + [C.POINTER(C.c_int)] * 5),
+    "nvh_floor1_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int64, _vp]),
+    "nvh_stream_floor_info": (C.c_int, [_vp, C.c_int] + [C.POINTER(C.c_int)] * 3),
     "nvh_mdct_tables": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),
     "nvh_calc_window": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp]),
     "nvh_calc_overlap": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]),

@@ -194,6 +194,26 @@ class Stream:
                                     C.byref(b), C.byref(c)), "nvh_mode_decode")
         return (bs.value, a.value, b.value, c.value) if dec.value else None
 
+    def floor_info(self, floor_index):
+        """(type, post count, range) of one of the stream's floors."""
+        t, pc, rg = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().nvh_stream_floor_info(self._h, int(floor_index), C.byref(t), C.byref(pc), C.byref(rg)), "nvh_stream_floor_info")
+        return t.value, pc.value, rg.value
+
+    def floor1_apply(self, floor_index, block_size, posts, post_counts, d_residue, stride):
+        """IFloor.Apply (Floor1.cs:186-341) on a batch of device vectors: posts [batch][64] raw Unpack values, post_counts
+        [batch] (0 or the floor's post count), d_residue a device pointer to [batch][stride] floats of which the first
+        block_size/2 of each row are scaled (or cleared).  Returns the per-item status array."""
+        posts = np.ascontiguousarray(posts, dtype=np.int32)
+        post_counts = np.ascontiguousarray(post_counts, dtype=np.int32)
+        batch = post_counts.shape[0]
+        if posts.shape != (batch, 64):
+            raise ValueError("posts must be [batch][64]")
+        status = np.zeros(batch, np.int32)
+        check(lib().nvh_floor1_apply(self._h, int(floor_index), int(block_size), batch, posts.ctypes.data, post_counts.ctypes.data,
+                                     C.c_void_p(d_residue), int(stride), status.ctypes.data), "nvh_floor1_apply")
+        return status
+
     def set_gpu_parse(self, on):
         """Parse packets on the GPU (kernels_parse.hip); raises NvhError(UNSUPPORTED) for ineligible stream shapes."""
         check(lib().nvh_stream_set_gpu_parse(self._h, 1 if on else 0), "nvh_stream_set_gpu_parse")

@@ -118,6 +118,14 @@ const orc_frame_trace *orc_trace_data(const orc_decoder *d);
 int orc_decode_packet_block(orc_decoder *d, const uint8_t *pkt, int len, float *planes /* ch*block1 */,
                             int *start, int *valid, int *total, int *block_size);
 
+/* IFloor.Apply (Floor1.cs:186-222) of the stream's floor `floor_index` on raw posts as Floor1.Unpack leaves them:
+ * residue holds block_size/2 values (of a block1-long buffer in the reference; reslen says how long).
+ * Returns 0, or ORC_ERR_RUNTIME where the reference would throw (residue is then partly modified). */
+int orc_floor1_apply_posts(orc_decoder *d, int floor_index, int block_size, const int *posts, int post_count,
+                           float *residue, int reslen);
+/* type, post count (_xList.Length) and _range of floor `floor_index`; returns the number of floors. */
+int orc_floor_info(const orc_decoder *d, int floor_index, int *type, int *post_count, int *range);
+
 #ifdef __cplusplus
 }
 #endif

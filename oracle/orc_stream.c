@@ -414,3 +414,28 @@ int orc_decode_packet_block(orc_decoder *d, const uint8_t *pkt, int len, float *
   free_planes(tmp, d->channels);
   return rc;
 }
+
+/* Operator-level entry points for the parity tests. */
+int orc_floor1_apply_posts(orc_decoder *d, int floor_index, int block_size, const int *posts, int post_count,
+                           float *residue, int reslen) {
+  orc_floor_data data;
+  int i;
+  if (!d || floor_index < 0 || floor_index >= d->nfloors || d->floors[floor_index].type != 1) return ORC_ERR_ARGUMENT;
+  if (post_count < 0 || post_count > 256) return ORC_ERR_ARGUMENT;
+  memset(&data, 0, sizeof data);
+  data.type = 1;
+  data.post_count = post_count;
+  for (i = 0; i < post_count; i++) data.posts[i] = posts[i];
+  return orc_floor_apply(&d->floors[floor_index], &data, block_size, residue, reslen);
+}
+
+int orc_floor_info(const orc_decoder *d, int floor_index, int *type, int *post_count, int *range) {
+  if (!d) return 0;
+  if (floor_index >= 0 && floor_index < d->nfloors) {
+    const orc_floor *f = &d->floors[floor_index];
+    if (type) *type = f->type;
+    if (post_count) *post_count = f->type == 1 ? f->f1.x_count : 0;
+    if (range) *range = f->type == 1 ? f->f1.range : 0;
+  }
+  return d->nfloors;
+}

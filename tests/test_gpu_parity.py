@@ -354,3 +354,87 @@ def test_mode_decode_synthetic_shapes(oracle, gpu_ctx, name):
     finally:
         st.close()
         oracle.L.orc_close(d)
+
+
+def _open_headers(oracle, pk):
+    import ctypes as C
+    hdr = pk[:3]
+    blob = np.frombuffer(b"".join(hdr), dtype=np.uint8)
+    offs = np.zeros(4, np.int64)
+    offs[1:] = np.cumsum([len(p) for p in hdr])
+    g3, f3, err = np.full(3, -1, np.int64), np.zeros(3, np.uint8), C.c_int(0)
+    d = oracle.L.orc_open_packets(blob.ctypes.data, offs.ctypes.data, g3.ctypes.data, f3.ctypes.data, 3, C.byref(err))
+    assert d
+    return d
+
+
+def _floor1_apply_case(oracle, gpu_ctx, pk, seed):
+    """IFloor.Apply on random posts for every Floor1 of a setup, both block sizes; returns (ok items, refused items)."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    torch = _torch()
+    rng = np.random.default_rng(seed)
+    d = _open_headers(oracle, pk)
+    st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+    n_ok = n_err = 0
+    try:
+        nfloors = oracle.L.orc_floor_info(d, 0, None, None, None)
+        for fi in range(nfloors):
+            t, pc, rg = st.floor_info(fi)
+            ot, opc, org = C.c_int(), C.c_int(), C.c_int()
+            oracle.L.orc_floor_info(d, fi, C.byref(ot), C.byref(opc), C.byref(org))
+            assert (t, pc, rg) == (ot.value, opc.value, org.value)
+            if t != 1:
+                continue
+            for n in sorted({st.block0, st.block1}):
+                half, batch = n // 2, 96
+                posts = np.zeros((batch, 64), np.int32)
+                counts = np.full(batch, pc, np.int32)
+                for b in range(batch):
+                    kind = b % 4
+                    if kind == 3 and b % 8 == 3:
+                        counts[b] = 0  # floor without energy: Apply clears the vector
+                        continue
+                    hi = rg if kind < 2 else (rg * 3) // 2  # kind 2/3: values past the dB table's range now and then
+                    posts[b, :2] = rng.integers(0, hi, 2)
+                    v = rng.integers(0, rg if kind != 3 else 2 * rg, pc)
+                    v[rng.random(pc) < (0.5 if kind != 1 else 0.1)] = 0  # unused posts
+                    posts[b, 2:pc] = v[2:]
+                res = rng.standard_normal((batch, half)).astype(np.float32)
+                got = torch.from_numpy(res.copy()).cuda()
+                status = st.floor1_apply(fi, n, posts, counts, got.data_ptr(), half)
+                got = got.cpu().numpy()
+                for b in range(batch):
+                    ref = np.zeros(st.block1, np.float32)
+                    ref[:half] = res[b]
+                    p = np.ascontiguousarray(posts[b])
+                    rc = oracle.L.orc_floor1_apply_posts(d, fi, n, p.ctypes.data, int(counts[b]), ref.ctypes.data, st.block1)
+                    assert (rc == 0) == (status[b] == 0), (fi, n, b, rc, status[b])
+                    if rc == 0:
+                        n_ok += 1
+                        assert np.array_equal(got[b].view(np.uint32), ref[:half].view(np.uint32)), (fi, n, b)
+                    else:
+                        n_err += 1
+    finally:
+        st.close()
+        oracle.L.orc_close(d)
+    return n_ok, n_err
+
+
+@pytest.mark.parametrize("name", ["2test", "3test"])
+def test_floor1_apply_operator_files(oracle, gpu_ctx, ogg_bytes, name):
+    """Fine-grained ABI: IFloor.Apply (Floor1.cs:186-341) with the shipped files' floors on random posts == the oracle's
+    floor1_apply, item by item; items whose curve leaves inverse_dB_table (quirk B-7) are refused by both."""
+    import nvorbis_amd as nv
+    pk, _, _ = nv.demux_ogg(ogg_bytes[name])
+    n_ok, n_err = _floor1_apply_case(oracle, gpu_ctx, pk, 5)
+    assert n_ok > 100
+
+
+@pytest.mark.parametrize("name", ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "mono_8192"])
+def test_floor1_apply_operator_synthetic(oracle, gpu_ctx, name):
+    """The same for synthetic setups: random post X lists, multipliers 1..4, blocks 64..8192."""
+    from tests import synth_stream as ss
+    pk, _, _ = ss.filtered_stream(oracle, name, 4, 21)
+    n_ok, n_err = _floor1_apply_case(oracle, gpu_ctx, pk, 9)
+    assert n_ok > 50

@@ -172,3 +172,41 @@ def test_db_table_copies_agree(oracle):
     closed = np.exp((np.arange(256) - 255) * 0.546875 * 0.11512925)
     assert np.abs(vals / closed - 1).max() < 1e-7
     assert vals[255] == 1.0
+
+
+@pytest.mark.parametrize("name", ["2test", "3test"])
+def test_floor1_apply_flat_curve_and_empty(oracle, ogg_bytes, name):
+    """Floor1.Apply in closed form (Floor1.cs:186-222): equal end posts and no used inner posts give one flat line and
+    the trailing flat run, i.e. every bin times inverse_dB_table[y * multiplier]; a floor without posts clears."""
+    import ctypes as C
+    data = ogg_bytes[name]
+    err = C.c_int(0)
+    d = oracle.L.orc_open_ogg(data, len(data), C.byref(err))
+    assert d
+    try:
+        b0, b1 = oracle.L.orc_block0(d), oracle.L.orc_block1(d)
+        nfloors = oracle.L.orc_floor_info(d, 0, None, None, None)
+        assert nfloors >= 1
+        rng = np.random.default_rng(2)
+        for fi in range(nfloors):
+            t, pc, rg = C.c_int(), C.c_int(), C.c_int()
+            oracle.L.orc_floor_info(d, fi, C.byref(t), C.byref(pc), C.byref(rg))
+            assert t.value == 1 and 2 <= pc.value <= 64
+            mult = {256: 1, 128: 2, 86: 3, 64: 4}[rg.value]  # Floor1.cs:74-76
+            for n in (b0, b1):
+                for y in (0, 1, rg.value // 2, rg.value - 1):
+                    if y * mult > 255:
+                        continue
+                    posts = np.zeros(64, np.int32)
+                    posts[:2] = y
+                    x = rng.standard_normal(b1).astype(np.float32)
+                    v = x.copy()
+                    assert oracle.L.orc_floor1_apply_posts(d, fi, n, posts.ctypes.data, pc.value, v.ctypes.data, b1) == 0
+                    want = x[:n // 2] * np.float32(oracle.L.orc_inverse_db(y * mult))
+                    assert np.array_equal(v[:n // 2], want)
+                    assert np.array_equal(v[n // 2:], x[n // 2:])
+                v = rng.standard_normal(b1).astype(np.float32)
+                assert oracle.L.orc_floor1_apply_posts(d, fi, n, None, 0, v.ctypes.data, b1) == 0
+                assert not v[:n // 2].any()
+    finally:
+        oracle.L.orc_close(d)
