@@ -46,6 +46,17 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern int nvh_inverse_couple(IntPtr ctx, IntPtr dMagnitude, IntPtr dAngle, int count);
         /// <summary>IFloor.Apply for a Floor1 (Floor1.cs:186-341) on a batch of device vectors; posts is [batch][64] raw Unpack values.</summary>
         [DllImport(Lib)] public static extern unsafe int nvh_floor1_apply(IntPtr stream, int floorIndex, int blockSize, int batch, int* posts, int* postCounts, IntPtr dResidue, long stride, int* status);
+        /// <summary>IFloor.Apply for a Floor0 (Floor0.cs:152-212) from Data.Amp / Data.Coeff, batched.</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_floor0_apply(IntPtr stream, int floorIndex, int blockSize, int batch, float* amps, float* coeffs, int coeffStride, IntPtr dResidue, long stride, int* status);
+        /// <summary>IResidue.Decode (Residue0.cs:119-201) from a packet cursor into device planes [channels][block1].</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_residue_decode(IntPtr stream, int residueIndex, byte* packet, int len, int bitOffset, int anyChannelDecodes, int blockSize, IntPtr dBuffer, out int bitsConsumed);
+        /// <summary>Mode.Decode's window loop (Mode.cs:160-166).</summary>
+        [DllImport(Lib)] public static extern int nvh_window_apply(IntPtr stream, int modeIndex, int prevFlag, int nextFlag, int batch, IntPtr dBuf, long stride);
+        /// <summary>StreamDecoder.OverlapBuffers (StreamDecoder.cs:532-541).</summary>
+        [DllImport(Lib)] public static extern int nvh_overlap_buffers(IntPtr ctx, IntPtr dPrevious, IntPtr dNext, int prevStart, int prevStop, int nextStart, int channels, long planeStride);
+        /// <summary>ClippingCopyBuffer / CopyBuffer (StreamDecoder.cs:391-415).</summary>
+        [DllImport(Lib)] public static extern int nvh_copy_buffer(IntPtr ctx, IntPtr dPlanes, int start, int count, int channels, long planeStride, IntPtr dTarget, int clip, out int clipped);
+        [DllImport(Lib)] public static extern int nvh_stream_mode_info(IntPtr stream, int modeIndex, out int blockFlag, out int blockSize, out int mapping);
         [DllImport(Lib)] public static extern int nvh_stream_floor_info(IntPtr stream, int floorIndex, out int type, out int postCount, out int range);
         [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);
         [DllImport(Lib)] public static extern unsafe int nvh_stream_synth(IntPtr stream, float* pcmHost, IntPtr dPcm, long capacity, out long written);

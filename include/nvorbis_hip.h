@@ -75,8 +75,42 @@ int nvh_inverse_couple(nvh_ctx *c, float *d_magnitude, float *d_angle, int count
  * with status == NULL the first such code is the return value.  Synchronous. */
 int nvh_floor1_apply(nvh_stream *s, int floor_index, int block_size, int batch, const int32_t *posts,
                      const int32_t *post_counts, float *d_residue, int64_t stride, int32_t *status);
-/* type (0/1), number of posts (Floor1: _xList.Length, Floor1.cs:93-107) and _range (:76) of floor `floor_index`. */
+/* IFloor.Apply for a Floor0 (Floor0.cs:152-212): item b scales d_residue[b*stride .. +block_size/2) by the curve of
+ * its LSP coefficients (coeffs: host, [batch][coeff_stride], the first `order` of each row as Floor0.Unpack leaves
+ * them in Data.Coeff, :98-150) and amplitude amps[b] (Data.Amp), or clears it when amps[b] <= 0 (:208-211).
+ * Floating point: cos / sqrt / exp are evaluated in double and rounded to float as in the reference; values differ
+ * from it only where the math libraries' last ulp does.  status as for nvh_floor1_apply. */
+int nvh_floor0_apply(nvh_stream *s, int floor_index, int block_size, int batch, const float *amps, const float *coeffs,
+                     int coeff_stride, float *d_residue, int64_t stride, int32_t *status);
+/* type (0/1), number of posts (Floor1: _xList.Length, Floor1.cs:93-107; Floor0: _order) and _range (Floor1.cs:76)
+ * of floor `floor_index`. */
 int nvh_stream_floor_info(const nvh_stream *s, int floor_index, int *type, int *post_count, int *range);
+
+/* Mode.cs:24-50 of mode `mode_index`: its block flag, block size and mapping index (NVH_ERR_ARGUMENT past the last mode). */
+int nvh_stream_mode_info(const nvh_stream *s, int mode_index, int *block_flag, int *block_size, int *mapping);
+
+/* IResidue.Decode(IPacket, bool[] doNotDecodeChannel, int blockSize, float[][] buffer) (Contracts/IResidue.cs:6;
+ * Residue0.cs:119-201, Residue1.cs:8-26, Residue2.cs:10-47) for residue `residue_index` of stream `s`: reads the
+ * classifications and codebook entries from `pkt` starting at bit `bit_offset` and adds the decoded vectors into
+ * d_buffer, device planes [channels][block1] (the reference's float[channels][block1Size] working buffer).
+ * any_channel_decodes = doNotDecodeChannel contains a false (:125; otherwise the call reads nothing).
+ * *bits_consumed: how far the packet cursor moved.  The stream must have nothing pending.  Synchronous. */
+int nvh_residue_decode(nvh_stream *s, int residue_index, const uint8_t *pkt, int len, int bit_offset,
+                       int any_channel_decodes, int block_size, float *d_buffer, int *bits_consumed);
+
+/* Mode.Decode's window loop (Mode.cs:160-166) for mode `mode_index`: d_buf[b*stride + i] *= window[i], i < the
+ * mode's block size, b < batch; the window is the one the packet's previous/next flag bits select (Mode.cs:135). */
+int nvh_window_apply(nvh_stream *s, int mode_index, int prev_flag, int next_flag, int batch, float *d_buf,
+                     int64_t stride);
+/* StreamDecoder.OverlapBuffers (StreamDecoder.cs:532-541) on device planes [channels][plane_stride]:
+ * next[c][next_start + j] += previous[c][prev_start + j] for j < prev_stop - prev_start. */
+int nvh_overlap_buffers(nvh_ctx *c, const float *d_previous, float *d_next, int prev_start, int prev_stop,
+                        int next_start, int channels, int64_t plane_stride);
+/* ClippingCopyBuffer / CopyBuffer (StreamDecoder.cs:391-415, Utils.ClipValue Utils.cs:30-43): `count` samples per
+ * channel from index `start` of device planes [channels][plane_stride], interleaved into d_target[count*channels];
+ * clip != 0 clamps to +-0.99999994f and reports in *clipped whether any value was (HasClipped).  Synchronous. */
+int nvh_copy_buffer(nvh_ctx *c, const float *d_planes, int start, int count, int channels, int64_t plane_stride,
+                    float *d_target, int clip, int *clipped);
 
 /* IMdct.Reverse(float[] samples, int sampleCount) (Contracts/IMdct.cs:5, Mdct.cs:13-21) on `batch`
  * buffers: buffer b = d_buf + b*stride holds n floats, reads [0,n/2), writes [0,n).  n = 64..8192. */

@@ -375,6 +375,34 @@ int StreamParser::parse_audio(BitReader& p, FrameBatch& out, int* decoded) {
   return NVH_OK;
 }
 
+int StreamParser::parse_residue(int residue_idx, const uint8_t* data, int len, int bit_offset, int block_size, FrameBatch& out,
+                                int* bits_consumed) {
+  if (residue_idx < 0 || residue_idx >= (int)s_->residues.size()) return NVH_ERR_ARGUMENT;
+  BitReader p(data, len);
+  p.skip(bit_offset);
+  NvhFrame f;
+  std::memset(&f, 0, sizeof f);
+  f.n = block_size;
+  f.mdct_slot = block_size == s_->block1 ? 1 : 0;
+  f.chan_off = (uint32_t)out.chans.size();
+  f.pass_begin = (uint32_t)out.passes.size();
+  f.op_begin = (uint32_t)out.ops.size();
+  f.ent_begin = (uint32_t)out.entries.size();
+  NvhChan ch;
+  std::memset(&ch, 0, sizeof ch);
+  for (int c = 0; c < s_->channels; c++) out.chans.push_back(ch);
+  NvhResPass pass;
+  int rc = decode_residue(residue_idx, p, block_size, out, pass, f.op_begin);
+  if (rc != NVH_OK) return rc;
+  out.passes.push_back(pass);
+  f.pass_end = (uint32_t)out.passes.size();
+  f.op_count = (uint32_t)out.ops.size() - f.op_begin;
+  f.ent_count = (uint32_t)out.entries.size() - f.ent_begin;
+  out.frames.push_back(f);
+  if (bits_consumed) *bits_consumed = p.pos - bit_offset;
+  return NVH_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // stream state machine
 // ---------------------------------------------------------------------------------------------

@@ -62,6 +62,11 @@ class StreamParser {
   // Call after a batch was handed to synthesis: following frames refer to the carried tail.
   void begin_batch();
 
+  // IResidue.Decode on its own (Residue0.cs:119-178, fine-grained ABI): the bit-consuming half of one call, starting at
+  // bit `bit_offset` of the packet, recorded as a single-frame batch whose only pass is this residue.
+  int parse_residue(int residue_idx, const uint8_t* data, int len, int bit_offset, int block_size, FrameBatch& out,
+                    int* bits_consumed);
+
   // Light mode: only the packet type, mode number and window flags are read here (frame geometry, overlap and
   // position bookkeeping); floors and residues are left to kernels_parse.hip, which receives the packet bytes.
   void set_light(bool on) { light_ = on; }

@@ -327,17 +327,19 @@ __device__ __forceinline__ void residue_apply(const NvhDevSetup& S, const NvhDev
 }
 
 extern "C" __global__ void __launch_bounds__(NVH_THREADS)
-k_residue(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work) {
+k_residue(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int clear) {
   const int f = blockIdx.x;
   const NvhFrame fr = Bt.frames[f];
   if (fr.n == 0) return;
   const int half = fr.n >> 1;
   const int tid = threadIdx.x;
   float* planes = work + (long long)f * S.channels * S.block1;
-  // Array.Clear(buffer[i], 0, halfBlockSize) (Mapping.cs:108)
-  for (int c = 0; c < S.channels; ++c)
-    for (int i = tid; i < half; i += NVH_THREADS) planes[(long long)c * S.block1 + i] = 0.0f;
-  __syncthreads();
+  // Array.Clear(buffer[i], 0, halfBlockSize) (Mapping.cs:108); nvh_residue_decode adds into what is there
+  if (clear) {
+    for (int c = 0; c < S.channels; ++c)
+      for (int i = tid; i < half; i += NVH_THREADS) planes[(long long)c * S.block1 + i] = 0.0f;
+    __syncthreads();
+  }
 
   for (unsigned ps = fr.pass_begin; ps < fr.pass_end; ++ps) {
     const NvhResPass* pass = &Bt.passes[ps];
@@ -820,4 +822,49 @@ k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, fl
     const float* plane = work + ((long long)f * ch + c) * S.block1;
     carry_out[(long long)c * S.block1 + i] = compact_value(plane, w, fr.n, Bt.chans[fr.chan_off + c].exec, i);
   }
+}
+
+// ================================================================================================
+// Stand-alone mirrors of the remaining per-packet float loops (fine-grained ABI, unit parity)
+// ================================================================================================
+
+// Mode.Decode's window loop (Mode.cs:160-166): buf[b*stride + i] *= window[i] for i < n.
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_window_apply(float* __restrict__ buf, const float* __restrict__ window, int n, long long stride, int batch) {
+  const long long total = (long long)batch * n;
+  for (long long idx = (long long)blockIdx.x * NVH_THREADS + threadIdx.x; idx < total; idx += (long long)gridDim.x * NVH_THREADS) {
+    const long long b = idx / n;
+    const int i = (int)(idx - b * n);
+    float* p = buf + b * stride + i;
+    *p = *p * window[i];
+  }
+}
+
+// StreamDecoder.OverlapBuffers (StreamDecoder.cs:532-541): next[c][next_start + j] += previous[c][prev_start + j].
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_overlap_buffers(const float* __restrict__ previous, float* __restrict__ next, int prev_start, int len, int next_start,
+                  int channels, long long plane_stride) {
+  const long long total = (long long)channels * len;
+  for (long long idx = (long long)blockIdx.x * NVH_THREADS + threadIdx.x; idx < total; idx += (long long)gridDim.x * NVH_THREADS) {
+    const int c = (int)(idx / len);
+    const int j = (int)(idx - (long long)c * len);
+    float* p = next + c * plane_stride + next_start + j;
+    *p = *p + previous[c * plane_stride + prev_start + j];
+  }
+}
+
+// ClippingCopyBuffer / CopyBuffer (StreamDecoder.cs:391-415): planar -> interleaved, Utils.ClipValue when asked.
+extern "C" __global__ void __launch_bounds__(NVH_THREADS)
+k_copy_buffer(const float* __restrict__ planes, int start, int count, int channels, long long plane_stride,
+              float* __restrict__ target, int clip, int* __restrict__ clipped_flag) {
+  const long long total = (long long)count * channels;
+  int clipped = 0;
+  for (long long idx = (long long)blockIdx.x * NVH_THREADS + threadIdx.x; idx < total; idx += (long long)gridDim.x * NVH_THREADS) {
+    const long long t = idx / channels;
+    const int c = (int)(idx - t * channels);
+    float v = planes[c * plane_stride + start + t];
+    if (clip) v = clip_value(v, &clipped);
+    target[idx] = v;
+  }
+  if (clipped) atomicOr(clipped_flag, 1);
 }

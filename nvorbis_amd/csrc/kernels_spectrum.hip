@@ -360,6 +360,45 @@ __device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* _
   }
 }
 
+// Floor0.Apply's curve (Floor0.cs:152-212) for one channel with Amp > 0: all NT threads of the workgroup; s_coeff holds
+// `order` floats.  The reference evaluates once per run of equal barkMap entries and reuses the value: the same
+// arithmetic per bin here.
+template <int NT>
+__device__ __forceinline__ void floor0_curve(const NvhDevSetup& S, const NvhDevFloor0* F0, const float* __restrict__ coeff,
+                                             float amp, int slot, float* res, int half, float* s_coeff, int tid,
+                                             int* __restrict__ err) {
+  __syncthreads();
+  for (int i = tid; i < F0->order; i += NT) s_coeff[i] = 2.0f * (float)cos((double)coeff[i]);
+  __syncthreads();
+  const int32_t* bark = S.ipool + F0->bark_off[slot];
+  const float* wmap = S.fpool + F0->wmap_off[slot];
+  for (int i = tid; i < half; i += NT) {
+    int kk = bark[i];
+    if (kk < 0 || kk >= half) {
+      atomicOr(err, NVH_DEVERR_FLOOR0_W);
+      continue;
+    }
+    float p = .5f, q = .5f;
+    float w = wmap[kk];
+    int j;
+    for (j = 1; j < F0->order; j += 2) {
+      q = q * (w - s_coeff[j - 1]);
+      p = p * (w - s_coeff[j]);
+    }
+    if (j == F0->order) {
+      q = q * (w - s_coeff[j - 1]);
+      p = p * (p * (4.0f - w * w));
+      q = q * q;
+    } else {
+      p = p * (p * (2.0f - w));
+      q = q * (q * (2.0f + w));
+    }
+    q = amp / (float)sqrt((double)(p + q)) - (float)F0->amp_ofs;
+    q = (float)exp((double)(q * 0.11512925f));
+    res[i] = res[i] * q;
+  }
+}
+
 __device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150-178
   const float oldM = M, oldA = A;
   float newM, newA;
@@ -832,38 +871,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       }
       if (FLOOR0) {  // Floor0 (Floor0.cs:152-212)
         const NvhChan ck = chans[cc];
-        const NvhDevFloor0* F0 = &S.floors[ck.floor].f0;
-        __syncthreads();
-        for (int i = tid; i < F0->order; i += SP_THREADS) s_coeff[i] = 2.0f * (float)cos((double)Bt.coeffs[ck.data_off + i]);
-        __syncthreads();
-        const int slot = fr.mdct_slot;
-        const int32_t* bark = S.ipool + F0->bark_off[slot];
-        const float* wmap = S.fpool + F0->wmap_off[slot];
-        for (int i = tid; i < half; i += SP_THREADS) {
-          int kk = bark[i];
-          if (kk < 0 || kk >= half) {
-            atomicOr(err, NVH_DEVERR_FLOOR0_W);
-            continue;
-          }
-          float p = .5f, q = .5f;
-          float w = wmap[kk];
-          int j;
-          for (j = 1; j < F0->order; j += 2) {
-            q = q * (w - s_coeff[j - 1]);
-            p = p * (w - s_coeff[j]);
-          }
-          if (j == F0->order) {
-            q = q * (w - s_coeff[j - 1]);
-            p = p * (p * (4.0f - w * w));
-            q = q * q;
-          } else {
-            p = p * (p * (2.0f - w));
-            q = q * (q * (2.0f + w));
-          }
-          q = ck.amp / (float)sqrt((double)(p + q)) - (float)F0->amp_ofs;
-          q = (float)exp((double)(q * 0.11512925f));
-          res[i] = res[i] * q;
-        }
+        floor0_curve<SP_THREADS>(S, &S.floors[ck.floor].f0, Bt.coeffs + ck.data_off, ck.amp, fr.mdct_slot, res, half, s_coeff, tid, err);
       }
     }
     __syncthreads();
@@ -960,4 +968,21 @@ k_floor1_apply(NvhDevSetup S, int floor_idx, const uint16_t* __restrict__ posts,
     v.w = v.w * m[3];
     *reinterpret_cast<float4*>(res + x0) = v;
   }
+}
+
+// IFloor.Apply for Floor0 (Floor0.cs:152-212) as an operator: item b scales data[b*stride .. +n/2) by the LSP curve of
+// its coefficients, or clears it when its amplitude is not positive (:208-211).
+extern "C" __global__ void __launch_bounds__(SP_THREADS)
+k_floor0_apply(NvhDevSetup S, int floor_idx, const float* __restrict__ amps, const float* __restrict__ coeffs, int coeff_stride,
+               int n, float* __restrict__ data, long long stride, int* __restrict__ status) {
+  __shared__ float s_coeff[256];
+  const int item = (int)blockIdx.x, tid = (int)threadIdx.x, half = n >> 1;
+  float* res = data + (long long)item * stride;
+  const float amp = amps[item];
+  if (!(amp > 0.0f)) {
+    for (int i = tid; i < half; i += SP_THREADS) res[i] = 0.0f;
+    return;
+  }
+  floor0_curve<SP_THREADS>(S, &S.floors[floor_idx].f0, coeffs + (long long)item * coeff_stride, amp, n == S.block1 ? 1 : 0, res,
+                           half, s_coeff, tid, status + item);
 }

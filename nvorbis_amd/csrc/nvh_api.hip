@@ -50,9 +50,16 @@ __global__ void k_parse_g(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacke
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
                               uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
+__global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
+__global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,
+                                  long long plane_stride);
+__global__ void k_copy_buffer(const float* planes, int start, int count, int channels, long long plane_stride, float* target,
+                              int clip, int* clipped_flag);
+__global__ void k_floor0_apply(NvhDevSetup S, int floor_idx, const float* amps, const float* coeffs, int coeff_stride, int n,
+                               float* data, long long stride, int* status);
 __global__ void k_floor1_apply(NvhDevSetup S, int floor_idx, const uint16_t* posts, const int32_t* counts, int n, float* data,
                                long long stride, int* status);
-__global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work, int clear);
 __global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
 __global__ void k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
                            int* clipped_flag);
@@ -1353,7 +1360,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
       }
     } else {
       b->slot_name[0] = "k_residue"; b->slot_name[1] = "k_couple_floor";
-      hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work);
+      hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, 1);
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));
       hipLaunchKernelGGL(k_couple_floor, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, flags);
     }
@@ -1414,13 +1421,115 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   return NVH_OK;
 }
 
+static unsigned grid_for(long long total) {
+  long long blocks = (total + 255) / 256;
+  return (unsigned)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+}
+
+extern "C" int nvh_window_apply(nvh_stream* s, int mode_index, int prev_flag, int next_flag, int batch, float* d_buf,
+                                int64_t stride) {
+  if (!s || mode_index < 0 || mode_index >= (int)s->setup.modes.size() || batch < 0 || (batch > 0 && !d_buf)) return NVH_ERR_ARGUMENT;
+  const nvh::Mode& m = s->setup.modes[(size_t)mode_index];
+  if (stride < m.block_size) return NVH_ERR_ARGUMENT;
+  if (!s->ctx) return NVH_ERR_NO_GPU;
+  if (batch == 0) return NVH_OK;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  // Mode.cs:135: the long-block window is chosen by the packet's two flag bits; a short-block mode has one window
+  const int wi = m.block_flag ? ((prev_flag ? 1 : 0) + (next_flag ? 2 : 0)) : 0;
+  hipLaunchKernelGGL(k_window_apply, dim3(grid_for((long long)batch * m.block_size)), dim3(256), 0, s->ctx->stream, d_buf,
+                     s->dev.windows + m.window_off[wi], m.block_size, (long long)stride, batch);
+  HIP_TRY(hipGetLastError());
+  return NVH_OK;
+}
+
+extern "C" int nvh_overlap_buffers(nvh_ctx* c, const float* d_previous, float* d_next, int prev_start, int prev_stop,
+                                   int next_start, int channels, int64_t plane_stride) {
+  if (!c || !d_previous || !d_next || prev_start < 0 || next_start < 0 || channels <= 0) return NVH_ERR_ARGUMENT;
+  const int len = prev_stop - prev_start;
+  if (len <= 0) return NVH_OK;  // the reference's loop does not run
+  if (prev_stop > plane_stride || (int64_t)next_start + len > plane_stride) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_overlap_buffers, dim3(grid_for((long long)channels * len)), dim3(256), 0, c->stream, d_previous, d_next,
+                     prev_start, len, next_start, channels, (long long)plane_stride);
+  HIP_TRY(hipGetLastError());
+  return NVH_OK;
+}
+
+extern "C" int nvh_copy_buffer(nvh_ctx* c, const float* d_planes, int start, int count, int channels, int64_t plane_stride,
+                               float* d_target, int clip, int* clipped) {
+  if (!c || start < 0 || count < 0 || channels <= 0 || (int64_t)start + count > plane_stride) return NVH_ERR_ARGUMENT;
+  if (clipped) *clipped = 0;
+  if (count == 0) return NVH_OK;
+  if (!d_planes || !d_target) return NVH_ERR_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  DevBuf flag;
+  flag.pool = &c->pool;
+  int rc = flag.reserve(sizeof(int));
+  if (rc != NVH_OK) return rc;
+  HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_copy_buffer, dim3(grid_for((long long)channels * count)), dim3(256), 0, c->stream, d_planes, start, count,
+                     channels, (long long)plane_stride, d_target, clip, (int*)flag.p);
+  HIP_TRY(hipGetLastError());
+  int h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, flag.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (clipped) *clipped = h ? 1 : 0;
+  return NVH_OK;
+}
+
 // IFloor.Apply for the stream's floor `floor_index` on `batch` device vectors (see include/nvorbis_hip.h).
 extern "C" int nvh_stream_floor_info(const nvh_stream* s, int floor_index, int* type, int* post_count, int* range) {
   if (!s || floor_index < 0 || floor_index >= (int)s->setup.floors.size()) return NVH_ERR_ARGUMENT;
   const nvh::Floor& f = s->setup.floors[(size_t)floor_index];
   if (type) *type = f.type;
-  if (post_count) *post_count = f.type == 1 ? (int)f.f1.x_list.size() : 0;
+  if (post_count) *post_count = f.type == 1 ? (int)f.f1.x_list.size() : f.f0.order;
   if (range) *range = f.type == 1 ? f.f1.range : 0;
+  return NVH_OK;
+}
+
+extern "C" int nvh_floor0_apply(nvh_stream* s, int floor_index, int block_size, int batch, const float* amps, const float* coeffs,
+                                int coeff_stride, float* d_residue, int64_t stride, int32_t* status) {
+  if (!s || batch < 0 || (batch > 0 && (!amps || !coeffs || !d_residue))) return NVH_ERR_ARGUMENT;
+  if (floor_index < 0 || floor_index >= (int)s->setup.floors.size()) return NVH_ERR_ARGUMENT;
+  const nvh::Floor& f = s->setup.floors[(size_t)floor_index];
+  if (f.type != 0 || f.f0.order > 256 || coeff_stride < f.f0.order) return NVH_ERR_ARGUMENT;
+  if (block_size != s->setup.block0 && block_size != s->setup.block1) return NVH_ERR_ARGUMENT;
+  if (stride < block_size / 2) return NVH_ERR_ARGUMENT;
+  if (!s->ctx) return NVH_ERR_NO_GPU;
+  if (batch == 0) return NVH_OK;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  hipStream_t st = s->ctx->stream;
+  DevBuf d_amps, d_coeffs, d_status;
+  d_amps.pool = d_coeffs.pool = d_status.pool = &s->ctx->pool;
+  const size_t ncoef = (size_t)batch * (size_t)coeff_stride;
+  int rc;
+  if ((rc = d_amps.reserve((size_t)batch * sizeof(float))) != NVH_OK) return rc;
+  if ((rc = d_coeffs.reserve(ncoef * sizeof(float))) != NVH_OK) return rc;
+  if ((rc = d_status.reserve((size_t)batch * sizeof(int32_t))) != NVH_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(d_amps.p, amps, (size_t)batch * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_coeffs.p, coeffs, ncoef * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_status.p, 0, (size_t)batch * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_floor0_apply, dim3((unsigned)batch), dim3(256), 0, st, s->dev, floor_index, (const float*)d_amps.p,
+                     (const float*)d_coeffs.p, coeff_stride, block_size, d_residue, (long long)stride, (int*)d_status.p);
+  HIP_TRY(hipGetLastError());
+  std::vector<int32_t> h_status((size_t)batch, 0);
+  HIP_TRY(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  int any = NVH_OK;
+  for (int b = 0; b < batch; ++b) {
+    const int code = h_status[(size_t)b] ? NVH_ERR_RUNTIME : NVH_OK;  // wMap index out of range (Floor0.cs:90, :163)
+    if (status) status[b] = code;
+    if (code != NVH_OK && any == NVH_OK) any = code;
+  }
+  return status ? NVH_OK : any;
+}
+
+extern "C" int nvh_stream_mode_info(const nvh_stream* s, int mode_index, int* block_flag, int* block_size, int* mapping) {
+  if (!s || mode_index < 0 || mode_index >= (int)s->setup.modes.size()) return NVH_ERR_ARGUMENT;
+  const nvh::Mode& m = s->setup.modes[(size_t)mode_index];
+  if (block_flag) *block_flag = m.block_flag ? 1 : 0;
+  if (block_size) *block_size = m.block_size;
+  if (mapping) *mapping = m.mapping;
   return NVH_OK;
 }
 
@@ -1573,6 +1682,45 @@ extern "C" int nvh_mode_decode(nvh_stream* s, const uint8_t* pkt, int len, float
   if (start) *start = f0.start;
   if (valid) *valid = f0.valid;
   if (total) *total = f0.total;
+  return NVH_OK;
+}
+
+// IResidue.Decode(packet, doNotDecodeChannel, blockSize, buffer) on its own (see include/nvorbis_hip.h): the host reads
+// the classifications and entries from the packet, k_residue adds the vectors into the caller's planes.
+extern "C" int nvh_residue_decode(nvh_stream* s, int residue_index, const uint8_t* pkt, int len, int bit_offset,
+                                  int any_channel_decodes, int block_size, float* d_buffer, int* bits_consumed) {
+  if (!s || (!pkt && len > 0) || len < 0 || bit_offset < 0 || !d_buffer) return NVH_ERR_ARGUMENT;
+  if (residue_index < 0 || residue_index >= (int)s->setup.residues.size()) return NVH_ERR_ARGUMENT;
+  if (block_size != s->setup.block0 && block_size != s->setup.block1) return NVH_ERR_ARGUMENT;
+  if (!s->ctx) return NVH_ERR_NO_GPU;
+  if (!s->pending.frames.empty()) return NVH_ERR_ARGUMENT;
+  if (bits_consumed) *bits_consumed = 0;
+  if (!any_channel_decodes) return NVH_OK;  // Array.IndexOf(doNotDecodeChannel, false) == -1 (Residue0.cs:125): nothing is read
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  static const uint8_t empty = 0;
+  nvh::StreamParser one(&s->setup);
+  nvh::FrameBatch fb;
+  int rc = one.parse_residue(residue_index, pkt ? pkt : &empty, len, bit_offset, block_size, fb, bits_consumed);
+  if (rc != NVH_OK) return rc;
+  nvh_batch b;
+  b.blob.pool = b.work.pool = b.carry_in.pool = b.slabs.pool = &s->ctx->pool;
+  b.h_blob.host = true;
+  b.h_blob.pool = &s->ctx->hpool;
+  const bool was_gpu = s->gpu_parse;
+  s->gpu_parse = false;
+  std::swap(s->pending, fb);
+  rc = batch_upload(s, &b);
+  std::swap(s->pending, fb);
+  s->pending.clear();
+  s->gpu_parse = was_gpu;
+  if (rc != NVH_OK) return rc;
+  hipStream_t st = s->ctx->stream;
+  const size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(b.work.p, d_buffer, plane, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_residue, dim3(1), dim3(256), 0, st, s->dev, b.dev, (float*)b.work.p, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(d_buffer, b.work.p, plane, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return NVH_OK;
 }
 

@@ -45,6 +45,12 @@ SIGNATURES = {
     "nvh_mdct_reverse": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int64]),
     "nvh_inverse_couple": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "nvh_mode_decode": (C.c_int, [_vp, _vp, C.c_int, _vp] + [C.POINTER(C.c_int)] * 5),
+    "nvh_residue_decode": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)]),
+    "nvh_window_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64]),
+    "nvh_overlap_buffers": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "nvh_copy_buffer": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, C.c_int, C.POINTER(C.c_int)]),
+    "nvh_stream_mode_info": (C.c_int, [_vp, C.c_int] + [C.POINTER(C.c_int)] * 3),
+    "nvh_floor0_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64, _vp]),
     "nvh_floor1_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int64, _vp]),
     "nvh_stream_floor_info": (C.c_int, [_vp, C.c_int] + [C.POINTER(C.c_int)] * 3),
     "nvh_mdct_tables": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),

@@ -79,6 +79,18 @@ class Context:
         """IMdct.Reverse on `batch` device buffers (Contracts/IMdct.cs:5)."""
         check(lib().nvh_mdct_reverse(self._h, int(n), int(batch), C.c_void_p(d_ptr), int(stride)), "nvh_mdct_reverse")
 
+    def overlap_buffers(self, d_previous, d_next, prev_start, prev_stop, next_start, channels, plane_stride):
+        """StreamDecoder.OverlapBuffers on device planes [channels][plane_stride]."""
+        check(lib().nvh_overlap_buffers(self._h, C.c_void_p(d_previous), C.c_void_p(d_next), int(prev_start), int(prev_stop),
+                                        int(next_start), int(channels), int(plane_stride)), "nvh_overlap_buffers")
+
+    def copy_buffer(self, d_planes, start, count, channels, plane_stride, d_target, clip=True):
+        """ClippingCopyBuffer / CopyBuffer: planar device planes -> interleaved device target; returns HasClipped."""
+        clipped = C.c_int(0)
+        check(lib().nvh_copy_buffer(self._h, C.c_void_p(d_planes), int(start), int(count), int(channels), int(plane_stride),
+                                    C.c_void_p(d_target), 1 if clip else 0, C.byref(clipped)), "nvh_copy_buffer")
+        return bool(clipped.value)
+
     def inverse_couple(self, d_magnitude, d_angle, count):
         """One inverse square-polar coupling step over two device vectors, in place (Mapping.cs:150-178)."""
         check(lib().nvh_inverse_couple(self._h, C.c_void_p(d_magnitude), C.c_void_p(d_angle), int(count)), "nvh_inverse_couple")
@@ -194,11 +206,42 @@ class Stream:
                                     C.byref(b), C.byref(c)), "nvh_mode_decode")
         return (bs.value, a.value, b.value, c.value) if dec.value else None
 
+    def residue_decode(self, residue_index, packet, bit_offset, block_size, d_buffer, any_channel_decodes=True):
+        """IResidue.Decode: adds the vectors packet[bit_offset:] encodes into the device planes [channels][block1] at
+        d_buffer; returns the number of bits consumed."""
+        bits = C.c_int(0)
+        check(lib().nvh_residue_decode(self._h, int(residue_index), packet, len(packet), int(bit_offset),
+                                       1 if any_channel_decodes else 0, int(block_size), C.c_void_p(d_buffer), C.byref(bits)),
+              "nvh_residue_decode")
+        return bits.value
+
+    def window_apply(self, mode_index, prev_flag, next_flag, batch, d_buf, stride):
+        """Mode.Decode's window loop on `batch` device buffers."""
+        check(lib().nvh_window_apply(self._h, int(mode_index), int(prev_flag), int(next_flag), int(batch), C.c_void_p(d_buf),
+                                     int(stride)), "nvh_window_apply")
+
+    def mode_info(self, mode_index):
+        """(block flag, block size, mapping) of one of the stream's modes; None past the last one."""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        if lib().nvh_stream_mode_info(self._h, int(mode_index), C.byref(a), C.byref(b), C.byref(c)) != 0:
+            return None
+        return bool(a.value), b.value, c.value
+
     def floor_info(self, floor_index):
         """(type, post count, range) of one of the stream's floors."""
         t, pc, rg = C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().nvh_stream_floor_info(self._h, int(floor_index), C.byref(t), C.byref(pc), C.byref(rg)), "nvh_stream_floor_info")
         return t.value, pc.value, rg.value
+
+    def floor0_apply(self, floor_index, block_size, amps, coeffs, d_residue, stride):
+        """IFloor.Apply (Floor0.cs:152-212) on a batch of device vectors: amps [batch], coeffs [batch][>= order]."""
+        amps = np.ascontiguousarray(amps, dtype=np.float32)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.float32)
+        batch = amps.shape[0]
+        status = np.zeros(batch, np.int32)
+        check(lib().nvh_floor0_apply(self._h, int(floor_index), int(block_size), batch, amps.ctypes.data, coeffs.ctypes.data,
+                                     int(coeffs.shape[1]), C.c_void_p(d_residue), int(stride), status.ctypes.data), "nvh_floor0_apply")
+        return status
 
     def floor1_apply(self, floor_index, block_size, posts, post_counts, d_residue, stride):
         """IFloor.Apply (Floor1.cs:186-341) on a batch of device vectors: posts [batch][64] raw Unpack values, post_counts

@@ -123,7 +123,19 @@ int orc_decode_packet_block(orc_decoder *d, const uint8_t *pkt, int len, float *
  * Returns 0, or ORC_ERR_RUNTIME where the reference would throw (residue is then partly modified). */
 int orc_floor1_apply_posts(orc_decoder *d, int floor_index, int block_size, const int *posts, int post_count,
                            float *residue, int reslen);
-/* type, post count (_xList.Length) and _range of floor `floor_index`; returns the number of floors. */
+/* IResidue.Decode (Residue0.cs:119-178 and the WriteVectors of types 0/1/2) of residue `residue_index` reading `pkt`
+ * from bit `bit_offset`, adding into planes [channels][block1]; *bits_consumed = cursor movement. */
+int orc_residue_decode_at(orc_decoder *d, int residue_index, const uint8_t *pkt, int len, int bit_offset,
+                          int any_channel_decodes, int block_size, float *planes, int *bits_consumed);
+/* The IResidue.Decode calls Mapping.DecodePacket made for the last packet given to orc_decode_packet_block:
+ * returns their number; pos[i] = packet cursor before call i, idx[i] = residue index, *any = some channel executes. */
+int orc_last_residue_calls(const orc_decoder *d, int *pos, int *idx, int cap, int *any);
+/* block flag, block size and mapping of mode `mode_index`; returns the number of modes. */
+int orc_mode_info(const orc_decoder *d, int mode_index, int *block_flag, int *block_size, int *mapping);
+/* IFloor.Apply (Floor0.cs:152-212) of floor `floor_index` for Data.Amp = amp and Data.Coeff = coeff[0..order). */
+int orc_floor0_apply_coeffs(orc_decoder *d, int floor_index, int block_size, float amp, const float *coeff,
+                            float *residue, int reslen);
+/* type, post count (Floor1 _xList.Length; Floor0 _order) and _range of floor `floor_index`; returns the number of floors. */
 int orc_floor_info(const orc_decoder *d, int floor_index, int *type, int *post_count, int *range);
 
 #ifdef __cplusplus

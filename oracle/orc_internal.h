@@ -135,6 +135,8 @@ struct orc_decoder {
   int prev_start, prev_end, prev_stop;
 
   int last_error;
+  /* test hook: the IResidue.Decode calls of the last Mapping.DecodePacket (cursor before the call, residue index) */
+  int res_calls, res_call_pos[16], res_call_idx[16], res_call_any;
   int trace_on, trace_n, trace_cap;
   orc_frame_trace *trace;
 };

@@ -109,10 +109,19 @@ int orc_mapping_decode_packet(orc_decoder *d, const orc_mapping *m, orc_packet *
 
   /* decode the submaps into the residue buffer (:122-134).  Object identity of floors/residues
    * in the reference == index identity here (each index is a distinct object). */
+  d->res_calls = 0;
+  d->res_call_any = 0;
+  for (j = 0; j < nch; j++)
+    if (!no_execute[j]) d->res_call_any = 1;
   for (i = 0; i < m->submap_count; i++) {
     for (j = 0; j < nch; j++) {
       if (m->submap_floor[i] != m->channel_floor[j] || m->submap_residue[i] != m->channel_residue[j])
         floor_data[j].force_no_energy = 1;
+    }
+    if (d->res_calls < 16) {
+      d->res_call_pos[d->res_calls] = p->pos;
+      d->res_call_idx[d->res_calls] = m->submap_residue[i];
+      d->res_calls++;
     }
     rc = orc_residue_decode(&d->residues[m->submap_residue[i]], d->books, p, no_execute, nch, block_size, buffer,
                             d->block1);

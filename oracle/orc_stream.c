@@ -434,8 +434,58 @@ int orc_floor_info(const orc_decoder *d, int floor_index, int *type, int *post_c
   if (floor_index >= 0 && floor_index < d->nfloors) {
     const orc_floor *f = &d->floors[floor_index];
     if (type) *type = f->type;
-    if (post_count) *post_count = f->type == 1 ? f->f1.x_count : 0;
+    if (post_count) *post_count = f->type == 1 ? f->f1.x_count : f->f0.order;
     if (range) *range = f->type == 1 ? f->f1.range : 0;
   }
   return d->nfloors;
+}
+
+int orc_residue_decode_at(orc_decoder *d, int residue_index, const uint8_t *pkt, int len, int bit_offset,
+                          int any_channel_decodes, int block_size, float *planes, int *bits_consumed) {
+  orc_packet p;
+  float **rows;
+  int no_decode = !any_channel_decodes, rc, c;
+  if (!d || residue_index < 0 || residue_index >= d->nresidues) return ORC_ERR_ARGUMENT;
+  rows = (float **)calloc((size_t)d->channels, sizeof *rows);
+  if (!rows) return ORC_ERR_NOMEM;
+  for (c = 0; c < d->channels; c++) rows[c] = planes + (size_t)c * d->block1;
+  orc_packet_init(&p, pkt, len);
+  orc_skip_bits(&p, bit_offset);
+  rc = orc_residue_decode(&d->residues[residue_index], d->books, &p, &no_decode, 1, block_size, rows, d->block1);
+  if (bits_consumed) *bits_consumed = p.pos - bit_offset;
+  free(rows);
+  return rc;
+}
+
+int orc_last_residue_calls(const orc_decoder *d, int *pos, int *idx, int cap, int *any) {
+  int i;
+  if (!d) return 0;
+  for (i = 0; i < d->res_calls && i < cap; i++) {
+    pos[i] = d->res_call_pos[i];
+    idx[i] = d->res_call_idx[i];
+  }
+  if (any) *any = d->res_call_any;
+  return d->res_calls;
+}
+
+int orc_mode_info(const orc_decoder *d, int mode_index, int *block_flag, int *block_size, int *mapping) {
+  if (!d) return 0;
+  if (mode_index >= 0 && mode_index < d->nmodes) {
+    if (block_flag) *block_flag = d->modes[mode_index].block_flag;
+    if (block_size) *block_size = d->modes[mode_index].block_size;
+    if (mapping) *mapping = d->modes[mode_index].mapping;
+  }
+  return d->nmodes;
+}
+
+int orc_floor0_apply_coeffs(orc_decoder *d, int floor_index, int block_size, float amp, const float *coeff,
+                            float *residue, int reslen) {
+  orc_floor_data data;
+  int i;
+  if (!d || floor_index < 0 || floor_index >= d->nfloors || d->floors[floor_index].type != 0) return ORC_ERR_ARGUMENT;
+  memset(&data, 0, sizeof data);
+  data.type = 0;
+  data.amp = amp;
+  for (i = 0; i < d->floors[floor_index].f0.order && i < 257; i++) data.coeff[i] = coeff[i];
+  return orc_floor_apply(&d->floors[floor_index], &data, block_size, residue, reslen);
 }

@@ -48,6 +48,10 @@ class Oracle:
         L.orc_render_point.argtypes = [C.c_int] * 5
         L.orc_inverse_couple.argtypes = [vp, vp, C.c_int]
         L.orc_decode_packet_block.argtypes = [vp, vp, C.c_int, vp] + [C.POINTER(C.c_int)] * 4
+        L.orc_residue_decode_at.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]
+        L.orc_last_residue_calls.argtypes = [vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
+        L.orc_mode_info.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int)] * 3
+        L.orc_floor0_apply_coeffs.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp, C.c_int]
         L.orc_floor1_apply_posts.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
         L.orc_floor_info.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int)] * 3
 

@@ -438,3 +438,183 @@ def test_floor1_apply_operator_synthetic(oracle, gpu_ctx, name):
     pk, _, _ = ss.filtered_stream(oracle, name, 4, 21)
     n_ok, n_err = _floor1_apply_case(oracle, gpu_ctx, pk, 9)
     assert n_ok > 50
+
+
+def _residue_decode_case(oracle, gpu_ctx, pk, packet_ids, seed):
+    """IResidue.Decode call by call: the cursor and residue index of every call Mapping.DecodePacket makes come from the
+    oracle's trace of the full packet; each call is then replayed on both sides into the same random planes."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    torch = _torch()
+    rng = np.random.default_rng(seed)
+    d = _open_headers(oracle, pk)
+    st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+    calls = 0
+    kinds = set()
+    try:
+        ch, b1 = st.channels, st.block1
+        scratch = np.zeros(ch * b1, np.float32)
+        for i in packet_ids:
+            a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            if oracle.L.orc_decode_packet_block(d, pk[i], len(pk[i]), scratch.ctypes.data, C.byref(a), C.byref(b), C.byref(c), C.byref(e)) != 1:
+                continue
+            pos, idx, anyx = np.zeros(16, np.int32), np.zeros(16, np.int32), C.c_int()
+            ncall = oracle.L.orc_last_residue_calls(d, pos.ctypes.data, idx.ctypes.data, 16, C.byref(anyx))
+            for k in range(ncall):
+                init = rng.standard_normal(ch * b1).astype(np.float32)
+                ref = init.copy()
+                rbits = C.c_int()
+                rc = oracle.L.orc_residue_decode_at(d, int(idx[k]), pk[i], len(pk[i]), int(pos[k]), anyx.value, e.value, ref.ctypes.data,
+                                                    C.byref(rbits))
+                assert rc == 0
+                got = torch.from_numpy(init.copy()).cuda()
+                gbits = st.residue_decode(int(idx[k]), pk[i], int(pos[k]), e.value, got.data_ptr(), bool(anyx.value))
+                got = got.cpu().numpy()
+                half = e.value // 2
+                g = got.reshape(ch, b1)[:, :half]
+                r = ref.reshape(ch, b1)[:, :half]
+                assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), (i, k, float(np.abs(g - r).max()))
+                # [n/2, block1) is scratch in the reference too (overwritten by the IMDCT or cleared): not compared
+                if int(pos[k]) + rbits.value < len(pk[i]) * 8:
+                    assert gbits == rbits.value, (i, k, gbits, rbits.value)
+                calls += 1
+                kinds.add((int(idx[k]), e.value, bool(np.any(g != init.reshape(ch, b1)[:, :half]))))
+    finally:
+        st.close()
+        oracle.L.orc_close(d)
+    return calls, kinds
+
+
+@pytest.mark.parametrize("name", ["2test", "3test"])
+def test_residue_decode_operator_files(oracle, gpu_ctx, ogg_bytes, name):
+    """Fine-grained ABI: IResidue.Decode (Residue0.cs:119-201, Residue1.cs, Residue2.cs) on its own, bit-exact."""
+    import nvorbis_amd as nv
+    pk, _, _ = nv.demux_ogg(ogg_bytes[name])
+    ids = list(range(3, min(len(pk), 30))) + list(range(30, len(pk), max(1, (len(pk) - 30) // 30)))
+    calls, kinds = _residue_decode_case(oracle, gpu_ctx, pk, ids, 3)
+    assert calls > 30 and any(k[2] for k in kinds)
+
+
+@pytest.mark.parametrize("name", ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
+                                  "two_submaps", "equal_blocks_overrun"])
+def test_residue_decode_operator_synthetic(oracle, gpu_ctx, name):
+    from tests import synth_stream as ss
+    pk, _, _ = ss.filtered_stream(oracle, name, 24, 21)
+    calls, kinds = _residue_decode_case(oracle, gpu_ctx, pk, range(3, len(pk)), 4)
+    assert calls > 10 and any(k[2] for k in kinds)
+
+
+@pytest.mark.parametrize("name", ["2test", "3test"])
+def test_window_overlap_copy_operators(oracle, gpu_ctx, ogg_bytes, name):
+    """Fine-grained ABI: Mode.Decode's window loop vs the oracle's CalcWindow table, OverlapBuffers and
+    ClippingCopyBuffer / CopyBuffer vs their definitions (StreamDecoder.cs:391-415, 532-541; Utils.cs:30-43)."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    torch = _torch()
+    rng = np.random.default_rng(8)
+    pk, _, _ = nv.demux_ogg(ogg_bytes[name])
+    d = _open_headers(oracle, pk)
+    st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+    try:
+        b0, b1, ch = st.block0, st.block1, st.channels
+        nmodes = oracle.L.orc_mode_info(d, 0, None, None, None)
+        assert st.mode_info(nmodes) is None
+        for mi in range(nmodes):
+            f, n, mp = C.c_int(), C.c_int(), C.c_int()
+            oracle.L.orc_mode_info(d, mi, C.byref(f), C.byref(n), C.byref(mp))
+            assert st.mode_info(mi) == (bool(f.value), n.value, mp.value)
+            for prev in (0, 1):
+                for nxt in (0, 1):
+                    # Mode.cs:41-50: the flags pick the neighbours' block sizes for a long block; short blocks have one window
+                    w = oracle.window(b1 if (prev or not f.value) else b0, n.value, b1 if (nxt or not f.value) else b0) if f.value \
+                        else oracle.window(b0, n.value, b0)
+                    x = rng.standard_normal((5, n.value + 8)).astype(np.float32)
+                    g = torch.from_numpy(x.copy()).cuda()
+                    st.window_apply(mi, prev, nxt, 5, g.data_ptr(), n.value + 8)
+                    want = x.copy()
+                    want[:, :n.value] = x[:, :n.value] * w
+                    assert np.array_equal(g.cpu().numpy().view(np.uint32), want.view(np.uint32)), (mi, prev, nxt)
+        # OverlapBuffers
+        prev = rng.standard_normal((ch, b1)).astype(np.float32)
+        nxt = rng.standard_normal((ch, b1)).astype(np.float32)
+        for (ps, pe, ns) in [(b1 // 2, b1 * 3 // 4, 0), (b1 * 3 // 4 - b0 // 4, b1 * 3 // 4 + b0 // 4, b1 // 4 - b0 // 4), (7, 7, 3), (0, b1, 0)]:
+            gp, gn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt.copy()).cuda()
+            gpu_ctx.overlap_buffers(gp.data_ptr(), gn.data_ptr(), ps, pe, ns, ch, b1)
+            want = nxt.copy()
+            want[:, ns:ns + pe - ps] = nxt[:, ns:ns + pe - ps] + prev[:, ps:pe]
+            assert np.array_equal(gn.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        # ClippingCopyBuffer / CopyBuffer
+        planes = (rng.standard_normal((ch, b1)) * 0.6).astype(np.float32)
+        planes[0, 5], planes[ch - 1, 9] = np.float32(0.99999994), np.float32(-0.99999994)  # the bounds themselves are not clipped
+        gp = torch.from_numpy(planes).cuda()
+        for clip in (True, False):
+            for (s0, cnt) in [(0, b1), (3, 1000 if b1 > 1100 else 40), (11, 0)]:
+                out = torch.zeros(max(cnt, 1) * ch, dtype=torch.float32, device="cuda")
+                clipped = gpu_ctx.copy_buffer(gp.data_ptr(), s0, cnt, ch, b1, out.data_ptr(), clip)
+                seg = planes[:, s0:s0 + cnt]
+                lim = np.float32(0.99999994)
+                want = np.clip(seg, -lim, lim) if clip else seg
+                assert np.array_equal(out.cpu().numpy()[:cnt * ch].view(np.uint32), np.ascontiguousarray(want.T).reshape(-1).view(np.uint32))
+                assert clipped == bool(clip and cnt and (np.abs(seg) > lim).any())
+        quiet = torch.from_numpy((planes * 0.1).astype(np.float32)).cuda()
+        out = torch.zeros(b1 * ch, dtype=torch.float32, device="cuda")
+        assert gpu_ctx.copy_buffer(quiet.data_ptr(), 0, b1, ch, b1, out.data_ptr(), True) is False
+    finally:
+        st.close()
+        oracle.L.orc_close(d)
+
+
+def test_floor0_apply_operator(oracle, gpu_ctx):
+    """Fine-grained ABI: IFloor.Apply for Floor0 (Floor0.cs:152-212) on random LSP coefficients; double-precision
+    cos/sqrt/exp rounded to float on both sides: almost every value identical, the rest within the last-ulp differences
+    of the two math libraries (a 1-ulp coefficient moves the exponent's argument); empty floors cleared."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    torch = _torch()
+    rng = np.random.default_rng(12)
+    pk, _, _ = ss.filtered_stream(oracle, "floor0_stereo", 4, 21)
+    d = _open_headers(oracle, pk)
+    st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+    try:
+        nfloors = oracle.L.orc_floor_info(d, 0, None, None, None)
+        done = 0
+        for fi in range(nfloors):
+            t, order, _ = st.floor_info(fi)
+            ot, oo = C.c_int(), C.c_int()
+            oracle.L.orc_floor_info(d, fi, C.byref(ot), C.byref(oo), None)
+            assert (t, order) == (ot.value, oo.value)
+            if t != 0:
+                continue
+            for n in sorted({st.block0, st.block1}):
+                half, batch = n // 2, 40
+                amps = rng.uniform(0.25, 6.0, batch).astype(np.float32)
+                amps[::7] = 0.0
+                coeffs = np.sort(rng.uniform(0.05, 3.1, (batch, order + 3)), axis=1).astype(np.float32)
+                res = rng.standard_normal((batch, half)).astype(np.float32)
+                got = torch.from_numpy(res.copy()).cuda()
+                status = st.floor0_apply(fi, n, amps, coeffs, got.data_ptr(), half)
+                got = got.cpu().numpy()
+                assert not status.any()
+                exact = total = 0
+                for b in range(batch):
+                    ref = np.zeros(st.block1, np.float32)
+                    ref[:half] = res[b]
+                    cf = np.ascontiguousarray(coeffs[b])
+                    assert oracle.L.orc_floor0_apply_coeffs(d, fi, n, float(amps[b]), cf.ctypes.data, ref.ctypes.data, st.block1) == 0
+                    r = ref[:half]
+                    if amps[b] <= 0:
+                        assert not got[b].any() and not r.any()
+                        continue
+                    fin = np.isfinite(r)
+                    assert np.array_equal(got[b][~fin].view(np.uint32), r[~fin].view(np.uint32))  # overflowed curves: same inf
+                    g64, r64 = got[b][fin].astype(np.float64), r[fin].astype(np.float64)
+                    assert np.all(np.abs(g64 - r64) <= 2e-5 * np.abs(r64) + 1e-30), (fi, n, b)
+                    exact += int((got[b].view(np.uint32) == r.view(np.uint32)).sum())
+                    total += half
+                    done += 1
+                assert exact >= 0.95 * total, (exact, total)
+        assert done > 40
+    finally:
+        st.close()
+        oracle.L.orc_close(d)

@@ -210,3 +210,41 @@ def test_floor1_apply_flat_curve_and_empty(oracle, ogg_bytes, name):
                 assert not v[:n // 2].any()
     finally:
         oracle.L.orc_close(d)
+
+
+def test_residue_call_trace_and_replay(oracle, ogg_bytes):
+    """The oracle's record of Mapping.DecodePacket's IResidue.Decode calls: one call per submap, cursor inside the packet;
+    a replay is deterministic, and a call with every channel marked do-not-decode reads nothing (Residue0.cs:125)."""
+    import ctypes as C
+    data = ogg_bytes["3test"]
+    err = C.c_int(0)
+    d = oracle.L.orc_open_ogg(data, len(data), C.byref(err))
+    assert d
+    try:
+        ch, b1 = oracle.L.orc_channels(d), oracle.L.orc_block1(d)
+        import nvorbis_amd as nv
+        pk, _, _ = nv.demux_ogg(data)
+        scratch = np.zeros(ch * b1, np.float32)
+        seen = 0
+        for i in range(3, 40):
+            a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            if oracle.L.orc_decode_packet_block(d, pk[i], len(pk[i]), scratch.ctypes.data, C.byref(a), C.byref(b), C.byref(c), C.byref(e)) != 1:
+                continue
+            pos, idx, anyx = np.zeros(16, np.int32), np.zeros(16, np.int32), C.c_int()
+            n = oracle.L.orc_last_residue_calls(d, pos.ctypes.data, idx.ctypes.data, 16, C.byref(anyx))
+            assert n == 1 and 0 < pos[0] < len(pk[i]) * 8
+            zero = np.zeros(ch * b1, np.float32)
+            bits = C.c_int()
+            assert oracle.L.orc_residue_decode_at(d, int(idx[0]), pk[i], len(pk[i]), int(pos[0]), 1, e.value, zero.ctypes.data, C.byref(bits)) == 0
+            if anyx.value:
+                assert bits.value > 0 and zero.any()
+                seen += 1
+            again = np.zeros(ch * b1, np.float32)
+            assert oracle.L.orc_residue_decode_at(d, int(idx[0]), pk[i], len(pk[i]), int(pos[0]), 1, e.value, again.ctypes.data, C.byref(bits)) == 0
+            assert np.array_equal(zero, again)
+            none = np.ones(ch * b1, np.float32)
+            assert oracle.L.orc_residue_decode_at(d, int(idx[0]), pk[i], len(pk[i]), int(pos[0]), 0, e.value, none.ctypes.data, C.byref(bits)) == 0
+            assert bits.value == 0 and (none == 1).all()
+        assert seen > 20
+    finally:
+        oracle.L.orc_close(d)
