@@ -155,6 +155,14 @@ int nvh_stream_push_packet(nvh_stream *s, const uint8_t *data, int len, int64_t 
  * max_packets, at the first error, or once the stream has seen its end-of-stream packet; *consumed = packets taken. */
 int nvh_stream_push_packets(nvh_stream *s, const uint8_t *bytes, const int64_t *offsets, const int64_t *granules,
                             const uint8_t *flags, int n, int max_packets, int *consumed);
+/* _hasPosition / _currentPosition (StreamDecoder.cs:35-39) after everything pushed so far was read.  Setting them is
+ * what a caller does that starts a decoder in the middle of a stream (the state SeekTo leaves behind, :562-628):
+ * nvorbis_amd/corpus.py's chunked decode pushes one lead-in packet, then sets the state the serial decoder has there. */
+int nvh_stream_position_state(const nvh_stream *s, int *has_position, int64_t *position);
+int nvh_stream_set_position_state(nvh_stream *s, int has_position, int64_t position);
+/* Forget the pending (parsed, not yet synthesised) frames without synthesising them: for callers that only want the
+ * integer geometry (positions, sample counts) of a stretch of packets. */
+int nvh_stream_drop_pending(nvh_stream *s);
 /* The packet provider returned null (StreamDecoder.cs:472-475). */
 int nvh_stream_push_end(nvh_stream *s);
 /* Pending (parsed, not yet synthesised) work. */

@@ -177,3 +177,168 @@ def decode_files_threaded(files, device=0, workers=16, batch_frames=4096, gpu_pa
     if errors:
         raise RuntimeError("decode failed for files %s: %r" % ([i for i, _ in errors], errors[0][1]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One stream across several GPUs: contiguous chunks of packets with a one-packet lead-in
+# ---------------------------------------------------------------------------------------------------------------------
+#
+# Packets of a stream are independent given the setup; the only coupling between neighbours is the overlap-add of
+# adjacent blocks (StreamDecoder.cs:440-445) and three integers of decoder state (_hasPosition, _currentPosition and
+# the previous block's geometry).  A decoder that is given packet k-1 first emits nothing for it (the reference's
+# "first packet" rule, :446-450 -- the same pre-roll SeekTo uses, :602-623) and from packet k on produces exactly the
+# samples the serial decoder produces there.  So a stream is cut into `world` chunks; rank r decodes
+# packets [first_r - 1, last_r) and keeps everything it emits; the concatenation is byte-identical to a serial decode.
+# What has to be known per cut is integer geometry only: plan_stream_chunks runs the host parser over the packets
+# (in its light mode when a GPU context is given: packet type, mode number and window flags only) and records the
+# serial decoder's position state and emitted-sample count at every cut.
+
+
+def _push_range(st, packets, granules, flags, lo, hi):
+    """Push packets [lo, hi); stops at the stream's end-of-stream packet.  Returns the index after the last one pushed."""
+    from .reader import PacketArray
+    i = lo
+    if isinstance(packets, PacketArray):
+        while i < hi and not st.position()[2]:
+            took = st.push_packets(packets, i, hi - i)
+            if took == 0:
+                break
+            i += took
+        return i
+    while i < hi and not st.position()[2]:
+        st.push_packet(packets[i], granules[i], flags[i])
+        i += 1
+    return i
+
+
+def plan_stream_chunks(packets, granules, flags, world, ctx=None):
+    """Cut points for decoding one logical stream (packets[0:3] = its headers) as `world` contiguous chunks.
+
+    Returns a list of dicts, one per chunk (possibly fewer than `world` for very short streams):
+      first, last   the chunk emits the samples the serial decoder emits while it processes packets [first, last)
+      has_position, position   _hasPosition / _currentPosition of the serial decoder before packet `first`
+      emitted0, emitted1       samples per channel the serial decoder has emitted before packet `first` / `last`
+                               (emitted1 of the final chunk includes the end-of-stream drain or trim)
+    A cut is only placed after a packet that decodes and whose own overlap does not reach into its tail (otherwise the
+    lead-in packet alone would not reproduce the tail the next packet overlaps with); the host parser's geometry says so.
+    """
+    from .reader import Stream
+    from . import native
+    n = len(packets)
+    st = Stream(ctx, packets[0], packets[1], packets[2])
+    try:
+        if ctx is not None:
+            try:
+                st.set_gpu_parse(True)  # light parse: geometry only
+            except native.NvhError as e:
+                if e.code != native.ERR_UNSUPPORTED:
+                    raise
+        cuts = []  # (first, has_position, position, emitted)
+        cur = 3
+        world = max(1, int(world))
+        for r in range(1, world):
+            target = 3 + ((n - 3) * r) // world
+            k = max(target, cur + 1, 4)
+            placed = False
+            while k < n and not placed:
+                cur = _push_range(st, packets, granules, flags, cur, k - 1)
+                if cur < k - 1 or st.position()[2]:
+                    break  # the serial decoder stops pulling packets here (_eosFound)
+                st.drop_pending()
+                st.push_packet(packets[k - 1], granules[k - 1], flags[k - 1])
+                cur = k
+                if st.position()[2]:
+                    break
+                geo = st.pending_geometry()
+                ok = len(geo) >= 1 and geo[-1][0] > 0 and (geo[-1][7] == 0 or geo[-1][1] + geo[-1][7] <= geo[-1][2])
+                # a packet that was rejected appends no frame of its own (a drain may append a pseudo-frame with n == 0)
+                if ok:
+                    has, pos = st.position_state()
+                    cuts.append((k, has, pos, st.position()[1]))
+                    placed = True
+                else:
+                    k += 1
+            st.drop_pending()
+            if not placed:
+                break
+        cur = _push_range(st, packets, granules, flags, cur, n)
+        if not st.position()[2]:
+            st.push_end()
+        total = st.position()[1]
+    finally:
+        st.close()
+    chunks = []
+    bounds = [(3, False, 0, 0)] + cuts
+    for i, (first, has, pos, em) in enumerate(bounds):
+        last = bounds[i + 1][0] if i + 1 < len(bounds) else n
+        em1 = bounds[i + 1][3] if i + 1 < len(bounds) else total
+        chunks.append({"first": first, "last": last, "has_position": has, "position": pos, "emitted0": em, "emitted1": em1})
+    return chunks
+
+
+def decode_stream_chunk(ctx, packets, granules, flags, chunk, final, batch_frames=4096, gpu_parse=True, clip=True):
+    """Decode one chunk of plan_stream_chunks on the GPU of `ctx`; returns (interleaved float32 PCM, has_clipped).
+
+    The lead-in packet (chunk['first'] - 1) is pushed without granule or flags -- the serial decoder's position state at
+    the cut already accounts for them -- then the state is set and the chunk's own packets follow.  Only the stream's
+    final chunk ends with the provider running dry (push_end); the others simply stop: the tail of their last block is
+    emitted by the next chunk."""
+    from .reader import Stream
+    from . import native
+    st = Stream(ctx, packets[0], packets[1], packets[2])
+    try:
+        st.set_clip(clip)
+        if gpu_parse:
+            try:
+                st.set_gpu_parse(True)
+            except native.NvhError as e:
+                if e.code != native.ERR_UNSUPPORTED:
+                    raise
+        first, last = chunk["first"], chunk["last"]
+        if first > 3:
+            st.push_packet(packets[first - 1], -1, 0)
+        st.set_position_state(chunk["has_position"], chunk["position"])
+        want = (chunk["emitted1"] - chunk["emitted0"]) * st.channels
+        pcm = np.empty(want, dtype=np.float32)  # every batch is read back straight into its place
+        got, cur = 0, first
+        while True:
+            hi = min(last, cur + batch_frames)
+            cur2 = _push_range(st, packets, granules, flags, cur, hi)
+            done = cur2 >= last or cur2 < hi or st.position()[2]
+            cur = cur2
+            if done and final and not st.position()[2]:
+                st.push_end()
+            if st.pending()[0]:
+                need = st.pending()[1] * st.channels
+                if got + need > want:
+                    raise RuntimeError("chunk [%d, %d) produces more than the %d floats the plan says" % (first, last, want))
+                got += st.synth_host(out=pcm[got:]).size
+            if done:
+                break
+        if got != want:
+            raise RuntimeError("chunk [%d, %d) produced %d floats, the plan says %d" % (first, last, got, want))
+        return pcm, st.has_clipped()
+    finally:
+        st.close()
+
+
+def decode_stream_sharded(packets, granules, flags, rank=0, world=1, dist=None, device="cpu", ctx=None, decode_chunk_fn=None,
+                          batch_frames=4096):
+    """Decode ONE logical stream with `world` ranks (one GPU each): rank r decodes chunk r of plan_stream_chunks, the PCM
+    is gathered to rank 0 (gather_pcm: sample counts all_gather + point-to-point payloads) and concatenated there.
+    Returns the interleaved PCM on rank 0 (None elsewhere); byte-identical to a serial decode.
+
+    decode_chunk_fn(chunk, final) -> float32 PCM replaces the GPU decode (the CPU test suite passes the oracle)."""
+    chunks = plan_stream_chunks(packets, granules, flags, world, ctx)
+    local = {}
+    for i in range(rank, len(chunks), world):  # fewer chunks than ranks for very short streams
+        final = i == len(chunks) - 1
+        if decode_chunk_fn is not None:
+            pcm = decode_chunk_fn(chunks[i], final)
+        else:
+            pcm, _ = decode_stream_chunk(ctx, packets, granules, flags, chunks[i], final, batch_frames=batch_frames)
+        local[i] = np.ascontiguousarray(pcm, dtype=np.float32)
+    parts = gather_pcm(local, len(chunks), rank, world, dist, device)
+    if parts is None:
+        return None
+    return np.concatenate(parts) if parts else np.zeros(0, np.float32)

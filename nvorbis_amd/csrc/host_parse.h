@@ -71,6 +71,10 @@ class StreamParser {
   // position bookkeeping); floors and residues are left to kernels_parse.hip, which receives the packet bytes.
   void set_light(bool on) { light_ = on; }
   bool light() const { return light_; }
+  // _hasPosition / _currentPosition (StreamDecoder.cs:35-39): read and set by a caller that starts a decoder in the
+  // middle of a stream (what SeekTo leaves behind, :562-628; the chunked decode of nvorbis_amd/corpus.py)
+  bool has_position() const { return has_position_; }
+  void set_position_state(bool has, int64_t pos) { has_position_ = has; position_ = pos; }
   bool eos() const { return eos_found_; }
   int64_t position() const { return position_; }   // IStreamDecoder.SamplePosition after everything parsed was read
   int64_t emitted() const { return emitted_; }

@@ -791,6 +791,26 @@ extern "C" int nvh_stream_position(const nvh_stream* s, int64_t* position, int64
   return NVH_OK;
 }
 
+extern "C" int nvh_stream_position_state(const nvh_stream* s, int* has_position, int64_t* position) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  if (has_position) *has_position = s->parser->has_position() ? 1 : 0;
+  if (position) *position = s->parser->position();
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_set_position_state(nvh_stream* s, int has_position, int64_t position) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  s->parser->set_position_state(has_position != 0, position);
+  return NVH_OK;
+}
+
+extern "C" int nvh_stream_drop_pending(nvh_stream* s) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  s->pending.clear();
+  s->parser->begin_batch();  // later frames refer to the previous block as a carried tail
+  return NVH_OK;
+}
+
 extern "C" int nvh_stream_push_packet(nvh_stream* s, const uint8_t* data, int len, int64_t granule, int flags) {
   if (!s || (!data && len > 0) || len < 0) return NVH_ERR_ARGUMENT;
   static const uint8_t empty = 0;

@@ -198,6 +198,18 @@ class Stream:
         check(lib().nvh_stream_position(self._h, C.byref(pos), C.byref(em), C.byref(eos)), "nvh_stream_position")
         return pos.value, em.value, bool(eos.value)
 
+    def position_state(self):
+        """(_hasPosition, _currentPosition) after everything pushed so far was read."""
+        h, p = C.c_int(0), C.c_int64(0)
+        check(lib().nvh_stream_position_state(self._h, C.byref(h), C.byref(p)), "nvh_stream_position_state")
+        return bool(h.value), p.value
+
+    def set_position_state(self, has_position, position):
+        check(lib().nvh_stream_set_position_state(self._h, 1 if has_position else 0, int(position)), "nvh_stream_set_position_state")
+
+    def drop_pending(self):
+        check(lib().nvh_stream_drop_pending(self._h), "nvh_stream_drop_pending")
+
     def mode_decode(self, packet, d_block):
         """IMode.Decode on one packet: the windowed block before overlap into d_block [channels][block1] (device pointer).
         Returns None if the packet is not decoded, else (block_size, start, valid, total)."""
@@ -269,15 +281,23 @@ class Stream:
         check(lib().nvh_stream_has_clipped(self._h, C.byref(v)), "nvh_stream_has_clipped")
         return bool(v.value)
 
-    def synth_host(self, pinned=False):
+    def synth_host(self, pinned=False, out=None):
         """Synthesise the pending batch; returns interleaved float32 PCM (numpy).
+
+        out: a contiguous float32 array to write into (must hold the batch); the written prefix is returned.
 
         pinned=True: the result is a view of a page-locked buffer owned by this stream (written by the copy engine
         directly, no extra copy) and stays valid until the next call."""
         _, smp = self.pending()
         n = max(smp * self.channels, 1)
         wr = C.c_int64(0)
-        if pinned:
+        if out is not None:
+            if out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"] or out.size < smp * self.channels:
+                raise ValueError("out must be a contiguous float32 array that holds the pending batch")
+            if out.size == 0:
+                out = np.empty(1, dtype=np.float32)
+            n = out.size
+        elif pinned:
             if getattr(self, "_pin_cap", 0) < n:
                 if getattr(self, "_pin_ptr", None):
                     lib().nvh_pinned_free(self._pin_ptr)

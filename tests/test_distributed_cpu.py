@@ -61,3 +61,79 @@ def test_gloo_world2_gather_is_byte_identical(oracle, ogg_bytes):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == single
+
+
+# ---- one stream across ranks: contiguous packet chunks with a one-packet lead-in ----
+
+def _oracle_chunk_decoder(orc, pk, gr, fl):
+    """decode_chunk_fn for decode_stream_sharded backed by the CPU oracle: a fresh decoder over the headers, the lead-in
+    packet and the chunk's packets; the oracle has no way to stop without draining, so the drained tail is cut off at the
+    sample count the plan states."""
+    def fn(chunk, final):
+        first, last = chunk["first"], chunk["last"]
+        lo = first - 1 if first > 3 else 3
+        sel = list(pk[:3]) + list(pk[lo:last])
+        g = [-1, -1, -1] + list(gr[lo:last])
+        f = [0, 0, 0] + list(fl[lo:last])
+        pcm, info = orc.decode_packets(sel, g, f)
+        want = (chunk["emitted1"] - chunk["emitted0"]) * info["channels"]
+        assert pcm.size >= want, (first, last, pcm.size, want)
+        return pcm[:want]
+    return fn
+
+
+@pytest.mark.parametrize("name", ["1test", "2test", "3test", "issue6test"])
+@pytest.mark.parametrize("world", [2, 3, 7])
+def test_stream_chunk_plan_and_serial_equivalence(oracle, ogg_bytes, name, world):
+    """The chunk plan tiles the stream (contiguous packets, contiguous sample counts, the reference's total) and the
+    chunks decoded independently -- lead-in packet first -- concatenate to the serial decode, byte for byte."""
+    import nvorbis_amd as nv
+    from nvorbis_amd.corpus import decode_stream_sharded, plan_stream_chunks
+    pk, gr, fl = nv.demux_ogg(ogg_bytes[name])
+    chunks = plan_stream_chunks(pk, gr, fl, world)
+    assert chunks[0]["first"] == 3 and chunks[-1]["last"] == len(pk) and chunks[0]["emitted0"] == 0
+    for a, b in zip(chunks, chunks[1:]):
+        assert a["last"] == b["first"] and a["emitted1"] == b["emitted0"]
+    serial, info = oracle.decode_ogg(ogg_bytes[name])
+    assert chunks[-1]["emitted1"] * info["channels"] == serial.size
+    assert len(chunks) == min(world, len(chunks))
+    got = decode_stream_sharded(pk, gr, fl, decode_chunk_fn=_oracle_chunk_decoder(oracle, pk, gr, fl), world=1)
+    # world=1 above only means "this process decodes every chunk"; the plan itself was made for `world` chunks
+    assert got.tobytes() == serial.tobytes()
+    parts = [_oracle_chunk_decoder(oracle, pk, gr, fl)(c, i == len(chunks) - 1) for i, c in enumerate(chunks)]
+    assert np.concatenate(parts).tobytes() == serial.tobytes()
+
+
+def _chunk_worker(rank, world, port, data, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import nvorbis_amd as nv
+    from nvorbis_amd.corpus import decode_stream_sharded
+    from tests import oracle_py
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = oracle_py.load()
+    pk, gr, fl = nv.demux_ogg(data)
+    out = decode_stream_sharded(pk, gr, fl, rank, world, dist, "cpu", decode_chunk_fn=_oracle_chunk_decoder(orc, pk, gr, fl))
+    if rank == 0:
+        q.put(out.tobytes())
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_stream_chunks_byte_identical(oracle, ogg_bytes):
+    """One stream decoded by two ranks (each its own chunk, PCM gathered to rank 0) == the serial decode."""
+    import torch.multiprocessing as mp
+    data = ogg_bytes["3test"]
+    serial = oracle.decode_ogg(data)[0].tobytes()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, data, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == serial

@@ -618,3 +618,47 @@ def test_floor0_apply_operator(oracle, gpu_ctx):
     finally:
         st.close()
         oracle.L.orc_close(d)
+
+
+def _chunked_gpu(gpu_ctx, pk, gr, fl, world, gpu_parse, clip=True, batch_frames=64):
+    from nvorbis_amd.corpus import decode_stream_chunk, plan_stream_chunks
+    chunks = plan_stream_chunks(pk, gr, fl, world, gpu_ctx if gpu_parse else None)
+    parts, clipped = [], False
+    for i, c in enumerate(chunks):
+        pcm, cl = decode_stream_chunk(gpu_ctx, pk, gr, fl, c, i == len(chunks) - 1, batch_frames=batch_frames, gpu_parse=gpu_parse,
+                                      clip=clip)
+        parts.append(pcm)
+        clipped |= cl
+    return (np.concatenate(parts) if parts else np.zeros(0, np.float32)), chunks, clipped
+
+
+@pytest.mark.parametrize("name", ["1test", "2test", "3test", "issue6test"])
+@pytest.mark.parametrize("gpu_parse", [False, True])
+def test_stream_chunks_on_gpu_equal_serial(oracle, gpu_ctx, ogg_bytes, name, gpu_parse):
+    """SURVEY 8e, one stream over several GPUs: every chunk of the plan decoded by its own nvh_stream (lead-in packet,
+    then the serial decoder's position state) -- here one after the other on one GPU -- concatenates to the serial
+    decode and to the oracle, bit for bit, including issue6test's non-zero start position and end-of-stream drain."""
+    import nvorbis_amd as nv
+    pk, gr, fl = nv.demux_ogg(ogg_bytes[name])
+    ref, info = oracle.decode_ogg(ogg_bytes[name])
+    for world in (2, 5):
+        got, chunks, clipped = _chunked_gpu(gpu_ctx, pk, gr, fl, world, gpu_parse)
+        assert len(chunks) == world
+        assert got.size == ref.size
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, world)
+        assert clipped == info["has_clipped"]
+
+
+@pytest.mark.parametrize("name", ["stereo_res1_coupled", "three_ch_res2_misaligned", "equal_blocks_overrun"])
+@pytest.mark.parametrize("consistent", [True, False])
+def test_stream_chunks_synthetic(oracle, gpu_ctx, name, consistent):
+    """The same on random-bit streams, including inconsistent window flags: cuts are only placed where the lead-in
+    packet alone reproduces the tail the next packet overlaps with, so the result is still the serial one."""
+    from tests import synth_stream as ss
+    pk, gr, fl = ss.filtered_stream(oracle, name, 150, 31 + int(consistent), consistent_windows=consistent)
+    ref, _ = oracle.decode_packets(pk, gr, fl)
+    for world in (2, 4):
+        got, chunks, _ = _chunked_gpu(gpu_ctx, pk, gr, fl, world, False)
+        assert len(chunks) >= 2
+        assert got.size == ref.size
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, consistent, world)
