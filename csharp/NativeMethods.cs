@@ -56,6 +56,10 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern int nvh_overlap_buffers(IntPtr ctx, IntPtr dPrevious, IntPtr dNext, int prevStart, int prevStop, int nextStart, int channels, long planeStride);
         /// <summary>ClippingCopyBuffer / CopyBuffer (StreamDecoder.cs:391-415).</summary>
         [DllImport(Lib)] public static extern int nvh_copy_buffer(IntPtr ctx, IntPtr dPlanes, int start, int count, int channels, long planeStride, IntPtr dTarget, int clip, out int clipped);
+        /// <summary>_hasPosition / _currentPosition (StreamDecoder.cs:35-39); set when a decoder starts mid-stream.</summary>
+        [DllImport(Lib)] public static extern int nvh_stream_position_state(IntPtr stream, out int hasPosition, out long position);
+        [DllImport(Lib)] public static extern int nvh_stream_set_position_state(IntPtr stream, int hasPosition, long position);
+        [DllImport(Lib)] public static extern int nvh_stream_drop_pending(IntPtr stream);
         [DllImport(Lib)] public static extern int nvh_stream_mode_info(IntPtr stream, int modeIndex, out int blockFlag, out int blockSize, out int mapping);
         [DllImport(Lib)] public static extern int nvh_stream_floor_info(IntPtr stream, int floorIndex, out int type, out int postCount, out int range);
         [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);
