@@ -240,6 +240,15 @@ struct nvh_stream {
 
 // ------------------------------------------------------------------------------------------------
 
+// hipEvent that is destroyed on every path out of a function (the HIP_TRY macro returns early).
+struct ScopedEvent {
+  hipEvent_t e = nullptr;
+  ~ScopedEvent() {
+    if (e) (void)hipEventDestroy(e);
+  }
+  int create() { HIP_TRY(hipEventCreate(&e)); return NVH_OK; }
+};
+
 static int ensure_device(int device) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -1321,9 +1330,14 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   float* work = (float*)b->work.p;
   int* flags = (int*)s->flags.p;
   const size_t lds = (size_t)s->setup.block1 * sizeof(float);
+  ScopedEvent sev[5];
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (timing)
-    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    for (int k = 0; k < 5; k++) {
+      int rc = sev[k].create();
+      if (rc != NVH_OK) return rc;
+      ev[k] = sev[k].e;
+    }
   if (timing) HIP_TRY(hipEventRecord(ev[0], st));
   // compact hand-over (two independent quarters per block, windowed in the overlap kernel) whenever no overlap
   // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
@@ -1436,7 +1450,6 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
       HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
       kernel_ms[k] += ms;
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   return NVH_OK;
 }
@@ -1564,6 +1577,7 @@ extern "C" int nvh_floor1_apply(nvh_stream* s, int floor_index, int block_size, 
   if (!s->ctx) return NVH_ERR_NO_GPU;
   if (batch == 0) return NVH_OK;
   const int pc = (int)f.f1.x_list.size();
+  if (pc > NVH_MAX_POSTS) return NVH_ERR_RUNTIME;  // Data.Posts = new int[64] (Floor1.cs:12): Unpack itself throws for such a floor
   // Unpack leaves either no posts or all of them (Floor1.cs:135-184); the values are sums of codebook entries
   std::vector<uint16_t> h_posts((size_t)batch * NVH_MAX_POSTS, 0);
   for (int b = 0; b < batch; ++b) {
@@ -1822,21 +1836,20 @@ extern "C" int nvh_batch_time(nvh_batch* b, float* d_pcm, int64_t capacity, int 
     for (int k = 0; k < 4; k++) kernel_ms[k] = km[k] / (float)iters;
   }
   if (total_ms) {
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, st));
+    ScopedEvent e0, e1;
+    int rc = e0.create();
+    if (rc == NVH_OK) rc = e1.create();
+    if (rc != NVH_OK) return rc;
+    HIP_TRY(hipEventRecord(e0.e, st));
     for (int i = 0; i < iters; i++) {
-      int rc = batch_launch(b, (const float*)b->carry_in.p, (float*)s->carry[s->carry_cur].p, d_pcm, false, nullptr);
+      rc = batch_launch(b, (const float*)b->carry_in.p, (float*)s->carry[s->carry_cur].p, d_pcm, false, nullptr);
       if (rc != NVH_OK) return rc;
     }
-    HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventRecord(e1.e, st));
+    HIP_TRY(hipEventSynchronize(e1.e));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&ms, e0.e, e1.e));
     *total_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
   }
   return collect_flags(s);
 }
