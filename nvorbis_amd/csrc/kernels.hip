@@ -737,10 +737,8 @@ __device__ __forceinline__ int ola_vec(const NvhDevSetup& S, const NvhFrame& fr,
   return clipped;
 }
 
-#ifndef NVH_OLA_THREADS
-#define NVH_OLA_THREADS 64
-#endif
-extern "C" __global__ void __launch_bounds__(NVH_OLA_THREADS)
+#define NVH_OLA_THREADS ((int)blockDim.x)
+extern "C" __global__ void __launch_bounds__(256)
 k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const float* __restrict__ carry,
               float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag, float* __restrict__ carry_out, int last_decoded) {
   const int f = blockIdx.x;
