@@ -23,6 +23,7 @@ namespace NVorbis.Hip
         float[] _ring = Array.Empty<float>();
         int _ringPos, _ringLen;
         bool _ended, _clip = true;
+        long _skip;   // floats to drop in front of the next samples: SeekTo's roll-forward
 
         public GpuStreamDecoder(Contracts.IPacketProvider packetProvider, int device = 0, int batchPackets = 1024)
         {
@@ -59,9 +60,12 @@ namespace NVorbis.Hip
         public bool IsEndOfStream => _ended && _ringPos >= _ringLen;
         public long SamplePosition
         {
-            get { NativeMethods.Check(NativeMethods.nvh_stream_position(_stream, out long pos, out _, out _)); return pos - (_ringLen - _ringPos) / _channels; }
-            set => throw new NotSupportedException("seeking is outside the accelerated path (SURVEY 8 f3)");
+            get { NativeMethods.Check(NativeMethods.nvh_stream_position(_stream, out long pos, out _, out _)); return pos - (_ringLen - _ringPos) / _channels + _skip / _channels; }
+            set => SeekTo(value);
         }
+        public TimeSpan TimePosition { get => TimeSpan.FromSeconds((double)SamplePosition / _sampleRate); set => SeekTo(value); }
+        public long TotalSamples => _packetProvider.GetGranuleCount();                       // StreamDecoder.cs:700
+        public TimeSpan TotalTime => TimeSpan.FromSeconds((double)TotalSamples / _sampleRate);
 
         // Parse up to _batchPackets packets ahead on the host, synthesise them on the GPU in one go.
         bool Refill()
@@ -103,6 +107,7 @@ namespace NVorbis.Hip
             while (idx < tgt)
             {
                 if (_ringPos >= _ringLen && !Refill()) break;
+                if (_skip > 0) { int drop = (int)Math.Min(_skip, _ringLen - _ringPos); _ringPos += drop; _skip -= drop; continue; }
                 int take = Math.Min(tgt - idx, _ringLen - _ringPos);
                 new Span<float>(_ring, _ringPos, take).CopyTo(buffer.Slice(idx, take));
                 _ringPos += take; idx += take;
@@ -116,8 +121,61 @@ namespace NVorbis.Hip
             if (_ctx != IntPtr.Zero) { NativeMethods.nvh_ctx_destroy(_ctx); _ctx = IntPtr.Zero; }
         }
 
-        // members of IStreamDecoder that sit outside the accelerated path
-        public void SeekTo(long samplePosition, System.IO.SeekOrigin seekOrigin = System.IO.SeekOrigin.Begin) => throw new NotSupportedException();
-        public void SeekTo(TimeSpan timePosition, System.IO.SeekOrigin seekOrigin = System.IO.SeekOrigin.Begin) => throw new NotSupportedException();
+        // StreamDecoder.SeekTo (StreamDecoder.cs:552-628).  The page / packet search stays the reference's
+        // (IPacketProvider.SeekTo, Ogg/PacketProvider.cs:56-260, fed by GetPacketGranules below); the decoder side is
+        // ResetDecoder + pre-roll packet + position, and the roll-forward is taken off the front of the next samples.
+        public void SeekTo(TimeSpan timePosition, System.IO.SeekOrigin seekOrigin = System.IO.SeekOrigin.Begin)
+            => SeekTo((long)(SampleRate * timePosition.TotalSeconds), seekOrigin);
+
+        public void SeekTo(long samplePosition, System.IO.SeekOrigin seekOrigin = System.IO.SeekOrigin.Begin)
+        {
+            if (_stream == IntPtr.Zero) throw new ObjectDisposedException(nameof(GpuStreamDecoder));
+            if (!_packetProvider.CanSeek) throw new InvalidOperationException("Seek is not supported by the Contracts.IPacketProvider instance.");
+            switch (seekOrigin)
+            {
+                case System.IO.SeekOrigin.Begin: break;
+                case System.IO.SeekOrigin.Current: samplePosition = SamplePosition - samplePosition; break;   // sic (:573)
+                case System.IO.SeekOrigin.End: samplePosition = TotalSamples - samplePosition; break;
+                default: throw new ArgumentOutOfRangeException(nameof(seekOrigin));
+            }
+            if (samplePosition < 0) throw new ArgumentOutOfRangeException(nameof(samplePosition));
+
+            int rollForward;
+            if (samplePosition == 0) { _packetProvider.SeekTo(0, 0, GetPacketGranules); rollForward = 0; }
+            else { var pos = _packetProvider.SeekTo(samplePosition, 1, GetPacketGranules); rollForward = (int)(samplePosition - pos); }
+
+            NativeMethods.Check(NativeMethods.nvh_stream_reset(_stream));          // ResetDecoder (:599)
+            _ringPos = _ringLen = 0; _ended = false;
+            // the pre-roll packet: a first packet, emits nothing, only provides the overlap (:602-614)
+            var preRoll = _packetProvider.GetNextPacket();
+            if (preRoll == null)
+            {
+                _ended = true;
+                if (_packetProvider.GetGranuleCount() != samplePosition)
+                    throw new InvalidOperationException("Could not read pre-roll packet!  Try seeking again prior to reading more samples.");
+                NativeMethods.Check(NativeMethods.nvh_stream_set_position_state(_stream, 1, samplePosition));
+                return;
+            }
+            byte[] data = ReadAll(preRoll);
+            fixed (byte* p = data)
+                NativeMethods.Check(NativeMethods.nvh_stream_push_packet(_stream, p, data.Length, -1, 0));
+            NativeMethods.Check(NativeMethods.nvh_stream_pending(_stream, out int frames, out _));
+            if (frames == 0) { _ended = true; throw new InvalidOperationException("Could not read pre-roll packet!  Try seeking again prior to reading more samples."); }
+            // _hasPosition = true (:600); the samples of the packet that follows start at samplePosition - rollForward, and
+            // Read drops rollForward of them (_prevPacketStart += rollForward; _currentPosition = samplePosition, :625-626)
+            NativeMethods.Check(NativeMethods.nvh_stream_set_position_state(_stream, 1, samplePosition - rollForward));
+            _skip = (long)rollForward * _channels;
+        }
+
+        // StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647), computed natively from the packet's first bits
+        int GetPacketGranules(IPacket packet)
+        {
+            if (packet.IsResync) return 0;
+            var head = new byte[8];
+            int n = packet.Read(head, 0, head.Length);
+            fixed (byte* p = head)
+                NativeMethods.Check(NativeMethods.nvh_stream_packet_sample_count(_stream, p, n, 0, out int count));
+            return count;
+        }
     }
 }

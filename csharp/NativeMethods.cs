@@ -60,6 +60,12 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern int nvh_stream_position_state(IntPtr stream, out int hasPosition, out long position);
         [DllImport(Lib)] public static extern int nvh_stream_set_position_state(IntPtr stream, int hasPosition, long position);
         [DllImport(Lib)] public static extern int nvh_stream_drop_pending(IntPtr stream);
+        /// <summary>StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647) from the first bytes of a packet.</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_packet_sample_count(IntPtr stream, byte* packet, int len, int isResync, out int count);
+        /// <summary>ResetDecoder (StreamDecoder.cs:295-305).</summary>
+        [DllImport(Lib)] public static extern int nvh_stream_reset(IntPtr stream);
+        /// <summary>Geometry-only index of a run of audio packets (positions, emitted samples, decodable / lead-in flags).</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_index_packets(IntPtr stream, byte* bytes, long* offsets, long* granules, byte* flags, int n, long* positionAfter, long* emittedAfter, byte* stateAfter, out long totalEmitted);
         [DllImport(Lib)] public static extern int nvh_stream_mode_info(IntPtr stream, int modeIndex, out int blockFlag, out int blockSize, out int mapping);
         [DllImport(Lib)] public static extern int nvh_stream_floor_info(IntPtr stream, int floorIndex, out int type, out int postCount, out int range);
         [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);

@@ -160,6 +160,28 @@ int nvh_stream_push_packets(nvh_stream *s, const uint8_t *bytes, const int64_t *
  * nvorbis_amd/corpus.py's chunked decode pushes one lead-in packet, then sets the state the serial decoder has there. */
 int nvh_stream_position_state(const nvh_stream *s, int *has_position, int64_t *position);
 int nvh_stream_set_position_state(nvh_stream *s, int has_position, int64_t position);
+/* Index of a run of `n` audio packets (packet i = bytes[offsets[i] .. offsets[i+1]), granule -1 = none, flags NVH_PKT_*;
+ * granules / flags may be NULL) as a serial decoder that starts with packet 0 of the run sees them -- the integer half of
+ * ReadNextPacket (StreamDecoder.cs:417-463) and Mode.GetPacketInfo (Mode.cs:119-151) only, no floor / residue bits:
+ *   position_after[i]  _currentPosition once everything packet i lets the decoder emit was read
+ *   emitted_after[i]   samples per channel emitted so far
+ *   state_after[i]     bit 0: the packet decodes; bit 1: and its overlap stays out of its own tail (a decoder may start
+ *                      right after it with this packet as its only lead-in); bit 2: _hasPosition; bit 3: _eosFound
+ * *total_emitted: samples per channel the whole run yields, including the drain of the last block's tail when the run
+ * ends without an end-of-stream packet (StreamDecoder.cs:352-356).  Any output pointer may be NULL.
+ * Host only; does not touch the stream's own state.  Callers: seeking and the chunked decode of nvorbis_amd. */
+int nvh_stream_index_packets(const nvh_stream *s, const uint8_t *bytes, const int64_t *offsets, const int64_t *granules,
+                             const uint8_t *flags, int n, int64_t *position_after, int64_t *emitted_after,
+                             uint8_t *state_after, int64_t *total_emitted);
+/* StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647): the sample count a packet stands for in the reference's
+ * page granule arithmetic (Mode.GetPacketSampleCount, Mode.cs:172-176); 0 for resync, non-audio and short packets and
+ * for an invalid mode number.  What a binding passes to IPacketProvider.SeekTo as its GetPacketGranuleCount delegate. */
+int nvh_stream_packet_sample_count(const nvh_stream *s, const uint8_t *pkt, int len, int is_resync, int *count);
+/* ResetDecoder (StreamDecoder.cs:295-305): previous block, position, end-of-stream and clipped flag forgotten, pending
+ * frames dropped; the next packet pushed is a first packet again (emits nothing, :446-450).  SeekTo = reset, push the
+ * pre-roll packet, nvh_stream_set_position_state(1, position of the packet that follows), carry on, discard the
+ * roll-forward samples (:596-627). */
+int nvh_stream_reset(nvh_stream *s);
 /* Forget the pending (parsed, not yet synthesised) frames without synthesising them: for callers that only want the
  * integer geometry (positions, sample counts) of a stretch of packets. */
 int nvh_stream_drop_pending(nvh_stream *s);

@@ -220,59 +220,36 @@ def plan_stream_chunks(packets, granules, flags, world, ctx=None):
       emitted0, emitted1       samples per channel the serial decoder has emitted before packet `first` / `last`
                                (emitted1 of the final chunk includes the end-of-stream drain or trim)
     A cut is only placed after a packet that decodes and whose own overlap does not reach into its tail (otherwise the
-    lead-in packet alone would not reproduce the tail the next packet overlaps with); the host parser's geometry says so.
+    lead-in packet alone would not reproduce the tail the next packet overlaps with); the host parser's geometry-only
+    index of the stream (nvh_stream_index_packets: packet type, mode number, window flags) says so.  `ctx` is unused
+    (the index is host work) and kept for callers that pass their context.
     """
-    from .reader import Stream
-    from . import native
-    n = len(packets)
-    st = Stream(ctx, packets[0], packets[1], packets[2])
+    from .reader import PacketArray, Stream
+    pa = PacketArray.from_list(packets, granules, flags)
+    n = len(pa)
+    st = Stream(None, pa[0], pa[1], pa[2])
     try:
-        if ctx is not None:
-            try:
-                st.set_gpu_parse(True)  # light parse: geometry only
-            except native.NvhError as e:
-                if e.code != native.ERR_UNSUPPORTED:
-                    raise
-        cuts = []  # (first, has_position, position, emitted)
-        cur = 3
-        world = max(1, int(world))
-        for r in range(1, world):
-            target = 3 + ((n - 3) * r) // world
-            k = max(target, cur + 1, 4)
-            placed = False
-            while k < n and not placed:
-                cur = _push_range(st, packets, granules, flags, cur, k - 1)
-                if cur < k - 1 or st.position()[2]:
-                    break  # the serial decoder stops pulling packets here (_eosFound)
-                st.drop_pending()
-                st.push_packet(packets[k - 1], granules[k - 1], flags[k - 1])
-                cur = k
-                if st.position()[2]:
-                    break
-                geo = st.pending_geometry()
-                ok = len(geo) >= 1 and geo[-1][0] > 0 and (geo[-1][7] == 0 or geo[-1][1] + geo[-1][7] <= geo[-1][2])
-                # a packet that was rejected appends no frame of its own (a drain may append a pseudo-frame with n == 0)
-                if ok:
-                    has, pos = st.position_state()
-                    cuts.append((k, has, pos, st.position()[1]))
-                    placed = True
-                else:
-                    k += 1
-            st.drop_pending()
-            if not placed:
-                break
-        cur = _push_range(st, packets, granules, flags, cur, n)
-        if not st.position()[2]:
-            st.push_end()
-        total = st.position()[1]
+        pos, em, state, total = st.index_packets(pa, 3)
     finally:
         st.close()
+    world = max(1, int(world))
+    cuts = []  # (first, has_position, position, emitted)
+    prev = 3
+    for r in range(1, world):
+        k = max(3 + ((n - 3) * r) // world, prev + 1, 4)
+        # the serial decoder stops pulling packets at _eosFound: no cut at or after that packet
+        while k < n and not (state[k - 4] & 8) and not (state[k - 4] & 2):
+            k += 1
+        if k >= n or (state[k - 4] & 8):
+            break
+        cuts.append((k, bool(state[k - 4] & 4), int(pos[k - 4]), int(em[k - 4])))
+        prev = k
     chunks = []
     bounds = [(3, False, 0, 0)] + cuts
-    for i, (first, has, pos, em) in enumerate(bounds):
+    for i, (first, has, p, e0) in enumerate(bounds):
         last = bounds[i + 1][0] if i + 1 < len(bounds) else n
-        em1 = bounds[i + 1][3] if i + 1 < len(bounds) else total
-        chunks.append({"first": first, "last": last, "has_position": has, "position": pos, "emitted0": em, "emitted1": em1})
+        e1 = bounds[i + 1][3] if i + 1 < len(bounds) else total
+        chunks.append({"first": first, "last": last, "has_position": has, "position": p, "emitted0": e0, "emitted1": e1})
     return chunks
 
 

@@ -813,6 +813,89 @@ extern "C" int nvh_stream_set_position_state(nvh_stream* s, int has_position, in
   return NVH_OK;
 }
 
+// Integer geometry of a run of audio packets as a serial decoder that starts with the first of them sees it (see
+// include/nvorbis_hip.h).  A parser of its own in light mode: no bits beyond the packet type, mode number and window
+// flags are read, nothing of `s` changes, no GPU is involved.
+extern "C" int nvh_stream_index_packets(const nvh_stream* s, const uint8_t* bytes, const int64_t* offsets, const int64_t* granules,
+                                        const uint8_t* flags, int n, int64_t* position_after, int64_t* emitted_after,
+                                        uint8_t* state_after, int64_t* total_emitted) {
+  if (!s || n < 0 || (n > 0 && (!bytes || !offsets))) return NVH_ERR_ARGUMENT;
+  nvh::StreamParser one(&s->setup);
+  one.set_light(true);
+  nvh::FrameBatch fb;
+  static const uint8_t empty = 0;
+  for (int i = 0; i < n; i++) {
+    const int64_t len = offsets[i + 1] - offsets[i];
+    if (len < 0 || len > 0x7FFFFFFF) return NVH_ERR_ARGUMENT;
+    uint8_t st = 0;
+    if (!one.eos()) {
+      const size_t before = fb.frames.size();
+      int rc = one.push_packet(len ? bytes + offsets[i] : &empty, (int)len, granules ? granules[i] : -1, flags ? flags[i] : 0, fb);
+      if (rc != NVH_OK) return rc;
+      if (fb.frames.size() > before && fb.frames.back().n > 0) {
+        const NvhFrame& f = fb.frames.back();
+        st |= 1;                                                      // the packet decodes (mode level)
+        if (f.ov_len == 0 || f.start + f.ov_len <= f.valid) st |= 2;  // its overlap stays out of its own tail
+      }
+    }
+    if (one.has_position()) st |= 4;
+    if (one.eos()) st |= 8;  // _eosFound: the serial decoder pulls nothing after this packet
+    if (position_after) position_after[i] = one.position();
+    if (emitted_after) emitted_after[i] = one.emitted();
+    if (state_after) state_after[i] = st;
+    if (fb.frames.size() >= 1024) {
+      fb.clear();
+      one.begin_batch();
+    }
+  }
+  if (total_emitted) {
+    int rc = one.push_end(fb);  // the provider runs dry: the last block's tail is drained unless _eosFound (StreamDecoder.cs:352-356)
+    if (rc != NVH_OK) return rc;
+    *total_emitted = one.emitted();
+  }
+  return NVH_OK;
+}
+
+// StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647) -> Mode.GetPacketSampleCount (Mode.cs:172-176): the number of
+// samples a packet stands for in the page granule arithmetic of the reference's seek (Ogg/PacketProvider.cs:74-146).
+extern "C" int nvh_stream_packet_sample_count(const nvh_stream* s, const uint8_t* pkt, int len, int is_resync, int* count) {
+  if (!s || !count || (!pkt && len > 0) || len < 0) return NVH_ERR_ARGUMENT;
+  *count = 0;
+  if (is_resync) return NVH_OK;  // a resync packet carries no audio data to return
+  static const uint8_t empty = 0;
+  nvh::BitReader p(pkt ? pkt : &empty, len);
+  if (p.read_bit()) return NVH_OK;  // not an audio packet
+  const int mode_idx = (int)p.read(s->setup.mode_field_bits);
+  if (mode_idx < 0 || mode_idx >= (int)s->setup.modes.size()) return NVH_OK;
+  const nvh::Mode& m = s->setup.modes[(size_t)mode_idx];
+  if (p.is_short) return NVH_OK;  // Mode.GetPacketInfo: IsShort is looked at before the flag bits (Mode.cs:121-128)
+  if (m.block_flag) {
+    const bool prev_flag = p.read_bit();
+    const bool next_flag = p.read_bit();
+    const int wi = (prev_flag ? 1 : 0) + (next_flag ? 2 : 0);
+    *count = m.ov_valid[wi] - m.ov_start[wi];
+  } else {
+    *count = m.block_size / 2;
+  }
+  return NVH_OK;
+}
+
+// ResetDecoder (StreamDecoder.cs:295-305): forget the previous block, the position, end of stream and the clipped flag;
+// the next packet pushed is a "first packet" again.  Pending frames are dropped.
+extern "C" int nvh_stream_reset(nvh_stream* s) {
+  if (!s) return NVH_ERR_ARGUMENT;
+  s->pending.clear();
+  s->parser.reset(new (std::nothrow) nvh::StreamParser(&s->setup));
+  if (!s->parser) return NVH_ERR_NOMEM;
+  s->parser->set_light(s->gpu_parse);
+  s->has_clipped = 0;
+  if (s->ctx && s->flags.p) {
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipMemsetAsync(s->flags.p, 0, 2 * sizeof(int), s->ctx->stream));
+  }
+  return NVH_OK;
+}
+
 extern "C" int nvh_stream_drop_pending(nvh_stream* s) {
   if (!s) return NVH_ERR_ARGUMENT;
   s->pending.clear();

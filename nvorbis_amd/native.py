@@ -53,6 +53,9 @@ SIGNATURES = {
     "nvh_stream_position_state": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "nvh_stream_set_position_state": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "nvh_stream_drop_pending": (C.c_int, [_vp]),
+    "nvh_stream_packet_sample_count": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "nvh_stream_reset": (C.c_int, [_vp]),
+    "nvh_stream_index_packets": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.POINTER(C.c_int64)]),
     "nvh_floor0_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64, _vp]),
     "nvh_floor1_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int64, _vp]),
     "nvh_stream_floor_info": (C.c_int, [_vp, C.c_int] + [C.POINTER(C.c_int)] * 3),

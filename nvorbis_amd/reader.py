@@ -34,6 +34,19 @@ class PacketArray:
             raise IndexError(i)
         return self.data[self.offsets[i]:self.offsets[i + 1]].tobytes()
 
+    @staticmethod
+    def from_list(packets, granules=None, flags=None):
+        """The same from a list of packet byte strings."""
+        if isinstance(packets, PacketArray):
+            return packets
+        n = len(packets)
+        offs = np.zeros(n + 1, np.int64)
+        offs[1:] = np.cumsum([len(p) for p in packets])
+        blob = np.frombuffer(b"".join(packets) or b"\0", dtype=np.uint8)
+        gr = np.asarray(granules if granules is not None else [-1] * n, np.int64)
+        fl = np.asarray(flags if flags is not None else [0] * n, np.uint8)
+        return PacketArray(blob, offs, gr if n else np.zeros(1, np.int64), fl if n else np.zeros(1, np.uint8))
+
 
 def demux_ogg_array(data: bytes):
     """First logical stream of an Ogg file as a PacketArray.
@@ -207,6 +220,29 @@ class Stream:
     def set_position_state(self, has_position, position):
         check(lib().nvh_stream_set_position_state(self._h, 1 if has_position else 0, int(position)), "nvh_stream_set_position_state")
 
+    def index_packets(self, pa, first=3):
+        """Integer geometry of the audio packets pa[first:] as a serial decoder sees them (nvh_stream_index_packets).
+        Returns (position_after, emitted_after, state_after, total_emitted); state bits: 1 decodes, 2 safe lead-in,
+        4 _hasPosition, 8 _eosFound."""
+        n = max(0, len(pa) - first)
+        pos, em, st = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.uint8)
+        total = C.c_int64(0)
+        check(lib().nvh_stream_index_packets(self._h, pa.data.ctypes.data, pa.offsets[first:].ctypes.data if n else pa.offsets.ctypes.data,
+                                             pa.granules[first:].ctypes.data if n else None, pa.flags[first:].ctypes.data if n else None,
+                                             n, pos.ctypes.data, em.ctypes.data, st.ctypes.data, C.byref(total)), "nvh_stream_index_packets")
+        return pos[:n], em[:n], st[:n], total.value
+
+    def packet_sample_count(self, packet, is_resync=False):
+        """StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647)."""
+        n = C.c_int(0)
+        check(lib().nvh_stream_packet_sample_count(self._h, packet, len(packet), 1 if is_resync else 0, C.byref(n)),
+              "nvh_stream_packet_sample_count")
+        return n.value
+
+    def reset(self):
+        """ResetDecoder (StreamDecoder.cs:295-305)."""
+        check(lib().nvh_stream_reset(self._h), "nvh_stream_reset")
+
     def drop_pending(self):
         check(lib().nvh_stream_drop_pending(self._h), "nvh_stream_drop_pending")
 
@@ -351,10 +387,17 @@ class StreamDecoder:
             except native.NvhError as e:
                 if e.code != native.ERR_UNSUPPORTED:
                     raise
+        self._ctx = ctx
+        self._gpu_parse = bool(gpu_parse)
+        self._index = None
+        self._skip = 0  # floats to discard in front of the next samples (roll-forward after a seek)
         self._packets = packets
         self._array = packets if isinstance(packets, PacketArray) else None  # batched push, no per-packet FFI call
-        self._granules = granules if granules is not None else [-1] * len(packets)
-        self._flags = flags if flags is not None else [0] * len(packets)
+        if self._array is not None and granules is None and flags is None:
+            self._granules, self._flags = packets.granules, packets.flags
+        else:
+            self._granules = granules if granules is not None else [-1] * len(packets)
+            self._flags = flags if flags is not None else [0] * len(packets)
         self._next = 3
         self._batch_frames = int(batch_frames)
         self._ring = np.zeros(0, dtype=np.float32)
@@ -382,7 +425,7 @@ class StreamDecoder:
     @property
     def SamplePosition(self):
         pos, _, _ = self._stream.position()
-        return pos - (self._ring.size - self._ring_pos) // self.Channels
+        return pos - (self._ring.size - self._ring_pos) // self.Channels + self._skip // self.Channels
 
     def _refill(self):
         """Parse up to batch_frames packets ahead and synthesise them."""
@@ -434,11 +477,91 @@ class StreamDecoder:
             if self._ring_pos >= self._ring.size:
                 if not self._refill():
                     break
+            if self._skip:  # SeekTo's roll-forward into the packet that holds the target (StreamDecoder.cs:625)
+                drop = min(self._skip, self._ring.size - self._ring_pos)
+                self._ring_pos += drop
+                self._skip -= drop
+                continue
             take = min(tgt - idx, self._ring.size - self._ring_pos)
             buffer[idx:idx + take] = self._ring[self._ring_pos:self._ring_pos + take]
             self._ring_pos += take
             idx += take
         return idx - offset
+
+    # ---- seeking (StreamDecoder.cs:562-628) ----
+    def _granule_index(self):
+        """Granule position after every audio packet, from the geometry-only index of the stream (host work, built once).
+        The reference derives the same numbers page by page from the page granule positions and the packets' nominal
+        sample counts (Ogg/PacketProvider.cs:74-146); for packets before the first page end they are back-filled from it."""
+        if self._index is None:
+            pa = PacketArray.from_list(self._packets, self._granules, self._flags)
+            pos, em, state, total = self._stream.index_packets(pa, 3)
+            gp = pos.copy()
+            synced = np.nonzero(state & 4)[0]
+            off = int(pos[synced[0]] - em[synced[0]]) if synced.size else 0
+            un = (state & 4) == 0
+            gp[un] = em[un] + off
+            self._index = (gp, state, total + off)
+        return self._index
+
+    @property
+    def TotalSamples(self):
+        """IPacketProvider.GetGranuleCount (StreamDecoder.cs:700): the largest page granule position."""
+        g = np.asarray(self._granules[3:] if len(self._granules) > 3 else [], dtype=np.int64)
+        g = g[g >= 0]
+        if g.size == 0:
+            raise native.NvhError(native.ERR_INVALID_DATA, "TotalSamples: no granule positions")
+        return int(g.max())
+
+    @property
+    def TotalTime(self):
+        return self.TotalSamples / float(self.SampleRate)
+
+    def SeekTo(self, sample_position, origin="begin"):
+        """StreamDecoder.SeekTo(long, SeekOrigin) (StreamDecoder.cs:562-628): the next Read returns the samples from
+        `sample_position` on -- the same floats a decode from the start yields there.  As in the reference the decoder
+        restarts one packet early (that packet's own output is discarded, it only provides the overlap) and rolls
+        forward inside the packet that holds the target.  origin: "begin", "current" (SamplePosition - value, as the
+        reference computes it), "end" (TotalSamples - value).  IndexError = ArgumentOutOfRangeException.
+
+        Not mirrored: the reference's page-granule corner cases (its treatment of the first two packets of a stream and
+        the workaround for a mis-counting encoder, Ogg/PacketProvider.cs:148-222); positions here follow the sample
+        counts a serial decode produces."""
+        s = int(sample_position)
+        if origin == "current":
+            s = self.SamplePosition - s
+        elif origin == "end":
+            s = self.TotalSamples - s
+        elif origin != "begin":
+            raise IndexError("origin")
+        if s < 0:
+            raise IndexError("samplePosition")
+        gp, state, end_pos = self._granule_index()
+        if gp.size == 0:
+            raise IndexError("samplePosition")
+        if s == 0 or s == int(gp[0]):
+            j, lead, roll, start_pos = 0, None, 0, (0 if s == 0 else int(gp[0]))
+        else:
+            if s < int(gp[0]) or s > end_pos:
+                raise IndexError("samplePosition")
+            j = int(np.searchsorted(gp, s, side="left"))  # first packet whose samples reach position s
+            if j >= gp.size:
+                j = gp.size - 1  # inside the drained tail of the last block
+                while j > 0 and gp[j - 1] >= s:
+                    j -= 1
+            lead = j - 1
+            if not (state[lead] & 1):
+                raise RuntimeError("Could not read pre-roll packet!")  # InvalidOperationException
+            roll, start_pos = s - int(gp[lead]), int(gp[lead])
+        self._stream.reset()  # ResetDecoder (:599)
+        if lead is not None:
+            self._stream.push_packet(self._packets[3 + lead], -1, 0)  # pre-roll: emits nothing (StreamDecoder.cs:446-450)
+        self._stream.set_position_state(True, start_pos)  # _hasPosition = true (:600); _currentPosition ends up at s
+        self._next = 3 + j
+        self._ring = np.zeros(0, dtype=np.float32)
+        self._ring_pos = 0
+        self._ended = False
+        self._skip = roll * self.Channels
 
     def close(self):
         self._stream.close()
@@ -462,7 +585,27 @@ class VorbisReader:
     SampleRate = property(lambda self: self._dec.SampleRate)
     IsEndOfStream = property(lambda self: self._dec.IsEndOfStream)
     HasClipped = property(lambda self: self._dec.HasClipped)
-    SamplePosition = property(lambda self: self._dec.SamplePosition)
+    TotalSamples = property(lambda self: self._dec.TotalSamples)
+    TotalTime = property(lambda self: self._dec.TotalTime)
+
+    @property
+    def SamplePosition(self):
+        return self._dec.SamplePosition
+
+    @SamplePosition.setter
+    def SamplePosition(self, value):  # VorbisReader.SamplePosition set => SeekTo (StreamDecoder.cs:714-718)
+        self._dec.SeekTo(value)
+
+    @property
+    def TimePosition(self):
+        return self._dec.SamplePosition / float(self.SampleRate)
+
+    @TimePosition.setter
+    def TimePosition(self, seconds):  # SeekTo(TimeSpan): (long)(SampleRate * TotalSeconds) (StreamDecoder.cs:552-555)
+        self._dec.SeekTo(int(self.SampleRate * float(seconds)))
+
+    def SeekTo(self, sample_position, origin="begin"):
+        self._dec.SeekTo(sample_position, origin)
 
     @property
     def ClipSamples(self):

@@ -662,3 +662,65 @@ def test_stream_chunks_synthetic(oracle, gpu_ctx, name, consistent):
         assert len(chunks) >= 2
         assert got.size == ref.size
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, consistent, world)
+
+
+@pytest.mark.parametrize("name", ["1test", "2test", "3test", "issue6test"])
+@pytest.mark.parametrize("gpu_parse", [False, True])
+def test_seek_returns_the_serial_samples(oracle, ogg_bytes, name, gpu_parse):
+    """SeekTo (StreamDecoder.cs:562-628): after a seek to position S the reader yields exactly what a decode from the
+    start yields from S on (pre-roll packet + roll-forward), SamplePosition reports S, for targets at packet boundaries,
+    inside long and short blocks, at the very start and in the drained tail; SamplePosition / TimePosition setters,
+    SeekOrigin arithmetic, out-of-range targets."""
+    import nvorbis_amd as nv
+    ref, info = oracle.decode_ogg(ogg_bytes[name])
+    ch = info["channels"]
+    rd = nv.VorbisReader(ogg_bytes[name], device=0, batch_frames=64, gpu_parse=gpu_parse)
+    try:
+        full = rd.read_all()
+        assert np.array_equal(full.view(np.uint32), ref.view(np.uint32))
+        end = rd.SamplePosition          # position after everything was read
+        first = end - ref.size // ch     # position of the first sample (63 for issue6test, else 0)
+        total = rd.TotalSamples
+        assert first >= 0 and total > 0
+        rng = np.random.default_rng(17)
+        targets = [first, first + 1, first + 127, first + 128, first + 129, first + 1024, end - 1, end - 700, (first + end) // 2]
+        targets += [int(t) for t in rng.integers(first, end, 12)]
+        buf = np.empty(5000 * ch, np.float32)
+        for t in targets:
+            if t < first or t >= end:
+                continue
+            rd.SeekTo(t)
+            assert rd.SamplePosition == t
+            n = rd.ReadSamples(buf, 0, buf.size)
+            want = ref[(t - first) * ch:(t - first) * ch + buf.size]
+            assert n == want.size, (t, n, want.size)
+            assert np.array_equal(buf[:n].view(np.uint32), want.view(np.uint32)), t
+            assert rd.SamplePosition == t + n // ch
+        # to the end of the stream: everything from a late position on, then end of stream
+        rd.SeekTo(end - 300)
+        tail = rd.read_all()
+        assert np.array_equal(tail.view(np.uint32), ref[(end - 300 - first) * ch:].view(np.uint32))
+        assert rd.IsEndOfStream and rd.ReadSamples(buf, 0, buf.size) == 0
+        # setters and origins
+        mid = (first + end) // 2
+        rd.SamplePosition = mid
+        assert rd.SamplePosition == mid
+        rd.SeekTo(100, "end")
+        assert rd.SamplePosition == total - 100
+        rd.SeekTo(50, "current")  # the reference computes SamplePosition - value (StreamDecoder.cs:573)
+        assert rd.SamplePosition == total - 150
+        secs = 0.25 * rd.TotalTime
+        rd.TimePosition = secs
+        assert rd.SamplePosition == int(rd.SampleRate * secs)
+        n = rd.ReadSamples(buf, 0, 64 * ch)
+        p = int(rd.SampleRate * secs) - first
+        assert np.array_equal(buf[:n].view(np.uint32), ref[p * ch:p * ch + n].view(np.uint32))
+        # back to the very beginning: position 0 restarts the stream
+        rd.SeekTo(0)
+        again = rd.read_all()
+        assert np.array_equal(again.view(np.uint32), ref.view(np.uint32))
+        for bad in (-1, end + 10_000_000):
+            with pytest.raises(IndexError):
+                rd.SeekTo(bad)
+    finally:
+        rd.close()

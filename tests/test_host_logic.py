@@ -191,3 +191,48 @@ def test_push_packets_equals_per_packet_push(ogg_bytes):
         assert (a.pending_geometry() == b.pending_geometry()).all()
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("name", ["1test", "2test", "3test", "issue6test"])
+def test_packet_index_and_sample_counts(oracle, ogg_bytes, name):
+    """Host-only geometry: nvh_stream_packet_sample_count == Mode.GetPacketSampleCount of the oracle (valid - start of
+    every decodable packet, 0 for the others, StreamDecoder.cs:630-647); nvh_stream_index_packets == the state of a
+    stream the same packets were pushed into one by one; reset makes the next packet a first packet again."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    pa = nv.demux_ogg_array(ogg_bytes[name])
+    st = nv.Stream(None, pa[0], pa[1], pa[2])
+    hdr = [pa[0], pa[1], pa[2]]
+    blob = np.frombuffer(b"".join(hdr), dtype=np.uint8)
+    offs = np.zeros(4, np.int64)
+    offs[1:] = np.cumsum([len(p) for p in hdr])
+    g3, f3, err = np.full(3, -1, np.int64), np.zeros(3, np.uint8), C.c_int(0)
+    d = oracle.L.orc_open_packets(blob.ctypes.data, offs.ctypes.data, g3.ctypes.data, f3.ctypes.data, 3, C.byref(err))
+    assert d
+    try:
+        planes = np.zeros(st.channels * st.block1, np.float32)
+        for i in range(3, len(pa)):
+            a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            rc = oracle.L.orc_decode_packet_block(d, pa[i], len(pa[i]), planes.ctypes.data, C.byref(a), C.byref(b), C.byref(c), C.byref(e))
+            want = (b.value - a.value) if rc == 1 else 0
+            assert st.packet_sample_count(pa[i]) == want, i
+            assert st.packet_sample_count(pa[i], is_resync=True) == 0
+        assert st.packet_sample_count(b"") == 0 and st.packet_sample_count(b"\x01") == 0
+        pos, em, state, total = st.index_packets(pa, 3)
+        for i in range(3, len(pa)):
+            if st.position()[2]:
+                break
+            st.push_packet(pa[i], int(pa.granules[i]), int(pa.flags[i]))
+            p, e, eos = st.position()
+            assert (p, e) == (int(pos[i - 3]), int(em[i - 3])), i
+            assert st.position_state()[0] == bool(state[i - 3] & 4) and eos == bool(state[i - 3] & 8)
+        if not st.position()[2]:
+            st.push_end()
+        assert st.position()[1] == total
+        st.reset()  # ResetDecoder
+        assert st.position() == (0, 0, False) and st.pending() == (0, 0) and st.position_state() == (False, 0)
+        st.push_packet(pa[3], -1, 0)
+        assert st.position()[1] == 0  # a first packet emits nothing again
+    finally:
+        st.close()
+        oracle.L.orc_close(d)
