@@ -907,9 +907,9 @@ k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* _
 // partitions, Residue0).
 extern "C" __global__ void __launch_bounds__(SP_THREADS)
 k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
-               int cap_ent) {
+               int cap_ent, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<false, false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem);
+  spectrum_body<false, false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg);
 }
 
 // Variant for setups that contain a Floor0 (double-precision cos / sqrt / exp: costs registers, kept apart).

@@ -36,7 +36,7 @@ __global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err,
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent,
                                  long long* dbg, int phase_mask);
-__global__ void k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
+__global__ void k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent, long long* dbg);
 __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
                             int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
@@ -1455,7 +1455,7 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
                            cap_pass, cap_ops, cap_ent);
       } else if (!fast) {
         hipLaunchKernelGGL(k_spectrum_gen, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
-                           cap_pass, cap_ops, cap_ent);
+                           cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf);
       } else {
         if (getenv("NVH_DEBUG_OCC")) {
           int nb = -1;
