@@ -423,16 +423,21 @@ __device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150
 // IMDCT (FAST only, block1 <= 2048): the inverse MDCT runs in the same workgroup, one wavefront per channel, straight
 // from the LDS spectrum, and the work planes receive the compact IMDCT output k_ola_compact expects -- the
 // spectrum never travels through HBM.
-template <bool FLOOR0, bool FAST, bool IMDCT = false>
+template <bool FLOOR0, bool FAST, bool IMDCT = false, int NT = SP_THREADS>
 __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDevBatch& Bt, float* __restrict__ work,
                                               int* __restrict__ err, int cap_pass, int cap_ops, int cap_ent, float* smem,
                                               long long* dbg = nullptr, int phase_mask = 7) {
   const int nch = S.channels;
-  const int ngrp_lds = nch < SP_GROUP ? nch : SP_GROUP;
+  // channels whose floors are prepared concurrently (one wavefront each, one scratch block each) on the general path
+  constexpr int grp = NT / 64;
+  const int ngrp_lds = nch < grp ? nch : grp;
   float* s_db = smem;
   float* s_coeff = smem + 256;  // FLOOR0 only
   FloorScratch* fs = reinterpret_cast<FloorScratch*>(smem + (FLOOR0 ? 512 : 256));
-  uint32_t* s_pass = reinterpret_cast<uint32_t*>(fs + ngrp_lds);  // per pass, 16 words: residue, op_begin[0..8] (frame relative), residue geometry (below)
+  // 8-wavefront variant (never the fused tail): the floors are prepared after the residue and coupling phases, when the
+  // staged side information is dead, so the floor scratch shares its storage
+  constexpr bool kAliasScratch = NT > SP_THREADS;
+  uint32_t* s_pass = reinterpret_cast<uint32_t*>(kAliasScratch ? fs : fs + ngrp_lds);  // per pass, 16 words: residue, op_begin[0..8] (frame relative), residue geometry (below)
   NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(s_pass + cap_pass * 16);
   uint32_t* s_lat = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(s_books) + S.nbooks * 8);
   NvhResOp* s_ops = reinterpret_cast<NvhResOp*>(s_lat + ((S.lattice_words + 3) & ~3));
@@ -440,6 +445,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   uint16_t* s_link = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(s_oprec) + cap_ops * 4);  // cap_ops % 8 == 0
   uint16_t* s_ent = s_link + cap_ops;
   float* spec = reinterpret_cast<float*>(s_ent) + (cap_ent >> 1);  // [ch][half], 16-byte aligned (cap_ent % 8 == 0)
+  if (kAliasScratch && spec < reinterpret_cast<float*>(fs + ngrp_lds)) spec = reinterpret_cast<float*>(fs + ngrp_lds);
 
   const int f = blockIdx.x;
 #define DBG_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + (k)] = clock64(); } while (0)
@@ -476,7 +482,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   if (wv < nprep) {
     if (phase_mask & 4) floor_prepare(&fs[wv], first_lane, lane, half, err);
   } else {
-    const int st = tid - nprep * 64, sn = SP_THREADS - nprep * 64;
+    const int st = tid - nprep * 64, sn = NT - nprep * 64;
     for (int i = st; i < 256; i += sn) s_db[i] = k_inverse_db[i];
     const uint4* gb = reinterpret_cast<const uint4*>(S.books);
     for (int i = st; i < S.nbooks * 2; i += sn) reinterpret_cast<uint4*>(s_books)[i] = gb[i];
@@ -524,7 +530,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     const int o_end = __builtin_amdgcn_readfirstlane((int)P[1 + NVH_MAX_STAGES]);
     const unsigned rch = __builtin_amdgcn_readfirstlane(P[11]), psz = __builtin_amdgcn_readfirstlane(P[12]);
     const unsigned rch_magic = __builtin_amdgcn_readfirstlane(P[14]), rbegin = __builtin_amdgcn_readfirstlane(P[15]);
-    for (int o = __builtin_amdgcn_readfirstlane((int)P[1]) + tid; o < o_end; o += SP_THREADS) {
+    for (int o = __builtin_amdgcn_readfirstlane((int)P[1]) + tid; o < o_end; o += NT) {
       const NvhResOp op = ops[o];
       const NvhDevBook bk = s_books[op.book];
       const unsigned offset = rbegin + (unsigned)op.partition * psz;
@@ -560,7 +566,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       const unsigned hp = (unsigned)psize >> 1;
       const unsigned o0 = __builtin_amdgcn_readfirstlane(P[1]), o1 = __builtin_amdgcn_readfirstlane(P[1 + NVH_MAX_STAGES]);
       const unsigned total = (o1 - o0) * hp;
-      for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
+      for (unsigned idx = tid; idx < total; idx += NT) {
         const unsigned oq = hp > 1 ? __umulhi(idx, hp_magic) : idx;
         const unsigned i2 = idx - oq * hp, i = i2 << 1;  // pair / first component index inside the partition
         unsigned o = o0 + oq;
@@ -625,7 +631,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         // lat_values digits of the entry number, peeled with exact reciprocal multiplies; nothing leaves LDS.
         const unsigned hp = (unsigned)psize >> 1;
         const unsigned total = (oe - ob) * hp;
-        for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
+        for (unsigned idx = tid; idx < total; idx += NT) {
           const unsigned o = hp > 1 ? __umulhi(idx, hp_magic) : idx;
           const unsigned i2 = idx - o * hp, i = i2 << 1;  // pair / first component index inside the partition
           const uint4 rec = s_oprec[ob + o];
@@ -672,12 +678,12 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         // elements of one stage never alias (that is what !sequential means), so four of them are fetched as
         // independent dependency chains before their adds are committed
         const int total = (int)(oe - ob) * psize;
-        for (int base = tid; base < total; base += 4 * SP_THREADS) {
+        for (int base = tid; base < total; base += 4 * NT) {
           float* tp[4];
           float tv[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * SP_THREADS;
+            const int idx = base + u * NT;
             tp[u] = nullptr;
             tv[u] = 0.0f;
             if (idx < total) {
@@ -694,7 +700,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       } else if (!(rflags & 0x200u)) {
         const NvhDevResidue R = *Rg;
         const int total = (int)(oe - ob) * psize;
-        for (int idx = tid; idx < total; idx += SP_THREADS) {
+        for (int idx = tid; idx < total; idx += NT) {
           unsigned o = (unsigned)idx / (unsigned)psize;
           int i = idx - (int)o * psize;
           const NvhResOp op = ops[ob + o];
@@ -709,7 +715,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           const NvhDevBook bk = s_books[op.book];
           const int dims = (int)bk.dim;
           const int cnt = ((psize + dims - 1) / dims) * dims;
-          for (int i = tid; i < cnt; i += SP_THREADS) residue_apply_lds(bk, S.vq, R, op, ent, fr.ent_begin, i, spec, half);
+          for (int i = tid; i < cnt; i += NT) residue_apply_lds(bk, S.vq, R, op, ent, fr.ent_begin, i, spec, half);
           __syncthreads();
         }
       }
@@ -739,7 +745,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     const int md0 = __builtin_amdgcn_readfirstlane(fs[0].mode), md1 = nch == 2 ? __builtin_amdgcn_readfirstlane(fs[1].mode) : 0;
     // TB bins per lane: the segment search and the recurrence restart are paid once per TB bins and channel
     constexpr int TB = SP_TAIL_BINS;
-    for (int x0 = tid * TB; x0 < half; x0 += SP_THREADS * TB) {
+    for (int x0 = tid * TB; x0 < half; x0 += NT * TB) {
       float r0[TB], r1[TB];
 #pragma unroll
       for (int q = 0; q < TB; q += 4) {
@@ -828,7 +834,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     if (chans[an].exec || chans[mg].exec) {
       float* M = spec + mg * half;
       float* Aa = spec + an * half;
-      for (int j = tid; j < half; j += SP_THREADS) {
+      for (int j = tid; j < half; j += NT) {
         float vm = M[j], va = Aa[j];
         couple1(vm, va);
         M[j] = vm;
@@ -839,25 +845,25 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   }
 
   DBG_T(4);
-  // floors, SP_GROUP channels at a time: wavefront w prepares channel c0 + w
-  for (int c0 = 0; c0 < nch; c0 += SP_GROUP) {
+  // floors, `grp` channels at a time: wavefront w < grp prepares channel c0 + w
+  for (int c0 = 0; c0 < nch; c0 += grp) {
     const FloorLane fl_lane = (c0 == 0) ? first_lane : load_floor_lane(S, Bt, chans, c0 + wv, nch, lane);
     if (c0 + wv < nch) floor_prepare(&fs[wv], fl_lane, lane, half, err);
     __syncthreads();
 
     // render / apply: all threads over the group's channels
-    const int ngrp = (nch - c0) < SP_GROUP ? (nch - c0) : SP_GROUP;
+    const int ngrp = (nch - c0) < grp ? (nch - c0) : grp;
     for (int k = 0; k < ngrp; ++k) {
       const int cc = c0 + k;
       const int md = __builtin_amdgcn_readfirstlane(fs[k].mode);
       float* res = spec + cc * half;
       if (md == 0) continue;
       if (md == 2) {
-        for (int i = tid; i < half; i += SP_THREADS) res[i] = 0.0f;  // Floor1.cs:218-221 / Floor0.cs:208-211
+        for (int i = tid; i < half; i += NT) res[i] = 0.0f;  // Floor1.cs:218-221 / Floor0.cs:208-211
         continue;
       }
       if (md == 1) {
-        for (int x0 = tid * 4; x0 < half; x0 += SP_THREADS * 4) {
+        for (int x0 = tid * 4; x0 < half; x0 += NT * 4) {
           float m[4];
           floor_walk<4>(&fs[k], s_db, x0, m);
           float4 v = *reinterpret_cast<float4*>(res + x0);
@@ -871,7 +877,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       }
       if (FLOOR0) {  // Floor0 (Floor0.cs:152-212)
         const NvhChan ck = chans[cc];
-        floor0_curve<SP_THREADS>(S, &S.floors[ck.floor].f0, Bt.coeffs + ck.data_off, ck.amp, fr.mdct_slot, res, half, s_coeff, tid, err);
+        floor0_curve<NT>(S, &S.floors[ck.floor].f0, Bt.coeffs + ck.data_off, ck.amp, fr.mdct_slot, res, half, s_coeff, tid, err);
       }
     }
     __syncthreads();
@@ -880,7 +886,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   DBG_T(5);
   // spectrum -> work planes
   const int q4 = half >> 2;
-  for (int i = tid; i < nch * q4; i += SP_THREADS) {
+  for (int i = tid; i < nch * q4; i += NT) {
     int c = i / q4, k = i - c * q4;
     reinterpret_cast<float4*>(planes + (long long)c * S.block1)[k] = reinterpret_cast<const float4*>(spec + c * half)[k];
   }
@@ -910,6 +916,15 @@ k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __r
                int cap_ent, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   spectrum_body<false, false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg);
+}
+
+// k_spectrum_gen with 8 wavefronts per workgroup, for more than four channels: 48 KB of spectrum (six channels, n = 4096)
+// leave 3 workgroups per CU, so the wavefronts have to come from inside the workgroup; all floors are unwrapped at once.
+extern "C" __global__ void __launch_bounds__(512)
+k_spectrum_gen8(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
+                int cap_ent, long long* dbg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  spectrum_body<false, false, false, 512>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg);
 }
 
 // Variant for setups that contain a Floor0 (double-precision cos / sqrt / exp: costs registers, kept apart).

@@ -37,6 +37,7 @@ __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* e
 __global__ void k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent,
                                  long long* dbg, int phase_mask);
 __global__ void k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent, long long* dbg);
+__global__ void k_spectrum_gen8(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent, long long* dbg);
 __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
                             int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
@@ -1436,12 +1437,18 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
   // LDS window; LDS map in kernels_spectrum.hip.
   {
     const bool has_floor0 = s->has_floor0;
-    const size_t fixed_words = (size_t)(has_floor0 ? 512 : 256) + (size_t)(ch < 4 ? ch : 4) * NVH_SP_FLOOR_SCRATCH_WORDS +
-                               (size_t)s->setup.books.size() * 8 + (size_t)((s->dev.lattice_words + 3) & ~3) +
-                               (size_t)ch * (size_t)(s->setup.block1 / 2);
+    // more than four channels without Floor0: 8 wavefronts per workgroup (k_spectrum_gen8), one floor scratch block each
+    static const int no_gen8 = getenv("NVH_NO_GEN8") ? 1 : 0;
+    const bool gen8 = !has_floor0 && !fast && ch > 4 && !no_gen8;
+    const int scratch_blocks = gen8 ? (ch < 8 ? ch : 8) : (ch < 4 ? ch : 4);
+    const size_t scratch_words = (size_t)scratch_blocks * NVH_SP_FLOOR_SCRATCH_WORDS;
     // staging capacities; the entry slice is copied from its enclosing 16-byte boundary (up to 7 entries of slack)
     int cap_pass = b->max_pass, cap_ops = (b->max_ops + 7) & ~7, cap_ent = (b->max_ent + 14) & ~7;
-    size_t words = fixed_words + (size_t)cap_pass * 16 + (size_t)cap_ops * 6 + (size_t)cap_ops / 2 + (size_t)cap_ent / 2;  // ops 2 + pair records 4 + links 1/2 words per op
+    const size_t staging_words = (size_t)s->setup.books.size() * 8 + (size_t)((s->dev.lattice_words + 3) & ~3) + (size_t)cap_pass * 16 +
+                                 (size_t)cap_ops * 6 + (size_t)cap_ops / 2 + (size_t)cap_ent / 2;  // ops 2 + pair records 4 + links 1/2 words per op
+    // k_spectrum_gen8 overlays the floor scratch on the staged side information (dead by the time the floors are prepared)
+    size_t words = (size_t)(has_floor0 ? 512 : 256) + (gen8 ? std::max(scratch_words, staging_words) : scratch_words + staging_words) +
+                   (size_t)ch * (size_t)(s->setup.block1 / 2);
     if (getenv("NVH_UNFUSED")) words = 1u << 20;  // test aid: force the unfused kernels below
     if ((words + (size_t)(s->setup.block1 / 16)) * 4 > 64 * 1024) fuse_imdct = false;
     static const int phase_mask = getenv("NVH_DEBUG_SPECTRUM_MASK") ? atoi(getenv("NVH_DEBUG_SPECTRUM_MASK")) : 7;  // profiling aid
@@ -1453,6 +1460,10 @@ static int batch_launch(nvh_batch* b, const float* carry, float* carry_out, floa
       if (has_floor0) {
         hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent);
+      } else if (gen8) {
+        b->slot_name[1] = "k_spectrum_gen8";
+        hipLaunchKernelGGL(k_spectrum_gen8, dim3((unsigned)b->nframes), dim3(512), words * 4, st, s->dev, b->dev, work, flags,
+                           cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf);
       } else if (!fast) {
         hipLaunchKernelGGL(k_spectrum_gen, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent, (long long*)g_dbg_buf);

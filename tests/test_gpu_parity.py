@@ -240,6 +240,24 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_six_channel_four_wavefront_kernel_bit_exact():
+    """Streams with more than four channels run k_spectrum_gen8 (8 wavefronts per workgroup); NVH_NO_GEN8 sends them
+    through k_spectrum_gen instead: the six-channel cases replayed in a child process."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NVH_TEST_CHILD"):
+        pytest.skip("already inside a fallback-path run")
+    env = dict(os.environ)
+    env["NVH_NO_GEN8"] = "1"
+    env["NVH_TEST_CHILD"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "six_ch", "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_threaded_corpus_decode_matches_serial(oracle, ogg_bytes):
     """File-parallel decode with a pool of host threads on one GPU (corpus.decode_files_threaded) returns, per file,
     exactly the oracle's PCM: concurrent contexts / HIP streams do not interfere."""
