@@ -60,7 +60,11 @@ void nvh_ctx_destroy(nvh_ctx *ctx);
 int nvh_ctx_set_hip_stream(nvh_ctx *ctx, void *hip_stream);
 int nvh_ctx_synchronize(nvh_ctx *ctx);
 
-/* ---- level 1: batched mirrors of the plug-in interface methods (device pointers) ---- */
+/* ---- level 1: batched mirrors of the plug-in interface methods (device pointers) ----
+ * nvh_inverse_couple, nvh_mdct_reverse, nvh_window_apply and nvh_overlap_buffers only enqueue their kernel on the
+ * context's stream (nvh_ctx_synchronize, or work queued on the same HIP stream, orders against them); the entry points
+ * that return per-item status or read packets (nvh_floor*_apply, nvh_residue_decode, nvh_copy_buffer, nvh_mode_decode)
+ * are synchronous. */
 
 /* One inverse square-polar coupling step over two device vectors of `count` floats, in place (Mapping.cs:150-178). */
 int nvh_inverse_couple(nvh_ctx *c, float *d_magnitude, float *d_angle, int count);
@@ -233,6 +237,15 @@ void nvh_batch_free(nvh_batch *b);
  * size, then again with buffers. */
 int nvh_ogg_demux(const uint8_t *bytes, size_t len, uint8_t *pkt_bytes, int64_t pkt_bytes_cap, int64_t *offsets,
                   int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets, int64_t *total_bytes);
+/* The same for logical stream `stream_index` of a multiplexed or chained file; *nstreams (may be NULL) = number of
+ * logical streams in the file.  A stream begins with the first page of a serial number that has no open stream, ends with
+ * its end-of-stream page (a later page with the same serial number starts another one); a page without packets is refused
+ * and its serial number ignored from then on (Ogg/PageReader.cs:126-158, Ogg/PageReaderBase.cs:72-85).  Streams that are
+ * not Vorbis are listed too: nvh_stream_open refuses them (NVH_ERR_NOT_VORBIS), as VorbisReader's new-stream callback
+ * does (VorbisReader.cs:74-87).  NVH_ERR_ARGUMENT for a stream_index past the last stream. */
+int nvh_ogg_demux_stream(const uint8_t *bytes, size_t len, int stream_index, uint8_t *pkt_bytes, int64_t pkt_bytes_cap,
+                         int64_t *offsets, int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets,
+                         int64_t *total_bytes, int *nstreams);
 
 #ifdef __cplusplus
 }

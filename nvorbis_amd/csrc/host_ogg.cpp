@@ -1,13 +1,14 @@
 // host_ogg.cpp -- minimal forward-only Ogg demux (product host code).
 //
 // The container is outside the accelerated path; this exists so that .ogg files can feed it.  It
-// reproduces what NVorbis' seekable reader delivers to StreamDecoder for the FIRST logical stream:
+// reproduces what NVorbis' seekable reader delivers to StreamDecoder for one logical stream of the file:
 //   page sync + CRC-32 (poly 0x04c11db7)                      Ogg/PageReaderBase.cs:33-70, Ogg/Crc.cs:5-40
 //   lacing -> packets; zero-length packets are dropped         Ogg/PageReader.cs:27-93
 //   a page without packets is rejected and blacklists the serial  Ogg/PageReader.cs:131, Ogg/PageReaderBase.cs:72-85
 //   continued packets; the granule position goes to the packet that is last on the page it completes
 //   on; end-of-stream to that packet of the EOS-flagged page    Ogg/PacketProvider.cs:324-438
-// Seeking, multiplexed / chained streams and the libvorbis granule workaround are not implemented.
+//   multiplexed / chained files: pages are routed by serial number to logical streams                Ogg/PageReader.cs:126-158
+// The page-level seek search and the libvorbis granule workaround are not implemented.
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -52,13 +53,23 @@ bool page_crc_ok(const uint8_t* pg, size_t total) {
 }  // namespace
 
 
-int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out) {
-  std::vector<Page> pages;
-  bool have_serial = false, has_all_pages = false, resync = false;
-  uint32_t serial = 0;
+int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index, int* nstreams) {
+  // Logical streams in the order their first page appears (Ogg/PageReader.cs:126-158): a page with a serial number that
+  // has no reader opens a new stream (multiplexed streams interleave their pages, chained streams follow one another);
+  // the end-of-stream page retires the serial, so a later page with the same number starts another stream; a page
+  // without packets is refused and its serial ignored from then on (Ogg/PageReaderBase.cs:72-85).
+  struct Logical {
+    uint32_t serial = 0;
+    std::vector<Page> pages;
+    bool has_all_pages = false;
+  };
+  std::vector<Logical> streams;
+  std::vector<std::pair<uint32_t, int>> active;  // serial -> index into streams
+  std::vector<uint32_t> ignored;
+  bool resync = false;
   size_t pos = 0;
 
-  while (pos + 27 <= len && !has_all_pages) {
+  while (pos + 27 <= len) {
     const uint8_t* h = bytes + pos;
     if (!(h[0] == 0x4f && h[1] == 0x67 && h[2] == 0x67 && h[3] == 0x53)) {
       ++pos;
@@ -80,11 +91,9 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out) {
       continue;
     }
     uint32_t pg_serial = (uint32_t)h[14] | ((uint32_t)h[15] << 8) | ((uint32_t)h[16] << 16) | ((uint32_t)h[17] << 24);
-    if (!have_serial) {
-      have_serial = true;
-      serial = pg_serial;
-    }
-    if (pg_serial == serial) {
+    bool skip = false;
+    for (uint32_t ig : ignored) skip = skip || ig == pg_serial;
+    if (!skip) {
       Page pg;
       pg.data_off = pos + 27 + (size_t)seg_cnt;
       pg.flags = h[5];
@@ -108,13 +117,44 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out) {
         pg.pk_off.push_back(off);
         pg.pk_len.push_back(size);
       }
-      if (pg.pk_off.empty()) break;  // rejected page: the serial is ignored from here on
-      if (pg.flags & 0x04) has_all_pages = true;
-      pages.push_back(std::move(pg));
+      int slot = -1;
+      for (size_t a = 0; a < active.size(); a++)
+        if (active[a].first == pg_serial) slot = (int)a;
+      if (pg.pk_off.empty()) {
+        // refused page: the serial is ignored from here on; a stream it would have opened does not come to exist
+        ignored.push_back(pg_serial);
+        if (slot >= 0) active.erase(active.begin() + slot);
+      } else {
+        if (slot < 0) {
+          Logical lg;
+          lg.serial = pg_serial;
+          streams.push_back(std::move(lg));
+          active.emplace_back(pg_serial, (int)streams.size() - 1);
+          slot = (int)active.size() - 1;
+        }
+        Logical& lg = streams[(size_t)active[(size_t)slot].second];
+        const bool eos_page = (pg.flags & 0x04) != 0;
+        lg.pages.push_back(std::move(pg));
+        if (eos_page) {
+          lg.has_all_pages = true;
+          active.erase(active.begin() + slot);
+        }
+      }
     }
     resync = false;
     pos += total;
   }
+  if (nstreams) *nstreams = (int)streams.size();
+  out.bytes.clear();
+  out.offs.clear();
+  out.granule.clear();
+  out.flags.clear();
+  if (stream_index < 0 || stream_index >= (int)streams.size()) {
+    out.offs.push_back(0);
+    return stream_index == 0 ? NVH_OK : NVH_ERR_ARGUMENT;  // an input without any page: an empty packet list, as before
+  }
+  const std::vector<Page>& pages = streams[(size_t)stream_index].pages;
+  const bool has_all_pages = streams[(size_t)stream_index].has_all_pages;
 
   out.bytes.clear();
   out.offs.clear();

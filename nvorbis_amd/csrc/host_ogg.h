@@ -13,6 +13,7 @@ struct OggPackets {
   std::vector<uint8_t> flags;     // NVH_PKT_EOS | NVH_PKT_RESYNC
 };
 
-int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out);
+// Packets of logical stream `stream_index` (0 = the first one whose page appears); *nstreams = how many there are.
+int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index = 0, int* nstreams = nullptr);
 
 }  // namespace nvh

@@ -1965,12 +1965,12 @@ extern "C" void nvh_batch_free(nvh_batch* b) {
 // container helper
 // ------------------------------------------------------------------------------------------------
 
-extern "C" int nvh_ogg_demux(const uint8_t* bytes, size_t len, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
-                             int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
-                             int64_t* total_bytes) {
-  if (!bytes || !npackets || !total_bytes) return NVH_ERR_ARGUMENT;
+extern "C" int nvh_ogg_demux_stream(const uint8_t* bytes, size_t len, int stream_index, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
+                                    int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
+                                    int64_t* total_bytes, int* nstreams) {
+  if (!bytes || !npackets || !total_bytes || stream_index < 0) return NVH_ERR_ARGUMENT;
   nvh::OggPackets pk;
-  int rc = nvh::ogg_demux(bytes, len, pk);
+  int rc = nvh::ogg_demux(bytes, len, pk, stream_index, nstreams);
   if (rc != NVH_OK) return rc;
   int n = (int)pk.granule.size();
   *npackets = n;
@@ -1985,4 +1985,10 @@ extern "C" int nvh_ogg_demux(const uint8_t* bytes, size_t len, uint8_t* pkt_byte
     std::memcpy(flags, pk.flags.data(), (size_t)n);
   }
   return NVH_OK;
+}
+
+extern "C" int nvh_ogg_demux(const uint8_t* bytes, size_t len, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
+                             int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
+                             int64_t* total_bytes) {
+  return nvh_ogg_demux_stream(bytes, len, 0, pkt_bytes, pkt_bytes_cap, offsets, granules, flags, pkt_cap, npackets, total_bytes, nullptr);
 }

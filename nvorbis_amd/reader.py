@@ -48,21 +48,31 @@ class PacketArray:
         return PacketArray(blob, offs, gr if n else np.zeros(1, np.int64), fl if n else np.zeros(1, np.uint8))
 
 
-def demux_ogg_array(data: bytes):
-    """First logical stream of an Ogg file as a PacketArray.
+def ogg_stream_count(data: bytes):
+    """Number of logical streams in an Ogg file (multiplexed or chained), Vorbis or not."""
+    n, total, ns = C.c_int(0), C.c_int64(0), C.c_int(0)
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    check(lib().nvh_ogg_demux_stream(buf, len(data), 0, None, 0, None, None, None, 0, C.byref(n), C.byref(total), C.byref(ns)),
+          "nvh_ogg_demux_stream")
+    return ns.value
+
+
+def demux_ogg_array(data: bytes, stream_index=0):
+    """Logical stream `stream_index` (default: the first) of an Ogg file as a PacketArray.
 
     Delivers packets the way NVorbis' seekable reader does (Ogg/PacketProvider.cs:324-438)."""
     L = lib()
     n = C.c_int(0)
     total = C.c_int64(0)
+    k = int(stream_index)
     buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
-    check(L.nvh_ogg_demux(buf, len(data), None, 0, None, None, None, 0, C.byref(n), C.byref(total)), "nvh_ogg_demux")
+    check(L.nvh_ogg_demux_stream(buf, len(data), k, None, 0, None, None, None, 0, C.byref(n), C.byref(total), None), "nvh_ogg_demux")
     pk = np.zeros(max(total.value, 1), dtype=np.uint8)
     offs = np.zeros(n.value + 1, dtype=np.int64)
     gran = np.zeros(max(n.value, 1), dtype=np.int64)
     flags = np.zeros(max(n.value, 1), dtype=np.uint8)
-    check(L.nvh_ogg_demux(buf, len(data), pk.ctypes.data, pk.size, offs.ctypes.data, gran.ctypes.data,
-                          flags.ctypes.data, n.value, C.byref(n), C.byref(total)), "nvh_ogg_demux")
+    check(L.nvh_ogg_demux_stream(buf, len(data), k, pk.ctypes.data, pk.size, offs.ctypes.data, gran.ctypes.data,
+                                 flags.ctypes.data, n.value, C.byref(n), C.byref(total), None), "nvh_ogg_demux")
     return PacketArray(pk, offs[:n.value + 1], gran, flags)
 
 
@@ -579,7 +589,50 @@ class VorbisReader:
                 data = fh.read()
         self._own_ctx = ctx is None
         self._ctx = ctx if ctx is not None else Context(device)
-        self._dec = StreamDecoder(self._ctx, demux_ogg_array(data), None, None, batch_frames, gpu_parse)
+        self._data, self._batch_frames, self._gpu_parse = data, batch_frames, gpu_parse
+        # VorbisReader keeps one decoder per logical Vorbis stream of the container and starts on the first
+        # (VorbisReader.cs:47-63, 74-87); streams that are not Vorbis are passed over
+        self._stream_ids = []
+        for k in range(max(1, ogg_stream_count(data))):
+            if self._is_vorbis(k):
+                self._stream_ids.append(k)
+        if not self._stream_ids:
+            if self._own_ctx:
+                self._ctx.close()
+            raise native.NvhError(native.ERR_NOT_VORBIS, "VorbisReader")  # ArgumentException: could not load the container
+        self._stream_index = 0
+        self._dec = StreamDecoder(self._ctx, demux_ogg_array(data, self._stream_ids[0]), None, None, batch_frames, gpu_parse)
+        self._decs = {0: self._dec}  # one decoder per logical stream, created on first use, kept like VorbisReader._decoders
+
+    def _is_vorbis(self, k):
+        try:
+            pa = demux_ogg_array(self._data, k)
+            if len(pa) < 3:
+                return False
+            Stream(None, pa[0], pa[1], pa[2]).close()  # header parse only, on the host
+            return True
+        except native.NvhError:
+            return False
+
+    StreamCount = property(lambda self: len(self._stream_ids))
+    StreamIndex = property(lambda self: self._stream_index)
+
+    def SwitchStreams(self, index):
+        """VorbisReader.SwitchStreams (VorbisReader.cs:300-322): make logical Vorbis stream `index` the one ReadSamples
+        decodes; returns True when its channel count or sample rate differs from the previous stream's."""
+        if index < 0 or index >= len(self._stream_ids):
+            raise IndexError("index")  # ArgumentOutOfRangeException
+        if index == self._stream_index:
+            return False
+        old = (self.Channels, self.SampleRate)
+        clip = self.ClipSamples
+        if index not in self._decs:
+            self._decs[index] = StreamDecoder(self._ctx, demux_ogg_array(self._data, self._stream_ids[index]), None, None,
+                                              self._batch_frames, self._gpu_parse)
+        self._dec = self._decs[index]
+        self._dec.ClipSamples = clip  # carry-through the clipping setting
+        self._stream_index = index
+        return (self.Channels, self.SampleRate) != old
 
     Channels = property(lambda self: self._dec.Channels)
     SampleRate = property(lambda self: self._dec.SampleRate)
@@ -635,6 +688,8 @@ class VorbisReader:
         return np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.float32)
 
     def close(self):
-        self._dec.close()
+        for d in self._decs.values():
+            d.close()
+        self._decs = {}
         if self._own_ctx:
             self._ctx.close()

@@ -549,6 +549,7 @@ def test_window_overlap_copy_operators(oracle, gpu_ctx, ogg_bytes, name):
                     x = rng.standard_normal((5, n.value + 8)).astype(np.float32)
                     g = torch.from_numpy(x.copy()).cuda()
                     st.window_apply(mi, prev, nxt, 5, g.data_ptr(), n.value + 8)
+                    gpu_ctx.synchronize()  # asynchronous on the context's stream; torch reads on its own
                     want = x.copy()
                     want[:, :n.value] = x[:, :n.value] * w
                     assert np.array_equal(g.cpu().numpy().view(np.uint32), want.view(np.uint32)), (mi, prev, nxt)
@@ -558,6 +559,7 @@ def test_window_overlap_copy_operators(oracle, gpu_ctx, ogg_bytes, name):
         for (ps, pe, ns) in [(b1 // 2, b1 * 3 // 4, 0), (b1 * 3 // 4 - b0 // 4, b1 * 3 // 4 + b0 // 4, b1 // 4 - b0 // 4), (7, 7, 3), (0, b1, 0)]:
             gp, gn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt.copy()).cuda()
             gpu_ctx.overlap_buffers(gp.data_ptr(), gn.data_ptr(), ps, pe, ns, ch, b1)
+            gpu_ctx.synchronize()
             want = nxt.copy()
             want[:, ns:ns + pe - ps] = nxt[:, ns:ns + pe - ps] + prev[:, ps:pe]
             assert np.array_equal(gn.cpu().numpy().view(np.uint32), want.view(np.uint32))
@@ -740,5 +742,38 @@ def test_seek_returns_the_serial_samples(oracle, ogg_bytes, name, gpu_parse):
         for bad in (-1, end + 10_000_000):
             with pytest.raises(IndexError):
                 rd.SeekTo(bad)
+    finally:
+        rd.close()
+
+
+def test_reader_switches_between_logical_streams(oracle, ogg_bytes):
+    """VorbisReader over a chained + multiplexed container: StreamCount, SwitchStreams (VorbisReader.cs:290-305) with the
+    clipping setting carried over and the changed-format return value; each logical stream decodes to the PCM of the file
+    it came from, and a stream that was left half read resumes where it was."""
+    import nvorbis_amd as nv
+    from tests.test_host_logic import _ogg_pages
+    pa, pb = _ogg_pages(ogg_bytes["2test"]), _ogg_pages(ogg_bytes["3test"])
+    mux = b"".join((pa[i] if i < len(pa) else b"") + (pb[i] if i < len(pb) else b"") for i in range(max(len(pa), len(pb))))
+    data = mux + ogg_bytes["issue6test"]  # streams: 2test (mono), 3test (stereo), issue6test (stereo)
+    want = [oracle.decode_ogg(ogg_bytes[n])[0] for n in ("2test", "3test", "issue6test")]
+    rd = nv.VorbisReader(data, device=0)
+    try:
+        assert rd.StreamCount == 3 and rd.StreamIndex == 0 and rd.Channels == 1
+        head = np.empty(5000, np.float32)
+        n0 = rd.ReadSamples(head, 0, head.size)
+        assert np.array_equal(head[:n0].view(np.uint32), want[0][:n0].view(np.uint32))
+        rd.ClipSamples = False
+        assert rd.SwitchStreams(1) is True and rd.Channels == 2 and rd.ClipSamples is False
+        ref_noclip = oracle.decode_ogg(ogg_bytes["3test"], clip=False)[0]
+        got = rd.read_all()
+        assert np.array_equal(got.view(np.uint32), ref_noclip.view(np.uint32))
+        assert rd.SwitchStreams(2) is False  # stereo 44.1 kHz again
+        rd.ClipSamples = True
+        assert np.array_equal(rd.read_all().view(np.uint32), want[2].view(np.uint32))
+        assert rd.SwitchStreams(2) is False and rd.SwitchStreams(0) is True
+        rest = rd.read_all()  # the first stream resumes after the 5000 samples read before
+        assert np.array_equal(rest.view(np.uint32), want[0][n0:].view(np.uint32))
+        with pytest.raises(IndexError):
+            rd.SwitchStreams(3)
     finally:
         rd.close()

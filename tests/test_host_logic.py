@@ -236,3 +236,46 @@ def test_packet_index_and_sample_counts(oracle, ogg_bytes, name):
     finally:
         st.close()
         oracle.L.orc_close(d)
+
+
+def _ogg_pages(x):
+    out, pos = [], 0
+    while pos < len(x):
+        nseg = x[pos + 26]
+        tot = 27 + nseg + sum(x[pos + 27:pos + 27 + nseg])
+        out.append(x[pos:pos + tot])
+        pos += tot
+    return out
+
+
+def test_demux_chained_and_multiplexed_streams(ogg_bytes):
+    """Logical streams of one physical file (Ogg/PageReader.cs:126-158): chained (files one after the other) and
+    multiplexed (pages interleaved) containers deliver, per stream, exactly the packets, granule positions and flags the
+    stream delivers on its own; a serial number that comes back after its end-of-stream page opens a new stream; junk
+    between pages marks the next packet as a resync point and nothing else."""
+    import nvorbis_amd as nv
+    names = ["2test", "3test", "1test"]
+    alone = {n: nv.demux_ogg_array(ogg_bytes[n]) for n in names}
+
+    def same(a, b):
+        return (len(a) == len(b) and np.array_equal(a.data[:a.offsets[-1]], b.data[:b.offsets[-1]]) and
+                np.array_equal(a.offsets, b.offsets) and np.array_equal(a.granules, b.granules) and np.array_equal(a.flags, b.flags))
+
+    chained = b"".join(ogg_bytes[n] for n in names)
+    assert nv.ogg_stream_count(chained) == 3
+    for k, n in enumerate(names):
+        assert same(nv.demux_ogg_array(chained, k), alone[n])
+    pa, pb = _ogg_pages(ogg_bytes["2test"]), _ogg_pages(ogg_bytes["3test"])
+    mux = b"".join((pa[i] if i < len(pa) else b"") + (pb[i] if i < len(pb) else b"") for i in range(max(len(pa), len(pb))))
+    assert nv.ogg_stream_count(mux) == 2
+    assert same(nv.demux_ogg_array(mux, 0), alone["2test"]) and same(nv.demux_ogg_array(mux, 1), alone["3test"])
+    twice = ogg_bytes["1test"] + ogg_bytes["1test"]  # the same serial number again after its end-of-stream page
+    assert nv.ogg_stream_count(twice) == 2
+    assert same(nv.demux_ogg_array(twice, 0), alone["1test"]) and same(nv.demux_ogg_array(twice, 1), alone["1test"])
+    assert nv.ogg_stream_count(b"") == 0 and len(nv.demux_ogg_array(b"")) == 0
+    with pytest.raises(nv.NvhError):
+        nv.demux_ogg_array(mux, 2)
+    junk = ogg_bytes["2test"] + b"\\x00garbage between streams" + ogg_bytes["3test"]
+    second = nv.demux_ogg_array(junk, 1)
+    assert len(second) == len(alone["3test"]) and np.array_equal(second.granules, alone["3test"].granules)
+    assert second.flags[0] & 2 and np.array_equal(second.flags[1:], alone["3test"].flags[1:])
