@@ -11,6 +11,15 @@ def _torch():
     return torch
 
 
+def _dev_zeros(n):
+    """Zero-filled device vector whose fill has completed: torch fills on its own stream, the library's kernels run on the
+    context's (non-blocking) stream, so a pointer is only handed over once the fill is done."""
+    torch = _torch()
+    t = torch.zeros(n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    return t
+
+
 @pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048, 4096, 8192])
 def test_mdct_reverse_bit_exact(oracle, gpu_ctx, n):
     """IMdct.Reverse (Mdct.cs:13-21): HIP k_mdct_reverse == oracle restatement, every bit."""
@@ -140,6 +149,7 @@ def test_batch_repeat_and_periodicity_full_size(gpu_ctx, ogg_bytes):
     assert b.frames == 4096 and b.samples == 4096 * 1024
     pcm1 = torch.zeros(b.samples * ch, dtype=torch.float32, device="cuda")
     pcm2 = torch.full_like(pcm1, 7.0)
+    torch.cuda.synchronize()  # torch's fills run on its stream, the synthesis on the context's
     b.synth(pcm1.data_ptr(), pcm1.numel())
     b.synth(pcm2.data_ptr(), pcm2.numel())
     torch.cuda.synchronize()
@@ -308,7 +318,7 @@ def test_mode_decode_blocks_bit_exact(oracle, gpu_ctx, ogg_bytes, name):
     try:
         ch, b1 = st.channels, st.block1
         ref = np.zeros(ch * b1, np.float32)
-        got = torch.zeros(ch * b1, dtype=torch.float32, device="cuda")
+        got = _dev_zeros(ch * b1)
         kinds = set()
         step = max(1, (len(pk) - 3) // 60)
         for i in list(range(3, min(len(pk), 40))) + list(range(40, len(pk), step)):
@@ -351,7 +361,7 @@ def test_mode_decode_synthetic_shapes(oracle, gpu_ctx, name):
     try:
         ch, b1 = st.channels, st.block1
         ref = np.zeros(ch * b1, np.float32)
-        got = torch.zeros(ch * b1, dtype=torch.float32, device="cuda")
+        got = _dev_zeros(ch * b1)
         seen = 0
         for i in range(3, len(pk)):
             a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
@@ -569,7 +579,7 @@ def test_window_overlap_copy_operators(oracle, gpu_ctx, ogg_bytes, name):
         gp = torch.from_numpy(planes).cuda()
         for clip in (True, False):
             for (s0, cnt) in [(0, b1), (3, 1000 if b1 > 1100 else 40), (11, 0)]:
-                out = torch.zeros(max(cnt, 1) * ch, dtype=torch.float32, device="cuda")
+                out = _dev_zeros(max(cnt, 1) * ch)
                 clipped = gpu_ctx.copy_buffer(gp.data_ptr(), s0, cnt, ch, b1, out.data_ptr(), clip)
                 seg = planes[:, s0:s0 + cnt]
                 lim = np.float32(0.99999994)
@@ -577,7 +587,7 @@ def test_window_overlap_copy_operators(oracle, gpu_ctx, ogg_bytes, name):
                 assert np.array_equal(out.cpu().numpy()[:cnt * ch].view(np.uint32), np.ascontiguousarray(want.T).reshape(-1).view(np.uint32))
                 assert clipped == bool(clip and cnt and (np.abs(seg) > lim).any())
         quiet = torch.from_numpy((planes * 0.1).astype(np.float32)).cuda()
-        out = torch.zeros(b1 * ch, dtype=torch.float32, device="cuda")
+        out = _dev_zeros(b1 * ch)
         assert gpu_ctx.copy_buffer(quiet.data_ptr(), 0, b1, ch, b1, out.data_ptr(), True) is False
     finally:
         st.close()
