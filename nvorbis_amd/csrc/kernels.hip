@@ -616,7 +616,7 @@ k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const 
     if (clip) v = clip_value(v, &clipped);
     out[o] = v;
   }
-  if (clipped) atomicOr(clipped_flag, 1);
+  report_clipped(clipped, clipped_flag);
 }
 
 // Sequential form: one workgroup walks the frames in order and performs the adds in place, exactly
@@ -650,7 +650,7 @@ k_ola_emit_seq(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, const fl
     }
     __syncthreads();
   }
-  if (clipped) atomicOr(clipped_flag, 1);
+  report_clipped(clipped, clipped_flag);
 }
 
 
@@ -782,7 +782,7 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
       case 7: clipped = ola_vec<7>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
       default: clipped = ola_vec<8>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
     }
-    if (clipped) atomicOr(clipped_flag, 1);
+    report_clipped(clipped, clipped_flag);
     return;
   }
 
@@ -805,7 +805,7 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
     if (clip) v = clip_value(v, &clipped);
     out[o] = v;
   }
-  if (clipped) atomicOr(clipped_flag, 1);
+  report_clipped(clipped, clipped_flag);
 }
 
 // Expands the compact planes of one frame into the fully windowed block (the carried tail format shared by all
@@ -864,5 +864,5 @@ k_copy_buffer(const float* __restrict__ planes, int start, int count, int channe
     if (clip) v = clip_value(v, &clipped);
     target[idx] = v;
   }
-  if (clipped) atomicOr(clipped_flag, 1);
+  report_clipped(clipped, clipped_flag);
 }

@@ -45,3 +45,15 @@ struct NvhDevBatch {
 
 // error word written by kernels when the reference would have thrown (index out of range)
 enum { NVH_DEVERR_FLOOR1_Y = 1, NVH_DEVERR_FLOOR0_W = 2 };
+
+#ifdef __HIPCC__
+// HasClipped (StreamDecoder.cs:728) is sticky: one lane per wavefront that clipped looks at the flag and only sets it
+// while it is still clear.  A stream that clips everywhere (loud material; Floor0 curves on random bits) otherwise
+// serialises one atomic per lane -- or still 8192 per launch with one per wavefront, ~35 us -- on a single address.
+__device__ __forceinline__ void report_clipped(int clipped, int* __restrict__ clipped_flag) {
+  const unsigned long long any = __ballot(clipped != 0);
+  if (any && (int)(threadIdx.x & 63u) == __ffsll((long long)any) - 1) {
+    if (__atomic_load_n(clipped_flag, __ATOMIC_RELAXED) == 0) atomicOr(clipped_flag, 1);
+  }
+}
+#endif

@@ -329,5 +329,5 @@ k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const
     }
     clipped |= ola_frame_any(n, S, Bt, f, true, work, carry_out, pcm, clip, last_decoded, lds, stride, BUF);
   }
-  if (clipped) atomicOr(clipped_flag, 1);
+  report_clipped(clipped, clipped_flag);
 }

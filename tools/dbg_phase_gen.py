@@ -10,6 +10,8 @@ orc = oracle_py.load()
 pk, gr, fl = ss.filtered_stream(orc, name, 300, 3, True)
 ctx = nv.Context(0); st = nv.Stream(ctx, pk[0], pk[1], pk[2])
 audio = pk[3:]
+if os.environ.get("NOCLIP"):
+    st.set_clip(False)
 st.push_packet(audio[0], -1, 0); st.synth_host()
 k = 0
 while st.pending()[0] < 4096:
