@@ -496,9 +496,11 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   frames[f].ent_begin = ent_base;
   frames[f].ent_count = nent;
   frames[f].exec_mask = exec_mask;
-  atomicMax(&result->max_ops, (int)nops);
-  atomicMax(&result->max_ent, (int)nent);
-  atomicMax(&result->max_pass, (int)npass);
+  // batch maxima: look before the atomic -- they settle after a few packets, and tens of thousands of atomics on one
+  // cache line are not free
+  if ((int)nops > __atomic_load_n(&result->max_ops, __ATOMIC_RELAXED)) atomicMax(&result->max_ops, (int)nops);
+  if ((int)nent > __atomic_load_n(&result->max_ent, __ATOMIC_RELAXED)) atomicMax(&result->max_ent, (int)nent);
+  if ((int)npass > __atomic_load_n(&result->max_pass, __ATOMIC_RELAXED)) atomicMax(&result->max_pass, (int)npass);
   if (!links_ok) atomicAnd(&result->links_ok, 0);
   if (err) {
     const int prev = atomicMin(&result->err_frame, f);
