@@ -479,23 +479,45 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   // the entry slice starts at any 2-byte offset: copy from the enclosing 16-byte boundary
   const unsigned ent_shift = fr.ent_begin & 7u;
   DBG_T(20);
-  if (wv < nprep) {
-    if (phase_mask & 4) floor_prepare(&fs[wv], first_lane, lane, half, err);
-  } else {
-    const int st = tid - nprep * 64, sn = NT - nprep * 64;
-    for (int i = st; i < 256; i += sn) s_db[i] = k_inverse_db[i];
+  // both sources are indexed relative to the frame's slice (op.ent_off and pass->op_begin[] are batch offsets)
+  const NvhResOp* ops = s_ops;
+  const uint16_t* ent = s_ent + ent_shift;
+  // pair path: everything a lane needs about an op and its codebook in one 16-byte record, resolved once per op
+  // (from the staged copies) instead of once per element in the stage loops
+  //   x: entry slice offset | first bin << 16      y: lattice pool offset | lat_values << 16
+  //   z: ceil(2^32 / lat_values)                   w: dim | channel << 8 | ceil(2^16 / dim) << 16
+  auto build_pair_records = [&](int first, int stride) {
+    for (int ps = 0; ps < npass; ++ps) {
+      const uint32_t* P = s_pass + ps * 16;
+      const unsigned rflags = __builtin_amdgcn_readfirstlane(P[10]);
+      if (!(rflags & 0x100u)) continue;
+      const int o_end = __builtin_amdgcn_readfirstlane((int)P[1 + NVH_MAX_STAGES]);
+      const unsigned rch = __builtin_amdgcn_readfirstlane(P[11]), psz = __builtin_amdgcn_readfirstlane(P[12]);
+      const unsigned rch_magic = __builtin_amdgcn_readfirstlane(P[14]), rbegin = __builtin_amdgcn_readfirstlane(P[15]);
+      for (int o = __builtin_amdgcn_readfirstlane((int)P[1]) + first; o < o_end; o += stride) {
+        const NvhResOp op = ops[o];
+        const NvhDevBook bk = s_books[op.book];
+        const unsigned offset = rbegin + (unsigned)op.partition * psz;
+        const unsigned xbase = ((rflags & 0xFFu) == 2 && rch > 1) ? __umulhi(offset, rch_magic) : offset;
+        uint4 rec;
+        rec.x = (op.ent_off - fr.ent_begin) | (xbase << 16);
+        rec.y = bk.lat_off | (bk.lat_values << 16);
+        rec.z = bk.lat_magic;
+        rec.w = bk.dim | ((unsigned)op.channel << 8) | (((65536u + bk.dim - 1u) / bk.dim) << 16);
+        s_oprec[o] = rec;
+      }
+    }
+  };
+  // staging pieces; (first, stride) say which lanes of the staging wavefronts share a piece
+  auto stage_ops = [&](int st, int sn) {
     const uint4* gb = reinterpret_cast<const uint4*>(S.books);
     for (int i = st; i < S.nbooks * 2; i += sn) reinterpret_cast<uint4*>(s_books)[i] = gb[i];
-    for (int i = st; i < S.lattice_words; i += sn) s_lat[i] = S.lattice[i];
     const uint2* go = reinterpret_cast<const uint2*>(Bt.ops + fr.op_begin);
     for (int i = st; i < (int)fr.op_count; i += sn) reinterpret_cast<uint2*>(s_ops)[i] = go[i];
     if (FAST) {
       const uint16_t* gl = Bt.op_link + fr.op_begin;
       for (int i = st; i < (int)fr.op_count; i += sn) s_link[i] = gl[i];
     }
-    const uint4* ge = reinterpret_cast<const uint4*>(Bt.entries + (fr.ent_begin - ent_shift));
-    const int nvec = (int)((ent_shift + fr.ent_count + 7u) >> 3);
-    for (int i = st; i < nvec; i += sn) reinterpret_cast<uint4*>(s_ent)[i] = ge[i];
     // pass records: op ranges per stage plus the residue geometry the stage loops need, so that those do not
     // start with another global round trip (frame -> pass -> residue)
     for (int p = st; p < npass; p += sn) {
@@ -511,39 +533,41 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       P[14] = Rp->rch_magic;
       P[15] = (uint32_t)Rp->begin;
     }
+  };
+  auto stage_rest = [&](int st, int sn) {
+    for (int i = st; i < 256; i += sn) s_db[i] = k_inverse_db[i];
+    for (int i = st; i < S.lattice_words; i += sn) s_lat[i] = S.lattice[i];
+    const uint4* ge = reinterpret_cast<const uint4*>(Bt.entries + (fr.ent_begin - ent_shift));
+    const int nvec = (int)((ent_shift + fr.ent_count + 7u) >> 3);
+    for (int i = st; i < nvec; i += sn) reinterpret_cast<uint4*>(s_ent)[i] = ge[i];
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int i = st; i < (nch * half) >> 2; i += sn) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
+  };
+  if (wv < nprep) {
+    if (phase_mask & 4) floor_prepare(&fs[wv], first_lane, lane, half, err);
+  } else if (FAST) {
+    // The floor unwrap is the longer chain, so the staging wavefronts have time left: the last of them stages the op
+    // side and turns it into pair records on its own (wavefront-local ordering only), the other(s) take the rest;
+    // when the floors are ready the residue sweep can start at once.
+    const int nstage = NT / 64 - nprep, sw = wv - nprep;  // nch <= 2: two or three staging wavefronts
+    if (sw == nstage - 1) {
+      stage_ops(lane, 64);
+      sp_wave_sync();
+      build_pair_records(lane, 64);
+    } else {
+      stage_rest(sw * 64 + lane, (nstage - 1) * 64);
+    }
+  } else {
+    const int st = tid - nprep * 64, sn = NT - nprep * 64;
+    stage_ops(st, sn);
+    stage_rest(st, sn);
   }
   DBG_T(21);
   __syncthreads();
-  // both sources are indexed relative to the frame's slice (op.ent_off and pass->op_begin[] are batch offsets)
-  const NvhResOp* ops = s_ops;
-  const uint16_t* ent = s_ent + ent_shift;
-  // pair path: everything a lane needs about an op and its codebook in one 16-byte record, resolved once per op
-  // (from the staged copies) instead of once per element in the stage loops
-  //   x: entry slice offset | first bin << 16      y: lattice pool offset | lat_values << 16
-  //   z: ceil(2^32 / lat_values)                   w: dim | channel << 8 | ceil(2^16 / dim) << 16
-  for (int ps = 0; ps < npass; ++ps) {
-    const uint32_t* P = s_pass + ps * 16;
-    const unsigned rflags = __builtin_amdgcn_readfirstlane(P[10]);
-    if (!(rflags & 0x100u)) continue;
-    const int o_end = __builtin_amdgcn_readfirstlane((int)P[1 + NVH_MAX_STAGES]);
-    const unsigned rch = __builtin_amdgcn_readfirstlane(P[11]), psz = __builtin_amdgcn_readfirstlane(P[12]);
-    const unsigned rch_magic = __builtin_amdgcn_readfirstlane(P[14]), rbegin = __builtin_amdgcn_readfirstlane(P[15]);
-    for (int o = __builtin_amdgcn_readfirstlane((int)P[1]) + tid; o < o_end; o += NT) {
-      const NvhResOp op = ops[o];
-      const NvhDevBook bk = s_books[op.book];
-      const unsigned offset = rbegin + (unsigned)op.partition * psz;
-      const unsigned xbase = ((rflags & 0xFFu) == 2 && rch > 1) ? __umulhi(offset, rch_magic) : offset;
-      uint4 rec;
-      rec.x = (op.ent_off - fr.ent_begin) | (xbase << 16);
-      rec.y = bk.lat_off | (bk.lat_values << 16);
-      rec.z = bk.lat_magic;
-      rec.w = bk.dim | ((unsigned)op.channel << 8) | (((65536u + bk.dim - 1u) / bk.dim) << 16);
-      s_oprec[o] = rec;
-    }
+  if (!FAST) {
+    build_pair_records(tid, NT);
+    __syncthreads();
   }
-  __syncthreads();
   DBG_T(2);
 
   // ---- residue ----
