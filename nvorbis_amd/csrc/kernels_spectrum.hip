@@ -323,12 +323,17 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
 template <int NB>
 __device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* __restrict__ s_db, int x0, float m[NB]) {
   const int ns = __builtin_amdgcn_readfirstlane(Q->nseg);
-  int lo = 0, hi = ns - 1;
-  while (lo < hi) {  // last segment whose start is <= x0
-    const int mid = (lo + hi + 1) >> 1;
-    if ((int)(Q->seg[mid].x_xend & 0xFFFFu) <= x0) lo = mid; else hi = mid - 1;
+  // last segment whose start is <= x0: a fixed-trip binary search (the trip count depends on ns only, so the loop
+  // control is scalar; the data-dependent form costs an exec-mask loop per lane)
+  int sg = 0;
+#pragma unroll
+  for (int step = 64; step > 0; step >>= 1) {
+    if (step >= ns) continue;  // wave-uniform
+    const int cand = sg + step;
+    const int ci = cand < ns ? cand : ns - 1;
+    const int xs = (int)(Q->seg[ci].x_xend & 0xFFFFu);
+    if (cand < ns && xs <= x0) sg = cand;
   }
-  int sg = lo;
   FloorSeg s = Q->seg[sg];
   int sadx = (int)s.ady_adx >> 16, sady = (int)(s.ady_adx & 0xFFFFu), sb = s.b;
   int adx = sadx < 0 ? -sadx : sadx, sy = sadx < 0 ? -1 : 1;
@@ -399,18 +404,16 @@ __device__ __forceinline__ void floor0_curve(const NvhDevSetup& S, const NvhDevF
   }
 }
 
-__device__ __forceinline__ void couple1(float& M, float& A) {  // Mapping.cs:150-178
+// Mapping.cs:150-178 without branches.  The reference's four cases
+//   M > 0, A > 0: (M, M - A)    M > 0, A <= 0: (M + A, M)    M <= 0, A > 0: (M, M + A)    M <= 0, A <= 0: (M - A, M)
+// all compute v = M +/- A, subtracting exactly when the two comparisons agree, and put v in the angle slot when A > 0,
+// in the magnitude slot otherwise.  M - A and M + (-A) are the same IEEE operation.
+__device__ __forceinline__ void couple1(float& M, float& A) {
   const float oldM = M, oldA = A;
-  float newM, newA;
-  if (oldM > 0) {
-    if (oldA > 0) { newM = oldM; newA = oldM - oldA; }
-    else          { newA = oldM; newM = oldM + oldA; }
-  } else {
-    if (oldA > 0) { newM = oldM; newA = oldM + oldA; }
-    else          { newA = oldM; newM = oldM - oldA; }
-  }
-  M = newM;
-  A = newA;
+  const bool mpos = oldM > 0, apos = oldA > 0;
+  const float v = oldM + ((mpos == apos) ? -oldA : oldA);
+  M = apos ? oldM : v;
+  A = apos ? v : oldM;
 }
 
 }  // namespace
