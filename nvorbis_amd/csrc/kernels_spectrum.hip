@@ -345,7 +345,9 @@ __device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* _
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
     const int x = x0 + q;
-    if (x >= xend && sg + 1 < ns) {  // the next segment starts exactly here
+    // the next segment starts exactly here; the last segment ends at or beyond n/2 (floor_prepare: the walk stops at the
+    // first end point >= n/2, else the closing flat run ends at n/2), so x < n/2 never runs off the list
+    if (x >= xend) {
       ++sg;
       s = Q->seg[sg];
       sadx = (int)s.ady_adx >> 16; sady = (int)(s.ady_adx & 0xFFFFu); sb = s.b;
