@@ -86,7 +86,8 @@ struct FloorScratch {
 static_assert(sizeof(FloorScratch) % 16 == 0, "keep the LDS map 16-byte aligned");
 static_assert(sizeof(FloorScratch) == NVH_SP_FLOOR_SCRATCH_WORDS * 4, "host-side LDS sizing (nvh_api.hip) follows this");
 
-// floor(n / d) for 0 <= n < 2^28 from m = floor((2^32 - 1) / d): the estimate is at most one short.
+// floor(n / d) for 0 <= n <= 2^31, d <= 2^16 from m = floor((2^32 - 1) / d): the estimate is at most one short
+// (n*m/2^32 > n/d - (n/2^32)(1 + 1/d) >= n/d - 1).
 __device__ __forceinline__ unsigned sp_div_magic(unsigned n, unsigned d, unsigned m) {
   unsigned q = __umulhi(n, m);
   return (n - q * d >= d) ? q + 1 : q;
@@ -222,15 +223,18 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
   sp_wave_sync();
   for (int lv = 1; lv < L.levels; ++lv) {
     if (lane >= 2 && lane < pc && L.level == lv) {
-      // RenderPoint (Floor1.cs:299-314) with the static divisor's reciprocal; anything unusual (a corrupt
-      // stream's huge or wrapped err) takes the plain division
+      // RenderPoint (Floor1.cs:299-314) with the static divisor's reciprocal
       int predicted;
       {
         const int y0 = Q->u.fy[L.lo], y1 = Q->u.fy[L.hi];
         const int dy = y1 - y0, adx = L.x_hi - L.x_lo;
         const int ady = dy < 0 ? -dy : dy;
-        const int er = ady * (L.x - L.x_lo);
-        const int off = ((unsigned)er < (1u << 28)) ? (int)sp_div_magic((unsigned)er, (unsigned)adx, L.adx_magic) : er / adx;
+        const int er = (int)((unsigned)ady * (unsigned)(L.x - L.x_lo));  // the managed product wraps (unchecked int)
+        // truncating division of the (possibly wrapped, hence negative) product: |er| <= 2^31 and adx <= 2^13 keep
+        // the reciprocal estimate within one of the quotient
+        const unsigned aer = er < 0 ? 0u - (unsigned)er : (unsigned)er;
+        const int qa = (int)sp_div_magic(aer, (unsigned)adx, L.adx_magic);
+        const int off = er < 0 ? -qa : qa;
         predicted = dy < 0 ? y0 - off : y0 + off;
       }
       int val = L.val;
@@ -508,7 +512,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
         rec.x = (op.ent_off - fr.ent_begin) | (xbase << 16);
         rec.y = bk.lat_off | (bk.lat_values << 16);
         rec.z = bk.lat_magic;
-        rec.w = bk.dim | ((unsigned)op.channel << 8) | (((65536u + bk.dim - 1u) / bk.dim) << 16);
+        rec.w = bk.dim | ((unsigned)op.channel << 8) | (bk.dim_magic16 << 16);
         s_oprec[o] = rec;
       }
     }

@@ -453,7 +453,7 @@ static int upload_setup(nvh_stream* s) {
     books[i].lat_values = 0;
     books[i].lat_magic = 0;
     books[i].lat_off = 0;
-    books[i].pad = 0;
+    books[i].dim_magic16 = b.dimensions >= 1 ? (uint32_t)((65536u + (uint32_t)b.dimensions - 1u) / (uint32_t)b.dimensions) : 0u;
     // lattice fast path: digits via exact reciprocal multiplies (entry < 2^16, powers <= entries)
     if (b.lattice_values >= 1 && b.dimensions >= 1 && b.dimensions <= 16 && b.entries <= 0xFFFF) {
       bool ok = true;

@@ -31,7 +31,7 @@ struct NvhDevBook {      // Codebook lookup table (Codebook.cs:222-283, indexer 
   uint32_t lat_values;
   uint32_t lat_magic;    // ceil(2^32 / lat_values)
   uint32_t lat_off;
-  uint32_t pad;
+  uint32_t dim_magic16;  // ceil(2^16 / dim): i / dim == (i * dim_magic16) >> 16 for i < 4096, dim <= 16 (pair records)
 };
 
 struct NvhDevFloor1 {    // Floor1.cs:21-25, :93-133
