@@ -25,6 +25,7 @@ struct NvhDevSetup {
   const float* mdct_c[2];
   const uint16_t* mdct_br[2];
   const float* mdct_tw[2];        // lane-ordered copies of _a for the wavefront IMDCT (host_setup.cpp)
+  const uint32_t* recip;          // recip[d] = floor((2^32 - 1) / d) for 1 <= d <= block1 / 2 (segment lengths of a floor curve)
 };
 
 // One uploaded frame batch.

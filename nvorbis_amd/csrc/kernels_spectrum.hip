@@ -212,7 +212,8 @@ __device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const
 //   UnwrapPosts (Floor1.cs:224-297): lane i owns post i; posts of one dependency level are independent.
 //   Apply's walk over the sorted posts (Floor1.cs:196-216): the flagged posts compacted in X order; the walk
 //   stops at the first end point at or beyond n/2, else a flat run to n/2 closes the curve (:213-216).
-__device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& L, int lane, int half, int* __restrict__ err) {
+__device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& L, int lane, int half, int* __restrict__ err,
+                                              const uint32_t* __restrict__ recip) {
   const int mode = L.mode, pc = L.pc;
   if (lane == 0) Q->mode = mode;
   if (mode != 1) return;  // wave-uniform
@@ -302,8 +303,11 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
     const int dy = y1 - y0;
     const int adx = x1 - x0;
     const int ady = dy < 0 ? -dy : dy;
-    const int b = dy / adx;
-    const int ab = b < 0 ? -b : b;
+    // floor((2^32 - 1) / adx) from the setup's table (1 <= adx <= n/2): it restarts the error recurrence in the tail and
+    // gives b = dy / adx (truncating) here -- two emulated 32-bit divisions per segment otherwise
+    const unsigned mg = recip[adx];
+    const int ab = (int)sp_div_magic((unsigned)ady, (unsigned)adx, mg);
+    const int b = dy < 0 ? -ab : ab;
     const int ady2 = ady - ab * adx;
     FloorSeg sgm;
     sgm.x_xend = (uint32_t)x0 | ((uint32_t)x1n << 16);
@@ -311,7 +315,6 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
     sgm.b = b;
     sgm.ady_adx = ((uint32_t)ady2 & 0xFFFFu) | ((uint32_t)((dy < 0) ? -adx : adx) << 16);
     Q->seg[lane] = sgm;
-    const unsigned mg = 0xFFFFFFFFu / (unsigned)adx;
     Q->magic[lane] = mg;
     // inverse_dB_table[y] throws for y outside 0..255 (quirk B-7).  The curve is monotone inside a segment, so
     // its first and last drawn values decide; the render loop itself then only clamps.
@@ -553,7 +556,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     for (int i = st; i < (nch * half) >> 2; i += sn) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
   };
   if (wv < nprep) {
-    if (phase_mask & 4) floor_prepare(&fs[wv], first_lane, lane, half, err);
+    if (phase_mask & 4) floor_prepare(&fs[wv], first_lane, lane, half, err, S.recip);
   } else if (FAST) {
     // The floor unwrap is the longer chain, so the staging wavefronts have time left: the last of them stages the op
     // side and turns it into pair records on its own (wavefront-local ordering only), the other(s) take the rest;
@@ -881,7 +884,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   // floors, `grp` channels at a time: wavefront w < grp prepares channel c0 + w
   for (int c0 = 0; c0 < nch; c0 += grp) {
     const FloorLane fl_lane = (c0 == 0) ? first_lane : load_floor_lane(S, Bt, chans, c0 + wv, nch, lane);
-    if (c0 + wv < nch) floor_prepare(&fs[wv], fl_lane, lane, half, err);
+    if (c0 + wv < nch) floor_prepare(&fs[wv], fl_lane, lane, half, err, S.recip);
     __syncthreads();
 
     // render / apply: all threads over the group's channels
@@ -999,7 +1002,7 @@ k_floor1_apply(NvhDevSetup S, int floor_idx, const uint16_t* __restrict__ posts,
     L.x_sorted = F->x_sorted[lane];
     L.adx_magic = F->adx_magic[lane];
   }
-  floor_prepare(&Q, L, lane, half, status + item);
+  floor_prepare(&Q, L, lane, half, status + item, S.recip);
   __syncthreads();
   float* res = data + (long long)item * stride;
   if (L.mode == 2) {

@@ -622,6 +622,10 @@ static int upload_setup(nvh_stream* s) {
   size_t o_map = ab.add(mappings.data(), mappings.size() * sizeof(NvhDevMapping));
   size_t o_cpl = ab.add(coupling.data(), coupling.size());
   size_t o_win = ab.add(S.windows.data(), S.windows.size() * sizeof(float));
+  // reciprocals of every possible floor segment length (kernels_spectrum.hip: floor_prepare)
+  std::vector<uint32_t> recip((size_t)S.block1 / 2 + 1, 0u);
+  for (size_t d = 1; d < recip.size(); d++) recip[d] = (uint32_t)(0xFFFFFFFFull / d);
+  size_t o_recip = ab.add(recip.data(), recip.size() * sizeof(uint32_t));
   size_t o_ip = ab.add(ipool.data(), ipool.size() * sizeof(int32_t));
   size_t o_fp = ab.add(fpool.data(), fpool.size() * sizeof(float));
   size_t o_a[2], o_b[2], o_c[2], o_br[2], o_tw[2];
@@ -661,6 +665,7 @@ static int upload_setup(nvh_stream* s) {
   D.mappings = (const NvhDevMapping*)(base + o_map);
   D.coupling = base + o_cpl;
   D.windows = (const float*)(base + o_win);
+  D.recip = (const uint32_t*)(base + o_recip);
   D.ipool = (const int32_t*)(base + o_ip);
   D.fpool = (const float*)(base + o_fp);
   for (int w = 0; w < 2; w++) {
