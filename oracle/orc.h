@@ -138,6 +138,11 @@ int orc_floor0_apply_coeffs(orc_decoder *d, int floor_index, int block_size, flo
 /* type, post count (Floor1 _xList.Length; Floor0 _order) and _range of floor `floor_index`; returns the number of floors. */
 int orc_floor_info(const orc_decoder *d, int floor_index, int *type, int *post_count, int *range);
 
+/* Test instrumentation: residue coverage of the calling thread's decodes between begin and end.
+ * mask[channel * plane_len + bin] gets bit s set when cascade stage s added a value to that bin. */
+int orc_coverage_begin(int channels, int plane_len);
+int orc_coverage_end(unsigned char *mask_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -386,8 +386,10 @@ static void calc_reverse(const mdct_impl *m, float *buffer) {
   free(buf2);
 }
 
-/* Mdct.cs:11-21: per-n cache of MdctImpl.  n is a power of two in [64, 8192]. */
-static mdct_impl g_cache[16];
+/* Mdct.cs:11-21: per-n cache of MdctImpl.  n is a power of two in [64, 8192].  The reference's cache belongs to one Mdct
+ * instance (one per StreamDecoder, used by one thread); here it is per thread, so that several oracle decoders may run
+ * on different threads (bench.py's all-cores CPU baseline) without sharing mutable state. */
+static __thread mdct_impl g_cache[16];
 
 void orc_mdct_reverse(float *buf, int n) {
   int slot = orc_ilog(n) & 15;

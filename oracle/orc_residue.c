@@ -87,6 +87,34 @@ void orc_residue_free(orc_residue *r) {
   memset(r, 0, sizeof *r);
 }
 
+/* Test instrumentation (not part of the restated algorithm): which bins each cascade stage added to.
+ * orc_coverage_begin(channels, plane_len) arms it for the calling thread; every residue add then ORs (1 << stage)
+ * into mask[channel * plane_len + bin]; orc_coverage_end copies the mask out and disarms. */
+static __thread unsigned char *g_cov_mask = NULL;
+static __thread int g_cov_channels = 0, g_cov_len = 0, g_cov_stage = 0;
+
+int orc_coverage_begin(int channels, int plane_len) {
+  free(g_cov_mask);
+  g_cov_mask = (unsigned char *)calloc((size_t)channels * (size_t)plane_len + 1, 1);
+  if (!g_cov_mask) return ORC_ERR_NOMEM;
+  g_cov_channels = channels;
+  g_cov_len = plane_len;
+  return ORC_OK;
+}
+
+int orc_coverage_end(unsigned char *mask_out) {
+  if (!g_cov_mask) return ORC_ERR_ARGUMENT;
+  if (mask_out) memcpy(mask_out, g_cov_mask, (size_t)g_cov_channels * (size_t)g_cov_len);
+  free(g_cov_mask);
+  g_cov_mask = NULL;
+  return ORC_OK;
+}
+
+static void cov_mark(int channel, int offset) {
+  if (g_cov_mask && channel >= 0 && channel < g_cov_channels && offset >= 0 && offset < g_cov_len)
+    g_cov_mask[(size_t)channel * (size_t)g_cov_len + (size_t)offset] |= (unsigned char)(1u << (g_cov_stage & 7));
+}
+
 /* WriteVectors: Residue0.cs:180-201, Residue1.cs:8-26, Residue2.cs:23-47.
  * returns 1 = "bad packet, stop", 0 = ok, <0 = runtime fault */
 static int write_vectors(const orc_residue *r, const orc_codebook *cb, orc_packet *p, float **residue, int buflen,
@@ -118,6 +146,7 @@ static int write_vectors(const orc_residue *r, const orc_codebook *cb, orc_packe
           return ORC_ERR_RUNTIME;
         }
         res[offset] += cb->lookup[entry_cache[step] * dims + dim];
+        cov_mark(channel, offset);
       }
     }
     free(entry_cache);
@@ -133,6 +162,7 @@ static int write_vectors(const orc_residue *r, const orc_codebook *cb, orc_packe
       for (j = 0; j < dims; i++, j++) {
         if (offset + i < 0 || offset + i >= buflen) return ORC_ERR_RUNTIME;
         res[offset + i] += cb->lookup[entry * dims + j];
+        cov_mark(channel, offset + i);
       }
     }
     return 0;
@@ -147,6 +177,7 @@ static int write_vectors(const orc_residue *r, const orc_codebook *cb, orc_packe
       for (d = 0; d < dims; d++, c++) {
         if (offset < 0 || offset >= buflen) return ORC_ERR_RUNTIME;
         residue[ch_ptr][offset] += cb->lookup[entry * dims + d];
+        cov_mark(ch_ptr, offset);
         if (++ch_ptr == r->real_channels) {
           ch_ptr = 0;
           offset++;
@@ -181,6 +212,7 @@ int orc_residue_decode(const orc_residue *r, const orc_codebook *books, orc_pack
 
     for (stage = 0; stage < r->max_stages; stage++) {
       int partition_idx, entry_idx;
+      g_cov_stage = stage;
       for (partition_idx = 0, entry_idx = 0; partition_idx < partition_count; entry_idx++) {
         int dimension_idx, ch;
         if (stage == 0) {

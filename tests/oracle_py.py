@@ -54,6 +54,8 @@ class Oracle:
         L.orc_floor0_apply_coeffs.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp, C.c_int]
         L.orc_floor1_apply_posts.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
         L.orc_floor_info.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int)] * 3
+        L.orc_coverage_begin.argtypes = [C.c_int, C.c_int]
+        L.orc_coverage_end.argtypes = [vp]
 
     # ---- transforms / tables ----
     def mdct_reverse(self, x, n):
@@ -77,6 +79,32 @@ class Oracle:
         s, v, t = C.c_int(0), C.c_int(0), C.c_int(0)
         self.L.orc_calc_overlap(prev, block, nxt, C.byref(s), C.byref(v), C.byref(t))
         return s.value, v.value, t.value
+
+    # ---- single packets ----
+    def open_headers(self, headers):
+        """Decoder handle over the three header packets only (for orc_decode_packet_block); close with L.orc_close."""
+        blob = np.frombuffer(b"".join(headers), dtype=np.uint8)
+        offs = np.zeros(4, np.int64)
+        offs[1:] = np.cumsum([len(p) for p in headers])
+        g3, f3, err = np.full(3, -1, np.int64), np.zeros(3, np.uint8), C.c_int(0)
+        d = self.L.orc_open_packets(blob.ctypes.data, offs.ctypes.data, g3.ctypes.data, f3.ctypes.data, 3, C.byref(err))
+        if not d:
+            raise RuntimeError("oracle open failed: %d" % err.value)
+        return d
+
+    def packet_coverage(self, d, pkt):
+        """Decode one packet (Mode.Decode) with the residue coverage hook armed.
+        Returns (block_size, mask[channels][block1]) -- mask bit s set where cascade stage s added a value -- or None."""
+        ch, b1 = self.L.orc_channels(d), self.L.orc_block1(d)
+        planes = np.zeros(ch * b1, np.float32)
+        mask = np.zeros((ch, b1), np.uint8)
+        a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert self.L.orc_coverage_begin(ch, b1) == 0
+        rc = self.L.orc_decode_packet_block(d, pkt, len(pkt), planes.ctypes.data, C.byref(a), C.byref(b), C.byref(c), C.byref(e))
+        self.L.orc_coverage_end(mask.ctypes.data)
+        if rc != 1:
+            return None
+        return e.value, mask
 
     # ---- decoding ----
     def decode_ogg(self, data, clip=True, chunk=4096, trace=False):
