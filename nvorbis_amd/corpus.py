@@ -25,77 +25,250 @@ def lpt_shards(sizes, world):
     return shards
 
 
-def gather_pcm(local, nfiles, rank, world, dist=None, device="cpu"):
-    """Gather {file index -> float32 PCM array} from every rank onto rank 0.
+def gather_pcm(local, nfiles, rank, world, dist=None, device="cpu", to_host=True):
+    """Gather {file index -> interleaved float32 PCM} from every rank onto rank 0.
 
-    Returns a list of nfiles arrays on rank 0 (None elsewhere).  `dist` is torch.distributed (already
-    initialised) or None for a single process.  `device` is where the exchange buffers live
-    ("cuda:<n>" for RCCL over xGMI, "cpu" for gloo).
-    """
-    if dist is None or world == 1:
-        return [local[i] for i in range(nfiles)]
+    `local` values are numpy arrays (host) or torch tensors; tensors that already live on `device` are sent from where
+    they are -- with backend "nccl" (= RCCL over xGMI) the PCM goes from the decoding GPU's memory to the root GPU's
+    memory with no host bounce on either side.  Returns a list of nfiles arrays on rank 0 (None elsewhere): numpy arrays
+    when to_host, else torch tensors on `device` (views of the receive buffers).  `dist` is torch.distributed (already
+    initialised) or None for a single process.
+
+    Exchange: one all_gather of per-file sample counts, then one flat payload per rank (ascending file index) sent
+    point-to-point to the root, all transfers posted as one group (xGMI is point-to-point: every peer has its own
+    link to the root, so the root receives from all of them at once; a ring collective would be the wrong shape)."""
+    import_torch = dist is not None and world > 1
+    if not import_torch:
+        vals = [local.get(i) for i in range(nfiles)]
+        if to_host:
+            return [_to_numpy(v) for v in vals]
+        return vals
     import torch
-    counts = torch.zeros(nfiles, dtype=torch.int64, device=device)
+    dev = torch.device(device)
+
+    def as_tensor(a):
+        if isinstance(a, np.ndarray):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        return a.to(dev) if a.device != dev else a
+
+    counts = torch.zeros(nfiles, dtype=torch.int64)
     for i, a in local.items():
-        counts[i] = a.size
+        counts[i] = int(a.size if isinstance(a, np.ndarray) else a.numel())
+    counts = counts.to(dev)
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts)
-    owner = {}
-    sizes = {}
+    owner, sizes = {}, {}
     for r in range(world):
         c = all_counts[r].cpu().numpy()
         for i in np.nonzero(c)[0]:
             owner[int(i)] = r
             sizes[int(i)] = int(c[i])
-    out = [None] * nfiles if rank == 0 else None
-    # one flat payload per rank: deterministic order (ascending file index)
     mine = sorted(local.keys())
-    flat = np.concatenate([local[i] for i in mine]) if mine else np.zeros(0, np.float32)
+    parts = [as_tensor(local[i]).reshape(-1) for i in mine]
+    out = [None] * nfiles if rank == 0 else None
+    ops, bufs = [], {}
     if rank == 0:
-        off = 0
-        for i in mine:
-            out[i] = flat[off:off + local[i].size].copy()
-            off += local[i].size
-        reqs, bufs = [], {}
+        for i, t in zip(mine, parts):
+            out[i] = t
         for r in range(1, world):
             idx = sorted(i for i, o in owner.items() if o == r)
             tot = sum(sizes[i] for i in idx)
-            buf = torch.empty(max(tot, 1), dtype=torch.float32, device=device)
-            bufs[r] = (buf, idx)
             if tot > 0:
-                reqs.append(dist.irecv(buf[:tot], src=r))
-        for q in reqs:
+                buf = torch.empty(tot, dtype=torch.float32, device=dev)
+                bufs[r] = (buf, idx)
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+    else:
+        flat = _flat_payload(parts, torch, dev)
+        if flat.numel() > 0:
+            ops.append(dist.P2POp(dist.isend, flat, 0))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):  # one group: ncclGroupStart / ncclGroupEnd around all sends / receives
             q.wait()
+    if rank == 0:
         for r, (buf, idx) in bufs.items():
-            host = buf.cpu().numpy()
             off = 0
             for i in idx:
-                out[i] = host[off:off + sizes[i]].copy()
+                out[i] = buf[off:off + sizes[i]]
                 off += sizes[i]
         for i in range(nfiles):
             if out[i] is None:
-                out[i] = np.zeros(0, np.float32)  # files that produced no samples
-    else:
-        if flat.size > 0:
-            t = torch.from_numpy(flat).to(device)
-            dist.send(t, dst=0)
+                out[i] = torch.zeros(0, dtype=torch.float32, device=dev)  # files that produced no samples
+        if to_host:
+            out = [_to_numpy(t) for t in out]
     dist.barrier()
     return out
 
 
-def transcode(files, decode_fn=None, rank=0, world=1, dist=None, device="cpu", gpu=0, workers=16):
+def _to_numpy(v):
+    if v is None:
+        return np.zeros(0, np.float32)
+    if isinstance(v, np.ndarray):
+        return v
+    return v.detach().cpu().numpy()
+
+
+def _flat_payload(parts, torch, dev):
+    """One contiguous tensor holding `parts` back to back; no copy when they already are (slices of one arena)."""
+    parts = [p for p in parts if p.numel() > 0]
+    if not parts:
+        return torch.zeros(0, dtype=torch.float32, device=dev)
+    base = parts[0]
+    contiguous = True
+    ptr = base.data_ptr()
+    for p in parts:
+        if p.data_ptr() != ptr or not p.is_contiguous():
+            contiguous = False
+            break
+        ptr += p.numel() * 4
+    if contiguous and len(parts) > 1:
+        total = sum(p.numel() for p in parts)
+        try:
+            return torch.as_strided(base, (total,), (1,))  # the arena the slices were cut from
+        except RuntimeError:
+            pass
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+
+def transcode(files, decode_fn=None, rank=0, world=1, dist=None, device="cpu", gpu=0, workers=16, to_host=True):
     """Decode `files` (list of bytes) file-parallel; rank 0 returns the list of PCM arrays in file order.
 
     decode_fn(bytes) -> float32 numpy PCM decodes one file; None = this package's GPU path with a pool of `workers`
-    host threads on HIP device `gpu` (decode_files_threaded).  Gathered PCM is byte-identical to a single-rank run."""
+    host threads on HIP device `gpu`, every file's PCM written by the synthesis kernels straight into one device arena
+    (decode_files_to_device) and gathered from there.  Gathered PCM is byte-identical to a single-rank run."""
     shards = lpt_shards([len(f) for f in files], world)
     mine = shards[rank]
     if decode_fn is None:
-        pcm = decode_files_threaded([files[i] for i in mine], device=gpu, workers=workers)
-        local = {i: np.ascontiguousarray(a, dtype=np.float32) for i, a in zip(mine, pcm)}
+        arena, views = decode_files_to_device([files[i] for i in mine], device=gpu, workers=workers)
+        local = {i: v for i, v in zip(mine, views)}
+        if device == "cpu":  # host exchange (gloo): one read-back of the whole arena
+            host = arena.cpu().numpy()
+            off = 0
+            for i, v in zip(mine, views):
+                local[i] = host[off:off + v.numel()]
+                off += v.numel()
     else:
         local = {i: np.ascontiguousarray(decode_fn(files[i]), dtype=np.float32) for i in mine}
-    return gather_pcm(local, len(files), rank, world, dist, device)
+    return gather_pcm(local, len(files), rank, world, dist, device, to_host)
+
+
+def _decode_file_packets(st, pa, batch_frames, sink):
+    """The ReadSamples loop of VorbisReader without its ring buffer: whole look-ahead batches handed to `sink(stream)`
+    (which synthesises the pending batch wherever it wants the PCM)."""
+    nxt = 3
+    while True:
+        if nxt < len(pa) and not st.position()[2]:
+            nxt += st.push_packets(pa, nxt, batch_frames)
+            last = nxt >= len(pa) or st.position()[2]
+        else:
+            last = True
+        if last and not st.position()[2]:
+            st.push_end()  # the provider ran dry: drains the carried tail (StreamDecoder.cs:352-356)
+        if st.pending()[0]:
+            sink(st)
+        if last:
+            break
+
+
+def _run_pool(n_items, workers, device, fn):
+    """fn(index, ctx) for every index on a pool of host threads, one nvh_ctx (= one HIP stream) per thread."""
+    import queue
+    import threading
+
+    from .reader import Context
+    errors = []
+    q = queue.Queue()
+    for i in range(n_items):
+        q.put(i)
+
+    def work():
+        ctx = Context(device)
+        try:
+            while True:
+                try:
+                    i = q.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    fn(i, ctx)
+                except Exception as e:  # one bad file must not take the pool down; the caller sees it
+                    errors.append((i, e))
+        finally:
+            ctx.close()
+
+    threads = [threading.Thread(target=work, daemon=True) for _ in range(max(1, min(workers, n_items)))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return errors
+
+
+def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False):
+    """Decode .ogg byte strings on ONE GPU into ONE device arena: returns (arena, views) with views[i] the interleaved
+    float32 PCM of files[i] as a slice of `arena` (torch tensors on cuda:<device>), files back to back in list order.
+
+    Two passes over the worker pool: a geometry-only index of every stream (nvh_stream_index_packets: packet type, mode
+    number, window flags -- how many samples the serial decoder emits), which sizes the arena; then the decode, whose
+    overlap-add kernels write each batch's PCM at its final address (nvh_stream_synth with a device destination).  No
+    PCM crosses PCIe."""
+    import torch
+
+    from .reader import Stream, demux_ogg_array
+    n = len(files)
+    arrays = [None] * n
+    totals = [0] * n
+    chans = [1] * n
+
+    def index_one(i, ctx):
+        pa = demux_ogg_array(files[i])
+        st = Stream(None, pa[0], pa[1], pa[2])
+        try:
+            totals[i] = int(st.index_packets(pa, 3)[3]) * st.channels
+            chans[i] = st.channels
+        finally:
+            st.close()
+        arrays[i] = pa
+
+    errors = _run_pool(n, workers, device, index_one)
+    if errors:
+        raise RuntimeError("index failed for files %s: %r" % ([i for i, _ in errors], errors[0][1]))
+    offs = np.zeros(n + 1, np.int64)
+    offs[1:] = np.cumsum(totals)
+    arena = torch.empty(max(int(offs[-1]), 1), dtype=torch.float32, device="cuda:%d" % device)
+    torch.cuda.synchronize(device)
+    base = arena.data_ptr()
+    order = sorted(range(n), key=lambda i: (-len(files[i]), i))  # longest first: shorter tail
+
+    def decode_one(k, ctx):
+        i = order[k]
+        pa = arrays[i]
+        st = Stream(ctx, pa[0], pa[1], pa[2])
+        try:
+            if gpu_parse:
+                try:
+                    st.set_gpu_parse(True)
+                except Exception:
+                    pass
+            pos = [int(offs[i])]
+
+            def sink(s):
+                room = int(offs[i + 1]) - pos[0]
+                need = s.pending()[1] * s.channels
+                if need > room:
+                    raise RuntimeError("file %d produces more than the %d floats its index says" % (i, totals[i]))
+                pos[0] += s.synth_device(base + 4 * pos[0], room)
+
+            _decode_file_packets(st, pa, batch_frames, sink)
+            if pos[0] != int(offs[i + 1]):
+                raise RuntimeError("file %d produced %d floats, its index says %d" % (i, pos[0] - int(offs[i]), totals[i]))
+        finally:
+            st.close()
+
+    errors = _run_pool(n, workers, device, decode_one)
+    if errors:
+        raise RuntimeError("decode failed for files %s: %r" % ([order[k] for k, _ in errors], errors[0][1]))
+    views = [arena[int(offs[i]):int(offs[i + 1])] for i in range(n)]
+    return arena, views
 
 
 def decode_files_threaded(files, device=0, workers=16, batch_frames=4096, gpu_parse=False):
@@ -109,15 +282,14 @@ def decode_files_threaded(files, device=0, workers=16, batch_frames=4096, gpu_pa
     (nvh_stream_push_packets), so the pool scales with cores.  gpu_parse=True moves the packet parse to the GPU as well
     (kernels_parse.hip): less host work per file, at ~0.8 ms of kernel latency per batch.  Results are byte-identical
     to a serial decode either way."""
-    import queue
-    import threading
+    from .reader import Stream, demux_ogg_array
+    out = [None] * len(files)
+    order = sorted(range(len(files)), key=lambda i: (-len(files[i]), i))  # longest first: shorter tail
 
-    from .reader import Context, Stream, demux_ogg_array
-
-    def decode_one(data, ctx):
-        # the ReadSamples loop of VorbisReader without its ring buffer: whole look-ahead batches straight into the
-        # result (a file that fits one batch is returned without a single extra copy)
-        pa = demux_ogg_array(data)
+    def decode_one(k, ctx):
+        i = order[k]
+        out[i] = np.zeros(0, np.float32)
+        pa = demux_ogg_array(files[i])
         st = Stream(ctx, pa[0], pa[1], pa[2])
         try:
             if gpu_parse:  # packets parsed by k_parse; shapes outside its limits keep the host parser
@@ -125,57 +297,22 @@ def decode_files_threaded(files, device=0, workers=16, batch_frames=4096, gpu_pa
                     st.set_gpu_parse(True)
                 except Exception:
                     pass
-            chunks, nxt = [], 3
-            while True:
-                if nxt < len(pa) and not st.position()[2]:
-                    nxt += st.push_packets(pa, nxt, batch_frames)
-                    last = nxt >= len(pa) or st.position()[2]
-                else:
-                    last = True
-                if last and not st.position()[2]:
-                    st.push_end()  # the provider ran dry: drains the carried tail (StreamDecoder.cs:352-356)
-                if st.pending()[0]:
-                    pcm = st.synth_host()
-                    if pcm.size:
-                        chunks.append(pcm)
-                if last:
-                    break
-            if not chunks:
-                return np.zeros(0, np.float32)
-            return chunks[0] if len(chunks) == 1 else np.concatenate(chunks)
+            chunks = []
+
+            def sink(s):
+                pcm = s.synth_host()
+                if pcm.size:
+                    chunks.append(pcm)
+
+            _decode_file_packets(st, pa, batch_frames, sink)
+            if chunks:
+                out[i] = chunks[0] if len(chunks) == 1 else np.concatenate(chunks)
         finally:
             st.close()
 
-    out = [None] * len(files)
-    errors = []
-    order = sorted(range(len(files)), key=lambda i: (-len(files[i]), i))  # longest first: shorter tail
-    q = queue.Queue()
-    for i in order:
-        q.put(i)
-
-    def work():
-        ctx = Context(device)
-        try:
-            while True:
-                try:
-                    i = q.get_nowait()
-                except queue.Empty:
-                    return
-                try:
-                    out[i] = decode_one(files[i], ctx)
-                except Exception as e:  # one bad file must not take the pool down; the caller sees it
-                    errors.append((i, e))
-                    out[i] = np.zeros(0, np.float32)
-        finally:
-            ctx.close()
-
-    threads = [threading.Thread(target=work, daemon=True) for _ in range(max(1, min(workers, len(files))))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    errors = _run_pool(len(files), workers, device, decode_one)
     if errors:
-        raise RuntimeError("decode failed for files %s: %r" % ([i for i, _ in errors], errors[0][1]))
+        raise RuntimeError("decode failed for files %s: %r" % ([order[k] for k, _ in errors], errors[0][1]))
     return out
 
 

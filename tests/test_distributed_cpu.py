@@ -43,6 +43,52 @@ def _worker(rank, world, port, files, q):
     dist.destroy_process_group()
 
 
+def _arena_worker(rank, world, port, files, q):
+    """As _worker, but the rank's PCM sits in one torch arena and the gather gets slices of it (the shape the GPU path
+    has: decode_files_to_device + gather_pcm(to_host=False)); the payload must go out without a concatenation copy."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from nvorbis_amd import corpus
+    from tests import oracle_py
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = oracle_py.load()
+    mine = corpus.lpt_shards([len(f) for f in files], world)[rank]
+    pcm = [orc.decode_ogg(files[i])[0] for i in mine]
+    arena = torch.from_numpy(np.concatenate(pcm)) if pcm else torch.zeros(0)
+    local, off = {}, 0
+    for i, a in zip(mine, pcm):
+        local[i] = arena[off:off + a.size]
+        off += a.size
+    flat = corpus._flat_payload([local[i] for i in sorted(local)], torch, torch.device("cpu"))
+    assert flat.data_ptr() == arena.data_ptr() and flat.numel() == arena.numel()
+    out = corpus.gather_pcm(local, len(files), rank, world, dist, "cpu", to_host=False)
+    if rank == 0:
+        assert all(isinstance(o, torch.Tensor) for o in out)
+        q.put([o.numpy().tobytes() for o in out])
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gather_from_arena_slices(oracle, ogg_bytes):
+    """The device-resident form of the gather (tensor slices of one arena in, tensors out), on CPU tensors over gloo."""
+    import torch.multiprocessing as mp
+    files = [ogg_bytes[n] for n in ("3test", "1test", "2test", "issue6test", "1test")]
+    single = [oracle.decode_ogg(b)[0].tobytes() for b in files]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, files, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == single
+
+
 def test_gloo_world2_gather_is_byte_identical(oracle, ogg_bytes):
     """Gathered PCM of a 2-rank run == single-process PCM, byte for byte.  The decoder behind
     the shard is the CPU oracle here (no GPU in this suite); the GPU suite runs the same code path with

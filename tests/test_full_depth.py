@@ -1,0 +1,150 @@
+"""GPU parity on the BASELINE.json workloads with FULL-DEPTH packets (SURVEY 8d generators, tests/vorbis_encode.py).
+
+Random-byte packets end long before the residue does, so they only ever exercise the first few partitions; here every
+packet is written by the structured encoder (chosen floor posts, a classification for every partition, a VQ entry for
+every vector of every cascade stage) and the oracle's own residue trace is asserted to cover the spectrum.
+All comparisons are bit-exact against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from tests import ogg_py, vorbis_encode as ve
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode_gpu(nv, ctx, pk, gr, fl, clip, batch_frames, gpu_parse=False):
+    dec = nv.StreamDecoder(ctx, pk, gr, fl, batch_frames=batch_frames, gpu_parse=gpu_parse)
+    dec.ClipSamples = clip
+    chunks = []
+    buf = np.zeros(1 << 22, np.float32)
+    buf = buf[: buf.size - buf.size % dec.Channels]
+    while True:
+        n = dec.Read(buf, 0, buf.size)
+        if n == 0:
+            break
+        chunks.append(buf[:n].copy())
+    dec.close()
+    return np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+
+
+def _coverage(oracle, S, headers, packets, end_per_channel):
+    d = oracle.open_headers(headers)
+    try:
+        fracs, stages = [], set()
+        for p in packets:
+            got = oracle.packet_coverage(d, p)
+            assert got is not None
+            bs, mask = got
+            if bs != S.block1:
+                continue
+            m = mask[:, :end_per_channel]
+            fracs.append(float((m != 0).mean()))
+            for s in range(8):
+                if (m & (1 << s)).any():
+                    stages.add(s)
+        return fracs, stages
+    finally:
+        oracle.L.orc_close(d)
+
+
+def _assert_same(got, ref, what):
+    assert got.size == ref.size, (what, got.size, ref.size)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (what, float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize("psize", [48, 32])
+def test_c4_six_channel_full_depth_bit_exact(oracle, gpu_ctx, ogg_bytes, psize):
+    """BASELINE C4: 6 channels, 48 kHz, n = 4096, coupling [(0,2),(3,4)], Residue2 over 6 channels, end = 6 * 1536.
+    psize 48 = the headline shape, psize 32 = quirk B-1 at six channels (Residue2.cs:25-27: offset /= channels with
+    chPtr = 0, partitions not a multiple of the channel count -> the sequential path).  The oracle's residue trace of
+    the very packets decoded shows >= 95 % of [0, 1536) per channel touched (psize 48) and all three cascade stages."""
+    import nvorbis_amd as nv
+    hdr = ve.c4_headers(ve.shipped_headers(ogg_bytes["3test"]), psize=psize)
+    S = ve.setup_of(hdr)
+    weights = [0] + [1] * 9  # class 0 of this setup carries no books
+    pool = ve.packet_pool(S, 100 + psize, per_kind=40, class_weights=weights)
+    fracs, stages = _coverage(oracle, S, hdr, pool[(True, 1, 1)], 1536)
+    assert stages == {0, 1, 2}
+    assert min(fracs) >= (0.95 if psize == 48 else 0.60), min(fracs)
+    rng = np.random.default_rng(psize)
+    # all-long (the C4 definition) and a mixed stream with short blocks and every window transition
+    for kinds in (np.ones(1100, dtype=bool), ve.markov_kinds(rng, 300, 0.1, 0.3)):
+        pk, gr = ve.stream_from_pool(S, hdr, pool, kinds, rng)
+        fl = [0] * len(pk)
+        for clip in (True, False):
+            ref, info = oracle.decode_packets(pk, gr, fl, clip=clip)
+            assert info["channels"] == 6
+            for bf in (13, 1024):
+                _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, clip, bf), ref, (psize, clip, bf))
+        _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, True, 512, gpu_parse=True), oracle.decode_packets(pk, gr, fl)[0],
+                     (psize, "gpu_parse"))
+
+
+def test_c2_grand_full_size_bit_exact(oracle, gpu_ctx, ogg_bytes):
+    """BASELINE C2, generator G-rand (numpy default_rng(20260928)): 4096 stereo long frames, n = 2048, Floor1 + Residue2
+    on 3test.ogg's setup, every packet unique and full depth; one 4096-frame batch and small batches, host and GPU parser."""
+    import nvorbis_amd as nv
+    hdr = ve.shipped_headers(ogg_bytes["3test"])
+    S = ve.setup_of(hdr)
+    kinds = np.ones(4097, dtype=bool)
+    pk, gr = ve.encode_stream(S, hdr, kinds, 20260928)
+    fl = [0] * len(pk)
+    fracs, stages = _coverage(oracle, S, hdr, pk[3:200], 1888 // 2)
+    assert stages == {0, 1, 2} and np.mean(fracs) >= 0.88
+    for clip in (True, False):
+        ref, _ = oracle.decode_packets(pk, gr, fl, clip=clip)
+        assert ref.size == (4096 * 1024 + 1024) * 2
+        _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, clip, 4096), ref, ("C2", clip, 4096))
+    ref, _ = oracle.decode_packets(pk, gr, fl)
+    _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, True, 333), ref, ("C2", 333))
+    _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, True, 4096, gpu_parse=True), ref, ("C2", "gpu_parse"))
+
+
+def test_c3_markov_8192_frames_bit_exact(oracle, gpu_ctx, ogg_bytes):
+    """BASELINE C3: 8192 frames, block kinds from a 2-state Markov chain (P(L->S) = 0.03, P(S->L) = 0.12, seed 7) so all four
+    long windows and the short window occur with lapping transitions; full-depth packets; output count = sum(valid - start)."""
+    import nvorbis_amd as nv
+    hdr = ve.shipped_headers(ogg_bytes["3test"])
+    S = ve.setup_of(hdr)
+    rng = np.random.default_rng(7)
+    kinds = ve.markov_kinds(rng, 8192)
+    assert 0.1 < 1.0 - kinds.mean() < 0.4
+    pool = ve.packet_pool(S, 7, per_kind=96)
+    pk, gr = ve.stream_from_pool(S, hdr, pool, kinds, rng)
+    fl = [0] * len(pk)
+    ref, info = oracle.decode_packets(pk, gr, fl, trace=True)
+    tr = info["trace"]
+    seen = {(int(r[4]), int(r[5])) for r in tr if r[3]}
+    assert seen >= {(256, 0), (2048, 0), (2048, 1), (2048, 2), (2048, 3)}
+    # every packet but the first emits valid - start; the provider runs dry at the end, so the last block's tail follows
+    ok = [r for r in tr if r[3]]
+    emitted = sum(int(r[1] - r[0]) for r in ok[1:]) + int(ok[-1][2] - ok[-1][1])
+    assert ref.size == emitted * 2
+    assert gr[-1] * 2 <= ref.size
+    for bf in (1024, 4096):
+        _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, True, bf), ref, ("C3", bf))
+    _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, True, 2048, gpu_parse=True), ref, ("C3", "gpu_parse"))
+
+
+def test_c5_corpus_world1_from_device_buffers(oracle, ogg_bytes):
+    """BASELINE C5 at world size 1: files written by the corpus writer (Huffman-encoded side information, CRC-valid pages,
+    Markov block kinds, seed = file index) + the shipped files, decoded file-parallel into ONE device arena and "gathered"
+    from device memory (tools/corpus_transcode.py's path: transcode(..., to_host=False)); every file equals the oracle."""
+    import torch
+    from nvorbis_amd import corpus
+    hdr = ve.shipped_headers(ogg_bytes["3test"])
+    S = ve.setup_of(hdr)
+    pool = ve.packet_pool(S, 5, per_kind=24)
+    files = [ve.corpus_file(S, hdr, pool, i, scale=0.02) for i in range(28)] + [ogg_bytes[n] for n in ("1test", "2test", "3test", "issue6test")]
+    out = corpus.transcode(files, rank=0, world=1, dist=None, device="cuda:0", gpu=0, workers=6, to_host=False)
+    assert len(out) == len(files) and all(isinstance(o, torch.Tensor) and o.is_cuda for o in out)
+    # one arena: consecutive files are adjacent in device memory
+    assert all(out[i].data_ptr() + 4 * out[i].numel() == out[i + 1].data_ptr() for i in range(len(out) - 1))
+    for i, data in enumerate(files):
+        ref, _ = oracle.decode_ogg(data)
+        got = out[i].cpu().numpy()
+        _assert_same(got, ref, ("C5 file", i))
+    # and the threaded host-destination path gives the same bytes
+    host = corpus.decode_files_threaded(files[:8], device=0, workers=4, batch_frames=700)
+    for i in range(8):
+        _assert_same(host[i], out[i].cpu().numpy(), ("C5 host", i))

@@ -4,9 +4,12 @@
          tools/corpus_transcode.py --files 1000 [--dir DIR] [--workers 16]
 
 One process per GPU.  Files are sharded LPT-greedy by compressed size (no data-path collective), each rank decodes its
-shard with a pool of host threads (nvorbis_amd.corpus.decode_files_threaded), and the only exchange is the final gather
-of the PCM to rank 0 over RCCL / xGMI (all_gather of sample counts + point-to-point payloads, nvorbis_amd.corpus.gather_pcm).
-Without --dir the corpus is the four shipped test files cycled to --files entries.  Rank 0 prints one JSON line."""
+shard with a pool of host threads into one device arena (nvorbis_amd.corpus.decode_files_to_device: the overlap-add
+kernels write every file's PCM at its final device address), and the only exchange is the final gather of the PCM to
+rank 0 over RCCL / xGMI, device memory to device memory (all_gather of sample counts + grouped point-to-point payloads,
+nvorbis_amd.corpus.gather_pcm).  Corpus: --dir DIR (*.ogg), or --synthetic (files written by
+tests/vorbis_encode.py from 3test.ogg's setup, lengths log-uniform 5-300 s x --scale, seed = file index), else the four
+shipped test files cycled to --files entries.  Rank 0 prints one JSON line."""
 import argparse, glob, json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -18,6 +21,8 @@ ap.add_argument("--files", type=int, default=1000)
 ap.add_argument("--dir", type=str, default=None)
 ap.add_argument("--workers", type=int, default=16)
 ap.add_argument("--gpu-parse", action="store_true")
+ap.add_argument("--synthetic", action="store_true")
+ap.add_argument("--scale", type=float, default=0.05, help="length scale of the synthetic corpus (1.0 = 5-300 s per file)")
 a = ap.parse_args()
 rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
 torch.cuda.set_device(local)
@@ -30,6 +35,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if a.dir:
     names = sorted(glob.glob(os.path.join(a.dir, "*.ogg")))
     files = [open(n, "rb").read() for n in names]
+elif a.synthetic:
+    from tests import vorbis_encode as ve
+    hdr = ve.shipped_headers(open(os.path.join(root, "tests", "golden", "3test.ogg"), "rb").read())
+    S = ve.setup_of(hdr)
+    pool = ve.packet_pool(S, 5, per_kind=64)
+    files = [ve.corpus_file(S, hdr, pool, i, scale=a.scale) for i in range(a.files)]
 else:
     base = [open(os.path.join(root, "tests", "golden", n + ".ogg"), "rb").read() for n in ("1test", "2test", "3test", "issue6test")]
     files = [base[i % len(base)] for i in range(a.files)]
@@ -39,14 +50,14 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 shards = corpus.lpt_shards([len(f) for f in files], world)
 mine = shards[rank]
-pcm = corpus.decode_files_threaded([files[i] for i in mine], device=local, workers=a.workers, gpu_parse=a.gpu_parse)
+arena, views = corpus.decode_files_to_device([files[i] for i in mine], device=local, workers=a.workers, gpu_parse=a.gpu_parse)
 t1 = time.perf_counter()
-local_map = {i: np.ascontiguousarray(p, dtype=np.float32) for i, p in zip(mine, pcm)}
-out = corpus.gather_pcm(local_map, len(files), rank, world, dist, "cuda:%d" % local)
+local_map = {i: v for i, v in zip(mine, views)}
+out = corpus.gather_pcm(local_map, len(files), rank, world, dist, "cuda:%d" % local, to_host=False)  # stays in HBM
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 if rank == 0:
-    samples = sum(o.size for o in out)
+    samples = sum(int(o.numel()) for o in out)
     print(json.dumps({"files": len(files), "n_gpus": world, "workers_per_gpu": a.workers, "decode_s": t1 - t0, "gather_s": t2 - t1,
                       "files_per_s": len(files) / (t2 - t0), "pcm_floats": int(samples),
                       "long_frame_equivalents_per_s": samples / 2 / 1024 / (t2 - t0)}), flush=True)
