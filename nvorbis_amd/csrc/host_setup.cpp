@@ -152,11 +152,14 @@ int Codebook::init(BitReader& p) {
   if (p.read_bit()) {
     int len = (int)p.read(5) + 1;
     for (int i = 0; i < entries;) {
+      // The reference's loop (Codebook.cs:84-97) has no exit when the packet runs out: every further read returns 0,
+      // `i` stops advancing and `len` counts up for ever.  A hang is not behaviour to mirror across a C ABI that is
+      // handed untrusted files: a truncated header, a length no code can have, or a run past the last entry is
+      // reported as invalid data.
       int cnt = (int)p.read(ilog(entries - i));
-      while (--cnt >= 0) {
-        if (i >= entries) return NVH_ERR_RUNTIME;
-        lengths[i++] = len;
-      }
+      if (p.is_short || len > 32) return NVH_ERR_INVALID_DATA;
+      if (cnt > entries - i) return NVH_ERR_RUNTIME;  // lengths[i++] past the array: IndexOutOfRangeException
+      while (--cnt >= 0) lengths[i++] = len;
       ++len;
     }
     total = 0;
@@ -209,6 +212,11 @@ int Codebook::init(BitReader& p) {
   int value_bits = (int)p.read(4) + 1;
   bool sequence_p = p.read_bit();
   int64_t table_len = (int64_t)entries * dimensions;
+  // Documented limit of this build: a lookup table of more than 2^26 values (256 MB of floats;
+  // the largest table of any shipped file has 52 488) is refused before anything is sized by it -- the header fields
+  // are untrusted, entries * dimensions can reach 2^40.
+  if (table_len > ((int64_t)1 << 26)) return NVH_ERR_UNSUPPORTED;
+  if (p.is_short) return NVH_ERR_INVALID_DATA;  // truncated header: nothing below would be meaningful
   int lookup_value_count = (int)table_len;
   if (map_type == 1) {
     if (dimensions == 0 || entries == 0) return NVH_ERR_RUNTIME;
