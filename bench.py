@@ -9,7 +9,12 @@ IMDCT + window -> overlap-add + interleave + clip) over that batch, descriptors 
 HBM, PCM written to HBM.  Weak scaling: every rank owns one GPU and one such batch, no collective in
 the data path.
 
-Launch: python bench.py --gpus N --steps K --warmup W   (N > 1 via torch.distributed.run, one rank per GPU)
+Launch: python bench.py --gpus N --steps K --warmup W.  For N > 1 the script starts its own ranks (it re-executes
+itself under torch.distributed.run, one rank per GPU over RCCL) unless it already runs as a rank (WORLD_SIZE set).
+
+A step is `passes_per_step` passes over the batch, chosen from a calibration run so that the timed region lasts at least
+~0.25 s whatever --steps says (a 20-step run of one 45 us pass each would time 0.9 ms of launch jitter); the line states
+it in config, and `value` counts every pass.
 """
 import argparse
 import json
@@ -104,17 +109,49 @@ def cpu_baseline(headers, ll, seconds=12.0):
     return out
 
 
+def copy_ceiling(torch, nv, ctx, ts, mib=1024, iters=20):
+    """Measured HBM ceiling of this GPU: the library's float4 copy kernel (nvh_measure_copy) over buffers well past the
+    256 MiB Infinity Cache; bytes read + bytes written per second, hipEvents on the context's stream."""
+    import ctypes as C
+    n = mib << 20
+    src = torch.empty(n // 4, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    torch.cuda.synchronize()
+    ms = C.c_float(0)
+    nv.native.check(nv.lib().nvh_measure_copy(ctx._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n, 3, C.byref(ms)), "nvh_measure_copy")
+    nv.native.check(nv.lib().nvh_measure_copy(ctx._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n, iters, C.byref(ms)), "nvh_measure_copy")
+    ok = bool(torch.equal(src[:4096], dst[:4096]) and torch.equal(src[-4096:], dst[-4096:]))
+    del src, dst
+    return (2.0 * n * iters) / (ms.value * 1e-3) / 1e9 if ok and ms.value > 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
-                    help="independent decoder instances (own nvh_ctx / HIP stream / resident batch) the steps rotate over")
+                    help="independent decoder instances (own nvh_ctx / HIP stream / resident batch) the passes rotate over")
+    ap.add_argument("--min-timed-ms", type=float, default=250.0, help="lower bound of the timed region (sets passes_per_step)")
     args = ap.parse_args()
 
     import torch
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: become N ranks (one per GPU of this node, RCCL over xGMI)
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py --gpus %d: this node shows %d HIP device(s); the multi-GPU run needs %d\n" % (args.gpus, have, args.gpus))
+            raise SystemExit(2)
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     import nvorbis_amd as nv
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,6 +159,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU path to measure")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d (the ranks that actually run)\n" % (args.gpus, world, world))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -160,25 +199,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        insts[i % nin][3].synth(insts[i % nin][4].data_ptr(), cap)
+    def run_passes(n):
+        for i in range(n):
+            insts[i % nin][3].synth(insts[i % nin][4].data_ptr(), cap)
+
+    # calibration (untimed): how long one pass takes here, so that a step can be made of enough passes
+    run_passes(8)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        insts[i % nin][3].synth(insts[i % nin][4].data_ptr(), cap)
+    run_passes(64)
+    barrier()
+    pass_ms = (time.perf_counter() - t0) / 64 * 1e3
+    if dist is not None:
+        t = torch.tensor([pass_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pass_ms = float(t.item())
+    passes_per_step = max(1, int(args.min_timed_ms / max(args.steps, 1) / max(pass_ms, 1e-6) + 0.999))
+
+    for _ in range(args.warmup):
+        run_passes(passes_per_step)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_passes(passes_per_step)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    total_passes = args.steps * passes_per_step
 
     # per-kernel durations, hipEvents on the launch stream (rank 0 reports)
-    iters = max(10, min(args.steps, 50))
+    iters = 50
     total_ms, km = batch.time(pcm.data_ptr(), cap, iters)
     checksum = float(pcm.double().abs().sum().item())
-    if not os.environ.get("NVH_DEBUG_SPECTRUM_MASK"):
-        assert checksum > 0 and bool(torch.isfinite(pcm).all().item())
+    assert checksum > 0 and bool(torch.isfinite(pcm).all().item())
 
     if rank == 0:
         # the library says which kernel variant sits behind each timing slot ("-" = empty: only event overhead)
@@ -192,16 +248,21 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh);
         # null when the committed profile does not cover the kernel that ran
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("kernels", {}).get(names[dom], {}).get("hbm_bytes")
+                tj = json.load(open(tfile))
+                traffic = tj.get("kernels", {}).get(names[dom], {}).get("hbm_bytes")
+                if traffic is not None:
+                    traffic_source = "profiles/traffic.json: %s (committed rocprofv3 --pmc passes of this command, not measured in this run)" % tj.get("source", "?")
             except Exception:
                 traffic = None
+        ceiling = copy_ceiling(torch, nv, ctx, insts[0][0])
+        step_ms = elapsed / total_passes * 1e3
         out = {
             "metric": "decoded Vorbis frames/sec (44.1 kHz stereo long-block)",
-            "value": world * FRAMES * args.steps / elapsed,
+            "value": world * FRAMES * total_passes / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -214,12 +275,16 @@ def main():
             "data": "synthetic (3test.ogg long/long packets tiled to 4096 frames per GPU, device resident)",
             "config": {"workload": "C2: 4096 stereo long-block (n=2048) frames, Floor1+Residue2+coupling, IMDCT+window+OLA",
                        "frames_per_gpu": FRAMES, "channels": ch, "block": BLOCK, "parallelism": "frame-parallel x%d, %d HIP streams per GPU" % (world, nin),
+                       "passes_per_step": passes_per_step, "ms_per_pass": step_ms,
                        "descriptor_bytes_per_frame": batch.descriptor_bytes / FRAMES},
             "kernels_ms": {names[k]: km[k] for k in live},
             "pipeline_ms_events": total_ms / iters,
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                         # the same bytes over one whole pass of the pipeline (all kernels, the batches of the %d streams overlapped)
+                         "whole_pass_GBps": alg_bytes / (step_ms * 1e-3) / 1e9, "whole_pass_frac": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "copy_ceiling_GBps": ceiling},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(headers, ll)

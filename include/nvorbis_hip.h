@@ -116,6 +116,11 @@ int nvh_overlap_buffers(nvh_ctx *c, const float *d_previous, float *d_next, int 
 int nvh_copy_buffer(nvh_ctx *c, const float *d_planes, int start, int count, int channels, int64_t plane_stride,
                     float *d_target, int clip, int *clipped);
 
+/* Measurement helper (no reference counterpart): `iters` passes of a float4 copy kernel over `bytes` bytes (a multiple
+ * of 16) from d_src to d_dst, timed with HIP events on the context's stream; *ms = total.  bench.py reports
+ * 2 * bytes * iters / ms as the measured HBM ceiling next to the roofline figure. */
+int nvh_measure_copy(nvh_ctx *c, const void *d_src, void *d_dst, size_t bytes, int iters, float *ms);
+
 /* IMdct.Reverse(float[] samples, int sampleCount) (Contracts/IMdct.cs:5, Mdct.cs:13-21) on `batch`
  * buffers: buffer b = d_buf + b*stride holds n floats, reads [0,n/2), writes [0,n).  n = 64..8192. */
 int nvh_mdct_reverse(nvh_ctx *ctx, int n, int batch, float *d_buf, int64_t stride);
@@ -133,6 +138,9 @@ int nvh_calc_overlap(int prev_block, int block, int next_block, int *start, int 
 int nvh_stream_open(nvh_ctx *ctx, const uint8_t *id_pkt, int id_len, const uint8_t *comment_pkt, int comment_len,
                     const uint8_t *setup_pkt, int setup_len, nvh_stream **out);
 void nvh_stream_close(nvh_stream *s);
+/* IStreamDecoder.UpperBitrate / NominalBitrate / LowerBitrate (Contracts/IStreamDecoder.cs; the three 32-bit fields
+ * of the identification header, StreamDecoder.cs:191-193). */
+int nvh_stream_bitrates(const nvh_stream *s, int *upper, int *nominal, int *lower);
 int nvh_stream_info(const nvh_stream *s, int *channels, int *sample_rate, int *block0, int *block1);
 /* IStreamDecoder.ClipSamples (StreamDecoder.cs:723, default on) / HasClipped (:728) */
 /* Page-locked host memory for PCM destinations: nvh_stream_synth writes a pinned pcm_host directly with the copy
@@ -202,6 +210,11 @@ int nvh_stream_pending(const nvh_stream *s, int *frames, int64_t *pcm_samples_pe
  * pcm_host / d_pcm is non-NULL; capacity is in floats and must hold pending samples * channels.
  * Advances the overlap state (the last block's tail is carried to the next batch). */
 int nvh_stream_synth(nvh_stream *s, float *pcm_host, float *d_pcm, int64_t capacity, int64_t *written);
+/* After nvh_stream_synth returned an error code together with *written > 0 (GPU-parse mode: some packet of the batch
+ * made the parser fail -- the code nvh_stream_push_packet returns for it in host-parse mode -- and the batch was parsed
+ * again on the host without it): the number of samples per channel of that batch that precede the failing packet, i.e.
+ * where in the PCM the reference's exception would have surfaced; -1 when the last synthesis reported no such error. */
+int nvh_stream_error_offset(const nvh_stream *s, int64_t *samples_before);
 
 /* ---- device-resident batches (benchmarks, pipelined callers) ---- */
 /* Move the pending batch into HBM as an object of its own; the stream's pending batch becomes empty

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnvorbis_hip.so")
-SOURCES = ["nvh_api.hip", "kernels.hip", "kernels_imdct.hip", "kernels_spectrum.hip", "kernels_parse.hip", "host_setup.cpp", "host_parse.cpp", "host_ogg.cpp"]
+SOURCES = ["nvh_api.hip", "nvh_setup.hip", "nvh_launch.hip", "nvh_ops.hip", "kernels.hip", "kernels_imdct.hip", "kernels_spectrum.hip", "kernels_parse.hip", "host_setup.cpp", "host_parse.cpp", "host_ogg.cpp"]
 # -ffp-contract=off: bit-exact parity with the reference needs separately rounded mul/add (no v_fma_f32);
 # fp32 denormals are preserved by default (no -fgpu-flush-denormals-to-zero).
 # -fno-slp-vectorize: the SLP vectorizer pairs the butterflies of the wavefront IMDCT into v_pk_add_f32 / v_pk_mul_f32;
@@ -48,6 +48,23 @@ def build(force=False, verbose=False):
     return OUT
 
 
+DEBUG_OUT = os.path.join(HERE, "libnvorbis_hip_dbg.so")
+
+
+def build_debug(verbose=False):
+    """The profiling build (-DNVH_DEBUG): the spectrum kernels take a timestamp buffer and a phase mask
+    (nvh_debug_set_buffer, NVH_DEBUG_SPECTRUM_MASK; tools/dbg_phase*.py, tools/pmc_phases.sh).  Load it with
+    NVH_LIB=nvorbis_amd/libnvorbis_hip_dbg.so.  The release library has neither the parameters nor the export."""
+    cmd = [hipcc()] + FLAGS + ["-DNVH_DEBUG", "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", DEBUG_OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return DEBUG_OUT
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(OUT)
+    if "--debug" in sys.argv:
+        print(build_debug(verbose=True))
+    else:
+        build(force="--force" in sys.argv, verbose=True)
+        print(OUT)

@@ -343,8 +343,8 @@ def _push_range(st, packets, granules, flags, lo, hi):
             i += took
         return i
     while i < hi and not st.position()[2]:
-        st.push_packet(packets[i], granules[i], flags[i])
-        i += 1
+        i += 1  # a packet that makes push_packet raise is consumed all the same (the reference's `packet.Done()`)
+        st.push_packet(packets[i - 1], granules[i - 1], flags[i - 1])
     return i
 
 

@@ -658,11 +658,13 @@ int Setup::parse_id(const uint8_t* pkt, int len) {  // StreamDecoder.cs:179-204
   if (!validate_header(p, sig, 11)) return NVH_ERR_NOT_VORBIS;
   channels = (int)(uint8_t)p.read(8);
   sample_rate = (int)p.read(32);
-  p.read(32);
-  p.read(32);
-  p.read(32);
+  upper_bitrate = (int)p.read(32);    // StreamDecoder.cs:191-193: (int)packet.ReadBits(32)
+  nominal_bitrate = (int)p.read(32);
+  lower_bitrate = (int)p.read(32);
   block0 = 1 << (int)p.read(4);
   block1 = 1 << (int)p.read(4);
+  if (nominal_bitrate == 0 && upper_bitrate > 0 && lower_bitrate > 0)  // StreamDecoder.cs:196-199
+    nominal_bitrate = (int)((uint32_t)upper_bitrate + (uint32_t)lower_bitrate) / 2;  // the managed int sum wraps
   if (channels < 1) return NVH_ERR_RUNTIME;  // count % _channels divides by zero in the reference
   return NVH_OK;
 }

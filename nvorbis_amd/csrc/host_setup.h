@@ -107,6 +107,7 @@ struct MdctTables {                // Mdct.cs:30-63
 
 struct Setup {
   int channels = 0, sample_rate = 0, block0 = 0, block1 = 0;
+  int upper_bitrate = 0, nominal_bitrate = 0, lower_bitrate = 0;  // IStreamDecoder.UpperBitrate / NominalBitrate / LowerBitrate
   int mode_field_bits = 0;
   std::vector<Codebook> books;
   std::vector<Floor> floors;

@@ -826,6 +826,12 @@ k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, fl
 // Stand-alone mirrors of the remaining per-packet float loops (fine-grained ABI, unit parity)
 // ================================================================================================
 
+// Plain float4 copy (grid-stride, 16 bytes per lane): the measured HBM ceiling bench.py reports next to the roofline.
+extern "C" __global__ void __launch_bounds__(256)
+k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
 // Mode.Decode's window loop (Mode.cs:160-166): buf[b*stride + i] *= window[i] for i < n.
 extern "C" __global__ void __launch_bounds__(NVH_THREADS)
 k_window_apply(float* __restrict__ buf, const float* __restrict__ window, int n, long long stride, int batch) {

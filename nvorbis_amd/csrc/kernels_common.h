@@ -44,6 +44,17 @@ struct NvhDevBatch {
 // LDS words of one per-channel floor scratch block of k_spectrum (kernels_spectrum.hip: FloorScratch)
 #define NVH_SP_FLOOR_SCRATCH_WORDS 332
 
+// Profiling aids of the spectrum kernels (per-workgroup phase timestamps, phases masked out one at a time) exist only in
+// the debug build of the library (python -m nvorbis_amd.build --debug -> libnvorbis_hip_dbg.so, -DNVH_DEBUG); the release
+// kernels take neither parameter, so nothing in the shipped .so can skip work.
+#ifdef NVH_DEBUG
+#define NVH_DBG_PARAMS , long long* dbg, int phase_mask
+#define NVH_DBG_ARGS , dbg, phase_mask
+#else
+#define NVH_DBG_PARAMS
+#define NVH_DBG_ARGS
+#endif
+
 // error word written by kernels when the reference would have thrown (index out of range)
 enum { NVH_DEVERR_FLOOR1_Y = 1, NVH_DEVERR_FLOOR0_W = 2 };
 

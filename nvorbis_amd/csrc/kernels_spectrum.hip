@@ -932,35 +932,35 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
 // 8 waves per SIMD = 8 resident workgroups per CU: the register budget (64 VGPRs, 96 SGPRs) is part of the design
 extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
-           int cap_ent, long long* dbg, int phase_mask) {
+           int cap_ent NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<false, true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg, phase_mask);
+  spectrum_body<false, true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem NVH_DBG_ARGS);
 }
 
 // k_spectrum with the inverse MDCT behind it (block sizes 256..2048): writes the compact IMDCT output.
 extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
-                 int cap_ent, long long* dbg, int phase_mask) {
+                 int cap_ent NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<false, true, true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg, phase_mask);
+  spectrum_body<false, true, true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem NVH_DBG_ARGS);
 }
 
 // Any other Floor1 stream shape (more than two channels, several coupling steps, non-lattice books, aliasing
 // partitions, Residue0).
 extern "C" __global__ void __launch_bounds__(SP_THREADS)
 k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
-               int cap_ent, long long* dbg) {
+               int cap_ent NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<false, false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg);
+  spectrum_body<false, false>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem NVH_DBG_ARGS);
 }
 
 // k_spectrum_gen with 8 wavefronts per workgroup, for more than four channels: 48 KB of spectrum (six channels, n = 4096)
 // leave 3 workgroups per CU, so the wavefronts have to come from inside the workgroup; all floors are unwrapped at once.
 extern "C" __global__ void __launch_bounds__(512)
 k_spectrum_gen8(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
-                int cap_ent, long long* dbg) {
+                int cap_ent NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  spectrum_body<false, false, false, 512>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem, dbg);
+  spectrum_body<false, false, false, 512>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem NVH_DBG_ARGS);
 }
 
 // Variant for setups that contain a Floor0 (double-precision cos / sqrt / exp: costs registers, kept apart).

@@ -1,0 +1,311 @@
+// nvh_internal.h -- shared by the translation units behind the C ABI of libnvorbis_hip.so:
+//   nvh_api.hip     contexts, streams (packets in, PCM out), resident batches, the Ogg helper
+//   nvh_setup.hip   device images of a stream's setup (synthesis tables, GPU-parser tables)
+//   nvh_launch.hip  batch upload and the launch policy (which kernel variants a batch runs through)
+//   nvh_ops.hip     level-1 operators: device-pointer mirrors of the reference's interface methods
+// Nothing here is part of the ABI (include/nvorbis_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iterator>
+#include <map>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nvorbis_hip.h"
+#include "host_ogg.h"
+#include "host_parse.h"
+#include "host_setup.h"
+#include "kernels_common.h"
+#include "nvh_parse_format.h"
+
+extern "C" {
+__global__ void k_mdct_reverse(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
+                               const uint16_t* BR);
+__global__ void k_imdct_window(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_imdct_compact(NvhDevSetup S, NvhDevBatch Bt, float* work);
+__global__ void k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* work, float* carry_out, int f);
+__global__ void k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
+                              int* clipped_flag, float* carry_out, int last_decoded);
+__global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
+__global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
+__global__ void k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
+__global__ void k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
+__global__ void k_spectrum_gen8(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
+__global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
+                            int clip, int* clipped_flag, int run_len, int last_decoded);
+__global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
+                                    const float* TW);
+__global__ void k_parse(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
+                        NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
+                        NvhParseResult* result, int lanes, int scratch_words, int pkt_words);
+__global__ void k_parse_g(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
+                          NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
+                          NvhParseResult* result, int lanes, int scratch_words, int pkt_words);
+__global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
+                              uint32_t* carry_exec_out, int last_decoded);
+__global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
+__global__ void k_copy_f4(const float4* src, float4* dst, long long n4);
+__global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
+__global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,
+                                  long long plane_stride);
+__global__ void k_copy_buffer(const float* planes, int start, int count, int channels, long long plane_stride, float* target,
+                              int clip, int* clipped_flag);
+__global__ void k_floor0_apply(NvhDevSetup S, int floor_idx, const float* amps, const float* coeffs, int coeff_stride, int n,
+                               float* data, long long stride, int* status);
+__global__ void k_floor1_apply(NvhDevSetup S, int floor_idx, const uint16_t* posts, const int32_t* counts, int n, float* data,
+                               long long stride, int* status);
+__global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work, int clear);
+__global__ void k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err);
+__global__ void k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
+                           int* clipped_flag);
+__global__ void k_ola_emit_seq(NvhDevSetup S, NvhDevBatch Bt, float* work, const float* carry, float* pcm, int clip,
+                               int* clipped_flag);
+}
+
+extern thread_local int g_last_hip_error;
+
+#define HIP_TRY(expr)                        \
+  do {                                       \
+    hipError_t e_ = (expr);                  \
+    if (e_ != hipSuccess) {                  \
+      g_last_hip_error = (int)e_;            \
+      return NVH_ERR_DEVICE;                 \
+    }                                        \
+  } while (0)
+
+// No C++ exception may unwind through the C ABI (a P/Invoke or ctypes caller would be torn down with it): every
+// extern "C" entry point runs its body inside this barrier.  Header fields are untrusted and size std::vectors.
+template <class F>
+static inline int nvh_guard(F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return NVH_ERR_NOMEM;
+  } catch (...) {
+    return NVH_ERR_RUNTIME;
+  }
+}
+template <class F>
+static inline void nvh_guard_void(F&& body) noexcept {
+  try {
+    body();
+  } catch (...) {
+  }
+}
+
+// Test / experiment switches from the environment, read once per process (before the first context exists).
+struct NvhToggles {
+  bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
+  int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
+  int phase_mask;  // debug build only (NVH_DEBUG_SPECTRUM_MASK)
+};
+const NvhToggles& nvh_toggles();
+#ifdef NVH_DEBUG
+extern void* g_dbg_buf;  // per-workgroup phase timestamps of the spectrum kernels (nvh_debug_set_buffer)
+#define NVH_DBG_LAUNCH , (long long*)g_dbg_buf, nvh_toggles().phase_mask
+#else
+#define NVH_DBG_LAUNCH
+#endif
+
+// Device allocations are recycled through a per-context pool: hipMalloc / hipFree cost 0.1-1 ms each and
+// serialise inside the runtime, which is what a file-parallel transcoder (many short streams per context, many
+// contexts per GPU) would otherwise spend its time on.  Every buffer of a context is used on that context's HIP
+// stream only, so handing a block from a closed stream to the next one is ordered by the stream itself.
+struct BufPool {
+  bool host = false;  // true: pinned host memory (hipHostMalloc), staging for asynchronous copies
+  std::multimap<size_t, void*> free_;
+  size_t bytes_ = 0;
+  void raw_free(void* p) const { (void)(host ? hipHostFree(p) : hipFree(p)); }
+  static constexpr size_t kKeepBytes = (size_t)2 << 30;  // beyond this, returned blocks go back to the runtime
+  // size classes with two mantissa bits (<= 25 % slack) so that blocks are interchangeable between streams
+  static size_t size_class(size_t bytes) {
+    size_t v = bytes < 4096 ? 4096 : bytes;
+    size_t p = 1;
+    while ((p << 1) <= v) p <<= 1;
+    size_t step = p >> 2;
+    return (v + step - 1) / step * step;
+  }
+  void* take(size_t cls) {
+    auto it = free_.find(cls);
+    if (it == free_.end()) return nullptr;
+    void* p = it->second;
+    free_.erase(it);
+    bytes_ -= cls;
+    return p;
+  }
+  void give(void* p, size_t cls) {
+    if (bytes_ + cls > kKeepBytes) {
+      raw_free(p);
+      return;
+    }
+    free_.emplace(cls, p);
+    bytes_ += cls;
+  }
+  void clear() {
+    for (auto& kv : free_) raw_free(kv.second);
+    free_.clear();
+    bytes_ = 0;
+  }
+};
+
+struct DevBuf {  // growable device (or pinned host) allocation, optionally backed by a context's pool
+  void* p = nullptr;
+  size_t cap = 0;
+  BufPool* pool = nullptr;
+  bool host = false;  // pinned host memory; must match pool->host
+  ~DevBuf() { release(); }
+  void release() {
+    if (!p) return;
+    if (pool) pool->give(p, cap);
+    else (void)(host ? hipHostFree(p) : hipFree(p));
+    p = nullptr;
+    cap = 0;
+  }
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return NVH_OK;
+    release();
+    const size_t want = BufPool::size_class(bytes + 256);
+    if (pool) p = pool->take(want);
+    if (!p) {
+      if (host) HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+      else HIP_TRY(hipMalloc(&p, want));
+    }
+    cap = want;
+    return NVH_OK;
+  }
+};
+
+struct MdctDev {
+  int n = 0;
+  float *a = nullptr, *b = nullptr, *c = nullptr, *tw = nullptr;
+  uint16_t* br = nullptr;
+};
+
+// Everything derived from a stream's headers: parsed tables on the host, their device image, kernel-selection
+// flags.  Immutable once built, so streams with byte-identical identification + setup packets (the normal case
+// inside one corpus: same encoder, same settings) share one entry per context.
+struct SharedSetup {
+  nvh::Setup setup;
+  DevBuf arena;  // setup tables
+  NvhDevSetup dev{};
+  bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
+  bool has_floor0 = false;
+  // GPU packet parser (kernels_parse.hip): its tables, and whether this stream shape is inside its limits
+  DevBuf parse_arena;
+  NvhDevParse parse{};
+  bool gpu_parse_ok = false;
+};
+
+struct nvh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::map<int, MdctDev> mdct_cache;  // Mdct._setupCache (Mdct.cs:11)
+  BufPool pool;
+  BufPool hpool;  // pinned staging blocks
+  std::map<std::string, std::shared_ptr<SharedSetup>> setup_cache;  // key: identification packet + setup packet bytes
+  bool parse_lds_attr_set = false;  // k_parse's 80 KB dynamic-LDS opt-in was made on this context's device
+};
+
+struct nvh_batch {
+  nvh_stream* s = nullptr;
+  DevBuf blob;          // all descriptor arrays, one allocation
+  DevBuf h_blob;        // pinned staging image of it (the upload is asynchronous)
+  DevBuf slabs;         // GPU-parse mode: per-frame output slabs of k_parse + its scratch + result block
+  DevBuf work;          // [frames][ch][block1] float planes
+  DevBuf carry_in;      // snapshot of the tail this batch overlaps its first frame with
+  NvhDevBatch dev{};
+  int nframes = 0, chan_frames = 0;
+  int64_t pcm_samples = 0;
+  int64_t descriptor_bytes = 0;
+  int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // frames, chans, passes, ops, entries, posts, coeffs, -
+  bool sequential_ola = false;
+  int last_decoded = -1;  // last frame with n != 0 (its block becomes the next carried tail)
+  const char* slot_name[4] = {"-", "-", "-", "-"};  // kernels behind the four timing slots of the last launch
+  bool links_ok = false;  // op_link chains usable (every frame has < 32767 ops): k_spectrum's chain walk
+  int max_ops = 0, max_ent = 0, max_pass = 0;  // largest per-frame op / entry / pass slice (LDS staging capacity of k_spectrum)
+  bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
+  bool block_only = false;       // nvh_mode_decode: stop after the windowed IMDCT (full blocks in the work planes, no overlap-add)
+  bool has_carry_in = false;
+};
+
+// GPU-parse mode: everything pushed since the last batch boundary, so that a batch in which k_parse found a packet the
+// reference would throw on can be replayed through the host parser (same frames kept, same state, same error code as in
+// host-parse mode) instead of being dropped.
+struct ReplayLog {
+  enum { kPacket = 0, kEnd = 1, kPosition = 2 };
+  struct Event { int kind; int64_t off, len, granule; int flags; };
+  std::vector<uint8_t> bytes;
+  std::vector<Event> events;
+  void clear() { bytes.clear(); events.clear(); }
+};
+
+#define NVH_INTERNAL_REPLAY 1000  // batch_upload_gpu -> batch_upload: parse the logged packets on the host instead
+
+struct nvh_stream {
+  nvh_ctx* ctx = nullptr;
+  std::shared_ptr<SharedSetup> shared;
+  nvh::Setup& setup;
+  DevBuf& arena;
+  NvhDevSetup& dev;
+  bool& fast_spectrum;
+  bool& has_floor0;
+  std::unique_ptr<nvh::StreamParser> parser;
+  nvh::FrameBatch pending;
+  DevBuf carry[2];  // [ch][block1] windowed block of the last decoded frame (ping-pong: read one, write the other)
+  int carry_cur = 0;
+  DevBuf flags;  // int[2]: device error word, clipped flag
+  DevBuf pcm;    // staging for host-destination synth
+  DevBuf h_pcm;  // pinned bounce buffer behind it (+ 2 ints: the flag words), read back asynchronously
+  int clip = 1;
+  int has_clipped = 0;
+  bool gpu_parse = false;  // packets are parsed by k_parse; the host parser runs in light mode
+  DevBuf carry_exec;       // uint32[2], ping-pong with carry[]: execute flags of the carried block (GPU-parse mode)
+  nvh_batch scratch;  // reused by nvh_stream_synth
+  ReplayLog replay;
+  std::unique_ptr<nvh::StreamParser> replay_start;  // parser state at the first logged event
+  int replay_error = NVH_OK;                         // first error of the last replay (reported by the synthesis call)
+  int64_t replay_error_samples = 0;                  // samples per channel the batch emits before that packet
+
+  nvh_stream(nvh_ctx* c, std::shared_ptr<SharedSetup> sh)
+      : ctx(c), shared(std::move(sh)), setup(shared->setup), arena(shared->arena), dev(shared->dev),
+        fast_spectrum(shared->fast_spectrum), has_floor0(shared->has_floor0) {
+    BufPool* pool = c ? &c->pool : nullptr;
+    carry[0].pool = carry[1].pool = flags.pool = pcm.pool = carry_exec.pool = pool;
+    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = pool;
+    h_pcm.host = scratch.h_blob.host = true;
+    h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;
+    scratch.s = this;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+
+// hipEvent that is destroyed on every path out of a function (the HIP_TRY macro returns early).
+struct ScopedEvent {
+  hipEvent_t e = nullptr;
+  ~ScopedEvent() {
+    if (e) (void)hipEventDestroy(e);
+  }
+  int create() { HIP_TRY(hipEventCreate(&e)); return NVH_OK; }
+};
+
+static inline bool valid_block(int n) { return n >= 64 && n <= 8192 && (n & (n - 1)) == 0; }
+// LDS bytes of the wavefront IMDCT: n/4 complex points + 1/8 padding (kernels_imdct.hip Geo<LD>::LDS_FLOATS)
+static inline size_t wave_lds_bytes(int n) { return (size_t)2 * ((size_t)(n / 4) + (size_t)(n / 32)) * sizeof(float); }
+
+int get_mdct(nvh_ctx* c, int n, MdctDev** out);                 // nvh_ops.hip
+int upload_setup(nvh_stream* s);                                 // nvh_setup.hip
+int upload_parse_tables(nvh_stream* s);                          // nvh_setup.hip
+int batch_upload(nvh_stream* s, nvh_batch* b);                   // nvh_launch.hip
+int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms);  // nvh_launch.hip
+int collect_flags(nvh_stream* s);                                // nvh_launch.hip
+void replay_note(nvh_stream* s, int kind, const uint8_t* data, int len, int64_t granule, int flags);  // nvh_launch.hip

@@ -1,0 +1,425 @@
+// nvh_launch.hip -- moving a parsed batch into HBM and the launch policy: which kernel variants a batch runs through.
+#include "nvh_internal.h"
+
+static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResult* d_res);
+
+void replay_note(nvh_stream* s, int kind, const uint8_t* data, int len, int64_t granule, int flags) {
+  if (!s->gpu_parse) return;
+  if (s->replay.events.empty()) s->replay_start.reset(new nvh::StreamParser(*s->parser));
+  ReplayLog::Event e{kind, (int64_t)s->replay.bytes.size(), (int64_t)len, granule, flags};
+  if (kind == ReplayLog::kPacket && len > 0) s->replay.bytes.insert(s->replay.bytes.end(), data, data + len);
+  s->replay.events.push_back(e);
+}
+
+// k_parse found a packet the managed decoder would throw on.  The host parser in light mode has already walked past the
+// whole look-ahead batch, so: back to the state at the batch boundary, and the logged packets once more through the full
+// host parser.  The throwing packet(s) are consumed and leave no frame -- exactly what a caller of the host-parse mode
+// gets who catches the exception and keeps reading, as a caller of the reference may (StreamDecoder.cs:465-530: the
+// packet is `Done()` in the finally block, the previous-block state is untouched).  The first error code and the number
+// of samples emitted before it are kept for the synthesis call to report.
+static int replay_on_host(nvh_stream* s) {
+  if (!s->replay_start) return NVH_ERR_RUNTIME;
+  *s->parser = *s->replay_start;
+  s->parser->set_light(false);
+  s->pending.clear();
+  static const uint8_t empty = 0;
+  int first = NVH_OK;
+  for (const ReplayLog::Event& e : s->replay.events) {
+    int rc = NVH_OK;
+    if (e.kind == ReplayLog::kEnd) rc = s->parser->push_end(s->pending);
+    else if (e.kind == ReplayLog::kPosition) s->parser->set_position_state(e.flags != 0, e.granule);
+    else rc = s->parser->push_packet(e.len ? s->replay.bytes.data() + e.off : &empty, (int)e.len, e.granule, e.flags, s->pending);
+    if (rc != NVH_OK && first == NVH_OK) {
+      first = rc;
+      s->replay_error_samples = s->pending.pcm_samples;
+    }
+  }
+  s->parser->set_light(true);
+  s->replay_error = first;
+  return NVH_OK;
+}
+
+// GPU-parse mode: upload frame geometry + packets, let k_parse produce the descriptors into per-frame slabs.
+static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
+  nvh::FrameBatch& P = s->pending;
+  const NvhDevParse& T = s->shared->parse;
+  const int ch = s->setup.channels;
+  const size_t nf = P.frames.size();
+  P.pkt_refs.resize(nf);  // trailing pseudo-frames
+  if (P.pkt_pool.empty()) P.pkt_pool.resize(8, 0);
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  // host-written prefix of the blob ...
+  const size_t o_fr = 0;
+  const size_t o_ch = al(o_fr + std::max<size_t>(nf, 1) * sizeof(NvhFrame));
+  const size_t o_rf = al(o_ch + std::max<size_t>(nf * ch, 1) * sizeof(NvhChan));
+  const size_t o_pk = al(o_rf + std::max<size_t>(nf, 1) * sizeof(NvhPacketRef));
+  const size_t host_bytes = al(o_pk + P.pkt_pool.size() + 8);
+  // ... and the device-only slabs behind it
+  const size_t o_ps = host_bytes;
+  const size_t o_op = al(o_ps + nf * (size_t)T.cap_pass * sizeof(NvhResPass));
+  const size_t o_lk = al(o_op + nf * (size_t)T.cap_ops * sizeof(NvhResOp));
+  const size_t o_en = al(o_lk + nf * (size_t)T.cap_ops * sizeof(uint16_t));
+  const size_t o_po = al(o_en + nf * (size_t)T.cap_ent * sizeof(uint16_t) + 64);
+  const size_t o_sc = al(o_po + nf * (size_t)ch * NVH_MAX_POSTS * sizeof(uint16_t));
+  const size_t o_rs = al(o_sc + nf * 2 * (size_t)T.cap_parts * sizeof(int));
+  const size_t total = al(o_rs + sizeof(NvhParseResult));
+  int rc = b->blob.reserve(total);
+  if (rc != NVH_OK) return rc;
+  if ((rc = b->h_blob.reserve(host_bytes)) != NVH_OK) return rc;
+  uint8_t* h = (uint8_t*)b->h_blob.p;
+  if (nf) std::memcpy(h + o_fr, P.frames.data(), nf * sizeof(NvhFrame));
+  if (nf) std::memcpy(h + o_ch, P.chans.data(), std::min(P.chans.size(), nf * (size_t)ch) * sizeof(NvhChan));
+  if (nf) std::memcpy(h + o_rf, P.pkt_refs.data(), nf * sizeof(NvhPacketRef));
+  std::memcpy(h + o_pk, P.pkt_pool.data(), P.pkt_pool.size());
+  std::memset(h + o_pk + P.pkt_pool.size(), 0, 8);
+  b->descriptor_bytes = (int64_t)(nf * (sizeof(NvhFrame) + sizeof(NvhPacketRef)) + P.pkt_pool.size());
+  hipStream_t st = s->ctx->stream;
+  uint8_t* base = (uint8_t*)b->blob.p;
+  HIP_TRY(hipMemcpyAsync(base, h, host_bytes, hipMemcpyHostToDevice, st));
+  NvhParseResult init{};
+  init.err_frame = 0x7FFFFFFF;
+  init.links_ok = 1;
+  // (a 32-byte pageable source: staged by the runtime before the call returns)
+  HIP_TRY(hipMemcpyAsync(base + o_rs, &init, sizeof init, hipMemcpyHostToDevice, st));
+  b->dev.frames = (const NvhFrame*)(base + o_fr);
+  b->dev.chans = (const NvhChan*)(base + o_ch);
+  b->dev.passes = (const NvhResPass*)(base + o_ps);
+  b->dev.ops = (const NvhResOp*)(base + o_op);
+  b->dev.op_link = (const uint16_t*)(base + o_lk);
+  b->dev.entries = (const uint16_t*)(base + o_en);
+  b->dev.posts = (const uint16_t*)(base + o_po);
+  b->dev.coeffs = (const float*)(base + o_po);  // no Floor0 in this mode
+  b->dev.nframes = b->nframes;
+  b->dev.pad = 0;
+  if (nf) {
+    const unsigned blocks = (unsigned)((nf + 63) / 64);
+    // Launch shape.  Packets take different paths through the parser, so the lanes of a wavefront mostly run one after
+    // the other, and one wavefront alone issues an instruction every ~5 cycles at best: aim at ~2 wavefronts per SIMD
+    // (2048 in all) with as few packets each as that allows; workgroups of 4 wavefronts, two per CU (LDS tables).
+    const int lanes_env = nvh_toggles().parse_lanes, waves_env = nvh_toggles().parse_waves;
+    const int kParseWaves = (waves_env >= 1 && waves_env <= 16) ? waves_env : 4;
+    int lanes = 1;
+    while (lanes < 64 && (nf + (size_t)lanes - 1) / (size_t)lanes > 2048) lanes *= 2;
+    if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
+    const size_t per_wg = (size_t)kParseWaves * (size_t)lanes;
+    const unsigned pblocks = (unsigned)((nf + per_wg - 1) / per_wg);
+    // per-lane LDS next to the tables, while two workgroups still fit a CU (2 x 80 KB): the residue scratch rows first,
+    // then the packets (sized for the longest packet of the batch)
+    size_t max_pkt_words = 1;
+    for (size_t i = 0; i < nf; i++) max_pkt_words = std::max<size_t>(max_pkt_words, ((size_t)P.pkt_refs[i].bit_len + 31) / 32 + 1);
+    const size_t table_words = (size_t)(T.lds_words + T.meta_words);
+    const size_t lds_cap_words = 80 * 1024 / 4;
+    int scratch_words = 2 * T.cap_parts, pkt_words = (int)max_pkt_words;
+    // LDS variant only when both the rows and the longest packet of the batch fit for every lane; else everything per-lane
+    // stays in global memory (k_parse_g)
+    const bool in_lds = table_words + per_wg * (size_t)(scratch_words + pkt_words) <= lds_cap_words;
+    if (!in_lds) scratch_words = pkt_words = 0;
+    const size_t parse_lds = (table_words + per_wg * (size_t)(scratch_words + pkt_words)) * sizeof(uint32_t);
+    if (!s->ctx->parse_lds_attr_set) {  // the opt-in is per device: once per context (contexts are single-threaded)
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_g, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      s->ctx->parse_lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(in_lds ? k_parse : k_parse_g, dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
+                       (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
+                       (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
+                       (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
+                       (NvhParseResult*)(base + o_rs), lanes, scratch_words, pkt_words);
+    // the carried block's execute flags ping-pong together with the carried block (nvh_stream_synth flips carry_cur)
+    uint32_t* ce = (uint32_t*)s->carry_exec.p;
+    hipLaunchKernelGGL(k_parse_links, dim3(blocks), dim3(64), 0, st, (int)nf, ch, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch),
+                       (const uint32_t*)(ce + s->carry_cur), ce + (s->carry_cur ^ 1), b->last_decoded);
+    HIP_TRY(hipGetLastError());
+  }
+  rc = collect_parse_result(s, b, (const NvhParseResult*)(base + o_rs));
+  if (rc != NVH_OK) return rc;
+  size_t plane = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
+  rc = b->work.reserve(std::max<size_t>((size_t)b->nframes, 1) * plane);
+  if (rc != NVH_OK) return rc;
+  P.clear();
+  s->parser->begin_batch();
+  return NVH_OK;
+}
+
+// Reads k_parse's batch-level result back (one small copy + synchronisation): sizes the LDS staging of the
+// spectrum kernel and reports the first packet the reference would have thrown on.
+static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResult* d_res) {
+  hipStream_t st = s->ctx->stream;
+  int rc = s->h_pcm.reserve(sizeof(NvhParseResult));
+  if (rc != NVH_OK) return rc;
+  NvhParseResult* r = (NvhParseResult*)s->h_pcm.p;
+  HIP_TRY(hipMemcpyAsync(r, d_res, sizeof *r, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  b->max_ops = r->max_ops;
+  b->max_ent = r->max_ent;
+  b->max_pass = r->max_pass;
+  b->links_ok = r->links_ok != 0;
+  // some packet of the batch would have made the managed decoder throw: the batch is parsed again on the host
+  if (r->err_frame != 0x7FFFFFFF) return NVH_INTERNAL_REPLAY;
+  return NVH_OK;
+}
+
+int batch_upload(nvh_stream* s, nvh_batch* b) {
+  nvh::FrameBatch& P = s->pending;
+  b->s = s;
+  b->nframes = (int)P.frames.size();
+  b->chan_frames = (int)P.chans.size();
+  b->pcm_samples = P.pcm_samples;
+  b->sequential_ola = P.sequential_ola;
+  b->last_decoded = -1;
+  b->max_ops = b->max_ent = b->max_pass = 0;
+  b->links_ok = P.links_ok && P.op_link.size() == P.ops.size();
+  for (const NvhFrame& fr : P.frames) {
+    if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
+    if ((int)fr.ent_count > b->max_ent) b->max_ent = (int)fr.ent_count;
+    if ((int)(fr.pass_end - fr.pass_begin) > b->max_pass) b->max_pass = (int)(fr.pass_end - fr.pass_begin);
+    // kernels index channel records by frame: every frame owns exactly `channels` of them (host_parse.cpp)
+    if (fr.chan_off != (uint32_t)((size_t)(&fr - P.frames.data()) * (size_t)s->setup.channels)) return NVH_ERR_RUNTIME;
+  }
+  {
+    // preconditions of the fused IMDCT + overlap-add kernel (kernels_imdct.hip, k_imdct_ola)
+    bool ok = !P.sequential_ola && s->setup.block0 >= 256 && s->setup.block1 <= 2048 && s->setup.channels <= 4;
+    for (size_t i = 0; ok && i < P.frames.size(); i++) {
+      const NvhFrame& fr = P.frames[i];
+      if (fr.n == 0) {
+        ok = fr.ov_frame == -2;
+        continue;
+      }
+      if (fr.ov_len > 0) {
+        const bool src_ok = fr.ov_frame == -2 || (fr.ov_frame == (int)i - 1 && P.frames[i - 1].n != 0);
+        ok = src_ok && fr.start + fr.ov_len <= fr.n / 2 && fr.ov_src >= fr.ov_n / 2 && fr.ov_src + fr.ov_len <= fr.ov_n &&
+             fr.ov_n >= 256 && fr.ov_n <= 2048;
+      }
+    }
+    b->fused_ola = ok;
+  }
+  for (int i = b->nframes - 1; i >= 0; --i)
+    if (P.frames[(size_t)i].n != 0) {
+      b->last_decoded = i;
+      break;
+    }
+
+  b->stats[0] = (int64_t)P.frames.size(); b->stats[1] = (int64_t)P.chans.size(); b->stats[2] = (int64_t)P.passes.size();
+  b->stats[3] = (int64_t)P.ops.size(); b->stats[4] = (int64_t)P.entries.size(); b->stats[5] = (int64_t)P.posts.size();
+  b->stats[6] = (int64_t)P.coeffs.size();
+  if (s->gpu_parse) {
+    int rc = batch_upload_gpu(s, b);
+    if (rc != NVH_INTERNAL_REPLAY) {
+      if (rc == NVH_OK) s->replay.clear();
+      return rc;
+    }
+    if ((rc = replay_on_host(s)) != NVH_OK) return rc;
+    s->gpu_parse = false;  // this batch goes up as host-parsed descriptors
+    rc = batch_upload(s, b);
+    s->gpu_parse = true;
+    s->replay.clear();
+    return rc;
+  }
+  // the descriptor arrays are laid out back to back (16-byte aligned) in one pinned staging block and go to the
+  // device with one asynchronous copy; the caller decides when the stream is synchronised
+  auto pad1 = [](size_t n) { return n ? n : (size_t)1; };
+  static const uint8_t dummy[64] = {0};
+  struct Piece { const void* src; size_t n, off; };
+  std::vector<Piece> pieces;
+  size_t total = 0;
+  auto add = [&](const void* src, size_t count, size_t elem) {
+    const size_t n = pad1(count) * elem;
+    total = (total + 15) / 16 * 16;
+    pieces.push_back({count ? src : (const void*)dummy, count ? n : (n < sizeof dummy ? n : sizeof dummy), total});
+    total += n;
+    return pieces.back().off;
+  };
+  size_t o_fr = add(P.frames.data(), P.frames.size(), sizeof(NvhFrame));
+  size_t o_ch = add(P.chans.data(), P.chans.size(), sizeof(NvhChan));
+  size_t o_ps = add(P.passes.data(), P.passes.size(), sizeof(NvhResPass));
+  size_t o_op = add(P.ops.data(), P.ops.size(), sizeof(NvhResOp));
+  size_t o_lk = add(P.op_link.data(), P.op_link.size(), sizeof(uint16_t));
+  size_t o_en = add(P.entries.data(), P.entries.size(), sizeof(uint16_t));
+  size_t o_po = add(P.posts.data(), P.posts.size(), sizeof(uint16_t));
+  size_t o_co = add(P.coeffs.data(), P.coeffs.size(), sizeof(float));
+  total += 64;  // k_spectrum copies entry slices in whole 16-byte vectors
+  b->descriptor_bytes = (int64_t)(P.frames.size() * sizeof(NvhFrame) + P.chans.size() * sizeof(NvhChan) +
+                                  P.passes.size() * sizeof(NvhResPass) + P.ops.size() * (sizeof(NvhResOp) + sizeof(uint16_t)) +
+                                  P.entries.size() * 2 + P.posts.size() * 2 + P.coeffs.size() * 4);
+  int rc = b->blob.reserve(total);
+  if (rc != NVH_OK) return rc;
+  if ((rc = b->h_blob.reserve(total)) != NVH_OK) return rc;
+  for (const Piece& pc : pieces) std::memcpy((uint8_t*)b->h_blob.p + pc.off, pc.src, pc.n);
+  hipStream_t st = s->ctx->stream;
+  HIP_TRY(hipMemcpyAsync(b->blob.p, b->h_blob.p, total, hipMemcpyHostToDevice, st));
+  const uint8_t* base = (const uint8_t*)b->blob.p;
+  b->dev.frames = (const NvhFrame*)(base + o_fr);
+  b->dev.chans = (const NvhChan*)(base + o_ch);
+  b->dev.passes = (const NvhResPass*)(base + o_ps);
+  b->dev.ops = (const NvhResOp*)(base + o_op);
+  b->dev.op_link = (const uint16_t*)(base + o_lk);
+  b->dev.entries = (const uint16_t*)(base + o_en);
+  b->dev.posts = (const uint16_t*)(base + o_po);
+  b->dev.coeffs = (const float*)(base + o_co);
+  b->dev.nframes = b->nframes;
+  b->dev.pad = 0;
+
+  size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
+  rc = b->work.reserve(pad1((size_t)b->nframes) * plane);
+  if (rc != NVH_OK) return rc;
+  P.clear();
+  s->parser->begin_batch();
+  return NVH_OK;
+}
+
+int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms) {
+  nvh_stream* s = b->s;
+  hipStream_t st = s->ctx->stream;
+  if (b->nframes == 0) return NVH_OK;
+  const int ch = s->setup.channels;
+  float* work = (float*)b->work.p;
+  int* flags = (int*)s->flags.p;
+  const size_t lds = (size_t)s->setup.block1 * sizeof(float);
+  ScopedEvent sev[5];
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (timing)
+    for (int k = 0; k < 5; k++) {
+      int rc = sev[k].create();
+      if (rc != NVH_OK) return rc;
+      ev[k] = sev[k].e;
+    }
+  if (timing) HIP_TRY(hipEventRecord(ev[0], st));
+  // compact hand-over (two independent quarters per block, windowed in the overlap kernel) whenever no overlap
+  // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
+  const NvhToggles& T = nvh_toggles();
+  const bool no_compact = T.no_compact, no_fused_ola = !T.fused_ola /* experimental run-based kernel: opt-in */, no_fused_imdct = T.no_fused_imdct;
+  const bool use_fused_ola = b->fused_ola && !no_fused_ola && !b->block_only;
+  const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola && !b->block_only;
+  // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers
+  const bool fast = s->fast_spectrum && b->links_ok;  // k_spectrum proper (pair path by chain walk, fused tail)
+  bool fuse_imdct = compact && fast && s->setup.block1 <= 2048 && !no_fused_imdct;  // and the LDS-resident path is taken (below)
+  // Fused spectrum kernel when a frame's spectrum (+ staged side information) fits the default 64 KB dynamic
+  // LDS window; LDS map in kernels_spectrum.hip.
+  {
+    const bool has_floor0 = s->has_floor0;
+    // more than four channels without Floor0: 8 wavefronts per workgroup (k_spectrum_gen8), one floor scratch block each
+    const bool no_gen8 = T.no_gen8;
+    const bool gen8 = !has_floor0 && !fast && ch > 4 && !no_gen8;
+    const int scratch_blocks = gen8 ? (ch < 8 ? ch : 8) : (ch < 4 ? ch : 4);
+    const size_t scratch_words = (size_t)scratch_blocks * NVH_SP_FLOOR_SCRATCH_WORDS;
+    // staging capacities; the entry slice is copied from its enclosing 16-byte boundary (up to 7 entries of slack)
+    int cap_pass = b->max_pass, cap_ops = (b->max_ops + 7) & ~7, cap_ent = (b->max_ent + 14) & ~7;
+    const size_t staging_words = (size_t)s->setup.books.size() * 8 + (size_t)((s->dev.lattice_words + 3) & ~3) + (size_t)cap_pass * 16 +
+                                 (size_t)cap_ops * 6 + (size_t)cap_ops / 2 + (size_t)cap_ent / 2;  // ops 2 + pair records 4 + links 1/2 words per op
+    // k_spectrum_gen8 overlays the floor scratch on the staged side information (dead by the time the floors are prepared)
+    size_t words = (size_t)(has_floor0 ? 512 : 256) + (gen8 ? std::max(scratch_words, staging_words) : scratch_words + staging_words) +
+                   (size_t)ch * (size_t)(s->setup.block1 / 2);
+    if (T.unfused) words = 1u << 20;  // test aid: force the unfused kernels below
+    if ((words + (size_t)(s->setup.block1 / 16)) * 4 > 64 * 1024) fuse_imdct = false;
+    const size_t lds_pad = (size_t)T.lds_pad;  // occupancy experiments
+    if (words * 4 <= 64 * 1024) {
+      if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
+      b->slot_name[0] = "-";
+      b->slot_name[1] = has_floor0 ? "k_spectrum_f0" : (fast ? "k_spectrum" : "k_spectrum_gen");
+      if (has_floor0) {
+        hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
+                           cap_pass, cap_ops, cap_ent);
+      } else if (gen8) {
+        b->slot_name[1] = "k_spectrum_gen8";
+        hipLaunchKernelGGL(k_spectrum_gen8, dim3((unsigned)b->nframes), dim3(512), words * 4, st, s->dev, b->dev, work, flags,
+                           cap_pass, cap_ops, cap_ent NVH_DBG_LAUNCH);
+      } else if (!fast) {
+        hipLaunchKernelGGL(k_spectrum_gen, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
+                           cap_pass, cap_ops, cap_ent NVH_DBG_LAUNCH);
+      } else {
+        if (T.debug_occ) {
+          int nb = -1;
+          hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_spectrum, 256, words * 4 + lds_pad);
+          hipFuncAttributes fa;
+          (void)hipFuncGetAttributes(&fa, (const void*)k_spectrum);
+          fprintf(stderr, "k_spectrum: lds %zu B, occupancy %d WG/CU (err %d), regs %d, static lds %zu, max dyn lds %d\n", words * 4 + lds_pad, nb,
+                  (int)oe, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+        }
+        if (fuse_imdct) {
+          // + the IMDCT padding of the last channel (n/16 floats past the spectrum area)
+          b->slot_name[1] = "k_spectrum_imdct";
+          hipLaunchKernelGGL(k_spectrum_imdct, dim3((unsigned)b->nframes), dim3(256), words * 4 + (size_t)(s->setup.block1 / 16) * 4 + lds_pad,
+                             st, s->dev, b->dev, work, flags, cap_pass, cap_ops, cap_ent NVH_DBG_LAUNCH);
+        } else {
+          hipLaunchKernelGGL(k_spectrum, dim3((unsigned)b->nframes), dim3(256), words * 4 + lds_pad, st, s->dev, b->dev, work, flags,
+                             cap_pass, cap_ops, cap_ent NVH_DBG_LAUNCH);
+        }
+      }
+    } else {
+      b->slot_name[0] = "k_residue"; b->slot_name[1] = "k_couple_floor";
+      hipLaunchKernelGGL(k_residue, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, 1);
+      if (timing) HIP_TRY(hipEventRecord(ev[1], st));
+      hipLaunchKernelGGL(k_couple_floor, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, work, flags);
+    }
+  }
+  if (timing) HIP_TRY(hipEventRecord(ev[2], st));
+  const int run_len_env = T.run_len;
+  const size_t plane_bytes = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
+  if (use_fused_ola) {
+    // one workgroup per run of frames, one wavefront per channel; keep >= ~2048 waves in flight
+    int run_len = run_len_env > 0 ? run_len_env : 4;
+    while (run_len > 1 && (long long)(b->nframes / run_len) * ch < 2048) run_len >>= 1;
+    const int runs = (b->nframes + run_len - 1) / run_len;
+    const size_t ola_lds = (size_t)ch * (wave_lds_bytes(s->setup.block1) + (size_t)(s->setup.block1 / 2) * sizeof(float));
+    b->slot_name[2] = "k_imdct_ola"; b->slot_name[3] = "-";
+    hipLaunchKernelGGL(k_imdct_ola, dim3((unsigned)runs), dim3((unsigned)(64 * ch)), ola_lds, st, s->dev, b->dev, (const float*)work,
+                       carry, carry_out, d_pcm, s->clip, flags + 1, run_len, b->last_decoded);
+    if (timing) HIP_TRY(hipEventRecord(ev[3], st));  // slot 2 = fused IMDCT+OLA, slot 3 empty
+  } else {
+    b->slot_name[2] = fuse_imdct ? "-" : compact ? "k_imdct_compact" : (s->setup.block0 >= 256 ? "k_imdct_wave" : "k_imdct_window");
+    b->slot_name[3] = compact ? "k_ola_compact" : (!b->sequential_ola ? "k_ola_emit" : "k_ola_emit_seq");
+    if (fuse_imdct)
+      ;  // done inside k_spectrum_imdct
+    else if (compact)
+      hipLaunchKernelGGL(k_imdct_compact, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
+                         b->dev, work);
+    else if (s->setup.block0 >= 256)
+      hipLaunchKernelGGL(k_imdct_wave, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
+                         b->dev, work);
+    else
+      hipLaunchKernelGGL(k_imdct_window, dim3((unsigned)(b->nframes * ch)), dim3(256), lds, st, s->dev, b->dev, work);
+    if (timing) HIP_TRY(hipEventRecord(ev[3], st));
+    if (b->block_only) {
+      b->slot_name[3] = "-";  // nvh_mode_decode: the caller wants the windowed blocks themselves
+    } else if (compact) {
+      // 128 lanes per frame: 21.4 us instead of 24.8 us on its own (more loads in flight per frame); with two batches
+      // in flight it is a wash against 64, and 256 lanes start to take wave slots from the other batch's spectrum kernel
+      const int ola_env = T.ola_threads;
+      const int ola_threads = (ola_env == 64 || ola_env == 128 || ola_env == 256) ? ola_env : 128;
+      hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
+                         (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded);
+    } else if (!b->sequential_ola)
+      hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
+                         d_pcm, s->clip, flags + 1);
+    else
+      hipLaunchKernelGGL(k_ola_emit_seq, dim3(1), dim3(256), 0, st, s->dev, b->dev, work, carry, d_pcm, s->clip, flags + 1);
+    // the last decoded block becomes the carried tail (StreamDecoder's _prevPacketBuf), always fully windowed
+    if (!compact && !b->block_only && b->last_decoded >= 0 && carry_out)
+      HIP_TRY(hipMemcpyAsync(carry_out, (const uint8_t*)b->work.p + (size_t)b->last_decoded * plane_bytes, plane_bytes,
+                             hipMemcpyDeviceToDevice, st));
+  }
+  if (timing) HIP_TRY(hipEventRecord(ev[4], st));
+  HIP_TRY(hipGetLastError());
+  if (timing) {
+    HIP_TRY(hipEventSynchronize(ev[4]));
+    for (int k = 0; k < 4; k++) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+      kernel_ms[k] += ms;
+    }
+  }
+  return NVH_OK;
+}
+
+// Reads and clears the device error / clipped words; maps device errors to status codes.
+int collect_flags(nvh_stream* s) {
+  int h[2] = {0, 0};
+  hipStream_t st = s->ctx->stream;
+  HIP_TRY(hipMemcpyAsync(h, s->flags.p, sizeof h, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (h[0] || h[1]) HIP_TRY(hipMemsetAsync(s->flags.p, 0, sizeof h, st));
+  if (h[1]) s->has_clipped = 1;
+  if (h[0]) return NVH_ERR_RUNTIME;  // inverse_dB_table / wMap index out of range in the reference
+  return NVH_OK;
+}
+

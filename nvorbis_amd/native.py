@@ -42,6 +42,8 @@ SIGNATURES = {
     "nvh_ctx_destroy": (None, [_vp]),
     "nvh_ctx_set_hip_stream": (C.c_int, [_vp, _vp]),
     "nvh_ctx_synchronize": (C.c_int, [_vp]),
+    "nvh_measure_copy": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _f32p]),
+    "nvh_stream_bitrates": (C.c_int, [_vp, _ip, _ip, _ip]),
     "nvh_mdct_reverse": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int64]),
     "nvh_inverse_couple": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "nvh_mode_decode": (C.c_int, [_vp, _vp, C.c_int, _vp] + [C.POINTER(C.c_int)] * 5),
@@ -77,6 +79,7 @@ SIGNATURES = {
     "nvh_stream_pending": (C.c_int, [_vp, _ip, _i64p]),
     "nvh_stream_pending_geometry": (C.c_int, [_vp, _vp, C.c_int]),
     "nvh_stream_synth": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i64p]),
+    "nvh_stream_error_offset": (C.c_int, [_vp, _i64p]),
     "nvh_batch_upload": (C.c_int, [_vp, _vpp]),
     "nvh_batch_info": (C.c_int, [_vp, _ip, _ip, _i64p, _i64p]),
     "nvh_batch_stats": (C.c_int, [_vp, _i64p]),

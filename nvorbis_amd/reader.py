@@ -188,6 +188,13 @@ class Stream:
         ch, sr, b0, b1 = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().nvh_stream_info(self._h, C.byref(ch), C.byref(sr), C.byref(b0), C.byref(b1)), "nvh_stream_info")
         self.channels, self.sample_rate, self.block0, self.block1 = ch.value, sr.value, b0.value, b1.value
+        self.parse_error = None
+
+    def bitrates(self):
+        """(UpperBitrate, NominalBitrate, LowerBitrate) of the identification header (StreamDecoder.cs:191-199)."""
+        u, n, l = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().nvh_stream_bitrates(self._h, C.byref(u), C.byref(n), C.byref(l)), "nvh_stream_bitrates")
+        return u.value, n.value, l.value
 
     def push_packet(self, data, granule=-1, flags=0):
         check(lib().nvh_stream_push_packet(self._h, data, len(data), int(granule), int(flags)), "nvh_stream_push_packet")
@@ -197,9 +204,16 @@ class Stream:
         returns the number consumed."""
         took = C.c_int(0)
         n = len(pa) - first
-        check(lib().nvh_stream_push_packets(self._h, pa.data.ctypes.data, pa.offsets[first:].ctypes.data,
-                                            pa.granules[first:].ctypes.data, pa.flags[first:].ctypes.data, int(n),
-                                            int(max_packets), C.byref(took)), "nvh_stream_push_packets")
+        rc = lib().nvh_stream_push_packets(self._h, pa.data.ctypes.data, pa.offsets[first:].ctypes.data,
+                                           pa.granules[first:].ctypes.data, pa.flags[first:].ctypes.data, int(n),
+                                           int(max_packets), C.byref(took))
+        if rc != native.OK:
+            # packets [first, first + took) were consumed, packet first + took is the one the reference throws on; it is
+            # consumed too (StreamDecoder.cs:465-530: `packet?.Done()` runs in the finally block).  The caller gets the
+            # count through the exception so that it does not push them again.
+            e = native.NvhError(rc, "nvh_stream_push_packets")
+            e.consumed = took.value + 1
+            raise e
         return took.value
 
     def push_end(self):
@@ -355,13 +369,31 @@ class Stream:
             out = self._pin_arr
         else:
             out = np.empty(n, dtype=np.float32)
-        check(lib().nvh_stream_synth(self._h, out.ctypes.data, None, n, C.byref(wr)), "nvh_stream_synth")
+        rc = lib().nvh_stream_synth(self._h, out.ctypes.data, None, n, C.byref(wr))
+        self._note_parse_error(rc, wr.value, "nvh_stream_synth")
         return out[:wr.value]
 
     def synth_device(self, d_ptr, capacity):
         wr = C.c_int64(0)
-        check(lib().nvh_stream_synth(self._h, None, C.c_void_p(d_ptr), int(capacity), C.byref(wr)), "nvh_stream_synth")
+        rc = lib().nvh_stream_synth(self._h, None, C.c_void_p(d_ptr), int(capacity), C.byref(wr))
+        self._note_parse_error(rc, wr.value, "nvh_stream_synth")
         return wr.value
+
+    def _note_parse_error(self, rc, written, where):
+        """A synthesis call that returns an error code together with PCM (GPU-parse mode: a packet of the batch made the
+        parser fail and the batch was parsed again without it): the PCM is complete; the error is kept in
+        `parse_error` = (NvhError, floats of this batch's PCM that precede the failing packet) for the caller to raise
+        where the reference would have thrown.  Any other failure raises here."""
+        self.parse_error = None
+        if rc == native.OK:
+            return
+        if written <= 0:
+            raise native.NvhError(rc, where)
+        before = C.c_int64(-1)
+        check(lib().nvh_stream_error_offset(self._h, C.byref(before)), "nvh_stream_error_offset")
+        if before.value < 0:
+            raise native.NvhError(rc, where)
+        self.parse_error = (native.NvhError(rc, where), before.value * self.channels)
 
     def upload_batch(self):
         h = C.c_void_p()
@@ -414,7 +446,13 @@ class StreamDecoder:
         self._ring_pos = 0
         self._ended = False
         self._position = 0
+        # An exception the reference would throw from inside Read surfaces here at the same place in the PCM: the
+        # look-ahead batch is synthesised up to the failing packet's position first.  (error, ring index it belongs at)
+        self._pending_error = None
 
+    UpperBitrate = property(lambda self: self._stream.bitrates()[0])
+    NominalBitrate = property(lambda self: self._stream.bitrates()[1])
+    LowerBitrate = property(lambda self: self._stream.bitrates()[2])
     Channels = property(lambda self: self._stream.channels)
     SampleRate = property(lambda self: self._stream.sample_rate)
     HasClipped = property(lambda self: self._stream.has_clipped())
@@ -439,8 +477,12 @@ class StreamDecoder:
 
     def _refill(self):
         """Parse up to batch_frames packets ahead and synthesise them."""
+        if self._pending_error is not None and self._pending_error[1] is None:
+            err, self._pending_error = self._pending_error[0], None
+            raise err
         while not self._ended:
             pushed = 0
+            push_error = None
             if self._array is not None:
                 if self._stream.position()[2]:
                     self._ended = True
@@ -448,9 +490,15 @@ class StreamDecoder:
                     self._stream.push_end()
                     self._ended = True
                 else:
-                    took = self._stream.push_packets(self._array, self._next, self._batch_frames)
+                    try:
+                        took = self._stream.push_packets(self._array, self._next, self._batch_frames)
+                    except native.NvhError as e:
+                        took = getattr(e, "consumed", None)
+                        if took is None:
+                            raise
+                        push_error = e  # surfaces once the frames parsed before it have been read
                     self._next += took
-                    if took < self._batch_frames and self._next < len(self._array):
+                    if push_error is None and took < self._batch_frames and self._next < len(self._array):
                         self._ended = True  # stopped early: _eosFound
                 pushed = self._batch_frames
             while pushed < self._batch_frames:
@@ -463,16 +511,32 @@ class StreamDecoder:
                     break
                 i = self._next
                 self._next += 1
-                self._stream.push_packet(self._packets[i], self._granules[i], self._flags[i])
+                try:
+                    self._stream.push_packet(self._packets[i], self._granules[i], self._flags[i])
+                except native.NvhError as e:
+                    push_error = e  # the packet is consumed (`_next` already points past it)
+                    break
                 pushed += 1
             frames, _ = self._stream.pending()
+            pcm = None
             if frames:
                 # the ring is only replaced once it has been read out, so the stream's pinned buffer can be it
                 pcm = self._stream.synth_host(pinned=True)
-                if pcm.size:
-                    self._ring = pcm
-                    self._ring_pos = 0
-                    return True
+            got = pcm is not None and pcm.size > 0
+            if got:
+                self._ring = pcm
+                self._ring_pos = 0
+            if self._stream.parse_error is not None:  # GPU-parse mode: a packet inside the batch failed
+                err, at = self._stream.parse_error
+                self._stream.parse_error = None
+                self._pending_error = (err, at if got else None)
+            elif push_error is not None:  # host-parse mode: everything parsed before the packet comes first
+                self._pending_error = (push_error, pcm.size if got else None)
+            if got:
+                return True
+            if self._pending_error is not None:
+                err, self._pending_error = self._pending_error[0], None
+                raise err
         return False
 
     def Read(self, buffer, offset, count):
@@ -484,6 +548,11 @@ class StreamDecoder:
             raise ValueError("count must be a multiple of Channels")
         idx, tgt = offset, offset + count
         while idx < tgt:
+            if self._pending_error is not None and self._pending_error[1] is not None and self._ring_pos >= self._pending_error[1]:
+                # the packet that follows here made the decoder throw; the samples before it have been delivered.  (The
+                # reference's Read loses what it copied into the caller's buffer in the same call; so does this.)
+                err, self._pending_error = self._pending_error[0], None
+                raise err
             if self._ring_pos >= self._ring.size:
                 if not self._refill():
                     break
@@ -493,6 +562,8 @@ class StreamDecoder:
                 self._skip -= drop
                 continue
             take = min(tgt - idx, self._ring.size - self._ring_pos)
+            if self._pending_error is not None and self._pending_error[1] is not None:
+                take = min(take, self._pending_error[1] - self._ring_pos)
             buffer[idx:idx + take] = self._ring[self._ring_pos:self._ring_pos + take]
             self._ring_pos += take
             idx += take

@@ -63,36 +63,99 @@ def test_floor0_streams_are_refused(oracle, gpu_ctx):
     st.close()
 
 
-def test_throwing_packet_is_reported_at_synth(gpu_ctx):
-    """A packet that makes the managed decoder throw -- here the unassigned code of an incomplete Huffman tree without an
-    overflow list (Codebook.cs:306, NullReferenceException) -- fails nvh_stream_push_packet on the host path with
-    NVH_ERR_RUNTIME; in GPU-parse mode the same code comes from nvh_stream_synth for the look-ahead batch."""
-    import nvorbis_amd as nv
-    from nvorbis_amd import native
+def _throwing_stream():
     from tests import synth_stream as ss
     cfg = ss.config("stereo_res1_coupled")
     old = cfg["books"][3]
     cfg["books"][3] = ss.IncompleteBook(old.bits, dims=old.dims, lookup=old.lookup, min_me=old.min_me, delta_me=old.delta_me,
                                         value_bits=old.value_bits, sequence_p=old.sequence_p, mults=old.mults)
-    pk, gr, fl = ss.make_stream(cfg, 200, 1)  # seed 1: the first throwing packet is the third audio packet
-    st = nv.Stream(None, pk[0], pk[1], pk[2])
-    bad = None
-    for i in range(3, len(pk)):
+    return ss.make_stream(cfg, 200, 1)  # seed 1: the first throwing packet is the third audio packet
+
+
+def test_throwing_packet_keeps_the_rest_of_the_batch(gpu_ctx):
+    """A packet that makes the managed decoder throw -- here the unassigned code of an incomplete Huffman tree without an
+    overflow list (Codebook.cs:306, NullReferenceException) -- fails nvh_stream_push_packet on the host path with
+    NVH_ERR_RUNTIME.  In GPU-parse mode k_parse finds it inside the look-ahead batch: the batch is parsed again on the
+    host, nvh_stream_synth delivers the PCM of every other packet together with the same code, and
+    nvh_stream_error_offset says where in that PCM the exception belongs."""
+    import nvorbis_amd as nv
+    from nvorbis_amd import native
+    pk, gr, fl = _throwing_stream()
+    st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+    bad, before = [], []
+    for i in range(3, 40):
         try:
             st.push_packet(pk[i], gr[i], fl[i])
         except native.NvhError as e:
             assert e.code == native.ERR_RUNTIME
-            bad = i
-            break
+            bad.append(i)
+            before.append(st.pending()[1])
+    assert bad and bad[0] > 3, "random packets never hit the unassigned code"
+    ref = st.synth_host().copy()
+    assert st.parse_error is None
     st.close()
-    assert bad is not None and bad > 3, "random packets never hit the unassigned code"
     st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
     st.set_gpu_parse(True)
-    for i in range(3, bad + 1):
+    for i in range(3, 40):
         st.push_packet(pk[i], gr[i], fl[i])  # light parse: nothing to throw on yet
-    with pytest.raises(native.NvhError) as e:
-        st.synth_host()
-    assert e.value.code == native.ERR_RUNTIME
-    # the batch was dropped; the stream object stays usable
+    got = st.synth_host().copy()
+    assert st.parse_error is not None
+    err, at = st.parse_error
+    assert err.code == native.ERR_RUNTIME and at == before[0] * st.channels
+    assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     assert st.pending() == (0, 0)
+    # the stream goes on in GPU-parse mode with the state the host-parse path has at this point
+    more = [i for i in range(40, 60)]
+    for i in more:
+        try:
+            st.push_packet(pk[i], gr[i], fl[i])
+        except native.NvhError:
+            pass
+    st.synth_host()
     st.close()
+
+
+@pytest.mark.parametrize("gpu_parse", [False, True])
+@pytest.mark.parametrize("batch_frames", [7, 64])
+def test_exceptions_surface_where_the_reference_throws(oracle, gpu_ctx, gpu_parse, batch_frames):
+    """Read() past throwing packets, one sample frame per call (so that no call loses samples it had already copied, as
+    the reference's Read does when it throws): the same samples and the same exceptions at the same positions as the
+    oracle's read loop, whichever parser runs and however far the look-ahead reaches."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    from nvorbis_amd import native
+    pk, gr, fl = _throwing_stream()
+    L = oracle.L
+    blob = np.frombuffer(b"".join(pk), dtype=np.uint8)
+    offs = np.zeros(len(pk) + 1, np.int64)
+    offs[1:] = np.cumsum([len(p) for p in pk])
+    g, f, err = np.asarray(gr, np.int64), np.asarray(fl, np.uint8), C.c_int(0)
+    d = L.orc_open_packets(blob.ctypes.data, offs.ctypes.data, g.ctypes.data, f.ctypes.data, len(pk), C.byref(err))
+    assert d
+    buf = np.zeros(2, np.float32)
+    ref, ref_err = [], []
+    while True:
+        n = L.orc_read_samples(d, buf.ctypes.data, 2, 0, 2)
+        if n < 0:
+            ref_err.append((len(ref), n))
+            continue
+        if n == 0:
+            break
+        ref.append(buf[:n].copy())
+    L.orc_close(d)
+    assert len(ref_err) > 50
+    dec = nv.StreamDecoder(gpu_ctx, pk, gr, fl, batch_frames=batch_frames, gpu_parse=gpu_parse)
+    got, got_err = [], []
+    while True:
+        try:
+            n = dec.Read(buf, 0, 2)
+        except native.NvhError as e:
+            got_err.append((len(got), e.code))
+            continue
+        if n == 0:
+            break
+        got.append(buf[:n].copy())
+    dec.close()
+    assert got_err == ref_err
+    a, b = np.concatenate(got), np.concatenate(ref)
+    assert a.size == b.size and np.array_equal(a.view(np.uint32), b.view(np.uint32))

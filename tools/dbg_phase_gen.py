@@ -20,6 +20,7 @@ b = st.upload_batch(); print(b.stats())
 ch = st.channels
 pcm = torch.empty(b.samples * ch, dtype=torch.float32, device="cuda")
 dbg = torch.zeros(4096 * 24, dtype=torch.int64, device="cuda")
+# needs the profiling build: python -m nvorbis_amd.build --debug; NVH_LIB=nvorbis_amd/libnvorbis_hip_dbg.so
 L = nv.lib(); L.nvh_debug_set_buffer.argtypes = [ctypes.c_void_p]; L.nvh_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
 for _ in range(3): b.synth(pcm.data_ptr(), pcm.numel())
 ctx.synchronize(); torch.cuda.synchronize()
