@@ -210,11 +210,12 @@ int nvh_stream_pending(const nvh_stream *s, int *frames, int64_t *pcm_samples_pe
  * pcm_host / d_pcm is non-NULL; capacity is in floats and must hold pending samples * channels.
  * Advances the overlap state (the last block's tail is carried to the next batch). */
 int nvh_stream_synth(nvh_stream *s, float *pcm_host, float *d_pcm, int64_t capacity, int64_t *written);
-/* After nvh_stream_synth returned an error code together with *written > 0 (GPU-parse mode: some packet of the batch
- * made the parser fail -- the code nvh_stream_push_packet returns for it in host-parse mode -- and the batch was parsed
- * again on the host without it): the number of samples per channel of that batch that precede the failing packet, i.e.
- * where in the PCM the reference's exception would have surfaced; -1 when the last synthesis reported no such error. */
-int nvh_stream_error_offset(const nvh_stream *s, int64_t *samples_before);
+/* After nvh_stream_synth returned an error code together with *written > 0 (GPU-parse mode: packets of the batch made
+ * the parser fail -- with the codes nvh_stream_push_packet returns for them in host-parse mode -- and the batch was
+ * parsed again on the host without them): every such packet in stream order, codes[i] and samples_before[i] = the
+ * samples per channel of that batch's PCM that precede it, i.e. where the reference's exception would have surfaced.
+ * *count = how many there are (0 when the last synthesis reported none); at most `cap` are written. */
+int nvh_stream_parse_errors(const nvh_stream *s, int32_t *codes, int64_t *samples_before, int cap, int *count);
 
 /* ---- device-resident batches (benchmarks, pipelined callers) ---- */
 /* Move the pending batch into HBM as an object of its own; the stream's pending batch becomes empty

@@ -829,7 +829,14 @@ k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, fl
 // Plain float4 copy (grid-stride, 16 bytes per lane): the measured HBM ceiling bench.py reports next to the roofline.
 extern "C" __global__ void __launch_bounds__(256)
 k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) dst[i] = src[i];
+  // four independent 16-byte loads per lane in flight before the first store
+  const long long step = (long long)gridDim.x * 1024;
+  long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  for (; i + 768 < n4; i += step) {
+    const float4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+    dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
+  }
+  for (; i < n4; i += 256) dst[i] = src[i];  // the last, partial group of this workgroup's stride
 }
 
 // Mode.Decode's window loop (Mode.cs:160-166): buf[b*stride + i] *= window[i] for i < n.

@@ -477,6 +477,7 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
     if (capacity < need) return NVH_ERR_ARGUMENT;
     nvh_batch* b = &s->scratch;
     s->replay_error = NVH_OK;
+    s->replay_errors.clear();
     int rc = batch_upload(s, b);
     if (rc != NVH_OK) return rc;
     // GPU-parse mode: a batch with a throwing packet was parsed again on the host (nvh_launch.hip: replay_on_host); the
@@ -514,15 +515,20 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
     if (h_flags[0]) return NVH_ERR_RUNTIME;  // inverse_dB_table / wMap index out of range in the reference
     if (written) *written = need;
     // a packet of this batch made the parser fail (the code nvh_stream_push_packet returns in host-parse mode): the PCM of
-    // every other packet is complete and *written says so; nvh_stream_error_offset tells where the exception belongs
+    // every other packet is complete and *written says so; nvh_stream_parse_errors tells where the exceptions belong
     return s->replay_error;
   });
 }
 
-extern "C" int nvh_stream_error_offset(const nvh_stream* s, int64_t* samples_before) {
+extern "C" int nvh_stream_parse_errors(const nvh_stream* s, int32_t* codes, int64_t* samples_before, int cap, int* count) {
   return nvh_guard([&]() -> int {
-    if (!s || !samples_before) return NVH_ERR_ARGUMENT;
-    *samples_before = s->replay_error != NVH_OK ? s->replay_error_samples : -1;
+    if (!s || !count || cap < 0 || (cap > 0 && (!codes || !samples_before))) return NVH_ERR_ARGUMENT;
+    const int n = s->replay_error != NVH_OK ? (int)s->replay_errors.size() : 0;
+    *count = n;
+    for (int i = 0; i < n && i < cap; i++) {
+      codes[i] = s->replay_errors[(size_t)i].first;
+      samples_before[i] = s->replay_errors[(size_t)i].second;
+    }
     return NVH_OK;
   });
 }

@@ -273,7 +273,7 @@ struct nvh_stream {
   ReplayLog replay;
   std::unique_ptr<nvh::StreamParser> replay_start;  // parser state at the first logged event
   int replay_error = NVH_OK;                         // first error of the last replay (reported by the synthesis call)
-  int64_t replay_error_samples = 0;                  // samples per channel the batch emits before that packet
+  std::vector<std::pair<int, int64_t>> replay_errors;  // every error of it: (code, samples per channel the batch emits before that packet)
 
   nvh_stream(nvh_ctx* c, std::shared_ptr<SharedSetup> sh)
       : ctx(c), shared(std::move(sh)), setup(shared->setup), arena(shared->arena), dev(shared->dev),

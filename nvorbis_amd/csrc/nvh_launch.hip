@@ -24,14 +24,15 @@ static int replay_on_host(nvh_stream* s) {
   s->pending.clear();
   static const uint8_t empty = 0;
   int first = NVH_OK;
+  s->replay_errors.clear();
   for (const ReplayLog::Event& e : s->replay.events) {
     int rc = NVH_OK;
     if (e.kind == ReplayLog::kEnd) rc = s->parser->push_end(s->pending);
     else if (e.kind == ReplayLog::kPosition) s->parser->set_position_state(e.flags != 0, e.granule);
     else rc = s->parser->push_packet(e.len ? s->replay.bytes.data() + e.off : &empty, (int)e.len, e.granule, e.flags, s->pending);
-    if (rc != NVH_OK && first == NVH_OK) {
-      first = rc;
-      s->replay_error_samples = s->pending.pcm_samples;
+    if (rc != NVH_OK) {
+      if (first == NVH_OK) first = rc;
+      s->replay_errors.emplace_back(rc, s->pending.pcm_samples);
     }
   }
   s->parser->set_light(true);

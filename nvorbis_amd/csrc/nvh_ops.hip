@@ -77,7 +77,7 @@ extern "C" int nvh_measure_copy(nvh_ctx* c, const void* d_src, void* d_dst, size
     const long long n4 = (long long)(bytes / 16);
     HIP_TRY(hipEventRecord(e0.e, c->stream));
     for (int i = 0; i < iters; i++)
-      hipLaunchKernelGGL(k_copy_f4, dim3(256 * 8 * 4), dim3(256), 0, c->stream, (const float4*)d_src, (float4*)d_dst, n4);
+      hipLaunchKernelGGL(k_copy_f4, dim3(256 * 8 * 2), dim3(256), 0, c->stream, (const float4*)d_src, (float4*)d_dst, n4);
     HIP_TRY(hipEventRecord(e1.e, c->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventSynchronize(e1.e));

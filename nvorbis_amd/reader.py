@@ -188,7 +188,7 @@ class Stream:
         ch, sr, b0, b1 = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().nvh_stream_info(self._h, C.byref(ch), C.byref(sr), C.byref(b0), C.byref(b1)), "nvh_stream_info")
         self.channels, self.sample_rate, self.block0, self.block1 = ch.value, sr.value, b0.value, b1.value
-        self.parse_error = None
+        self.parse_errors = []
 
     def bitrates(self):
         """(UpperBitrate, NominalBitrate, LowerBitrate) of the identification header (StreamDecoder.cs:191-199)."""
@@ -381,19 +381,20 @@ class Stream:
 
     def _note_parse_error(self, rc, written, where):
         """A synthesis call that returns an error code together with PCM (GPU-parse mode: a packet of the batch made the
-        parser fail and the batch was parsed again without it): the PCM is complete; the error is kept in
-        `parse_error` = (NvhError, floats of this batch's PCM that precede the failing packet) for the caller to raise
-        where the reference would have thrown.  Any other failure raises here."""
-        self.parse_error = None
+        parser fail and the batch was parsed again without them): the PCM is complete; the errors are kept in
+        `parse_errors` = [(NvhError, floats of this batch's PCM that precede the failing packet), ...] in stream order for
+        the caller to raise where the reference would have thrown.  Any other failure raises here."""
+        self.parse_errors = []
         if rc == native.OK:
             return
-        if written <= 0:
+        n = C.c_int(0)
+        check(lib().nvh_stream_parse_errors(self._h, None, None, 0, C.byref(n)), "nvh_stream_parse_errors")
+        if n.value <= 0:
             raise native.NvhError(rc, where)
-        before = C.c_int64(-1)
-        check(lib().nvh_stream_error_offset(self._h, C.byref(before)), "nvh_stream_error_offset")
-        if before.value < 0:
-            raise native.NvhError(rc, where)
-        self.parse_error = (native.NvhError(rc, where), before.value * self.channels)
+        codes, before = np.zeros(n.value, np.int32), np.zeros(n.value, np.int64)
+        check(lib().nvh_stream_parse_errors(self._h, codes.ctypes.data_as(C.POINTER(C.c_int32)), before.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            n.value, C.byref(n)), "nvh_stream_parse_errors")
+        self.parse_errors = [(native.NvhError(int(c), where), int(b) * self.channels) for c, b in zip(codes, before)]
 
     def upload_batch(self):
         h = C.c_void_p()
@@ -448,7 +449,7 @@ class StreamDecoder:
         self._position = 0
         # An exception the reference would throw from inside Read surfaces here at the same place in the PCM: the
         # look-ahead batch is synthesised up to the failing packet's position first.  (error, ring index it belongs at)
-        self._pending_error = None
+        self._pending_errors = []  # [(error, ring index)], ascending
 
     UpperBitrate = property(lambda self: self._stream.bitrates()[0])
     NominalBitrate = property(lambda self: self._stream.bitrates()[1])
@@ -477,9 +478,8 @@ class StreamDecoder:
 
     def _refill(self):
         """Parse up to batch_frames packets ahead and synthesise them."""
-        if self._pending_error is not None and self._pending_error[1] is None:
-            err, self._pending_error = self._pending_error[0], None
-            raise err
+        if self._pending_errors:  # left over from a batch whose ring has been read out
+            raise self._pending_errors.pop(0)[0]
         while not self._ended:
             pushed = 0
             push_error = None
@@ -526,17 +526,16 @@ class StreamDecoder:
             if got:
                 self._ring = pcm
                 self._ring_pos = 0
-            if self._stream.parse_error is not None:  # GPU-parse mode: a packet inside the batch failed
-                err, at = self._stream.parse_error
-                self._stream.parse_error = None
-                self._pending_error = (err, at if got else None)
-            elif push_error is not None:  # host-parse mode: everything parsed before the packet comes first
-                self._pending_error = (push_error, pcm.size if got else None)
+            size = pcm.size if got else 0
+            if self._stream.parse_errors:  # GPU-parse mode: packets inside the batch failed
+                self._pending_errors = [(e, min(at, size)) for e, at in self._stream.parse_errors]
+                self._stream.parse_errors = []
+            if push_error is not None:  # host-parse mode: everything parsed before the packet comes first
+                self._pending_errors.append((push_error, size))
             if got:
                 return True
-            if self._pending_error is not None:
-                err, self._pending_error = self._pending_error[0], None
-                raise err
+            if self._pending_errors:
+                raise self._pending_errors.pop(0)[0]
         return False
 
     def Read(self, buffer, offset, count):
@@ -548,11 +547,10 @@ class StreamDecoder:
             raise ValueError("count must be a multiple of Channels")
         idx, tgt = offset, offset + count
         while idx < tgt:
-            if self._pending_error is not None and self._pending_error[1] is not None and self._ring_pos >= self._pending_error[1]:
+            if self._pending_errors and self._ring_pos >= self._pending_errors[0][1]:
                 # the packet that follows here made the decoder throw; the samples before it have been delivered.  (The
                 # reference's Read loses what it copied into the caller's buffer in the same call; so does this.)
-                err, self._pending_error = self._pending_error[0], None
-                raise err
+                raise self._pending_errors.pop(0)[0]
             if self._ring_pos >= self._ring.size:
                 if not self._refill():
                     break
@@ -562,8 +560,8 @@ class StreamDecoder:
                 self._skip -= drop
                 continue
             take = min(tgt - idx, self._ring.size - self._ring_pos)
-            if self._pending_error is not None and self._pending_error[1] is not None:
-                take = min(take, self._pending_error[1] - self._ring_pos)
+            if self._pending_errors:
+                take = min(take, self._pending_errors[0][1] - self._ring_pos)
             buffer[idx:idx + take] = self._ring[self._ring_pos:self._ring_pos + take]
             self._ring_pos += take
             idx += take

@@ -77,7 +77,7 @@ def test_throwing_packet_keeps_the_rest_of_the_batch(gpu_ctx):
     overflow list (Codebook.cs:306, NullReferenceException) -- fails nvh_stream_push_packet on the host path with
     NVH_ERR_RUNTIME.  In GPU-parse mode k_parse finds it inside the look-ahead batch: the batch is parsed again on the
     host, nvh_stream_synth delivers the PCM of every other packet together with the same code, and
-    nvh_stream_error_offset says where in that PCM the exception belongs."""
+    nvh_stream_parse_errors says where in that PCM each exception belongs."""
     import nvorbis_amd as nv
     from nvorbis_amd import native
     pk, gr, fl = _throwing_stream()
@@ -92,16 +92,14 @@ def test_throwing_packet_keeps_the_rest_of_the_batch(gpu_ctx):
             before.append(st.pending()[1])
     assert bad and bad[0] > 3, "random packets never hit the unassigned code"
     ref = st.synth_host().copy()
-    assert st.parse_error is None
+    assert st.parse_errors == []
     st.close()
     st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
     st.set_gpu_parse(True)
     for i in range(3, 40):
         st.push_packet(pk[i], gr[i], fl[i])  # light parse: nothing to throw on yet
     got = st.synth_host().copy()
-    assert st.parse_error is not None
-    err, at = st.parse_error
-    assert err.code == native.ERR_RUNTIME and at == before[0] * st.channels
+    assert [(e.code, at) for e, at in st.parse_errors] == [(native.ERR_RUNTIME, b * st.channels) for b in before]
     assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     assert st.pending() == (0, 0)
     # the stream goes on in GPU-parse mode with the state the host-parse path has at this point
