@@ -23,6 +23,8 @@ const NvhToggles& nvh_toggles() {
     x.ola_threads = num("NVH_OLA_THREADS");
     x.parse_lanes = num("NVH_PARSE_LANES");
     x.parse_waves = num("NVH_PARSE_WAVES");
+    x.run = on("NVH_RUN");
+    x.run_waves = num("NVH_RUN_WAVES");
     x.phase_mask = std::getenv("NVH_DEBUG_SPECTRUM_MASK") ? num("NVH_DEBUG_SPECTRUM_MASK") : 7;
     return x;
   }();
@@ -541,7 +543,7 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
     HIP_TRY(hipSetDevice(s->ctx->device));
     std::unique_ptr<nvh_batch> b(new (std::nothrow) nvh_batch());
     if (b && s && s->ctx) {
-      b->blob.pool = b->work.pool = b->carry_in.pool = b->slabs.pool = &s->ctx->pool;
+      b->blob.pool = b->work.pool = b->carry_in.pool = b->slabs.pool = b->run_flags.pool = b->dev_copy.pool = &s->ctx->pool;
       b->h_blob.host = true;
       b->h_blob.pool = &s->ctx->hpool;
     }

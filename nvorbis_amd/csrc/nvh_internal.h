@@ -53,6 +53,10 @@ __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhCh
                               uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
 __global__ void k_copy_f4(const float4* src, float4* dst, long long n4);
+__global__ void k_run4_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
+__global__ void k_run4_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
+__global__ void k_run6_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
+__global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
 __global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,
                                   long long plane_stride);
@@ -105,6 +109,8 @@ static inline void nvh_guard_void(F&& body) noexcept {
 struct NvhToggles {
   bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
+  bool run;       // NVH_RUN: the run kernel (kernels_run.hip) instead of k_spectrum_imdct + k_ola_compact -- opt-in, it measured slower
+  int run_waves;  // NVH_RUN_WAVES = 4 | 6
   int phase_mask;  // debug build only (NVH_DEBUG_SPECTRUM_MASK)
 };
 const NvhToggles& nvh_toggles();
@@ -196,6 +202,7 @@ struct SharedSetup {
   nvh::Setup setup;
   DevBuf arena;  // setup tables
   NvhDevSetup dev{};
+  DevBuf dev_copy;  // the NvhDevSetup block itself in device memory (the run kernel reads it from there, see kernels_run.hip)
   bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
   bool has_floor0 = false;
   // GPU packet parser (kernels_parse.hip): its tables, and whether this stream shape is inside its limits
@@ -235,6 +242,12 @@ struct nvh_batch {
   bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
   bool block_only = false;       // nvh_mode_decode: stop after the windowed IMDCT (full blocks in the work planes, no overlap-add)
   bool has_carry_in = false;
+  // run kernel (kernels_run.hip): the batch's geometry is inside its contract; hand-off flags and their epoch
+  bool run_ok = false;
+  bool force_classic = false;  // a hand-off timed out once: this batch object stays on the two-kernel path
+  DevBuf run_flags;
+  unsigned run_epoch = 0;
+  DevBuf dev_copy;  // the NvhDevBatch block in device memory
 };
 
 // GPU-parse mode: everything pushed since the last batch boundary, so that a batch in which k_parse found a packet the
@@ -280,7 +293,7 @@ struct nvh_stream {
         fast_spectrum(shared->fast_spectrum), has_floor0(shared->has_floor0) {
     BufPool* pool = c ? &c->pool : nullptr;
     carry[0].pool = carry[1].pool = flags.pool = pcm.pool = carry_exec.pool = pool;
-    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = pool;
+    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = scratch.run_flags.pool = scratch.dev_copy.pool = pool;
     h_pcm.host = scratch.h_blob.host = true;
     h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;
     scratch.s = this;

@@ -193,6 +193,20 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       }
     }
     b->fused_ola = ok;
+    // contract of the run kernel (kernels_run.hip): the same geometry, whole groups of four samples, a pseudo-frame
+    // (drain of the carried block) only in front
+    bool run = ok && s->fast_spectrum && b->links_ok && s->setup.channels <= 2 && !b->block_only;
+    for (size_t i = 0; run && i < P.frames.size(); i++) {
+      const NvhFrame& fr = P.frames[i];
+      if (fr.n == 0) {
+        run = i == 0 && fr.ov_frame == -2;
+        continue;
+      }
+      run = ((fr.start | fr.emit_start | fr.ov_src | fr.ov_len) & 3) == 0 && fr.emit_start >= 0 && fr.emit_count >= 0 &&
+            fr.emit_start + fr.emit_count <= fr.n;
+      if (fr.ov_len > 0 && fr.ov_frame == -2) run = run && i == 0;  // the carried block is the first frame's source only
+    }
+    b->run_ok = run;
   }
   for (int i = b->nframes - 1; i >= 0; --i)
     if (P.frames[(size_t)i].n != 0) {
@@ -289,6 +303,79 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
   const NvhToggles& T = nvh_toggles();
   const bool no_compact = T.no_compact, no_fused_ola = !T.fused_ola /* experimental run-based kernel: opt-in */, no_fused_imdct = T.no_fused_imdct;
+  // ---- the run kernel: everything from side information to PCM in one launch (opt-in: NVH_RUN=1; DESIGN.md section 6
+  // has the measurement that keeps it off by default) ----
+  if (b->run_ok && !b->force_classic && T.run && !T.unfused && !no_fused_imdct && !no_compact && !T.fused_ola && d_pcm != nullptr &&
+      s->fast_spectrum && b->links_ok && s->setup.block0 >= 256 && s->setup.block1 <= 2048) {
+    const int waves = T.run_waves == 4 ? 4 : 6;
+    const int cap_pass = b->max_pass, cap_ops = (b->max_ops + 7) & ~7, cap_ent = (b->max_ent + 14) & ~7;
+    const size_t hmax = (size_t)s->setup.block1 / 2;
+    const size_t words = 256 + (size_t)NVH_SP_FLOOR_SCRATCH_WORDS * (size_t)ch + (size_t)cap_pass * 16 + (size_t)s->setup.books.size() * 8 +
+                         (size_t)((s->dev.lattice_words + 3) & ~3) + (size_t)cap_ops * 6 + (size_t)cap_ops / 2 + (size_t)cap_ent / 2 +
+                         2 * ((size_t)s->setup.block1 / 16) + 3 * (size_t)ch * hmax;  // spectrum + two parked heads
+    if (words * 4 <= 64 * 1024) {
+      // every workgroup resident at once: the run length follows from the number of workgroups a CU holds
+      int dev_cus = 256;
+      (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device);
+      size_t per_cu = (160 * 1024) / (words * 4 + 64);
+      const size_t wave_cap = 24 / (size_t)waves;  // the kernels are built for 6 wavefronts per SIMD (80 VGPRs)
+      if (per_cu > wave_cap) per_cu = wave_cap;
+      if (per_cu < 1) per_cu = 1;
+      const size_t slots = per_cu * (size_t)(dev_cus > 0 ? dev_cus : 256);
+      int run_len = (int)(((size_t)b->nframes + slots - 1) / slots);
+      if (run_len < 1) run_len = 1;
+      if (T.run_len > 0) run_len = T.run_len;
+      const int runs = (b->nframes + run_len - 1) / run_len;
+      // hand-off flags: one word per (frame, channel), valid when equal to this launch's epoch
+      const size_t flag_bytes = (size_t)b->nframes * (size_t)ch * sizeof(unsigned);
+      const void* before = b->run_flags.p;
+      int rc = b->run_flags.reserve(flag_bytes);
+      if (rc != NVH_OK) return rc;
+      if (b->run_flags.p != before || b->run_epoch == 0xFFFFFFFFu) {
+        HIP_TRY(hipMemsetAsync(b->run_flags.p, 0, b->run_flags.cap, st));
+        b->run_epoch = 0;
+      }
+      if ((rc = b->dev_copy.reserve(sizeof(NvhDevBatch))) != NVH_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(b->dev_copy.p, &b->dev, sizeof(NvhDevBatch), hipMemcpyHostToDevice, st));  // 80 bytes, staged by the runtime
+      NvhRunArgs ra;
+      ra.tails = work;
+      ra.flags = (unsigned*)b->run_flags.p;
+      ra.epoch = ++b->run_epoch;
+      ra.run_len = run_len;
+      ra.pcm = d_pcm;
+      ra.carry = carry;
+      ra.carry_out = carry_out;
+      ra.clip = s->clip;
+      ra.clipped_flag = flags + 1;
+      ra.last_decoded = b->last_decoded;
+#ifdef NVH_DEBUG
+      ra.dbg = (long long*)g_dbg_buf;
+#endif
+      if (timing) HIP_TRY(hipEventRecord(ev[1], st));
+      b->slot_name[0] = "-"; b->slot_name[2] = "-"; b->slot_name[3] = "-";
+      {
+        auto kern = waves == 6 ? (ch == 1 ? k_run6_c1 : k_run6_c2) : (ch == 1 ? k_run4_c1 : k_run4_c2);
+        b->slot_name[1] = waves == 6 ? "k_run6" : "k_run4";
+        hipLaunchKernelGGL(kern, dim3((unsigned)runs), dim3((unsigned)(64 * waves)), words * 4, st,
+                           (const NvhDevSetup*)s->shared->dev_copy.p, (const NvhDevBatch*)b->dev_copy.p, ra, flags, cap_pass, cap_ops, cap_ent);
+      }
+      if (timing) {
+        HIP_TRY(hipEventRecord(ev[2], st));
+        HIP_TRY(hipEventRecord(ev[3], st));
+        HIP_TRY(hipEventRecord(ev[4], st));
+      }
+      HIP_TRY(hipGetLastError());
+      if (timing) {
+        HIP_TRY(hipEventSynchronize(ev[4]));
+        for (int k = 0; k < 4; k++) {
+          float ms = 0;
+          HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+          kernel_ms[k] += ms;
+        }
+      }
+      return NVH_OK;
+    }
+  }
   const bool use_fused_ola = b->fused_ola && !no_fused_ola && !b->block_only;
   const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola && !b->block_only;
   // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers

@@ -257,6 +257,9 @@ int upload_setup(nvh_stream* s) {
     D.mdct_br[w] = (const uint16_t*)(base + o_br[w]);
     D.mdct_tw[w] = (const float*)(base + o_tw[w]);
   }
+  s->shared->dev_copy.pool = s->arena.pool;
+  if ((rc = s->shared->dev_copy.reserve(sizeof(NvhDevSetup))) != NVH_OK) return rc;
+  HIP_TRY(hipMemcpy(s->shared->dev_copy.p, &D, sizeof D, hipMemcpyHostToDevice));
   return NVH_OK;
 }
 

@@ -250,6 +250,28 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("waves", ["6", "4"])
+def test_run_kernel_bit_exact(waves):
+    """The run kernel (kernels_run.hip, opt-in NVH_RUN=1: spectrum + IMDCT + window + overlap-add + clip + interleave in one
+    launch, the overlap kept in LDS, one cross-workgroup hand-off per run of frames): the file, fuzz, chunk, seek and
+    full-depth C2 / C3 tests replayed through it in a child process, with 6 and 4 wavefronts per workgroup."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NVH_TEST_CHILD"):
+        pytest.skip("already inside a fallback-path run")
+    env = dict(os.environ)
+    env["NVH_RUN"] = "1"
+    env["NVH_RUN_WAVES"] = waves
+    env["NVH_TEST_CHILD"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_full_depth.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "ogg_files or clip_samples or partial_reads or fuzzed or bench_workload or stream_chunks or seek or c2_grand or c3_markov or c5_corpus or stereo_res1"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_six_channel_four_wavefront_kernel_bit_exact():
     """Streams with more than four channels run k_spectrum_gen8 (8 wavefronts per workgroup); NVH_NO_GEN8 sends them
     through k_spectrum_gen instead: the six-channel cases replayed in a child process."""
