@@ -7,9 +7,14 @@
 //
 //     VorbisReader.CreateStreamDecoder = pp => new NVorbis.Hip.GpuStreamDecoder(pp, device: 0);
 //
+// CreateStreamDecoder is `internal static` (VorbisReader.cs:14-15) and Tags / Stats are built from the reference's internal
+// TagData / StreamStats classes, so this file is compiled INTO the NVorbis assembly (csharp/README.md), next to
+// GpuFactory.cs (the interface-by-interface path) and NativeMethods.cs.
 // Source-only here (no .NET toolchain in the build image); the same call sequence is exercised by the
 // Python mirror nvorbis_amd/reader.py::StreamDecoder against the identical C ABI.
 using System;
+using System.Collections.Generic;
+using System.Text;
 using NVorbis.Contracts;
 
 namespace NVorbis.Hip
@@ -24,6 +29,13 @@ namespace NVorbis.Hip
         int _ringPos, _ringLen;
         bool _ended, _clip = true;
         long _skip;   // floats to drop in front of the next samples: SeekTo's roll-forward
+        int _upperBitrate, _nominalBitrate, _lowerBitrate;
+        readonly string _vendor;
+        readonly string[] _comments;
+        ITagData _tags;
+        readonly StreamStats _stats = new StreamStats();
+        // exceptions the reference would throw from inside Read, queued at the ring position they belong to
+        readonly Queue<KeyValuePair<Exception, int>> _pendingErrors = new Queue<KeyValuePair<Exception, int>>();
 
         public GpuStreamDecoder(Contracts.IPacketProvider packetProvider, int device = 0, int batchPackets = 1024)
         {
@@ -37,6 +49,12 @@ namespace NVorbis.Hip
             fixed (byte* pi = id, pc = comment, ps = setup)
                 NativeMethods.Check(NativeMethods.nvh_stream_open(_ctx, pi, id.Length, pc, comment.Length, ps, setup.Length, out _stream));
             NativeMethods.Check(NativeMethods.nvh_stream_info(_stream, out _channels, out _sampleRate, out _block0, out _block1));
+            NativeMethods.Check(NativeMethods.nvh_stream_bitrates(_stream, out _upperBitrate, out _nominalBitrate, out _lowerBitrate));
+            ParseComments(comment, out _vendor, out _comments);                 // LoadComments (StreamDecoder.cs:206-224)
+            _stats.SetSampleRate(_sampleRate);                                   // StreamDecoder.cs:200
+            _stats.AddPacket(-1, id.Length * 8, 0, 0);                           // header packets (:201, :221, :286)
+            _stats.AddPacket(-1, comment.Length * 8, 0, 0);
+            _stats.AddPacket(-1, setup.Length * 8, 0, 0);
             // Parse the packets on the GPU as well when the stream shape allows it (-7 = outside the GPU parser's limits:
             // the host parser stays in charge).  Same PCM either way.
             int rc = NativeMethods.nvh_stream_set_gpu_parse(_stream, 1);
@@ -53,8 +71,36 @@ namespace NVorbis.Hip
             return buf;
         }
 
+        // "\x03vorbis", vendor string, comment count, comments: 32-bit little-endian lengths, UTF-8 (StreamDecoder.cs:163-177, 206-224)
+        static void ParseComments(byte[] p, out string vendor, out string[] comments)
+        {
+            int pos = 7;
+            string ReadString()
+            {
+                if (pos + 4 > p.Length) throw new System.IO.InvalidDataException("Could not read full string!");
+                int len = BitConverter.ToInt32(p, pos); pos += 4;
+                if (len == 0) return string.Empty;
+                if (len < 0 || pos + len > p.Length) throw new System.IO.InvalidDataException("Could not read full string!");
+                var str = Encoding.UTF8.GetString(p, pos, len); pos += len;
+                return str;
+            }
+            vendor = ReadString();
+            if (pos + 4 > p.Length) throw new System.IO.InvalidDataException("Could not read full string!");
+            int n = BitConverter.ToInt32(p, pos); pos += 4;
+            comments = new string[n];
+            for (int i = 0; i < n; i++) comments[i] = ReadString();
+        }
+
         public int Channels => _channels;
         public int SampleRate => _sampleRate;
+        public int UpperBitrate => _upperBitrate;
+        public int NominalBitrate => _nominalBitrate;
+        public int LowerBitrate => _lowerBitrate;
+        public ITagData Tags => _tags ?? (_tags = new TagData(_vendor, _comments));      // StreamDecoder.cs:690
+        // The reference counts, per audio packet, the samples it yielded and the bits the decode read / left over
+        // (StreamStats.cs:94-121).  Packets are parsed a batch ahead here and the native parser does not report how far
+        // into each packet it read, so a packet is booked with its nominal sample count and all of its bits as read.
+        public IStreamStats Stats => _stats;
         public bool ClipSamples { get => _clip; set { _clip = value; NativeMethods.Check(NativeMethods.nvh_stream_set_clip(_stream, value ? 1 : 0)); } }
         public bool HasClipped { get { NativeMethods.Check(NativeMethods.nvh_stream_has_clipped(_stream, out int c)); return c != 0; } }
         public bool IsEndOfStream => _ended && _ringPos >= _ringLen;
@@ -72,6 +118,7 @@ namespace NVorbis.Hip
         {
             while (!_ended)
             {
+                Exception pushError = null;
                 for (int pushed = 0; pushed < _batchPackets; pushed++)
                 {
                     NativeMethods.Check(NativeMethods.nvh_stream_position(_stream, out _, out _, out int eos));
@@ -80,21 +127,56 @@ namespace NVorbis.Hip
                     if (packet == null) { NativeMethods.Check(NativeMethods.nvh_stream_push_end(_stream)); _ended = true; break; }
                     int flags = (packet.IsEndOfStream ? NativeMethods.NVH_PKT_EOS : 0) | (packet.IsResync ? NativeMethods.NVH_PKT_RESYNC : 0);
                     long granule = packet.GranulePosition ?? -1;
+                    int overhead = packet.ContainerOverheadBits;
                     byte[] data = ReadAll(packet);
+                    int rc, nominal = 0;
                     fixed (byte* p = data)
-                        NativeMethods.Check(NativeMethods.nvh_stream_push_packet(_stream, p, data.Length, granule, flags));
+                    {
+                        NativeMethods.nvh_stream_packet_sample_count(_stream, p, Math.Min(data.Length, 8), packet.IsResync ? 1 : 0, out nominal);
+                        rc = NativeMethods.nvh_stream_push_packet(_stream, p, data.Length, granule, flags);
+                    }
+                    _stats.AddPacket(nominal, data.Length * 8, 0, overhead);
+                    if (rc != 0)
+                    {
+                        // host-parse mode: this packet makes the managed decoder throw.  It is consumed (packet.Done() in the
+                        // reference's finally block); what was parsed before it is synthesised and read first.
+                        pushError = ToException(rc);
+                        break;
+                    }
                 }
                 NativeMethods.Check(NativeMethods.nvh_stream_pending(_stream, out int frames, out long samples));
-                if (frames == 0) continue;
-                long need = samples * _channels;
-                if (_ring.Length < need) _ring = new float[need];
-                long written;
-                fixed (float* dst = _ring)
-                    NativeMethods.Check(NativeMethods.nvh_stream_synth(_stream, dst, IntPtr.Zero, _ring.Length, out written));
-                _ringPos = 0; _ringLen = (int)written;
+                long written = 0;
+                if (frames != 0)
+                {
+                    long need = samples * _channels;
+                    if (_ring.Length < need) _ring = new float[need];
+                    int rc;
+                    fixed (float* dst = _ring)
+                        rc = NativeMethods.nvh_stream_synth(_stream, dst, IntPtr.Zero, _ring.Length, out written);
+                    _ringPos = 0; _ringLen = (int)written;
+                    if (rc != 0)
+                    {
+                        // GPU-parse mode: packets inside the batch failed; the PCM of all others is complete
+                        NativeMethods.Check(NativeMethods.nvh_stream_parse_errors(_stream, null, null, 0, out int n));
+                        if (n <= 0) NativeMethods.Check(rc);
+                        var codes = new int[n]; var before = new long[n];
+                        fixed (int* pc = codes) fixed (long* pb = before)
+                            NativeMethods.Check(NativeMethods.nvh_stream_parse_errors(_stream, pc, pb, n, out n));
+                        for (int i = 0; i < n; i++)
+                            _pendingErrors.Enqueue(new KeyValuePair<Exception, int>(ToException(codes[i]), (int)Math.Min(before[i] * _channels, written)));
+                    }
+                }
+                if (pushError != null) _pendingErrors.Enqueue(new KeyValuePair<Exception, int>(pushError, (int)written));
                 if (written > 0) return true;
+                if (_pendingErrors.Count > 0) throw _pendingErrors.Dequeue().Key;
             }
             return false;
+        }
+
+        static Exception ToException(int rc)
+        {
+            try { NativeMethods.Check(rc); } catch (Exception e) { return e; }
+            return new InvalidOperationException("nvorbis_hip: unexpected success code");
         }
 
         // StreamDecoder.Read (StreamDecoder.cs:320-389): same argument checks, partial reads, 0 at end of stream.
@@ -106,9 +188,12 @@ namespace NVorbis.Hip
             int idx = offset, tgt = offset + count;
             while (idx < tgt)
             {
+                // an exception of the packet that follows this ring position: the samples before it have been delivered
+                if (_pendingErrors.Count > 0 && _ringPos >= _pendingErrors.Peek().Value) throw _pendingErrors.Dequeue().Key;
                 if (_ringPos >= _ringLen && !Refill()) break;
                 if (_skip > 0) { int drop = (int)Math.Min(_skip, _ringLen - _ringPos); _ringPos += drop; _skip -= drop; continue; }
                 int take = Math.Min(tgt - idx, _ringLen - _ringPos);
+                if (_pendingErrors.Count > 0) take = Math.Min(take, _pendingErrors.Peek().Value - _ringPos);
                 new Span<float>(_ring, _ringPos, take).CopyTo(buffer.Slice(idx, take));
                 _ringPos += take; idx += take;
             }
@@ -146,6 +231,7 @@ namespace NVorbis.Hip
 
             NativeMethods.Check(NativeMethods.nvh_stream_reset(_stream));          // ResetDecoder (:599)
             _ringPos = _ringLen = 0; _ended = false;
+            _pendingErrors.Clear();
             // the pre-roll packet: a first packet, emits nothing, only provides the overlap (:602-614)
             var preRoll = _packetProvider.GetNextPacket();
             if (preRoll == null)

@@ -1,6 +1,8 @@
 // NativeMethods.cs -- P/Invoke declarations for libnvorbis_hip.so (include/nvorbis_hip.h).
 // Source-only in this repository: the build image has no .NET toolchain.  The Python ctypes binding
 // (nvorbis_amd/native.py) declares exactly the same entry points and is what the test suite drives.
+// These files are compiled INTO the NVorbis assembly (csharp/README.md): IFactory, the plug-in interfaces, TagData and
+// StreamStats are `internal` there.
 using System;
 using System.Runtime.InteropServices;
 
@@ -69,6 +71,16 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern int nvh_stream_mode_info(IntPtr stream, int modeIndex, out int blockFlag, out int blockSize, out int mapping);
         [DllImport(Lib)] public static extern int nvh_stream_floor_info(IntPtr stream, int floorIndex, out int type, out int postCount, out int range);
         [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);
+        /// <summary>IStreamDecoder.UpperBitrate / NominalBitrate / LowerBitrate (StreamDecoder.cs:191-199).</summary>
+        [DllImport(Lib)] public static extern int nvh_stream_bitrates(IntPtr stream, out int upper, out int nominal, out int lower);
+        /// <summary>Packets of the last synthesised batch that made the parser fail (GPU-parse mode), with their positions in its PCM.</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_parse_errors(IntPtr stream, int* codes, long* samplesBefore, int cap, out int count);
+        /// <summary>Device memory for the managed float[] contract of the plug-in interfaces (GpuFactory.cs).</summary>
+        [DllImport(Lib)] public static extern int nvh_dev_alloc(IntPtr ctx, UIntPtr bytes, out IntPtr dPtr);
+        [DllImport(Lib)] public static extern void nvh_dev_free(IntPtr ctx, IntPtr dPtr);
+        [DllImport(Lib)] public static extern unsafe int nvh_dev_upload(IntPtr ctx, IntPtr dDst, void* hSrc, UIntPtr bytes);
+        [DllImport(Lib)] public static extern unsafe int nvh_dev_download(IntPtr ctx, void* hDst, IntPtr dSrc, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int nvh_measure_copy(IntPtr ctx, IntPtr dSrc, IntPtr dDst, UIntPtr bytes, int iters, out float ms);
         [DllImport(Lib)] public static extern unsafe int nvh_stream_synth(IntPtr stream, float* pcmHost, IntPtr dPcm, long capacity, out long written);
 
         internal static void Check(int rc)

@@ -116,6 +116,13 @@ int nvh_overlap_buffers(nvh_ctx *c, const float *d_previous, float *d_next, int 
 int nvh_copy_buffer(nvh_ctx *c, const float *d_planes, int start, int count, int channels, int64_t plane_stride,
                     float *d_target, int clip, int *clipped);
 
+/* Device memory for callers without a HIP binding of their own (csharp/GpuFactory.cs stages the managed float[] arrays of
+ * the plug-in interfaces through these).  Copies complete before the call returns. */
+int nvh_dev_alloc(nvh_ctx *c, size_t bytes, void **out);
+void nvh_dev_free(nvh_ctx *c, void *d_ptr);
+int nvh_dev_upload(nvh_ctx *c, void *d_dst, const void *h_src, size_t bytes);
+int nvh_dev_download(nvh_ctx *c, void *h_dst, const void *d_src, size_t bytes);
+
 /* Measurement helper (no reference counterpart): `iters` passes of a float4 copy kernel over `bytes` bytes (a multiple
  * of 16) from d_src to d_dst, timed with HIP events on the context's stream; *ms = total.  bench.py reports
  * 2 * bytes * iters / ms as the measured HBM ceiling next to the roofline figure. */

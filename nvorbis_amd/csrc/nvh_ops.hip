@@ -64,6 +64,50 @@ int get_mdct(nvh_ctx* c, int n, MdctDev** out) {
   return NVH_OK;
 }
 
+// Device memory for callers without a HIP binding of their own (the C# GpuMdct / GpuFloor / GpuResidue / GpuMode classes keep
+// the managed float[] contract of the plug-in interfaces and stage through these).  Copies are ordered on the context's
+// stream and complete before the call returns.
+extern "C" int nvh_dev_alloc(nvh_ctx* c, size_t bytes, void** out) {
+  return nvh_guard([&]() -> int {
+    if (!c || !out) return NVH_ERR_ARGUMENT;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return NVH_OK;
+  });
+}
+
+extern "C" void nvh_dev_free(nvh_ctx* c, void* d_ptr) {
+  nvh_guard_void([&] {
+    if (!c || !d_ptr) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_ptr);
+  });
+}
+
+extern "C" int nvh_dev_upload(nvh_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+  return nvh_guard([&]() -> int {
+    if (!c || (bytes && (!d_dst || !h_src))) return NVH_ERR_ARGUMENT;
+    if (!bytes) return NVH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NVH_OK;
+  });
+}
+
+extern "C" int nvh_dev_download(nvh_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+  return nvh_guard([&]() -> int {
+    if (!c || (bytes && (!h_dst || !d_src))) return NVH_ERR_ARGUMENT;
+    if (!bytes) return NVH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NVH_OK;
+  });
+}
+
 // Measured HBM ceiling for the roofline report: `iters` passes of a float4 copy kernel over `bytes` (a multiple of 16),
 // timed with HIP events on the context's stream.  *ms = total time of the `iters` passes.
 extern "C" int nvh_measure_copy(nvh_ctx* c, const void* d_src, void* d_dst, size_t bytes, int iters, float* ms) {

@@ -42,6 +42,10 @@ SIGNATURES = {
     "nvh_ctx_destroy": (None, [_vp]),
     "nvh_ctx_set_hip_stream": (C.c_int, [_vp, _vp]),
     "nvh_ctx_synchronize": (C.c_int, [_vp]),
+    "nvh_dev_alloc": (C.c_int, [_vp, C.c_size_t, _vpp]),
+    "nvh_dev_free": (None, [_vp, _vp]),
+    "nvh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "nvh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "nvh_measure_copy": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _f32p]),
     "nvh_stream_bitrates": (C.c_int, [_vp, _ip, _ip, _ip]),
     "nvh_mdct_reverse": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int64]),

@@ -138,6 +138,13 @@ int orc_floor0_apply_coeffs(orc_decoder *d, int floor_index, int block_size, flo
 /* type, post count (Floor1 _xList.Length; Floor0 _order) and _range of floor `floor_index`; returns the number of floors. */
 int orc_floor_info(const orc_decoder *d, int floor_index, int *type, int *post_count, int *range);
 
+/* IFloorData of one channel as Mapping.DecodePacket left it for the last packet given to orc_decode_packet_block
+ * (returns the floor type, or a negative ORC_ERR_*), and the static structure of a mapping. */
+int orc_last_floor_data(const orc_decoder *d, int channel, int *execute, int *posts, int *post_count, float *amp, float *coeff,
+                        int coeff_cap);
+int orc_mapping_info(const orc_decoder *d, int mapping_index, int *coupling_steps, int *magnitude, int *angle, int cap,
+                     int *channel_floor, int ch_cap);
+
 /* Test instrumentation: residue coverage of the calling thread's decodes between begin and end.
  * mask[channel * plane_len + bin] gets bit s set when cascade stage s added a value to that bin. */
 int orc_coverage_begin(int channels, int plane_len);

@@ -137,6 +137,10 @@ struct orc_decoder {
   int last_error;
   /* test hook: the IResidue.Decode calls of the last Mapping.DecodePacket (cursor before the call, residue index) */
   int res_calls, res_call_pos[16], res_call_idx[16], res_call_any;
+  /* test hook: the floor data Mapping.DecodePacket worked with for the last packet (after the ForceEnergy / ForceNoEnergy
+   * fix-ups), first 8 channels */
+  orc_floor_data last_floor[8];
+  int last_floor_n;
   int trace_on, trace_n, trace_cap;
   orc_frame_trace *trace;
 };

@@ -136,6 +136,9 @@ int orc_mapping_decode_packet(orc_decoder *d, const orc_mapping *m, orc_packet *
     }
   }
 
+  d->last_floor_n = nch < 8 ? nch : 8; /* test hook (orc_last_floor_data) */
+  for (c = 0; c < d->last_floor_n; c++) d->last_floor[c] = floor_data[c];
+
   /* floor apply + IMDCT (:185-197) */
   for (c = 0; c < nch; c++) {
     if (orc_floor_execute_channel(&floor_data[c])) {

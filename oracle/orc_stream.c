@@ -468,6 +468,41 @@ int orc_last_residue_calls(const orc_decoder *d, int *pos, int *idx, int cap, in
   return d->res_calls;
 }
 
+/* Test hook: IFloorData of channel `channel` as Mapping.DecodePacket left it for the last packet given to
+ * orc_decode_packet_block: *execute = ExecuteChannel, Floor1: posts[64] + *post_count, Floor0: *amp + coeff[order]. */
+int orc_last_floor_data(const orc_decoder *d, int channel, int *execute, int *posts, int *post_count, float *amp, float *coeff,
+                        int coeff_cap) {
+  const orc_floor_data *f;
+  int i;
+  if (!d || channel < 0 || channel >= d->last_floor_n) return ORC_ERR_ARGUMENT;
+  f = &d->last_floor[channel];
+  if (execute) *execute = orc_floor_execute_channel(f);
+  if (post_count) *post_count = f->post_count;
+  if (posts)
+    for (i = 0; i < 64; i++) posts[i] = f->posts[i];
+  if (amp) *amp = f->amp;
+  if (coeff)
+    for (i = 0; i < coeff_cap && i < 257; i++) coeff[i] = f->coeff[i];
+  return f->type;
+}
+
+/* Mapping.cs:16-93 of mapping `mapping_index`: coupling pairs (magnitude, angle), floor index per channel. */
+int orc_mapping_info(const orc_decoder *d, int mapping_index, int *coupling_steps, int *magnitude, int *angle, int cap,
+                     int *channel_floor, int ch_cap) {
+  const orc_mapping *m;
+  int i;
+  if (!d || mapping_index < 0 || mapping_index >= d->nmappings) return ORC_ERR_ARGUMENT;
+  m = &d->mappings[mapping_index];
+  if (coupling_steps) *coupling_steps = m->coupling_steps;
+  for (i = 0; i < m->coupling_steps && i < cap; i++) {
+    if (magnitude) magnitude[i] = m->coupling_magnitude[i];
+    if (angle) angle[i] = m->coupling_angle[i];
+  }
+  for (i = 0; i < m->channels && i < ch_cap; i++)
+    if (channel_floor) channel_floor[i] = m->channel_floor[i];
+  return ORC_OK;
+}
+
 int orc_mode_info(const orc_decoder *d, int mode_index, int *block_flag, int *block_size, int *mapping) {
   if (!d) return 0;
   if (mode_index >= 0 && mode_index < d->nmodes) {

@@ -54,6 +54,8 @@ class Oracle:
         L.orc_floor0_apply_coeffs.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp, C.c_int]
         L.orc_floor1_apply_posts.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
         L.orc_floor_info.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int)] * 3
+        L.orc_last_floor_data.argtypes = [vp, C.c_int, C.POINTER(C.c_int), vp, C.POINTER(C.c_int), C.POINTER(C.c_float), vp, C.c_int]
+        L.orc_mapping_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), vp, vp, C.c_int, vp, C.c_int]
         L.orc_coverage_begin.argtypes = [C.c_int, C.c_int]
         L.orc_coverage_end.argtypes = [vp]
 

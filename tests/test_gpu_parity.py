@@ -250,6 +250,120 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def _level1_in_mapping_order(oracle, gpu_ctx, pk, pick):
+    """Mode.Decode of single packets assembled from the level-1 entry points, called in the order Mapping.DecodePacket and
+    Mode.Decode call the plug-in interfaces (Mapping.cs:95-198, Mode.cs:153-170):
+        Array.Clear -> IResidue.Decode per submap -> inverse coupling, last step first -> per channel IFloor.Apply +
+        IMdct.Reverse (or clearing the back half) -> window loop
+    -- what csharp/GpuFactory.cs's classes do -- must equal nvh_mode_decode of the same packet, bit for bit.  The bit-consuming
+    results each call needs (posts / LSP coefficients, execute flags, the packet cursor at every IResidue.Decode) are the
+    oracle's for that packet."""
+    import ctypes as C
+    import nvorbis_amd as nv
+    torch = _torch()
+    L = oracle.L
+    d = oracle.open_headers(pk[:3])
+    st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+    checked = 0
+    try:
+        ch, b1 = st.channels, st.block1
+        nmodes = L.orc_mode_info(d, 0, None, None, None)
+        mode_bits = max(0, (nmodes - 1).bit_length())
+        ref_planes = np.zeros(ch * b1, np.float32)
+        want = _dev_zeros(ch * b1)
+        for i in pick:
+            p = pk[i]
+            a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            rc = L.orc_decode_packet_block(d, p, len(p), ref_planes.ctypes.data, C.byref(a), C.byref(b), C.byref(c), C.byref(e))
+            geo = st.mode_decode(p, want.data_ptr())
+            if rc != 1 or geo is None:
+                continue
+            n = e.value
+            bits = int.from_bytes(p[:8].ljust(8, b"\0"), "little")
+            mode_idx = (bits >> 1) & ((1 << mode_bits) - 1)
+            flag, bs, mp = C.c_int(), C.c_int(), C.c_int()
+            L.orc_mode_info(d, mode_idx, C.byref(flag), C.byref(bs), C.byref(mp))
+            assert bs.value == n
+            prev_f = (bits >> (1 + mode_bits)) & 1 if flag.value else 0
+            next_f = (bits >> (2 + mode_bits)) & 1 if flag.value else 0
+            steps = C.c_int()
+            mag, ang, chfl = np.zeros(64, np.int32), np.zeros(64, np.int32), np.zeros(16, np.int32)
+            assert L.orc_mapping_info(d, mp.value, C.byref(steps), mag.ctypes.data, ang.ctypes.data, 64, chfl.ctypes.data, 16) == 0
+            # IFloorData of every channel
+            ex, posts, counts, amps, coeffs, ftype = [], [], [], [], [], []
+            for cc in range(ch):
+                xe, pc, am = C.c_int(), C.c_int(), C.c_float()
+                po, co = np.zeros(64, np.int32), np.zeros(257, np.float32)
+                t = L.orc_last_floor_data(d, cc, C.byref(xe), po.ctypes.data, C.byref(pc), C.byref(am), co.ctypes.data, 257)
+                assert t >= 0
+                ex.append(bool(xe.value)); posts.append(po); counts.append(pc.value); amps.append(am.value); coeffs.append(co); ftype.append(t)
+            # buffers as DecodeNextPacket hands them over: whatever the previous packet left, front halves cleared (Mapping.cs:108)
+            host = np.random.default_rng(i).normal(0, 1, ch * b1).astype(np.float32).reshape(ch, b1)
+            host[:, : n // 2] = 0.0
+            planes = torch.from_numpy(host.reshape(-1).copy()).cuda()
+            torch.cuda.synchronize()
+            base = planes.data_ptr()
+            pos, idx, any_ = np.zeros(16, np.int32), np.zeros(16, np.int32), C.c_int()
+            ncalls = L.orc_last_residue_calls(d, pos.ctypes.data, idx.ctypes.data, 16, C.byref(any_))
+            for k in range(ncalls):  # IResidue.Decode per submap (Mapping.cs:122-134)
+                st.residue_decode(int(idx[k]), p, int(pos[k]), n, base, any_channel_decodes=bool(any_.value))
+            for k in range(steps.value - 1, -1, -1):  # inverse coupling (Mapping.cs:137-182)
+                if ex[int(ang[k])] or ex[int(mag[k])]:
+                    gpu_ctx.inverse_couple(base + 4 * b1 * int(mag[k]), base + 4 * b1 * int(ang[k]), n // 2)
+            for cc in range(ch):  # IFloor.Apply + IMdct.Reverse (Mapping.cs:185-197)
+                row = base + 4 * b1 * cc
+                if ex[cc]:
+                    if ftype[cc] == 1:
+                        status = st.floor1_apply(int(chfl[cc]), n, posts[cc].reshape(1, 64), np.array([counts[cc]], np.int32), row, b1)
+                    else:
+                        am = amps[cc]
+                        status = st.floor0_apply(int(chfl[cc]), n, np.array([am], np.float32), coeffs[cc][:256].reshape(1, 256), row, b1)
+                    assert status[0] == 0
+                    gpu_ctx.mdct_reverse(n, 1, row, b1)
+                else:
+                    gpu_ctx.synchronize()
+                    planes.view(ch, b1)[cc, n // 2:n] = 0.0  # Array.Clear(buffer[c], halfBlockSize, halfBlockSize)
+                    torch.cuda.synchronize()
+            st.window_apply(mode_idx, prev_f, next_f, ch, base, b1)  # Mode.cs:160-166
+            gpu_ctx.synchronize()
+            got = planes.cpu().numpy().reshape(ch, b1)[:, :n]
+            exp = want.cpu().numpy().reshape(ch, b1)[:, :n]
+            if any(t == 0 for t in ftype):
+                assert float(np.abs(got - exp).max()) <= 1e-6
+            else:
+                assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (i, float(np.abs(got - exp).max()))
+            checked += 1
+    finally:
+        st.close()
+        L.orc_close(d)
+    return checked
+
+
+@pytest.mark.parametrize("name", ["2test", "3test"])
+def test_level1_entries_in_mapping_order_files(oracle, gpu_ctx, ogg_bytes, name):
+    import nvorbis_amd as nv
+    pk, gr, fl = nv.demux_ogg(ogg_bytes[name])
+    pick = list(range(3, 30)) + list(range(30, len(pk), max(1, (len(pk) - 30) // 40)))
+    assert _level1_in_mapping_order(oracle, gpu_ctx, pk, pick) >= 40
+
+
+@pytest.mark.parametrize("name", ["stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096", "two_submaps", "mono_res0_small_blocks"])
+def test_level1_entries_in_mapping_order_synthetic(oracle, gpu_ctx, name):
+    from tests import synth_stream as ss
+    pk, gr, fl = ss.filtered_stream(oracle, name, 40, 3)
+    assert _level1_in_mapping_order(oracle, gpu_ctx, pk, range(3, len(pk))) >= 20
+
+
+def test_level1_entries_in_mapping_order_c4_full_depth(oracle, gpu_ctx, ogg_bytes):
+    from tests import vorbis_encode as ve
+    hdr = ve.c4_headers(ve.shipped_headers(ogg_bytes["3test"]), psize=32)
+    S = ve.setup_of(hdr)
+    kinds = np.ones(10, dtype=bool)
+    kinds[4:6] = False
+    pk, gr = ve.encode_stream(S, hdr, kinds, 9)
+    assert _level1_in_mapping_order(oracle, gpu_ctx, pk, range(3, len(pk))) == 10
+
+
 @pytest.mark.parametrize("waves", ["6", "4"])
 def test_run_kernel_bit_exact(waves):
     """The run kernel (kernels_run.hip, opt-in NVH_RUN=1: spectrum + IMDCT + window + overlap-add + clip + interleave in one

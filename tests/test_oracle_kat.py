@@ -248,3 +248,22 @@ def test_residue_call_trace_and_replay(oracle, ogg_bytes):
         assert seen > 20
     finally:
         oracle.L.orc_close(d)
+
+
+def test_reference_pcm_digests_when_present(oracle, ogg_bytes):
+    """Digests of the REFERENCE's own PCM (csharp/GoldenGenerator, run on a machine with .NET against the unmodified
+    NVorbis project) pin the oracle when they have been generated and committed as tests/golden/<name>[.noclip].pcm.sha256.
+    None can be generated in this image (no dotnet / mono / csc), which is why the oracle header says "parity unpinned"."""
+    import glob
+    import hashlib
+    import os
+    from tests.conftest import GOLDEN
+    files = sorted(glob.glob(os.path.join(GOLDEN, "*.pcm.sha256")))
+    if not files:
+        pytest.skip("no reference digests committed (needs a .NET box: csharp/GoldenGenerator)")
+    for path in files:
+        name = os.path.basename(path).split(".")[0]
+        digest, count, channels, rate, clip = open(path).read().split()
+        pcm, info = oracle.decode_ogg(ogg_bytes[name], clip=clip.endswith("1"))
+        assert (pcm.size, info["channels"], info["sample_rate"]) == (int(count), int(channels), int(rate)), path
+        assert hashlib.sha256(pcm.astype("<f4").tobytes()).hexdigest() == digest, path
