@@ -62,6 +62,10 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
     uint32_t serial = 0;
     std::vector<Page> pages;
     bool has_all_pages = false;
+    // StreamPageReader.AddPage state (Ogg/StreamPageReader.cs:44-91)
+    int32_t last_seq = 0;
+    bool have_first_data_page = false;
+    int64_t max_granule = 0;
   };
   std::vector<Logical> streams;
   std::vector<std::pair<uint32_t, int>> active;  // serial -> index into streams
@@ -133,6 +137,21 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
           slot = (int)active.size() - 1;
         }
         Logical& lg = streams[(size_t)active[(size_t)slot].second];
+        {
+          // StreamPageReader.AddPage (Ogg/StreamPageReader.cs:50-86).  Granule sanity: the reference throws InvalidDataException
+          // from inside its page reader; here the file is refused.  Resync mark: lost page sync, or a page sequence number
+          // that does not follow the previous one ("out of order page / sequence jump, we're counting it as a resync").
+          const int32_t seq = (int32_t)((uint32_t)h[18] | ((uint32_t)h[19] << 8) | ((uint32_t)h[20] << 16) | ((uint32_t)h[21] << 24));
+          if (pg.granule != -1) {
+            if (!lg.have_first_data_page && pg.granule > 0) lg.have_first_data_page = true;
+            else if (lg.max_granule > pg.granule) return NVH_ERR_INVALID_DATA;  // "Granule Position regressed?!"
+            lg.max_granule = pg.granule;
+          } else if (lg.have_first_data_page && (!pg.continued || pg.pk_off.size() != 1)) {
+            return NVH_ERR_INVALID_DATA;  // "Granule Position was -1 but page does not have exactly 1 continued packet."
+          }
+          pg.resync = pg.resync || (lg.last_seq != 0 && (int32_t)((uint32_t)lg.last_seq + 1u) != seq);
+          lg.last_seq = seq;
+        }
         const bool eos_page = (pg.flags & 0x04) != 0;
         lg.pages.push_back(std::move(pg));
         if (eos_page) {

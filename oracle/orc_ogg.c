@@ -96,6 +96,10 @@ int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t
   int32_t serial = 0;
   size_t pos = 0;
   int resync = 0, i;
+  /* StreamPageReader.AddPage state (Ogg/StreamPageReader.cs:44-91) */
+  int32_t last_seq = 0;
+  int have_first_data_page = 0;
+  int64_t max_granule = 0;
   pkt_list pl;
   memset(&pl, 0, sizeof pl);
   if (!g_crc_ready) crc_init();
@@ -169,7 +173,27 @@ int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t
         pg->seg_cnt = seg_cnt;
         pg->flags = h[5];
         memcpy(&pg->granule, h + 6, 8); /* little-endian host */
-        pg->is_resync = resync;
+        {
+          /* StreamPageReader.AddPage (Ogg/StreamPageReader.cs:50-86): granule sanity, then the resync mark -- lost page sync
+           * or a page sequence number that does not follow the previous one */
+          const int32_t seq = (int32_t)((uint32_t)h[18] | ((uint32_t)h[19] << 8) | ((uint32_t)h[20] << 16) | ((uint32_t)h[21] << 24));
+          if (pg->granule != -1) {
+            if (!have_first_data_page && pg->granule > 0) {
+              have_first_data_page = 1;
+            } else if (max_granule > pg->granule) {
+              rc = ORC_ERR_INVALID_DATA; /* "Granule Position regressed?!" */
+              npages--;
+              goto done;
+            }
+            max_granule = pg->granule;
+          } else if (have_first_data_page && (!is_continued || pkt_cnt != 1)) {
+            rc = ORC_ERR_INVALID_DATA; /* "Granule Position was -1 but page does not have exactly 1 continued packet." */
+            npages--;
+            goto done;
+          }
+          pg->is_resync = resync || (last_seq != 0 && (int32_t)((uint32_t)last_seq + 1u) != seq);
+          last_seq = seq;
+        }
         pg->is_continued = is_continued;
         pg->packet_count = pkt_cnt;
         pg->pk_off = (int *)calloc((size_t)pkt_cnt, sizeof(int));

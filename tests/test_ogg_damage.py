@@ -1,0 +1,129 @@
+"""Damaged containers: a flipped CRC byte, a dropped page, a page out of sequence, junk between pages,
+regressing granule positions.  What the reference's page reader does with them (Ogg/PageReaderBase.cs:227-292 byte-wise resync;
+Ogg/StreamPageReader.cs:44-91 granule sanity + "sequence jump counts as a resync"; Ogg/PacketProvider.cs:324-438 packet
+assembly) is restated twice, independently -- oracle/orc_ogg.c and the product's host_ogg.cpp: both must deliver the same
+packets, granule positions and end-of-stream / resync flags, and the decoders behind them the same PCM."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import ogg_py, vorbis_encode as ve
+
+
+def _oracle_demux(oracle, data):
+    L = oracle.L
+    L.orc_ogg_demux.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    b, o, g, f, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+    rc = L.orc_ogg_demux(data, len(data), C.byref(b), C.byref(o), C.byref(g), C.byref(f), C.byref(n))
+    if rc != 0:
+        return rc, None
+    cnt = n.value
+    offs = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_int64)), shape=(cnt + 1,)).copy()
+    gran = np.ctypeslib.as_array(C.cast(g, C.POINTER(C.c_int64)), shape=(max(cnt, 1),)).copy()[:cnt]
+    flags = np.ctypeslib.as_array(C.cast(f, C.POINTER(C.c_uint8)), shape=(max(cnt, 1),)).copy()[:cnt]
+    raw = C.string_at(b, int(offs[-1])) if cnt else b""
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for ptr in (b, o, g, f):
+        libc.free(ptr)
+    return 0, ([raw[int(offs[i]):int(offs[i + 1])] for i in range(cnt)], gran.tolist(), flags.tolist())
+
+
+def _product_demux(data):
+    import nvorbis_amd as nv
+    from nvorbis_amd import native
+    try:
+        pk, gr, fl = nv.demux_ogg(data)
+    except native.NvhError as e:
+        return e.code, None
+    return 0, (pk, gr.tolist(), fl.tolist())
+
+
+def _stream(ogg_bytes, seed=1, frames=90, page_packets=4):
+    hdr = ve.shipped_headers(ogg_bytes["3test"])
+    S = ve.setup_of(hdr)
+    rng = np.random.default_rng(seed)
+    kinds = ve.markov_kinds(rng, frames, 0.1, 0.3)
+    kinds[:4] = True
+    pool = ve.packet_pool(S, seed, per_kind=8)
+    pk, gr = ve.stream_from_pool(S, hdr, pool, kinds, rng)
+    data = ogg_py.write_ogg(pk, gr, page_packets=page_packets)
+    return data, ogg_py.read_pages(data)
+
+
+def _damage(data, pages, kind, rng):
+    """Returns the damaged byte string."""
+    k = int(rng.integers(3, len(pages) - 2))  # an audio page in the middle
+    pg = pages[k]
+    a, b = pg["offset"], pg["offset"] + pg["length"]
+    if kind == "crc":  # one bit of the body: the page fails its CRC, the reader resyncs byte by byte to the next page
+        buf = bytearray(data)
+        buf[a + 27 + len(pg["segs"]) + int(rng.integers(0, max(1, pg["length"] - 27 - len(pg["segs"]))))] ^= 0x10
+        return bytes(buf)
+    if kind == "drop":  # the page is gone: the next one arrives with a sequence gap
+        return data[:a] + data[b:]
+    if kind == "junk":  # garbage between two pages: sync lost and found again
+        return data[:a] + bytes(rng.integers(0, 256, int(rng.integers(1, 300))).astype(np.uint8)) + data[a:]
+    if kind == "swap":  # two neighbouring pages exchanged: sequence numbers out of order, granule position regresses
+        nb = pages[k + 1]
+        return data[:a] + data[nb["offset"]:nb["offset"] + nb["length"]] + data[a:b] + data[nb["offset"] + nb["length"]:]
+    if kind == "seq":  # a page whose sequence number jumps (rewritten with a valid CRC): counted as a resync
+        seg, body = pg["segs"], pg["body"]
+        new = ogg_py.make_page(pg["serial"], pg["seq"] + 5, pg["granule"], pg["flags"], seg, body)
+        return data[:a] + new + data[b:]
+    if kind == "truncate":
+        return data[: a + pg["length"] // 2]
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["crc", "drop", "junk", "swap", "seq", "truncate"])
+def test_damaged_pages_same_packets_and_flags(oracle, ogg_bytes, kind):
+    rng = np.random.default_rng(hash(kind) & 0xFFFF)
+    seen_resync = False
+    for trial in range(6):
+        data, pages = _stream(ogg_bytes, seed=trial + 1, page_packets=int(rng.integers(1, 6)))
+        bad = _damage(data, pages, kind, rng)
+        rc_o, got_o = _oracle_demux(oracle, bad)
+        rc_p, got_p = _product_demux(bad)
+        assert (rc_o == 0) == (rc_p == 0), (kind, trial, rc_o, rc_p)
+        if rc_o != 0:
+            assert kind == "swap"  # "Granule Position regressed?!" (Ogg/StreamPageReader.cs:59-63): both refuse the file
+            assert rc_o == -1 and rc_p == -1
+            continue
+        assert got_o[0] == got_p[0], (kind, trial)
+        assert got_o[1] == got_p[1] and got_o[2] == got_p[2], (kind, trial)
+        seen_resync = seen_resync or any(f & 2 for f in got_p[2])
+        # the oracle behind its own demux == the oracle fed the product's packets
+        a, _ = oracle.decode_ogg(bad)
+        b, _ = oracle.decode_packets(got_p[0], got_p[1], got_p[2])
+        assert a.size == b.size and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    if kind in ("crc", "drop", "junk", "seq"):
+        assert seen_resync, "the damage never produced a resync packet"
+
+
+def test_undamaged_stream_has_no_resync(oracle, ogg_bytes):
+    data, pages = _stream(ogg_bytes)
+    rc, got = _product_demux(data)
+    assert rc == 0 and not any(f & 2 for f in got[2]) and (got[2][-1] & 1)
+    rc_o, got_o = _oracle_demux(oracle, data)
+    assert rc_o == 0 and got_o == got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["crc", "drop", "junk", "seq"])
+def test_damaged_files_decode_like_the_oracle(oracle, gpu_ctx, ogg_bytes, kind):
+    """VorbisReader over damaged files: a resync packet makes the decoder pick up a new position (StreamDecoder.cs:481-484);
+    the PCM equals the oracle's, bit for bit, with both packet parsers."""
+    import nvorbis_amd as nv
+    rng = np.random.default_rng(7)
+    for trial in range(4):
+        data, pages = _stream(ogg_bytes, seed=20 + trial, frames=300, page_packets=int(rng.integers(2, 9)))
+        bad = _damage(data, pages, kind, rng)
+        ref, info = oracle.decode_ogg(bad)
+        for gpu_parse in (False, True):
+            rd = nv.VorbisReader(bad, ctx=gpu_ctx, batch_frames=64, gpu_parse=gpu_parse)
+            got = rd.read_all()
+            rd.close()
+            assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (kind, trial, gpu_parse)
