@@ -205,6 +205,7 @@ struct SharedSetup {
   DevBuf dev_copy;  // the NvhDevSetup block itself in device memory (the run kernel reads it from there, see kernels_run.hip)
   bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
   bool has_floor0 = false;
+  bool has_sequential = false;  // some residue replays the reference's partition order (quirk B-1 / vector overrun)
   // GPU packet parser (kernels_parse.hip): its tables, and whether this stream shape is inside its limits
   DevBuf parse_arena;
   NvhDevParse parse{};
@@ -219,6 +220,7 @@ struct nvh_ctx {
   BufPool pool;
   BufPool hpool;  // pinned staging blocks
   std::map<std::string, std::shared_ptr<SharedSetup>> setup_cache;  // key: identification packet + setup packet bytes
+  bool big_lds_attr_set = false;    // the general spectrum kernels' 152 KB dynamic-LDS opt-in was made on this context's device
   bool parse_lds_attr_set = false;  // k_parse's 80 KB dynamic-LDS opt-in was made on this context's device
 };
 

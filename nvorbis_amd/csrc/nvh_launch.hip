@@ -400,7 +400,22 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     if (T.unfused) words = 1u << 20;  // test aid: force the unfused kernels below
     if ((words + (size_t)(s->setup.block1 / 16)) * 4 > 64 * 1024) fuse_imdct = false;
     const size_t lds_pad = (size_t)T.lds_pad;  // occupancy experiments
-    if (words * 4 <= 64 * 1024) {
+    // A frame that does not fit the default 64 KB dynamic-LDS window (six channels at n = 4096 with full-depth packets:
+    // 48 KB of spectrum + ~25 KB of staged ops and entries) still fits the CU's 160 KB: the general kernels opt in to a larger
+    // window, one workgroup per CU, instead of falling back to the global-memory kernels (measured on the C4 full-depth
+    // stream: k_residue + k_couple_floor 510 us per 2048 frames).
+    size_t lds_limit = 64 * 1024;
+    // (not for residues that replay the reference's partition order, one vector write at a time: a lone 8-wavefront workgroup
+    // per CU is the worst shape for that -- 1135 us against 840 us for the global-memory kernels on the psize-32 C4 stream)
+    if (!has_floor0 && !fast && !T.unfused && !s->shared->has_sequential && words * 4 > lds_limit && words * 4 <= 152 * 1024) {
+      if (!s->ctx->big_lds_attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_spectrum_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_spectrum_gen8, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        s->ctx->big_lds_attr_set = true;
+      }
+      lds_limit = 152 * 1024;
+    }
+    if (words * 4 <= lds_limit) {
       if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = fused spectrum kernel
       b->slot_name[0] = "-";
       b->slot_name[1] = has_floor0 ? "k_spectrum_f0" : (fast ? "k_spectrum" : "k_spectrum_gen");

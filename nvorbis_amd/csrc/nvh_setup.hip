@@ -155,6 +155,7 @@ int upload_setup(nvh_stream* s) {
         if (bk.dimensions > 0 && r.type != 0 && r.partition_size % bk.dimensions != 0) seq = true;  // vector overrun
       }
     d.sequential = seq ? 1 : 0;
+    if (seq) s->shared->has_sequential = true;
     d.psize_magic = r.partition_size > 1 ? (uint32_t)((0x100000000ull + (uint64_t)r.partition_size - 1) / (uint64_t)r.partition_size) : 0u;
     d.rch_magic = r.real_channels > 1 ? (uint32_t)((0x100000000ull + (uint64_t)r.real_channels - 1) / (uint64_t)r.real_channels) : 0u;
     // reciprocal multiplies are exact while index * divisor < 2^32; indices stay below

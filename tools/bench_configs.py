@@ -1,6 +1,8 @@
 """Kernel timings of the other BASELINE.json configurations (parity-test cases, not bench.py lines):
 C3 mixed short/long blocks (the shipped 3test.ogg as is), C4 six channels n=4096 (synthetic, Residue2 + coupling),
-plus the remaining synthetic shapes.  Random packets, so the numbers describe the code paths, not an encoder's output."""
+plus the remaining synthetic shapes.  The C2 / C3 / C4 lines marked "full depth" use packets written by the structured
+encoder (tests/vorbis_encode.py: a classification for every partition, a VQ entry for every vector of every cascade stage);
+the other synthetic shapes are random-bit packets, so those numbers describe the code paths, not an encoder's output."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -44,6 +46,21 @@ lo, hi = ll[0], ll[-1]
 seg = pk[lo:hi]
 nshort = 0
 run("C3 3test.ogg mixed 256/2048 (%d-packet loop)" % len(seg), pk[:3] + [pk[lo]] + seg * 40)
+from tests import vorbis_encode as ve
+hdr3 = ve.shipped_headers(data)
+S3 = ve.setup_of(hdr3)
+rng = np.random.default_rng(7)
+pool3 = ve.packet_pool(S3, 20260928, per_kind=256)
+p, g = ve.stream_from_pool(S3, hdr3, pool3, np.ones(4200, dtype=bool), rng)
+run("C2 G-rand full depth (stereo n=2048)", p)
+p, g = ve.stream_from_pool(S3, hdr3, pool3, ve.markov_kinds(np.random.default_rng(7), 4700), rng)
+run("C3 Markov full depth (256/2048)", p)
+for ps in (48, 32):
+    h4 = ve.c4_headers(hdr3, psize=ps)
+    S4 = ve.setup_of(h4)
+    pool4 = ve.packet_pool(S4, 100 + ps, per_kind=128, class_weights=[0] + [1] * 9)
+    p, g = ve.stream_from_pool(S4, h4, pool4, np.ones(2100, dtype=bool), rng)
+    run("C4 6ch n=4096 psize %d full depth" % ps, p, target_frames=2048)
 for name in ("six_ch_res2_4096", "stereo_res1_coupled", "three_ch_res2_misaligned", "two_submaps", "mono_8192", "floor0_stereo", "mono_res0_small_blocks"):
     p, g, f = ss.filtered_stream(orc, name, 300, 3, True)
     run(name, p)
