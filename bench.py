@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="profiling builds with phases masked out produce garbage PCM")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent decoder instances (own nvh_ctx / HIP stream / resident batch) the passes rotate over")
     ap.add_argument("--min-timed-ms", type=float, default=250.0, help="lower bound of the timed region (sets passes_per_step)")
@@ -234,7 +235,7 @@ def main():
     iters = 50
     total_ms, km = batch.time(pcm.data_ptr(), cap, iters)
     checksum = float(pcm.double().abs().sum().item())
-    assert checksum > 0 and bool(torch.isfinite(pcm).all().item())
+    assert args.no_check or (checksum > 0 and bool(torch.isfinite(pcm).all().item()))
 
     if rank == 0:
         # the library says which kernel variant sits behind each timing slot ("-" = empty: only event overhead)

@@ -196,9 +196,12 @@ template <int LD, bool WIN, typename Sink, bool INPLACE = false>
 __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __restrict__ w, float* lds,
                                                 const float* __restrict__ A, const float* __restrict__ B,
                                                 const float* __restrict__ C, const float* __restrict__ TW, int lane,
-                                                Sink sink) {
+                                                Sink sink, long long* stamp = nullptr) {
   using G = Geo<LD>;
   float2* l2 = reinterpret_cast<float2*>(lds);
+  // profiling builds: shader-clock stamps of lane 0 (0 entry, 1 step 0 done, 2 radix passes done, 3 D=4,2,1 done, 4 end)
+#define IMDCT_T(k) do { if (stamp && lane == 0) stamp[k] = clock64(); } while (0)
+  IMDCT_T(0);
 
   // step 0 (Mdct.cs:74-97).  The float4 at X[4j] feeds the first-half item j (even elements) and the
   // second-half item n8-1-j (odd elements): complex points N-1-j and j.
@@ -233,13 +236,16 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
     for (int j = lane; j < G::n8; j += 64) step0(j, reinterpret_cast<const float4*>(X)[j]);
   }
   wave_sync();
+  IMDCT_T(1);
 
   // radix-2 stages D = N/2 ... 8, three per register pass
   Passes<LD, LD - 5>::run(l2, TW, lane);
+  IMDCT_T(2);
 
   // D = 4, 2, 1
   ld654_pass<LD>(l2, A, lane);
   wave_sync();
+  IMDCT_T(3);
 
   // steps 4-6 (bit reversal), 7 and 8 fused.  Pair index p covers step-7 iterations 2p and 2p+1, whose
   // results are exactly the inputs of step-8 iterations p and n/16-1-p.
@@ -322,6 +328,8 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       sink(4 * h + 3, d3, o3);
     }
   }
+  IMDCT_T(4);
+#undef IMDCT_T
 }
 
 // ---- latency-optimised form for n <= 2048 ---------------------------------------------------------------
@@ -566,12 +574,13 @@ __device__ __forceinline__ void imdct_wave_fast(const float* X, const float* __r
 template <int LD, bool WIN, bool COMPACT = false, bool LEAN = false>
 __device__ __forceinline__ void imdct_wave(const float* X, float* out, const float* __restrict__ w, float* lds,
                                            const float* __restrict__ A, const float* __restrict__ B,
-                                           const float* __restrict__ C, const float* __restrict__ TW, int lane) {
+                                           const float* __restrict__ C, const float* __restrict__ TW, int lane,
+                                           long long* stamp = nullptr) {
   auto sink = [=](int slot, int idx, float4 v) {
     if (!COMPACT || (slot & 1) == 0) *reinterpret_cast<float4*>(out + idx) = v;
   };
   if constexpr (LEAN)
-    imdct_wave_sink<LD, WIN, decltype(sink), true>(X, w, lds, A, B, C, TW, lane, sink);
+    imdct_wave_sink<LD, WIN, decltype(sink), true>(X, w, lds, A, B, C, TW, lane, sink, stamp);
   else if constexpr (LD <= 11)
     imdct_wave_fast<LD, WIN>(X, w, lds, A, B, C, TW, lane, sink);
   else

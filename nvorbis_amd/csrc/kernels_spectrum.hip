@@ -45,7 +45,7 @@
 template <bool FLOOR0, bool FAST, bool IMDCT = false, int NT = SP_THREADS>
 __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDevBatch& Bt, float* __restrict__ work,
                                               int* __restrict__ err, int cap_pass, int cap_ops, int cap_ent, float* smem,
-                                              long long* dbg = nullptr, int phase_mask = 7) {
+                                              long long* dbg = nullptr, int phase_mask = 15) {
   const int nch = S.channels;
   // channels whose floors are prepared concurrently (one wavefront each, one scratch block each) on the general path
   constexpr int grp = NT / 64;
@@ -173,6 +173,25 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       stage_ops(lane, 64);
       sp_wave_sync();
       build_pair_records(lane, 64);
+      // Chain heads of every pass, compacted (op indices, 16 bits each) over the staged ops, which nothing reads any more:
+      // the sweep below walks one chain per lane and pair of bins, and two thirds of a three-stage pass's ops are not
+      // heads -- whole wavefronts of the sweep used to find nothing but "not a head".  P[0] becomes the pass's head range.
+      sp_wave_sync();
+      uint16_t* heads = reinterpret_cast<uint16_t*>(s_ops);
+      int hcount = 0;
+      for (int ps = 0; ps < npass; ++ps) {
+        uint32_t* P = s_pass + ps * 16;
+        const int o_lo = __builtin_amdgcn_readfirstlane((int)P[1]), o_hi = __builtin_amdgcn_readfirstlane((int)P[1 + NVH_MAX_STAGES]);
+        const int hb = hcount;
+        for (int base = o_lo; base < o_hi; base += 64) {
+          const int o = base + lane;
+          const bool head = o < o_hi && !(s_link[o] & 0x8000u);
+          const unsigned long long m = __ballot(head);
+          if (head) heads[hcount + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)o;
+          hcount += __popcll(m);
+        }
+        if (lane == 0) P[0] = (uint32_t)hb | ((uint32_t)hcount << 16);
+      }
     } else {
       stage_rest(sw * 64 + lane, (nstage - 1) * 64);
     }
@@ -220,14 +239,14 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       // the running sums in registers, and writes once.  Same additions in the same order as the reference's
       // stage loop, without a barrier and an LDS read-modify-write per stage.
       const unsigned hp = (unsigned)psize >> 1;
-      const unsigned o0 = __builtin_amdgcn_readfirstlane(P[1]), o1 = __builtin_amdgcn_readfirstlane(P[1 + NVH_MAX_STAGES]);
-      const unsigned total = (o1 - o0) * hp;
+      const unsigned hrange = __builtin_amdgcn_readfirstlane(P[0]);  // chain heads of this pass (phase A)
+      const uint16_t* heads = reinterpret_cast<const uint16_t*>(s_ops) + (hrange & 0xFFFFu);
+      const unsigned total = ((hrange >> 16) - (hrange & 0xFFFFu)) * hp;
       for (unsigned idx = tid; idx < total; idx += NT) {
         const unsigned oq = hp > 1 ? __umulhi(idx, hp_magic) : idx;
         const unsigned i2 = idx - oq * hp, i = i2 << 1;  // pair / first component index inside the partition
-        unsigned o = o0 + oq;
+        unsigned o = heads[oq];
         unsigned link = s_link[o];
-        if (link & 0x8000u) continue;  // not a chain head: an earlier-stage op owns these bins
         uint4 rec = s_oprec[o];
         const unsigned xbase = rec.x >> 16;
         unsigned c0, x0, c1, x1;
@@ -475,7 +494,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       }
     }
     DBG_T(4);
-    if (IMDCT) {
+    if (IMDCT && (phase_mask & 8)) {
       // ---- inverse MDCT (Mdct.cs:65-313), one wavefront per channel ----
       // The transform's LDS slice (n/2 floats + n/16 of padding) overlays the channel's own spectrum, which the
       // wavefront has fully in registers before its first store (imdct_wave_fast loads everything up front):
@@ -496,11 +515,12 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
           const float* B = S.mdct_b[sl];
           const float* C = S.mdct_c[sl];
           const float* TW = S.mdct_tw[sl];
+          long long* stamp = (dbg && wv == 0) ? dbg + (long long)blockIdx.x * 24 + 8 : nullptr;  // profiling builds
           switch (fr.n) {
-            case 256: imdct_wave<8, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
-            case 512: imdct_wave<9, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
-            case 1024: imdct_wave<10, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
-            case 2048: imdct_wave<11, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+            case 256: imdct_wave<8, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp); break;
+            case 512: imdct_wave<9, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp); break;
+            case 1024: imdct_wave<10, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp); break;
+            case 2048: imdct_wave<11, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp); break;
             default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
           }
         }

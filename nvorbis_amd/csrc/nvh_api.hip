@@ -25,7 +25,9 @@ const NvhToggles& nvh_toggles() {
     x.parse_waves = num("NVH_PARSE_WAVES");
     x.run = on("NVH_RUN");
     x.run_waves = num("NVH_RUN_WAVES");
-    x.phase_mask = std::getenv("NVH_DEBUG_SPECTRUM_MASK") ? num("NVH_DEBUG_SPECTRUM_MASK") : 7;
+    x.multi = num("NVH_MULTI");
+    x.multi_wgs = num("NVH_MULTI_WGS");
+    x.phase_mask = std::getenv("NVH_DEBUG_SPECTRUM_MASK") ? num("NVH_DEBUG_SPECTRUM_MASK") : 15;
     return x;
   }();
   return t;

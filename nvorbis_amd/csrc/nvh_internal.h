@@ -53,6 +53,8 @@ __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhCh
                               uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
 __global__ void k_copy_f4(const float4* src, float4* dst, long long n4);
+__global__ void k_spectrum_imdct2_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
+__global__ void k_spectrum_imdct2_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_run4_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_run4_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_run6_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
@@ -111,6 +113,8 @@ struct NvhToggles {
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
   bool run;       // NVH_RUN: the run kernel (kernels_run.hip) instead of k_spectrum_imdct + k_ola_compact -- opt-in, it measured slower
   int run_waves;  // NVH_RUN_WAVES = 4 | 6
+  int multi;      // NVH_MULTI=1: frame loop (k_spectrum_imdct2) instead of one frame per workgroup (k_spectrum_imdct) -- opt-in, it measured slower
+  int multi_wgs;  // NVH_MULTI_WGS: workgroups per CU the frame loop is sized for (default 8)
   int phase_mask;  // debug build only (NVH_DEBUG_SPECTRUM_MASK)
 };
 const NvhToggles& nvh_toggles();
@@ -250,6 +254,7 @@ struct nvh_batch {
   DevBuf run_flags;
   unsigned run_epoch = 0;
   DevBuf dev_copy;  // the NvhDevBatch block in device memory
+  bool dev_copy_valid = false;  // ... and whether it holds the current upload's pointers
 };
 
 // GPU-parse mode: everything pushed since the last batch boundary, so that a batch in which k_parse found a packet the

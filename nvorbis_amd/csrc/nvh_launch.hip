@@ -92,6 +92,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   b->dev.coeffs = (const float*)(base + o_po);  // no Floor0 in this mode
   b->dev.nframes = b->nframes;
   b->dev.pad = 0;
+  b->dev_copy_valid = false;
   if (nf) {
     const unsigned blocks = (unsigned)((nf + 63) / 64);
     // Launch shape.  Packets take different paths through the parser, so the lanes of a wavefront mostly run one after
@@ -273,12 +274,24 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->dev.coeffs = (const float*)(base + o_co);
   b->dev.nframes = b->nframes;
   b->dev.pad = 0;
+  b->dev_copy_valid = false;
 
   size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
   rc = b->work.reserve(pad1((size_t)b->nframes) * plane);
   if (rc != NVH_OK) return rc;
   P.clear();
   s->parser->begin_batch();
+  return NVH_OK;
+}
+
+// The batch's parameter block in device memory (the frame-loop kernels read it from there instead of holding its pointers
+// in scalar registers); 80 bytes from pageable memory, staged by the runtime before the call returns, once per upload.
+static int upload_dev_copy(nvh_batch* b, hipStream_t st) {
+  if (b->dev_copy_valid && b->dev_copy.p) return NVH_OK;
+  int rc = b->dev_copy.reserve(sizeof(NvhDevBatch));
+  if (rc != NVH_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(b->dev_copy.p, &b->dev, sizeof(NvhDevBatch), hipMemcpyHostToDevice, st));
+  b->dev_copy_valid = true;
   return NVH_OK;
 }
 
@@ -335,8 +348,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
         HIP_TRY(hipMemsetAsync(b->run_flags.p, 0, b->run_flags.cap, st));
         b->run_epoch = 0;
       }
-      if ((rc = b->dev_copy.reserve(sizeof(NvhDevBatch))) != NVH_OK) return rc;
-      HIP_TRY(hipMemcpyAsync(b->dev_copy.p, &b->dev, sizeof(NvhDevBatch), hipMemcpyHostToDevice, st));  // 80 bytes, staged by the runtime
+      if ((rc = upload_dev_copy(b, st)) != NVH_OK) return rc;
       NvhRunArgs ra;
       ra.tails = work;
       ra.flags = (unsigned*)b->run_flags.p;
@@ -438,7 +450,25 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
           fprintf(stderr, "k_spectrum: lds %zu B, occupancy %d WG/CU (err %d), regs %d, static lds %zu, max dyn lds %d\n", words * 4 + lds_pad, nb,
                   (int)oe, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
         }
-        if (fuse_imdct) {
+        if (fuse_imdct && T.multi && s->setup.block0 >= 256) {
+          // frame loop (kernels_spectrum2.hip): as many workgroups as the device holds at once, each takes every grid-th frame
+          int dev_cus = 256;
+          (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device);
+          const size_t lds_bytes = words * 4 + 2 * (size_t)(s->setup.block1 / 16) * 4 + lds_pad;
+          size_t per_cu = (160 * 1024) / (lds_bytes + 64);
+          const size_t want = T.multi_wgs > 0 ? (size_t)T.multi_wgs : 8;  // 8 x 4 wavefronts: the 64-VGPR budget of the kernel
+          if (per_cu > want) per_cu = want;
+          if (per_cu < 1) per_cu = 1;
+          const size_t slots = per_cu * (size_t)(dev_cus > 0 ? dev_cus : 256);
+          const size_t per_wg = ((size_t)b->nframes + slots - 1) / slots;
+          const unsigned grid = (unsigned)(((size_t)b->nframes + per_wg - 1) / per_wg);
+          int rc = upload_dev_copy(b, st);
+          if (rc != NVH_OK) return rc;
+          b->slot_name[1] = "k_spectrum_imdct2";
+          hipLaunchKernelGGL(ch == 1 ? k_spectrum_imdct2_c1 : k_spectrum_imdct2_c2, dim3(grid), dim3(256), lds_bytes, st,
+                             (const NvhDevSetup*)s->shared->dev_copy.p, (const NvhDevBatch*)b->dev_copy.p, work, flags, cap_pass, cap_ops,
+                             cap_ent NVH_DBG_LAUNCH);
+        } else if (fuse_imdct) {
           // + the IMDCT padding of the last channel (n/16 floats past the spectrum area)
           b->slot_name[1] = "k_spectrum_imdct";
           hipLaunchKernelGGL(k_spectrum_imdct, dim3((unsigned)b->nframes), dim3(256), words * 4 + (size_t)(s->setup.block1 / 16) * 4 + lds_pad,
@@ -485,6 +515,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     if (b->block_only) {
       b->slot_name[3] = "-";  // nvh_mode_decode: the caller wants the windowed blocks themselves
     } else if (compact) {
+      // (frame order by XCD -- blocks f and f-1, which share a quarter, behind the same L2 -- measured slower: 23.3 us, not 21.8)
       // 128 lanes per frame: 21.4 us instead of 24.8 us on its own (more loads in flight per frame); with two batches
       // in flight it is a wash against 64, and 256 lanes start to take wave slots from the other batch's spectrum kernel
       const int ola_env = T.ola_threads;

@@ -186,18 +186,36 @@ __device__ __forceinline__ FloorLane load_floor_lane(const NvhDevSetup& S, const
 //   UnwrapPosts (Floor1.cs:224-297): lane i owns post i; posts of one dependency level are independent.
 //   Apply's walk over the sorted posts (Floor1.cs:196-216): the flagged posts compacted in X order; the walk
 //   stops at the first end point at or beyond n/2, else a flat run to n/2 closes the curve (:213-216).
+//   DUAL: one wavefront, two channels -- lanes 0..31 take channel 0 (scratch Q[0]), lanes 32..63 channel 1 (Q[1]); every
+//   post count involved is <= 32 (the caller checks).  The unwrap is a chain of dependent LDS round trips with at most
+//   `posts` lanes busy, so two channels side by side cost the time of one.
+template <bool DUAL = false>
 __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& L, int lane, int half, int* __restrict__ err,
                                               const uint32_t* __restrict__ recip) {
   const int mode = L.mode, pc = L.pc;
+  const int wlane = lane;  // position in the wavefront (ballot masks)
+  if (DUAL) {
+    Q += lane >> 5;
+    lane &= 31;
+  }
+  const bool on = mode == 1;  // uniform over the wavefront (DUAL: over its half)
   if (lane == 0) Q->mode = mode;
-  if (mode != 1) return;  // wave-uniform
-  if (lane < pc) {
+  if (!DUAL && !on) return;
+  int levels = L.levels;
+  if (DUAL) {
+    const int l0 = __shfl(on ? L.levels : 0, 0), l1 = __shfl(on ? L.levels : 0, 32);
+    levels = l0 > l1 ? l0 : l1;
+    if (levels == 0) return;  // neither channel draws a curve
+  }
+  // the part of a 64-lane ballot that belongs to this lane's channel
+  auto mine = [&](unsigned long long m) -> unsigned long long { return DUAL ? ((m >> (wlane & 32)) & 0xFFFFFFFFull) : m; };
+  if (on && lane < pc) {
     Q->u.fy[lane] = (lane < 2) ? L.val : 0;
     Q->u.step[lane] = (lane < 2) ? 1 : 0;
   }
   sp_wave_sync();
-  for (int lv = 1; lv < L.levels; ++lv) {
-    if (lane >= 2 && lane < pc && L.level == lv) {
+  for (int lv = 1; lv < levels; ++lv) {
+    if (on && lane >= 2 && lane < pc && L.level == lv) {
       // RenderPoint (Floor1.cs:299-314) with the static divisor's reciprocal
       int predicted;
       {
@@ -238,11 +256,11 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
   }
   // compact the flagged posts in X order; the unwrap state is read into registers before the segment view
   // (which shares its storage) is written
-  const bool active = (lane < pc) && Q->u.step[L.sorted] != 0;
-  const int ys = (lane < pc) ? Q->u.fy[L.sorted] * L.mult : 0;
-  const unsigned long long mask = __ballot(active);
+  const bool active = on && (lane < pc) && Q->u.step[L.sorted] != 0;
+  const int ys = (on && lane < pc) ? Q->u.fy[L.sorted] * L.mult : 0;
+  const unsigned long long mask = mine(__ballot(active));
   const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-  const unsigned long long beyond = __ballot(active && rank >= 1 && L.x_sorted >= half);
+  const unsigned long long beyond = mine(__ballot(active && rank >= 1 && L.x_sorted >= half));
   int ns;
   if (beyond) {
     const int fl0 = __ffsll((long long)beyond) - 1;
@@ -250,13 +268,14 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
   } else {
     ns = __popcll(mask);  // trailing flat run to n/2
   }
+  if (!on) ns = 0;
   sp_wave_sync();
   if (active) {
     Q->seg[rank].x_xend = (uint32_t)L.x_sorted;
     Q->seg[rank].y = ys;
   }
   sp_wave_sync();
-  if (lane == 0) {
+  if (on && lane == 0) {
     if (!beyond) {
       Q->seg[ns].x_xend = (uint32_t)half;
       Q->seg[ns].y = Q->seg[ns - 1].y;

@@ -61,3 +61,8 @@ for k in list(np.unique(key))[:3]:
     sel = np.nonzero(key == k)[0]
     o = sel[np.argsort(t[sel])]
     print(" CU", int(k), "blockIdx in start order:", o.tolist())
+im = d[:, 8:13]
+if (im[:, 0] > 0).all():
+    names = ["step 0 (spectrum -> LDS, _a loads)", "radix passes (twiddle loads)", "D = 4, 2, 1", "bit reversal + steps 7, 8 (_c, _b loads) + stores"]
+    print("inverse MDCT of channel 0 (wavefront 0), cycles: " + "; ".join("%s %.0f" % (names[k], (im[:, k + 1] - im[:, k]).mean()) for k in range(4)) +
+          "; total %.0f; barrier -> transform start %.0f" % ((im[:, 4] - im[:, 0]).mean(), (im[:, 0] - d[:, 4]).mean()))

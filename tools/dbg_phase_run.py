@@ -1,12 +1,17 @@
-"""Per-phase wall-clock timestamps of the run kernel (profiling build only):
-   python -m nvorbis_amd.build --debug && NVH_LIB=nvorbis_amd/libnvorbis_hip_dbg.so python tools/dbg_phase_run.py [waves]"""
+"""Per-phase wall-clock timestamps of the frame-loop kernels (profiling build only):
+   python -m nvorbis_amd.build --debug && NVH_LIB=nvorbis_amd/libnvorbis_hip_dbg.so python tools/dbg_phase_run.py [waves | multi]
+   waves = 4 | 6: the run kernel (kernels_run.hip, NVH_RUN=1); multi: k_spectrum_imdct2 (kernels_spectrum2.hip)"""
 import ctypes, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench, nvorbis_amd as nv
-waves = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-os.environ["NVH_RUN_WAVES"] = str(waves)
-os.environ["NVH_RUN"] = "1"
+multi = len(sys.argv) > 1 and sys.argv[1] == "multi"
+waves = 4 if multi else (int(sys.argv[1]) if len(sys.argv) > 1 else 6)
+if multi:
+    os.environ["NVH_MULTI"] = "1"
+else:
+    os.environ["NVH_RUN_WAVES"] = str(waves)
+    os.environ["NVH_RUN"] = "1"
 L = nv.lib(); L.nvh_debug_set_buffer.argtypes = [ctypes.c_void_p]
 headers, ll, ch = bench.ll_packets(nv, os.path.join(bench.ROOT, "tests", "golden", "3test.ogg"))
 ctx = nv.Context(0)
