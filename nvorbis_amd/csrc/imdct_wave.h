@@ -192,7 +192,10 @@ struct Passes<LD, 0> {
 // compile-time constant after unrolling), idx = position of the chunk inside the n-sample block.
 // INPLACE: X may be (part of) the wavefront's own LDS slice `lds` -- the whole spectrum is then read into
 // registers before the first store (n <= 2048: at most 4 float4 per lane).
-template <int LD, bool WIN, typename Sink, bool INPLACE = false>
+// WGSYNC (with INPLACE): the slice may overlay OTHER wavefronts' spectra as well -- a workgroup barrier, not the
+// wavefront's own program order, separates the spectrum loads from the first store (every wavefront of the workgroup
+// passes exactly one __syncthreads; those without a transform of their own call it themselves).
+template <int LD, bool WIN, typename Sink, bool INPLACE = false, bool WGSYNC = false>
 __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __restrict__ w, float* lds,
                                                 const float* __restrict__ A, const float* __restrict__ B,
                                                 const float* __restrict__ C, const float* __restrict__ TW, int lane,
@@ -218,14 +221,14 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
   };
   if constexpr (INPLACE) {
     constexpr int J = (G::n8 + 63) / 64;
-    static_assert(J <= 4, "in-place form keeps the spectrum in registers");
+    static_assert(J <= (WGSYNC ? 8 : 4), "in-place form keeps the spectrum in registers");
     float4 xin[J];
 #pragma unroll
     for (int r = 0; r < J; ++r) {
       const int j = lane + 64 * r;
       xin[r] = reinterpret_cast<const float4*>(X)[j < G::n8 ? j : G::n8 - 1];
     }
-    wave_sync();
+    if constexpr (WGSYNC) __syncthreads(); else wave_sync();
 #pragma unroll
     for (int r = 0; r < J; ++r) {
       const int j = lane + 64 * r;
@@ -571,7 +574,7 @@ __device__ __forceinline__ void imdct_wave_fast(const float* X, const float* __r
 // and are rebuilt, windowed, by k_ola_compact.  Halves the bytes this kernel writes and the next one reads.
 // LEAN: the looped form with the spectrum preloaded (fits 64 VGPRs; X may alias the wavefront's LDS slice) instead
 // of the everything-prefetched form (~100 VGPRs): for callers that bring their own occupancy (kernels_spectrum.hip).
-template <int LD, bool WIN, bool COMPACT = false, bool LEAN = false>
+template <int LD, bool WIN, bool COMPACT = false, bool LEAN = false, bool WGSYNC = false>
 __device__ __forceinline__ void imdct_wave(const float* X, float* out, const float* __restrict__ w, float* lds,
                                            const float* __restrict__ A, const float* __restrict__ B,
                                            const float* __restrict__ C, const float* __restrict__ TW, int lane,
@@ -580,7 +583,7 @@ __device__ __forceinline__ void imdct_wave(const float* X, float* out, const flo
     if (!COMPACT || (slot & 1) == 0) *reinterpret_cast<float4*>(out + idx) = v;
   };
   if constexpr (LEAN)
-    imdct_wave_sink<LD, WIN, decltype(sink), true>(X, w, lds, A, B, C, TW, lane, sink, stamp);
+    imdct_wave_sink<LD, WIN, decltype(sink), true, WGSYNC>(X, w, lds, A, B, C, TW, lane, sink, stamp);
   else if constexpr (LD <= 11)
     imdct_wave_fast<LD, WIN>(X, w, lds, A, B, C, TW, lane, sink);
   else

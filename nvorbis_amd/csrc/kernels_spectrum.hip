@@ -590,6 +590,42 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   }
 
   DBG_T(5);
+  if (IMDCT) {
+    // ---- inverse MDCT behind the general path (k_spectrum_gen8_imdct): one wavefront per channel (NT / 64 >= channels) ----
+    // Every wavefront first takes its channel's whole spectrum into registers; behind the workgroup barrier inside
+    // imdct_wave<.., WGSYNC> the floor scratch, the staged side information and all spectra are dead, and the transforms'
+    // slices (n/2 + n/16 floats each) are laid out back to back from the start of that area.
+    float* slices = smem + 256;
+    const bool mine = wv < nch;
+    if (mine && chans[wv].exec) {
+      const float* X = spec + wv * half;
+      float* out = planes + (long long)wv * S.block1;
+      float* scratch = slices + wv * (half + (fr.n >> 4));
+      const int sl = fr.mdct_slot;
+      const float* A = S.mdct_a[sl];
+      const float* B = S.mdct_b[sl];
+      const float* C = S.mdct_c[sl];
+      const float* TW = S.mdct_tw[sl];
+      switch (fr.n) {
+        case 256: imdct_wave<8, false, true, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+        case 512: imdct_wave<9, false, true, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+        case 1024: imdct_wave<10, false, true, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+        case 2048: imdct_wave<11, false, true, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+        case 4096: imdct_wave<12, false, true, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane); break;
+        default: __builtin_trap();  // the host launches this kernel for block sizes up to 4096 only
+      }
+    } else {
+      if (mine) {
+        // Mapping.cs:192-196: the residue stays in [0, n/2) (k_ola_compact windows it); its tail quarter is zero
+        const float* X = spec + wv * half;
+        float* out = planes + (long long)wv * S.block1;
+        for (int i = lane * 4; i < half; i += 256) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(X + i);
+        for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+      __syncthreads();  // the one barrier every transforming wavefront passes
+    }
+    return;
+  }
   // spectrum -> work planes
   const int q4 = half >> 2;
   for (int i = tid; i < nch * q4; i += NT) {
@@ -631,6 +667,23 @@ k_spectrum_gen8(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __
                 int cap_ent NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   spectrum_body<false, false, false, 512>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem NVH_DBG_ARGS);
+}
+
+// k_spectrum_gen with the inverse MDCT behind it: the fused-tail form for mono / stereo (block sizes 256..2048, as in
+// k_spectrum_imdct), the general form for three and four channels (256..4096).
+extern "C" __global__ void __launch_bounds__(SP_THREADS)
+k_spectrum_gen_imdct(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
+                     int cap_ent NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  spectrum_body<false, false, true>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem NVH_DBG_ARGS);
+}
+
+// k_spectrum_gen8 with the inverse MDCT behind it (block sizes 256..4096, at most 8 channels): writes the compact IMDCT output.
+extern "C" __global__ void __launch_bounds__(512)
+k_spectrum_gen8_imdct(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __restrict__ err, int cap_pass, int cap_ops,
+                      int cap_ent NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  spectrum_body<false, false, true, 512>(S, Bt, work, err, cap_pass, cap_ops, cap_ent, smem NVH_DBG_ARGS);
 }
 
 // Variant for setups that contain a Floor0 (double-precision cos / sqrt / exp: costs registers, kept apart).

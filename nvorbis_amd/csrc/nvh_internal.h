@@ -39,6 +39,8 @@ __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* e
 __global__ void k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_spectrum_gen8(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
+__global__ void k_spectrum_gen_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
+__global__ void k_spectrum_gen8_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
                             int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,

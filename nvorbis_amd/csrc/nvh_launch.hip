@@ -393,6 +393,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers
   const bool fast = s->fast_spectrum && b->links_ok;  // k_spectrum proper (pair path by chain walk, fused tail)
   bool fuse_imdct = compact && fast && s->setup.block1 <= 2048 && !no_fused_imdct;  // and the LDS-resident path is taken (below)
+  bool fuse_gen8 = false;  // k_spectrum_gen8_imdct (below)
   // Fused spectrum kernel when a frame's spectrum (+ staged side information) fits the default 64 KB dynamic
   // LDS window; LDS map in kernels_spectrum.hip.
   {
@@ -423,6 +424,8 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       if (!s->ctx->big_lds_attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_spectrum_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void*)k_spectrum_gen8, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_spectrum_gen8_imdct, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_spectrum_gen_imdct, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         s->ctx->big_lds_attr_set = true;
       }
       lds_limit = 152 * 1024;
@@ -435,12 +438,31 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
         hipLaunchKernelGGL(k_spectrum_f0, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
                            cap_pass, cap_ops, cap_ent);
       } else if (gen8) {
-        b->slot_name[1] = "k_spectrum_gen8";
-        hipLaunchKernelGGL(k_spectrum_gen8, dim3((unsigned)b->nframes), dim3(512), words * 4, st, s->dev, b->dev, work, flags,
-                           cap_pass, cap_ops, cap_ent NVH_DBG_LAUNCH);
+        // the inverse MDCT in the same workgroup (one wavefront per channel, slices laid over the dead floor scratch, side
+        // information and spectra): block sizes the in-register spectrum covers, and the padding has to fit in front of the spectra
+        const size_t front_words = words - (size_t)ch * (size_t)(s->setup.block1 / 2);
+        fuse_gen8 = compact && !no_fused_imdct && ch <= 8 && s->setup.block1 <= 4096 &&
+                    256 + (size_t)ch * (size_t)(s->setup.block1 / 16) <= front_words;
+        b->slot_name[1] = fuse_gen8 ? "k_spectrum_gen8_imdct" : "k_spectrum_gen8";
+        hipLaunchKernelGGL(fuse_gen8 ? k_spectrum_gen8_imdct : k_spectrum_gen8, dim3((unsigned)b->nframes), dim3(512), words * 4, st, s->dev,
+                           b->dev, work, flags, cap_pass, cap_ops, cap_ent NVH_DBG_LAUNCH);
       } else if (!fast) {
-        hipLaunchKernelGGL(k_spectrum_gen, dim3((unsigned)b->nframes), dim3(256), words * 4, st, s->dev, b->dev, work, flags,
-                           cap_pass, cap_ops, cap_ent NVH_DBG_LAUNCH);
+        // the inverse MDCT in the same workgroup where a wavefront per channel exists: mono / stereo setups take the kernel's
+        // fused tail and k_spectrum_imdct's transform (one n/16-float pad behind the spectra), three and four channels the general
+        // tail and the transform of k_spectrum_gen8_imdct (slices over the dead front of the LDS area)
+        size_t extra = 0;
+        if (compact && !no_fused_imdct && ch <= 4) {
+          if (s->dev.fused_tail_ok) {
+            fuse_gen8 = s->setup.block1 <= 2048 && (words + (size_t)(s->setup.block1 / 16)) * 4 <= lds_limit;
+            if (fuse_gen8) extra = (size_t)(s->setup.block1 / 16) * 4;
+          } else {
+            const size_t front_words = words - (size_t)ch * (size_t)(s->setup.block1 / 2);
+            fuse_gen8 = s->setup.block1 <= 4096 && 256 + (size_t)ch * (size_t)(s->setup.block1 / 16) <= front_words;
+          }
+        }
+        if (fuse_gen8) b->slot_name[1] = "k_spectrum_gen_imdct";
+        hipLaunchKernelGGL(fuse_gen8 ? k_spectrum_gen_imdct : k_spectrum_gen, dim3((unsigned)b->nframes), dim3(256), words * 4 + extra, st,
+                           s->dev, b->dev, work, flags, cap_pass, cap_ops, cap_ent NVH_DBG_LAUNCH);
       } else {
         if (T.debug_occ) {
           int nb = -1;
@@ -499,10 +521,10 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
                        carry, carry_out, d_pcm, s->clip, flags + 1, run_len, b->last_decoded);
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));  // slot 2 = fused IMDCT+OLA, slot 3 empty
   } else {
-    b->slot_name[2] = fuse_imdct ? "-" : compact ? "k_imdct_compact" : (s->setup.block0 >= 256 ? "k_imdct_wave" : "k_imdct_window");
+    b->slot_name[2] = (fuse_imdct || fuse_gen8) ? "-" : compact ? "k_imdct_compact" : (s->setup.block0 >= 256 ? "k_imdct_wave" : "k_imdct_window");
     b->slot_name[3] = compact ? "k_ola_compact" : (!b->sequential_ola ? "k_ola_emit" : "k_ola_emit_seq");
-    if (fuse_imdct)
-      ;  // done inside k_spectrum_imdct
+    if (fuse_imdct || fuse_gen8)
+      ;  // done inside k_spectrum_imdct / k_spectrum_gen8_imdct
     else if (compact)
       hipLaunchKernelGGL(k_imdct_compact, dim3((unsigned)(b->nframes * ch)), dim3(64), wave_lds_bytes(s->setup.block1), st, s->dev,
                          b->dev, work);
