@@ -703,10 +703,10 @@ __device__ __forceinline__ float4 compact_value4(const float* __restrict__ plane
 // sample times of every channel and writes them as CH 16-byte stores (its 4*CH interleaved floats are contiguous).
 template <int CH>
 __device__ __forceinline__ int ola_vec(const NvhDevSetup& S, const NvhFrame& fr, const float* cur, const float* prev, bool prev_full,
-                                       const float* __restrict__ w, const float* __restrict__ wp, float* out, int clip, int threads) {
+                                       const float* __restrict__ w, const float* __restrict__ wp, float* out, int clip, int tid, int threads) {
   int clipped = 0;
   const int groups = fr.emit_count >> 2;
-  for (int g = threadIdx.x; g < groups; g += threads) {
+  for (int g = tid; g < groups; g += threads) {
     const int idx0 = fr.emit_start + 4 * g;
     const int j0 = idx0 - fr.start;
     const bool ov = prev && j0 >= 0 && j0 < fr.ov_len;  // whole group inside or outside (all multiples of 4)
@@ -737,7 +737,10 @@ __device__ __forceinline__ int ola_vec(const NvhDevSetup& S, const NvhFrame& fr,
   return clipped;
 }
 
-#define NVH_OLA_THREADS ((int)blockDim.x)
+// A frame may be shared by gridDim.y workgroups (large frames: six channels at n = 4096 are 48 KB of PCM, and 128 lanes
+// per frame leave the CUs with four wavefronts each): lane `OLA_TID` of `NVH_OLA_THREADS`.
+#define NVH_OLA_THREADS ((int)(blockDim.x * gridDim.y))
+#define NVH_OLA_TID ((int)(blockIdx.y * blockDim.x + threadIdx.x))
 extern "C" __global__ void __launch_bounds__(256)
 k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const float* __restrict__ carry,
               float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag, float* __restrict__ carry_out, int last_decoded) {
@@ -747,7 +750,7 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
   if (f == last_decoded && carry_out) {
     // this block becomes the carried tail of the next batch (StreamDecoder's _prevPacketBuf), stored fully windowed
     const float* __restrict__ wl = S.windows + fr.window_off;
-    for (int o = threadIdx.x; o < (fr.n >> 2) * ch; o += NVH_OLA_THREADS) {
+    for (int o = NVH_OLA_TID; o < (fr.n >> 2) * ch; o += NVH_OLA_THREADS) {
       int c = o / (fr.n >> 2), g = o - c * (fr.n >> 2);
       const float* plane = work + ((long long)f * ch + c) * S.block1;
       *reinterpret_cast<float4*>(carry_out + (long long)c * S.block1 + 4 * g) =
@@ -773,20 +776,20 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
                    ((fr.out_pos * ch) & 3) == 0;
   if (vec) {
     switch (ch) {
-      case 1: clipped = ola_vec<1>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
-      case 2: clipped = ola_vec<2>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
-      case 3: clipped = ola_vec<3>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
-      case 4: clipped = ola_vec<4>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
-      case 5: clipped = ola_vec<5>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
-      case 6: clipped = ola_vec<6>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
-      case 7: clipped = ola_vec<7>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
-      default: clipped = ola_vec<8>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_THREADS); break;
+      case 1: clipped = ola_vec<1>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 2: clipped = ola_vec<2>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 3: clipped = ola_vec<3>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 4: clipped = ola_vec<4>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 5: clipped = ola_vec<5>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 6: clipped = ola_vec<6>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 7: clipped = ola_vec<7>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      default: clipped = ola_vec<8>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
     }
     report_clipped(clipped, clipped_flag);
     return;
   }
 
-  for (int o = threadIdx.x; o < total; o += NVH_OLA_THREADS) {
+  for (int o = NVH_OLA_TID; o < total; o += NVH_OLA_THREADS) {
     int t = o / ch, c = o - t * ch;
     int idx = fr.emit_start + t;
     const NvhChan cn = chans[c];

@@ -624,6 +624,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       }
       __syncthreads();  // the one barrier every transforming wavefront passes
     }
+    DBG_T(6);
     return;
   }
   // spectrum -> work planes

@@ -26,6 +26,7 @@ const NvhToggles& nvh_toggles() {
     x.run = on("NVH_RUN");
     x.run_waves = num("NVH_RUN_WAVES");
     x.multi = num("NVH_MULTI");
+    x.ola_segs = num("NVH_OLA_SEGS");
     x.multi_wgs = num("NVH_MULTI_WGS");
     x.phase_mask = std::getenv("NVH_DEBUG_SPECTRUM_MASK") ? num("NVH_DEBUG_SPECTRUM_MASK") : 15;
     return x;

@@ -115,6 +115,7 @@ struct NvhToggles {
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
   bool run;       // NVH_RUN: the run kernel (kernels_run.hip) instead of k_spectrum_imdct + k_ola_compact -- opt-in, it measured slower
   int run_waves;  // NVH_RUN_WAVES = 4 | 6
+  int ola_segs;   // NVH_OLA_SEGS: workgroups per frame in k_ola_compact (default: by frame size)
   int multi;      // NVH_MULTI=1: frame loop (k_spectrum_imdct2) instead of one frame per workgroup (k_spectrum_imdct) -- opt-in, it measured slower
   int multi_wgs;  // NVH_MULTI_WGS: workgroups per CU the frame loop is sized for (default 8)
   int phase_mask;  // debug build only (NVH_DEBUG_SPECTRUM_MASK)

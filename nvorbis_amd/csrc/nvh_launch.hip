@@ -542,7 +542,13 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       // in flight it is a wash against 64, and 256 lanes start to take wave slots from the other batch's spectrum kernel
       const int ola_env = T.ola_threads;
       const int ola_threads = (ola_env == 64 || ola_env == 128 || ola_env == 256) ? ola_env : 128;
-      hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
+      // large frames are shared by several workgroups (kernels.hip): aim at one group of four sample times per lane
+      int segs = T.ola_segs > 0 ? T.ola_segs : (int)(((size_t)s->setup.block1 / 8 * (size_t)ch) / (size_t)(2 * 256));
+      if (segs < 1) segs = 1;
+      if (segs > 8) segs = 8;
+      if (segs > (s->setup.block1 / 8) / ola_threads) segs = (s->setup.block1 / 8) / ola_threads;
+      if (segs < 1) segs = 1;
+      hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
                          (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded);
     } else if (!b->sequential_ola)
       hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
