@@ -106,7 +106,12 @@ namespace NVorbis.Hip
         public bool IsEndOfStream => _ended && _ringPos >= _ringLen;
         public long SamplePosition
         {
-            get { NativeMethods.Check(NativeMethods.nvh_stream_position(_stream, out long pos, out _, out _)); return pos - (_ringLen - _ringPos) / _channels + _skip / _channels; }
+            get
+            {
+                NativeMethods.Check(NativeMethods.nvh_stream_position(_stream, out long pos, out _, out _));
+                NativeMethods.Check(NativeMethods.nvh_stream_pending(_stream, out _, out long pending));   // pushed, not yet synthesised (right after a seek)
+                return pos - pending - (_ringLen - _ringPos) / _channels + _skip / _channels;
+            }
             set => SeekTo(value);
         }
         public TimeSpan TimePosition { get => TimeSpan.FromSeconds((double)SamplePosition / _sampleRate); set => SeekTo(value); }
@@ -207,8 +212,9 @@ namespace NVorbis.Hip
         }
 
         // StreamDecoder.SeekTo (StreamDecoder.cs:552-628).  The page / packet search stays the reference's
-        // (IPacketProvider.SeekTo, Ogg/PacketProvider.cs:56-260, fed by GetPacketGranules below); the decoder side is
-        // ResetDecoder + pre-roll packet + position, and the roll-forward is taken off the front of the next samples.
+        // (IPacketProvider.SeekTo, Ogg/PacketProvider.cs:56-260, fed by GetPacketGranules below; nvh_ogg_seek is the same
+        // search for hosts without the managed container code); the decoder side is ResetDecoder + pre-roll packet + the packet
+        // that holds the target, and the roll-forward is taken off the front of the next samples.
         public void SeekTo(TimeSpan timePosition, System.IO.SeekOrigin seekOrigin = System.IO.SeekOrigin.Begin)
             => SeekTo((long)(SampleRate * timePosition.TotalSeconds), seekOrigin);
 
@@ -229,28 +235,62 @@ namespace NVorbis.Hip
             if (samplePosition == 0) { _packetProvider.SeekTo(0, 0, GetPacketGranules); rollForward = 0; }
             else { var pos = _packetProvider.SeekTo(samplePosition, 1, GetPacketGranules); rollForward = (int)(samplePosition - pos); }
 
+            long oldPosition = SamplePosition;                                      // ResetDecoder leaves _currentPosition alone (:294-305)
             NativeMethods.Check(NativeMethods.nvh_stream_reset(_stream));          // ResetDecoder (:599)
-            _ringPos = _ringLen = 0; _ended = false;
+            _ringPos = _ringLen = 0; _ended = false; _skip = 0;
             _pendingErrors.Clear();
-            // the pre-roll packet: a first packet, emits nothing, only provides the overlap (:602-614)
-            var preRoll = _packetProvider.GetNextPacket();
-            if (preRoll == null)
+            NativeMethods.Check(NativeMethods.nvh_stream_set_position_state(_stream, 1, oldPosition));   // _hasPosition = true (:600)
+            // the pre-roll packet (:603-614): a first packet, emits nothing, only provides the overlap
+            if (!PushOne(out _))
             {
                 _ended = true;
+                NativeMethods.Check(NativeMethods.nvh_stream_drop_pending(_stream));
                 if (_packetProvider.GetGranuleCount() != samplePosition)
                     throw new InvalidOperationException("Could not read pre-roll packet!  Try seeking again prior to reading more samples.");
                 NativeMethods.Check(NativeMethods.nvh_stream_set_position_state(_stream, 1, samplePosition));
                 return;
             }
-            byte[] data = ReadAll(preRoll);
-            fixed (byte* p = data)
-                NativeMethods.Check(NativeMethods.nvh_stream_push_packet(_stream, p, data.Length, -1, 0));
-            NativeMethods.Check(NativeMethods.nvh_stream_pending(_stream, out int frames, out _));
-            if (frames == 0) { _ended = true; throw new InvalidOperationException("Could not read pre-roll packet!  Try seeking again prior to reading more samples."); }
-            // _hasPosition = true (:600); the samples of the packet that follows start at samplePosition - rollForward, and
-            // Read drops rollForward of them (_prevPacketStart += rollForward; _currentPosition = samplePosition, :625-626)
-            NativeMethods.Check(NativeMethods.nvh_stream_set_position_state(_stream, 1, samplePosition - rollForward));
+            // the packet that holds the target (:616-621)
+            if (!PushOne(out long count))
+            {
+                NativeMethods.Check(NativeMethods.nvh_stream_reset(_stream));
+                _ended = true;
+                throw new InvalidOperationException("Could not read pre-roll packet!  Try seeking again prior to reading more samples.");
+            }
+            if (rollForward > count || rollForward < 0)
+            {
+                // _prevPacketStart += rollForward past _prevPacketEnd: the reference's Read never returns (copyLen < 0 with
+                // start != end, :341-377).  Possible on the first data page, where GetIsVorbisBugDiff takes the first packet's
+                // nominal length for the encoder bug (Ogg/PacketProvider.cs:150-172, 224-260).
+                NativeMethods.Check(NativeMethods.nvh_stream_reset(_stream));
+                _ended = true;
+                throw new IndexOutOfRangeException("nvorbis_hip: the managed decoder does not return from the Read that follows this seek");
+            }
+            // _prevPacketStart += rollForward; _currentPosition = samplePosition (:624-626): the pending frame's `count` samples are
+            // ahead of the position, Read drops rollForward of them
             _skip = (long)rollForward * _channels;
+            NativeMethods.Check(NativeMethods.nvh_stream_set_position_state(_stream, 1, samplePosition - rollForward + count));
+        }
+
+        // ReadNextPacket for the provider's next packet: true when it decoded; `emitted` = samples per channel it adds
+        bool PushOne(out long emitted)
+        {
+            emitted = 0;
+            var packet = _packetProvider.GetNextPacket();
+            if (packet == null) { NativeMethods.Check(NativeMethods.nvh_stream_push_end(_stream)); return false; }
+            int flags = (packet.IsEndOfStream ? NativeMethods.NVH_PKT_EOS : 0) | (packet.IsResync ? NativeMethods.NVH_PKT_RESYNC : 0);
+            long granule = packet.GranulePosition ?? -1;
+            byte[] data = ReadAll(packet);
+            NativeMethods.Check(NativeMethods.nvh_stream_pending(_stream, out int f0, out long s0));
+            fixed (byte* p = data)
+                NativeMethods.Check(NativeMethods.nvh_stream_push_packet(_stream, p, data.Length, granule, flags));
+            NativeMethods.Check(NativeMethods.nvh_stream_pending(_stream, out int f1, out long s1));
+            emitted = s1 - s0;
+            if (f1 <= f0) return false;
+            // a rejected packet drains the previous block into a pseudo-frame of block size 0
+            var geo = new int[8 * f1];
+            fixed (int* g = geo) NativeMethods.Check(NativeMethods.nvh_stream_pending_geometry(_stream, g, f1));
+            return geo[8 * (f1 - 1)] != 0;
         }
 
         // StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647), computed natively from the packet's first bits

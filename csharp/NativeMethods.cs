@@ -71,6 +71,15 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern int nvh_stream_mode_info(IntPtr stream, int modeIndex, out int blockFlag, out int blockSize, out int mapping);
         [DllImport(Lib)] public static extern int nvh_stream_floor_info(IntPtr stream, int floorIndex, out int type, out int postCount, out int range);
         [DllImport(Lib)] public static extern int nvh_stream_pending(IntPtr stream, out int frames, out long samplesPerChannel);
+        /// <summary>[frames][8] ints: block size (0 = drained tail), start, valid, total, ... of every pending frame.</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_pending_geometry(IntPtr stream, int* geometry, int capFrames);
+        /// <summary>Page table of one logical Ogg stream + IPacketProvider.SeekTo over it (Ogg/PacketProvider.cs:56-295), for hosts
+        /// that do not bring NVorbis' own container code.</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_ogg_index_open(byte* bytes, UIntPtr len, int streamIndex, out IntPtr index);
+        [DllImport(Lib)] public static extern void nvh_ogg_index_close(IntPtr index);
+        [DllImport(Lib)] public static extern int nvh_ogg_index_info(IntPtr index, out int pages, out int packets, out int firstDataPage, out long maxGranule, out int hasAllPages);
+        [DllImport(Lib)] public static extern int nvh_ogg_index_page(IntPtr index, int page, out long granule, out int flags, out int packetCount, out int firstPacket);
+        [DllImport(Lib)] public static extern int nvh_ogg_seek(IntPtr index, IntPtr stream, long granulePos, int preRoll, out long packetIndex, out long granuleOut);
         /// <summary>IStreamDecoder.UpperBitrate / NominalBitrate / LowerBitrate (StreamDecoder.cs:191-199).</summary>
         [DllImport(Lib)] public static extern int nvh_stream_bitrates(IntPtr stream, out int upper, out int nominal, out int lower);
         /// <summary>Packets of the last synthesised batch that made the parser fail (GPU-parse mode), with their positions in its PCM.</summary>

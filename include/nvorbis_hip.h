@@ -268,6 +268,30 @@ int nvh_ogg_demux_stream(const uint8_t *bytes, size_t len, int stream_index, uin
                          int64_t *offsets, int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets,
                          int64_t *total_bytes, int *nstreams);
 
+
+/* ---- seeking ----
+ * Page table of one logical stream plus the reference's seek search over it:
+ *   StreamPageReader.FindPage / FindPageBisection / FindPageForward   Ogg/StreamPageReader.cs:122-264
+ *   PacketProvider.SeekTo / FindPacket / granule-bug workaround        Ogg/PacketProvider.cs:56-260
+ *   PacketProvider.NormalizePacketIndex                                 Ogg/PacketProvider.cs:262-295
+ * in the state the reference's reader is in once it has read every page of the stream.  The index copies what it needs;
+ * `bytes` may be released after nvh_ogg_index_open returns. */
+typedef struct nvh_ogg_index nvh_ogg_index;
+int nvh_ogg_index_open(const uint8_t *bytes, size_t len, int stream_index, nvh_ogg_index **out);
+void nvh_ogg_index_close(nvh_ogg_index *ix);
+/* pages and packets of the stream, StreamPageReader.FirstDataPageIndex (-1: none), MaxGranulePosition, HasAllPages */
+int nvh_ogg_index_info(const nvh_ogg_index *ix, int *npages, int *npackets, int *first_data_page, int64_t *max_granule,
+                       int *has_all_pages);
+/* StreamPageReader.GetPage (Ogg/StreamPageReader.cs:292-377): granule position, flags (1 resync, 2 continuation, 4 continued),
+ * packet count, and the index (in nvh_ogg_demux_stream's packet list) of the first packet that starts on the page (-1: none) */
+int nvh_ogg_index_page(const nvh_ogg_index *ix, int page, int64_t *granule, int *flags, int *packet_count, int *first_packet);
+/* IPacketProvider.SeekTo(granulePos, preRoll, getPacketGranuleCount) (Ogg/PacketProvider.cs:56-72) with the stream's
+ * StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647) as the callback: *packet_index = position in the packet list of the
+ * packet GetNextPacket returns next, *granule_out = the method's return value.  NVH_ERR_ARGUMENT where the reference throws
+ * ArgumentOutOfRangeException, NVH_ERR_INVALID_DATA for its InvalidDataExceptions, NVH_ERR_RUNTIME for an index fault. */
+int nvh_ogg_seek(const nvh_ogg_index *ix, const nvh_stream *s, int64_t granule_pos, int pre_roll, int64_t *packet_index,
+                 int64_t *granule_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,10 @@
 //   continued packets; the granule position goes to the packet that is last on the page it completes
 //   on; end-of-stream to that packet of the EOS-flagged page    Ogg/PacketProvider.cs:324-438
 //   multiplexed / chained files: pages are routed by serial number to logical streams                Ogg/PageReader.cs:126-158
-// The page-level seek search and the libvorbis granule workaround are not implemented.
+// Seeking: the page table ogg_demux can return and ogg_seek below restate
+//   StreamPageReader.FindPage / FindPageBisection / FindPageForward     Ogg/StreamPageReader.cs:122-264
+//   PacketProvider.SeekTo, FindPacket, the libvorbis granule workaround  Ogg/PacketProvider.cs:56-260
+//   PacketProvider.NormalizePacketIndex                                   Ogg/PacketProvider.cs:262-295
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -53,7 +56,7 @@ bool page_crc_ok(const uint8_t* pg, size_t total) {
 }  // namespace
 
 
-int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index, int* nstreams) {
+int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index, int* nstreams, bool want_pages) {
   // Logical streams in the order their first page appears (Ogg/PageReader.cs:126-158): a page with a serial number that
   // has no reader opens a new stream (multiplexed streams interleave their pages, chained streams follow one another);
   // the end-of-stream page retires the serial, so a later page with the same number starts another stream; a page
@@ -66,6 +69,7 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
     int32_t last_seq = 0;
     bool have_first_data_page = false;
     int64_t max_granule = 0;
+    int first_data_page = -1;
   };
   std::vector<Logical> streams;
   std::vector<std::pair<uint32_t, int>> active;  // serial -> index into streams
@@ -143,7 +147,10 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
           // that does not follow the previous one ("out of order page / sequence jump, we're counting it as a resync").
           const int32_t seq = (int32_t)((uint32_t)h[18] | ((uint32_t)h[19] << 8) | ((uint32_t)h[20] << 16) | ((uint32_t)h[21] << 24));
           if (pg.granule != -1) {
-            if (!lg.have_first_data_page && pg.granule > 0) lg.have_first_data_page = true;
+            if (!lg.have_first_data_page && pg.granule > 0) {
+              lg.have_first_data_page = true;
+              lg.first_data_page = (int)lg.pages.size();
+            }
             else if (lg.max_granule > pg.granule) return NVH_ERR_INVALID_DATA;  // "Granule Position regressed?!"
             lg.max_granule = pg.granule;
           } else if (lg.have_first_data_page && (!pg.continued || pg.pk_off.size() != 1)) {
@@ -174,6 +181,30 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
   }
   const std::vector<Page>& pages = streams[(size_t)stream_index].pages;
   const bool has_all_pages = streams[(size_t)stream_index].has_all_pages;
+  out.pages.clear();
+  out.first_data_page = streams[(size_t)stream_index].first_data_page;
+  out.has_all_pages = has_all_pages;
+  out.max_granule = streams[(size_t)stream_index].max_granule;
+  if (want_pages) {
+    out.pages.resize(pages.size());
+    for (size_t i = 0; i < pages.size(); i++) {
+      const Page& pg = pages[i];
+      OggPageInfo& pi = out.pages[i];
+      pi.granule = pg.granule;
+      pi.resync = pg.resync;
+      pi.continuation = (pg.flags & 0x01) != 0;
+      pi.continued = pg.continued;
+      pi.packet_count = (int)pg.pk_off.size();
+      pi.flat.assign(pg.pk_off.size(), -1);
+      pi.len.resize(pg.pk_off.size());
+      pi.head.assign(pg.pk_off.size() * 8, 0);
+      for (size_t k = 0; k < pg.pk_off.size(); k++) {
+        pi.len[k] = pg.pk_len[k];
+        const int nb = pg.pk_len[k] < 8 ? pg.pk_len[k] : 8;
+        std::memcpy(&pi.head[k * 8], bytes + pg.data_off + pg.pk_off[k], (size_t)nb);
+      }
+    }
+  }
 
   out.bytes.clear();
   out.offs.clear();
@@ -225,6 +256,7 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
       gr = granule_pos < 0 ? -1 : granule_pos;
       if (has_all_pages && final_page == npages - 1) fl |= 1;
     }
+    if (want_pages) out.pages[(size_t)page_index].flat[(size_t)packet_index] = (int32_t)out.granule.size();
     out.offs.push_back((int64_t)mark);
     out.granule.push_back(gr);
     out.flags.push_back(fl);
@@ -240,6 +272,217 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
     }
   }
   out.offs.push_back((int64_t)out.bytes.size());
+  return NVH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// seek search
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct SeekCtx {
+  const OggPackets& ix;
+  OggGranuleCount count;
+  void* user;
+  int npages() const { return (int)ix.pages.size(); }
+};
+
+// What PacketProvider.CreatePacket(.., advance: false, ..) (Ogg/PacketProvider.cs:324-400) leaves of a packet as far as
+// GetPacketGranules is concerned: its first bytes (the slot's fragment, then the slot-0 fragments of the pages the
+// continuation walk adds) and the IsResync flag the walk ends with.  false = the method returns null.
+bool create_packet(const SeekCtx& c, int page_index, int packet_index, bool is_resync, bool is_continued, int packet_count,
+                   uint8_t head[8], int* head_len, bool* resync_out, int* fault) {
+  const OggPageInfo& pg = c.ix.pages[(size_t)page_index];
+  if (packet_index < 0 || packet_index >= pg.packet_count) {  // GetPagePackets(pageIndex)[packetIndex]
+    *fault = NVH_ERR_RUNTIME;
+    return false;
+  }
+  int n = pg.len[(size_t)packet_index] < 8 ? pg.len[(size_t)packet_index] : 8;
+  std::memcpy(head, &pg.head[(size_t)packet_index * 8], (size_t)n);
+  if (is_continued && packet_index == packet_count - 1) {
+    int cont = page_index;
+    while (is_continued) {
+      if (++cont >= c.npages()) return false;  // "no more pages?  In any case, we can't satisfy the request"
+      const OggPageInfo& np = c.ix.pages[(size_t)cont];
+      is_resync = np.resync;
+      is_continued = np.continued;
+      packet_count = np.packet_count;
+      if (!np.continuation || is_resync) break;
+      if (is_continued && packet_count > 1) is_continued = false;
+      const int more = np.len[0] < 8 - n ? np.len[0] : 8 - n;
+      if (more > 0) {
+        std::memcpy(head + n, &np.head[0], (size_t)more);
+        n += more;
+      }
+    }
+  }
+  *head_len = n;
+  *resync_out = is_resync;
+  return true;
+}
+
+// Ogg/PacketProvider.cs:224-260
+bool is_vorbis_bug_diff(int64_t diff) {
+  if (diff < 0) diff = -diff;
+  int64_t temp = diff;
+  int short_bits = 0;
+  while (temp > 0 && (temp & 1) == 0) {
+    ++short_bits;
+    temp >>= 1;
+  }
+  int long_bits = short_bits;
+  while ((temp & 1) == 1) {
+    ++long_bits;
+    temp >>= 1;
+  }
+  return temp == 0 && diff == ((int64_t)1 << long_bits) - ((int64_t)1 << short_bits);  // (1 << n): 32-bit in the reference, n < 31 here
+}
+
+// StreamPageReader.FindPage with every page already read (Ogg/StreamPageReader.cs:122-264); -1 = ArgumentOutOfRangeException
+int find_page(const SeekCtx& c, int64_t granule_pos) {
+  const int n = c.npages();
+  if (granule_pos == 0) return c.ix.first_data_page;
+  int page_index = -1;
+  const int last = n - 1;
+  if (last < 0) return -1;
+  const int64_t last_gp = c.ix.pages[(size_t)last].granule;
+  if (granule_pos < last_gp) {
+    // FindPageBisection(granulePos, FindFirstDataPage(), lastPageIndex, pageGP) (:232-264)
+    int low = c.ix.first_data_page, high = last;
+    int64_t low_gp = 0, high_gp = last_gp;
+    int dist;
+    while ((dist = high - low) > 0) {
+      const int index = low + (int)((double)dist * ((double)(granule_pos - low_gp) / (double)(high_gp - low_gp)));
+      if (index < 0 || index >= n) return -2;  // _pageOffsets[index] faults (a stream without a data page: low == -1)
+      const int64_t idx_gp = c.ix.pages[(size_t)index].granule;
+      if (idx_gp > granule_pos) {
+        high = index;
+        high_gp = idx_gp;
+      } else if (idx_gp < granule_pos) {
+        low = index + 1;
+        low_gp = idx_gp + 1;
+      } else {
+        return index + 1;
+      }
+    }
+    page_index = low;
+  } else if (granule_pos > last_gp) {
+    // FindPageForward (:171-199): no page is left to read, so the walk ends at once; the reader then knows it has all
+    // pages (GetNextPageGranulePos, :201-230) and MaxGranulePosition < granulePos decides
+    page_index = last + 1;
+    if (c.ix.max_granule < granule_pos) page_index = -1;
+  } else {
+    page_index = last + 1;
+  }
+  return page_index;
+}
+
+}  // namespace
+
+int ogg_seek(const OggPackets& ix, OggGranuleCount granule_count, void* user, int64_t granule_pos, int pre_roll, int64_t* packet,
+             int64_t* granule_out) {
+  const SeekCtx c{ix, granule_count, user};
+  const int n = c.npages();
+  int fault = NVH_OK;
+  int page_index = find_page(c, granule_pos);
+  if (page_index == -2) return NVH_ERR_RUNTIME;
+  if (page_index == -1) return NVH_ERR_ARGUMENT;  // ArgumentOutOfRangeException(nameof(granulePos)) (:157-160)
+
+  // ---- FindPacket(pageIndex, preRoll, ref granulePos, ..) (Ogg/PacketProvider.cs:204-222) ----
+  // GetPreviousPageInfo (:74-108)
+  int64_t last_page_gp = 0;
+  int last_page_packet_length = 0, first_real_packet = 0;
+  if (page_index > 0) {
+    if (page_index - 1 >= n) return NVH_ERR_INVALID_DATA;  // "Could not get preceding page?!"
+    const OggPageInfo& prev = ix.pages[(size_t)(page_index - 1)];
+    last_page_gp = prev.granule;
+    if (page_index > ix.first_data_page) {
+      uint8_t head[8];
+      int hl = 0;
+      bool rs = false;
+      // the last slot of the previous page: "either a continued packet OR the last packet of the last page"
+      if (!create_packet(c, page_index - 1, prev.packet_count - 1, false, prev.continued, prev.packet_count, head, &hl, &rs, &fault))
+        return fault != NVH_OK ? fault : NVH_ERR_INVALID_DATA;  // "Could not find end of continuation!"
+      last_page_packet_length = granule_count(user, head, hl, rs);
+    }
+    first_real_packet = prev.continued ? 1 : 0;
+  }
+  // GetTargetPageInfo (:110-146)
+  if (page_index < 0 || page_index >= n) return NVH_ERR_INVALID_DATA;  // "Could not get found page?!"
+  const OggPageInfo& pg = ix.pages[(size_t)page_index];
+  int packet_count = pg.packet_count;
+  if (pg.continued) packet_count--;  // "if continued, the last packet index doesn't apply"
+  std::vector<int64_t> gps((size_t)(packet_count > 0 ? packet_count : 0));
+  int64_t end_gp = pg.granule;
+  for (int i = packet_count - 1; i >= first_real_packet; i--) {
+    gps[(size_t)i] = end_gp;
+    uint8_t head[8];
+    int hl = 0;
+    bool rs = false;
+    // (the reduced packet count and the page's continued flag go in as they are: the last complete packet of a continued page
+    // is walked as if it were the continued one, and takes its resync flag from the next page)
+    if (!create_packet(c, page_index, i, i == 0 && pg.resync, pg.continued, packet_count, head, &hl, &rs, &fault))
+      return fault != NVH_OK ? fault : NVH_ERR_INVALID_DATA;  // "Could not find end of continuation!"
+    end_gp -= granule_count(user, head, hl, rs);
+  }
+  if (first_real_packet == 1) {
+    if (gps.empty()) return NVH_ERR_RUNTIME;  // gps[0] of an empty array
+    gps[0] = end_gp;
+    end_gp -= last_page_packet_length;
+  }
+  // FindPacket(pageIndex, gps, endGP, lastPageGranulePos, lastPagePacketLength, ref granulePos) (:148-202)
+  int packet_index = -2;
+  if (end_gp != last_page_gp) {
+    const int64_t diff = end_gp - last_page_gp;
+    if (is_vorbis_bug_diff(diff)) {
+      if (diff > 0) {
+        // the last packet of the previous page is a long block libvorbis mis-counted
+        if (granule_pos <= end_gp) {
+          granule_pos = end_gp - last_page_packet_length;
+          packet_index = -1;
+        }
+      } else {
+        for (int64_t& g : gps) g -= diff;  // "our pageGranulePos is wrong, so adjust everything"
+      }
+    } else if (page_index > ix.first_data_page) {
+      return NVH_ERR_INVALID_DATA;  // "GranulePos mismatch"
+    }
+  }
+  if (packet_index == -2) {
+    for (size_t i = 0; i < gps.size(); i++) {
+      if (gps[i] >= granule_pos) {
+        granule_pos = i == 0 ? end_gp : gps[i - 1];
+        packet_index = (int)i;
+        break;
+      }
+    }
+    if (packet_index == -2) return NVH_ERR_INVALID_DATA;  // "Could not find seek packet?!"
+  }
+  // the pre-roll, "but only if we're not seeking into the first packet, which is its own preRoll" (:216-220)
+  if (end_gp > 0 || packet_index > 1) packet_index -= pre_roll;
+
+  // ---- NormalizePacketIndex (:262-295): false = ArgumentOutOfRangeException (:63-66) ----
+  {
+    bool is_resync = pg.resync, is_continuation = pg.continuation;
+    int pg_idx = page_index, pkt_idx = packet_index;
+    while (pkt_idx < (is_continuation ? 1 : 0)) {
+      if (is_continuation && is_resync) return NVH_ERR_ARGUMENT;  // can't merge across resync
+      const bool was_continuation = is_continuation;
+      if (--pg_idx < 0) return NVH_ERR_ARGUMENT;
+      const OggPageInfo& pp = ix.pages[(size_t)pg_idx];
+      is_resync = pp.resync;
+      is_continuation = pp.continuation;
+      if (was_continuation && !pp.continued) return NVH_ERR_ARGUMENT;  // continuation flags do not match
+      pkt_idx += pp.packet_count - (was_continuation ? 1 : 0);
+    }
+    page_index = pg_idx;
+    packet_index = pkt_idx;
+  }
+  // (page, packet) -> position in the demuxed list; a slot no packet starts at makes GetNextPacket fault or stitch garbage
+  const OggPageInfo& fin = ix.pages[(size_t)page_index];
+  if (packet_index >= fin.packet_count || fin.flat[(size_t)packet_index] < 0) return NVH_ERR_RUNTIME;
+  *packet = fin.flat[(size_t)packet_index];
+  *granule_out = granule_pos;
   return NVH_OK;
 }
 

@@ -6,14 +6,43 @@
 
 namespace nvh {
 
+// One page of the logical stream as StreamPageReader.GetPage reports it (Ogg/StreamPageReader.cs:292-377), plus what the
+// seek search needs of its packet slots.
+struct OggPageInfo {
+  int64_t granule = 0;       // raw header value, -1 on a page that completes no packet
+  bool resync = false;       // lost page sync or sequence-number jump (Ogg/StreamPageReader.cs:77-86)
+  bool continuation = false; // header flag "continues a packet"
+  bool continued = false;    // last lacing value 255
+  int packet_count = 0;      // slots (a continuation tail counts as slot 0)
+  std::vector<int32_t> flat; // per slot: index of the packet of the demuxed list that STARTS there, or -1
+  std::vector<uint8_t> head; // per slot: its first (up to) 8 bytes, 8 per slot
+  std::vector<int32_t> len;  // per slot: byte length of the fragment on this page
+};
+
 struct OggPackets {
   std::vector<uint8_t> bytes;
   std::vector<int64_t> offs;      // n + 1 byte offsets
   std::vector<int64_t> granule;   // -1 = packet carries no granule position
   std::vector<uint8_t> flags;     // NVH_PKT_EOS | NVH_PKT_RESYNC
+  // page table (filled when ogg_demux is asked for it)
+  std::vector<OggPageInfo> pages;
+  int first_data_page = -1;       // StreamPageReader._firstDataPageIndex: first page with a granule position > 0
+  bool has_all_pages = false;     // the end-of-stream page was seen
+  int64_t max_granule = 0;        // StreamPageReader._maxGranulePos
 };
 
 // Packets of logical stream `stream_index` (0 = the first one whose page appears); *nstreams = how many there are.
-int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index = 0, int* nstreams = nullptr);
+int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index = 0, int* nstreams = nullptr, bool want_pages = false);
+
+// PacketProvider.SeekTo (Ogg/PacketProvider.cs:56-72) over a demuxed stream with its page table, in the state the reference's
+// reader is in once it has seen every page: the page search (StreamPageReader.FindPage, Ogg/StreamPageReader.cs:122-264), the
+// packet search with the libvorbis granule workaround (Ogg/PacketProvider.cs:74-260) and NormalizePacketIndex (:262-295).
+// granule_count(head bytes, length, is_resync) is StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647).
+// *packet = index into the demuxed packet list of the packet GetNextPacket returns next; *granule_out = the returned position.
+// NVH_ERR_ARGUMENT = ArgumentOutOfRangeException, NVH_ERR_INVALID_DATA = InvalidDataException, NVH_ERR_RUNTIME = an index
+// fault of the managed code.
+typedef int (*OggGranuleCount)(void* user, const uint8_t* head, int len, bool is_resync);
+int ogg_seek(const OggPackets& ix, OggGranuleCount granule_count, void* user, int64_t granule_pos, int pre_roll, int64_t* packet,
+             int64_t* granule_out);
 
 }  // namespace nvh

@@ -694,3 +694,74 @@ extern "C" int nvh_ogg_demux(const uint8_t* bytes, size_t len, uint8_t* pkt_byte
     return nvh_ogg_demux_stream(bytes, len, 0, pkt_bytes, pkt_bytes_cap, offsets, granules, flags, pkt_cap, npackets, total_bytes, nullptr);
   });
 }
+
+// ------------------------------------------------------------------------------------------------
+// seeking: page table + PacketProvider.SeekTo (host_ogg.cpp)
+// ------------------------------------------------------------------------------------------------
+struct nvh_ogg_index {
+  nvh::OggPackets pk;
+};
+
+extern "C" int nvh_ogg_index_open(const uint8_t* bytes, size_t len, int stream_index, nvh_ogg_index** out) {
+  return nvh_guard([&]() -> int {
+    if (!bytes || !out || stream_index < 0) return NVH_ERR_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<nvh_ogg_index> ix(new (std::nothrow) nvh_ogg_index());
+    if (!ix) return NVH_ERR_NOMEM;
+    int rc = nvh::ogg_demux(bytes, len, ix->pk, stream_index, nullptr, true);
+    if (rc != NVH_OK) return rc;
+    ix->pk.bytes.clear();  // the seek search works on the page table alone
+    ix->pk.bytes.shrink_to_fit();
+    *out = ix.release();
+    return NVH_OK;
+  });
+}
+
+extern "C" void nvh_ogg_index_close(nvh_ogg_index* ix) {
+  nvh_guard_void([&]() { delete ix; });
+}
+
+extern "C" int nvh_ogg_index_info(const nvh_ogg_index* ix, int* npages, int* npackets, int* first_data_page, int64_t* max_granule,
+                                  int* has_all_pages) {
+  return nvh_guard([&]() -> int {
+    if (!ix) return NVH_ERR_ARGUMENT;
+    if (npages) *npages = (int)ix->pk.pages.size();
+    if (npackets) *npackets = (int)ix->pk.granule.size();
+    if (first_data_page) *first_data_page = ix->pk.first_data_page;
+    if (max_granule) *max_granule = ix->pk.max_granule;
+    if (has_all_pages) *has_all_pages = ix->pk.has_all_pages ? 1 : 0;
+    return NVH_OK;
+  });
+}
+
+extern "C" int nvh_ogg_index_page(const nvh_ogg_index* ix, int page, int64_t* granule, int* flags, int* packet_count, int* first_packet) {
+  return nvh_guard([&]() -> int {
+    if (!ix || page < 0 || page >= (int)ix->pk.pages.size()) return NVH_ERR_ARGUMENT;
+    const nvh::OggPageInfo& pg = ix->pk.pages[(size_t)page];
+    if (granule) *granule = pg.granule;
+    if (flags) *flags = (pg.resync ? 1 : 0) | (pg.continuation ? 2 : 0) | (pg.continued ? 4 : 0);
+    if (packet_count) *packet_count = pg.packet_count;
+    if (first_packet) {
+      *first_packet = -1;
+      for (int32_t f : pg.flat)
+        if (f >= 0) {
+          *first_packet = f;
+          break;
+        }
+    }
+    return NVH_OK;
+  });
+}
+
+extern "C" int nvh_ogg_seek(const nvh_ogg_index* ix, const nvh_stream* s, int64_t granule_pos, int pre_roll, int64_t* packet_index,
+                            int64_t* granule_out) {
+  return nvh_guard([&]() -> int {
+    if (!ix || !s || !packet_index || !granule_out) return NVH_ERR_ARGUMENT;
+    auto count = [](void* user, const uint8_t* head, int len, bool is_resync) -> int {
+      int n = 0;
+      (void)nvh_stream_packet_sample_count((const nvh_stream*)user, head, len, is_resync ? 1 : 0, &n);
+      return n;
+    };
+    return nvh::ogg_seek(ix->pk, count, (void*)s, granule_pos, pre_roll, packet_index, granule_out);
+  });
+}

@@ -474,7 +474,8 @@ class StreamDecoder:
     @property
     def SamplePosition(self):
         pos, _, _ = self._stream.position()
-        return pos - (self._ring.size - self._ring_pos) // self.Channels + self._skip // self.Channels
+        pending = self._stream.pending()[1]  # pushed, not yet synthesised (only right after a seek)
+        return pos - pending - (self._ring.size - self._ring_pos) // self.Channels + self._skip // self.Channels
 
     def _refill(self):
         """Parse up to batch_frames packets ahead and synthesise them."""
@@ -596,16 +597,71 @@ class StreamDecoder:
     def TotalTime(self):
         return self.TotalSamples / float(self.SampleRate)
 
-    def SeekTo(self, sample_position, origin="begin"):
-        """StreamDecoder.SeekTo(long, SeekOrigin) (StreamDecoder.cs:562-628): the next Read returns the samples from
-        `sample_position` on -- the same floats a decode from the start yields there.  As in the reference the decoder
-        restarts one packet early (that packet's own output is discarded, it only provides the overlap) and rolls
-        forward inside the packet that holds the target.  origin: "begin", "current" (SamplePosition - value, as the
-        reference computes it), "end" (TotalSamples - value).  IndexError = ArgumentOutOfRangeException.
+    def attach_ogg(self, data, stream_index=0):
+        """The container the packet list came from: SeekTo then runs the reference's page-level search (nvh_ogg_seek) instead
+        of the sample-count index a bare packet list allows."""
+        self._ogg = (data, int(stream_index))
+        self._ogg_index = None
 
-        Not mirrored: the reference's page-granule corner cases (its treatment of the first two packets of a stream and
-        the workaround for a mis-counting encoder, Ogg/PacketProvider.cs:148-222); positions here follow the sample
-        counts a serial decode produces."""
+    def _provider_seek(self, granule_pos, pre_roll):
+        """IPacketProvider.SeekTo(granulePos, preRoll, GetPacketGranules) -> (index into the packet list of the packet the
+        provider returns next, the granule position the method returns).
+
+        With the Ogg file at hand this is Ogg/PacketProvider.cs:56-72 as the reference runs it once it has read every page:
+        page search (Ogg/StreamPageReader.cs:122-264), packet search with the libvorbis granule workaround
+        (Ogg/PacketProvider.cs:74-260), NormalizePacketIndex (:262-295) -- including what that does on the first data page,
+        where the first packet's nominal length looks like the encoder bug to GetIsVorbisBugDiff (:224-260) and every
+        position of the page moves by it.  A bare packet list has no pages: positions then follow the sample counts a serial
+        decode produces."""
+        if getattr(self, "_ogg", None) is not None:
+            L = lib()
+            if self._ogg_index is None:
+                data, k = self._ogg
+                buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+                h = C.c_void_p()
+                check(L.nvh_ogg_index_open(buf, len(data), k, C.byref(h)), "nvh_ogg_index_open")
+                self._ogg_index = h
+            pk, gp = C.c_int64(0), C.c_int64(0)
+            rc = L.nvh_ogg_seek(self._ogg_index, self._stream._h, int(granule_pos), int(pre_roll), C.byref(pk), C.byref(gp))
+            if rc == native.ERR_ARGUMENT:
+                raise IndexError("granulePos")  # ArgumentOutOfRangeException
+            check(rc, "nvh_ogg_seek")
+            return int(pk.value), int(gp.value)
+        gp, state, end_pos = self._granule_index()
+        s = int(granule_pos)
+        if gp.size == 0:
+            raise IndexError("granulePos")
+        if s == 0 or s == int(gp[0]):
+            return 3, (0 if s == 0 else int(gp[0]))
+        if s < int(gp[0]) or s > end_pos:
+            raise IndexError("granulePos")
+        j = int(np.searchsorted(gp, s, side="left"))  # first packet whose samples reach position s
+        if j >= gp.size:
+            j = gp.size - 1  # inside the drained tail of the last block
+            while j > 0 and gp[j - 1] >= s:
+                j -= 1
+        return 3 + j - pre_roll, int(gp[j - 1])
+
+    def _push_one(self, i):
+        """ReadNextPacket for packet i of the list: True when it decoded (a frame is pending), with its emitted samples."""
+        if i >= len(self._packets):
+            self._stream.push_end()
+            return False, 0
+        f0, s0 = self._stream.pending()
+        self._stream.push_packet(self._packets[i], self._granules[i], self._flags[i])
+        f1, s1 = self._stream.pending()
+        decoded = f1 > f0 and int(self._stream.pending_geometry()[-1][0]) != 0  # (a rejected packet drains the previous block: n = 0)
+        return decoded, s1 - s0
+
+    def SeekTo(self, sample_position, origin="begin"):
+        """StreamDecoder.SeekTo(long, SeekOrigin) (StreamDecoder.cs:562-628): position the provider one packet early
+        (:593-598), ResetDecoder, read the pre-roll packet and the packet that holds the target (:603-621), roll forward
+        inside it (:624-625).  origin: "begin", "current" (SamplePosition - value, as the reference computes it), "end"
+        (TotalSamples - value).  IndexError = ArgumentOutOfRangeException, RuntimeError = InvalidOperationException.
+
+        One place cannot be mirrored: when the roll-forward is longer than the packet's output (possible on the first data
+        page, see _provider_seek) the reference's next Read never returns (copyLen < 0 with start != end,
+        StreamDecoder.cs:341-377); this raises NvhError(ERR_RUNTIME) instead."""
         s = int(sample_position)
         if origin == "current":
             s = self.SamplePosition - s
@@ -615,34 +671,49 @@ class StreamDecoder:
             raise IndexError("origin")
         if s < 0:
             raise IndexError("samplePosition")
-        gp, state, end_pos = self._granule_index()
-        if gp.size == 0:
-            raise IndexError("samplePosition")
-        if s == 0 or s == int(gp[0]):
-            j, lead, roll, start_pos = 0, None, 0, (0 if s == 0 else int(gp[0]))
+        old_pos = self.SamplePosition  # ResetDecoder leaves _currentPosition alone (StreamDecoder.cs:294-305)
+        if s == 0:
+            k, _ = self._provider_seek(0, 0)  # "short circuit for the looping case" (:587-592)
+            roll = 0
+            pos = 0
         else:
-            if s < int(gp[0]) or s > end_pos:
-                raise IndexError("samplePosition")
-            j = int(np.searchsorted(gp, s, side="left"))  # first packet whose samples reach position s
-            if j >= gp.size:
-                j = gp.size - 1  # inside the drained tail of the last block
-                while j > 0 and gp[j - 1] >= s:
-                    j -= 1
-            lead = j - 1
-            if not (state[lead] & 1):
-                raise RuntimeError("Could not read pre-roll packet!")  # InvalidOperationException
-            roll, start_pos = s - int(gp[lead]), int(gp[lead])
-        self._stream.reset()  # ResetDecoder (:599)
-        if lead is not None:
-            self._stream.push_packet(self._packets[3 + lead], -1, 0)  # pre-roll: emits nothing (StreamDecoder.cs:446-450)
-        self._stream.set_position_state(True, start_pos)  # _hasPosition = true (:600); _currentPosition ends up at s
-        self._next = 3 + j
+            k, pos = self._provider_seek(s, 1)
+            roll = s - pos
+        self._stream.reset()
         self._ring = np.zeros(0, dtype=np.float32)
         self._ring_pos = 0
+        self._pending_errors = []
         self._ended = False
+        self._skip = 0
+        self._stream.set_position_state(True, old_pos)  # _hasPosition = true (:600)
+        ok, _ = self._push_one(k)
+        self._next = k + 1
+        if not ok:
+            self._ended = True  # _eosFound: "we'll use this to force ReadSamples to fail to read"
+            self._stream.drop_pending()
+            if self.TotalSamples != s:
+                raise RuntimeError("Could not read pre-roll packet!  Try seeking again prior to reading more samples.")
+            self._stream.set_position_state(True, s)
+            return
+        ok, count = self._push_one(k + 1)
+        self._next = k + 2
+        if not ok:
+            self._stream.reset()
+            self._ended = True
+            raise RuntimeError("Could not read pre-roll packet!  Try seeking again prior to reading more samples.")
+        if roll > count or roll < 0:
+            self._stream.reset()
+            self._ended = True
+            raise native.NvhError(native.ERR_RUNTIME, "SeekTo: roll-forward of %d samples into a packet that emits %d: the "
+                                  "reference's Read does not return from here" % (roll, count))
         self._skip = roll * self.Channels
+        # _currentPosition = samplePosition (:626): the pending frame's `count` samples are ahead of it
+        self._stream.set_position_state(True, s - roll + count)
 
     def close(self):
+        if getattr(self, "_ogg_index", None):
+            lib().nvh_ogg_index_close(self._ogg_index)
+            self._ogg_index = None
         self._stream.close()
 
 
@@ -671,6 +742,7 @@ class VorbisReader:
             raise native.NvhError(native.ERR_NOT_VORBIS, "VorbisReader")  # ArgumentException: could not load the container
         self._stream_index = 0
         self._dec = StreamDecoder(self._ctx, demux_ogg_array(data, self._stream_ids[0]), None, None, batch_frames, gpu_parse)
+        self._dec.attach_ogg(data, self._stream_ids[0])
         self._decs = {0: self._dec}  # one decoder per logical stream, created on first use, kept like VorbisReader._decoders
 
     def _is_vorbis(self, k):
@@ -698,6 +770,7 @@ class VorbisReader:
         if index not in self._decs:
             self._decs[index] = StreamDecoder(self._ctx, demux_ogg_array(self._data, self._stream_ids[index]), None, None,
                                               self._batch_frames, self._gpu_parse)
+            self._decs[index].attach_ogg(self._data, self._stream_ids[index])
         self._dec = self._decs[index]
         self._dec.ClipSamples = clip  # carry-through the clipping setting
         self._stream_index = index

@@ -32,7 +32,8 @@ enum {
   ORC_ERR_ARGUMENT = -2,     /* ArgumentOutOfRangeException on Read()                */
   ORC_ERR_RUNTIME = -3,      /* IndexOutOfRange / NullReference / DivideByZero class */
   ORC_ERR_NOMEM = -4,
-  ORC_ERR_NOT_VORBIS = -5
+  ORC_ERR_NOT_VORBIS = -5,
+  ORC_ERR_STATE = -6         /* InvalidOperationException (StreamDecoder.SeekTo)      */
 };
 
 /* ---- DataPacket (DataPacket.cs:150-283) ---- */
@@ -82,6 +83,20 @@ typedef struct orc_decoder orc_decoder;
 /* Ogg container -> decoder (minimal forward demux: Ogg/PageReaderBase.cs:33-70,227-292,
  * Ogg/PageReader.cs:27-93, Ogg/PacketProvider.cs:324-438, Ogg/Crc.cs).  First logical stream only. */
 orc_decoder *orc_open_ogg(const uint8_t *bytes, size_t len, int *err);
+/* IPacketProvider.SeekTo(granulePos, preRoll, GetPacketGranules) on the first logical stream of an Ogg file, for a reader
+ * that has read every page (Ogg/PacketProvider.cs:56-295, Ogg/StreamPageReader.cs:122-264, StreamDecoder.cs:630-647; d supplies the
+ * modes).  *packet_index = position in orc_ogg_demux's list of the packet GetNextPacket returns next, *granule_out = the method's
+ * return value; ORC_ERR_ARGUMENT / ORC_ERR_INVALID_DATA / ORC_ERR_RUNTIME where the reference throws ArgumentOutOfRangeException /
+ * InvalidDataException / faults on an index. */
+int orc_ogg_seek(const uint8_t *bytes, size_t len, orc_decoder *d, int64_t granule_pos, int pre_roll, int64_t *packet_index,
+                 int64_t *granule_out);
+/* StreamDecoder.SeekTo(samplePosition, SeekOrigin.Begin) (StreamDecoder.cs:562-628) on a decoder opened with orc_open_ogg:
+ * provider seek (orc_ogg_seek) one packet early, ResetDecoder, the pre-roll packet, the packet that holds the target, the
+ * roll-forward.  ORC_ERR_STATE = InvalidOperationException; other codes as orc_ogg_seek.  (Where the roll-forward exceeds the
+ * packet's output the managed Read spins; orc_read_samples then returns ORC_ERR_RUNTIME.) */
+int orc_seek_to(orc_decoder *d, int64_t sample_position);
+/* IPacketProvider.GetGranuleCount (Ogg/PacketProvider.cs:30-42) of the first logical stream: the largest page granule position */
+int64_t orc_total_samples(const orc_decoder *d);
 /* Raw packets: packet i = bytes[offs[i] .. offs[i+1]); granule[i] < 0 => none; flags bit0 = EOS, bit1 = resync.
  * The first three packets must be the Vorbis id / comment / setup headers. */
 orc_decoder *orc_open_packets(const uint8_t *bytes, const int64_t *offs, const int64_t *granule,

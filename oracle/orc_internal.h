@@ -118,6 +118,10 @@ struct orc_decoder {
   int64_t *granule;
   uint8_t *flags;
   int npackets, next_packet;
+  /* the Ogg file the list came from (orc_open_ogg): seeking works on its pages */
+  uint8_t *ogg_bytes;
+  size_t ogg_len;
+  int64_t max_granule;
 
   /* StreamDecoder.cs:19-39 */
   int channels, sample_rate, block0, block1;
@@ -156,5 +160,8 @@ int orc_mode_decode(orc_decoder *d, const orc_mode *m, orc_packet *p, float **bu
 /* Ogg demux -> packet list (orc_ogg.c) */
 int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t **out_offs, int64_t **out_granule,
                   uint8_t **out_flags, int *out_n);
+
+/* largest page granule position of the first logical stream (StreamPageReader._maxGranulePos) */
+int orc_ogg_max_granule(const uint8_t *bytes, size_t len, int64_t *max_granule);
 
 #endif

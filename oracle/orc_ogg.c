@@ -7,8 +7,12 @@
  *   - continuation across pages, granule attached to the packet that is LAST on the page it
  *     completes on, EOS on that packet of the EOS-flagged page        Ogg/PacketProvider.cs:324-438
  *   - pages after the EOS-flagged page ignored                        Ogg/StreamPageReader.cs:44-91
- * Only the first logical stream (serial of the first page) is demuxed.  Seeking, multiplexing and
- * the libvorbis granule-bug workaround are out of scope.
+ * Only the first logical stream (serial of the first page) is demuxed; multiplexing is out of scope.
+ * Seeking, orc_ogg_seek at the end of the file:
+ *   - StreamPageReader.FindPage / FindPageBisection / FindPageForward   Ogg/StreamPageReader.cs:122-264
+ *   - PacketProvider.SeekTo / FindPacket / granule-bug workaround        Ogg/PacketProvider.cs:56-260
+ *   - PacketProvider.NormalizePacketIndex                                 Ogg/PacketProvider.cs:262-295
+ *   - StreamDecoder.GetPacketGranules                                     StreamDecoder.cs:630-647
  */
 #include "orc_internal.h"
 
@@ -89,19 +93,33 @@ static int pl_append(pkt_list *l, const uint8_t *src, size_t len) {
   return ORC_OK;
 }
 
-int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t **out_offs, int64_t **out_granule,
-                  uint8_t **out_flags, int *out_n) {
+typedef struct {
+  ogg_page *pages;
+  int npages, has_all_pages, first_data_page;
+  int64_t max_granule;
+} page_table;
+
+static void free_pages(page_table *t) {
+  int i;
+  for (i = 0; i < t->npages; i++) {
+    free(t->pages[i].pk_off);
+    free(t->pages[i].pk_len);
+  }
+  free(t->pages);
+  memset(t, 0, sizeof *t);
+}
+
+/* The pages of the first logical stream, as StreamPageReader.AddPage accepts them (Ogg/StreamPageReader.cs:44-91). */
+static int scan_pages(const uint8_t *bytes, size_t len, page_table *out) {
   ogg_page *pages = NULL;
   int npages = 0, pcap = 0, have_serial = 0, has_all_pages = 0, rc = ORC_OK;
   int32_t serial = 0;
   size_t pos = 0;
-  int resync = 0, i;
+  int resync = 0;
   /* StreamPageReader.AddPage state (Ogg/StreamPageReader.cs:44-91) */
   int32_t last_seq = 0;
-  int have_first_data_page = 0;
+  int have_first_data_page = 0, first_data_page = -1;
   int64_t max_granule = 0;
-  pkt_list pl;
-  memset(&pl, 0, sizeof pl);
   if (!g_crc_ready) crc_init();
 
   /* ---- page scan (ReadNextPage loop) ---- */
@@ -180,6 +198,7 @@ int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t
           if (pg->granule != -1) {
             if (!have_first_data_page && pg->granule > 0) {
               have_first_data_page = 1;
+              first_data_page = npages - 1; /* _firstDataPageIndex = _pageOffsets.Count (this page is not added yet) */
             } else if (max_granule > pg->granule) {
               rc = ORC_ERR_INVALID_DATA; /* "Granule Position regressed?!" */
               npages--;
@@ -227,6 +246,30 @@ int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t
       pos += total;
     }
   }
+
+done:
+  out->pages = pages;
+  out->npages = npages;
+  out->has_all_pages = has_all_pages;
+  out->first_data_page = first_data_page;
+  out->max_granule = max_granule;
+  if (rc != ORC_OK) free_pages(out);
+  return rc;
+}
+
+int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t **out_offs, int64_t **out_granule,
+                  uint8_t **out_flags, int *out_n) {
+  page_table tab;
+  ogg_page *pages;
+  int npages, has_all_pages, rc;
+  pkt_list pl;
+  memset(&pl, 0, sizeof pl);
+  memset(&tab, 0, sizeof tab);
+  rc = scan_pages(bytes, len, &tab);
+  if (rc != ORC_OK) return rc;
+  pages = tab.pages;
+  npages = tab.npages;
+  has_all_pages = tab.has_all_pages;
 
   /* ---- packet assembly (PacketProvider.GetNextPacket/CreatePacket) ---- */
   {
@@ -297,11 +340,7 @@ int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t
   if ((rc = pl_begin(&pl)) != ORC_OK) goto done; /* terminal offset */
 
 done:
-  for (i = 0; i < npages; i++) {
-    free(pages[i].pk_off);
-    free(pages[i].pk_len);
-  }
-  free(pages);
+  free_pages(&tab);
   if (rc != ORC_OK) {
     free(pl.bytes);
     free(pl.offs);
@@ -315,5 +354,329 @@ done:
   *out_granule = pl.granule;
   *out_flags = pl.flags;
   *out_n = pl.n;
+  return ORC_OK;
+}
+
+/* ================================================================================================
+ * Seeking: IPacketProvider.SeekTo(granulePos, preRoll, getPacketGranuleCount) restated method by method
+ * (test infrastructure; the reader is taken to have read every page already, as after TotalSamples).
+ * ================================================================================================ */
+
+typedef struct {
+  const uint8_t *bytes;
+  const page_table *t;
+  orc_decoder *d;
+  int err; /* ORC_ERR_* raised by a helper */
+} seek_ctx;
+
+/* StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647) on an assembled packet */
+static int packet_granules(seek_ctx *c, const uint8_t *data, int len, int is_resync) {
+  orc_packet p;
+  int mode_idx;
+  const orc_mode *m;
+  if (is_resync) return 0;
+  orc_packet_init(&p, data, len);
+  if (orc_read_bit(&p)) return 0;
+  mode_idx = (int)orc_read_bits(&p, c->d->mode_field_bits);
+  if (mode_idx < 0 || mode_idx >= c->d->nmodes) return 0;
+  m = &c->d->modes[mode_idx];
+  /* Mode.GetPacketSampleCount -> GetPacketInfo (Mode.cs:119-152, 172-177): valid - start */
+  if (p.is_short) return 0;
+  if (m->block_flag) {
+    int prev_flag = orc_read_bit(&p);
+    int next_flag = orc_read_bit(&p);
+    int wi = (prev_flag ? 1 : 0) + (next_flag ? 2 : 0);
+    return m->ov_valid[wi] - m->ov_start[wi];
+  }
+  return m->block_size / 2;
+}
+
+/* PacketProvider.CreatePacket with advance = false (Ogg/PacketProvider.cs:324-400), then getPacketGranuleCount on it.
+ * Returns 0 and sets *granules, or -1 where CreatePacket returns null, or -2 with c->err set. */
+static int create_packet_granules(seek_ctx *c, int page_index, int packet_index, int is_resync, int is_continued, int packet_count,
+                                  int *granules) {
+  const ogg_page *pg = &c->t->pages[page_index];
+  uint8_t *buf;
+  size_t n = 0, cap;
+  if (packet_index < 0 || packet_index >= pg->packet_count) { /* GetPagePackets(pageIndex)[packetIndex] */
+    c->err = ORC_ERR_RUNTIME;
+    return -2;
+  }
+  cap = (size_t)pg->pk_len[packet_index] + 16;
+  buf = (uint8_t *)malloc(cap);
+  if (!buf) {
+    c->err = ORC_ERR_NOMEM;
+    return -2;
+  }
+  memcpy(buf, c->bytes + pg->data_off + pg->pk_off[packet_index], (size_t)pg->pk_len[packet_index]);
+  n = (size_t)pg->pk_len[packet_index];
+  if (is_continued && packet_index == packet_count - 1) {
+    int cont = page_index;
+    while (is_continued) {
+      const ogg_page *np;
+      int is_continuation;
+      if (++cont >= c->t->npages) {
+        free(buf);
+        return -1;
+      }
+      np = &c->t->pages[cont];
+      is_resync = np->is_resync;
+      is_continuation = (np->flags & 0x01) != 0;
+      is_continued = np->is_continued;
+      packet_count = np->packet_count;
+      if (!is_continuation || is_resync) break;
+      if (is_continued && packet_count > 1) is_continued = 0;
+      if (n + (size_t)np->pk_len[0] > cap) {
+        uint8_t *nb;
+        cap = (n + (size_t)np->pk_len[0]) * 2;
+        nb = (uint8_t *)realloc(buf, cap);
+        if (!nb) {
+          free(buf);
+          c->err = ORC_ERR_NOMEM;
+          return -2;
+        }
+        buf = nb;
+      }
+      memcpy(buf + n, c->bytes + np->data_off + np->pk_off[0], (size_t)np->pk_len[0]);
+      n += (size_t)np->pk_len[0];
+    }
+  }
+  *granules = packet_granules(c, buf, (int)n, is_resync);
+  free(buf);
+  return 0;
+}
+
+/* Ogg/PacketProvider.cs:224-260 */
+static int get_is_vorbis_bug_diff(int64_t diff) {
+  int64_t temp;
+  int short_block_bits = 0, long_block_bits;
+  if (diff < 0) diff = -diff;
+  temp = diff;
+  while (temp > 0 && (temp & 1) == 0) {
+    ++short_block_bits;
+    temp >>= 1;
+  }
+  long_block_bits = short_block_bits;
+  while ((temp & 1) == 1) {
+    ++long_block_bits;
+    temp >>= 1;
+  }
+  return temp == 0 && diff == ((int64_t)1 << long_block_bits) - ((int64_t)1 << short_block_bits);
+}
+
+/* Ogg/StreamPageReader.cs:232-264 */
+static int find_page_bisection(const page_table *t, int64_t granule_pos, int low, int high, int64_t high_granule_pos, int *fault) {
+  int64_t low_granule_pos = 0;
+  int dist;
+  while ((dist = high - low) > 0) {
+    int index = low + (int)(dist * ((granule_pos - low_granule_pos) / (double)(high_granule_pos - low_granule_pos)));
+    int64_t idx_granule_pos;
+    if (index < 0 || index >= t->npages) { /* _pageOffsets[index] */
+      *fault = 1;
+      return -1;
+    }
+    idx_granule_pos = t->pages[index].granule;
+    if (idx_granule_pos > granule_pos) {
+      high = index;
+      high_granule_pos = idx_granule_pos;
+    } else if (idx_granule_pos < granule_pos) {
+      low = index + 1;
+      low_granule_pos = idx_granule_pos + 1;
+    } else {
+      return index + 1;
+    }
+  }
+  return low;
+}
+
+/* Ogg/StreamPageReader.cs:122-160, every page already read */
+static int find_page(const page_table *t, int64_t granule_pos, int *fault) {
+  int page_index = -1;
+  if (granule_pos == 0) {
+    page_index = t->first_data_page;
+  } else {
+    int last_page_index = t->npages - 1;
+    if (last_page_index >= 0) {
+      int64_t page_gp = t->pages[last_page_index].granule;
+      if (granule_pos < page_gp) {
+        page_index = find_page_bisection(t, granule_pos, t->first_data_page, last_page_index, page_gp, fault);
+      } else if (granule_pos > page_gp) {
+        /* FindPageForward (:171-199): the next index is past the last page, GetNextPageGranulePos finds nothing more to
+         * read and marks the reader complete (:201-230); "allow finding the last granulePos" */
+        page_index = last_page_index + 1;
+        if (t->max_granule < granule_pos) page_index = -1;
+      } else {
+        page_index = last_page_index + 1;
+      }
+    }
+  }
+  return page_index;
+}
+
+/* position of slot (page, packet) in the list GetNextPacket produces from the start of the stream, or -1 */
+static int64_t list_index_of(const page_table *t, int page, int packet) {
+  int page_index = 0, packet_index = 0;
+  int64_t k = 0;
+  while (page_index < t->npages) {
+    const ogg_page *pg = &t->pages[page_index];
+    int is_continued = pg->is_continued, packet_count = pg->packet_count, final_page = page_index;
+    if (page_index == page && packet_index == packet) return k;
+    if (page_index > page) return -1;
+    if (is_continued && packet_index == packet_count - 1) {
+      int cont = page_index;
+      while (is_continued) {
+        const ogg_page *np;
+        if (++cont >= t->npages) return -1;
+        np = &t->pages[cont];
+        is_continued = np->is_continued;
+        packet_count = np->packet_count;
+        if (!(np->flags & 0x01) || np->is_resync) break;
+        if (is_continued && packet_count > 1) is_continued = 0;
+      }
+      final_page = cont;
+    }
+    k++;
+    if (final_page != page_index) {
+      page_index = final_page;
+      packet_index = 0;
+    }
+    if (packet_index == packet_count - 1) {
+      ++page_index;
+      packet_index = 0;
+    } else {
+      ++packet_index;
+    }
+  }
+  return -1;
+}
+
+int orc_ogg_seek(const uint8_t *bytes, size_t len, orc_decoder *d, int64_t granule_pos, int pre_roll, int64_t *packet_index_out,
+                 int64_t *granule_out) {
+  page_table tab;
+  seek_ctx c;
+  int rc, page_index, packet_index = 0, fault = 0;
+  int64_t last_page_granule_pos = 0, end_gp, *gps = NULL;
+  int last_page_packet_length = 0, first_real_packet = 0, packet_count, i, found;
+  const ogg_page *pg;
+  memset(&tab, 0, sizeof tab);
+  if (!bytes || !d || !packet_index_out || !granule_out) return ORC_ERR_ARGUMENT;
+  if ((rc = scan_pages(bytes, len, &tab)) != ORC_OK) return rc;
+  c.bytes = bytes;
+  c.t = &tab;
+  c.d = d;
+  c.err = ORC_OK;
+  rc = ORC_OK;
+
+  /* SeekTo (:56-72) */
+  page_index = find_page(&tab, granule_pos, &fault);
+  if (fault) { rc = ORC_ERR_RUNTIME; goto done; }
+  if (page_index == -1) { rc = ORC_ERR_ARGUMENT; goto done; } /* FindPage throws ArgumentOutOfRangeException */
+
+  /* FindPacket(pageIndex, preRoll, ref granulePos, ..) (:204-222): GetPreviousPageInfo (:74-108) */
+  if (page_index > 0) {
+    const ogg_page *prev;
+    if (page_index - 1 >= tab.npages) { rc = ORC_ERR_INVALID_DATA; goto done; } /* "Could not get preceding page?!" */
+    prev = &tab.pages[page_index - 1];
+    last_page_granule_pos = prev->granule;
+    if (page_index > tab.first_data_page) {
+      int r = create_packet_granules(&c, page_index - 1, prev->packet_count - 1, 0, prev->is_continued, prev->packet_count,
+                                     &last_page_packet_length);
+      if (r == -1) { rc = ORC_ERR_INVALID_DATA; goto done; } /* "Could not find end of continuation!" */
+      if (r == -2) { rc = c.err; goto done; }
+    } else {
+      last_page_packet_length = 0;
+    }
+    first_real_packet = prev->is_continued ? 1 : 0;
+  }
+  /* GetTargetPageInfo (:110-146) */
+  if (page_index >= tab.npages) { rc = ORC_ERR_INVALID_DATA; goto done; } /* "Could not get found page?!" */
+  pg = &tab.pages[page_index];
+  packet_count = pg->packet_count;
+  if (pg->is_continued) packet_count--;
+  gps = (int64_t *)calloc((size_t)(packet_count > 0 ? packet_count : 1), sizeof *gps);
+  if (!gps) { rc = ORC_ERR_NOMEM; goto done; }
+  end_gp = pg->granule;
+  for (i = packet_count - 1; i >= first_real_packet; i--) {
+    int g = 0, r;
+    gps[i] = end_gp;
+    r = create_packet_granules(&c, page_index, i, i == 0 && pg->is_resync, pg->is_continued, packet_count, &g);
+    if (r == -1) { rc = ORC_ERR_INVALID_DATA; goto done; }
+    if (r == -2) { rc = c.err; goto done; }
+    end_gp -= g;
+  }
+  if (first_real_packet == 1) {
+    if (packet_count < 1) { rc = ORC_ERR_RUNTIME; goto done; } /* gps[0] of an empty array */
+    gps[0] = end_gp;
+    end_gp -= last_page_packet_length;
+  }
+  /* FindPacket(pageIndex, gps, endGP, lastPageGranulePos, lastPagePacketLength, ref granulePos) (:148-202) */
+  found = 0;
+  if (end_gp != last_page_granule_pos) {
+    int64_t diff = end_gp - last_page_granule_pos;
+    if (get_is_vorbis_bug_diff(diff)) {
+      if (diff > 0) {
+        if (granule_pos <= end_gp) {
+          granule_pos = end_gp - last_page_packet_length;
+          packet_index = -1;
+          found = 1;
+        }
+      } else {
+        for (i = 0; i < packet_count; i++) gps[i] -= diff;
+      }
+    } else if (page_index > tab.first_data_page) {
+      rc = ORC_ERR_INVALID_DATA; /* "GranulePos mismatch" */
+      goto done;
+    }
+  }
+  if (!found) {
+    for (i = 0; i < packet_count; i++) {
+      if (gps[i] >= granule_pos) {
+        granule_pos = i == 0 ? end_gp : gps[i - 1];
+        packet_index = i;
+        found = 1;
+        break;
+      }
+    }
+    if (!found) { rc = ORC_ERR_INVALID_DATA; goto done; } /* "Could not find seek packet?!" */
+  }
+  if (end_gp > 0 || packet_index > 1) packet_index -= pre_roll; /* :216-220 */
+
+  /* NormalizePacketIndex (:262-295) */
+  {
+    int is_resync = pg->is_resync, is_continuation = (pg->flags & 0x01) != 0;
+    int pg_idx = page_index, pkt_idx = packet_index;
+    while (pkt_idx < (is_continuation ? 1 : 0)) {
+      int was_continuation = is_continuation;
+      const ogg_page *pp;
+      if (is_continuation && is_resync) { rc = ORC_ERR_ARGUMENT; goto done; }
+      if (--pg_idx < 0) { rc = ORC_ERR_ARGUMENT; goto done; }
+      pp = &tab.pages[pg_idx];
+      is_resync = pp->is_resync;
+      is_continuation = (pp->flags & 0x01) != 0;
+      if (was_continuation && !pp->is_continued) { rc = ORC_ERR_ARGUMENT; goto done; }
+      pkt_idx += pp->packet_count - (was_continuation ? 1 : 0);
+    }
+    page_index = pg_idx;
+    packet_index = pkt_idx;
+  }
+  {
+    int64_t k = list_index_of(&tab, page_index, packet_index);
+    if (k < 0) { rc = ORC_ERR_RUNTIME; goto done; }
+    *packet_index_out = k;
+    *granule_out = granule_pos;
+  }
+done:
+  free(gps);
+  free_pages(&tab);
+  return rc;
+}
+
+int orc_ogg_max_granule(const uint8_t *bytes, size_t len, int64_t *max_granule) {
+  page_table tab;
+  int rc;
+  memset(&tab, 0, sizeof tab);
+  if ((rc = scan_pages(bytes, len, &tab)) != ORC_OK) return rc;
+  *max_granule = tab.max_granule;
+  free_pages(&tab);
   return ORC_OK;
 }

@@ -179,6 +179,14 @@ orc_decoder *orc_open_ogg(const uint8_t *bytes, size_t len, int *err) {
   free(offs);
   free(gr);
   free(fl);
+  if (d) {
+    d->ogg_bytes = (uint8_t *)malloc(len ? len : 1);
+    if (d->ogg_bytes) {
+      memcpy(d->ogg_bytes, bytes, len);
+      d->ogg_len = len;
+      (void)orc_ogg_max_granule(bytes, len, &d->max_granule);
+    }
+  }
   return d;
 }
 
@@ -196,6 +204,7 @@ void orc_close(orc_decoder *d) {
   free(d->modes);
   free_planes(d->buf_a, d->channels);
   free_planes(d->buf_b, d->channels);
+  free(d->ogg_bytes);
   free(d->bytes);
   free(d->offs);
   free(d->granule);
@@ -385,6 +394,57 @@ static int stream_read(orc_decoder *d, float *buffer, int buffer_len, int offset
   count = idx - offset;
   d->current_position += count / d->channels;
   return count;
+}
+
+/* StreamDecoder.cs:294-305 */
+static void reset_decoder(orc_decoder *d) {
+  d->prev_buf = NULL;
+  d->prev_start = 0;
+  d->prev_end = 0;
+  d->prev_stop = 0;
+  d->next_buf = NULL;
+  d->eos_found = 0;
+  d->has_clipped = 0;
+  d->has_position = 0;
+}
+
+int64_t orc_total_samples(const orc_decoder *d) { return d->max_granule; }
+
+/* StreamDecoder.cs:562-628, SeekOrigin.Begin */
+int orc_seek_to(orc_decoder *d, int64_t sample_position) {
+  int64_t k = 0, pos = 0;
+  int roll_forward, rc, has_pos = 0, err = ORC_OK;
+  int64_t p64 = 0;
+  if (!d || !d->ogg_bytes) return ORC_ERR_STATE; /* "Seek is not supported by the Contracts.IPacketProvider instance." */
+  if (sample_position < 0) return ORC_ERR_ARGUMENT;
+  if (sample_position == 0) {
+    rc = orc_ogg_seek(d->ogg_bytes, d->ogg_len, d, 0, 0, &k, &pos); /* "short circuit for the looping case" */
+    roll_forward = 0;
+  } else {
+    rc = orc_ogg_seek(d->ogg_bytes, d->ogg_len, d, sample_position, 1, &k, &pos);
+    roll_forward = (int)(sample_position - pos);
+  }
+  if (rc != ORC_OK) return rc;
+  d->next_packet = (int)k;
+  reset_decoder(d);
+  d->has_position = 1;
+  if (!read_next_packet(d, 0, &has_pos, &p64, &err)) { /* the pre-roll packet */
+    if (err) return err;
+    d->eos_found = 1;
+    if (d->max_granule != sample_position) return ORC_ERR_STATE; /* "Could not read pre-roll packet!" */
+    d->prev_start = d->prev_stop;
+    d->current_position = sample_position;
+    return ORC_OK;
+  }
+  if (!read_next_packet(d, 0, &has_pos, &p64, &err)) { /* the actual packet */
+    if (err) return err;
+    reset_decoder(d);
+    d->eos_found = 1;
+    return ORC_ERR_STATE;
+  }
+  d->prev_start += roll_forward;
+  d->current_position = sample_position;
+  return ORC_OK;
 }
 
 /* VorbisReader.cs:336-345 */

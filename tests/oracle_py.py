@@ -28,6 +28,10 @@ class Oracle:
         L.orc_open_packets.restype = vp
         L.orc_open_packets.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
         L.orc_close.argtypes = [vp]
+        L.orc_ogg_seek.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.orc_seek_to.argtypes = [vp, C.c_int64]
+        L.orc_total_samples.argtypes = [vp]
+        L.orc_total_samples.restype = C.c_int64
         L.orc_read_samples.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
         for f in ("orc_channels", "orc_sample_rate", "orc_block0", "orc_block1", "orc_packet_count", "orc_has_clipped",
                   "orc_is_end_of_stream", "orc_last_error", "orc_trace_count"):
@@ -107,6 +111,31 @@ class Oracle:
         if rc != 1:
             return None
         return e.value, mask
+
+    # ---- seeking (Ogg/PacketProvider.cs:56-295, StreamDecoder.cs:562-628) ----
+    def open_ogg(self, data):
+        err = C.c_int(0)
+        d = self.L.orc_open_ogg(data, len(data), C.byref(err))
+        if not d:
+            raise RuntimeError("oracle open failed: %d" % err.value)
+        return d
+
+    def ogg_seek(self, data, d, granule_pos, pre_roll):
+        """IPacketProvider.SeekTo -> (rc, packet index in the demuxed list, returned granule position)."""
+        k, g = C.c_int64(0), C.c_int64(0)
+        rc = self.L.orc_ogg_seek(data, len(data), d, int(granule_pos), int(pre_roll), C.byref(k), C.byref(g))
+        return rc, int(k.value), int(g.value)
+
+    def seek_and_read(self, d, sample_position, nfloats, clip=True):
+        """StreamDecoder.SeekTo then one ReadSamples: (rc of the seek, samples or the read's negative code, position after)."""
+        L = self.L
+        rc = L.orc_seek_to(d, int(sample_position))
+        if rc != 0:
+            return rc, None, int(L.orc_sample_position(d))
+        L.orc_set_clip_samples(d, 1 if clip else 0)
+        buf = np.zeros(nfloats, np.float32)
+        n = L.orc_read_samples(d, buf.ctypes.data, buf.size, 0, buf.size)
+        return 0, (buf[:n].copy() if n >= 0 else n), int(L.orc_sample_position(d))
 
     # ---- decoding ----
     def decode_ogg(self, data, clip=True, chunk=4096, trace=False):

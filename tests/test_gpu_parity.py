@@ -830,66 +830,115 @@ def test_stream_chunks_synthetic(oracle, gpu_ctx, name, consistent):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, consistent, world)
 
 
+def _seek_outcome(nv, rd, t, buf):
+    """(class, samples, position after) of SeekTo(t) + one ReadSamples on the product, classes named after the oracle's codes."""
+    try:
+        rd.SeekTo(t)
+    except IndexError:
+        return -2, None, rd.SamplePosition            # ArgumentOutOfRangeException
+    except nv.native.NvhError as e:
+        return e.code, None, None                    # InvalidDataException (-1) / the reference spins or faults (-3)
+    except RuntimeError:
+        return -6, None, None                        # InvalidOperationException
+    at = rd.SamplePosition
+    n = rd.ReadSamples(buf, 0, buf.size)
+    return 0, (at, buf[:n].copy()), rd.SamplePosition
+
+
 @pytest.mark.parametrize("name", ["1test", "2test", "3test", "issue6test"])
 @pytest.mark.parametrize("gpu_parse", [False, True])
-def test_seek_returns_the_serial_samples(oracle, ogg_bytes, name, gpu_parse):
-    """SeekTo (StreamDecoder.cs:562-628): after a seek to position S the reader yields exactly what a decode from the
-    start yields from S on (pre-roll packet + roll-forward), SamplePosition reports S, for targets at packet boundaries,
-    inside long and short blocks, at the very start and in the drained tail; SamplePosition / TimePosition setters,
-    SeekOrigin arithmetic, out-of-range targets."""
+def test_seek_matches_the_reference_decoder(oracle, ogg_bytes, name, gpu_parse):
+    """StreamDecoder.SeekTo (StreamDecoder.cs:562-628) over the reference's page-level search (tests/test_seek_pages.py): the same
+    sequence of seeks and reads on the product (VorbisReader over the C ABI) and on the oracle's restatement (orc_seek_to) gives
+    the same samples, positions and exception classes -- for targets at packet and page boundaries, inside long and short blocks,
+    on the first data page (where the reference lands early or, for a roll-forward longer than the packet, never returns from
+    Read: RUNTIME on both sides), on the last page (InvalidDataException where its granule position is trimmed), past the end.
+    Away from those pages the samples are also the serial decode's."""
     import nvorbis_amd as nv
-    ref, info = oracle.decode_ogg(ogg_bytes[name])
+    data = ogg_bytes[name]
+    ref, info = oracle.decode_ogg(data)
     ch = info["channels"]
-    rd = nv.VorbisReader(ogg_bytes[name], device=0, batch_frames=64, gpu_parse=gpu_parse)
+    d = oracle.open_ogg(data)
+    rd = nv.VorbisReader(data, device=0, batch_frames=64, gpu_parse=gpu_parse)
     try:
         full = rd.read_all()
         assert np.array_equal(full.view(np.uint32), ref.view(np.uint32))
-        end = rd.SamplePosition          # position after everything was read
-        first = end - ref.size // ch     # position of the first sample (63 for issue6test, else 0)
+        got_all = oracle._drain(oracle.open_ogg(data), True, 4096, False)[0]
+        assert got_all.size == ref.size
+        end = rd.SamplePosition
+        first = end - ref.size // ch
         total = rd.TotalSamples
-        assert first >= 0 and total > 0
+        assert total == oracle.L.orc_total_samples(d)
+        # bring the oracle decoder to the same state (everything read)
+        tmp = np.zeros(1 << 16, np.float32)
+        while oracle.L.orc_read_samples(d, tmp.ctypes.data, tmp.size, 0, tmp.size - tmp.size % ch) > 0:
+            pass
+        assert oracle.L.orc_sample_position(d) == end
         rng = np.random.default_rng(17)
-        targets = [first, first + 1, first + 127, first + 128, first + 129, first + 1024, end - 1, end - 700, (first + end) // 2]
-        targets += [int(t) for t in rng.integers(first, end, 12)]
+        targets = [0, 1, 64, 127, 128, 129, 1000, 1024, 2048, 5000, total - 1, total - 700, total, total + 1, (first + end) // 2]
+        targets += [int(t) for t in rng.integers(0, total, 40)]
         buf = np.empty(5000 * ch, np.float32)
+        seen = {}
+        serial_ok = 0
         for t in targets:
-            if t < first or t >= end:
+            rc, smp, pos_after = oracle.seek_and_read(d, t, buf.size)
+            cls, mine, my_pos = _seek_outcome(nv, rd, t, buf)
+            if rc == 0 and isinstance(smp, int):       # the seek went through, the managed Read would spin
+                assert smp == -3 and cls == -3, (t, smp, cls)
+                seen["spin"] = seen.get("spin", 0) + 1
                 continue
-            rd.SeekTo(t)
-            assert rd.SamplePosition == t
-            n = rd.ReadSamples(buf, 0, buf.size)
-            want = ref[(t - first) * ch:(t - first) * ch + buf.size]
-            assert n == want.size, (t, n, want.size)
-            assert np.array_equal(buf[:n].view(np.uint32), want.view(np.uint32)), t
-            assert rd.SamplePosition == t + n // ch
-        # to the end of the stream: everything from a late position on, then end of stream
-        rd.SeekTo(end - 300)
+            assert cls == rc, (name, t, cls, rc)
+            seen[rc] = seen.get(rc, 0) + 1
+            if rc != 0:
+                continue
+            at, pcm = mine
+            assert at == t and pcm.size == smp.size, (t, at, pcm.size, smp.size)
+            assert np.array_equal(pcm.view(np.uint32), smp.view(np.uint32)), t
+            assert my_pos == pos_after == t + pcm.size // ch
+            want = ref[(t - first) * ch:(t - first) * ch + pcm.size] if t >= first else None
+            if want is not None and want.size == pcm.size and np.array_equal(pcm.view(np.uint32), want.view(np.uint32)):
+                serial_ok += 1
+        assert seen.get(0, 0) >= 20 and serial_ok >= 10, (seen, serial_ok)
+        assert seen.get(-2, 0) >= 1                      # past the end
+        # read on to the end of the stream after a seek: same samples, then end of stream on both sides
+        t = int((first + end) // 2)
+        assert oracle.L.orc_seek_to(d, t) == 0
+        rd.SeekTo(t)
         tail = rd.read_all()
-        assert np.array_equal(tail.view(np.uint32), ref[(end - 300 - first) * ch:].view(np.uint32))
+        chunks = []
+        while True:
+            n = oracle.L.orc_read_samples(d, tmp.ctypes.data, tmp.size, 0, tmp.size - tmp.size % ch)
+            if n <= 0:
+                break
+            chunks.append(tmp[:n].copy())
+        otail = np.concatenate(chunks)
+        assert np.array_equal(tail.view(np.uint32), otail.view(np.uint32))
         assert rd.IsEndOfStream and rd.ReadSamples(buf, 0, buf.size) == 0
         # setters and origins
         mid = (first + end) // 2
         rd.SamplePosition = mid
         assert rd.SamplePosition == mid
-        rd.SeekTo(100, "end")
-        assert rd.SamplePosition == total - 100
+        rd.SeekTo(total // 3, "end")
+        assert rd.SamplePosition == total - total // 3
         rd.SeekTo(50, "current")  # the reference computes SamplePosition - value (StreamDecoder.cs:573)
-        assert rd.SamplePosition == total - 150
+        assert rd.SamplePosition == total - total // 3 - 50
         secs = 0.25 * rd.TotalTime
         rd.TimePosition = secs
         assert rd.SamplePosition == int(rd.SampleRate * secs)
-        n = rd.ReadSamples(buf, 0, 64 * ch)
-        p = int(rd.SampleRate * secs) - first
-        assert np.array_equal(buf[:n].view(np.uint32), ref[p * ch:p * ch + n].view(np.uint32))
         # back to the very beginning: position 0 restarts the stream
         rd.SeekTo(0)
         again = rd.read_all()
-        assert np.array_equal(again.view(np.uint32), ref.view(np.uint32))
+        assert oracle.L.orc_seek_to(d, 0) == 0
+        o_again = oracle._drain(d, True, 4096, False)[0]
+        d = None
+        assert np.array_equal(again.view(np.uint32), o_again.view(np.uint32))
         for bad in (-1, end + 10_000_000):
             with pytest.raises(IndexError):
                 rd.SeekTo(bad)
     finally:
         rd.close()
+        if d is not None:
+            oracle.L.orc_close(d)
 
 
 def test_reader_switches_between_logical_streams(oracle, ogg_bytes):
