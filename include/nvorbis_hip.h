@@ -268,6 +268,14 @@ int nvh_ogg_demux_stream(const uint8_t *bytes, size_t len, int stream_index, uin
                          int64_t *offsets, int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets,
                          int64_t *total_bytes, int *nstreams);
 
+/* The packet list of a source that cannot seek: ForwardOnlyPageReader + ForwardOnlyPacketProvider
+ * (Ogg/ForwardOnlyPageReader.cs:21-52, Ogg/ForwardOnlyPacketProvider.cs:36-67, 119-290), same calling convention.  It differs from
+ * the seekable reader's list in the resync marks (the first page always carries one, sequence numbers are checked without the
+ * exemption for 0), in zero-length packets (delivered), in pages that start with the tail of a lost packet (their packets are cut
+ * from the wrong bytes, as the reference cuts them) and in continued packets (no granule position, no end-of-stream mark). */
+int nvh_ogg_demux_forward(const uint8_t *bytes, size_t len, int stream_index, uint8_t *pkt_bytes, int64_t pkt_bytes_cap,
+                          int64_t *offsets, int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets,
+                          int64_t *total_bytes, int *nstreams);
 
 /* ---- seeking ----
  * Page table of one logical stream plus the reference's seek search over it:

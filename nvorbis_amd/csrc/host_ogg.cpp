@@ -276,6 +276,239 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward-only reader (non-seekable sources)
+// ------------------------------------------------------------------------------------------------
+// ForwardOnlyPageReader.AddPage + ForwardOnlyPacketProvider (Ogg/ForwardOnlyPageReader.cs:21-52,
+// Ogg/ForwardOnlyPacketProvider.cs:36-67, 119-290): what VorbisReader gets from a stream that cannot seek.  Same page sync
+// and CRC as above; the differences are the provider's:
+//   * the beginning-of-stream page is a resync page; every other page is one when its sequence number is not the previous + 1
+//     (no exemption for a previous number of 0), and there are no granule-position rules                       (:38-53)
+//   * a page is refused only when all its lacing values are 0; zero-length packets inside a page ARE delivered  (:55-64, 270-284)
+//   * a continuation page met at a packet start: resync, its partial first packet is skipped -- but only in the lacing table,
+//     the data offset stays where it was, so the packets of that page are cut from the wrong bytes            (:147-165)
+//   * the granule position (and end of stream) go to the last packet that is COMPLETE on its page; a packet that continues onto
+//     following pages never gets either                                                                         (:176-231)
+//   * a page that ends a continuation run abnormally (resync / not a continuation) is kept as the current page and its own
+//     resync flag is forgotten                                                                                  (:196-228)
+// The reference pulls pages on demand; with one logical stream per serial that is the same as having them all.
+int ogg_demux_forward(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index, int* nstreams) {
+  struct FPage {
+    const uint8_t* pg;  // page start (header)
+    bool resync;
+  };
+  struct Logical {
+    uint32_t serial = 0;
+    std::vector<FPage> pages;
+    int32_t last_seq = 0;
+    bool ended = false;  // SetEndOfStream
+  };
+  std::vector<Logical> streams;
+  std::vector<std::pair<uint32_t, int>> active;
+  std::vector<uint32_t> ignored;
+  bool resync = false;
+  size_t pos = 0;
+  while (pos + 27 <= len) {
+    const uint8_t* h = bytes + pos;
+    if (!(h[0] == 0x4f && h[1] == 0x67 && h[2] == 0x67 && h[3] == 0x53)) {
+      ++pos;
+      resync = true;
+      continue;
+    }
+    const int seg_cnt = h[26];
+    if (pos + 27 + (size_t)seg_cnt > len) {
+      ++pos;
+      resync = true;
+      continue;
+    }
+    size_t data_len = 0;
+    for (int s = 0; s < seg_cnt; s++) data_len += h[27 + s];
+    const size_t total = 27 + (size_t)seg_cnt + data_len;
+    if (pos + total > len || !page_crc_ok(h, total)) {
+      ++pos;
+      resync = true;
+      continue;
+    }
+    const uint32_t pg_serial = (uint32_t)h[14] | ((uint32_t)h[15] << 8) | ((uint32_t)h[16] << 16) | ((uint32_t)h[17] << 24);
+    bool skip = false;
+    for (uint32_t ig : ignored) skip = skip || ig == pg_serial;
+    if (!skip) {
+      int slot = -1;
+      for (size_t a = 0; a < active.size(); a++)
+        if (active[a].first == pg_serial) slot = (int)a;
+      const bool is_new = slot < 0;
+      Logical fresh;
+      fresh.serial = pg_serial;
+      Logical& lg = is_new ? fresh : streams[(size_t)active[(size_t)slot].second];
+      // ForwardOnlyPacketProvider.AddPage (:36-67)
+      bool accept = true, pg_resync = resync;
+      const int32_t seq = (int32_t)((uint32_t)h[18] | ((uint32_t)h[19] << 8) | ((uint32_t)h[20] << 16) | ((uint32_t)h[21] << 24));
+      if (h[5] & 0x02) {  // BeginningOfStream
+        if (lg.ended) accept = false;
+        pg_resync = true;
+        if (accept) lg.last_seq = seq;
+      } else {
+        pg_resync = pg_resync || seq != (int32_t)((uint32_t)lg.last_seq + 1u);
+        lg.last_seq = seq;
+      }
+      if (accept && data_len == 0) accept = false;  // "there must be at least one packet with data"
+      if (accept) {
+        lg.pages.push_back(FPage{h, pg_resync});
+        if (is_new) {
+          streams.push_back(std::move(fresh));
+          active.emplace_back(pg_serial, (int)streams.size() - 1);
+          slot = (int)active.size() - 1;
+        }
+        if (h[5] & 0x04) {  // EndOfStream: SetEndOfStream, the reader forgets the provider (ForwardOnlyPageReader.cs:28-33)
+          streams[(size_t)active[(size_t)slot].second].ended = true;
+          active.erase(active.begin() + slot);
+        }
+      } else {
+        ignored.push_back(pg_serial);  // PageReaderBase.AddPage (:72-85)
+        if (!is_new) active.erase(active.begin() + slot);
+      }
+    }
+    resync = false;
+    pos += total;
+  }
+  if (nstreams) *nstreams = (int)streams.size();
+  out.bytes.clear();
+  out.offs.clear();
+  out.granule.clear();
+  out.flags.clear();
+  out.pages.clear();
+  if (stream_index < 0 || stream_index >= (int)streams.size()) {
+    out.offs.push_back(0);
+    return stream_index == 0 ? NVH_OK : NVH_ERR_ARGUMENT;
+  }
+  const Logical& lg = streams[(size_t)stream_index];
+  const std::vector<FPage>& pages = lg.pages;
+
+  // ---- ForwardOnlyPacketProvider.GetPacket (:119-246), called until it returns false ----
+  size_t next_page = 0;            // the queue
+  const uint8_t* page_buf = nullptr;  // _pageBuf
+  int st_packet_index = 0x7fffffff, st_data_start = 0;
+  auto packet_length = [](const uint8_t* pb, int& packet_index) {  // GetPacketLength (:270-284)
+    int l = 0;
+    while (packet_index < pb[26] + 27 && pb[packet_index] == 255) {
+      l += pb[packet_index];
+      ++packet_index;
+    }
+    if (packet_index < pb[26] + 27) {
+      l += pb[packet_index];
+      ++packet_index;
+    }
+    return l;
+  };
+  auto read_next_page = [&](const uint8_t*& pb, bool& is_resync, int& data_start, int& packet_index, bool& is_cont, bool& is_cntd) {
+    if (next_page >= pages.size()) return false;  // the queue is empty and the reader has nothing more
+    pb = pages[next_page].pg;
+    is_resync = pages[next_page].resync;
+    ++next_page;
+    data_start = pb[26] + 27;
+    packet_index = 27;
+    is_cont = (pb[5] & 0x01) != 0;
+    is_cntd = pb[26 + pb[26]] == 255;
+    return true;
+  };
+  for (;;) {
+    const uint8_t* pb;
+    bool is_resync, is_cont, is_cntd;
+    int data_start, packet_index;
+    if (page_buf != nullptr && st_packet_index < 27 + page_buf[26]) {
+      pb = page_buf;
+      is_resync = false;
+      data_start = st_data_start;
+      packet_index = st_packet_index;
+      is_cont = false;
+      is_cntd = pb[26 + pb[26]] == 255;
+    } else if (!read_next_page(pb, is_resync, data_start, packet_index, is_cont, is_cntd)) {
+      break;
+    }
+    const bool is_first = packet_index == 27;
+    if (is_cont && is_first) {
+      is_resync = true;
+      (void)packet_length(pb, packet_index);  // "skip the first packet; it's a partial" -- the data offset is not moved
+      if (packet_index == 27 + pb[26]) continue;  // "we'll just recurse and try again": _pageBuf is still the exhausted old page
+    }
+    const int data_len = packet_length(pb, packet_index);
+    const size_t mark = out.bytes.size();
+    {
+      // the slice is taken from the page array as the lacing says, even where the stale offset runs it past the page's end
+      // in the file image (then whatever follows is read; the managed array would fault: kept inside the input here)
+      const uint8_t* src = pb + data_start;
+      size_t avail = (size_t)((bytes + len) - src);
+      size_t take = (size_t)data_len <= avail ? (size_t)data_len : avail;
+      out.bytes.insert(out.bytes.end(), src, src + take);
+      out.bytes.insert(out.bytes.end(), (size_t)data_len - take, (uint8_t)0);
+    }
+    data_start += data_len;
+    bool is_last = packet_index == 27 + pb[26];
+    if (is_cntd) {
+      if (is_last) {
+        is_last = false;
+      } else {
+        int pi = packet_index;
+        (void)packet_length(pb, pi);
+        is_last = pi == 27 + pb[26];
+      }
+    }
+    bool is_eos = false;
+    int64_t gr = -1;
+    bool has_gr = false;
+    if (is_last) {
+      std::memcpy(&gr, pb + 6, 8);
+      has_gr = true;
+      // (_isEndOfStream && _pageQueue.Count == 0 adds nothing when pages are pulled one at a time)
+      if (pb[5] & 0x04) is_eos = true;
+    } else {
+      while (is_cntd && packet_index == 27 + pb[26]) {
+        const uint8_t* nb;
+        bool n_resync, n_cont, n_cntd;
+        int n_start, n_index;
+        const bool got = read_next_page(nb, n_resync, n_start, n_index, n_cont, n_cntd);
+        if (got) {  // the out parameters are written whether or not the page continues the packet
+          pb = nb;
+          is_resync = n_resync;
+          data_start = n_start;
+          packet_index = n_index;
+          is_cont = n_cont;
+          is_cntd = n_cntd;
+        } else {
+          pb = nullptr;  // ReadNextPage sets pageBuf = null on failure
+          is_resync = false;
+          data_start = 0;
+          packet_index = 0;
+          is_cont = false;
+          is_cntd = false;
+        }
+        if (got && !is_resync && is_cont) {
+          const int cont_sz = packet_length(pb, packet_index);
+          out.bytes.insert(out.bytes.end(), pb + data_start, pb + data_start + cont_sz);
+          data_start += cont_sz;
+        } else {
+          break;
+        }
+      }
+    }
+    uint8_t fl = 0;
+    if (is_resync) fl |= 2;
+    if (is_eos) fl |= 1;
+    out.offs.push_back((int64_t)mark);
+    out.granule.push_back(has_gr ? gr : -1);
+    out.flags.push_back(fl);
+    page_buf = pb;
+    st_data_start = data_start;
+    st_packet_index = packet_index;
+    if (page_buf == nullptr) {
+      // _pageBuf = null: the next call goes straight to ReadNextPage, which has nothing left
+      st_packet_index = 0x7fffffff;
+    }
+  }
+  out.offs.push_back((int64_t)out.bytes.size());
+  return NVH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // seek search
 // ------------------------------------------------------------------------------------------------
 namespace {

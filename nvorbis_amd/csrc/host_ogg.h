@@ -34,6 +34,11 @@ struct OggPackets {
 // Packets of logical stream `stream_index` (0 = the first one whose page appears); *nstreams = how many there are.
 int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index = 0, int* nstreams = nullptr, bool want_pages = false);
 
+// The same for a source that cannot seek: ForwardOnlyPageReader + ForwardOnlyPacketProvider (Ogg/ForwardOnlyPageReader.cs,
+// Ogg/ForwardOnlyPacketProvider.cs:36-67, 119-290); the differences are listed in host_ogg.cpp.  A granule position of -1 in
+// `granule` stands for "none" as well as for a page value of -1.
+int ogg_demux_forward(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index = 0, int* nstreams = nullptr);
+
 // PacketProvider.SeekTo (Ogg/PacketProvider.cs:56-72) over a demuxed stream with its page table, in the state the reference's
 // reader is in once it has seen every page: the page search (StreamPageReader.FindPage, Ogg/StreamPageReader.cs:122-264), the
 // packet search with the libvorbis granule workaround (Ogg/PacketProvider.cs:74-260) and NormalizePacketIndex (:262-295).

@@ -687,6 +687,31 @@ extern "C" int nvh_ogg_demux_stream(const uint8_t* bytes, size_t len, int stream
   });
 }
 
+// ForwardOnlyPageReader / ForwardOnlyPacketProvider (host_ogg.cpp): the packet list a non-seekable source yields
+extern "C" int nvh_ogg_demux_forward(const uint8_t* bytes, size_t len, int stream_index, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
+                                     int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
+                                     int64_t* total_bytes, int* nstreams) {
+  return nvh_guard([&]() -> int {
+    if (!bytes || !npackets || !total_bytes || stream_index < 0) return NVH_ERR_ARGUMENT;
+    nvh::OggPackets pk;
+    int rc = nvh::ogg_demux_forward(bytes, len, pk, stream_index, nstreams);
+    if (rc != NVH_OK) return rc;
+    int n = (int)pk.granule.size();
+    *npackets = n;
+    *total_bytes = (int64_t)pk.bytes.size();
+    if (!pkt_bytes && !offsets && !granules && !flags) return NVH_OK;  // sizing call
+    if (pkt_cap < n || pkt_bytes_cap < (int64_t)pk.bytes.size() || !pkt_bytes || !offsets || !granules || !flags)
+      return NVH_ERR_ARGUMENT;
+    if (!pk.bytes.empty()) std::memcpy(pkt_bytes, pk.bytes.data(), pk.bytes.size());
+    std::memcpy(offsets, pk.offs.data(), sizeof(int64_t) * (size_t)(n + 1));
+    if (n) {
+      std::memcpy(granules, pk.granule.data(), sizeof(int64_t) * (size_t)n);
+      std::memcpy(flags, pk.flags.data(), (size_t)n);
+    }
+    return NVH_OK;
+  });
+}
+
 extern "C" int nvh_ogg_demux(const uint8_t* bytes, size_t len, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
                              int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
                              int64_t* total_bytes) {

@@ -92,6 +92,7 @@ SIGNATURES = {
     "nvh_batch_time": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _f32p, _f32p]),
     "nvh_batch_free": (None, [_vp]),
     "nvh_ogg_demux": (C.c_int, [_vp, C.c_size_t, _vp, C.c_int64, _vp, _vp, _vp, C.c_int, _ip, _i64p]),
+    "nvh_ogg_demux_forward": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, C.c_int, _ip, _i64p, _ip]),
     "nvh_ogg_index_open": (C.c_int, [_vp, C.c_size_t, C.c_int, C.POINTER(_vp)]),
     "nvh_ogg_index_close": (None, [_vp]),
     "nvh_ogg_index_info": (C.c_int, [_vp, _ip, _ip, _ip, _i64p, _ip]),

@@ -57,28 +57,30 @@ def ogg_stream_count(data: bytes):
     return ns.value
 
 
-def demux_ogg_array(data: bytes, stream_index=0):
+def demux_ogg_array(data: bytes, stream_index=0, forward_only=False):
     """Logical stream `stream_index` (default: the first) of an Ogg file as a PacketArray.
 
-    Delivers packets the way NVorbis' seekable reader does (Ogg/PacketProvider.cs:324-438)."""
+    Delivers packets the way NVorbis' seekable reader does (Ogg/PacketProvider.cs:324-438), or -- forward_only -- the way its
+    reader for sources that cannot seek does (Ogg/ForwardOnlyPacketProvider.cs:119-246)."""
     L = lib()
+    fn = L.nvh_ogg_demux_forward if forward_only else L.nvh_ogg_demux_stream
     n = C.c_int(0)
     total = C.c_int64(0)
     k = int(stream_index)
     buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
-    check(L.nvh_ogg_demux_stream(buf, len(data), k, None, 0, None, None, None, 0, C.byref(n), C.byref(total), None), "nvh_ogg_demux")
+    check(fn(buf, len(data), k, None, 0, None, None, None, 0, C.byref(n), C.byref(total), None), "nvh_ogg_demux")
     pk = np.zeros(max(total.value, 1), dtype=np.uint8)
     offs = np.zeros(n.value + 1, dtype=np.int64)
     gran = np.zeros(max(n.value, 1), dtype=np.int64)
     flags = np.zeros(max(n.value, 1), dtype=np.uint8)
-    check(L.nvh_ogg_demux_stream(buf, len(data), k, pk.ctypes.data, pk.size, offs.ctypes.data, gran.ctypes.data,
-                                 flags.ctypes.data, n.value, C.byref(n), C.byref(total), None), "nvh_ogg_demux")
+    check(fn(buf, len(data), k, pk.ctypes.data, pk.size, offs.ctypes.data, gran.ctypes.data,
+             flags.ctypes.data, n.value, C.byref(n), C.byref(total), None), "nvh_ogg_demux")
     return PacketArray(pk, offs[:n.value + 1], gran, flags)
 
 
-def demux_ogg(data: bytes):
+def demux_ogg(data: bytes, forward_only=False):
     """First logical stream of an Ogg file -> (list of packet bytes, granules, flags)."""
-    pa = demux_ogg_array(data)
+    pa = demux_ogg_array(data, 0, forward_only)
     n = len(pa)
     return [pa[i] for i in range(n)], pa.granules[:n].copy(), pa.flags[:n].copy()
 
@@ -662,6 +664,8 @@ class StreamDecoder:
         One place cannot be mirrored: when the roll-forward is longer than the packet's output (possible on the first data
         page, see _provider_seek) the reference's next Read never returns (copyLen < 0 with start != end,
         StreamDecoder.cs:341-377); this raises NvhError(ERR_RUNTIME) instead."""
+        if not getattr(self, "can_seek", True):
+            raise RuntimeError("Seek is not supported by the Contracts.IPacketProvider instance.")  # InvalidOperationException (:565)
         s = int(sample_position)
         if origin == "current":
             s = self.SamplePosition - s
@@ -720,8 +724,11 @@ class StreamDecoder:
 class VorbisReader:
     """VorbisReader-shaped facade (VorbisReader.cs): first logical stream of an .ogg file or byte string."""
 
-    def __init__(self, source, ctx=None, device=0, batch_frames=8192, gpu_parse=True):
+    def __init__(self, source, ctx=None, device=0, batch_frames=8192, gpu_parse=True, forward_only=False):
         # gpu_parse: parse the packets on the GPU too when the stream shape allows it (StreamDecoder falls back silently)
+        # forward_only: read the container the way the reference reads a source that cannot seek (ContainerReader picks
+        # ForwardOnlyPageReader for !stream.CanSeek, Ogg/ContainerReader.cs); SeekTo then raises as IPacketProvider.CanSeek is false
+        self._forward_only = bool(forward_only)
         if isinstance(source, (bytes, bytearray, memoryview)):
             data = bytes(source)
         else:
@@ -741,8 +748,11 @@ class VorbisReader:
                 self._ctx.close()
             raise native.NvhError(native.ERR_NOT_VORBIS, "VorbisReader")  # ArgumentException: could not load the container
         self._stream_index = 0
-        self._dec = StreamDecoder(self._ctx, demux_ogg_array(data, self._stream_ids[0]), None, None, batch_frames, gpu_parse)
-        self._dec.attach_ogg(data, self._stream_ids[0])
+        self._dec = StreamDecoder(self._ctx, demux_ogg_array(data, self._stream_ids[0], self._forward_only), None, None, batch_frames, gpu_parse)
+        if self._forward_only:
+            self._dec.can_seek = False
+        else:
+            self._dec.attach_ogg(data, self._stream_ids[0])
         self._decs = {0: self._dec}  # one decoder per logical stream, created on first use, kept like VorbisReader._decoders
 
     def _is_vorbis(self, k):
@@ -768,9 +778,12 @@ class VorbisReader:
         old = (self.Channels, self.SampleRate)
         clip = self.ClipSamples
         if index not in self._decs:
-            self._decs[index] = StreamDecoder(self._ctx, demux_ogg_array(self._data, self._stream_ids[index]), None, None,
-                                              self._batch_frames, self._gpu_parse)
-            self._decs[index].attach_ogg(self._data, self._stream_ids[index])
+            self._decs[index] = StreamDecoder(self._ctx, demux_ogg_array(self._data, self._stream_ids[index], self._forward_only), None,
+                                              None, self._batch_frames, self._gpu_parse)
+            if self._forward_only:
+                self._decs[index].can_seek = False
+            else:
+                self._decs[index].attach_ogg(self._data, self._stream_ids[index])
         self._dec = self._decs[index]
         self._dec.ClipSamples = clip  # carry-through the clipping setting
         self._stream_index = index

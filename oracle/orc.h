@@ -83,6 +83,15 @@ typedef struct orc_decoder orc_decoder;
 /* Ogg container -> decoder (minimal forward demux: Ogg/PageReaderBase.cs:33-70,227-292,
  * Ogg/PageReader.cs:27-93, Ogg/PacketProvider.cs:324-438, Ogg/Crc.cs).  First logical stream only. */
 orc_decoder *orc_open_ogg(const uint8_t *bytes, size_t len, int *err);
+/* The first logical stream as the reader for sources that cannot seek delivers it: ForwardOnlyPageReader.AddPage +
+ * ForwardOnlyPacketProvider.GetPacket (Ogg/ForwardOnlyPageReader.cs:21-52, Ogg/ForwardOnlyPacketProvider.cs:36-67, 119-284).
+ * Arrays are malloc'ed (caller frees); granule -1 = none (or a page value of -1); flags bit0 = EOS, bit1 = resync. */
+int orc_ogg_demux_forward(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t **out_offs, int64_t **out_granule,
+                          uint8_t **out_flags, int *out_n);
+/* the seekable reader's list (Ogg/PageReader.cs, Ogg/StreamPageReader.cs:44-91, Ogg/PacketProvider.cs:324-438), same convention */
+int orc_ogg_demux(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t **out_offs, int64_t **out_granule,
+                  uint8_t **out_flags, int *out_n);
+void orc_free(void *p);
 /* IPacketProvider.SeekTo(granulePos, preRoll, GetPacketGranules) on the first logical stream of an Ogg file, for a reader
  * that has read every page (Ogg/PacketProvider.cs:56-295, Ogg/StreamPageReader.cs:122-264, StreamDecoder.cs:630-647; d supplies the
  * modes).  *packet_index = position in orc_ogg_demux's list of the packet GetNextPacket returns next, *granule_out = the method's

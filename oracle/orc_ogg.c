@@ -680,3 +680,241 @@ int orc_ogg_max_granule(const uint8_t *bytes, size_t len, int64_t *max_granule) 
   free_pages(&tab);
   return ORC_OK;
 }
+
+/* ================================================================================================
+ * Forward-only reader: ForwardOnlyPageReader.AddPage (Ogg/ForwardOnlyPageReader.cs:21-52) and
+ * ForwardOnlyPacketProvider (Ogg/ForwardOnlyPacketProvider.cs), first logical stream, as a packet list.
+ * ================================================================================================ */
+
+typedef struct {
+  /* the page queue: pages of the stream in file order, pulled one at a time */
+  const uint8_t **queue_buf;
+  uint8_t *queue_resync;
+  int queue_n, queue_pos;
+  /* ForwardOnlyPacketProvider fields (:10-22) */
+  int last_seq_no;
+  const uint8_t *page_buf;
+  int packet_index;
+  int is_end_of_stream;
+  int data_start;
+} fwd_provider;
+
+/* :36-67 */
+static int fwd_add_page(fwd_provider *pp, const uint8_t *buf, int is_resync, int *resync_out) {
+  int ttl = 0, i, seq_no = (int32_t)((uint32_t)buf[18] | ((uint32_t)buf[19] << 8) | ((uint32_t)buf[20] << 16) | ((uint32_t)buf[21] << 24));
+  if (buf[5] & 0x02) { /* PageFlags.BeginningOfStream */
+    if (pp->is_end_of_stream) return 0;
+    is_resync = 1;
+    pp->last_seq_no = seq_no;
+  } else {
+    is_resync |= seq_no != (int32_t)((uint32_t)pp->last_seq_no + 1u);
+    pp->last_seq_no = seq_no;
+  }
+  for (i = 0; i < buf[26]; i++) ttl += buf[27 + i];
+  if (ttl == 0) return 0;
+  *resync_out = is_resync;
+  return 1;
+}
+
+/* :270-284 */
+static int fwd_get_packet_length(const uint8_t *page_buf, int *packet_index) {
+  int len = 0;
+  while (*packet_index < page_buf[26] + 27 && page_buf[*packet_index] == 255) {
+    len += page_buf[*packet_index];
+    ++*packet_index;
+  }
+  if (*packet_index < page_buf[26] + 27) {
+    len += page_buf[*packet_index];
+    ++*packet_index;
+  }
+  return len;
+}
+
+/* :248-268 */
+static int fwd_read_next_page(fwd_provider *pp, const uint8_t **page_buf, int *is_resync, int *data_start, int *packet_index,
+                              int *is_continuation, int *is_continued) {
+  if (pp->queue_pos >= pp->queue_n) { /* queue empty; _isEndOfStream, or the reader finds no further page */
+    *page_buf = NULL;
+    *is_resync = 0;
+    *data_start = 0;
+    *packet_index = 0;
+    *is_continuation = 0;
+    *is_continued = 0;
+    return 0;
+  }
+  *page_buf = pp->queue_buf[pp->queue_pos];
+  *is_resync = pp->queue_resync[pp->queue_pos];
+  pp->queue_pos++;
+  *data_start = (*page_buf)[26] + 27;
+  *packet_index = 27;
+  *is_continuation = ((*page_buf)[5] & 0x01) != 0;
+  *is_continued = (*page_buf)[26 + (*page_buf)[26]] == 255;
+  return 1;
+}
+
+int orc_ogg_demux_forward(const uint8_t *bytes, size_t len, uint8_t **out_bytes, int64_t **out_offs, int64_t **out_granule,
+                          uint8_t **out_flags, int *out_n) {
+  fwd_provider pp;
+  pkt_list pl;
+  size_t pos = 0;
+  int resync = 0, have_serial = 0, ignored = 0, rc = ORC_OK, qcap = 0, gone = 0;
+  int32_t serial = 0;
+  memset(&pp, 0, sizeof pp);
+  memset(&pl, 0, sizeof pl);
+  pp.packet_index = 0x7fffffff; /* "force the first page to read" (:29-30) */
+  if (!g_crc_ready) crc_init();
+
+  /* PageReaderBase.ReadNextPage (Ogg/PageReaderBase.cs:227-292) over the whole input */
+  while (pos + 27 <= len) {
+    const uint8_t *h = bytes + pos;
+    int seg_cnt, data_len = 0, s;
+    size_t total;
+    if (!(h[0] == 0x4f && h[1] == 0x67 && h[2] == 0x67 && h[3] == 0x53)) {
+      pos++;
+      resync = 1;
+      continue;
+    }
+    seg_cnt = h[26];
+    if (pos + 27 + (size_t)seg_cnt > len) {
+      pos++;
+      resync = 1;
+      continue;
+    }
+    for (s = 0; s < seg_cnt; s++) data_len += h[27 + s];
+    total = 27 + (size_t)seg_cnt + (size_t)data_len;
+    if (pos + total > len || !verify_page(h, total)) {
+      pos++;
+      resync = 1;
+      continue;
+    }
+    {
+      int32_t pg_serial = (int32_t)((uint32_t)h[14] | ((uint32_t)h[15] << 8) | ((uint32_t)h[16] << 16) | ((uint32_t)h[17] << 24));
+      if (!have_serial) {
+        have_serial = 1;
+        serial = pg_serial;
+      }
+      if (pg_serial == serial && !ignored && !gone) {
+        int pg_resync = 0;
+        if (fwd_add_page(&pp, h, resync, &pg_resync)) {
+          if (pp.queue_n == qcap) {
+            int cap = qcap ? qcap * 2 : 64;
+            const uint8_t **nb = (const uint8_t **)realloc((void *)pp.queue_buf, sizeof *nb * (size_t)cap);
+            uint8_t *nr = nb ? (uint8_t *)realloc(pp.queue_resync, (size_t)cap) : NULL;
+            if (nb) pp.queue_buf = nb;
+            if (nr) pp.queue_resync = nr;
+            if (!nb || !nr) {
+              rc = ORC_ERR_NOMEM;
+              goto done;
+            }
+            qcap = cap;
+          }
+          pp.queue_buf[pp.queue_n] = h;
+          pp.queue_resync[pp.queue_n] = (uint8_t)pg_resync;
+          pp.queue_n++;
+          if (h[5] & 0x04) { /* ForwardOnlyPageReader.cs:28-33: SetEndOfStream, the provider leaves the reader's list */
+            pp.is_end_of_stream = 1;
+            gone = 1; /* a later page with this serial would open another stream: not this one's business */
+          }
+        } else {
+          ignored = 1; /* PageReaderBase.AddPage: the serial goes on the ignore list (:72-85) */
+        }
+      }
+      resync = 0;
+      pos += total;
+    }
+  }
+  pp.is_end_of_stream = 0; /* the flag is raised when the EOS page is READ, which happens when the queue runs dry: see below */
+
+  /* GetNextPacket until null: GetPacket (:119-246) */
+  for (;;) {
+    const uint8_t *page_buf;
+    int is_resync, data_start, packet_index, is_cont, is_cntd, is_first, data_len, is_last, is_eos = 0, has_granule = 0;
+    int64_t granule_pos = 0;
+    size_t first_off;
+    if (pp.page_buf != NULL && pp.packet_index < 27 + pp.page_buf[26]) {
+      page_buf = pp.page_buf;
+      is_resync = 0;
+      data_start = pp.data_start;
+      packet_index = pp.packet_index;
+      is_cont = 0;
+      is_cntd = page_buf[26 + page_buf[26]] == 255;
+    } else {
+      if (!fwd_read_next_page(&pp, &page_buf, &is_resync, &data_start, &packet_index, &is_cont, &is_cntd)) break;
+    }
+    is_first = packet_index == 27;
+    if (is_cont) {
+      if (is_first) {
+        is_resync = 1;
+        (void)fwd_get_packet_length(page_buf, &packet_index); /* contOverhead += ...: the data offset is NOT advanced (:152) */
+        if (packet_index == 27 + page_buf[26]) continue;      /* return GetPacket(): the saved page is still the previous one */
+      }
+    }
+    data_len = fwd_get_packet_length(page_buf, &packet_index);
+    if ((rc = pl_begin(&pl)) != ORC_OK) goto done;
+    first_off = (size_t)(page_buf - bytes) + (size_t)data_start;
+    {
+      size_t avail = first_off <= len ? len - first_off : 0, take = (size_t)data_len <= avail ? (size_t)data_len : avail;
+      if ((rc = pl_append(&pl, bytes + first_off, take)) != ORC_OK) goto done;
+      while (take < (size_t)data_len) { /* (cannot happen: the stale offset only ever points earlier) */
+        static const uint8_t zero = 0;
+        if ((rc = pl_append(&pl, &zero, 1)) != ORC_OK) goto done;
+        take++;
+      }
+    }
+    data_start += data_len;
+    is_last = packet_index == 27 + page_buf[26];
+    if (is_cntd) {
+      if (is_last) {
+        is_last = 0;
+      } else {
+        int pi = packet_index;
+        (void)fwd_get_packet_length(page_buf, &pi);
+        is_last = pi == 27 + page_buf[26];
+      }
+    }
+    if (is_last) {
+      memcpy(&granule_pos, page_buf + 6, 8);
+      has_granule = 1;
+      if ((page_buf[5] & 0x04) != 0) is_eos = 1; /* (_isEndOfStream && _pageQueue.Count == 0): never true before this page */
+    } else {
+      while (is_cntd && packet_index == 27 + page_buf[26]) {
+        if (fwd_read_next_page(&pp, &page_buf, &is_resync, &data_start, &packet_index, &is_cont, &is_cntd) && !is_resync && is_cont) {
+          int cont_sz = fwd_get_packet_length(page_buf, &packet_index);
+          if ((rc = pl_append(&pl, page_buf + data_start, (size_t)cont_sz)) != ORC_OK) goto done;
+          data_start += cont_sz;
+        } else {
+          break;
+        }
+      }
+    }
+    if (is_resync) pl.flags[pl.n] |= 2;
+    if (has_granule) pl.granule[pl.n] = granule_pos;
+    if (is_eos) pl.flags[pl.n] |= 1;
+    pl.n++;
+    pp.page_buf = page_buf;
+    pp.data_start = data_start;
+    pp.packet_index = packet_index;
+    if (page_buf == NULL) pp.packet_index = 0x7fffffff;
+  }
+  if ((rc = pl_begin(&pl)) != ORC_OK) goto done;
+
+done:
+  free((void *)pp.queue_buf);
+  free(pp.queue_resync);
+  if (rc != ORC_OK) {
+    free(pl.bytes);
+    free(pl.offs);
+    free(pl.granule);
+    free(pl.flags);
+    return rc;
+  }
+  if (!pl.bytes) pl.bytes = (uint8_t *)malloc(1);
+  *out_bytes = pl.bytes;
+  *out_offs = pl.offs;
+  *out_granule = pl.granule;
+  *out_flags = pl.flags;
+  *out_n = pl.n;
+  return ORC_OK;
+}
+
+void orc_free(void *p) { free(p); }

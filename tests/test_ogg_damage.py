@@ -11,12 +11,13 @@ import pytest
 from tests import ogg_py, vorbis_encode as ve
 
 
-def _oracle_demux(oracle, data):
+def _oracle_demux(oracle, data, forward_only=False):
     L = oracle.L
-    L.orc_ogg_demux.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    fn = L.orc_ogg_demux_forward if forward_only else L.orc_ogg_demux
+    fn.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                   C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     b, o, g, f, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
-    rc = L.orc_ogg_demux(data, len(data), C.byref(b), C.byref(o), C.byref(g), C.byref(f), C.byref(n))
+    rc = fn(data, len(data), C.byref(b), C.byref(o), C.byref(g), C.byref(f), C.byref(n))
     if rc != 0:
         return rc, None
     cnt = n.value
@@ -31,11 +32,11 @@ def _oracle_demux(oracle, data):
     return 0, ([raw[int(offs[i]):int(offs[i + 1])] for i in range(cnt)], gran.tolist(), flags.tolist())
 
 
-def _product_demux(data):
+def _product_demux(data, forward_only=False):
     import nvorbis_amd as nv
     from nvorbis_amd import native
     try:
-        pk, gr, fl = nv.demux_ogg(data)
+        pk, gr, fl = nv.demux_ogg(data, forward_only)
     except native.NvhError as e:
         return e.code, None
     return 0, (pk, gr.tolist(), fl.tolist())
@@ -111,6 +112,98 @@ def test_undamaged_stream_has_no_resync(oracle, ogg_bytes):
     assert rc_o == 0 and got_o == got
 
 
+# ---- the reader for sources that cannot seek (Ogg/ForwardOnlyPageReader.cs, Ogg/ForwardOnlyPacketProvider.cs) ----
+
+def test_forward_only_reader_on_intact_files(oracle, ogg_bytes):
+    """ForwardOnlyPacketProvider on well-formed files: the same packet bytes as the seekable reader; the first packet is a resync
+    packet (the beginning-of-stream page, Ogg/ForwardOnlyPacketProvider.cs:38-46); granule positions and the end-of-stream mark
+    sit on the last packet that is complete on its page; product == restatement."""
+    for name in ("1test", "2test", "3test", "issue6test"):
+        data = ogg_bytes[name]
+        rc, fwd = _product_demux(data, True)
+        rc_o, fwd_o = _oracle_demux(oracle, data, True)
+        assert rc == 0 and rc_o == 0 and fwd == fwd_o, name
+        _, seek = _product_demux(data, False)
+        assert fwd[0] == seek[0], name                 # same packets
+        assert fwd[2][0] & 2 and not any(f & 2 for f in fwd[2][1:])
+        # granule positions only differ around packets that span pages (3test.ogg: the setup header and three audio packets):
+        # the forward-only provider gives such a packet none and stamps the packet before it with its page's value instead
+        diff = [i for i in range(len(seek[1])) if seek[1][i] != fwd[1][i]]
+        assert all(seek[1][i] == -1 or fwd[1][i] == -1 for i in diff), (name, diff[:5])
+        assert len(diff) <= 40
+        assert (fwd[2][-1] & 1) == (seek[2][-1] & 1)
+
+
+@pytest.mark.parametrize("page_packets,max_segments", [(4, 255), (3, 9), (None, 5)])
+def test_forward_only_reader_with_continued_packets(oracle, ogg_bytes, page_packets, max_segments):
+    """Packets that continue over two and more pages: assembled, but without granule position or end-of-stream mark
+    (Ogg/ForwardOnlyPacketProvider.cs:176-231); product == restatement, and the bytes are the seekable reader's."""
+    hdr = ve.shipped_headers(ogg_bytes["3test"])
+    S = ve.setup_of(hdr)
+    rng = np.random.default_rng(4)
+    kinds = ve.markov_kinds(rng, 200, 0.1, 0.3)
+    kinds[:3] = True
+    pool = ve.packet_pool(S, 2, per_kind=6)
+    pk, gr = ve.stream_from_pool(S, hdr, pool, kinds, rng)
+    data = ogg_py.write_ogg(pk, gr, page_packets=page_packets, max_segments=max_segments)
+    rc, fwd = _product_demux(data, True)
+    rc_o, fwd_o = _oracle_demux(oracle, data, True)
+    assert rc == 0 and rc_o == 0 and fwd == fwd_o
+    assert fwd[0] == [bytes(p) for p in pk]
+    _, seek = _product_demux(data, False)
+    if max_segments < 255:
+        lost = [i for i in range(len(pk)) if seek[1][i] >= 0 and fwd[1][i] < 0]
+        assert lost, "no continued packet carried a granule position in the seekable list"
+
+
+@pytest.mark.parametrize("kind", ["crc", "drop", "junk", "seq", "truncate", "zero"])
+def test_forward_only_reader_on_damaged_files(oracle, ogg_bytes, kind):
+    """Damage, forward-only: sequence gaps and lost sync mark packets as resync; a page that begins with the tail of a lost packet
+    has its packets cut from the start of the page data (the skipped tail's length is never added to the data offset,
+    Ogg/ForwardOnlyPacketProvider.cs:147-165) -- the product cuts the same bytes; a zero-length packet is delivered (:270-284)."""
+    rng = np.random.default_rng(hash(kind) & 0xFFF)
+    seen_resync = seen_shift = seen_empty = False
+    for trial in range(6):
+        if kind == "zero":
+            hdr = ve.shipped_headers(ogg_bytes["3test"])
+            S = ve.setup_of(hdr)
+            pool = ve.packet_pool(S, 3, per_kind=4)
+            kinds = np.ones(40, dtype=bool)
+            pk, gr = ve.stream_from_pool(S, hdr, pool, kinds, np.random.default_rng(trial))
+            pk = list(pk)
+            pk.insert(10 + trial, b"")  # an empty packet between two audio packets: lacing value 0
+            gr = list(gr)
+            gr.insert(10 + trial, gr[9 + trial])
+            bad = ogg_py.write_ogg(pk, gr, page_packets=5)
+        else:
+            hdr = ve.shipped_headers(ogg_bytes["3test"])
+            S = ve.setup_of(hdr)
+            r2 = np.random.default_rng(trial + 1)
+            kinds = ve.markov_kinds(r2, 90, 0.1, 0.3)
+            kinds[:4] = True
+            pool = ve.packet_pool(S, trial + 1, per_kind=8)
+            pk, gr = ve.stream_from_pool(S, hdr, pool, kinds, r2)
+            # small pages: packets continue across them, so that a lost page leaves a continuation page at a packet start
+            data = ogg_py.write_ogg(pk, gr, page_packets=int(rng.integers(2, 5)), max_segments=int(rng.integers(3, 12)))
+            bad = _damage(data, ogg_py.read_pages(data), kind, rng)
+        rc_o, got_o = _oracle_demux(oracle, bad, True)
+        rc_p, got_p = _product_demux(bad, True)
+        assert rc_o == 0 and rc_p == 0
+        assert got_o == got_p, (kind, trial)
+        seen_resync = seen_resync or any(f & 2 for f in got_p[2][1:])
+        seen_empty = seen_empty or any(len(p) == 0 for p in got_p[0])
+        _, seek = _product_demux(bad, False)
+        if seek is not None:
+            whole = set(bytes(p) for p in pk)
+            seen_shift = seen_shift or any(bytes(p) not in whole and len(p) > 0 for p in got_p[0][3:])
+    if kind in ("crc", "drop", "junk", "seq"):
+        assert seen_resync
+    if kind == "zero":
+        assert seen_empty
+    if kind == "drop":
+        assert seen_shift, "no trial produced a page whose packets are cut from the wrong offset"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["crc", "drop", "junk", "seq"])
 def test_damaged_files_decode_like_the_oracle(oracle, gpu_ctx, ogg_bytes, kind):
@@ -127,3 +220,24 @@ def test_damaged_files_decode_like_the_oracle(oracle, gpu_ctx, ogg_bytes, kind):
             got = rd.read_all()
             rd.close()
             assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (kind, trial, gpu_parse)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["3test", "issue6test"])
+def test_forward_only_reader_decodes_like_the_oracle(oracle, gpu_ctx, ogg_bytes, name):
+    """VorbisReader(forward_only=True): the packets ForwardOnlyPacketProvider delivers (first packet a resync packet, continued
+    packets without granule position) through the GPU path == the oracle's decoder fed the oracle's forward-only list; seeking is
+    refused the way StreamDecoder.SeekTo refuses a provider that cannot seek (StreamDecoder.cs:565)."""
+    import nvorbis_amd as nv
+    data = ogg_bytes[name]
+    rc, (pk, gr, fl) = _oracle_demux(oracle, data, True)
+    assert rc == 0
+    ref, _ = oracle.decode_packets(pk, gr, fl)
+    rd = nv.VorbisReader(data, ctx=gpu_ctx, batch_frames=200, forward_only=True)
+    try:
+        got = rd.read_all()
+        assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        with pytest.raises(RuntimeError):
+            rd.SeekTo(1000)
+    finally:
+        rd.close()
