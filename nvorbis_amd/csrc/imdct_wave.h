@@ -42,6 +42,14 @@ __device__ __forceinline__ void wave_sync() {
 // LDS layout: complex point c (float2) lives at float2 slot c + 8*(c>>6): the pad keeps the stride-8 and
 // stride-64 set patterns of the radix passes off each other's banks.
 __device__ __forceinline__ int phys(int c) { return c + ((c >> 6) << 3); }
+// The same slots with the four 16-byte chunks of every 8-point block rotated by (block / 4) mod 4: the layout between the
+// last radix pass and the end of the looped transform.  The D = 4, 2, 1 pass has every lane read a whole block (4 x 16 bytes,
+// all lanes at multiples of 64 bytes): unrotated, a 16-lane group of a ds_read_b128 hits 4 of the 16 slot residues -- 4-way
+// bank conflicts on all of its 8 LDS instructions (rocprofv3: 44 % of the transform's LDS cycles were conflict cycles).
+__device__ __forceinline__ int phys_rot(int c) {
+  const int b = c >> 3, p = c & 7;
+  return ((b + (b >> 3)) << 3) + ((((p >> 1) + (b >> 2)) & 3) << 1) + (p & 1);
+}
 
 template <int LD>
 struct Geo {
@@ -55,7 +63,7 @@ struct Geo {
 
 // One register pass over R radix-2 stages whose smallest distance is S complex points.
 // TW: this pass's lane-ordered twiddles, [pair component][set] (host_setup.cpp build_mdct_tables).
-template <int LD, int R, int S>
+template <int LD, int R, int S, bool ROT_OUT = false>
 __device__ __forceinline__ void radix_pass(float2* __restrict__ l2, const float* __restrict__ TW, int lane) {
   using G = Geo<LD>;
   constexpr int K = 1 << R;
@@ -92,7 +100,7 @@ __device__ __forceinline__ void radix_pass(float2* __restrict__ l2, const float*
       }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) l2[phys(base + S * k)] = v[k];
+    for (int k = 0; k < K; ++k) l2[ROT_OUT ? phys_rot(base + S * k) : phys(base + S * k)] = v[k];
   }
 }
 
@@ -119,7 +127,7 @@ __device__ __forceinline__ void iter_54_regs(float* e, int zo /* index of u[z] i
 }
 
 // Fused last three stages (Mdct.cs:463-507): blocks of 8 consecutive complex points.
-template <int LD>
+template <int LD, bool ROT = false>
 __device__ __forceinline__ void ld654_pass(float2* __restrict__ l2, const float* __restrict__ A, int lane) {
   using G = Geo<LD>;
   const float A2 = A[G::n >> 3];
@@ -128,9 +136,10 @@ __device__ __forceinline__ void ld654_pass(float2* __restrict__ l2, const float*
     const int c0 = G::N - 8 - 8 * q;  // complex index of u[z-15], z = n2-1-16q
     float e[16];
     float4* p4 = reinterpret_cast<float4*>(l2 + phys(c0));
+    const int rot = ROT ? (c0 >> 5) & 3 : 0;  // (block / 4) mod 4, see phys_rot
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float4 t = p4[j];
+      float4 t = p4[(j + rot) & 3];
       e[4 * j] = t.x; e[4 * j + 1] = t.y; e[4 * j + 2] = t.z; e[4 * j + 3] = t.w;
     }
 #define U(k) e[15 - (k)]
@@ -166,7 +175,7 @@ __device__ __forceinline__ void ld654_pass(float2* __restrict__ l2, const float*
     iter_54_regs(e, 15);
     iter_54_regs(e, 7);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p4[j] = make_float4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+    for (int j = 0; j < 4; ++j) p4[(j + rot) & 3] = make_float4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
   }
 }
 
@@ -176,7 +185,7 @@ struct Passes {
   static __device__ __forceinline__ void run(float2* l2, const float* TW, int lane) {
     constexpr int R = REMAIN >= 3 ? 3 : REMAIN;
     constexpr int S = 8 << (REMAIN - R);
-    radix_pass<LD, R, S>(l2, TW, lane);
+    radix_pass<LD, R, S, (REMAIN - R == 0)>(l2, TW, lane);  // the last pass leaves the rotated layout (phys_rot)
     wave_sync();
     Passes<LD, REMAIN - R>::run(l2, TW + 2 * ((1 << R) - 1) * (Geo<LD>::N >> R), lane);
   }
@@ -246,7 +255,7 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
   IMDCT_T(2);
 
   // D = 4, 2, 1
-  ld654_pass<LD>(l2, A, lane);
+  ld654_pass<LD, true>(l2, A, lane);
   wave_sync();
   IMDCT_T(3);
 
@@ -266,11 +275,11 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       const int kD0 = (int)(__brev((unsigned)(2 * ir)) >> (32 - (LD - 3))) << 2;
       const int kD1 = (int)(__brev((unsigned)(2 * ir + 1)) >> (32 - (LD - 3))) << 2;
       // v[d1+3]=u[k], v[d1+2]=u[k+1] (k=BR[2i]); v[d1+1]=u[k'], v[d1]=u[k'+1] (k'=BR[2i+1]); d1 = n2-4-4i
-      const float2 e0 = *reinterpret_cast<const float2*>(lf + 2 * phys(kE0 >> 1));
-      const float2 e1 = *reinterpret_cast<const float2*>(lf + 2 * phys(kE1 >> 1));
+      const float2 e0 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot(kE0 >> 1));
+      const float2 e1 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot(kE1 >> 1));
       // v[d0+3]=u[k+2], v[d0+2]=u[k+3] (k=BR[2i']); v[d0+1]=u[k'+2], v[d0]=u[k'+3]; d0 = n4-4-4i' = 4i
-      const float2 g0 = *reinterpret_cast<const float2*>(lf + 2 * phys((kD0 >> 1) + 1));
-      const float2 g1 = *reinterpret_cast<const float2*>(lf + 2 * phys((kD1 >> 1) + 1));
+      const float2 g0 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot((kD0 >> 1) + 1));
+      const float2 g1 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot((kD1 >> 1) + 1));
       float vD0 = g1.y, vD1 = g1.x, vD2 = g0.y, vD3 = g0.x;  // v[4i .. 4i+3]
       float vE0 = e1.y, vE1 = e1.x, vE2 = e0.y, vE3 = e0.x;  // v[n2-4-4i .. n2-1-4i]
       // step 7 (Mdct.cs:217-258) for iteration i: c = d = 4i, e = n2-4-4i
