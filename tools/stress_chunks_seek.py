@@ -51,6 +51,10 @@ def check(tag, pk, gr, fl, rng, gp):
             lead = int(np.searchsorted(gpos, t, side="left")) - 1
             if lead >= 0 and not (state[lead] & 2):
                 continue
+            # the two packets SeekTo reads are read against the position BEFORE the seek (ResetDecoder leaves _currentPosition
+            # alone, StreamDecoder.cs:294-305): an end-of-stream trim among them is not the serial decode's
+            if any(fl[i] & 1 for i in range(3 + max(lead, 0), min(3 + lead + 2, len(fl)))):
+                continue
             assert n == want.size and np.array_equal(buf[:n].view(np.uint32), want.view(np.uint32)), (tag, t)
             seeks += 1
     finally:
