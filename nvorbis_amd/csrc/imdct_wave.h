@@ -204,11 +204,13 @@ struct Passes<LD, 0> {
 // WGSYNC (with INPLACE): the slice may overlay OTHER wavefronts' spectra as well -- a workgroup barrier, not the
 // wavefront's own program order, separates the spectrum loads from the first store (every wavefront of the workgroup
 // passes exactly one __syncthreads; those without a transform of their own call it themselves).
-template <int LD, bool WIN, typename Sink, bool INPLACE = false, bool WGSYNC = false>
+// PRESYNC (with INPLACE): the caller's workgroup barrier in front of the transform (the spectrum is other wavefronts' work too) is
+// taken HERE, after the step-0 twiddle loads have been issued, so that their L2 round trip overlaps the wait.
+template <int LD, bool WIN, typename Sink, bool INPLACE = false, bool WGSYNC = false, bool PRESYNC = false>
 __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __restrict__ w, float* lds,
                                                 const float* __restrict__ A, const float* __restrict__ B,
                                                 const float* __restrict__ C, const float* __restrict__ TW, int lane,
-                                                Sink sink, long long* stamp = nullptr) {
+                                                Sink sink, long long* stamp = nullptr, int dbg_skip = 0) {
   using G = Geo<LD>;
   float2* l2 = reinterpret_cast<float2*>(lds);
   // profiling builds: shader-clock stamps of lane 0 (0 entry, 1 step 0 done, 2 radix passes done, 3 D=4,2,1 done, 4 end)
@@ -217,9 +219,7 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
 
   // step 0 (Mdct.cs:74-97).  The float4 at X[4j] feeds the first-half item j (even elements) and the
   // second-half item n8-1-j (odd elements): complex points N-1-j and j.
-  auto step0 = [&](int j, const float4 x) {
-    const float2 a_lo = reinterpret_cast<const float2*>(A)[j];                // A[2j], A[2j+1]
-    const float2 a_hi = reinterpret_cast<const float2*>(A)[G::n4 - 1 - j];    // A[n2-2-2j], A[n2-1-2j]
+  auto step0 = [&](int j, const float4 x, const float2 a_lo, const float2 a_hi) {
     float2 hi, lo;
     hi.y = (x.x * a_lo.x - x.z * a_lo.y);      // buf2[d+1], d = n2-2-2j
     hi.x = (x.x * a_lo.y + x.z * a_lo.x);      // buf2[d]
@@ -228,9 +228,19 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
     l2[phys(G::N - 1 - j)] = hi;
     l2[phys(j)] = lo;
   };
+  const float2* A2 = reinterpret_cast<const float2*>(A);  // a_lo = A[2j], A[2j+1]; a_hi = A[n2-2-2j], A[n2-1-2j]
   if constexpr (INPLACE) {
     constexpr int J = (G::n8 + 63) / 64;
     static_assert(J <= (WGSYNC ? 8 : 4), "in-place form keeps the spectrum in registers");
+    float2 pa_lo[J], pa_hi[J];
+#pragma unroll
+    for (int r = 0; r < J; ++r) {
+      const int j = lane + 64 * r;
+      const int jc = j < G::n8 ? j : G::n8 - 1;
+      pa_lo[r] = A2[jc];
+      pa_hi[r] = A2[G::n4 - 1 - jc];
+    }
+    if constexpr (PRESYNC) __syncthreads();
     float4 xin[J];
 #pragma unroll
     for (int r = 0; r < J; ++r) {
@@ -241,21 +251,35 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
 #pragma unroll
     for (int r = 0; r < J; ++r) {
       const int j = lane + 64 * r;
-      if (j < G::n8) step0(j, xin[r]);
+      if (j < G::n8) step0(j, xin[r], pa_lo[r], pa_hi[r]);
     }
   } else {
 #pragma unroll 1
-    for (int j = lane; j < G::n8; j += 64) step0(j, reinterpret_cast<const float4*>(X)[j]);
+    for (int j = lane; j < G::n8; j += 64) step0(j, reinterpret_cast<const float4*>(X)[j], A2[j], A2[G::n4 - 1 - j]);
   }
   wave_sync();
   IMDCT_T(1);
 
-  // radix-2 stages D = N/2 ... 8, three per register pass
-  Passes<LD, LD - 5>::run(l2, TW, lane);
+  // radix-2 stages D = N/2 ... 8, three per register pass (dbg_skip: profiling builds time the kernel without them)
+  if (!(dbg_skip & 1)) Passes<LD, LD - 5>::run(l2, TW, lane);
   IMDCT_T(2);
 
+  // the output stage's tables (_c, _b): with one pair index per lane they are fetched here, a phase ahead of their use
+  constexpr bool kPre = INPLACE && !WGSYNC && (G::n >> 5) <= 64;
+  float4 pcc[2], pbl[2], pbh[2];
+  if constexpr (kPre) {
+    const int pp = lane < (G::n >> 5) ? lane : (G::n >> 5) - 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      pcc[h] = reinterpret_cast<const float4*>(C)[2 * pp + h];
+      const int i8 = h == 0 ? pp : (G::n >> 4) - 1 - pp;
+      const int b = G::n2 - 8 - 8 * i8;
+      pbl[h] = *reinterpret_cast<const float4*>(B + b);
+      pbh[h] = *reinterpret_cast<const float4*>(B + b + 4);
+    }
+  }
   // D = 4, 2, 1
-  ld654_pass<LD, true>(l2, A, lane);
+  if (!(dbg_skip & 2)) ld654_pass<LD, true>(l2, A, lane);
   wave_sync();
   IMDCT_T(3);
 
@@ -283,7 +307,8 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       float vD0 = g1.y, vD1 = g1.x, vD2 = g0.y, vD3 = g0.x;  // v[4i .. 4i+3]
       float vE0 = e1.y, vE1 = e1.x, vE2 = e0.y, vE3 = e0.x;  // v[n2-4-4i .. n2-1-4i]
       // step 7 (Mdct.cs:217-258) for iteration i: c = d = 4i, e = n2-4-4i
-      const float4 cc = reinterpret_cast<const float4*>(C)[i];
+      float4 cc;
+      if constexpr (kPre) cc = pcc[h]; else cc = reinterpret_cast<const float4*>(C)[i];
       float a02, a11, b0, b1, b2, b3;
       a02 = vD0 - vE2;
       a11 = vD1 + vE3;
@@ -309,8 +334,14 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       const float* vv = h == 0 ? ve : vd;
       const int i8 = h == 0 ? p : (G::n >> 4) - 1 - p;
       const int b = G::n2 - 8 - 8 * i8;
-      const float4 b_lo = *reinterpret_cast<const float4*>(B + b);      // B[b .. b+3]
-      const float4 b_hi = *reinterpret_cast<const float4*>(B + b + 4);  // B[b+4 .. b+7]
+      float4 b_lo, b_hi;  // B[b .. b+3], B[b+4 .. b+7]
+      if constexpr (kPre) {
+        b_lo = pbl[h];
+        b_hi = pbh[h];
+      } else {
+        b_lo = *reinterpret_cast<const float4*>(B + b);
+        b_hi = *reinterpret_cast<const float4*>(B + b + 4);
+      }
       float p0, p1, p2, p3;
       float4 o0, o1, o2, o3;
       p3 = vv[6] * b_hi.w - vv[7] * b_hi.z;
@@ -583,16 +614,16 @@ __device__ __forceinline__ void imdct_wave_fast(const float* X, const float* __r
 // and are rebuilt, windowed, by k_ola_compact.  Halves the bytes this kernel writes and the next one reads.
 // LEAN: the looped form with the spectrum preloaded (fits 64 VGPRs; X may alias the wavefront's LDS slice) instead
 // of the everything-prefetched form (~100 VGPRs): for callers that bring their own occupancy (kernels_spectrum.hip).
-template <int LD, bool WIN, bool COMPACT = false, bool LEAN = false, bool WGSYNC = false>
+template <int LD, bool WIN, bool COMPACT = false, bool LEAN = false, bool WGSYNC = false, bool PRESYNC = false>
 __device__ __forceinline__ void imdct_wave(const float* X, float* out, const float* __restrict__ w, float* lds,
                                            const float* __restrict__ A, const float* __restrict__ B,
                                            const float* __restrict__ C, const float* __restrict__ TW, int lane,
-                                           long long* stamp = nullptr) {
+                                           long long* stamp = nullptr, int dbg_skip = 0) {
   auto sink = [=](int slot, int idx, float4 v) {
     if (!COMPACT || (slot & 1) == 0) *reinterpret_cast<float4*>(out + idx) = v;
   };
   if constexpr (LEAN)
-    imdct_wave_sink<LD, WIN, decltype(sink), true, WGSYNC>(X, w, lds, A, B, C, TW, lane, sink, stamp);
+    imdct_wave_sink<LD, WIN, decltype(sink), true, WGSYNC, PRESYNC>(X, w, lds, A, B, C, TW, lane, sink, stamp, dbg_skip);
   else if constexpr (LD <= 11)
     imdct_wave_fast<LD, WIN>(X, w, lds, A, B, C, TW, lane, sink);
   else

@@ -500,29 +500,34 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
       // wavefront has fully in registers before its first store (imdct_wave_fast loads everything up front):
       // channel nch-1 spills its padding past the end of the spectrum area, the one before it into the (dead)
       // staging area in front of it.
-      __syncthreads();
-      if (wv < nch) {
+      // The workgroup barrier between the floor multiply and the transform sits INSIDE imdct_wave<.., PRESYNC> for the
+      // wavefronts that transform (behind their first table loads), and here for the others: one barrier each.
+      if (wv < nch && ((fr.exec_mask >> wv) & 1u)) {
         const float* X = spec + wv * half;
         float* out = planes + (long long)wv * S.block1;
-        if (!((fr.exec_mask >> wv) & 1u)) {
+        float* scratch = spec + wv * half - (nch - 1 - wv) * (fr.n >> 4);
+        const int sl = fr.mdct_slot;
+        const float* A = S.mdct_a[sl];
+        const float* B = S.mdct_b[sl];
+        const float* C = S.mdct_c[sl];
+        const float* TW = S.mdct_tw[sl];
+        long long* stamp = (dbg && wv == 0) ? dbg + (long long)blockIdx.x * 24 + 8 : nullptr;  // profiling builds
+        const int skip = (phase_mask >> 4) & 3;
+        switch (fr.n) {
+          case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp, skip); break;
+          case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp, skip); break;
+          case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp, skip); break;
+          case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp, skip); break;
+          default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
+        }
+      } else {
+        __syncthreads();
+        if (wv < nch) {
           // Mapping.cs:192-196: the residue stays in [0, n/2) (k_ola_compact windows it); its tail quarter is zero
+          const float* X = spec + wv * half;
+          float* out = planes + (long long)wv * S.block1;
           for (int i = lane * 4; i < half; i += 256) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(X + i);
           for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        } else {
-          float* scratch = spec + wv * half - (nch - 1 - wv) * (fr.n >> 4);
-          const int sl = fr.mdct_slot;
-          const float* A = S.mdct_a[sl];
-          const float* B = S.mdct_b[sl];
-          const float* C = S.mdct_c[sl];
-          const float* TW = S.mdct_tw[sl];
-          long long* stamp = (dbg && wv == 0) ? dbg + (long long)blockIdx.x * 24 + 8 : nullptr;  // profiling builds
-          switch (fr.n) {
-            case 256: imdct_wave<8, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp); break;
-            case 512: imdct_wave<9, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp); break;
-            case 1024: imdct_wave<10, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp); break;
-            case 2048: imdct_wave<11, false, true, true>(X, out, nullptr, scratch, A, B, C, TW, lane, stamp); break;
-            default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
-          }
         }
       }
     }
