@@ -622,10 +622,25 @@ extern "C" int nvh_batch_time(nvh_batch* b, float* d_pcm, int64_t capacity, int 
     hipStream_t st = s->ctx->stream;
     float km[4] = {0, 0, 0, 0};
     if (kernel_ms) {
+      // all iterations queued back to back, five events each, read afterwards (batch_launch: ext_ev)
+      std::vector<ScopedEvent> evs((size_t)iters * 5);
+      std::vector<hipEvent_t> raw((size_t)iters * 5);
+      for (size_t k = 0; k < evs.size(); k++) {
+        int rc = evs[k].create();
+        if (rc != NVH_OK) return rc;
+        raw[k] = evs[k].e;
+      }
       for (int i = 0; i < iters; i++) {
-        int rc = batch_launch(b, (const float*)b->carry_in.p, (float*)s->carry[s->carry_cur].p, d_pcm, true, km);
+        int rc = batch_launch(b, (const float*)b->carry_in.p, (float*)s->carry[s->carry_cur].p, d_pcm, true, km, &raw[(size_t)i * 5]);
         if (rc != NVH_OK) return rc;
       }
+      HIP_TRY(hipEventSynchronize(raw.back()));
+      for (int i = 0; i < iters; i++)
+        for (int k = 0; k < 4; k++) {
+          float ms = 0;
+          HIP_TRY(hipEventElapsedTime(&ms, raw[(size_t)i * 5 + k], raw[(size_t)i * 5 + k + 1]));
+          km[k] += ms;
+        }
       for (int k = 0; k < 4; k++) kernel_ms[k] = km[k] / (float)iters;
     }
     if (total_ms) {

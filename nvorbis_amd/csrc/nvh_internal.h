@@ -329,6 +329,7 @@ int get_mdct(nvh_ctx* c, int n, MdctDev** out);                 // nvh_ops.hip
 int upload_setup(nvh_stream* s);                                 // nvh_setup.hip
 int upload_parse_tables(nvh_stream* s);                          // nvh_setup.hip
 int batch_upload(nvh_stream* s, nvh_batch* b);                   // nvh_launch.hip
-int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms);  // nvh_launch.hip
+int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms,
+                 hipEvent_t* ext_ev = nullptr);  // nvh_launch.hip
 int collect_flags(nvh_stream* s);                                // nvh_launch.hip
 void replay_note(nvh_stream* s, int kind, const uint8_t* data, int len, int64_t granule, int flags);  // nvh_launch.hip

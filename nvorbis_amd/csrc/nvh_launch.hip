@@ -295,7 +295,7 @@ static int upload_dev_copy(nvh_batch* b, hipStream_t st) {
   return NVH_OK;
 }
 
-int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms) {
+int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms, hipEvent_t* ext_ev) {
   nvh_stream* s = b->s;
   hipStream_t st = s->ctx->stream;
   if (b->nframes == 0) return NVH_OK;
@@ -305,8 +305,15 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   const size_t lds = (size_t)s->setup.block1 * sizeof(float);
   ScopedEvent sev[5];
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // timing: five event records bracket the four slots.  With the caller's events (ext_ev) nothing is waited for here: the caller
+  // queues many launches back to back and reads the events afterwards, so a slot is a kernel between two markers in a full queue
+  // rather than a kernel dispatched onto an idle GPU.
   if (timing)
     for (int k = 0; k < 5; k++) {
+      if (ext_ev) {
+        ev[k] = ext_ev[k];
+        continue;
+      }
       int rc = sev[k].create();
       if (rc != NVH_OK) return rc;
       ev[k] = sev[k].e;
@@ -377,7 +384,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
         HIP_TRY(hipEventRecord(ev[4], st));
       }
       HIP_TRY(hipGetLastError());
-      if (timing) {
+      if (timing && !ext_ev) {
         HIP_TRY(hipEventSynchronize(ev[4]));
         for (int k = 0; k < 4; k++) {
           float ms = 0;
@@ -562,7 +569,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   }
   if (timing) HIP_TRY(hipEventRecord(ev[4], st));
   HIP_TRY(hipGetLastError());
-  if (timing) {
+  if (timing && !ext_ev) {
     HIP_TRY(hipEventSynchronize(ev[4]));
     for (int k = 0; k < 4; k++) {
       float ms = 0;
