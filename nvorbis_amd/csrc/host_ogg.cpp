@@ -70,6 +70,7 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
     bool have_first_data_page = false;
     int64_t max_granule = 0;
     int first_data_page = -1;
+    int error = NVH_OK;  // a granule rule of AddPage was broken: the stream is refused (and takes no further pages)
   };
   std::vector<Logical> streams;
   std::vector<std::pair<uint32_t, int>> active;  // serial -> index into streams
@@ -151,10 +152,18 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
               lg.have_first_data_page = true;
               lg.first_data_page = (int)lg.pages.size();
             }
-            else if (lg.max_granule > pg.granule) return NVH_ERR_INVALID_DATA;  // "Granule Position regressed?!"
+            else if (lg.max_granule > pg.granule) lg.error = NVH_ERR_INVALID_DATA;  // "Granule Position regressed?!"
             lg.max_granule = pg.granule;
           } else if (lg.have_first_data_page && (!pg.continued || pg.pk_off.size() != 1)) {
-            return NVH_ERR_INVALID_DATA;  // "Granule Position was -1 but page does not have exactly 1 continued packet."
+            lg.error = NVH_ERR_INVALID_DATA;  // "Granule Position was -1 but page does not have exactly 1 continued packet."
+          }
+          if (lg.error != NVH_OK) {
+            // the reference throws from inside its page reader when it gets here; only a caller that asks for THIS stream is told
+            active.erase(active.begin() + slot);
+            ignored.push_back(pg_serial);
+            resync = false;
+            pos += total;
+            continue;
           }
           pg.resync = pg.resync || (lg.last_seq != 0 && (int32_t)((uint32_t)lg.last_seq + 1u) != seq);
           lg.last_seq = seq;
@@ -179,6 +188,7 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
     out.offs.push_back(0);
     return stream_index == 0 ? NVH_OK : NVH_ERR_ARGUMENT;  // an input without any page: an empty packet list, as before
   }
+  if (streams[(size_t)stream_index].error != NVH_OK) return streams[(size_t)stream_index].error;
   const std::vector<Page>& pages = streams[(size_t)stream_index].pages;
   const bool has_all_pages = streams[(size_t)stream_index].has_all_pages;
   out.pages.clear();

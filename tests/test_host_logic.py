@@ -279,3 +279,57 @@ def test_demux_chained_and_multiplexed_streams(ogg_bytes):
     second = nv.demux_ogg_array(junk, 1)
     assert len(second) == len(alone["3test"]) and np.array_equal(second.granules, alone["3test"].granules)
     assert second.flags[0] & 2 and np.array_equal(second.flags[1:], alone["3test"].flags[1:])
+
+
+def _c_params(sig):
+    sig = sig.strip()
+    if sig in ("", "void"):
+        return []
+    out, depth, cur = [], 0, ""
+    for ch in sig:
+        if ch == "(":
+            depth += 1
+        if ch == ")":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    out.append(cur.strip())
+    return out
+
+
+def test_csharp_pinvoke_declarations_follow_the_header():
+    """csharp/NativeMethods.cs cannot be compiled in this image; what can be checked is that every [DllImport] it declares names an
+    entry point of include/nvorbis_hip.h with the same number of parameters, pointer parameters where the header has pointers, and
+    64-bit integers where the header has int64_t / size_t -- and that the C# sources only call entry points that are declared."""
+    hdr = open(os.path.join(ROOT, "include", "nvorbis_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|void|const char\s*\*)\s*(nvh_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S):
+        protos[m.group(1)] = _c_params(re.sub(r"\s+", " ", m.group(2)))
+    cs = open(os.path.join(ROOT, "csharp", "NativeMethods.cs")).read()
+    decls = {}
+    for m in re.finditer(r"\[DllImport\(Lib\)\]\s*public static extern (?:unsafe )?\w+ (nvh_[a-z0-9_]+)\(([^;]*?)\);", cs, flags=re.S):
+        decls[m.group(1)] = _c_params(re.sub(r"\s+", " ", m.group(2)))
+    assert len(decls) >= 45
+    for name, cs_params in decls.items():
+        assert name in protos, "NativeMethods.cs declares %s, which the header does not" % name
+        c_params = protos[name]
+        assert len(cs_params) == len(c_params), (name, cs_params, c_params)
+        for cp, sp in zip(c_params, cs_params):
+            is_ptr = "*" in cp
+            cs_ptr = "*" in sp or sp.startswith(("out ", "ref ", "IntPtr ", "[Out] ")) or " IntPtr " in " " + sp
+            assert is_ptr == cs_ptr or (not is_ptr and sp.startswith("UIntPtr ")), (name, cp, sp)
+            if re.match(r"(const )?int64_t [a-z_]+$", cp):
+                assert sp.startswith("long "), (name, cp, sp)
+            if re.match(r"size_t [a-z_]+$", cp):
+                assert sp.startswith("UIntPtr "), (name, cp, sp)
+            if re.match(r"(const )?int [a-z_]+$", cp):
+                assert sp.startswith("int "), (name, cp, sp)
+    # every native call in the C# sources is declared
+    for fn in ("GpuStreamDecoder.cs", "GpuFactory.cs"):
+        src = open(os.path.join(ROOT, "csharp", fn)).read()
+        for called in set(re.findall(r"NativeMethods\.(nvh_[a-z0-9_]+)\(", src)):
+            assert called in decls, (fn, called)

@@ -4,6 +4,7 @@ Ogg/StreamPageReader.cs:44-91 granule sanity + "sequence jump counts as a resync
 assembly) is restated twice, independently -- oracle/orc_ogg.c and the product's host_ogg.cpp: both must deliver the same
 packets, granule positions and end-of-stream / resync flags, and the decoders behind them the same PCM."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -241,3 +242,85 @@ def test_forward_only_reader_decodes_like_the_oracle(oracle, gpu_ctx, ogg_bytes,
             rd.SeekTo(1000)
     finally:
         rd.close()
+
+
+def test_container_fuzz_valid_crc_mutations(oracle, ogg_bytes):
+    """Pages rewritten with a VALID checksum but mutated headers (flags flipped, granule positions moved / set to -1, sequence numbers
+    changed, lacing tables re-cut) and raw byte damage on top: whatever the three readers make of it -- seekable list, forward-only
+    list, seek search -- the product and the oracle's restatements make the same of it (packets, granule positions, flags, error
+    codes), and nothing crashes."""
+    import nvorbis_amd as nv
+    L = nv.lib()
+    hdr = ve.shipped_headers(ogg_bytes["3test"])
+    S = ve.setup_of(hdr)
+    pool = ve.packet_pool(S, 9, per_kind=4)
+    cases = agree = refused = seeks = 0
+    for trial in range(int(os.environ.get("NVH_FUZZ_TRIALS", "60"))):
+        rng = np.random.default_rng(1000 + trial)
+        kinds = ve.markov_kinds(rng, int(rng.integers(20, 70)), 0.15, 0.3)
+        kinds[:2] = True
+        pk, gr = ve.stream_from_pool(S, hdr, pool, kinds, rng)
+        data = ogg_py.write_ogg(pk, gr, serial=int(rng.integers(1, 1 << 30)), page_packets=int(rng.integers(1, 6)),
+                                max_segments=int(rng.choice([255, 12, 5])))
+        pages = ogg_py.read_pages(data)
+        out = []
+        for i, pg in enumerate(pages):
+            flags, granule, seq, segs, body = pg["flags"], pg["granule"], pg["seq"], list(pg["segs"]), pg["body"]
+            r = rng.random()
+            if i >= 2 and r < 0.10:
+                flags ^= int(rng.choice([1, 2, 4]))
+            elif i >= 2 and r < 0.18:
+                granule = int(rng.choice([-1, 0, granule + int(rng.integers(-2000, 2000)), granule + 448, granule - 448]))
+            elif i >= 2 and r < 0.24:
+                seq += int(rng.integers(-2, 5))
+            elif i >= 2 and r < 0.30 and len(segs) > 1:
+                # re-cut the lacing table: merge two packets / terminate one early (the body stays)
+                k = int(rng.integers(0, len(segs) - 1))
+                if segs[k] < 255 and segs[k] + segs[k + 1] <= 255:
+                    segs[k:k + 2] = [segs[k] + segs[k + 1]]
+            elif i >= 2 and r < 0.33:
+                continue  # page dropped
+            out.append(ogg_py.make_page(pg["serial"], seq, granule, flags, segs, body))
+        bad = bytearray(b"".join(out))
+        if rng.random() < 0.4 and len(bad) > 200:
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(100, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        for fwd in (False, True):
+            rc_o, got_o = _oracle_demux(oracle, bad, fwd)
+            rc_p, got_p = _product_demux(bad, fwd)
+            cases += 1
+            assert rc_o == rc_p, (trial, fwd, rc_o, rc_p)
+            if rc_o != 0:
+                refused += 1
+                continue
+            assert got_o == got_p, (trial, fwd)
+            agree += 1
+        # the seek search on whatever page table the seekable reader builds
+        rc_p, got_p = _product_demux(bad, False)
+        if rc_p != 0 or len(got_p[0]) < 4:
+            continue
+        try:
+            st = nv.Stream(None, got_p[0][0], got_p[0][1], got_p[0][2])
+            d = oracle.open_ogg(bad)
+        except Exception:
+            continue
+        buf = (C.c_uint8 * len(bad)).from_buffer_copy(bad)
+        h = C.c_void_p()
+        assert L.nvh_ogg_index_open(buf, len(bad), 0, C.byref(h)) == 0
+        try:
+            top = max([g for g in got_p[1] if g >= 0] + [1])
+            for g in [0, 1, 129, top // 3, top // 2, top - 1, top, top + 1] + [int(x) for x in rng.integers(0, top + 2, 6)]:
+                for pr in (0, 1):
+                    a, b = C.c_int64(), C.c_int64()
+                    rc = L.nvh_ogg_seek(h, st._h, int(g), pr, C.byref(a), C.byref(b))
+                    orc = oracle.ogg_seek(bad, d, g, pr)
+                    mine = (rc, a.value, b.value) if rc == 0 else (rc, 0, 0)
+                    ref = orc if orc[0] == 0 else (orc[0], 0, 0)
+                    assert mine == ref, (trial, g, pr, mine, ref)
+                    seeks += 1
+        finally:
+            L.nvh_ogg_index_close(h)
+            oracle.L.orc_close(d)
+            st.close()
+    assert agree > 60 and seeks > 400, (cases, agree, refused, seeks)
