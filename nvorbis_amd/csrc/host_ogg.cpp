@@ -578,7 +578,10 @@ bool is_vorbis_bug_diff(int64_t diff) {
     ++long_bits;
     temp >>= 1;
   }
-  return temp == 0 && diff == ((int64_t)1 << long_bits) - ((int64_t)1 << short_bits);  // (1 << n): 32-bit in the reference, n < 31 here
+  // (1 << longBlockBits) - (1 << shortBlockBits) is 32-bit arithmetic in the reference: shift counts taken modulo 32, the
+  // difference wrapped to int, then widened for the comparison
+  const uint32_t hi = 1u << (long_bits & 31), lo = 1u << (short_bits & 31);
+  return temp == 0 && diff == (int64_t)(int32_t)(hi - lo);
 }
 
 // StreamPageReader.FindPage with every page already read (Ogg/StreamPageReader.cs:122-264); -1 = ArgumentOutOfRangeException

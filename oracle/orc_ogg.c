@@ -461,7 +461,11 @@ static int get_is_vorbis_bug_diff(int64_t diff) {
     ++long_block_bits;
     temp >>= 1;
   }
-  return temp == 0 && diff == ((int64_t)1 << long_block_bits) - ((int64_t)1 << short_block_bits);
+  /* C#: (1 << longBlockBits) - (1 << shortBlockBits) on int -- shift counts are taken mod 32, the subtraction wraps */
+  {
+    int32_t a = (int32_t)(1u << (long_block_bits & 31)), b = (int32_t)(1u << (short_block_bits & 31));
+    return temp == 0 && diff == (int64_t)(int32_t)((uint32_t)a - (uint32_t)b);
+  }
 }
 
 /* Ogg/StreamPageReader.cs:232-264 */

@@ -270,7 +270,7 @@ def test_container_fuzz_valid_crc_mutations(oracle, ogg_bytes):
             if i >= 2 and r < 0.10:
                 flags ^= int(rng.choice([1, 2, 4]))
             elif i >= 2 and r < 0.18:
-                granule = int(rng.choice([-1, 0, granule + int(rng.integers(-2000, 2000)), granule + 448, granule - 448]))
+                granule = int(rng.choice([-1, 0, granule + int(rng.integers(-2000, 2000)), granule + 448, granule - 448, granule + (1 << 33), granule + (1 << 32) - (1 << 7), (1 << 40) + 5]))
             elif i >= 2 and r < 0.24:
                 seq += int(rng.integers(-2, 5))
             elif i >= 2 and r < 0.30 and len(segs) > 1:
