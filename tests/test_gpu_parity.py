@@ -229,12 +229,13 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
     assert exact > 0.99, exact
 
 
-@pytest.mark.parametrize("toggle", ["NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE"])
+@pytest.mark.parametrize("toggle", ["NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE", "NVH_MULTI"])
 def test_fallback_kernel_paths_bit_exact(toggle):
     """The library picks kernel variants by stream shape.  Each environment toggle disables one
     level of fusion, so the whole parity suite above is replayed through the general kernels in a child process:
     NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact,
-    NVH_NO_COMPACT -> k_imdct_wave + k_ola_emit; NVH_GPU_PARSE -> packets parsed by k_parse instead of the host parser."""
+    NVH_NO_COMPACT -> k_imdct_wave + k_ola_emit; NVH_GPU_PARSE -> packets parsed by k_parse instead of the host parser;
+    NVH_MULTI -> the opt-in frame-loop kernel k_spectrum_imdct2 (two-channel floor unwrap in one wavefront)."""
     import os
     import subprocess
     import sys
