@@ -69,6 +69,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   const int f = blockIdx.x;
 #define DBG_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + (k)] = clock64(); } while (0)
   DBG_T(0);
+  if (phase_mask & 64) return;   // profiling builds: the launch itself (NVH_DEBUG_SPECTRUM_MASK)
   if (dbg && threadIdx.x == 0) {
     dbg[(long long)blockIdx.x * 24 + 22] = wall_clock64();
     dbg[(long long)blockIdx.x * 24 + 19] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);  // XCC_ID, HW_ID
@@ -85,6 +86,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
   const int half = fr.n >> 1;
   const NvhDevMapping mp = S.mappings[fr.mapping];
   DBG_T(1);
+  if (phase_mask & 128) return;  // profiling builds: launch + frame record + mapping record
 
   // ---- stage the frame's side information (16-byte copies), clear the spectrum, prepare the floors ----
   // Mono / stereo Floor1 streams take the fused tail: their posts are unwrapped here, one wavefront per channel,
@@ -172,7 +174,7 @@ __device__ __forceinline__ void spectrum_body(const NvhDevSetup& S, const NvhDev
     if (sw == nstage - 1) {
       stage_ops(lane, 64);
       sp_wave_sync();
-      build_pair_records(lane, 64);
+      if (!(phase_mask & 256)) build_pair_records(lane, 64);
       // Chain heads of every pass, compacted (op indices, 16 bits each) over the staged ops, which nothing reads any more:
       // the sweep below walks one chain per lane and pair of bins, and two thirds of a three-stage pass's ops are not
       // heads -- whole wavefronts of the sweep used to find nothing but "not a head".  P[0] becomes the pass's head range.
