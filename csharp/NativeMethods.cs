@@ -91,6 +91,9 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern unsafe int nvh_dev_download(IntPtr ctx, void* hDst, IntPtr dSrc, UIntPtr bytes);
         [DllImport(Lib)] public static extern int nvh_measure_copy(IntPtr ctx, IntPtr dSrc, IntPtr dDst, UIntPtr bytes, int iters, out float ms);
         [DllImport(Lib)] public static extern unsafe int nvh_stream_synth(IntPtr stream, float* pcmHost, IntPtr dPcm, long capacity, out long written);
+        /// <summary>Pipelined form (pinned destination): the transfer of one batch overlaps the pushes, parse and kernels of the next.</summary>
+        [DllImport(Lib)] public static extern unsafe int nvh_stream_synth_begin(IntPtr stream, float* pcmHost, long capacity, out long expected);
+        [DllImport(Lib)] public static extern int nvh_stream_synth_end(IntPtr stream, out long written);
 
         internal static void Check(int rc)
         {

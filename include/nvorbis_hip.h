@@ -217,6 +217,14 @@ int nvh_stream_pending(const nvh_stream *s, int *frames, int64_t *pcm_samples_pe
  * pcm_host / d_pcm is non-NULL; capacity is in floats and must hold pending samples * channels.
  * Advances the overlap state (the last block's tail is carried to the next batch). */
 int nvh_stream_synth(nvh_stream *s, float *pcm_host, float *d_pcm, int64_t capacity, int64_t *written);
+/* Pipelined form for a destination in page-locked host memory (nvh_pinned_alloc): nvh_stream_synth_begin queues the upload, the
+ * synthesis and -- on a copy stream of its own -- the transfer of the PCM and returns (*expected = floats the batch will
+ * deliver); nvh_stream_synth_end waits for the OLDEST outstanding batch and reports what nvh_stream_synth would have (error
+ * codes, *written, nvh_stream_parse_errors).  Up to two batches may be outstanding, so the transfer of one overlaps the pushes,
+ * the parse and the kernels of the next; each needs its own destination buffer until its end call returns.  No counterpart in the
+ * reference (its Read is synchronous); nvh_stream_synth must not be mixed in while batches are outstanding (NVH_ERR_ARGUMENT). */
+int nvh_stream_synth_begin(nvh_stream *s, float *pcm_host, int64_t capacity, int64_t *expected);
+int nvh_stream_synth_end(nvh_stream *s, int64_t *written);
 /* After nvh_stream_synth returned an error code together with *written > 0 (GPU-parse mode: packets of the batch made
  * the parser fail -- with the codes nvh_stream_push_packet returns for them in host-parse mode -- and the batch was
  * parsed again on the host without them): every such packet in stream order, codes[i] and samples_before[i] = the

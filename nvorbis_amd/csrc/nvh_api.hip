@@ -206,6 +206,7 @@ extern "C" void nvh_stream_close(nvh_stream* s) {
     if (s->ctx) {
       (void)hipSetDevice(s->ctx->device);
       (void)hipStreamSynchronize(s->ctx->stream);
+      if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
     }
     delete s;
   });
@@ -386,6 +387,13 @@ extern "C" int nvh_stream_reset(nvh_stream* s) {
     if (!s->parser) return NVH_ERR_NOMEM;
     s->parser->set_light(s->gpu_parse);
     s->has_clipped = 0;
+    if (s->ctx && s->copy_stream) {  // outstanding pipelined batches are abandoned: let their copies land first
+      HIP_TRY(hipSetDevice(s->ctx->device));
+      HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+      HIP_TRY(hipStreamSynchronize(s->copy_stream));
+      s->flight[0].on = s->flight[1].on = false;
+      s->flight_next = s->flight_first = 0;
+    }
     if (s->ctx && s->flags.p) {
       HIP_TRY(hipSetDevice(s->ctx->device));
       HIP_TRY(hipMemsetAsync(s->flags.p, 0, 2 * sizeof(int), s->ctx->stream));
@@ -474,6 +482,7 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
     if (!s || (pcm_host && d_pcm)) return NVH_ERR_ARGUMENT;
     if (written) *written = 0;
     if (!s->ctx) return NVH_ERR_NO_GPU;
+    if (s->flight[0].on || s->flight[1].on) return NVH_ERR_ARGUMENT;  // pipelined batches outstanding: end them first
     HIP_TRY(hipSetDevice(s->ctx->device));
     const int ch = s->setup.channels;
     int64_t need = s->pending.pcm_samples * ch;
@@ -522,6 +531,97 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
     // a packet of this batch made the parser fail (the code nvh_stream_push_packet returns in host-parse mode): the PCM of
     // every other packet is complete and *written says so; nvh_stream_parse_errors tells where the exceptions belong
     return s->replay_error;
+  });
+}
+
+// Pipelined form of nvh_stream_synth for a destination in page-locked host memory: begin queues upload, (GPU parse,) synthesis and
+// -- on a copy stream of its own -- the transfer of the PCM, and returns; end waits for the OLDEST outstanding batch.  The
+// transfer of batch i (8 KB per stereo long frame over PCIe: the longest step of the end-to-end path) then runs while the host
+// pushes batch i+1 and the GPU parses and synthesises it.
+extern "C" int nvh_stream_synth_begin(nvh_stream* s, float* pcm_host, int64_t capacity, int64_t* expected) {
+  return nvh_guard([&]() -> int {
+    if (!s || !pcm_host) return NVH_ERR_ARGUMENT;
+    if (expected) *expected = 0;
+    if (!s->ctx) return NVH_ERR_NO_GPU;
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    const int slot = s->flight_next;
+    nvh_stream::Flight& F = s->flight[slot];
+    if (F.on) return NVH_ERR_ARGUMENT;  // two batches outstanding already
+    {
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, pcm_host) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return NVH_ERR_ARGUMENT;  // the copy engine needs page-locked memory (nvh_pinned_alloc)
+      }
+    }
+    const int ch = s->setup.channels;
+    hipStream_t st = s->ctx->stream;
+    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    if (!F.kernels) HIP_TRY(hipEventCreateWithFlags(&F.kernels, hipEventDisableTiming));
+    if (!F.done) HIP_TRY(hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
+    // the staging image of the previous batch's descriptors is about to be overwritten: its upload (and kernels) must be through
+    HIP_TRY(hipStreamSynchronize(st));
+    F.need = 0;
+    F.replay_error = NVH_OK;
+    F.replay_errors.clear();
+    if (s->pending.frames.empty()) {  // nothing to do: an outstanding "batch" of zero samples keeps begin / end paired
+      HIP_TRY(hipEventRecord(F.done, st));
+      F.on = true;
+      s->flight_next ^= 1;
+      return NVH_OK;
+    }
+    if (capacity < s->pending.pcm_samples * ch) return NVH_ERR_ARGUMENT;
+    nvh_batch* b = &s->scratch;
+    s->replay_error = NVH_OK;
+    s->replay_errors.clear();
+    int rc = batch_upload(s, b);
+    if (rc != NVH_OK) return rc;
+    const int64_t need = b->pcm_samples * ch;
+    if (capacity < need) return NVH_ERR_ARGUMENT;
+    if ((rc = s->pcm2[slot].reserve((size_t)(need > 0 ? need : 1) * sizeof(float))) != NVH_OK) return rc;
+    if ((rc = s->h_flags2.reserve(4 * sizeof(int))) != NVH_OK) return rc;
+    float* dst = (float*)s->pcm2[slot].p;
+    rc = batch_launch(b, (const float*)s->carry[s->carry_cur].p, (float*)s->carry[s->carry_cur ^ 1].p, dst, false, nullptr);
+    if (rc != NVH_OK) return rc;
+    if (b->last_decoded >= 0) s->carry_cur ^= 1;
+    // this batch's flag words, then a clean pair for the next one (all on the launch stream, in order)
+    HIP_TRY(hipMemcpyAsync((int*)s->h_flags2.p + 2 * slot, s->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(s->flags.p, 0, 2 * sizeof(int), st));
+    HIP_TRY(hipEventRecord(F.kernels, st));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, F.kernels, 0));
+    if (need > 0) HIP_TRY(hipMemcpyAsync(pcm_host, dst, (size_t)need * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
+    HIP_TRY(hipEventRecord(F.done, s->copy_stream));
+    F.need = need;
+    F.replay_error = s->replay_error;
+    F.replay_errors = s->replay_errors;
+    F.on = true;
+    s->flight_next ^= 1;
+    if (expected) *expected = need;
+    return NVH_OK;
+  });
+}
+
+extern "C" int nvh_stream_synth_end(nvh_stream* s, int64_t* written) {
+  return nvh_guard([&]() -> int {
+    if (!s) return NVH_ERR_ARGUMENT;
+    if (written) *written = 0;
+    if (!s->ctx) return NVH_ERR_NO_GPU;
+    nvh_stream::Flight& F = s->flight[s->flight_first];
+    if (!F.on) return NVH_ERR_ARGUMENT;
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipEventSynchronize(F.done));
+    F.on = false;
+    const int slot = s->flight_first;
+    s->flight_first ^= 1;
+    s->replay_error = F.replay_error;  // nvh_stream_parse_errors then describes THIS batch
+    s->replay_errors = F.replay_errors;
+    if (F.need > 0) {
+      const int* h = (const int*)s->h_flags2.p + 2 * slot;
+      if (h[1]) s->has_clipped = 1;
+      if (h[0]) return NVH_ERR_RUNTIME;
+    }
+    if (written) *written = F.need;
+    return F.replay_error;
   });
 }
 

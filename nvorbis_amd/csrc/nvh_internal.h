@@ -297,12 +297,35 @@ struct nvh_stream {
   std::unique_ptr<nvh::StreamParser> replay_start;  // parser state at the first logged event
   int replay_error = NVH_OK;                         // first error of the last replay (reported by the synthesis call)
   std::vector<std::pair<int, int64_t>> replay_errors;  // every error of it: (code, samples per channel the batch emits before that packet)
+  // Pipelined read-back (nvh_stream_synth_begin / _end): the PCM of batch i travels to the host on a stream of its own while
+  // batch i+1 is uploaded, parsed and synthesised.  Two batches may be outstanding, ended in the order they were begun.
+  struct Flight {
+    bool on = false;
+    hipEvent_t kernels = nullptr, done = nullptr;
+    int64_t need = 0;
+    int replay_error = NVH_OK;
+    std::vector<std::pair<int, int64_t>> replay_errors;
+  };
+  hipStream_t copy_stream = nullptr;
+  DevBuf pcm2[2];
+  DevBuf h_flags2;  // pinned int[4]: the two flag words of each outstanding batch
+  Flight flight[2];
+  int flight_next = 0, flight_first = 0;
+  ~nvh_stream() {
+    for (Flight& f : flight) {
+      if (f.kernels) (void)hipEventDestroy(f.kernels);
+      if (f.done) (void)hipEventDestroy(f.done);
+    }
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  }
 
   nvh_stream(nvh_ctx* c, std::shared_ptr<SharedSetup> sh)
       : ctx(c), shared(std::move(sh)), setup(shared->setup), arena(shared->arena), dev(shared->dev),
         fast_spectrum(shared->fast_spectrum), has_floor0(shared->has_floor0) {
     BufPool* pool = c ? &c->pool : nullptr;
-    carry[0].pool = carry[1].pool = flags.pool = pcm.pool = carry_exec.pool = pool;
+    carry[0].pool = carry[1].pool = flags.pool = pcm.pool = carry_exec.pool = pcm2[0].pool = pcm2[1].pool = pool;
+    h_flags2.host = true;
+    h_flags2.pool = c ? &c->hpool : nullptr;
     scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = scratch.run_flags.pool = scratch.dev_copy.pool = pool;
     h_pcm.host = scratch.h_blob.host = true;
     h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;

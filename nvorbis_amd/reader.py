@@ -375,6 +375,42 @@ class Stream:
         self._note_parse_error(rc, wr.value, "nvh_stream_synth")
         return out[:wr.value]
 
+    # ---- pipelined read-back (nvh_stream_synth_begin / _end) ----
+    def _pipe_buffer(self, k, n):
+        bufs = getattr(self, "_pipe", None)
+        if bufs is None:
+            bufs = self._pipe = [[None, 0, None], [None, 0, None]]  # [pointer, capacity in floats, numpy view]
+        ptr, cap, arr = bufs[k]
+        if cap < n:
+            if ptr:
+                lib().nvh_pinned_free(ptr)
+            p = C.c_void_p()
+            cap = max(n, 2 * cap)
+            check(lib().nvh_pinned_alloc(cap * 4, C.byref(p)), "nvh_pinned_alloc")
+            bufs[k] = [p, cap, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(cap,))]
+        return bufs[k][2]
+
+    def synth_begin(self):
+        """Queue the pending batch (upload, GPU parse, synthesis, transfer of the PCM on a copy stream) and return at once.
+        Two batches may be outstanding; synth_end() hands them back in order."""
+        _, smp = self.pending()
+        n = max(smp * self.channels, 1)
+        k = getattr(self, "_pipe_next", 0)
+        out = self._pipe_buffer(k, n)
+        exp = C.c_int64(0)
+        check(lib().nvh_stream_synth_begin(self._h, out.ctypes.data, out.size, C.byref(exp)), "nvh_stream_synth_begin")
+        self._pipe_next = k ^ 1
+        return exp.value
+
+    def synth_end(self):
+        """PCM of the oldest outstanding batch: a view of a page-locked buffer that stays valid until the begin after next."""
+        k = getattr(self, "_pipe_first", 0)
+        wr = C.c_int64(0)
+        rc = lib().nvh_stream_synth_end(self._h, C.byref(wr))
+        self._pipe_first = k ^ 1
+        self._note_parse_error(rc, wr.value, "nvh_stream_synth_end")
+        return self._pipe[k][2][:wr.value]
+
     def synth_device(self, d_ptr, capacity):
         wr = C.c_int64(0)
         rc = lib().nvh_stream_synth(self._h, None, C.c_void_p(d_ptr), int(capacity), C.byref(wr))
@@ -411,6 +447,11 @@ class Stream:
             self._pin_arr = None
             lib().nvh_pinned_free(self._pin_ptr)
             self._pin_ptr, self._pin_cap = None, 0
+        for b in getattr(self, "_pipe", None) or []:
+            if b[0]:
+                b[2] = None
+                lib().nvh_pinned_free(b[0])
+                b[0], b[1] = None, 0
 
     def __del__(self):
         try:

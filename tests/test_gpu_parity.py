@@ -973,3 +973,43 @@ def test_reader_switches_between_logical_streams(oracle, ogg_bytes):
             rd.SwitchStreams(3)
     finally:
         rd.close()
+
+
+@pytest.mark.parametrize("gpu_parse", [False, True])
+def test_pipelined_read_back_is_the_same_pcm(oracle, gpu_ctx, ogg_bytes, gpu_parse):
+    """nvh_stream_synth_begin / _end (two batches outstanding, the PCM of one travelling to the host while the next is pushed,
+    parsed and synthesised): the concatenated PCM is the oracle's, bit for bit, for a file with both block sizes and the
+    end-of-stream trim, with small and large batches; misuse (a third begin, an end without a begin, the synchronous call in
+    between) is refused with NVH_ERR_ARGUMENT and leaves the outstanding batches intact."""
+    import nvorbis_amd as nv
+    pk, gr, fl = nv.demux_ogg(ogg_bytes["3test"])
+    ref, _ = oracle.decode_packets(pk, gr.tolist(), fl.tolist())
+    for per_batch in (37, 500):
+        st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+        try:
+            st.set_gpu_parse(gpu_parse)
+            chunks, outstanding, i = [], 0, 3
+            while i < len(pk) or outstanding:
+                if i < len(pk) and outstanding < 2:
+                    j = min(i + per_batch, len(pk))
+                    for k in range(i, j):
+                        st.push_packet(pk[k], int(gr[k]), int(fl[k]))
+                    if j == len(pk):
+                        st.push_end()
+                    i = j
+                    st.synth_begin()
+                    outstanding += 1
+                    if outstanding == 2 and not chunks:  # misuse while two batches are in flight
+                        with pytest.raises(nv.native.NvhError):
+                            st.synth_begin()
+                        with pytest.raises(nv.native.NvhError):
+                            st.synth_host()
+                    continue
+                chunks.append(st.synth_end().copy())
+                outstanding -= 1
+            with pytest.raises(nv.native.NvhError):
+                st.synth_end()
+            got = np.concatenate(chunks)
+            assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (gpu_parse, per_batch)
+        finally:
+            st.close()
