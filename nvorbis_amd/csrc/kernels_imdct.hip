@@ -94,6 +94,7 @@ k_mdct_reverse_wave(float* __restrict__ buf, int n, long long stride, const floa
   }
 }
 
+#ifdef NVH_EXPERIMENTS  // k_imdct_ola measured slower than k_spectrum_imdct + k_ola_compact: experiments build only
 // ================================================================================================
 // Fused IMDCT + window + overlap-add + interleave + clip  (block sizes 256 .. 2048, up to 4 channels)
 // ================================================================================================
@@ -331,3 +332,4 @@ k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const
   }
   report_clipped(clipped, clipped_flag);
 }
+#endif  // NVH_EXPERIMENTS

@@ -51,7 +51,12 @@ static int ensure_device(int device) {
   return NVH_OK;
 }
 
-extern "C" const char* nvh_version(void) { return "nvorbis_hip 0.1 (gfx950)"; }
+#ifndef NVH_SRC_HASH
+#define NVH_SRC_HASH "unknown"  // nvorbis_amd/build.py passes the hash of the sources; a hand-rolled build has none
+#endif
+// "nvh-src-hash=<16 hex digits>": nvorbis_amd/build.py finds the marker in the file, native.lib() compares it with the
+// hash of the sources it sits next to and refuses (rebuilds) a stale binary.
+extern "C" const char* nvh_version(void) { return "nvorbis_hip 0.3 (gfx950) nvh-src-hash=" NVH_SRC_HASH; }
 extern "C" int nvh_last_hip_error(void) { return g_last_hip_error; }
 extern "C" int nvh_device_count(void) {
   int count = 0;

@@ -41,8 +41,6 @@ __global__ void k_spectrum_gen(NvhDevSetup S, NvhDevBatch Bt, float* work, int* 
 __global__ void k_spectrum_gen8(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_spectrum_gen_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_spectrum_gen8_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
-__global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
-                            int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
                                     const float* TW);
 __global__ void k_parse(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
@@ -55,12 +53,16 @@ __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhCh
                               uint32_t* carry_exec_out, int last_decoded);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
 __global__ void k_copy_f4(const float4* src, float4* dst, long long n4);
+#ifdef NVH_EXPERIMENTS  // measured slower than the default path: build.py --experiments only
+__global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
+                            int clip, int* clipped_flag, int run_len, int last_decoded);
 __global__ void k_spectrum_imdct2_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_spectrum_imdct2_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_run4_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_run4_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_run6_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
+#endif
 __global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
 __global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,
                                   long long plane_stride);

@@ -323,6 +323,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
   const NvhToggles& T = nvh_toggles();
   const bool no_compact = T.no_compact, no_fused_ola = !T.fused_ola /* experimental run-based kernel: opt-in */, no_fused_imdct = T.no_fused_imdct;
+#ifdef NVH_EXPERIMENTS
   // ---- the run kernel: everything from side information to PCM in one launch (opt-in: NVH_RUN=1; DESIGN.md section 6
   // has the measurement that keeps it off by default) ----
   if (b->run_ok && !b->force_classic && T.run && !T.unfused && !no_fused_imdct && !no_compact && !T.fused_ola && d_pcm != nullptr &&
@@ -395,7 +396,13 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       return NVH_OK;
     }
   }
+#endif  // NVH_EXPERIMENTS
+#ifdef NVH_EXPERIMENTS
   const bool use_fused_ola = b->fused_ola && !no_fused_ola && !b->block_only;
+#else
+  const bool use_fused_ola = false;  // k_imdct_ola lives in the experiments build only (build.py --experiments)
+  (void)no_fused_ola;
+#endif
   const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola && !b->block_only;
   // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers
   const bool fast = s->fast_spectrum && b->links_ok;  // k_spectrum proper (pair path by chain walk, fused tail)
@@ -479,6 +486,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
           fprintf(stderr, "k_spectrum: lds %zu B, occupancy %d WG/CU (err %d), regs %d, static lds %zu, max dyn lds %d\n", words * 4 + lds_pad, nb,
                   (int)oe, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
         }
+#ifdef NVH_EXPERIMENTS
         if (fuse_imdct && T.multi && s->setup.block0 >= 256) {
           // frame loop (kernels_spectrum2.hip): as many workgroups as the device holds at once, each takes every grid-th frame
           int dev_cus = 256;
@@ -497,7 +505,9 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
           hipLaunchKernelGGL(ch == 1 ? k_spectrum_imdct2_c1 : k_spectrum_imdct2_c2, dim3(grid), dim3(256), lds_bytes, st,
                              (const NvhDevSetup*)s->shared->dev_copy.p, (const NvhDevBatch*)b->dev_copy.p, work, flags, cap_pass, cap_ops,
                              cap_ent NVH_DBG_LAUNCH);
-        } else if (fuse_imdct) {
+        } else
+#endif
+        if (fuse_imdct) {
           // + the IMDCT padding of the last channel (n/16 floats past the spectrum area)
           b->slot_name[1] = "k_spectrum_imdct";
           hipLaunchKernelGGL(k_spectrum_imdct, dim3((unsigned)b->nframes), dim3(256), words * 4 + (size_t)(s->setup.block1 / 16) * 4 + lds_pad,
@@ -517,6 +527,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   if (timing) HIP_TRY(hipEventRecord(ev[2], st));
   const int run_len_env = T.run_len;
   const size_t plane_bytes = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
+#ifdef NVH_EXPERIMENTS
   if (use_fused_ola) {
     // one workgroup per run of frames, one wavefront per channel; keep >= ~2048 waves in flight
     int run_len = run_len_env > 0 ? run_len_env : 4;
@@ -527,7 +538,9 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     hipLaunchKernelGGL(k_imdct_ola, dim3((unsigned)runs), dim3((unsigned)(64 * ch)), ola_lds, st, s->dev, b->dev, (const float*)work,
                        carry, carry_out, d_pcm, s->clip, flags + 1, run_len, b->last_decoded);
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));  // slot 2 = fused IMDCT+OLA, slot 3 empty
-  } else {
+  } else
+#endif
+  {
     b->slot_name[2] = (fuse_imdct || fuse_gen8) ? "-" : compact ? "k_imdct_compact" : (s->setup.block0 >= 256 ? "k_imdct_wave" : "k_imdct_window");
     b->slot_name[3] = compact ? "k_ola_compact" : (!b->sequential_ola ? "k_ola_emit" : "k_ola_emit_seq");
     if (fuse_imdct || fuse_gen8)

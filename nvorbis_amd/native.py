@@ -123,15 +123,36 @@ def lib():
         except ImportError:
             pass
         path = lib_path()
-        if not os.path.exists(path):
-            _build.build()
+        # A stale binary must never run (the .so is git-ignored but travels to the GPU box with the snapshot): the
+        # library carries the hash of the sources it was built from.  The default library is rebuilt when it does not
+        # match; an explicitly chosen one (NVH_LIB: debug / experiments / A-B builds) raises instead, unless
+        # NVH_ALLOW_STALE=1 says the mismatch is intended (tools/ab_git.sh compares builds of older commits).
+        if os.environ.get("NVH_LIB"):
+            if not os.environ.get("NVH_ALLOW_STALE") and _build.embedded_hash(path) != _build.source_hash():
+                raise RuntimeError("%s was built from other sources (has %s, tree is %s): rebuild it or set NVH_ALLOW_STALE=1"
+                                   % (path, _build.embedded_hash(path), _build.source_hash()))
+        elif _build.needs_build(path):
+            import sys
+            sys.stderr.write("nvorbis_amd: %s is missing or stale (has %s, sources are %s): building\n"
+                             % (path, _build.embedded_hash(path), _build.source_hash()))
+            _build.build(force=True)
+            if _build.needs_build(path):
+                raise RuntimeError("libnvorbis_hip.so does not carry the hash of its sources after a rebuild")
         handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here == ABI drift, fail loudly
             fn.restype = res
             fn.argtypes = args
+        ver = handle.nvh_version().decode()
+        if not os.environ.get("NVH_ALLOW_STALE") and ("nvh-src-hash=" + _build.source_hash()) not in ver:
+            raise RuntimeError("loaded %s reports '%s', sources are %s" % (path, ver, _build.source_hash()))
         _lib = handle
     return _lib
+
+
+def build_id():
+    """'nvorbis_hip <version> (gfx950) nvh-src-hash=<hash>' of the library that is actually loaded."""
+    return lib().nvh_version().decode()
 
 
 def check(rc, where):

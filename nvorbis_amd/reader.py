@@ -268,6 +268,9 @@ class Stream:
     def reset(self):
         """ResetDecoder (StreamDecoder.cs:295-305)."""
         check(lib().nvh_stream_reset(self._h), "nvh_stream_reset")
+        # nvh_stream_reset synchronises and abandons the outstanding flights (both native slot indices go back to 0):
+        # the Python side of the pairing follows, or the next begin / end would address different buffers
+        self._pipe_next = self._pipe_first = self._pipe_out = 0
 
     def drop_pending(self):
         check(lib().nvh_stream_drop_pending(self._h), "nvh_stream_drop_pending")
@@ -393,21 +396,34 @@ class Stream:
     def synth_begin(self):
         """Queue the pending batch (upload, GPU parse, synthesis, transfer of the PCM on a copy stream) and return at once.
         Two batches may be outstanding; synth_end() hands them back in order."""
+        if getattr(self, "_pipe_out", 0) >= 2:
+            # refuse before touching a buffer: slot k is still the DMA destination of the oldest outstanding batch
+            raise native.NvhError(native.ERR_ARGUMENT, "nvh_stream_synth_begin (two batches are outstanding: call synth_end first)")
         _, smp = self.pending()
         n = max(smp * self.channels, 1)
         k = getattr(self, "_pipe_next", 0)
         out = self._pipe_buffer(k, n)
         exp = C.c_int64(0)
         check(lib().nvh_stream_synth_begin(self._h, out.ctypes.data, out.size, C.byref(exp)), "nvh_stream_synth_begin")
+        # only a begin that succeeded occupies a slot
         self._pipe_next = k ^ 1
+        self._pipe_out = getattr(self, "_pipe_out", 0) + 1
         return exp.value
 
     def synth_end(self):
         """PCM of the oldest outstanding batch: a view of a page-locked buffer that stays valid until the begin after next."""
+        if getattr(self, "_pipe_out", 0) <= 0:
+            raise native.NvhError(native.ERR_ARGUMENT, "nvh_stream_synth_end (nothing is outstanding)")
         k = getattr(self, "_pipe_first", 0)
         wr = C.c_int64(0)
         rc = lib().nvh_stream_synth_end(self._h, C.byref(wr))
+        if rc in (native.ERR_ARGUMENT, native.ERR_DEVICE, native.ERR_NO_GPU):
+            # the native side returned before it retired the flight (nothing outstanding / the wait itself failed):
+            # the pairing is unchanged
+            raise native.NvhError(rc, "nvh_stream_synth_end")
+        # any other outcome has retired the native flight (nvh_api.hip pops the slot before it reports a runtime or parse error)
         self._pipe_first = k ^ 1
+        self._pipe_out -= 1
         self._note_parse_error(rc, wr.value, "nvh_stream_synth_end")
         return self._pipe[k][2][:wr.value]
 
