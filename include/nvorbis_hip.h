@@ -92,6 +92,17 @@ int nvh_stream_floor_info(const nvh_stream *s, int floor_index, int *type, int *
 
 /* Mode.cs:24-50 of mode `mode_index`: its block flag, block size and mapping index (NVH_ERR_ARGUMENT past the last mode). */
 int nvh_stream_mode_info(const nvh_stream *s, int mode_index, int *block_flag, int *block_size, int *mapping);
+/* ICodebook (Contracts/ICodebook.cs:5-13) of the stream's codebook `book_index`, as Codebook.Init built it
+ * (Codebook.cs:59-283) with Huffman.GenerateTable's decode tables (Huffman.cs:15-76): Dimensions, Entries, MapType, and the
+ * sizes of the tables nvh_stream_codebook_tables copies out.  n_prefix = 1 << prefix_bits slots (0: the tree was never
+ * built), n_overflow = -1 for the reference's null overflow list. */
+int nvh_stream_codebook_info(const nvh_stream *s, int book_index, int *dimensions, int *entries, int *map_type, int *prefix_bits,
+                             int *max_bits, int *n_prefix, int *n_overflow);
+/* lengths[entries] (Codebook.cs:76-160; -1 = unused entry), lookup[entries * dimensions] = the indexer's table
+ * (Codebook.cs:222-283, :322; untouched for map type 0), prefix[n_prefix * 5] and overflow[n_overflow * 5] = the Huffman nodes
+ * as (present, value, length, bits, mask) (Huffman.cs:15-76).  Any pointer may be NULL. */
+int nvh_stream_codebook_tables(const nvh_stream *s, int book_index, int32_t *lengths, float *lookup, int32_t *prefix,
+                               int32_t *overflow);
 
 /* IResidue.Decode(IPacket, bool[] doNotDecodeChannel, int blockSize, float[][] buffer) (Contracts/IResidue.cs:6;
  * Residue0.cs:119-201, Residue1.cs:8-26, Residue2.cs:10-47) for residue `residue_index` of stream `s`: reads the

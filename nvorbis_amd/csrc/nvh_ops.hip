@@ -275,6 +275,46 @@ extern "C" int nvh_floor0_apply(nvh_stream* s, int floor_index, int block_size, 
   });
 }
 
+extern "C" int nvh_stream_codebook_info(const nvh_stream* s, int book_index, int* dimensions, int* entries, int* map_type,
+                                        int* prefix_bits, int* max_bits, int* n_prefix, int* n_overflow) {
+  return nvh_guard([&]() -> int {
+    if (!s || book_index < 0 || book_index >= (int)s->setup.books.size()) return NVH_ERR_ARGUMENT;
+    const nvh::Codebook& b = s->setup.books[(size_t)book_index];
+    if (dimensions) *dimensions = b.dimensions;
+    if (entries) *entries = b.entries;
+    if (map_type) *map_type = b.map_type;
+    if (prefix_bits) *prefix_bits = b.prefix_bits;
+    if (max_bits) *max_bits = b.max_bits;
+    if (n_prefix) *n_prefix = b.has_tree ? (int)b.prefix.size() : 0;
+    if (n_overflow) *n_overflow = b.has_overflow ? (int)b.overflow.size() : -1;
+    return NVH_OK;
+  });
+}
+
+extern "C" int nvh_stream_codebook_tables(const nvh_stream* s, int book_index, int32_t* lengths, float* lookup, int32_t* prefix,
+                                          int32_t* overflow) {
+  return nvh_guard([&]() -> int {
+    if (!s || book_index < 0 || book_index >= (int)s->setup.books.size()) return NVH_ERR_ARGUMENT;
+    const nvh::Codebook& b = s->setup.books[(size_t)book_index];
+    if (lengths)
+      for (size_t i = 0; i < b.lengths.size(); i++) lengths[i] = b.lengths[i];
+    if (lookup && b.map_type != 0)
+      for (size_t i = 0; i < b.lookup.size(); i++) lookup[i] = b.lookup[i];
+    auto nodes = [](const std::vector<nvh::HuffNode>& v, int32_t* out) {
+      for (size_t i = 0; i < v.size(); i++) {
+        out[5 * i] = v[i].present ? 1 : 0;
+        out[5 * i + 1] = v[i].value;
+        out[5 * i + 2] = v[i].length;
+        out[5 * i + 3] = v[i].bits;
+        out[5 * i + 4] = v[i].mask;
+      }
+    };
+    if (prefix && b.has_tree) nodes(b.prefix, prefix);
+    if (overflow && b.has_overflow) nodes(b.overflow, overflow);
+    return NVH_OK;
+  });
+}
+
 extern "C" int nvh_stream_mode_info(const nvh_stream* s, int mode_index, int* block_flag, int* block_size, int* mapping) {
   return nvh_guard([&]() -> int {
     if (!s || mode_index < 0 || mode_index >= (int)s->setup.modes.size()) return NVH_ERR_ARGUMENT;

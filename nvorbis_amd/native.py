@@ -56,6 +56,8 @@ SIGNATURES = {
     "nvh_overlap_buffers": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]),
     "nvh_copy_buffer": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, C.c_int, C.POINTER(C.c_int)]),
     "nvh_stream_mode_info": (C.c_int, [_vp, C.c_int] + [C.POINTER(C.c_int)] * 3),
+    "nvh_stream_codebook_info": (C.c_int, [_vp, C.c_int] + [C.POINTER(C.c_int)] * 7),
+    "nvh_stream_codebook_tables": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "nvh_stream_position_state": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "nvh_stream_set_position_state": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "nvh_stream_drop_pending": (C.c_int, [_vp]),

@@ -160,6 +160,12 @@ int orc_mode_info(const orc_decoder *d, int mode_index, int *block_flag, int *bl
 int orc_floor0_apply_coeffs(orc_decoder *d, int floor_index, int block_size, float amp, const float *coeff,
                             float *residue, int reslen);
 /* type, post count (Floor1 _xList.Length; Floor0 _order) and _range of floor `floor_index`; returns the number of floors. */
+/* test hook: the tables Codebook.Init / Huffman.GenerateTable built (Codebook.cs:59-283, Huffman.cs:15-76), same calling
+ * convention as the product's nvh_stream_codebook_info / nvh_stream_codebook_tables */
+int orc_codebook_info(const orc_decoder *d, int book_index, int *dimensions, int *entries, int *map_type, int *prefix_bits,
+                      int *max_bits, int *n_prefix, int *n_overflow);
+int orc_codebook_tables(const orc_decoder *d, int book_index, int32_t *lengths, float *lookup, int32_t *prefix, int32_t *overflow);
+int orc_book_count(const orc_decoder *d);
 int orc_floor_info(const orc_decoder *d, int floor_index, int *type, int *post_count, int *range);
 
 /* IFloorData of one channel as Mapping.DecodePacket left it for the last packet given to orc_decode_packet_block

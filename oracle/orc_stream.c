@@ -489,6 +489,44 @@ int orc_floor1_apply_posts(orc_decoder *d, int floor_index, int block_size, cons
   return orc_floor_apply(&d->floors[floor_index], &data, block_size, residue, reslen);
 }
 
+int orc_book_count(const orc_decoder *d) { return d ? d->nbooks : 0; }
+
+int orc_codebook_info(const orc_decoder *d, int book_index, int *dimensions, int *entries, int *map_type, int *prefix_bits,
+                      int *max_bits, int *n_prefix, int *n_overflow) {
+  if (!d || book_index < 0 || book_index >= d->nbooks) return -1;
+  const orc_codebook *b = &d->books[book_index];
+  if (dimensions) *dimensions = b->dimensions;
+  if (entries) *entries = b->entries;
+  if (map_type) *map_type = b->map_type;
+  if (prefix_bits) *prefix_bits = b->prefix_bits;
+  if (max_bits) *max_bits = b->max_bits;
+  if (n_prefix) *n_prefix = b->prefix ? b->prefix_count : 0;
+  if (n_overflow) *n_overflow = b->overflow ? b->overflow_count : -1;
+  return 0;
+}
+
+static void orc_copy_nodes(const orc_huff_node *v, int n, int32_t *out) {
+  for (int i = 0; i < n; i++) {
+    out[5 * i] = v[i].present ? 1 : 0;
+    out[5 * i + 1] = v[i].value;
+    out[5 * i + 2] = v[i].length;
+    out[5 * i + 3] = v[i].bits;
+    out[5 * i + 4] = v[i].mask;
+  }
+}
+
+int orc_codebook_tables(const orc_decoder *d, int book_index, int32_t *lengths, float *lookup, int32_t *prefix, int32_t *overflow) {
+  if (!d || book_index < 0 || book_index >= d->nbooks) return -1;
+  const orc_codebook *b = &d->books[book_index];
+  if (lengths)
+    for (int i = 0; i < b->entries; i++) lengths[i] = b->lengths[i];
+  if (lookup && b->lookup)
+    for (int i = 0; i < b->entries * b->dimensions; i++) lookup[i] = b->lookup[i];
+  if (prefix && b->prefix) orc_copy_nodes(b->prefix, b->prefix_count, prefix);
+  if (overflow && b->overflow) orc_copy_nodes(b->overflow, b->overflow_count, overflow);
+  return 0;
+}
+
 int orc_floor_info(const orc_decoder *d, int floor_index, int *type, int *post_count, int *range) {
   if (!d) return 0;
   if (floor_index >= 0 && floor_index < d->nfloors) {

@@ -148,3 +148,29 @@ def test_c5_corpus_world1_from_device_buffers(oracle, ogg_bytes):
     host = corpus.decode_files_threaded(files[:8], device=0, workers=4, batch_frames=700)
     for i in range(8):
         _assert_same(host[i], out[i].cpu().numpy(), ("C5 host", i))
+
+
+@pytest.mark.parametrize("scale", [0.1, 1.0])
+def test_c5_corpus_1004_files_digests(scale):
+    """BASELINE C5 at world size 1, >= 1000 files: the SURVEY 8d corpus (tests/c5_corpus.py: 1000 writer files, lengths
+    log-uniform 5-300 s x scale, seed = file index, + the 4 TestFiles) decoded file-parallel through the HIP path into one
+    device arena (corpus.decode_files_to_device, what corpus.transcode(..., world=1, to_host=False) runs per rank); the
+    SHA-256 of every file's PCM equals the oracle's committed digest (tests/golden/c5_digests_scale*.json, written by
+    tools/corpus_c5.py --make-digests).  scale 0.1 (0.5-30 s per file, 270 k frames, 2.2 GB of PCM) runs always; the stated
+    size, scale 1.0 (3.1 M frames, 25 GB of PCM, about two minutes), runs with NVH_C5_FULL=1 (profiles/ has that run)."""
+    import os
+
+    from nvorbis_amd import corpus
+    from tests import c5_corpus
+    if scale == 1.0 and not os.environ.get("NVH_C5_FULL"):
+        pytest.skip("the full-size corpus runs with NVH_C5_FULL=1 (tools/corpus_c5.py --run --scale 1.0)")
+    dig = c5_corpus.load_digests(scale)
+    assert dig is not None, "tests/golden/c5_digests_scale%g.json is missing" % scale
+    files = c5_corpus.build_files(scale)
+    assert len(files) == 1004
+    assert [c5_corpus.file_digest(f) for f in files] == [r[0] for r in dig["digests"]]  # the very files the oracle decoded
+    arena, views = corpus.decode_files_to_device(files, device=0, workers=16)
+    assert int(arena.numel()) == dig["total_floats"]
+    bad = [i for i, v in enumerate(views)
+           if int(v.numel()) != dig["digests"][i][1] or c5_corpus.pcm_digest(v.cpu().numpy()) != dig["digests"][i][2]]
+    assert not bad, bad[:10]

@@ -333,3 +333,93 @@ def test_csharp_pinvoke_declarations_follow_the_header():
         src = open(os.path.join(ROOT, "csharp", fn)).read()
         for called in set(re.findall(r"NativeMethods\.(nvh_[a-z0-9_]+)\(", src)):
             assert called in decls, (fn, called)
+
+
+def _spec_books(setup_pkt):
+    """The codebook section of a setup header parsed by the spec-derived decoder (tests/vorbis_spec.py: written from the
+    Vorbis I specification, follows neither the C# reference nor oracle/)."""
+    from tests import vorbis_spec as vs
+    r = vs.BitReader(setup_pkt)
+    assert bytes(r.read(8) for _ in range(7)) == b"\x05vorbis"
+    return [vs.Codebook.parse(r) for _ in range(r.read(8) + 1)]
+
+
+def _tables(info_fn, tables_fn, handle, b, ok):
+    v = [C.c_int(0) for _ in range(7)]
+    assert info_fn(handle, b, *[C.byref(x) for x in v]) == ok
+    dims, entries, map_type, prefix_bits, max_bits, n_prefix, n_overflow = [x.value for x in v]
+    lengths = np.zeros(entries, np.int32)
+    lookup = np.zeros(max(entries * dims, 1), np.float32)
+    prefix = np.zeros(max(n_prefix, 1) * 5, np.int32)
+    overflow = np.zeros(max(n_overflow, 1) * 5, np.int32)
+    assert tables_fn(handle, b, lengths.ctypes.data, lookup.ctypes.data, prefix.ctypes.data, overflow.ctypes.data) == ok
+    return dict(dims=dims, entries=entries, map_type=map_type, prefix_bits=prefix_bits, max_bits=max_bits, n_prefix=n_prefix,
+                n_overflow=n_overflow, lengths=lengths, lookup=lookup[:entries * dims if map_type else 0],
+                prefix=prefix[:max(n_prefix, 0) * 5].reshape(-1, 5), overflow=overflow[:max(n_overflow, 0) * 5].reshape(-1, 5))
+
+
+@pytest.mark.parametrize("source", ["1test", "2test", "3test", "issue6test", "synthetic", "synthetic_floor0"])
+def test_codebook_tables_product_vs_oracle_vs_spec(oracle, ogg_bytes, source):
+    """Codebook.Init / InitLookupTable / Huffman.GenerateTable (Codebook.cs:59-283, Huffman.cs:15-76) compared DIRECTLY, not
+    through decoded PCM: for every codebook of the four shipped files and of the synthetic setups (lookup type 2 and
+    sequence_p books included) the product's lengths, VQ lookup table (bit patterns), prefix table and overflow list
+    (nvh_stream_codebook_tables) equal the oracle's, node for node in list order (first-match semantics); and both agree with
+    the spec-derived decoder, which shares no code or reading with either: codeword assignment by spec 3.2.1 ("lowest valued
+    available codeword", bit-reversed because the stream is LSb-first) and the VQ unpack of spec 3.2.1 / 3.3 in double."""
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss, vorbis_spec as vs
+    if source.startswith("synthetic"):
+        name = "floor0_stereo" if source.endswith("floor0") else "three_ch_res2_misaligned"
+        try:
+            cfg = ss.config(name)
+        except Exception:
+            pytest.skip("no synthetic configuration called %s" % name)
+        headers = ss.make_stream(cfg, 1, 1)[0][:3]
+    else:
+        headers = nv.demux_ogg(ogg_bytes[source])[0][:3]
+    st = nv.Stream(None, headers[0], headers[1], headers[2])
+    d = oracle.open_headers(headers)
+    L, O = nv.lib(), oracle.L
+    vp = C.c_void_p
+    O.orc_codebook_info.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int)] * 7
+    O.orc_codebook_tables.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    O.orc_book_count.argtypes = [vp]
+    try:
+        spec = _spec_books(headers[2])
+        assert O.orc_book_count(d) == len(spec)
+        kinds = set()
+        for b in range(len(spec)):
+            p = _tables(L.nvh_stream_codebook_info, L.nvh_stream_codebook_tables, st._h, b, 0)
+            o = _tables(O.orc_codebook_info, O.orc_codebook_tables, d, b, 0)
+            for k in ("dims", "entries", "map_type", "prefix_bits", "max_bits", "n_prefix", "n_overflow"):
+                assert p[k] == o[k], (b, k, p[k], o[k])
+            assert np.array_equal(p["lengths"], o["lengths"]), b
+            assert np.array_equal(p["lookup"].view(np.uint32), o["lookup"].view(np.uint32)), b
+            # unoccupied prefix slots hold a null node in the reference: compare occupancy, then the occupied nodes
+            assert np.array_equal(p["prefix"][:, 0], o["prefix"][:, 0]), b
+            occ = p["prefix"][:, 0] != 0
+            assert np.array_equal(p["prefix"][occ], o["prefix"][occ]), b
+            assert np.array_equal(p["overflow"], o["overflow"]), b
+            # ---- against the specification ----
+            sb = spec[b]
+            assert (p["dims"], p["entries"], p["map_type"]) == (sb.dims, sb.entries, sb.lookup_type), b
+            assert np.array_equal(np.maximum(p["lengths"], 0), np.maximum(np.asarray(sb.lengths, np.int32), 0)), b
+            want = {(e, w[1], vs.bitrev(w[0], w[1])) for e, w in enumerate(sb.words) if w is not None}
+            nodes = np.concatenate([p["prefix"][occ], p["overflow"]]) if p["n_prefix"] else np.zeros((0, 5), np.int32)
+            got = {(int(r[1]), int(r[2]), int(r[3])) for r in nodes if r[0]}
+            if len(want) > 1:
+                assert got == want, (b, sorted(got ^ want)[:6])
+                # a prefix slot is filled by the code whose `length` low bits equal the slot's (Huffman.cs:40-61)
+                for slot in np.nonzero(occ)[0]:
+                    _, val, ln, bits, mask = p["prefix"][slot]
+                    assert (int(slot) & ((1 << ln) - 1)) == bits and mask == (1 << ln) - 1, (b, slot)
+            if sb.lookup_type:
+                kinds.add((sb.lookup_type, int(bool(sb.sequence_p))))
+                tab = p["lookup"].reshape(sb.entries, sb.dims).astype(np.float64)
+                ref = np.array([sb.vector(e) for e in range(sb.entries)], np.float64)
+                assert np.abs(tab - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), b
+        if source == "synthetic":
+            assert {(1, 0), (1, 1), (2, 0)} <= kinds, kinds
+    finally:
+        O.orc_close(d)
+        st.close()

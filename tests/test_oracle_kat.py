@@ -267,3 +267,31 @@ def test_reference_pcm_digests_when_present(oracle, ogg_bytes):
         pcm, info = oracle.decode_ogg(ogg_bytes[name], clip=clip.endswith("1"))
         assert (pcm.size, info["channels"], info["sample_rate"]) == (int(count), int(channels), int(rate)), path
         assert hashlib.sha256(pcm.astype("<f4").tobytes()).hexdigest() == digest, path
+
+
+def test_oracle_pcm_is_frozen():
+    """The oracle's PCM for the four shipped files (clipping on and off) equals the digests committed by
+    tools/freeze_oracle.py: a change to oracle/ that moves one sample fails here, independently of the product."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("freeze_oracle", os.path.join(root, "tools", "freeze_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(mod.OUT))["digests"]
+    assert mod.digests() == want
+
+
+def test_c5_corpus_fixture_sample():
+    """tests/golden/c5_digests_scale*.json (the oracle's PCM digest of every file of the C5 corpus, tools/corpus_c5.py):
+    the corpus writer is deterministic and a sample of files decodes to the committed digests on this machine too."""
+    from tests import c5_corpus, oracle_py
+    ws = c5_corpus.writer_setup()
+    for scale in c5_corpus.DIGEST_SCALES:
+        d = c5_corpus.load_digests(scale)
+        assert d is not None and len(d["digests"]) == 1004 and d["total_floats"] == sum(r[1] for r in d["digests"])
+        for i in ((0, 17, 999, 1000, 1003) if scale < 1 else (3,)):
+            f = c5_corpus.corpus_file(ws, i, scale)
+            pcm, info = oracle_py.load().decode_ogg(f)
+            assert [c5_corpus.file_digest(f), int(pcm.size), c5_corpus.pcm_digest(pcm), int(info["channels"])] == d["digests"][i], (scale, i)
