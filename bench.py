@@ -12,9 +12,17 @@ the data path.
 Launch: python bench.py --gpus N --steps K --warmup W.  For N > 1 the script starts its own ranks (it re-executes
 itself under torch.distributed.run, one rank per GPU over RCCL) unless it already runs as a rank (WORLD_SIZE set).
 
-A step is `passes_per_step` passes over the batch, chosen from a calibration run so that the timed region lasts at least
-~0.25 s whatever --steps says (a 20-step run of one 45 us pass each would time 0.9 ms of launch jitter); the line states
-it in config, and `value` counts every pass.
+A step is `passes_per_step` passes, chosen from a calibration run so that the timed region lasts at least ~2 s whatever
+--steps says (a 20-step run of one 45 us pass each would time 0.9 ms of launch jitter, and an outside observer sampling GPU
+activity would see nothing); the line states it in config, and `value` counts every pass.
+
+Working set: the passes rotate over `--streams` decoder instances (own nvh_ctx / HIP stream) x R resident 4096-frame batches
+each, R chosen so that what the passes touch (descriptors + work planes + PCM, ~76 MB per batch) exceeds `--working-set-mib`
+(default 512 MiB, twice the 256 MiB Infinity Cache): `value` and `roofline` are the HBM-resident regime.  The same loop over
+one batch per stream (working set ~150 MB, L3-resident -- what rounds 1 and 2 reported) is in `roofline.l3_resident`.
+
+`configs`: the other BASELINE.json workloads on full-depth packets (C2 G-rand, C3 Markov 256/2048, C4 six channels n = 4096
+psize 48), kernel-only, one stream, hipEvents -- parity-test cases timed for the record, not the headline.
 """
 import argparse
 import json
@@ -125,16 +133,89 @@ def copy_ceiling(torch, nv, ctx, ts, mib=1024, iters=20):
     return (2.0 * n * iters) / (ms.value * 1e-3) / 1e9 if ok and ms.value > 0 else None
 
 
+def make_batches(nv, torch, ctx, headers, audio, ch, frames, count, seed_off=0):
+    """`count` resident batches of `frames` frames each on one stream (= one HIP stream): (stream, [(batch, pcm)])."""
+    stream = nv.Stream(ctx, headers[0], headers[1], headers[2])
+    # priming frame (a first packet emits nothing, StreamDecoder.cs:446-450) goes through a batch of its own
+    stream.push_packet(audio[seed_off % len(audio)], -1, 0)
+    stream.synth_host()
+    out, k = [], seed_off + 1
+    for _ in range(count):
+        while stream.pending()[0] < frames:
+            stream.push_packet(audio[k % len(audio)], -1, 0)
+            k += 1
+        b = stream.upload_batch()
+        pcm = torch.empty(max(b.samples * ch, 1), dtype=torch.float32, device="cuda")
+        out.append((b, pcm))
+    return stream, out
+
+
+def config_lines(nv, torch, ctx, root):
+    """Kernel-only timings of the other BASELINE.json workloads on full-depth packets (tests/vorbis_encode.py writes them:
+    a classification for every partition, a VQ entry for every vector of every cascade stage; SURVEY 8d generators)."""
+    import numpy as np
+    from tests import vorbis_encode as ve
+    data = open(os.path.join(root, "tests", "golden", "3test.ogg"), "rb").read()
+    hdr3 = ve.shipped_headers(data)
+    S3 = ve.setup_of(hdr3)
+    rng = np.random.default_rng(7)
+    pool3 = ve.packet_pool(S3, 20260928, per_kind=256)
+    out = {}
+
+    def run(key, what, hdr, packets, frames):
+        st = nv.Stream(ctx, hdr[0], hdr[1], hdr[2])
+        audio = packets[3:]
+        st.push_packet(audio[0], -1, 0)
+        st.synth_host()
+        k = 0
+        while st.pending()[0] < frames and k < len(audio) - 1:
+            st.push_packet(audio[1 + k], -1, 0)
+            k += 1
+        geo = st.pending_geometry()
+        b = st.upload_batch()
+        pcm = torch.empty(max(b.samples * st.channels, 1), dtype=torch.float32, device="cuda")
+        b.time(pcm.data_ptr(), pcm.numel(), 5)
+        iters = 40
+        tot, km = b.time(pcm.data_ptr(), pcm.numel(), iters)
+        names = b.kernels()
+        live = [i for i in range(4) if names[i] != "-"]
+        # SURVEY 8d: per ch-frame n/2 * 4 B of spectrum in + (emitted samples) * 4 B of PCM out
+        alg = st.channels * 4 * (sum(int(g[0]) // 2 for g in geo) + b.samples)
+        pass_ms = tot / iters
+        dom = max(live, key=lambda i: km[i])
+        out[key] = {"workload": what, "frames": b.frames, "channels": st.channels, "frames_per_s_kernel_only": b.frames / (pass_ms * 1e-3),
+                    "us_per_batch": pass_ms * 1e3, "kernels_us": {names[i]: km[i] * 1e3 for i in live},
+                    "algorithmic_bytes_per_batch": alg, "frac_of_hbm_peak_pipeline": alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "frac_of_hbm_peak_dominant_kernel": alg / (km[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "descriptor_bytes_per_frame": b.descriptor_bytes / max(b.frames, 1)}
+        b.free()
+        st.close()
+
+    p, _ = ve.stream_from_pool(S3, hdr3, pool3, np.ones(4200, dtype=bool), rng)
+    run("C2_grand", "C2 G-rand: 4096 stereo n=2048 LL frames, every partition and cascade stage coded", hdr3, p, 4096)
+    p, _ = ve.stream_from_pool(S3, hdr3, pool3, ve.markov_kinds(np.random.default_rng(7), 4700), rng)
+    run("C3_markov", "C3: 4096 stereo frames, block kinds from the 256/2048 Markov chain (seed 7), full depth", hdr3, p, 4096)
+    h4 = ve.c4_headers(hdr3, psize=48)
+    S4 = ve.setup_of(h4)
+    pool4 = ve.packet_pool(S4, 148, per_kind=128, class_weights=[0] + [1] * 9)
+    p, _ = ve.stream_from_pool(S4, h4, pool4, np.ones(2100, dtype=bool), rng)
+    run("C4_psize48", "C4: 2048 six-channel n=4096 frames, coupling [(0,2),(3,4)], Residue2 psize 48, full depth", h4, p, 2048)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2 G-rand / C3 / C4 kernel-only lines")
     ap.add_argument("--no-check", action="store_true", help="profiling builds with phases masked out produce garbage PCM")
     ap.add_argument("--streams", type=int, default=2,
-                    help="independent decoder instances (own nvh_ctx / HIP stream / resident batch) the passes rotate over")
-    ap.add_argument("--min-timed-ms", type=float, default=250.0, help="lower bound of the timed region (sets passes_per_step)")
+                    help="independent decoder instances (own nvh_ctx / HIP stream) the passes rotate over")
+    ap.add_argument("--working-set-mib", type=float, default=512.0,
+                    help="lower bound of what the rotating passes touch (resident batches per stream follow from it)")
+    ap.add_argument("--min-timed-ms", type=float, default=2000.0, help="lower bound of the timed region (sets passes_per_step)")
     args = ap.parse_args()
 
     import torch
@@ -172,68 +253,93 @@ def main():
     headers, ll, ch = ll_packets(nv, os.path.join(ROOT, "tests", "golden", "3test.ogg"))
     assert ch == 2 and len(ll) > 0
 
-    # S independent decoder instances, each with its own HIP stream and its own resident 4096-frame batch: a
-    # step is one pass of the hot path over one batch, and consecutive steps go to different instances, so the
-    # GPU overlaps the tail of one batch's kernels with the head of the next one's (what a corpus transcoder
-    # does with independent files).  Instance 0 also provides the serial per-kernel timings below.
+    # S decoder instances, each with its own HIP stream, each holding R resident 4096-frame batches (own descriptors, work
+    # planes and PCM): a pass is the hot path over one batch; consecutive passes go to different instances, so the GPU
+    # overlaps the tail of one batch's kernels with the head of the next one's (what a corpus transcoder does with
+    # independent files), and a batch is revisited only after everything else -- > 2x the Infinity Cache -- went by.
+    nin = max(1, args.streams)
+    per_batch_bytes = FRAMES * (2200 + 2 * ch * (BLOCK // 2) * 4)  # descriptors + compact work planes + PCM, touched per pass
+    reps = max(1, int(args.working_set_mib * (1 << 20) / (nin * per_batch_bytes) + 0.999))
     insts = []
-    for k in range(max(1, args.streams)):
+    for k in range(nin):
         ts = torch.cuda.Stream()  # never the legacy default stream: it serialises against every other stream
         ctx_k = nv.Context(local_rank)
         ctx_k.set_hip_stream(ts.cuda_stream)
-        stream_k = nv.Stream(ctx_k, headers[0], headers[1], headers[2])
-        # priming frame (a first packet emits nothing, StreamDecoder.cs:446-450) goes through a batch of its own
-        stream_k.push_packet(ll[(rank * 7 + k * 13) % len(ll)], -1, 0)
-        stream_k.synth_host()
-        for i in range(FRAMES):
-            stream_k.push_packet(ll[(i + rank * 7 + k * 13 + 1) % len(ll)], -1, 0)
-        batch_k = stream_k.upload_batch()
-        assert batch_k.frames == FRAMES and batch_k.samples == FRAMES * (BLOCK // 2), (batch_k.frames, batch_k.samples)
-        pcm_k = torch.empty(batch_k.samples * ch, dtype=torch.float32, device="cuda")
-        insts.append((ts, ctx_k, stream_k, batch_k, pcm_k))
-    _, ctx, stream, batch, pcm = insts[0]
+        stream_k, batches_k = make_batches(nv, torch, ctx_k, headers, ll, ch, FRAMES, reps, seed_off=rank * 7 + k * 13)
+        for b, _ in batches_k:
+            assert b.frames == FRAMES and b.samples == FRAMES * (BLOCK // 2), (b.frames, b.samples)
+        insts.append((ts, ctx_k, stream_k, batches_k))
+    _, ctx, stream, batches0 = insts[0]
+    batch, pcm = batches0[0]
     cap = pcm.numel()
-    nin = len(insts)
+    touched = sum(b.descriptor_bytes + 2 * b.samples * ch * 4 for _, _, _, bk in insts for b, _ in bk)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_passes(n):
-        for i in range(n):
-            insts[i % nin][3].synth(insts[i % nin][4].data_ptr(), cap)
+    def make_order(r):
+        return [insts[k][3][j] for j in range(r) for k in range(nin)]
 
-    # calibration (untimed): how long one pass takes here, so that a step can be made of enough passes
-    run_passes(8)
-    barrier()
-    t0 = time.perf_counter()
-    run_passes(64)
-    barrier()
-    pass_ms = (time.perf_counter() - t0) / 64 * 1e3
-    if dist is not None:
-        t = torch.tensor([pass_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        pass_ms = float(t.item())
-    passes_per_step = max(1, int(args.min_timed_ms / max(args.steps, 1) / max(pass_ms, 1e-6) + 0.999))
+    def timed(order, steps, warmup, min_ms):
+        """`steps` steps of passes_per_step passes rotating over `order`; returns (elapsed s, passes, passes_per_step)."""
+        pos = [0]
 
-    for _ in range(args.warmup):
-        run_passes(passes_per_step)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_passes(passes_per_step)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_passes = args.steps * passes_per_step
+        def run_passes(n):
+            i = pos[0]
+            for _ in range(n):
+                b, p = order[i % len(order)]
+                b.synth(p.data_ptr(), cap)
+                i += 1
+            pos[0] = i
 
-    # per-kernel durations, hipEvents on the launch stream (rank 0 reports)
-    iters = 50
-    total_ms, km = batch.time(pcm.data_ptr(), cap, iters)
+        run_passes(2 * len(order))  # calibration (untimed): how long one pass takes here
+        barrier()
+        t0 = time.perf_counter()
+        run_passes(64)
+        barrier()
+        pass_ms = (time.perf_counter() - t0) / 64 * 1e3
+        if dist is not None:
+            t = torch.tensor([pass_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pass_ms = float(t.item())
+        pps = max(1, int(min_ms / max(steps, 1) / max(pass_ms, 1e-6) + 0.999))
+        for _ in range(warmup):
+            run_passes(pps)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_passes(pps)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, steps * pps, pps
+
+    # ---- the timed region of the headline: W warmup steps, exactly K steps, working set past the Infinity Cache ----
+    elapsed, total_passes, passes_per_step = timed(make_order(reps), args.steps, args.warmup, args.min_timed_ms)
+    # the same loop over one batch per stream (L3-resident, the regime of the round-1 / round-2 lines), shorter
+    el_l3, passes_l3, _ = timed(make_order(1), max(args.steps // 4, 1), max(args.warmup // 4, 1), args.min_timed_ms / 4)
+
+    # per-kernel durations, hipEvents on the launch stream (rank 0 reports): rotating over instance 0's batches one launch
+    # at a time (HBM-resident when reps > 1) and repeated on one batch (L3-resident)
+    names = None
+    km = [0.0] * 4
+    total_ms, rounds = 0.0, max(1, 48 // len(batches0))
+    for b, p in batches0:
+        b.time(p.data_ptr(), cap, 1)
+    for _ in range(rounds):
+        for b, p in batches0:
+            t, k4 = b.time(p.data_ptr(), cap, 1)
+            total_ms += t
+            km = [x + y for x, y in zip(km, k4)]
+    n_ev = rounds * len(batches0)
+    km = [x / n_ev for x in km]
+    total_ms /= n_ev
+    total_l3, km_l3 = batch.time(pcm.data_ptr(), cap, 50)
     checksum = float(pcm.double().abs().sum().item())
     assert args.no_check or (checksum > 0 and bool(torch.isfinite(pcm).all().item()))
 
@@ -249,18 +355,20 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh);
         # null when the committed profile does not cover the kernel that ran
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_build = None, None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 traffic = tj.get("kernels", {}).get(names[dom], {}).get("hbm_bytes")
+                traffic_build = tj.get("build")
                 if traffic is not None:
                     traffic_source = "profiles/traffic.json: %s (committed rocprofv3 --pmc passes of this command, not measured in this run)" % tj.get("source", "?")
             except Exception:
                 traffic = None
         ceiling = copy_ceiling(torch, nv, ctx, insts[0][0])
         step_ms = elapsed / total_passes * 1e3
+        l3_ms = el_l3 / passes_l3 * 1e3
         out = {
             "metric": "decoded Vorbis frames/sec (44.1 kHz stereo long-block)",
             "value": world * FRAMES * total_passes / elapsed,
@@ -273,25 +381,37 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (3test.ogg long/long packets tiled to 4096 frames per GPU, device resident)",
+            "data": "synthetic (3test.ogg long/long packets tiled to %d resident batches of 4096 frames per GPU)" % (nin * reps),
             "config": {"workload": "C2: 4096 stereo long-block (n=2048) frames, Floor1+Residue2+coupling, IMDCT+window+OLA",
-                       "frames_per_gpu": FRAMES, "channels": ch, "block": BLOCK, "parallelism": "frame-parallel x%d, %d HIP streams per GPU" % (world, nin),
-                       "passes_per_step": passes_per_step, "ms_per_pass": step_ms,
+                       "frames_per_gpu": FRAMES, "channels": ch, "block": BLOCK,
+                       "parallelism": "frame-parallel x%d, %d HIP streams per GPU x %d resident batches each" % (world, nin, reps),
+                       "passes_per_step": passes_per_step, "ms_per_pass": step_ms, "timed_region_s": elapsed,
+                       "working_set_MiB": touched / (1 << 20),
                        "descriptor_bytes_per_frame": batch.descriptor_bytes / FRAMES},
             "kernels_ms": {names[k]: km[k] for k in live},
-            "pipeline_ms_events": total_ms / iters,
+            "pipeline_ms_events": total_ms,
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_build_matches": (traffic_build == nv.native.build_id()) if traffic is not None else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                         # the same bytes over one whole pass of the pipeline (all kernels, the batches of the %d streams overlapped)
+                         "working_set_MiB": touched / (1 << 20), "regime": "HBM-resident: a batch is revisited after %.0f MiB went by (Infinity Cache: 256 MiB)" % (touched / (1 << 20)),
+                         # the same bytes over one whole pass of the pipeline (all kernels, the batches of the streams overlapped)
                          "whole_pass_GBps": alg_bytes / (step_ms * 1e-3) / 1e9, "whole_pass_frac": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "l3_resident": {"working_set_MiB": nin * per_batch_bytes / (1 << 20), "frames_per_s": world * FRAMES * passes_l3 / el_l3,
+                                         "ms_per_pass": l3_ms, "kernels_ms": {names[k]: km_l3[k] for k in live},
+                                         "frac": alg_bytes / (km_l3[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                         "whole_pass_frac": alg_bytes / (l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                          "copy_ceiling_GBps": ceiling},
+            "build": nv.native.build_id(),
         }
+        if world == 1 and not args.no_configs:
+            out["configs"] = config_lines(nv, torch, ctx, ROOT)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(headers, ll)
         print(json.dumps(out), flush=True)
-    for _, ctx_k, stream_k, batch_k, _ in insts:
-        batch_k.free()
+    for _, ctx_k, stream_k, batches_k in insts:
+        for b, _ in batches_k:
+            b.free()
         stream_k.close()
         ctx_k.close()
     if dist is not None:

@@ -1,16 +1,19 @@
 #!/bin/bash
-# profile_round.sh NAME -- the rocprofv3 passes behind profiles/NAME.{txt,json} (run on the GPU box via gpurun):
-#   kernel trace + stats, then FETCH_SIZE, WRITE_SIZE and the instruction mix in separate --pmc passes.
+# profile_round.sh NAME [NOTE] [BENCH FLAGS] -- the rocprofv3 passes behind profiles/NAME.{txt,json} (run on the GPU box via gpurun):
+#   kernel trace + stats, then FETCH_SIZE, WRITE_SIZE and the instruction mix in separate --pmc passes (never together with
+#   a trace domain other than --kernel-trace).  The profiled command is bench.py's headline loop: the passes rotate over
+#   enough resident batches to exceed the Infinity Cache (bench.py --working-set-mib), so FETCH_SIZE / WRITE_SIZE are HBM bytes.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-NAME=${1:-r01}
+NAME=${1:-r03}
 OUT=gpurun_out/prof_$NAME
 rm -rf $OUT; mkdir -p $OUT
-B="python bench.py --no-cpu-baseline --steps 20 --warmup 5 --streams 1"
+B="python bench.py --no-cpu-baseline --no-configs --steps 20 --warmup 5 --min-timed-ms 300 --streams 1 $3"
+BUILD=$(python -c "from nvorbis_amd import native; print(native.build_id())" 2>/dev/null | tail -1)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- $B > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES -d $OUT/insts -- $B > $OUT/insts.log 2>&1
 python tools/rocprof_summary.py --trace $(find $OUT/trace -name '*.db') --fetch $(find $OUT/fetch -name '*.db') \
   --write $(find $OUT/write -name '*.db') --insts $(find $OUT/insts -name '*.db') --out $OUT/summary \
-  --note "$2"
+  --note "$2" --traffic-out $OUT/traffic.json --build "$BUILD" --calibration-from profiles/traffic.json
 tail -1 $OUT/trace.log

@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--prefix", default="k_", help="only kernels whose name starts with this prefix")
     ap.add_argument("--note", default="")
+    ap.add_argument("--traffic-out", help="write the per-kernel HBM bytes in the shape of profiles/traffic.json (bench.py reads it)")
+    ap.add_argument("--build", default=None, help="nvh_version() of the library that was profiled (bench.py compares it with its own)")
+    ap.add_argument("--calibration-from", default=None, help="an older traffic.json whose `calibration` block is carried over")
     a = ap.parse_args()
     ks = {k: v for k, v in kernels_from_trace(a.trace).items() if k.startswith(a.prefix)}
     fetch = counter_avg(a.fetch, "FETCH_SIZE") if a.fetch else {}
@@ -76,6 +79,15 @@ def main():
         for k, v in ks.items():
             lines.append("%-22s %14.0f %14.0f %14.0f %16.0f" % (k, v.get("sq_insts_valu", 0), v.get("sq_insts_salu", 0),
                                                                  v.get("sq_insts_lds", 0), v.get("sq_wave_cycles", 0)))
+    if a.traffic_out:
+        tj = {"source": a.note, "build": a.build,
+              "kernels": {k: {kk: v[kk] for kk in ("avg_us", "hbm_bytes", "hbm_read_bytes", "hbm_write_bytes") if kk in v} for k, v in ks.items()}}
+        if a.calibration_from:
+            try:
+                tj["calibration"] = json.load(open(a.calibration_from)).get("calibration")
+            except Exception:
+                pass
+        json.dump(tj, open(a.traffic_out, "w"), indent=1, sort_keys=True)
     open(a.out + ".txt", "w").write("\n".join(lines) + "\n")
     json.dump(ks, open(a.out + ".json", "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
