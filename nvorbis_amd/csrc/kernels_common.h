@@ -77,6 +77,20 @@ struct NvhRunArgs {
 #endif
 };
 
+// Arguments of the slab synthesis kernel (kernels_synth.hip).
+struct NvhSynthArgs {
+  const uint4* consts;      // inverse_dB_table (256 floats) followed by the lattice pool, const_vecs 16-byte units
+  const uint4* slabs;       // nframes slabs at stride_vecs
+  float* work;              // [frame][channel][block1] planes: receives the compact IMDCT output k_ola_compact reads
+  int* err;                 // device error word
+  const float* mdct_a[2];
+  const float* mdct_b[2];
+  const float* mdct_c[2];
+  const float* mdct_tw[2];
+  int const_vecs, stride_vecs, cap_vecs;  // cap_vecs: largest slab of the batch = the LDS slab area
+  int channels, block1;
+};
+
 #ifdef __HIPCC__
 // HasClipped (StreamDecoder.cs:728) is sticky: one lane per wavefront that clipped looks at the flag and only sets it
 // while it is still clear.  A stream that clips everywhere (loud material; Floor0 curves on random bits) otherwise

@@ -1,0 +1,400 @@
+// kernels_synth.hip -- the slab synthesis kernel (round 3): residue adds + inverse coupling + Floor1 multiply + inverse MDCT
+// of one frame per workgroup, fed by ONE LDS-DMA round trip.
+//
+//   Array.Clear + IResidue.Decode adds   Mapping.cs:108,133; Residue1.cs:8-26, Residue2.cs:23-47
+//   inverse square-polar coupling         Mapping.cs:137-182
+//   IFloor.Apply (the multiply)           Floor1.cs:196-222, RenderLineMulti :316-341, inverse_dB_table :345-410
+//   IMdct.Reverse                         Mdct.cs:65-313 (imdct_wave.h)
+//   (integer side, k_prepare_slabs)       Floor1.UnwrapPosts :224-297, the sorted / flagged post walk :196-216,
+//                                         the (stage, partition, channel) geometry of Residue0.cs:157-170, Residue2.cs:23-47
+//
+// Why a second form of k_spectrum_imdct (kernels_spectrum.hip), same arithmetic, same stream shapes (<= 2 channels, Floor1,
+// lattice books, <= 1 coupling step, blocks 256..2048, one residue pass per frame): that kernel's workgroup spent 10.8 k of its
+// 29.8 k cycles before its first useful instruction -- frame record, then the slices the record points to, then the setup
+// records those point to (three dependent global round trips), then copies of all of it into LDS through registers, pair
+// records, chain-head compaction, and the Floor1 unwrap (a chain of dependent LDS round trips on two otherwise idle
+// wavefronts).  None of that depends on a float.  Here it is done once per batch by k_prepare_slabs (one wavefront per frame,
+// integer work only), which leaves every frame's side information as one contiguous slab in its final LDS layout
+// (nvh_format.h: NvhSlabHdr), at a fixed stride:
+//   * the workgroup issues the slab's first 4 KB (global_load_lds_dwordx4, 1 KB per wavefront-instruction) and the
+//     stream constants (inverse_dB_table + lattice pool) before it knows anything about the frame, clears the spectrum
+//     while they fly, and passes one barrier: ONE memory round trip, no staging instructions, no VGPR round trip;
+//   * the header then comes out of LDS; only frames whose slab exceeds 4 KB fetch the rest (second round trip);
+//   * the residue walk follows chain-major records (one ds_read_b128 per cascade stage, no link array), the floor multiply
+//     reads the segment list straight from the slab.
+// From the floor multiply on the kernel is k_spectrum_imdct's: same fused tail, same in-place wavefront IMDCT, same compact
+// output for k_ola_compact.  Bit-exactness: the additions of a partition happen in stage order inside the owning lane,
+// every float expression is one rounded operation (-ffp-contract=off).
+#include <hip/hip_runtime.h>
+
+#include "imdct_wave.h"
+#include "kernels_common.h"
+#include "spectrum_dev.h"
+
+namespace {
+
+// 16 bytes per lane, 1 KB per wavefront-instruction, global -> LDS without a register round trip.  The LDS destination is
+// wave-uniform (M0) + lane * 16; lanes that are switched off move nothing.
+__device__ __forceinline__ void dma16(const uint4* __restrict__ gsrc, float* lds_chunk_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_chunk_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+}  // namespace
+
+// ---- integer side: descriptors -> slabs, one wavefront per frame, once per batch -----------------------------------------
+extern "C" __global__ void __launch_bounds__(64)
+k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int stride_vecs) {
+  __shared__ __attribute__((aligned(16))) FloorScratch Q;
+  __shared__ int s_err;
+  const int f = blockIdx.x, lane = threadIdx.x, nch = S.channels;
+  uint4* slab = slabs + (long long)f * stride_vecs;
+  const NvhFrame fr = Bt.frames[f];
+  NvhSlabHdr H;
+  H.n = 0; H.exec_mask = 0; H.flags = 0; H.mode[0] = H.mode[1] = 0; H.nseg[0] = H.nseg[1] = 0; H.nheads = 0; H.nrec = 0;
+  H.off_seg[0] = H.off_seg[1] = 2; H.off_heads = H.off_rec = H.off_ent = 2; H.vecs = 2; H.hp = 0; H.rgeom = 0; H.pad = 0; H.hp_magic = 0;
+  if (fr.n == 0) {
+    if (lane == 0) {
+      slab[0] = reinterpret_cast<const uint4*>(&H)[0];
+      slab[1] = reinterpret_cast<const uint4*>(&H)[1];
+    }
+    return;
+  }
+  const int half = fr.n >> 1;
+  const NvhDevMapping mp = S.mappings[fr.mapping];
+  const NvhChan* chans = Bt.chans + (long long)f * nch;  // every frame owns exactly `channels` records (host_parse.cpp)
+  if (lane == 0) s_err = 0;
+  sp_wave_sync();
+  unsigned off = 2;
+  H.n = (uint16_t)fr.n;
+  H.exec_mask = (uint8_t)(fr.exec_mask & 3u);
+  if (fr.mdct_slot) H.flags |= NVH_SLAB_MDCT_SLOT;
+  // ---- floors: Floor1.UnwrapPosts + the segment list of the flagged posts in X order (spectrum_dev.h: floor_prepare) ----
+  for (int c = 0; c < nch && c < 2; ++c) {
+    const FloorLane L = load_floor_lane(S, Bt, chans, c, nch, lane);
+    floor_prepare(&Q, L, lane, half, &s_err, S.recip);
+    sp_wave_sync();
+    const int mode = L.mode;  // uniform
+    const int ns = mode == 1 ? Q.nseg : 0;
+    H.mode[c] = (uint8_t)mode;
+    H.nseg[c] = (uint8_t)ns;
+    H.off_seg[c] = (uint16_t)off;
+    if (mode == 1) {
+      for (int i = lane; i < ns; i += 64) slab[off + i] = *reinterpret_cast<const uint4*>(&Q.seg[i]);
+      uint32_t* mg = reinterpret_cast<uint32_t*>(slab + off + ns);
+      for (int i = lane; i < ((ns + 3) & ~3); i += 64) mg[i] = i < ns ? Q.magic[i] : 0u;
+      off += (unsigned)ns + (unsigned)((ns + 3) >> 2);
+    }
+    sp_wave_sync();  // the next channel reuses the scratch block
+  }
+  if (s_err) H.flags |= NVH_SLAB_FLOOR_FAULT;
+  // ---- residue: chains of vector writes, chain-major, every write resolved to its pair record ----
+  const int npass = (int)(fr.pass_end - fr.pass_begin);
+  if (npass > 1) __builtin_trap();  // the host launches this path for batches with at most one residue pass per frame
+  int rtype = 0, rch = 1;
+  H.off_heads = (uint16_t)off;
+  if (npass == 1) {
+    const NvhResPass* gp = Bt.passes + fr.pass_begin;
+    const NvhDevResidue* R = &S.residues[gp->residue];
+    rtype = R->type;
+    rch = R->real_channels;
+    const unsigned psz = (unsigned)R->partition_size, rbegin = (unsigned)R->begin, rch_magic = R->rch_magic;
+    H.hp = (uint16_t)(psz >> 1);
+    H.hp_magic = R->hp_magic;
+    const int nops = (int)fr.op_count;
+    const NvhResOp* ops = Bt.ops + fr.op_begin;
+    const uint16_t* links = Bt.op_link + fr.op_begin;
+    // pass A: how many chains
+    int nheads = 0;
+    for (int base = 0; base < nops; base += 64) {
+      const int o = base + lane;
+      nheads += __popcll(__ballot(o < nops && !(links[o < nops ? o : 0] & 0x8000u)));
+    }
+    uint16_t* heads = reinterpret_cast<uint16_t*>(slab + off);
+    const unsigned off_rec = off + (unsigned)((nheads + 7) >> 3);
+    uint4* recs = slab + off_rec;
+    // pass B: chain lengths -> record positions; every head lane then writes its chain
+    int hcount = 0, rpos = 0;
+    for (int base = 0; base < nops; base += 64) {
+      const int o = base + lane;
+      const bool head = o < nops && !(links[o < nops ? o : 0] & 0x8000u);
+      unsigned len = 0;
+      if (head) {
+        int q = o;
+        for (;;) {
+          ++len;
+          const unsigned l = links[q] & 0x7FFFu;
+          if (l == NVH_LINK_NONE) break;
+          q = (int)l;
+        }
+      }
+      const unsigned incl = wave_incl_scan(len, lane);
+      const unsigned total = __shfl(incl, 63);
+      const unsigned long long m = __ballot(head);
+      if (head) {
+        const unsigned first = (unsigned)rpos + incl - len;
+        heads[hcount + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)first;
+        int q = o;
+        for (unsigned k = 0; k < len; ++k) {
+          const NvhResOp op = ops[q];
+          const NvhDevBook bk = S.books[op.book];
+          const unsigned offset = rbegin + (unsigned)op.partition * psz;
+          const unsigned xbase = (rtype == 2 && rch > 1) ? __umulhi(offset, rch_magic) : offset;
+          uint4 rec;
+          rec.x = (op.ent_off - fr.ent_begin) | (xbase << 16);
+          rec.y = bk.lat_off | (bk.lat_values << 16);
+          rec.z = bk.lat_magic;
+          rec.w = bk.dim | ((unsigned)op.channel << 8) | (k + 1 < len ? 0x8000u : 0u) | (bk.dim_magic16 << 16);
+          recs[first + k] = rec;
+          q = (int)(links[q] & 0x7FFFu);
+        }
+      }
+      hcount += __popcll(m);
+      rpos += (int)total;
+    }
+    // pad the head list to whole vectors (read by nobody, but keep the slab deterministic)
+    for (int i = nheads + lane; i < ((nheads + 7) & ~7); i += 64) heads[i] = 0;
+    H.nheads = (uint16_t)nheads;
+    H.nrec = (uint16_t)rpos;
+    H.off_rec = (uint16_t)off_rec;
+    off = off_rec + (unsigned)rpos;
+  } else {
+    H.off_rec = (uint16_t)off;
+  }
+  H.rgeom = (uint8_t)(rtype | (rch << 4));
+  // ---- entries of the frame, from their 2-byte offset to a 16-byte boundary ----
+  H.off_ent = (uint16_t)off;
+  {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(slab + off);
+    const uint16_t* src = Bt.entries + fr.ent_begin;
+    const int ne = (int)fr.ent_count;
+    for (int i = lane; i < ((ne + 7) & ~7); i += 64) dst[i] = i < ne ? src[i] : (uint16_t)NVH_ENTRY_SKIP;
+    off += (unsigned)((ne + 7) >> 3);
+  }
+  if ((int)off > stride_vecs || off > 0xFFFFu) __builtin_trap();  // the host sizes the stride from the batch's largest frame
+  H.vecs = (uint16_t)off;
+  // ---- inverse coupling: in the chain walk when one lane holds both channels of a bin, else a pass of its own ----
+  if (nch == 2 && mp.coupling_steps == 1 && (fr.exec_mask & 3u) != 0) {
+    if (S.coupling[mp.coupling_off] == 1) H.flags |= NVH_SLAB_MG1;
+    H.flags |= (npass == 1 && rtype == 2 && rch == 2) ? NVH_SLAB_SWEEP_COUPLES : NVH_SLAB_COUPLE_PASS;
+  }
+  if (lane == 0) {
+    slab[0] = reinterpret_cast<const uint4*>(&H)[0];
+    slab[1] = reinterpret_cast<const uint4*>(&H)[1];
+  }
+}
+
+// ---- float side ------------------------------------------------------------------------------------------------------------
+// LDS map (dynamic, floats): [ inverse_dB_table 256 | lattice pool (const_vecs * 4 - 256) | slab image cap_vecs * 4 |
+//                              spectrum channels * block1 / 2 | block1 / 16 of IMDCT padding ]
+
+extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int f = blockIdx.x;
+  const int nch = A.channels;
+  float* s_db = smem;
+  const uint32_t* s_lat = reinterpret_cast<const uint32_t*>(smem + 256);
+  float* slab = smem + A.const_vecs * 4;
+  float* spec = slab + A.cap_vecs * 4;
+  const int half_max = A.block1 >> 1;
+#ifdef NVH_DEBUG
+#define SY_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + (k)] = clock64(); } while (0)
+#else
+#define SY_T(k) do { } while (0)
+#endif
+  SY_T(0);
+  // ---- one round trip: constants + the first 4 KB of the slab by LDS-DMA, the spectrum cleared meanwhile ----
+  const uint4* gslab = A.slabs + (long long)f * A.stride_vecs;
+  {
+    const int v = tid;  // 16-byte unit handled by this lane: wavefront w moves units [64 w, 64 w + 64)
+    if (v < A.cap_vecs) dma16(gslab + v, slab + wv * 256);
+    for (int c0 = wv * 64; c0 < A.const_vecs; c0 += SP_THREADS)
+      if (c0 + lane < A.const_vecs) dma16(A.consts + c0 + lane, smem + c0 * 4);
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = tid; i < (nch * half_max) >> 2; i += SP_THREADS) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
+  }
+  __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
+  SY_T(1);
+  const uint4 h0 = reinterpret_cast<const uint4*>(slab)[0], h1 = reinterpret_cast<const uint4*>(slab)[1];
+  const unsigned w0 = __builtin_amdgcn_readfirstlane(h0.x), w1 = __builtin_amdgcn_readfirstlane(h0.y);
+  const unsigned w2 = __builtin_amdgcn_readfirstlane(h0.z), w3 = __builtin_amdgcn_readfirstlane(h0.w);
+  const unsigned w4 = __builtin_amdgcn_readfirstlane(h1.x), w5 = __builtin_amdgcn_readfirstlane(h1.y);
+  const unsigned w6 = __builtin_amdgcn_readfirstlane(h1.z), w7 = __builtin_amdgcn_readfirstlane(h1.w);
+  const int n = (int)(w0 & 0xFFFFu);
+  if (n == 0) return;
+  const unsigned exec_mask = (w0 >> 16) & 0xFFu, flags = w0 >> 24;
+  const int md0 = (int)(w1 & 0xFFu), md1 = (int)((w1 >> 8) & 0xFFu);
+  const int ns0 = (int)((w1 >> 16) & 0xFFu), ns1 = (int)(w1 >> 24);
+  const unsigned nheads = w2 & 0xFFFFu;
+  const unsigned off_seg0 = w3 & 0xFFFFu, off_seg1 = w3 >> 16;
+  const unsigned off_heads = w4 & 0xFFFFu, off_rec = w4 >> 16;
+  const unsigned off_ent = w5 & 0xFFFFu, vecs = w5 >> 16;
+  const unsigned hp = w6 & 0xFFFFu, rgeom = (w6 >> 16) & 0xFFu;
+  const unsigned hp_magic = w7;
+  const int half = n >> 1;
+  if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
+  if (vecs > (unsigned)SP_THREADS) {  // a slab beyond the speculative 4 KB: fetch the rest
+    for (unsigned c0 = SP_THREADS + wv * 64; c0 < vecs; c0 += SP_THREADS)
+      if (c0 + lane < vecs) dma16(gslab + c0 + lane, slab + c0 * 4);
+    __syncthreads();
+  }
+  if ((flags & NVH_SLAB_FLOOR_FAULT) && tid == 0) atomicOr(A.err, NVH_DEVERR_FLOOR1_Y);
+  SY_T(2);
+
+  // ---- residue: one lane per pair of bins of one chain, all cascade stages with the sums in registers ----
+  {
+    const uint16_t* heads = reinterpret_cast<const uint16_t*>(slab + off_heads * 4);
+    const uint4* recs = reinterpret_cast<const uint4*>(slab + off_rec * 4);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
+    const unsigned rtype = rgeom & 0xFu, rch = rgeom >> 4;
+    const bool sweep_couples = (flags & NVH_SLAB_SWEEP_COUPLES) != 0;
+    const bool mg1 = (flags & NVH_SLAB_MG1) != 0;
+    const unsigned total = nheads * hp;
+    for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
+      const unsigned oq = hp > 1 ? __umulhi(idx, hp_magic) : idx;
+      const unsigned i2 = idx - oq * hp, i = i2 << 1;  // pair / first component index inside the partition
+      unsigned o = heads[oq];
+      uint4 rec = recs[o];
+      const unsigned xbase = rec.x >> 16;
+      unsigned c0, x0, c1, x1;
+      if (rtype == 1 || rch == 1) {
+        c0 = c1 = (rec.w >> 8) & 0x7Fu;
+        x0 = xbase + i;
+        x1 = x0 + 1;
+      } else {  // Residue2 over two channels: bin x of channel 0 and of channel 1
+        c0 = 0; c1 = 1;
+        x0 = x1 = xbase + i2;
+      }
+      const bool in0 = x0 < (unsigned)half, in1 = x1 < (unsigned)half;
+      float* p0 = spec + c0 * (unsigned)half + x0;
+      float* p1 = spec + c1 * (unsigned)half + x1;
+      float a0 = 0.0f, a1 = 0.0f;  // the spectrum was cleared and every bin belongs to one chain: nothing to read back
+      for (;;) {
+        const unsigned dims = rec.w & 0xFFu, lv = rec.y >> 16;
+        const unsigned j = (i * (rec.w >> 16)) >> 16;  // i / dims (i < 4096, dims <= 16: exact)
+        const unsigned comp = i - j * dims;
+        unsigned q = ent[(rec.x & 0xFFFFu) + j];
+        if (q != NVH_ENTRY_SKIP) {
+          const uint32_t* lat = s_lat + (rec.y & 0xFFFFu);
+          if (comp) q = __umulhi(q, lat[lv + comp]);  // e / lv^comp
+          // two base-lv digits (lv == 1: the magic is 0 and so are q and both digits)
+          const unsigned q1 = __umulhi(q, rec.z);
+          const unsigned d0 = q - q1 * lv;
+          const unsigned d1 = q1 - __umulhi(q1, rec.z) * lv;
+          a0 = a0 + __uint_as_float(lat[d0]);
+          a1 = a1 + __uint_as_float(lat[d1]);
+        }
+        if (!(rec.w & 0x8000u)) break;
+        rec = recs[++o];
+      }
+      if (sweep_couples) {  // a0 / a1 are bin x0 of channel 0 / 1 (Mapping.cs:137-182)
+        if (!mg1) couple1(a0, a1); else couple1(a1, a0);
+      }
+      if (in0) *p0 = a0;
+      if (in1) *p1 = a1;
+    }
+  }
+  __syncthreads();
+  SY_T(3);
+  if (flags & NVH_SLAB_COUPLE_PASS) {  // stereo streams whose residue does not put both channels of a bin into one lane
+    float* M = spec + ((flags & NVH_SLAB_MG1) ? half : 0);
+    float* An = spec + ((flags & NVH_SLAB_MG1) ? 0 : half);
+    for (int j = tid; j < half; j += SP_THREADS) {
+      float vm = M[j], va = An[j];
+      couple1(vm, va);
+      M[j] = vm;
+      An[j] = va;
+    }
+    __syncthreads();
+  }
+
+  // ---- floor multiply in place (Floor1.cs:196-222): the lanes split over the channels, 8 (stereo) / 4 (mono) bins each ----
+  {
+    const int c = nch == 2 ? (tid >> 7) : 0;  // wave-uniform
+    const int md = c ? md1 : md0, ns = c ? ns1 : ns0;
+    const unsigned oseg = c ? off_seg1 : off_seg0;
+    const FloorSeg* seg = reinterpret_cast<const FloorSeg*>(slab + oseg * 4);
+    const uint32_t* magic = reinterpret_cast<const uint32_t*>(slab + (oseg + (unsigned)ns) * 4);
+    float* sp = spec + c * half;
+    if (nch == 2) {
+      constexpr int TS = 8;
+      if (md != 0) {
+        for (int x0 = (tid & 127) * TS; x0 < half; x0 += 128 * TS) {
+          float r[TS], m[TS];
+          if (md == 1) {
+#pragma unroll
+            for (int q = 0; q < TS; q += 4) *reinterpret_cast<float4*>(r + q) = *reinterpret_cast<const float4*>(sp + x0 + q);
+            floor_walk_seg<TS>(seg, magic, ns, s_db, x0, m);
+#pragma unroll
+            for (int q = 0; q < TS; ++q) r[q] = r[q] * m[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < TS; ++q) r[q] = 0.0f;  // Floor1.cs:218-221
+          }
+#pragma unroll
+          for (int q = 0; q < TS; q += 4) *reinterpret_cast<float4*>(sp + x0 + q) = *reinterpret_cast<float4*>(r + q);
+        }
+      }
+    } else {
+      constexpr int TS = 4;
+      if (md != 0) {
+        for (int x0 = tid * TS; x0 < half; x0 += SP_THREADS * TS) {
+          float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (md == 1) {
+            float m[TS];
+            r = *reinterpret_cast<const float4*>(sp + x0);
+            floor_walk_seg<TS>(seg, magic, ns, s_db, x0, m);
+            r.x = r.x * m[0]; r.y = r.y * m[1]; r.z = r.z * m[2]; r.w = r.w * m[3];
+          }
+          *reinterpret_cast<float4*>(sp + x0) = r;
+        }
+      }
+    }
+  }
+  SY_T(4);
+
+  // ---- inverse MDCT (Mdct.cs:65-313), one wavefront per channel, in place over the channel's own spectrum ----
+  // (the transform's slice = n/2 floats + n/16 of padding: channel nch-1 spills its padding past the end of the spectrum
+  // area, the one before it into the dead slab area in front of it; the workgroup barrier between the floor multiply and
+  // the transform sits inside imdct_wave<.., PRESYNC>, behind the first table loads)
+  float* planes = A.work + (long long)f * nch * A.block1;
+  if (wv < nch && ((exec_mask >> wv) & 1u)) {
+    const float* X = spec + wv * half;
+    float* out = planes + (long long)wv * A.block1;
+    float* scratch = spec + wv * half - (nch - 1 - wv) * (n >> 4);
+    const int sl = (flags & NVH_SLAB_MDCT_SLOT) ? 1 : 0;
+    const float* Aa = A.mdct_a[sl];
+    const float* Bb = A.mdct_b[sl];
+    const float* Cc = A.mdct_c[sl];
+    const float* TW = A.mdct_tw[sl];
+    switch (n) {
+      case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+      case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+      case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+      case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+      default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
+    }
+  } else {
+    __syncthreads();
+    if (wv < nch) {
+      // Mapping.cs:192-196: the residue stays in [0, n/2) (k_ola_compact windows it); its tail quarter is zero
+      const float* X = spec + wv * half;
+      float* out = planes + (long long)wv * A.block1;
+      for (int i = lane * 4; i < half; i += 256) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(X + i);
+      for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  }
+  SY_T(5);
+#undef SY_T
+}

@@ -16,6 +16,7 @@ const NvhToggles& nvh_toggles() {
     x.no_gen8 = on("NVH_NO_GEN8");
     x.unfused = on("NVH_UNFUSED");
     x.no_pair = on("NVH_NO_PAIR");
+    x.no_slab = on("NVH_NO_SLAB");
     x.debug_occ = on("NVH_DEBUG_OCC");
     x.gpu_parse_default = on("NVH_GPU_PARSE");
     x.lds_pad = num("NVH_LDS_PAD");
@@ -651,7 +652,7 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
     HIP_TRY(hipSetDevice(s->ctx->device));
     std::unique_ptr<nvh_batch> b(new (std::nothrow) nvh_batch());
     if (b && s && s->ctx) {
-      b->blob.pool = b->work.pool = b->carry_in.pool = b->slabs.pool = b->run_flags.pool = b->dev_copy.pool = &s->ctx->pool;
+      b->blob.pool = b->work.pool = b->carry_in.pool = b->slabs.pool = b->run_flags.pool = b->dev_copy.pool = b->slab3.pool = &s->ctx->pool;
       b->h_blob.host = true;
       b->h_blob.pool = &s->ctx->hpool;
     }
@@ -666,6 +667,8 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
     rc = batch_upload(s, b.get());
     if (rc != NVH_OK) return rc;
     if (s->replay_error != NVH_OK) return s->replay_error;  // resident batches are all-or-nothing
+    // the per-frame slabs of the slab synthesis kernel are part of the resident image (k_prepare_slabs, once per upload)
+    if ((rc = ensure_slabs(b.get())) != NVH_OK) return rc;
     *out = b.release();
     return NVH_OK;
   });
@@ -686,6 +689,14 @@ extern "C" int nvh_batch_info(const nvh_batch* b, int* frames, int* chan_frames,
 extern "C" int nvh_batch_stats(const nvh_batch* b, int64_t* out8) {
   return nvh_guard([&]() -> int {
     if (!b || !out8) return NVH_ERR_ARGUMENT;
+    if (b->prepare_events_pending) {  // k_prepare_slabs of this upload: nanoseconds between its two events
+      nvh_batch* mb = const_cast<nvh_batch*>(b);
+      float ms = 0;
+      HIP_TRY(hipEventSynchronize(b->prep_e1));
+      HIP_TRY(hipEventElapsedTime(&ms, b->prep_e0, b->prep_e1));
+      mb->stats[7] = (int64_t)(ms * 1e6f);
+      mb->prepare_events_pending = false;
+    }
     for (int i = 0; i < 8; i++) out8[i] = b->stats[i];
     return NVH_OK;
   });

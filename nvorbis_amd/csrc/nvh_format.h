@@ -134,3 +134,38 @@ struct NvhFrame {
   uint32_t ov_exec_mask;          // same for the overlap source frame (mirrors NvhChan::ov_exec)
   uint32_t pad;
 };
+
+// ---- per-frame slabs of the slab synthesis kernel (kernels_synth.hip) ------------------------------------------------
+//
+// Everything k_synth needs about one frame, in its final LDS form, as ONE contiguous block at a fixed stride per batch,
+// so that the workgroup fetches it with LDS-DMA in a single round trip (no frame record -> slices -> setup records chain
+// of dependent loads, no staging copies, no unwrap in the kernel).  Written by k_prepare_slabs from the descriptors above
+// (integer work only: Floor1.UnwrapPosts + the segment list of the sorted, flagged posts, Floor1.cs:196-297; the
+// residue geometry of Residue0.cs:157-170 / Residue2.cs:23-47 resolved per vector write).  Sections, 16-byte aligned:
+//   NvhSlabHdr | per channel: FloorSeg[nseg + 1], uint32 magic[nseg] | uint16 heads[nheads] | uint4 rec[nrec] | uint16 entries[]
+// rec = one (stage, partition, channel) vector write in the pair-path form of kernels_spectrum.hip,
+//   x: entry offset (frame relative) | first bin << 16      y: lattice pool offset | lat_values << 16
+//   z: ceil(2^32 / lat_values)        w: dim | channel << 8 | more << 15 | ceil(2^16 / dim) << 16
+// laid out chain-major: the writes to one partition / channel through the cascade stages are consecutive records, in
+// stage order, `more` set on all but the last; heads[k] = index of chain k's first record.
+#define NVH_SLAB_SWEEP_COUPLES 1u  // stereo Residue2: the chain walk holds both channels of a bin and couples before its store
+#define NVH_SLAB_MG1 2u            // the magnitude channel of the coupling step is channel 1
+#define NVH_SLAB_COUPLE_PASS 4u    // inverse coupling as a pass of its own between the residue walk and the floor multiply
+#define NVH_SLAB_FLOOR_FAULT 8u    // a curve value outside inverse_dB_table (quirk B-7): the kernel raises NVH_DEVERR_FLOOR1_Y
+#define NVH_SLAB_MDCT_SLOT 16u     // block1 tables (else block0)
+struct NvhSlabHdr {      // 32 bytes
+  uint16_t n;            // block size of the packet's mode; 0 = pseudo-frame, nothing to compute
+  uint8_t exec_mask;     // bit c: channel c executes (NvhChan::exec)
+  uint8_t flags;         // NVH_SLAB_*
+  uint8_t mode[2];       // floor of channel c: 0 none (does not execute), 1 curve, 2 clear (Floor1.cs:218-221)
+  uint8_t nseg[2];
+  uint16_t nheads, nrec;
+  uint16_t off_seg[2];   // section offsets in 16-byte units from the start of the slab
+  uint16_t off_heads, off_rec, off_ent;
+  uint16_t vecs;         // size of the slab in 16-byte units
+  uint16_t hp;           // partition_size / 2: lanes per chain
+  uint8_t rgeom;         // residue type | real channels << 4
+  uint8_t pad;
+  uint32_t hp_magic;     // ceil(2^32 / hp), 0 when hp <= 1
+};
+

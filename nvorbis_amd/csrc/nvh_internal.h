@@ -63,6 +63,8 @@ __global__ void k_run4_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArg
 __global__ void k_run6_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 #endif
+__global__ void k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* slabs, int stride_vecs);
+__global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
 __global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,
                                   long long plane_stride);
@@ -114,6 +116,7 @@ static inline void nvh_guard_void(F&& body) noexcept {
 // Test / experiment switches from the environment, read once per process (before the first context exists).
 struct NvhToggles {
   bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
+  bool no_slab;   // NVH_NO_SLAB: k_spectrum_imdct instead of k_prepare_slabs + k_synth (test / A-B aid)
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
   bool run;       // NVH_RUN: the run kernel (kernels_run.hip) instead of k_spectrum_imdct + k_ola_compact -- opt-in, it measured slower
   int run_waves;  // NVH_RUN_WAVES = 4 | 6
@@ -214,6 +217,9 @@ struct SharedSetup {
   DevBuf dev_copy;  // the NvhDevSetup block itself in device memory (the run kernel reads it from there, see kernels_run.hip)
   bool fast_spectrum = false;  // every residue takes the pair path and the fused tail applies: k_spectrum proper
   bool has_floor0 = false;
+  const uint4* synth_consts = nullptr;  // inverse_dB_table + lattice pool in 16-byte units (kernels_synth.hip), inside `arena`
+  int synth_const_vecs = 0;
+  int max_posts = 0;            // largest Floor1 post count of the setup (bounds a slab's segment lists)
   bool has_sequential = false;  // some residue replays the reference's partition order (quirk B-1 / vector overrun)
   // GPU packet parser (kernels_parse.hip): its tables, and whether this stream shape is inside its limits
   DevBuf parse_arena;
@@ -259,7 +265,17 @@ struct nvh_batch {
   DevBuf run_flags;
   unsigned run_epoch = 0;
   DevBuf dev_copy;  // the NvhDevBatch block in device memory
-  bool dev_copy_valid = false;  // ... and whether it holds the current upload's pointers
+  bool dev_copy_valid = false;
+  // slab synthesis kernel (kernels_synth.hip): per-frame slabs written once per upload by k_prepare_slabs
+  DevBuf slab3;
+  int slab_stride_vecs = 0;   // 16-byte units between slabs = upper bound of the batch's largest slab
+  bool slabs_ready = false;
+  bool prepare_events_pending = false;  // prep_e0 / prep_e1 bracket k_prepare_slabs of this upload (read by nvh_batch_stats[7], ns)
+  hipEvent_t prep_e0 = nullptr, prep_e1 = nullptr;
+  ~nvh_batch() {
+    if (prep_e0) (void)hipEventDestroy(prep_e0);
+    if (prep_e1) (void)hipEventDestroy(prep_e1);
+  }  // ... and whether it holds the current upload's pointers
 };
 
 // GPU-parse mode: everything pushed since the last batch boundary, so that a batch in which k_parse found a packet the
@@ -328,7 +344,7 @@ struct nvh_stream {
     carry[0].pool = carry[1].pool = flags.pool = pcm.pool = carry_exec.pool = pcm2[0].pool = pcm2[1].pool = pool;
     h_flags2.host = true;
     h_flags2.pool = c ? &c->hpool : nullptr;
-    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = scratch.run_flags.pool = scratch.dev_copy.pool = pool;
+    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = scratch.run_flags.pool = scratch.dev_copy.pool = scratch.slab3.pool = pool;
     h_pcm.host = scratch.h_blob.host = true;
     h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;
     scratch.s = this;
@@ -356,5 +372,6 @@ int upload_parse_tables(nvh_stream* s);                          // nvh_setup.hi
 int batch_upload(nvh_stream* s, nvh_batch* b);                   // nvh_launch.hip
 int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms,
                  hipEvent_t* ext_ev = nullptr);  // nvh_launch.hip
+int ensure_slabs(nvh_batch* b);                                  // nvh_launch.hip
 int collect_flags(nvh_stream* s);                                // nvh_launch.hip
 void replay_note(nvh_stream* s, int kind, const uint8_t* data, int len, int64_t granule, int flags);  // nvh_launch.hip

@@ -170,6 +170,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->sequential_ola = P.sequential_ola;
   b->last_decoded = -1;
   b->max_ops = b->max_ent = b->max_pass = 0;
+  b->slabs_ready = false;
   b->links_ok = P.links_ok && P.op_link.size() == P.ops.size();
   for (const NvhFrame& fr : P.frames) {
     if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
@@ -295,10 +296,61 @@ static int upload_dev_copy(nvh_batch* b, hipStream_t st) {
   return NVH_OK;
 }
 
+// Whether a batch takes the slab synthesis kernel (kernels_synth.hip): the stream shapes of k_spectrum_imdct with at most one
+// residue pass per frame and slabs that fit 16-bit section offsets.
+static bool slab_path(const nvh_batch* b) {
+  const nvh_stream* s = b->s;
+  const NvhToggles& T = nvh_toggles();
+  return s->fast_spectrum && b->links_ok && s->setup.channels <= 2 && s->setup.block0 >= 256 && s->setup.block1 <= 2048 &&
+         !b->sequential_ola && !b->block_only && b->max_pass <= 1 && !T.no_slab && !T.unfused && !T.no_fused_imdct && !T.no_compact &&
+         s->shared->synth_consts != nullptr;
+}
+
+// Upper bound of a slab of this batch in 16-byte units: header, per channel a segment list of at most max_posts segments
+// + their magics, the chain heads, one record per vector write, the entries (nvh_format.h: NvhSlabHdr).
+static size_t slab_bound_vecs(const nvh_batch* b) {
+  const nvh_stream* s = b->s;
+  const size_t P = (size_t)s->shared->max_posts + 2;
+  size_t v = 2 + (size_t)s->setup.channels * (P + (P + 3) / 4) + ((size_t)b->max_ops + 7) / 8 + (size_t)b->max_ops + ((size_t)b->max_ent + 7) / 8 + 1;
+  if (v < (size_t)s->setup.block1 / 64 + 8) v = (size_t)s->setup.block1 / 64 + 8;  // the IMDCT padding of channel 0 overlays the slab area
+  return (v + 3) & ~(size_t)3;
+}
+
+// k_prepare_slabs once per upload: descriptors -> per-frame slabs (integer work: floor unwrap, chain-major pair records).
+int ensure_slabs(nvh_batch* b) {
+  if (b->slabs_ready || b->nframes == 0 || !slab_path(b)) return NVH_OK;
+  nvh_stream* s = b->s;
+  hipStream_t st = s->ctx->stream;
+  const size_t stride = slab_bound_vecs(b);
+  if (stride > 0xFFFFu) return NVH_OK;  // stays on k_spectrum_imdct (slab_path is re-checked at launch through slabs_ready)
+  int rc = b->slab3.reserve((size_t)b->nframes * stride * 16 + 4096);
+  if (rc != NVH_OK) return rc;
+  b->slab_stride_vecs = (int)stride;
+  // resident batches (nvh_batch_upload) time the conversion for nvh_batch_stats; the stream's own scratch batch does not
+  const bool timed = b != &s->scratch;
+  if (timed) {
+    if (!b->prep_e0) HIP_TRY(hipEventCreate(&b->prep_e0));
+    if (!b->prep_e1) HIP_TRY(hipEventCreate(&b->prep_e1));
+    HIP_TRY(hipEventRecord(b->prep_e0, st));
+  }
+  hipLaunchKernelGGL(k_prepare_slabs, dim3((unsigned)b->nframes), dim3(64), 0, st, s->dev, b->dev, (uint4*)b->slab3.p, (int)stride);
+  if (timed) {
+    HIP_TRY(hipEventRecord(b->prep_e1, st));
+    b->prepare_events_pending = true;
+  }
+  HIP_TRY(hipGetLastError());
+  b->slabs_ready = true;
+  return NVH_OK;
+}
+
 int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms, hipEvent_t* ext_ev) {
   nvh_stream* s = b->s;
   hipStream_t st = s->ctx->stream;
   if (b->nframes == 0) return NVH_OK;
+  {
+    int rc = ensure_slabs(b);  // no-op after the first launch of an upload
+    if (rc != NVH_OK) return rc;
+  }
   const int ch = s->setup.channels;
   float* work = (float*)b->work.p;
   int* flags = (int*)s->flags.p;
@@ -507,7 +559,25 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
                              cap_ent NVH_DBG_LAUNCH);
         } else
 #endif
-        if (fuse_imdct) {
+        if (fuse_imdct && b->slabs_ready) {
+          // slab synthesis kernel: LDS = constants + the largest slab + spectrum + the IMDCT padding of the last channel
+          NvhSynthArgs A;
+          A.consts = s->shared->synth_consts;
+          A.slabs = (const uint4*)b->slab3.p;
+          A.work = work;
+          A.err = flags;
+          for (int w = 0; w < 2; w++) {
+            A.mdct_a[w] = s->dev.mdct_a[w]; A.mdct_b[w] = s->dev.mdct_b[w]; A.mdct_c[w] = s->dev.mdct_c[w]; A.mdct_tw[w] = s->dev.mdct_tw[w];
+          }
+          A.const_vecs = s->shared->synth_const_vecs;
+          A.stride_vecs = A.cap_vecs = b->slab_stride_vecs;
+          A.channels = ch;
+          A.block1 = s->setup.block1;
+          const size_t synth_lds = ((size_t)A.const_vecs * 4 + (size_t)A.cap_vecs * 4 + (size_t)ch * (size_t)(s->setup.block1 / 2) +
+                                    (size_t)(s->setup.block1 / 16)) * sizeof(float) + lds_pad;
+          b->slot_name[1] = "k_synth";
+          hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+        } else if (fuse_imdct) {
           // + the IMDCT padding of the last channel (n/16 floats past the spectrum area)
           b->slot_name[1] = "k_spectrum_imdct";
           hipLaunchKernelGGL(k_spectrum_imdct, dim3((unsigned)b->nframes), dim3(256), words * 4 + (size_t)(s->setup.block1 / 16) * 4 + lds_pad,

@@ -199,6 +199,18 @@ int upload_setup(nvh_stream* s) {
 
   size_t o_vq = ab.add(vq.data(), vq.size() * sizeof(float));
   size_t o_lat = ab.add(lattice.data(), lattice.size() * sizeof(uint32_t));
+  // constants block of the slab synthesis kernel (kernels_synth.hip): inverse_dB_table followed by the lattice pool, in whole
+  // 16-byte units, fetched by LDS-DMA as one piece
+  std::vector<uint32_t> synth_consts(256);
+  {
+    static const float db_table[256] = {
+#include "floor1_db_table.inc"
+    };
+    std::memcpy(synth_consts.data(), db_table, sizeof db_table);
+    synth_consts.insert(synth_consts.end(), lattice.begin(), lattice.end());
+    while (synth_consts.size() & 3u) synth_consts.push_back(0u);
+  }
+  size_t o_sc = ab.add(synth_consts.data(), synth_consts.size() * sizeof(uint32_t));
   size_t o_books = ab.add(books.data(), books.size() * sizeof(NvhDevBook));
   size_t o_floors = ab.add(floors.data(), floors.size() * sizeof(NvhDevFloor));
   size_t o_res = ab.add(residues.data(), residues.size() * sizeof(NvhDevResidue));
@@ -234,6 +246,11 @@ int upload_setup(nvh_stream* s) {
   D.vq = (const float*)(base + o_vq);
   D.lattice = (const uint32_t*)(base + o_lat);
   D.lattice_words = (int32_t)lattice.size();
+  s->shared->synth_consts = (const uint4*)(base + o_sc);
+  s->shared->synth_const_vecs = (int)(synth_consts.size() / 4);
+  s->shared->max_posts = 0;
+  for (const auto& fl : S.floors)
+    if (fl.type == 1) s->shared->max_posts = std::max(s->shared->max_posts, (int)fl.f1.x_list.size());
   {
     bool ok = S.channels <= 2 && !s->has_floor0;
     for (const nvh::Mapping& m : S.mappings) ok = ok && m.coupling_angle.size() <= 1;

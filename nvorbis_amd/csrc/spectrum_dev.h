@@ -321,8 +321,8 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
 // reference's error-term recurrence (Floor1.cs:328-340) from its closed form, then step it, hopping segments
 // as they end.  Returns the NB inverse-dB multipliers.
 template <int NB>
-__device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* __restrict__ s_db, int x0, float m[NB]) {
-  const int ns = __builtin_amdgcn_readfirstlane(Q->nseg);
+__device__ __forceinline__ void floor_walk_seg(const FloorSeg* __restrict__ seg, const uint32_t* __restrict__ magic, int ns,
+                                               const float* __restrict__ s_db, int x0, float m[NB]) {
   // last segment whose start is <= x0: a fixed-trip binary search (the trip count depends on ns only, so the loop
   // control is scalar; the data-dependent form costs an exec-mask loop per lane)
   int sg = 0;
@@ -331,14 +331,14 @@ __device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* _
     if (step >= ns) continue;  // wave-uniform
     const int cand = sg + step;
     const int ci = cand < ns ? cand : ns - 1;
-    const int xs = (int)(Q->seg[ci].x_xend & 0xFFFFu);
+    const int xs = (int)(seg[ci].x_xend & 0xFFFFu);
     if (cand < ns && xs <= x0) sg = cand;
   }
-  FloorSeg s = Q->seg[sg];
+  FloorSeg s = seg[sg];
   int sadx = (int)s.ady_adx >> 16, sady = (int)(s.ady_adx & 0xFFFFu), sb = s.b;
   int adx = sadx < 0 ? -sadx : sadx, sy = sadx < 0 ? -1 : 1;
   const int t = x0 - (int)(s.x_xend & 0xFFFFu);
-  const int wq = (int)sp_div_magic((unsigned)(sady * t), (unsigned)adx, Q->magic[sg]);  // sady, t < adx <= 2^13
+  const int wq = (int)sp_div_magic((unsigned)(sady * t), (unsigned)adx, magic[sg]);  // sady, t < adx <= 2^13
   int y = s.y + sb * t + sy * wq;
   int e = -adx + sady * t - adx * wq;  // the reference's `err` after t steps
   int xend = (int)(s.x_xend >> 16);
@@ -349,7 +349,7 @@ __device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* _
     // first end point >= n/2, else the closing flat run ends at n/2), so x < n/2 never runs off the list
     if (x >= xend) {
       ++sg;
-      s = Q->seg[sg];
+      s = seg[sg];
       sadx = (int)s.ady_adx >> 16; sady = (int)(s.ady_adx & 0xFFFFu); sb = s.b;
       adx = sadx < 0 ? -sadx : sadx; sy = sadx < 0 ? -1 : 1;
       y = s.y;
@@ -365,6 +365,11 @@ __device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* _
       y += sy;
     }
   }
+}
+
+template <int NB>
+__device__ __forceinline__ void floor_walk(const FloorScratch* Q, const float* __restrict__ s_db, int x0, float m[NB]) {
+  floor_walk_seg<NB>(Q->seg, Q->magic, __builtin_amdgcn_readfirstlane(Q->nseg), s_db, x0, m);
 }
 
 // Floor0.Apply's curve (Floor0.cs:152-212) for one channel with Amp > 0: all NT threads of the workgroup; s_coeff holds

@@ -16,4 +16,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_
 python tools/rocprof_summary.py --trace $(find $OUT/trace -name '*.db') --fetch $(find $OUT/fetch -name '*.db') \
   --write $(find $OUT/write -name '*.db') --insts $(find $OUT/insts -name '*.db') --out $OUT/summary \
   --note "$2" --traffic-out $OUT/traffic.json --build "$BUILD" --calibration-from profiles/traffic.json
+# the raw rocpd databases are tens of MiB per pass: only the summaries travel back (gpurun merges <= 64 MiB)
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/insts
 tail -1 $OUT/trace.log
