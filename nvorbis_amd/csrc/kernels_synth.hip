@@ -49,6 +49,96 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
   return v;
 }
 
+// Residue adds of one frame (Residue1.cs:8-26, Residue2.cs:23-47 WriteVectors for lattice books).  A lane owns G consecutive
+// vector components of one partition / channel (a "chain": the writes to it through the cascade stages are consecutive
+// records) and keeps their running sums in registers from the first stage to the last: the reference's additions, in the
+// reference's order per element, one LDS store per element.  Component i of the partition lies in entry i / dim of the
+// stage's vector list as component i % dim; the entry's components are the base-lat_values digits of the entry number,
+// peeled two at a time with exact reciprocal multiplies (consecutive pairs of one entry continue from the previous quotient).
+template <int G>
+__device__ __forceinline__ void residue_walk(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
+                                             const uint32_t* __restrict__ s_lat, float* spec, int half, unsigned nheads,
+                                             unsigned lpc, unsigned lpc_magic, bool interleaved, unsigned flags, int tid) {
+  const uint16_t* heads = reinterpret_cast<const uint16_t*>(slab + off_heads * 4);
+  const uint4* recs = reinterpret_cast<const uint4*>(slab + off_rec * 4);
+  const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
+  const bool sweep_couples = (flags & NVH_SLAB_SWEEP_COUPLES) != 0;
+  const bool mg1 = (flags & NVH_SLAB_MG1) != 0;
+  const unsigned total = nheads * lpc;
+  for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
+    const unsigned oq = lpc > 1 ? __umulhi(idx, lpc_magic) : idx;
+    const unsigned g = idx - oq * lpc, i0 = g * G;  // first component of this lane's group inside the partition
+    unsigned o = heads[oq];
+    uint4 rec = recs[o];
+    const unsigned xbase = rec.x >> 16;
+    float a[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) a[k] = 0.0f;  // the spectrum was cleared and every bin belongs to one chain
+    for (;;) {
+      const unsigned dims = rec.w & 0xFFu, lv = rec.y >> 16, dm16 = rec.w >> 16;
+      const uint32_t* lat = s_lat + (rec.y & 0xFFFFu);
+      const uint16_t* eb = ent + (rec.x & 0xFFFFu);
+      unsigned q2 = 0;
+#pragma unroll
+      for (int k = 0; k < G; k += 2) {
+        const unsigned i = i0 + k;
+        const unsigned j = (i * dm16) >> 16;  // i / dims (i < 4096, dims <= 16: exact)
+        const unsigned comp = i - j * dims;
+        const unsigned e = eb[j];
+        unsigned q;
+        if (k == 0) q = comp ? __umulhi(e, lat[lv + comp]) : e;  // e / lv^comp: the group starts inside an entry
+        else q = comp ? q2 : e;                                   // the same entry continues, or the next one begins
+        // two base-lv digits (lv == 1: the magic is 0 and so are q and both digits)
+        const unsigned q1 = __umulhi(q, rec.z);
+        const unsigned d0 = q - q1 * lv;
+        q2 = __umulhi(q1, rec.z);
+        const unsigned d1 = q1 - q2 * lv;
+        const float v0 = __uint_as_float(lat[d0]), v1 = __uint_as_float(lat[d1]);
+        const bool add = e != NVH_ENTRY_SKIP;  // "no vector was added here" (quirks B-14 / B-16)
+        a[k] = add ? a[k] + v0 : a[k];
+        a[k + 1] = add ? a[k + 1] + v1 : a[k + 1];
+      }
+      if (!(rec.w & 0x8000u)) break;
+      rec = recs[++o];
+    }
+    if (interleaved) {
+      // a[2m] / a[2m + 1] = bin xb + m of channel 0 / 1
+      const unsigned xb = xbase + (i0 >> 1);
+      if (sweep_couples) {  // Mapping.cs:137-182 on the pair a lane holds anyway
+#pragma unroll
+        for (int m = 0; m < G / 2; ++m) {
+          if (!mg1) couple1(a[2 * m], a[2 * m + 1]); else couple1(a[2 * m + 1], a[2 * m]);
+        }
+      }
+      float* p0 = spec + xb;
+      float* p1 = spec + (unsigned)half + xb;
+      if (G == 8 && (xb & 3u) == 0 && xb + 4 <= (unsigned)half) {
+        *reinterpret_cast<float4*>(p0) = make_float4(a[0], a[2], a[4 % G], a[6 % G]);
+        *reinterpret_cast<float4*>(p1) = make_float4(a[1], a[3 % G], a[5 % G], a[7 % G]);
+      } else {
+#pragma unroll
+        for (int m = 0; m < G / 2; ++m)
+          if (xb + m < (unsigned)half) {
+            p0[m] = a[2 * m];
+            p1[m] = a[2 * m + 1];
+          }
+      }
+    } else {
+      const unsigned c = (rec.w >> 8) & 0x7Fu;
+      const unsigned xb = xbase + i0;
+      float* p = spec + c * (unsigned)half + xb;
+      if (G == 8 && (xb & 3u) == 0 && xb + 8 <= (unsigned)half) {
+        *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2 % G], a[3 % G]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(a[4 % G], a[5 % G], a[6 % G], a[7 % G]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+          if (xb + k < (unsigned)half) p[k] = a[k];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- integer side: descriptors -> slabs, one wavefront per frame, once per batch -----------------------------------------
@@ -61,7 +151,7 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
   const NvhFrame fr = Bt.frames[f];
   NvhSlabHdr H;
   H.n = 0; H.exec_mask = 0; H.flags = 0; H.mode[0] = H.mode[1] = 0; H.nseg[0] = H.nseg[1] = 0; H.nheads = 0; H.nrec = 0;
-  H.off_seg[0] = H.off_seg[1] = 2; H.off_heads = H.off_rec = H.off_ent = 2; H.vecs = 2; H.hp = 0; H.rgeom = 0; H.pad = 0; H.hp_magic = 0;
+  H.off_seg[0] = H.off_seg[1] = 2; H.off_heads = H.off_rec = H.off_ent = 2; H.vecs = 2; H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0;
   if (fr.n == 0) {
     if (lane == 0) {
       slab[0] = reinterpret_cast<const uint4*>(&H)[0];
@@ -93,6 +183,22 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
       uint32_t* mg = reinterpret_cast<uint32_t*>(slab + off + ns);
       for (int i = lane; i < ((ns + 3) & ~3); i += 64) mg[i] = i < ns ? Q.magic[i] : 0u;
       off += (unsigned)ns + (unsigned)((ns + 3) >> 2);
+      // segment index of every group of four bins (the last segment that starts at or before the group's first bin): the
+      // floor multiply starts its walk there instead of searching the list
+      uint8_t* tab = reinterpret_cast<uint8_t*>(slab + off);
+      const int ngroups = half >> 2;
+      for (int gq = lane; gq < ((ngroups + 15) & ~15); gq += 64) {
+        int sg = 0;
+        if (gq < ngroups) {
+          const int x0 = gq << 2;
+          for (int step = 64; step > 0; step >>= 1) {
+            const int cand = sg + step;
+            if (cand < ns && (int)(Q.seg[cand].x_xend & 0xFFFFu) <= x0) sg = cand;
+          }
+        }
+        tab[gq] = (uint8_t)sg;
+      }
+      off += (unsigned)((ngroups + 15) >> 4);
     }
     sp_wave_sync();  // the next channel reuses the scratch block
   }
@@ -108,8 +214,12 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
     rtype = R->type;
     rch = R->real_channels;
     const unsigned psz = (unsigned)R->partition_size, rbegin = (unsigned)R->begin, rch_magic = R->rch_magic;
-    H.hp = (uint16_t)(psz >> 1);
-    H.hp_magic = R->hp_magic;
+    {
+      const unsigned group = (psz & 7u) == 0 ? 8u : 2u, lpc = psz / group;
+      H.group = (uint8_t)group;
+      H.lpc = (uint16_t)lpc;
+      H.lpc_magic = lpc > 1 ? (uint32_t)((0x100000000ull + lpc - 1) / lpc) : 0u;
+    }
     const int nops = (int)fr.op_count;
     const NvhResOp* ops = Bt.ops + fr.op_begin;
     const uint16_t* links = Bt.op_link + fr.op_begin;
@@ -214,6 +324,9 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
 #define SY_T(k) do { } while (0)
 #endif
   SY_T(0);
+#ifdef NVH_DEBUG
+  if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 22] = wall_clock64();
+#endif
   // ---- one round trip: constants + the first 4 KB of the slab by LDS-DMA, the spectrum cleared meanwhile ----
   const uint4* gslab = A.slabs + (long long)f * A.stride_vecs;
   {
@@ -240,8 +353,8 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
   const unsigned off_seg0 = w3 & 0xFFFFu, off_seg1 = w3 >> 16;
   const unsigned off_heads = w4 & 0xFFFFu, off_rec = w4 >> 16;
   const unsigned off_ent = w5 & 0xFFFFu, vecs = w5 >> 16;
-  const unsigned hp = w6 & 0xFFFFu, rgeom = (w6 >> 16) & 0xFFu;
-  const unsigned hp_magic = w7;
+  const unsigned lpc = w6 & 0xFFFFu, rgeom = (w6 >> 16) & 0xFFu, group = w6 >> 24;
+  const unsigned lpc_magic = w7;
   const int half = n >> 1;
   if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
   if (vecs > (unsigned)SP_THREADS) {  // a slab beyond the speculative 4 KB: fetch the rest
@@ -252,58 +365,15 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
   if ((flags & NVH_SLAB_FLOOR_FAULT) && tid == 0) atomicOr(A.err, NVH_DEVERR_FLOOR1_Y);
   SY_T(2);
 
-  // ---- residue: one lane per pair of bins of one chain, all cascade stages with the sums in registers ----
+  // ---- residue: one lane per GROUP of consecutive vector components of one chain, all cascade stages with the sums in
+  // registers (the reference's additions in the reference's order per element) ----
   {
-    const uint16_t* heads = reinterpret_cast<const uint16_t*>(slab + off_heads * 4);
-    const uint4* recs = reinterpret_cast<const uint4*>(slab + off_rec * 4);
-    const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
     const unsigned rtype = rgeom & 0xFu, rch = rgeom >> 4;
-    const bool sweep_couples = (flags & NVH_SLAB_SWEEP_COUPLES) != 0;
-    const bool mg1 = (flags & NVH_SLAB_MG1) != 0;
-    const unsigned total = nheads * hp;
-    for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
-      const unsigned oq = hp > 1 ? __umulhi(idx, hp_magic) : idx;
-      const unsigned i2 = idx - oq * hp, i = i2 << 1;  // pair / first component index inside the partition
-      unsigned o = heads[oq];
-      uint4 rec = recs[o];
-      const unsigned xbase = rec.x >> 16;
-      unsigned c0, x0, c1, x1;
-      if (rtype == 1 || rch == 1) {
-        c0 = c1 = (rec.w >> 8) & 0x7Fu;
-        x0 = xbase + i;
-        x1 = x0 + 1;
-      } else {  // Residue2 over two channels: bin x of channel 0 and of channel 1
-        c0 = 0; c1 = 1;
-        x0 = x1 = xbase + i2;
-      }
-      const bool in0 = x0 < (unsigned)half, in1 = x1 < (unsigned)half;
-      float* p0 = spec + c0 * (unsigned)half + x0;
-      float* p1 = spec + c1 * (unsigned)half + x1;
-      float a0 = 0.0f, a1 = 0.0f;  // the spectrum was cleared and every bin belongs to one chain: nothing to read back
-      for (;;) {
-        const unsigned dims = rec.w & 0xFFu, lv = rec.y >> 16;
-        const unsigned j = (i * (rec.w >> 16)) >> 16;  // i / dims (i < 4096, dims <= 16: exact)
-        const unsigned comp = i - j * dims;
-        unsigned q = ent[(rec.x & 0xFFFFu) + j];
-        if (q != NVH_ENTRY_SKIP) {
-          const uint32_t* lat = s_lat + (rec.y & 0xFFFFu);
-          if (comp) q = __umulhi(q, lat[lv + comp]);  // e / lv^comp
-          // two base-lv digits (lv == 1: the magic is 0 and so are q and both digits)
-          const unsigned q1 = __umulhi(q, rec.z);
-          const unsigned d0 = q - q1 * lv;
-          const unsigned d1 = q1 - __umulhi(q1, rec.z) * lv;
-          a0 = a0 + __uint_as_float(lat[d0]);
-          a1 = a1 + __uint_as_float(lat[d1]);
-        }
-        if (!(rec.w & 0x8000u)) break;
-        rec = recs[++o];
-      }
-      if (sweep_couples) {  // a0 / a1 are bin x0 of channel 0 / 1 (Mapping.cs:137-182)
-        if (!mg1) couple1(a0, a1); else couple1(a1, a0);
-      }
-      if (in0) *p0 = a0;
-      if (in1) *p1 = a1;
-    }
+    const bool interleaved = !(rtype == 1 || rch == 1);  // Residue2 over two channels: component k = bin k / 2 of channel k & 1
+    if (group == 8)
+      residue_walk<8>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid);
+    else
+      residue_walk<2>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid);
   }
   __syncthreads();
   SY_T(3);
@@ -326,6 +396,7 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
     const unsigned oseg = c ? off_seg1 : off_seg0;
     const FloorSeg* seg = reinterpret_cast<const FloorSeg*>(slab + oseg * 4);
     const uint32_t* magic = reinterpret_cast<const uint32_t*>(slab + (oseg + (unsigned)ns) * 4);
+    const uint8_t* segtab = reinterpret_cast<const uint8_t*>(slab + (oseg + (unsigned)ns + (unsigned)((ns + 3) >> 2)) * 4);
     float* sp = spec + c * half;
     if (nch == 2) {
       constexpr int TS = 8;
@@ -335,7 +406,7 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
           if (md == 1) {
 #pragma unroll
             for (int q = 0; q < TS; q += 4) *reinterpret_cast<float4*>(r + q) = *reinterpret_cast<const float4*>(sp + x0 + q);
-            floor_walk_seg<TS>(seg, magic, ns, s_db, x0, m);
+            floor_walk_seg<TS>(seg, magic, ns, s_db, x0, m, segtab);
 #pragma unroll
             for (int q = 0; q < TS; ++q) r[q] = r[q] * m[q];
           } else {
@@ -354,7 +425,7 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
           if (md == 1) {
             float m[TS];
             r = *reinterpret_cast<const float4*>(sp + x0);
-            floor_walk_seg<TS>(seg, magic, ns, s_db, x0, m);
+            floor_walk_seg<TS>(seg, magic, ns, s_db, x0, m, segtab);
             r.x = r.x * m[0]; r.y = r.y * m[1]; r.z = r.z * m[2]; r.w = r.w * m[3];
           }
           *reinterpret_cast<float4*>(sp + x0) = r;
@@ -396,5 +467,8 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
     }
   }
   SY_T(5);
+#ifdef NVH_DEBUG
+  if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 23] = wall_clock64();
+#endif
 #undef SY_T
 }

@@ -142,7 +142,8 @@ struct NvhFrame {
 // of dependent loads, no staging copies, no unwrap in the kernel).  Written by k_prepare_slabs from the descriptors above
 // (integer work only: Floor1.UnwrapPosts + the segment list of the sorted, flagged posts, Floor1.cs:196-297; the
 // residue geometry of Residue0.cs:157-170 / Residue2.cs:23-47 resolved per vector write).  Sections, 16-byte aligned:
-//   NvhSlabHdr | per channel: FloorSeg[nseg + 1], uint32 magic[nseg] | uint16 heads[nheads] | uint4 rec[nrec] | uint16 entries[]
+//   NvhSlabHdr | per channel: FloorSeg[nseg], uint32 magic[nseg], uint8 first_segment[n / 8] (one per four bins) |
+//   uint16 heads[nheads] | uint4 rec[nrec] | uint16 entries[]
 // rec = one (stage, partition, channel) vector write in the pair-path form of kernels_spectrum.hip,
 //   x: entry offset (frame relative) | first bin << 16      y: lattice pool offset | lat_values << 16
 //   z: ceil(2^32 / lat_values)        w: dim | channel << 8 | more << 15 | ceil(2^16 / dim) << 16
@@ -163,9 +164,9 @@ struct NvhSlabHdr {      // 32 bytes
   uint16_t off_seg[2];   // section offsets in 16-byte units from the start of the slab
   uint16_t off_heads, off_rec, off_ent;
   uint16_t vecs;         // size of the slab in 16-byte units
-  uint16_t hp;           // partition_size / 2: lanes per chain
+  uint16_t lpc;          // lanes per chain = partition_size / group
   uint8_t rgeom;         // residue type | real channels << 4
-  uint8_t pad;
-  uint32_t hp_magic;     // ceil(2^32 / hp), 0 when hp <= 1
+  uint8_t group;         // consecutive vector components one lane owns through all cascade stages: 8 (partition_size % 8 == 0) or 2
+  uint32_t lpc_magic;    // ceil(2^32 / lpc), 0 when lpc <= 1
 };
 

@@ -322,17 +322,23 @@ __device__ __forceinline__ void floor_prepare(FloorScratch* Q, const FloorLane& 
 // as they end.  Returns the NB inverse-dB multipliers.
 template <int NB>
 __device__ __forceinline__ void floor_walk_seg(const FloorSeg* __restrict__ seg, const uint32_t* __restrict__ magic, int ns,
-                                               const float* __restrict__ s_db, int x0, float m[NB]) {
-  // last segment whose start is <= x0: a fixed-trip binary search (the trip count depends on ns only, so the loop
-  // control is scalar; the data-dependent form costs an exec-mask loop per lane)
+                                               const float* __restrict__ s_db, int x0, float m[NB],
+                                               const uint8_t* __restrict__ segtab = nullptr) {
+  // last segment whose start is <= x0: from the per-four-bins table when the caller has one (k_prepare_slabs), else a
+  // fixed-trip binary search (the trip count depends on ns only, so the loop control is scalar; the data-dependent form
+  // costs an exec-mask loop per lane)
   int sg = 0;
+  if (segtab) {
+    sg = segtab[x0 >> 2];
+  } else {
 #pragma unroll
-  for (int step = 64; step > 0; step >>= 1) {
-    if (step >= ns) continue;  // wave-uniform
-    const int cand = sg + step;
-    const int ci = cand < ns ? cand : ns - 1;
-    const int xs = (int)(seg[ci].x_xend & 0xFFFFu);
-    if (cand < ns && xs <= x0) sg = cand;
+    for (int step = 64; step > 0; step >>= 1) {
+      if (step >= ns) continue;  // wave-uniform
+      const int cand = sg + step;
+      const int ci = cand < ns ? cand : ns - 1;
+      const int xs = (int)(seg[ci].x_xend & 0xFFFFu);
+      if (cand < ns && xs <= x0) sg = cand;
+    }
   }
   FloorSeg s = seg[sg];
   int sadx = (int)s.ady_adx >> 16, sady = (int)(s.ady_adx & 0xFFFFu), sb = s.b;

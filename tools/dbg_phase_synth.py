@@ -1,0 +1,47 @@
+"""Per-workgroup phase timestamps of k_synth (kernels_synth.hip) on the bench workload (G-real) or on full-depth packets
+(G-rand):  NVH_LIB=nvorbis_amd/libnvorbis_hip_dbg.so python tools/dbg_phase_synth.py [grand]
+Needs the profiling build (python -m nvorbis_amd.build --debug)."""
+import os, sys, ctypes
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch, numpy as np
+import nvorbis_amd as nv
+import bench
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ctx = nv.Context(0)
+if len(sys.argv) > 1 and sys.argv[1] == "grand":
+    from tests import vorbis_encode as ve
+    hdr = ve.shipped_headers(open(os.path.join(root, "tests", "golden", "3test.ogg"), "rb").read())
+    S3 = ve.setup_of(hdr)
+    pool = ve.packet_pool(S3, 20260928, per_kind=256)
+    p, _ = ve.stream_from_pool(S3, hdr, pool, np.ones(4200, dtype=bool), np.random.default_rng(7))
+    headers, audio = p[:3], p[3:]
+else:
+    headers, audio, ch = bench.ll_packets(nv, os.path.join(root, "tests", "golden", "3test.ogg"))
+st, bl = bench.make_batches(nv, torch, ctx, headers, audio, 2, 4096, 1)
+b, pcm = bl[0]
+print(b.stats())
+dbg = torch.zeros(4096 * 24, dtype=torch.int64, device="cuda")
+L = nv.lib(); L.nvh_debug_set_buffer.argtypes = [ctypes.c_void_p]
+for _ in range(3): b.synth(pcm.data_ptr(), pcm.numel())
+ctx.synchronize()
+L.nvh_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
+b.synth(pcm.data_ptr(), pcm.numel())
+ctx.synchronize(); torch.cuda.synchronize()
+L.nvh_debug_set_buffer(None)
+print(b.kernels())
+d = dbg.cpu().numpy().reshape(4096, 24)
+names = ["DMA round trip + clear + barrier", "header (+ rest of a big slab)", "residue walk + barrier", "floor multiply", "inverse MDCT + store"]
+for k in range(5):
+    dt = d[:, k + 1] - d[:, k]
+    print("%-34s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (names[k], dt.mean(), np.median(dt), np.percentile(dt, 90)))
+life = d[:, 5] - d[:, 0]
+print("WG lifetime mean %.0f p50 %.0f p90 %.0f cycles" % (life.mean(), np.median(life), np.percentile(life, 90)))
+w0 = d[:, 22].min()
+start = (d[:, 22] - w0) / 100.0  # 100 MHz wall clock -> us
+end = (d[:, 23] - w0) / 100.0
+print("wall clock: first start 0, last start %.1f us, last end %.1f us; starts p50 %.1f p90 %.1f; lifetime mean %.2f us" % (
+    start.max(), end.max(), np.median(start), np.percentile(start, 90), (end - start).mean()))
+hist, edges = np.histogram(start, bins=12)
+print("start histogram (us):", [(round(float(edges[i]), 1), int(hist[i])) for i in range(len(hist))])
+tot, km = b.time(pcm.data_ptr(), pcm.numel(), 20)
+print({n: round(v * 1e3, 1) for n, v in zip(b.kernels(), km)})
