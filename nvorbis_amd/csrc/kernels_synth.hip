@@ -55,10 +55,21 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
 // reference's order per element, one LDS store per element.  Component i of the partition lies in entry i / dim of the
 // stage's vector list as component i % dim; the entry's components are the base-lat_values digits of the entry number,
 // peeled two at a time with exact reciprocal multiplies (consecutive pairs of one entry continue from the previous quotient).
-template <int G>
+struct FloorRef {  // the frame's floor curves as they lie in the slab (both channels), for the fused multiply
+  const FloorSeg* seg[2];
+  const uint32_t* magic[2];
+  const uint8_t* tab[2];
+  int md[2];
+  const float* s_db;
+};
+
+// FUSE: the floor multiply (Floor1.cs:196-222) happens here, on the registers that hold a chain's finished sums, and only
+// for bins some chain covers: every other bin of the cleared spectrum stays +0.0f, which is what 0 * curve gives anyway.
+template <int G, bool FUSE = false>
 __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
                                              const uint32_t* __restrict__ s_lat, float* spec, int half, unsigned nheads,
-                                             unsigned lpc, unsigned lpc_magic, bool interleaved, unsigned flags, int tid) {
+                                             unsigned lpc, unsigned lpc_magic, bool interleaved, unsigned flags, int tid,
+                                             const FloorRef* F = nullptr) {
   const uint16_t* heads = reinterpret_cast<const uint16_t*>(slab + off_heads * 4);
   const uint4* recs = reinterpret_cast<const uint4*>(slab + off_rec * 4);
   const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
@@ -78,26 +89,38 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
       const unsigned dims = rec.w & 0xFFu, lv = rec.y >> 16, dm16 = rec.w >> 16;
       const uint32_t* lat = s_lat + (rec.y & 0xFFFFu);
       const uint16_t* eb = ent + (rec.x & 0xFFFFu);
-      unsigned q2 = 0;
+      // Branch-free on purpose: every entry of the group is fetched first, then the digits, then the lattice values, so
+      // that the LDS round trips of the group overlap instead of queueing behind exec-mask regions.  A skipped entry
+      // ("no vector was added here", quirks B-14 / B-16) adds +0.0f, which is the identity on these sums: they start at
+      // +0.0f and a sum is -0.0f only when both operands are.
+      unsigned e[G / 2], comp[G / 2];
 #pragma unroll
       for (int k = 0; k < G; k += 2) {
         const unsigned i = i0 + k;
         const unsigned j = (i * dm16) >> 16;  // i / dims (i < 4096, dims <= 16: exact)
-        const unsigned comp = i - j * dims;
-        const unsigned e = eb[j];
+        comp[k / 2] = i - j * dims;
+        e[k / 2] = eb[j];
+      }
+      // e / lv^comp where the group starts inside an entry (dims > G): one more lookup, for the first pair only
+      const unsigned pw = lat[lv + comp[0]];
+      unsigned q2 = 0;
+      unsigned d[G];
+#pragma unroll
+      for (int k = 0; k < G; k += 2) {
         unsigned q;
-        if (k == 0) q = comp ? __umulhi(e, lat[lv + comp]) : e;  // e / lv^comp: the group starts inside an entry
-        else q = comp ? q2 : e;                                   // the same entry continues, or the next one begins
+        if (k == 0) q = comp[0] ? __umulhi(e[0], pw) : e[0];
+        else q = comp[k / 2] ? q2 : e[k / 2];  // the same entry continues from the previous quotient, or the next one begins
         // two base-lv digits (lv == 1: the magic is 0 and so are q and both digits)
         const unsigned q1 = __umulhi(q, rec.z);
-        const unsigned d0 = q - q1 * lv;
+        d[k] = q - __umul24(q1, lv);
         q2 = __umulhi(q1, rec.z);
-        const unsigned d1 = q1 - q2 * lv;
-        const float v0 = __uint_as_float(lat[d0]), v1 = __uint_as_float(lat[d1]);
-        const bool add = e != NVH_ENTRY_SKIP;  // "no vector was added here" (quirks B-14 / B-16)
-        a[k] = add ? a[k] + v0 : a[k];
-        a[k + 1] = add ? a[k + 1] + v1 : a[k + 1];
+        d[k + 1] = q1 - __umul24(q2, lv);
       }
+      float v[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) v[k] = __uint_as_float(lat[d[k]]);
+#pragma unroll
+      for (int k = 0; k < G; ++k) a[k] = a[k] + (e[k / 2] != NVH_ENTRY_SKIP ? v[k] : 0.0f);
       if (!(rec.w & 0x8000u)) break;
       rec = recs[++o];
     }
@@ -112,6 +135,24 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
       }
       float* p0 = spec + xb;
       float* p1 = spec + (unsigned)half + xb;
+      if constexpr (FUSE && G == 8) {  // xb is a multiple of 4 (k_prepare_slabs checked the residue's geometry)
+        if (xb + 4 <= (unsigned)half) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            if (F->md[c] == 1) {
+              float m[4];
+              floor_walk_seg<4>(F->seg[c], F->magic[c], 0, F->s_db, (int)xb, m, F->tab[c]);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) a[2 * q + c] = a[2 * q + c] * m[q];
+            } else if (F->md[c] == 2) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) a[2 * q + c] = 0.0f;  // Floor1.cs:218-221
+            }
+          }
+          *reinterpret_cast<float4*>(p0) = make_float4(a[0], a[2], a[4 % G], a[6 % G]);
+          *reinterpret_cast<float4*>(p1) = make_float4(a[1], a[3 % G], a[5 % G], a[7 % G]);
+        }
+      } else
       if (G == 8 && (xb & 3u) == 0 && xb + 4 <= (unsigned)half) {
         *reinterpret_cast<float4*>(p0) = make_float4(a[0], a[2], a[4 % G], a[6 % G]);
         *reinterpret_cast<float4*>(p1) = make_float4(a[1], a[3 % G], a[5 % G], a[7 % G]);
@@ -127,6 +168,25 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
       const unsigned c = (rec.w >> 8) & 0x7Fu;
       const unsigned xb = xbase + i0;
       float* p = spec + c * (unsigned)half + xb;
+      if constexpr (FUSE && G == 8) {  // xb is a multiple of 4
+        if (xb + 8 <= (unsigned)half) {
+          const bool c1 = c != 0;
+          const int md = c1 ? F->md[1] : F->md[0];
+          if (md == 1) {
+            float m[8];
+            floor_walk_seg<8>(c1 ? F->seg[1] : F->seg[0], c1 ? F->magic[1] : F->magic[0], 0, F->s_db, (int)xb, m, c1 ? F->tab[1] : F->tab[0]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q % G] = a[q % G] * m[q];
+          } else if (md == 2) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) a[q] = 0.0f;
+          }
+          *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2 % G], a[3 % G]);
+          *reinterpret_cast<float4*>(p + 4) = make_float4(a[4 % G], a[5 % G], a[6 % G], a[7 % G]);
+        } else if (xb + 4 <= (unsigned)half) {  // half = 4 (mod 8) cannot happen (powers of two >= 128): kept for clarity
+          __builtin_trap();
+        }
+      } else
       if (G == 8 && (xb & 3u) == 0 && xb + 8 <= (unsigned)half) {
         *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2 % G], a[3 % G]);
         *reinterpret_cast<float4*>(p + 4) = make_float4(a[4 % G], a[5 % G], a[6 % G], a[7 % G]);
@@ -207,6 +267,7 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
   const int npass = (int)(fr.pass_end - fr.pass_begin);
   if (npass > 1) __builtin_trap();  // the host launches this path for batches with at most one residue pass per frame
   int rtype = 0, rch = 1;
+  unsigned rbegin_al = 0;  // the residue's `begin`
   H.off_heads = (uint16_t)off;
   if (npass == 1) {
     const NvhResPass* gp = Bt.passes + fr.pass_begin;
@@ -214,6 +275,7 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
     rtype = R->type;
     rch = R->real_channels;
     const unsigned psz = (unsigned)R->partition_size, rbegin = (unsigned)R->begin, rch_magic = R->rch_magic;
+    rbegin_al = rbegin;
     {
       const unsigned group = (psz & 7u) == 0 ? 8u : 2u, lpc = psz / group;
       H.group = (uint8_t)group;
@@ -297,6 +359,10 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
     if (S.coupling[mp.coupling_off] == 1) H.flags |= NVH_SLAB_MG1;
     H.flags |= (npass == 1 && rtype == 2 && rch == 2) ? NVH_SLAB_SWEEP_COUPLES : NVH_SLAB_COUPLE_PASS;
   }
+  // The floor multiply moves into the chain walk when a lane's group of eight components is whole groups of four bins
+  // (segment table, 16-byte stores) and no coupling pass stands between the two.
+  if (!(H.flags & NVH_SLAB_COUPLE_PASS) && (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
+    H.flags |= NVH_SLAB_FUSE_FLOOR;
   if (lane == 0) {
     slab[0] = reinterpret_cast<const uint4*>(&H)[0];
     slab[1] = reinterpret_cast<const uint4*>(&H)[1];
@@ -370,13 +436,25 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
   {
     const unsigned rtype = rgeom & 0xFu, rch = rgeom >> 4;
     const bool interleaved = !(rtype == 1 || rch == 1);  // Residue2 over two channels: component k = bin k / 2 of channel k & 1
-    if (group == 8)
+    if (flags & NVH_SLAB_FUSE_FLOOR) {
+      FloorRef F;
+      F.seg[0] = reinterpret_cast<const FloorSeg*>(slab + off_seg0 * 4);
+      F.seg[1] = reinterpret_cast<const FloorSeg*>(slab + off_seg1 * 4);
+      F.magic[0] = reinterpret_cast<const uint32_t*>(slab + (off_seg0 + (unsigned)ns0) * 4);
+      F.magic[1] = reinterpret_cast<const uint32_t*>(slab + (off_seg1 + (unsigned)ns1) * 4);
+      F.tab[0] = reinterpret_cast<const uint8_t*>(slab + (off_seg0 + (unsigned)ns0 + (unsigned)((ns0 + 3) >> 2)) * 4);
+      F.tab[1] = reinterpret_cast<const uint8_t*>(slab + (off_seg1 + (unsigned)ns1 + (unsigned)((ns1 + 3) >> 2)) * 4);
+      F.md[0] = md0; F.md[1] = md1;
+      F.s_db = s_db;
+      residue_walk<8, true>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, &F);
+    } else if (group == 8)
       residue_walk<8>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid);
     else
       residue_walk<2>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid);
   }
-  __syncthreads();
   SY_T(3);
+  if (!(flags & NVH_SLAB_FUSE_FLOOR)) {
+  __syncthreads();
   if (flags & NVH_SLAB_COUPLE_PASS) {  // stereo streams whose residue does not put both channels of a bin into one lane
     float* M = spec + ((flags & NVH_SLAB_MG1) ? half : 0);
     float* An = spec + ((flags & NVH_SLAB_MG1) ? 0 : half);
@@ -433,6 +511,7 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
       }
     }
   }
+  }  // !NVH_SLAB_FUSE_FLOOR
   SY_T(4);
 
   // ---- inverse MDCT (Mdct.cs:65-313), one wavefront per channel, in place over the channel's own spectrum ----

@@ -154,6 +154,7 @@ struct NvhFrame {
 #define NVH_SLAB_COUPLE_PASS 4u    // inverse coupling as a pass of its own between the residue walk and the floor multiply
 #define NVH_SLAB_FLOOR_FAULT 8u    // a curve value outside inverse_dB_table (quirk B-7): the kernel raises NVH_DEVERR_FLOOR1_Y
 #define NVH_SLAB_MDCT_SLOT 16u     // block1 tables (else block0)
+#define NVH_SLAB_FUSE_FLOOR 32u    // the lane that finishes a chain multiplies its bins by the floor curve before its one store
 struct NvhSlabHdr {      // 32 bytes
   uint16_t n;            // block size of the packet's mode; 0 = pseudo-frame, nothing to compute
   uint8_t exec_mask;     // bit c: channel c executes (NvhChan::exec)
