@@ -737,13 +737,66 @@ __device__ __forceinline__ int ola_vec(const NvhDevSetup& S, const NvhFrame& fr,
   return clipped;
 }
 
+
+// The steady state of a stream -- a block whose whole first half overlaps the whole second half of a predecessor of the same
+// size (long/long, short/short), every channel executing -- read with each compact value fetched ONCE: y[i] and y[n/2-1-i]
+// of the block are +-A[i], y[n/2+i] and y[n-1-i] of the predecessor are both B[i] (Mdct.cs:275-303), so the pair of
+// sample times (i, n/2-1-i) needs exactly A[i] and B[i].  A lane takes four consecutive i: two 16-byte loads per channel,
+// two groups of four sample times out (ola_vec reads every value twice: once for i, once, reversed, for n/2-1-i).
+// Same products, same additions, same order as ola_vec / the reference (Mode.cs:160-166, StreamDecoder.cs:532-541).
+template <int CH>
+__device__ __forceinline__ int ola_sym(const NvhDevSetup& S, const NvhFrame& fr, const float* cur, const float* prev,
+                                       const float* __restrict__ w, const float* __restrict__ wp, float* out, int clip, int tid, int threads) {
+  int clipped = 0;
+  const int n = fr.n, n2 = n >> 1;
+  const int groups = n >> 4;  // n/4 compact values per quarter, four per lane
+  for (int g = tid; g < groups; g += threads) {
+    const int i0 = 4 * g;
+    const float4 wf = *reinterpret_cast<const float4*>(w + i0);                  // window at i0 .. i0+3
+    const float4 wm = *reinterpret_cast<const float4*>(w + (n2 - 4 - i0));       // window at n/2-4-i0 .. n/2-1-i0
+    const float4 pf = *reinterpret_cast<const float4*>(wp + (n2 + i0));          // predecessor's window at n/2+i0 ..
+    const float4 pm = *reinterpret_cast<const float4*>(wp + (n - 4 - i0));       // ... and at n-4-i0 .. n-1-i0
+    float fwd[4 * CH], mir[4 * CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(cur + (long long)c * S.block1 + i0);
+      const float4 b = *reinterpret_cast<const float4*>(prev + (long long)c * S.block1 + n2 + i0);
+      // sample times i0 .. i0+3
+      float4 v = make_float4(a.x * wf.x, a.y * wf.y, a.z * wf.z, a.w * wf.w);
+      float4 t = make_float4(b.x * pf.x, b.y * pf.y, b.z * pf.z, b.w * pf.w);
+      v.x = v.x + t.x; v.y = v.y + t.y; v.z = v.z + t.z; v.w = v.w + t.w;
+      // sample times n/2-4-i0 .. n/2-1-i0: the block's values are -A reversed, the predecessor's B reversed
+      float4 u = make_float4(-a.w * wm.x, -a.z * wm.y, -a.y * wm.z, -a.x * wm.w);
+      float4 r = make_float4(b.w * pm.x, b.z * pm.y, b.y * pm.z, b.x * pm.w);
+      u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
+      if (clip) {
+        v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
+        v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
+        u.x = clip_value(u.x, &clipped); u.y = clip_value(u.y, &clipped);
+        u.z = clip_value(u.z, &clipped); u.w = clip_value(u.w, &clipped);
+      }
+      fwd[0 * CH + c] = v.x; fwd[1 * CH + c] = v.y; fwd[2 * CH + c] = v.z; fwd[3 * CH + c] = v.w;
+      mir[0 * CH + c] = u.x; mir[1 * CH + c] = u.y; mir[2 * CH + c] = u.z; mir[3 * CH + c] = u.w;
+    }
+    float4* of = reinterpret_cast<float4*>(out) + (long long)g * CH;
+    float4* om = reinterpret_cast<float4*>(out) + (long long)((n >> 3) - 1 - g) * CH;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      of[k] = make_float4(fwd[4 * k], fwd[4 * k + 1], fwd[4 * k + 2], fwd[4 * k + 3]);
+      om[k] = make_float4(mir[4 * k], mir[4 * k + 1], mir[4 * k + 2], mir[4 * k + 3]);
+    }
+  }
+  return clipped;
+}
+
 // A frame may be shared by gridDim.y workgroups (large frames: six channels at n = 4096 are 48 KB of PCM, and 128 lanes
 // per frame leave the CUs with four wavefronts each): lane `OLA_TID` of `NVH_OLA_THREADS`.
 #define NVH_OLA_THREADS ((int)(blockDim.x * gridDim.y))
 #define NVH_OLA_TID ((int)(blockIdx.y * blockDim.x + threadIdx.x))
 extern "C" __global__ void __launch_bounds__(256)
 k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const float* __restrict__ carry,
-              float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag, float* __restrict__ carry_out, int last_decoded) {
+              float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag, float* __restrict__ carry_out, int last_decoded,
+              int nosym) {
   const int f = blockIdx.x;
   const NvhFrame fr = Bt.frames[f];
   const int ch = S.channels;
@@ -774,6 +827,25 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
   // EOS-trimmed last one), up to 8 channels
   const bool vec = fr.n != 0 && ch <= 8 && ((fr.emit_start | fr.emit_count | fr.start | fr.ov_src | fr.ov_len) & 3) == 0 &&
                    ((fr.out_pos * ch) & 3) == 0;
+  // steady state: whole first half over the whole second half of an executing predecessor of the same size
+  const unsigned all_ch = ch >= 32 ? 0xFFFFFFFFu : ((1u << ch) - 1u);
+  const bool sym = vec && prev && !prev_full && fr.ov_n == fr.n && fr.start == 0 && fr.emit_start == 0 && fr.emit_count == (fr.n >> 1) &&
+                   fr.ov_src == (fr.n >> 1) && fr.ov_len == (fr.n >> 1) && (fr.exec_mask & all_ch) == all_ch &&
+                   (fr.ov_exec_mask & all_ch) == all_ch && !nosym;
+  if (sym) {
+    switch (ch) {
+      case 1: clipped = ola_sym<1>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 2: clipped = ola_sym<2>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 3: clipped = ola_sym<3>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 4: clipped = ola_sym<4>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 5: clipped = ola_sym<5>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 6: clipped = ola_sym<6>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      case 7: clipped = ola_sym<7>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+      default: clipped = ola_sym<8>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;
+    }
+    report_clipped(clipped, clipped_flag);
+    return;
+  }
   if (vec) {
     switch (ch) {
       case 1: clipped = ola_vec<1>(S, fr, cur, prev, prev_full, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;

@@ -201,21 +201,61 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
 
 }  // namespace
 
+// ---- launch order: costliest frames first ---------------------------------------------------------------------------------
+// A batch is two occupancy rounds of workgroups (4096 frames over 2048 resident slots); the kernel ends when the last
+// workgroup of the second round does.  Frames differ in work (real material: 20..180 vector writes per frame), and the
+// dispatcher hands the next workgroup to whichever slot frees first -- so with the costly frames in front the slots that
+// free late receive the cheapest frames (longest-processing-time-first list scheduling).  Counting sort by the frame's
+// number of vector writes, one workgroup; rank[f] = position of frame f's slab.  Which of two equally costly frames comes
+// first depends on the order of the atomics; the PCM does not.
+extern "C" __global__ void __launch_bounds__(1024)
+k_rank_frames(NvhDevBatch Bt, uint32_t* __restrict__ rank, int identity) {
+  __shared__ unsigned hist[1024];
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x, n = Bt.nframes;
+  if (identity) {
+    for (int f = tid; f < n; f += 1024) rank[f] = (uint32_t)f;
+    return;
+  }
+  hist[tid] = 0;
+  __syncthreads();
+  auto key = [&](int f) -> unsigned {
+    const NvhFrame* fr = Bt.frames + f;
+    const unsigned c = fr->n == 0 ? 0u : fr->op_count + 1u;
+    return 1023u - (c < 1023u ? c : 1023u);  // descending cost
+  };
+  for (int f = tid; f < n; f += 1024) atomicAdd(&hist[key(f)], 1u);
+  __syncthreads();
+  // exclusive prefix sum over the 1024 bins
+  const unsigned mine = hist[tid];
+  unsigned incl = wave_incl_scan(mine, tid & 63);
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  unsigned base = 0;
+  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+  __syncthreads();
+  hist[tid] = base + incl - mine;
+  __syncthreads();
+  for (int f = tid; f < n; f += 1024) rank[f] = atomicAdd(&hist[key(f)], 1u);
+}
+
 // ---- integer side: descriptors -> slabs, one wavefront per frame, once per batch -----------------------------------------
 extern "C" __global__ void __launch_bounds__(64)
-k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int stride_vecs) {
+k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int stride_vecs, const uint32_t* __restrict__ rank) {
   __shared__ __attribute__((aligned(16))) FloorScratch Q;
   __shared__ int s_err;
   const int f = blockIdx.x, lane = threadIdx.x, nch = S.channels;
-  uint4* slab = slabs + (long long)f * stride_vecs;
+  uint4* slab = slabs + (long long)rank[f] * stride_vecs;  // launch order: k_rank_frames
   const NvhFrame fr = Bt.frames[f];
   NvhSlabHdr H;
   H.n = 0; H.exec_mask = 0; H.flags = 0; H.mode[0] = H.mode[1] = 0; H.nseg[0] = H.nseg[1] = 0; H.nheads = 0; H.nrec = 0;
-  H.off_seg[0] = H.off_seg[1] = 2; H.off_heads = H.off_rec = H.off_ent = 2; H.vecs = 2; H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0;
+  H.off_seg[0] = H.off_seg[1] = NVH_SLAB_HDR_VECS; H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS; H.vecs = NVH_SLAB_HDR_VECS;
+  H.frame = (uint32_t)f; H.pad3[0] = H.pad3[1] = H.pad3[2] = 0; H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0;
   if (fr.n == 0) {
     if (lane == 0) {
       slab[0] = reinterpret_cast<const uint4*>(&H)[0];
       slab[1] = reinterpret_cast<const uint4*>(&H)[1];
+      slab[2] = reinterpret_cast<const uint4*>(&H)[2];
     }
     return;
   }
@@ -224,7 +264,7 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
   const NvhChan* chans = Bt.chans + (long long)f * nch;  // every frame owns exactly `channels` records (host_parse.cpp)
   if (lane == 0) s_err = 0;
   sp_wave_sync();
-  unsigned off = 2;
+  unsigned off = NVH_SLAB_HDR_VECS;
   H.n = (uint16_t)fr.n;
   H.exec_mask = (uint8_t)(fr.exec_mask & 3u);
   if (fr.mdct_slot) H.flags |= NVH_SLAB_MDCT_SLOT;
@@ -366,6 +406,7 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
   if (lane == 0) {
     slab[0] = reinterpret_cast<const uint4*>(&H)[0];
     slab[1] = reinterpret_cast<const uint4*>(&H)[1];
+    slab[2] = reinterpret_cast<const uint4*>(&H)[2];
   }
 }
 
@@ -406,6 +447,7 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
   __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
   SY_T(1);
   const uint4 h0 = reinterpret_cast<const uint4*>(slab)[0], h1 = reinterpret_cast<const uint4*>(slab)[1];
+  const unsigned frame = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t*>(slab)[8]);
   const unsigned w0 = __builtin_amdgcn_readfirstlane(h0.x), w1 = __builtin_amdgcn_readfirstlane(h0.y);
   const unsigned w2 = __builtin_amdgcn_readfirstlane(h0.z), w3 = __builtin_amdgcn_readfirstlane(h0.w);
   const unsigned w4 = __builtin_amdgcn_readfirstlane(h1.x), w5 = __builtin_amdgcn_readfirstlane(h1.y);
@@ -518,7 +560,7 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
   // (the transform's slice = n/2 floats + n/16 of padding: channel nch-1 spills its padding past the end of the spectrum
   // area, the one before it into the dead slab area in front of it; the workgroup barrier between the floor multiply and
   // the transform sits inside imdct_wave<.., PRESYNC>, behind the first table loads)
-  float* planes = A.work + (long long)f * nch * A.block1;
+  float* planes = A.work + (long long)frame * nch * A.block1;
   if (wv < nch && ((exec_mask >> wv) & 1u)) {
     const float* X = spec + wv * half;
     float* out = planes + (long long)wv * A.block1;

@@ -155,7 +155,8 @@ struct NvhFrame {
 #define NVH_SLAB_FLOOR_FAULT 8u    // a curve value outside inverse_dB_table (quirk B-7): the kernel raises NVH_DEVERR_FLOOR1_Y
 #define NVH_SLAB_MDCT_SLOT 16u     // block1 tables (else block0)
 #define NVH_SLAB_FUSE_FLOOR 32u    // the lane that finishes a chain multiplies its bins by the floor curve before its one store
-struct NvhSlabHdr {      // 32 bytes
+#define NVH_SLAB_HDR_VECS 3
+struct NvhSlabHdr {      // 48 bytes
   uint16_t n;            // block size of the packet's mode; 0 = pseudo-frame, nothing to compute
   uint8_t exec_mask;     // bit c: channel c executes (NvhChan::exec)
   uint8_t flags;         // NVH_SLAB_*
@@ -169,5 +170,7 @@ struct NvhSlabHdr {      // 32 bytes
   uint8_t rgeom;         // residue type | real channels << 4
   uint8_t group;         // consecutive vector components one lane owns through all cascade stages: 8 (partition_size % 8 == 0) or 2
   uint32_t lpc_magic;    // ceil(2^32 / lpc), 0 when lpc <= 1
+  uint32_t frame;        // the frame this slab belongs to: slabs are laid out in launch order (costliest frames first), not in frame order
+  uint32_t pad3[3];
 };
 

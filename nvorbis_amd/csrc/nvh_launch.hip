@@ -311,7 +311,7 @@ static bool slab_path(const nvh_batch* b) {
 static size_t slab_bound_vecs(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   const size_t P = (size_t)s->shared->max_posts + 2;
-  size_t v = 2 + (size_t)s->setup.channels * (P + (P + 3) / 4 + ((size_t)s->setup.block1 / 8 + 15) / 16) + ((size_t)b->max_ops + 7) / 8 + (size_t)b->max_ops + ((size_t)b->max_ent + 7) / 8 + 1;
+  size_t v = NVH_SLAB_HDR_VECS + (size_t)s->setup.channels * (P + (P + 3) / 4 + ((size_t)s->setup.block1 / 8 + 15) / 16) + ((size_t)b->max_ops + 7) / 8 + (size_t)b->max_ops + ((size_t)b->max_ent + 7) / 8 + 1;
   if (v < (size_t)s->setup.block1 / 64 + 8) v = (size_t)s->setup.block1 / 64 + 8;  // the IMDCT padding of channel 0 overlays the slab area
   return (v + 3) & ~(size_t)3;
 }
@@ -323,7 +323,9 @@ int ensure_slabs(nvh_batch* b) {
   hipStream_t st = s->ctx->stream;
   const size_t stride = slab_bound_vecs(b);
   if (stride > 0xFFFFu) return NVH_OK;  // stays on k_spectrum_imdct (slab_path is re-checked at launch through slabs_ready)
-  int rc = b->slab3.reserve((size_t)b->nframes * stride * 16 + 4096);
+  const size_t slab_bytes = ((size_t)b->nframes * stride * 16 + 4096 + 255) & ~(size_t)255;
+  int rc = b->slab3.reserve(slab_bytes + (size_t)b->nframes * sizeof(uint32_t));
+  uint32_t* rank = (uint32_t*)((uint8_t*)b->slab3.p + slab_bytes);
   if (rc != NVH_OK) return rc;
   b->slab_stride_vecs = (int)stride;
   // resident batches (nvh_batch_upload) time the conversion for nvh_batch_stats; the stream's own scratch batch does not
@@ -333,7 +335,8 @@ int ensure_slabs(nvh_batch* b) {
     if (!b->prep_e1) HIP_TRY(hipEventCreate(&b->prep_e1));
     HIP_TRY(hipEventRecord(b->prep_e0, st));
   }
-  hipLaunchKernelGGL(k_prepare_slabs, dim3((unsigned)b->nframes), dim3(64), 0, st, s->dev, b->dev, (uint4*)b->slab3.p, (int)stride);
+  hipLaunchKernelGGL(k_rank_frames, dim3(1), dim3(1024), 0, st, b->dev, rank, nvh_toggles().no_lpt ? 1 : 0);
+  hipLaunchKernelGGL(k_prepare_slabs, dim3((unsigned)b->nframes), dim3(64), 0, st, s->dev, b->dev, (uint4*)b->slab3.p, (int)stride, (const uint32_t*)rank);
   if (timed) {
     HIP_TRY(hipEventRecord(b->prep_e1, st));
     b->prepare_events_pending = true;
@@ -639,7 +642,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       if (segs > (s->setup.block1 / 8) / ola_threads) segs = (s->setup.block1 / 8) / ola_threads;
       if (segs < 1) segs = 1;
       hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
-                         (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded);
+                         (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded, T.no_ola_sym ? 1 : 0);
     } else if (!b->sequential_ola)
       hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
                          d_pcm, s->clip, flags + 1);
