@@ -65,18 +65,21 @@ struct FloorRef {  // the frame's floor curves as they lie in the slab (both cha
 
 // FUSE: the floor multiply (Floor1.cs:196-222) happens here, on the registers that hold a chain's finished sums, and only
 // for bins some chain covers: every other bin of the cleared spectrum stays +0.0f, which is what 0 * curve gives anyway.
-template <int G, bool FUSE = false>
+// RCH >= 3: Residue2 over RCH channels, G = 2 RCH: a lane owns two bins of every channel (component k = channel k % RCH of
+// bin k / RCH, Residue2.cs:25-45).  RCH == 0: the two-channel interleave or a per-channel residue, told apart at run time.
+template <int G, bool FUSE = false, int RCH = 0, int NT = SP_THREADS>
 __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
                                              const uint32_t* __restrict__ s_lat, float* spec, int half, unsigned nheads,
                                              unsigned lpc, unsigned lpc_magic, bool interleaved, unsigned flags, int tid,
                                              const FloorRef* F = nullptr) {
+  static_assert(RCH == 0 || G == 2 * RCH, "two bins of every channel per lane");
   const uint16_t* heads = reinterpret_cast<const uint16_t*>(slab + off_heads * 4);
   const uint4* recs = reinterpret_cast<const uint4*>(slab + off_rec * 4);
   const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
   const bool sweep_couples = (flags & NVH_SLAB_SWEEP_COUPLES) != 0;
   const bool mg1 = (flags & NVH_SLAB_MG1) != 0;
   const unsigned total = nheads * lpc;
-  for (unsigned idx = tid; idx < total; idx += SP_THREADS) {
+  for (unsigned idx = tid; idx < total; idx += NT) {
     const unsigned oq = lpc > 1 ? __umulhi(idx, lpc_magic) : idx;
     const unsigned g = idx - oq * lpc, i0 = g * G;  // first component of this lane's group inside the partition
     unsigned o = heads[oq];
@@ -124,6 +127,16 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
       if (!(rec.w & 0x8000u)) break;
       rec = recs[++o];
     }
+    if constexpr (RCH >= 3) {
+      // a[c] / a[RCH + c] = bins xb / xb + 1 of channel c
+      const unsigned xb = xbase + 2 * g;
+#pragma unroll
+      for (int c = 0; c < RCH; ++c) {
+        float* p = spec + (unsigned)c * (unsigned)half + xb;
+        if (xb < (unsigned)half) p[0] = a[c];
+        if (xb + 1 < (unsigned)half) p[1] = a[RCH + c];
+      }
+    } else
     if (interleaved) {
       // a[2m] / a[2m + 1] = bin xb + m of channel 0 / 1
       const unsigned xb = xbase + (i0 >> 1);
@@ -248,17 +261,18 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
   uint4* slab = slabs + (long long)rank[f] * stride_vecs;  // launch order: k_rank_frames
   const NvhFrame fr = Bt.frames[f];
   NvhSlabHdr H;
-  H.n = 0; H.exec_mask = 0; H.flags = 0; H.mode[0] = H.mode[1] = 0; H.nseg[0] = H.nseg[1] = 0; H.nheads = 0; H.nrec = 0;
-  H.off_seg[0] = H.off_seg[1] = NVH_SLAB_HDR_VECS; H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS; H.vecs = NVH_SLAB_HDR_VECS;
-  H.frame = (uint32_t)f; H.pad3[0] = H.pad3[1] = H.pad3[2] = 0; H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0;
+  H.n = 0; H.exec_mask = 0; H.flags = 0; H.nheads = 0; H.nrec = 0;
+  H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS; H.vecs = NVH_SLAB_HDR_VECS;
+  H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0; H.frame = (uint32_t)f; H.coupling = 0;
+  for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) H.chan[c] = (uint32_t)NVH_SLAB_HDR_VECS << 16;
+  auto put_header = [&]() {
+    if (lane < NVH_SLAB_HDR_VECS) slab[lane] = reinterpret_cast<const uint4*>(&H)[lane];
+  };
   if (fr.n == 0) {
-    if (lane == 0) {
-      slab[0] = reinterpret_cast<const uint4*>(&H)[0];
-      slab[1] = reinterpret_cast<const uint4*>(&H)[1];
-      slab[2] = reinterpret_cast<const uint4*>(&H)[2];
-    }
+    put_header();
     return;
   }
+  if (nch > NVH_SLAB_MAX_CH) __builtin_trap();  // host: slab_path
   const int half = fr.n >> 1;
   const NvhDevMapping mp = S.mappings[fr.mapping];
   const NvhChan* chans = Bt.chans + (long long)f * nch;  // every frame owns exactly `channels` records (host_parse.cpp)
@@ -266,18 +280,16 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
   sp_wave_sync();
   unsigned off = NVH_SLAB_HDR_VECS;
   H.n = (uint16_t)fr.n;
-  H.exec_mask = (uint8_t)(fr.exec_mask & 3u);
+  H.exec_mask = (uint8_t)(fr.exec_mask & 0xFFu);
   if (fr.mdct_slot) H.flags |= NVH_SLAB_MDCT_SLOT;
   // ---- floors: Floor1.UnwrapPosts + the segment list of the flagged posts in X order (spectrum_dev.h: floor_prepare) ----
-  for (int c = 0; c < nch && c < 2; ++c) {
+  for (int c = 0; c < nch; ++c) {
     const FloorLane L = load_floor_lane(S, Bt, chans, c, nch, lane);
     floor_prepare(&Q, L, lane, half, &s_err, S.recip);
     sp_wave_sync();
     const int mode = L.mode;  // uniform
     const int ns = mode == 1 ? Q.nseg : 0;
-    H.mode[c] = (uint8_t)mode;
-    H.nseg[c] = (uint8_t)ns;
-    H.off_seg[c] = (uint16_t)off;
+    H.chan[c] = (uint32_t)mode | ((uint32_t)ns << 8) | ((uint32_t)off << 16);
     if (mode == 1) {
       for (int i = lane; i < ns; i += 64) slab[off + i] = *reinterpret_cast<const uint4*>(&Q.seg[i]);
       uint32_t* mg = reinterpret_cast<uint32_t*>(slab + off + ns);
@@ -317,7 +329,12 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
     const unsigned psz = (unsigned)R->partition_size, rbegin = (unsigned)R->begin, rch_magic = R->rch_magic;
     rbegin_al = rbegin;
     {
-      const unsigned group = (psz & 7u) == 0 ? 8u : 2u, lpc = psz / group;
+      // components one lane owns: two bins of every channel for Residue2 over more than two channels (the host checked that
+      // partitions are whole multiples of that), else eight when partitions are, else the pair
+      unsigned group = (psz & 7u) == 0 ? 8u : 2u;
+      if (rtype == 2 && rch > 2) group = (psz % (2u * (unsigned)rch)) == 0 ? 2u * (unsigned)rch : 0u;
+      if (group == 0) __builtin_trap();  // host: slab_path
+      const unsigned lpc = psz / group;
       H.group = (uint8_t)group;
       H.lpc = (uint16_t)lpc;
       H.lpc_magic = lpc > 1 ? (uint32_t)((0x100000000ull + lpc - 1) / lpc) : 0u;
@@ -394,29 +411,46 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
   }
   if ((int)off > stride_vecs || off > 0xFFFFu) __builtin_trap();  // the host sizes the stride from the batch's largest frame
   H.vecs = (uint16_t)off;
-  // ---- inverse coupling: in the chain walk when one lane holds both channels of a bin, else a pass of its own ----
-  if (nch == 2 && mp.coupling_steps == 1 && (fr.exec_mask & 3u) != 0) {
-    if (S.coupling[mp.coupling_off] == 1) H.flags |= NVH_SLAB_MG1;
-    H.flags |= (npass == 1 && rtype == 2 && rch == 2) ? NVH_SLAB_SWEEP_COUPLES : NVH_SLAB_COUPLE_PASS;
+  // ---- inverse coupling (Mapping.cs:137-182): in the chain walk when one lane holds both channels of a bin (stereo
+  // Residue2), else passes of their own, last step first, for the steps either of whose channels executes ----
+  if (nch == 2 && mp.coupling_steps == 1 && npass == 1 && rtype == 2 && rch == 2) {
+    if ((fr.exec_mask & 3u) != 0) {
+      if (S.coupling[mp.coupling_off] == 1) H.flags |= NVH_SLAB_MG1;
+      H.flags |= NVH_SLAB_SWEEP_COUPLES;
+    }
+  } else if (mp.coupling_steps > 0) {
+    if (mp.coupling_steps > NVH_SLAB_MAX_COUPLE) __builtin_trap();  // host: slab_path
+    unsigned word = 0, cnt = 0;
+    for (int st = mp.coupling_steps - 1; st >= 0; --st) {  // stored in the order they are applied
+      const unsigned mg = S.coupling[mp.coupling_off + 2 * st], an = S.coupling[mp.coupling_off + 2 * st + 1];
+      if (((fr.exec_mask >> mg) | (fr.exec_mask >> an)) & 1u) {
+        word |= (mg | (an << 3)) << (4 + 6 * cnt);
+        ++cnt;
+      }
+    }
+    if (cnt) {
+      H.coupling = word | cnt;
+      H.flags |= NVH_SLAB_COUPLE_PASS;
+    }
   }
   // The floor multiply moves into the chain walk when a lane's group of eight components is whole groups of four bins
-  // (segment table, 16-byte stores) and no coupling pass stands between the two.
-  if (!(H.flags & NVH_SLAB_COUPLE_PASS) && (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
+  // (segment table, 16-byte stores), no coupling pass stands between the two, and the stream has at most two channels.
+  if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) &&
+      (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
     H.flags |= NVH_SLAB_FUSE_FLOOR;
-  if (lane == 0) {
-    slab[0] = reinterpret_cast<const uint4*>(&H)[0];
-    slab[1] = reinterpret_cast<const uint4*>(&H)[1];
-    slab[2] = reinterpret_cast<const uint4*>(&H)[2];
-  }
+  put_header();
 }
 
 // ---- float side ------------------------------------------------------------------------------------------------------------
 // LDS map (dynamic, floats): [ inverse_dB_table 256 | lattice pool (const_vecs * 4 - 256) | slab image cap_vecs * 4 |
-//                              spectrum channels * block1 / 2 | block1 / 16 of IMDCT padding ]
-
-extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+//                              spectrum channels * block1 / 2 | block1 / 16 of IMDCT padding (k_synth) ]
+// NT = 256, MAXCH = 2 (k_synth): mono / stereo, blocks up to 2048, 8 workgroups per CU; the floor multiply inside the chain
+//   walk where the slab says so, the transform in place over the channel's own spectrum.
+// NT = 512, MAXCH = 8 (k_synth8): up to eight channels (one wavefront per channel in the transform), blocks up to 4096; coupling
+//   as passes of their own, the floor multiply as a pass over all channels, the transforms' slices laid over everything
+//   that is dead by then (imdct_wave<.., WGSYNC>).
+template <int NT, int MAXCH>
+__device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int f = blockIdx.x;
   const int nch = A.channels;
@@ -434,162 +468,204 @@ k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
 #ifdef NVH_DEBUG
   if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 22] = wall_clock64();
 #endif
-  // ---- one round trip: constants + the first 4 KB of the slab by LDS-DMA, the spectrum cleared meanwhile ----
+  // ---- one round trip: constants + the first NT * 16 bytes of the slab by LDS-DMA, the spectrum cleared meanwhile ----
   const uint4* gslab = A.slabs + (long long)f * A.stride_vecs;
   {
     const int v = tid;  // 16-byte unit handled by this lane: wavefront w moves units [64 w, 64 w + 64)
     if (v < A.cap_vecs) dma16(gslab + v, slab + wv * 256);
-    for (int c0 = wv * 64; c0 < A.const_vecs; c0 += SP_THREADS)
+    for (int c0 = wv * 64; c0 < A.const_vecs; c0 += NT)
       if (c0 + lane < A.const_vecs) dma16(A.consts + c0 + lane, smem + c0 * 4);
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int i = tid; i < (nch * half_max) >> 2; i += SP_THREADS) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
+    for (int i = tid; i < (nch * half_max) >> 2; i += NT) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
   }
   __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
   SY_T(1);
   const uint4 h0 = reinterpret_cast<const uint4*>(slab)[0], h1 = reinterpret_cast<const uint4*>(slab)[1];
-  const unsigned frame = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t*>(slab)[8]);
   const unsigned w0 = __builtin_amdgcn_readfirstlane(h0.x), w1 = __builtin_amdgcn_readfirstlane(h0.y);
   const unsigned w2 = __builtin_amdgcn_readfirstlane(h0.z), w3 = __builtin_amdgcn_readfirstlane(h0.w);
   const unsigned w4 = __builtin_amdgcn_readfirstlane(h1.x), w5 = __builtin_amdgcn_readfirstlane(h1.y);
-  const unsigned w6 = __builtin_amdgcn_readfirstlane(h1.z), w7 = __builtin_amdgcn_readfirstlane(h1.w);
+  const unsigned frame = __builtin_amdgcn_readfirstlane(h1.z), cpl_word = __builtin_amdgcn_readfirstlane(h1.w);
   const int n = (int)(w0 & 0xFFFFu);
   if (n == 0) return;
   const unsigned exec_mask = (w0 >> 16) & 0xFFu, flags = w0 >> 24;
-  const int md0 = (int)(w1 & 0xFFu), md1 = (int)((w1 >> 8) & 0xFFu);
-  const int ns0 = (int)((w1 >> 16) & 0xFFu), ns1 = (int)(w1 >> 24);
-  const unsigned nheads = w2 & 0xFFFFu;
-  const unsigned off_seg0 = w3 & 0xFFFFu, off_seg1 = w3 >> 16;
-  const unsigned off_heads = w4 & 0xFFFFu, off_rec = w4 >> 16;
-  const unsigned off_ent = w5 & 0xFFFFu, vecs = w5 >> 16;
-  const unsigned lpc = w6 & 0xFFFFu, rgeom = (w6 >> 16) & 0xFFu, group = w6 >> 24;
-  const unsigned lpc_magic = w7;
+  const unsigned nheads = w1 & 0xFFFFu;
+  const unsigned off_heads = w2 & 0xFFFFu, off_rec = w2 >> 16;
+  const unsigned off_ent = w3 & 0xFFFFu, vecs = w3 >> 16;
+  const unsigned lpc = w4 & 0xFFFFu, rgeom = (w4 >> 16) & 0xFFu, group = w4 >> 24;
+  const unsigned lpc_magic = w5;
+  const uint32_t* s_chan = reinterpret_cast<const uint32_t*>(slab) + 8;  // per channel: mode | nseg << 8 | off_seg << 16
   const int half = n >> 1;
   if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
-  if (vecs > (unsigned)SP_THREADS) {  // a slab beyond the speculative 4 KB: fetch the rest
-    for (unsigned c0 = SP_THREADS + wv * 64; c0 < vecs; c0 += SP_THREADS)
+  if (vecs > (unsigned)NT) {  // a slab beyond the speculative piece: fetch the rest
+    for (unsigned c0 = NT + wv * 64; c0 < vecs; c0 += NT)
       if (c0 + lane < vecs) dma16(gslab + c0 + lane, slab + c0 * 4);
     __syncthreads();
   }
   if ((flags & NVH_SLAB_FLOOR_FAULT) && tid == 0) atomicOr(A.err, NVH_DEVERR_FLOOR1_Y);
   SY_T(2);
 
+  // the floor curve of channel c as it lies in the slab
+  auto floor_of = [&](unsigned cw, const FloorSeg*& seg, const uint32_t*& magic, const uint8_t*& tab) {
+    const unsigned ns = (cw >> 8) & 0xFFu, oseg = cw >> 16;
+    seg = reinterpret_cast<const FloorSeg*>(slab + oseg * 4);
+    magic = reinterpret_cast<const uint32_t*>(slab + (oseg + ns) * 4);
+    tab = reinterpret_cast<const uint8_t*>(slab + (oseg + ns + ((ns + 3) >> 2)) * 4);
+  };
+
   // ---- residue: one lane per GROUP of consecutive vector components of one chain, all cascade stages with the sums in
   // registers (the reference's additions in the reference's order per element) ----
   {
     const unsigned rtype = rgeom & 0xFu, rch = rgeom >> 4;
-    const bool interleaved = !(rtype == 1 || rch == 1);  // Residue2 over two channels: component k = bin k / 2 of channel k & 1
-    if (flags & NVH_SLAB_FUSE_FLOOR) {
+    const bool interleaved = !(rtype == 1 || rch == 1);  // Residue2 over several channels: component k = bin k / rch of channel k % rch
+#define NVH_WALK(G, FUSE, RCH, FP) residue_walk<G, FUSE, RCH, NT>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP)
+    if (MAXCH <= 2 && (flags & NVH_SLAB_FUSE_FLOOR)) {
       FloorRef F;
-      F.seg[0] = reinterpret_cast<const FloorSeg*>(slab + off_seg0 * 4);
-      F.seg[1] = reinterpret_cast<const FloorSeg*>(slab + off_seg1 * 4);
-      F.magic[0] = reinterpret_cast<const uint32_t*>(slab + (off_seg0 + (unsigned)ns0) * 4);
-      F.magic[1] = reinterpret_cast<const uint32_t*>(slab + (off_seg1 + (unsigned)ns1) * 4);
-      F.tab[0] = reinterpret_cast<const uint8_t*>(slab + (off_seg0 + (unsigned)ns0 + (unsigned)((ns0 + 3) >> 2)) * 4);
-      F.tab[1] = reinterpret_cast<const uint8_t*>(slab + (off_seg1 + (unsigned)ns1 + (unsigned)((ns1 + 3) >> 2)) * 4);
-      F.md[0] = md0; F.md[1] = md1;
+      const unsigned c0w = __builtin_amdgcn_readfirstlane(s_chan[0]), c1w = __builtin_amdgcn_readfirstlane(s_chan[1]);
+      floor_of(c0w, F.seg[0], F.magic[0], F.tab[0]);
+      floor_of(c1w, F.seg[1], F.magic[1], F.tab[1]);
+      F.md[0] = (int)(c0w & 0xFFu); F.md[1] = (int)(c1w & 0xFFu);
       F.s_db = s_db;
-      residue_walk<8, true>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, &F);
-    } else if (group == 8)
-      residue_walk<8>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid);
-    else
-      residue_walk<2>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid);
-  }
-  SY_T(3);
-  if (!(flags & NVH_SLAB_FUSE_FLOOR)) {
-  __syncthreads();
-  if (flags & NVH_SLAB_COUPLE_PASS) {  // stereo streams whose residue does not put both channels of a bin into one lane
-    float* M = spec + ((flags & NVH_SLAB_MG1) ? half : 0);
-    float* An = spec + ((flags & NVH_SLAB_MG1) ? 0 : half);
-    for (int j = tid; j < half; j += SP_THREADS) {
-      float vm = M[j], va = An[j];
-      couple1(vm, va);
-      M[j] = vm;
-      An[j] = va;
-    }
-    __syncthreads();
-  }
-
-  // ---- floor multiply in place (Floor1.cs:196-222): the lanes split over the channels, 8 (stereo) / 4 (mono) bins each ----
-  {
-    const int c = nch == 2 ? (tid >> 7) : 0;  // wave-uniform
-    const int md = c ? md1 : md0, ns = c ? ns1 : ns0;
-    const unsigned oseg = c ? off_seg1 : off_seg0;
-    const FloorSeg* seg = reinterpret_cast<const FloorSeg*>(slab + oseg * 4);
-    const uint32_t* magic = reinterpret_cast<const uint32_t*>(slab + (oseg + (unsigned)ns) * 4);
-    const uint8_t* segtab = reinterpret_cast<const uint8_t*>(slab + (oseg + (unsigned)ns + (unsigned)((ns + 3) >> 2)) * 4);
-    float* sp = spec + c * half;
-    if (nch == 2) {
-      constexpr int TS = 8;
-      if (md != 0) {
-        for (int x0 = (tid & 127) * TS; x0 < half; x0 += 128 * TS) {
-          float r[TS], m[TS];
-          if (md == 1) {
-#pragma unroll
-            for (int q = 0; q < TS; q += 4) *reinterpret_cast<float4*>(r + q) = *reinterpret_cast<const float4*>(sp + x0 + q);
-            floor_walk_seg<TS>(seg, magic, ns, s_db, x0, m, segtab);
-#pragma unroll
-            for (int q = 0; q < TS; ++q) r[q] = r[q] * m[q];
-          } else {
-#pragma unroll
-            for (int q = 0; q < TS; ++q) r[q] = 0.0f;  // Floor1.cs:218-221
-          }
-#pragma unroll
-          for (int q = 0; q < TS; q += 4) *reinterpret_cast<float4*>(sp + x0 + q) = *reinterpret_cast<float4*>(r + q);
-        }
+      NVH_WALK(8, true, 0, &F);
+    } else if (!interleaved || rch == 2) {
+      if (group == 8) NVH_WALK(8, false, 0, nullptr);
+      else NVH_WALK(2, false, 0, nullptr);
+    } else if (MAXCH > 2) {
+      switch (rch) {  // group == 2 * rch (k_prepare_slabs)
+        case 3: NVH_WALK(6, false, 3, nullptr); break;
+        case 4: NVH_WALK(8, false, 4, nullptr); break;
+        case 5: NVH_WALK(10, false, 5, nullptr); break;
+        case 6: NVH_WALK(12, false, 6, nullptr); break;
+        case 7: NVH_WALK(14, false, 7, nullptr); break;
+        case 8: NVH_WALK(16, false, 8, nullptr); break;
+        default: __builtin_trap();
       }
     } else {
-      constexpr int TS = 4;
-      if (md != 0) {
-        for (int x0 = tid * TS; x0 < half; x0 += SP_THREADS * TS) {
-          float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (md == 1) {
-            float m[TS];
-            r = *reinterpret_cast<const float4*>(sp + x0);
-            floor_walk_seg<TS>(seg, magic, ns, s_db, x0, m, segtab);
-            r.x = r.x * m[0]; r.y = r.y * m[1]; r.z = r.z * m[2]; r.w = r.w * m[3];
-          }
-          *reinterpret_cast<float4*>(sp + x0) = r;
+      __builtin_trap();  // host: slab_path
+    }
+#undef NVH_WALK
+  }
+  SY_T(3);
+  if (!(MAXCH <= 2 && (flags & NVH_SLAB_FUSE_FLOOR))) {
+    __syncthreads();
+    if (flags & NVH_SLAB_COUPLE_PASS) {
+      // inverse coupling as passes of their own (Mapping.cs:137-182), in the order k_prepare_slabs stored them (last step first)
+      const unsigned cnt = cpl_word & 0xFu;
+      for (unsigned k = 0; k < cnt; ++k) {
+        const unsigned pr = (cpl_word >> (4 + 6 * k)) & 0x3Fu;
+        float* M = spec + (pr & 7u) * (unsigned)half;
+        float* An = spec + (pr >> 3) * (unsigned)half;
+        for (int j = tid * 4; j < half; j += NT * 4) {
+          float4 vm = *reinterpret_cast<const float4*>(M + j), va = *reinterpret_cast<const float4*>(An + j);
+          couple1(vm.x, va.x); couple1(vm.y, va.y); couple1(vm.z, va.z); couple1(vm.w, va.w);
+          *reinterpret_cast<float4*>(M + j) = vm;
+          *reinterpret_cast<float4*>(An + j) = va;
         }
+        __syncthreads();
+      }
+    }
+    // ---- floor multiply in place (Floor1.cs:196-222): 8 bins of one channel per lane ----
+    {
+      const int per_ch = half >> 3;
+      for (int t = tid; t < nch * per_ch; t += NT) {
+        const int c = t / per_ch, x0 = (t - c * per_ch) << 3;
+        const unsigned cw = s_chan[c];
+        const int md = (int)(cw & 0xFFu);
+        if (md == 0) continue;  // the channel does not execute: its residue stays (quirk B-4)
+        float* sp = spec + c * half + x0;
+        float r[8];
+        if (md == 1) {
+          const FloorSeg* seg; const uint32_t* magic; const uint8_t* tab;
+          floor_of(cw, seg, magic, tab);
+          float m[8];
+          *reinterpret_cast<float4*>(r) = *reinterpret_cast<const float4*>(sp);
+          *reinterpret_cast<float4*>(r + 4) = *reinterpret_cast<const float4*>(sp + 4);
+          floor_walk_seg<8>(seg, magic, 0, s_db, x0, m, tab);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r[q] = r[q] * m[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r[q] = 0.0f;  // Floor1.cs:218-221
+        }
+        *reinterpret_cast<float4*>(sp) = *reinterpret_cast<float4*>(r);
+        *reinterpret_cast<float4*>(sp + 4) = *reinterpret_cast<float4*>(r + 4);
+      }
+    }
+    // k_synth: the barrier in front of the transform sits inside imdct_wave<.., PRESYNC>; k_synth8's transform reads its
+    // spectrum before the one barrier it has (WGSYNC), so the floor multiply ends with one of its own
+    if (MAXCH > 2) __syncthreads();
+  }
+  SY_T(4);
+
+  // ---- inverse MDCT (Mdct.cs:65-313), one wavefront per channel ----
+  float* planes = A.work + (long long)frame * nch * A.block1;
+  const int sl = (flags & NVH_SLAB_MDCT_SLOT) ? 1 : 0;
+  const float* Aa = A.mdct_a[sl];
+  const float* Bb = A.mdct_b[sl];
+  const float* Cc = A.mdct_c[sl];
+  const float* TW = A.mdct_tw[sl];
+  const bool xform = wv < nch && ((exec_mask >> wv) & 1u);
+  if (MAXCH <= 2) {
+    // in place over the channel's own spectrum (the transform's slice = n/2 floats + n/16 of padding: channel nch-1 spills its
+    // padding past the end of the spectrum area, the one before it into the dead slab area in front of it; the workgroup
+    // barrier between the floor multiply and the transform sits inside imdct_wave<.., PRESYNC>, behind the first table loads)
+    if (xform) {
+      const float* X = spec + wv * half;
+      float* out = planes + (long long)wv * A.block1;
+      float* scratch = spec + wv * half - (nch - 1 - wv) * (n >> 4);
+      switch (n) {
+        case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
+      }
+    } else {
+      __syncthreads();
+    }
+  } else {
+    // Every transforming wavefront first takes its channel's whole spectrum into registers; behind the ONE workgroup barrier
+    // inside imdct_wave<.., WGSYNC> the constants, the slab and all spectra are dead, and the transforms' slices (n/2 + n/16
+    // floats each) are laid out back to back from the start of the LDS area.
+    if (xform) {
+      const float* X = spec + wv * half;
+      float* out = planes + (long long)wv * A.block1;
+      float* scratch = smem + wv * (half + (n >> 4));
+      switch (n) {
+        case 256: imdct_wave<8, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 512: imdct_wave<9, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 1024: imdct_wave<10, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 2048: imdct_wave<11, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 4096: imdct_wave<12, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        default: __builtin_trap();  // host launches this kernel for block sizes up to 4096 only
       }
     }
   }
-  }  // !NVH_SLAB_FUSE_FLOOR
-  SY_T(4);
-
-  // ---- inverse MDCT (Mdct.cs:65-313), one wavefront per channel, in place over the channel's own spectrum ----
-  // (the transform's slice = n/2 floats + n/16 of padding: channel nch-1 spills its padding past the end of the spectrum
-  // area, the one before it into the dead slab area in front of it; the workgroup barrier between the floor multiply and
-  // the transform sits inside imdct_wave<.., PRESYNC>, behind the first table loads)
-  float* planes = A.work + (long long)frame * nch * A.block1;
-  if (wv < nch && ((exec_mask >> wv) & 1u)) {
+  if (!xform && wv < nch) {
+    // Mapping.cs:192-196: the residue stays in [0, n/2) (k_ola_compact windows it); its tail quarter is zero
+    // (copied out before the barrier the transforming wavefronts pass: their slices may overlay this spectrum behind it)
     const float* X = spec + wv * half;
     float* out = planes + (long long)wv * A.block1;
-    float* scratch = spec + wv * half - (nch - 1 - wv) * (n >> 4);
-    const int sl = (flags & NVH_SLAB_MDCT_SLOT) ? 1 : 0;
-    const float* Aa = A.mdct_a[sl];
-    const float* Bb = A.mdct_b[sl];
-    const float* Cc = A.mdct_c[sl];
-    const float* TW = A.mdct_tw[sl];
-    switch (n) {
-      case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-      case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-      case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-      case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-      default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
-    }
-  } else {
-    __syncthreads();
-    if (wv < nch) {
-      // Mapping.cs:192-196: the residue stays in [0, n/2) (k_ola_compact windows it); its tail quarter is zero
-      const float* X = spec + wv * half;
-      float* out = planes + (long long)wv * A.block1;
-      for (int i = lane * 4; i < half; i += 256) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(X + i);
-      for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
+    for (int i = lane * 4; i < half; i += 256) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(X + i);
+    for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
+  if (MAXCH > 2 && !xform) __syncthreads();  // the one barrier every transforming wavefront passes inside imdct_wave<.., WGSYNC>
   SY_T(5);
 #ifdef NVH_DEBUG
   if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 23] = wall_clock64();
 #endif
 #undef SY_T
+}
+
+// 8 waves per SIMD = 8 resident workgroups per CU: the register budget (64 VGPRs) is part of the design
+extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_body<SP_THREADS, 2>(A, smem NVH_DBG_ARGS);
+}
+
+// up to eight channels, blocks up to 4096: 8 wavefronts per workgroup, the CU's LDS decides how many are resident
+extern "C" __global__ void __launch_bounds__(512)
+k_synth8(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_body<512, NVH_SLAB_MAX_CH>(A, smem NVH_DBG_ARGS);
 }

@@ -155,22 +155,24 @@ struct NvhFrame {
 #define NVH_SLAB_FLOOR_FAULT 8u    // a curve value outside inverse_dB_table (quirk B-7): the kernel raises NVH_DEVERR_FLOOR1_Y
 #define NVH_SLAB_MDCT_SLOT 16u     // block1 tables (else block0)
 #define NVH_SLAB_FUSE_FLOOR 32u    // the lane that finishes a chain multiplies its bins by the floor curve before its one store
-#define NVH_SLAB_HDR_VECS 3
-struct NvhSlabHdr {      // 48 bytes
+#define NVH_SLAB_HDR_VECS 4
+#define NVH_SLAB_MAX_CH 8          // channels a slab describes (k_synth: 2, k_synth8: 8)
+#define NVH_SLAB_MAX_COUPLE 4      // coupling steps of a pass of its own (3 + 3 bits each in NvhSlabHdr::coupling)
+struct NvhSlabHdr {      // 64 bytes
   uint16_t n;            // block size of the packet's mode; 0 = pseudo-frame, nothing to compute
   uint8_t exec_mask;     // bit c: channel c executes (NvhChan::exec)
   uint8_t flags;         // NVH_SLAB_*
-  uint8_t mode[2];       // floor of channel c: 0 none (does not execute), 1 curve, 2 clear (Floor1.cs:218-221)
-  uint8_t nseg[2];
   uint16_t nheads, nrec;
-  uint16_t off_seg[2];   // section offsets in 16-byte units from the start of the slab
-  uint16_t off_heads, off_rec, off_ent;
+  uint16_t off_heads, off_rec;  // section offsets in 16-byte units from the start of the slab
+  uint16_t off_ent;
   uint16_t vecs;         // size of the slab in 16-byte units
   uint16_t lpc;          // lanes per chain = partition_size / group
   uint8_t rgeom;         // residue type | real channels << 4
-  uint8_t group;         // consecutive vector components one lane owns through all cascade stages: 8 (partition_size % 8 == 0) or 2
+  uint8_t group;         // consecutive vector components one lane owns through all cascade stages: 8 (stereo / per-channel
+                         // residues, partition_size % 8 == 0), 2 * channels (Residue2 over more than two channels), else 2
   uint32_t lpc_magic;    // ceil(2^32 / lpc), 0 when lpc <= 1
   uint32_t frame;        // the frame this slab belongs to: slabs are laid out in launch order (costliest frames first), not in frame order
-  uint32_t pad3[3];
+  uint32_t coupling;     // NVH_SLAB_COUPLE_PASS: step count | (magnitude | angle << 3) << (4 + 6 k) for step k (Mapping.cs:137-182)
+  uint32_t chan[NVH_SLAB_MAX_CH];  // per channel: floor mode (0 none, 1 curve, 2 clear; Floor1.cs:218-221) | nseg << 8 | off_seg << 16
 };
 

@@ -66,6 +66,7 @@ __global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArg
 __global__ void k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* slabs, int stride_vecs, const uint32_t* rank);
 __global__ void k_rank_frames(NvhDevBatch Bt, uint32_t* rank, int identity);
 __global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
+__global__ void k_synth8(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
 __global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,
                                   long long plane_stride);
@@ -223,6 +224,7 @@ struct SharedSetup {
   const uint4* synth_consts = nullptr;  // inverse_dB_table + lattice pool in 16-byte units (kernels_synth.hip), inside `arena`
   int synth_const_vecs = 0;
   int max_posts = 0;            // largest Floor1 post count of the setup (bounds a slab's segment lists)
+  bool slab_setup_ok = false;   // the setup is inside the slab synthesis kernels' contract (nvh_launch.hip: slab_path)
   bool has_sequential = false;  // some residue replays the reference's partition order (quirk B-1 / vector overrun)
   // GPU packet parser (kernels_parse.hip): its tables, and whether this stream shape is inside its limits
   DevBuf parse_arena;
@@ -239,6 +241,7 @@ struct nvh_ctx {
   BufPool hpool;  // pinned staging blocks
   std::map<std::string, std::shared_ptr<SharedSetup>> setup_cache;  // key: identification packet + setup packet bytes
   bool big_lds_attr_set = false;    // the general spectrum kernels' 152 KB dynamic-LDS opt-in was made on this context's device
+  bool synth_lds_attr_set = false;  // k_synth8's 160 KB dynamic-LDS opt-in was made on this context's device
   bool parse_lds_attr_set = false;  // k_parse's 80 KB dynamic-LDS opt-in was made on this context's device
 };
 

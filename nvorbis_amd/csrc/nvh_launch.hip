@@ -296,24 +296,44 @@ static int upload_dev_copy(nvh_batch* b, hipStream_t st) {
   return NVH_OK;
 }
 
-// Whether a batch takes the slab synthesis kernel (kernels_synth.hip): the stream shapes of k_spectrum_imdct with at most one
-// residue pass per frame and slabs that fit 16-bit section offsets.
-static bool slab_path(const nvh_batch* b) {
-  const nvh_stream* s = b->s;
-  const NvhToggles& T = nvh_toggles();
-  return s->fast_spectrum && b->links_ok && s->setup.channels <= 2 && s->setup.block0 >= 256 && s->setup.block1 <= 2048 &&
-         !b->sequential_ola && !b->block_only && b->max_pass <= 1 && !T.no_slab && !T.unfused && !T.no_fused_imdct && !T.no_compact &&
-         s->shared->synth_consts != nullptr;
-}
+// The wide form (k_synth8: 512 threads, up to eight channels, blocks up to 4096) against k_synth (256 threads, mono / stereo,
+// blocks up to 2048, 8 workgroups per CU).
+static bool slab_wide(const nvh_stream* s) { return s->setup.channels > 2 || s->setup.block1 > 2048; }
 
 // Upper bound of a slab of this batch in 16-byte units: header, per channel a segment list of at most max_posts segments
-// + their magics, the chain heads, one record per vector write, the entries (nvh_format.h: NvhSlabHdr).
+// + their magics + the per-four-bins segment table, the chain heads, one record per vector write, the entries
+// (nvh_format.h: NvhSlabHdr).
 static size_t slab_bound_vecs(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   const size_t P = (size_t)s->shared->max_posts + 2;
-  size_t v = NVH_SLAB_HDR_VECS + (size_t)s->setup.channels * (P + (P + 3) / 4 + ((size_t)s->setup.block1 / 8 + 15) / 16) + ((size_t)b->max_ops + 7) / 8 + (size_t)b->max_ops + ((size_t)b->max_ent + 7) / 8 + 1;
+  size_t v = NVH_SLAB_HDR_VECS + (size_t)s->setup.channels * (P + (P + 3) / 4 + ((size_t)s->setup.block1 / 8 + 15) / 16) + ((size_t)b->max_ops + 7) / 8 +
+             (size_t)b->max_ops + ((size_t)b->max_ent + 7) / 8 + 1;
   if (v < (size_t)s->setup.block1 / 64 + 8) v = (size_t)s->setup.block1 / 64 + 8;  // the IMDCT padding of channel 0 overlays the slab area
   return (v + 3) & ~(size_t)3;
+}
+
+// Dynamic LDS of the slab synthesis kernel for this batch (kernels_synth.hip: LDS map): constants + the largest slab + the
+// spectra, and room for the transforms' slices where they are laid over everything (k_synth8).
+static size_t slab_lds_bytes(const nvh_batch* b) {
+  const nvh_stream* s = b->s;
+  const size_t ch = (size_t)s->setup.channels, b1 = (size_t)s->setup.block1;
+  size_t words = (size_t)s->shared->synth_const_vecs * 4 + slab_bound_vecs(b) * 4 + ch * (b1 / 2) + b1 / 16;
+  if (slab_wide(s)) words = std::max(words, ch * (b1 / 2 + b1 / 16));
+  return words * sizeof(float);
+}
+
+// Whether a batch takes the slab synthesis kernels (kernels_synth.hip): Floor1 only, every residue on the pair path (lattice
+// books of even dimension, no aliasing partitions), Residue2 over more than two channels only with partitions that are whole
+// multiples of two bins of every channel, at most NVH_SLAB_MAX_COUPLE coupling steps, at most one residue pass per frame,
+// up to eight channels, blocks 256..4096, slabs within 16-bit section offsets and the CU's LDS.
+static bool slab_path(const nvh_batch* b) {
+  const nvh_stream* s = b->s;
+  const NvhToggles& T = nvh_toggles();
+  if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->max_pass > 1) return false;
+  if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact) return false;
+  if (slab_wide(s) && T.no_gen8) return false;  // NVH_NO_GEN8 keeps its meaning: more than four channels through k_spectrum_gen
+  if (slab_bound_vecs(b) > 0xFFFFu) return false;
+  return slab_lds_bytes(b) + (size_t)T.lds_pad <= (slab_wide(s) ? (size_t)160 * 1024 - 1024 : (size_t)64 * 1024);
 }
 
 // k_prepare_slabs once per upload: descriptors -> per-frame slabs (integer work: floor unwrap, chain-major pair records).
@@ -322,7 +342,6 @@ int ensure_slabs(nvh_batch* b) {
   nvh_stream* s = b->s;
   hipStream_t st = s->ctx->stream;
   const size_t stride = slab_bound_vecs(b);
-  if (stride > 0xFFFFu) return NVH_OK;  // stays on k_spectrum_imdct (slab_path is re-checked at launch through slabs_ready)
   const size_t slab_bytes = ((size_t)b->nframes * stride * 16 + 4096 + 255) & ~(size_t)255;
   int rc = b->slab3.reserve(slab_bytes + (size_t)b->nframes * sizeof(uint32_t));
   uint32_t* rank = (uint32_t*)((uint8_t*)b->slab3.p + slab_bytes);
@@ -463,9 +482,38 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   const bool fast = s->fast_spectrum && b->links_ok;  // k_spectrum proper (pair path by chain walk, fused tail)
   bool fuse_imdct = compact && fast && s->setup.block1 <= 2048 && !no_fused_imdct;  // and the LDS-resident path is taken (below)
   bool fuse_gen8 = false;  // k_spectrum_gen8_imdct (below)
+  // ---- slab synthesis kernels (kernels_synth.hip): spectrum + inverse MDCT from per-frame slabs fetched by LDS-DMA ----
+  bool slab_done = false;
+  if (b->slabs_ready && compact && !no_fused_imdct) {
+    NvhSynthArgs A;
+    A.consts = s->shared->synth_consts;
+    A.slabs = (const uint4*)b->slab3.p;
+    A.work = work;
+    A.err = flags;
+    for (int w = 0; w < 2; w++) {
+      A.mdct_a[w] = s->dev.mdct_a[w]; A.mdct_b[w] = s->dev.mdct_b[w]; A.mdct_c[w] = s->dev.mdct_c[w]; A.mdct_tw[w] = s->dev.mdct_tw[w];
+    }
+    A.const_vecs = s->shared->synth_const_vecs;
+    A.stride_vecs = A.cap_vecs = b->slab_stride_vecs;
+    A.channels = ch;
+    A.block1 = s->setup.block1;
+    const bool wide = slab_wide(s);
+    const size_t synth_lds = slab_lds_bytes(b) + (size_t)T.lds_pad;
+    if (synth_lds > 64 * 1024 && !s->ctx->synth_lds_attr_set) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_synth8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      s->ctx->synth_lds_attr_set = true;
+    }
+    if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = the synthesis kernel
+    b->slot_name[0] = "-";
+    b->slot_name[1] = wide ? "k_synth8" : "k_synth";
+    if (wide) hipLaunchKernelGGL(k_synth8, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
+    else hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+    slab_done = true;
+    fuse_gen8 = true;  // the inverse MDCT is inside: no transform kernel behind it
+  }
   // Fused spectrum kernel when a frame's spectrum (+ staged side information) fits the default 64 KB dynamic
   // LDS window; LDS map in kernels_spectrum.hip.
-  {
+  if (!slab_done) {
     const bool has_floor0 = s->has_floor0;
     // more than four channels without Floor0: 8 wavefronts per workgroup (k_spectrum_gen8), one floor scratch block each
     const bool no_gen8 = T.no_gen8;
@@ -562,25 +610,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
                              cap_ent NVH_DBG_LAUNCH);
         } else
 #endif
-        if (fuse_imdct && b->slabs_ready) {
-          // slab synthesis kernel: LDS = constants + the largest slab + spectrum + the IMDCT padding of the last channel
-          NvhSynthArgs A;
-          A.consts = s->shared->synth_consts;
-          A.slabs = (const uint4*)b->slab3.p;
-          A.work = work;
-          A.err = flags;
-          for (int w = 0; w < 2; w++) {
-            A.mdct_a[w] = s->dev.mdct_a[w]; A.mdct_b[w] = s->dev.mdct_b[w]; A.mdct_c[w] = s->dev.mdct_c[w]; A.mdct_tw[w] = s->dev.mdct_tw[w];
-          }
-          A.const_vecs = s->shared->synth_const_vecs;
-          A.stride_vecs = A.cap_vecs = b->slab_stride_vecs;
-          A.channels = ch;
-          A.block1 = s->setup.block1;
-          const size_t synth_lds = ((size_t)A.const_vecs * 4 + (size_t)A.cap_vecs * 4 + (size_t)ch * (size_t)(s->setup.block1 / 2) +
-                                    (size_t)(s->setup.block1 / 16)) * sizeof(float) + lds_pad;
-          b->slot_name[1] = "k_synth";
-          hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
-        } else if (fuse_imdct) {
+        if (fuse_imdct) {
           // + the IMDCT padding of the last channel (n/16 floats past the spectrum area)
           b->slot_name[1] = "k_spectrum_imdct";
           hipLaunchKernelGGL(k_spectrum_imdct, dim3((unsigned)b->nframes), dim3(256), words * 4 + (size_t)(s->setup.block1 / 16) * 4 + lds_pad,

@@ -229,11 +229,12 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
     assert exact > 0.99, exact
 
 
-@pytest.mark.parametrize("toggle", ["NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE"])
+@pytest.mark.parametrize("toggle", ["NVH_NO_SLAB", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE"])
 def test_fallback_kernel_paths_bit_exact(toggle):
     """The library picks kernel variants by stream shape.  Each environment toggle disables one
     level of fusion, so the whole parity suite above is replayed through the general kernels in a child process:
-    NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact,
+    NVH_NO_SLAB -> k_spectrum_imdct / k_spectrum_gen(8)_imdct (descriptors staged by the kernel itself) instead of the slab
+    synthesis kernels k_prepare_slabs + k_synth / k_synth8; NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact,
     NVH_NO_COMPACT -> k_imdct_wave + k_ola_emit; NVH_GPU_PARSE -> packets parsed by k_parse instead of the host parser."""
     import os
     import subprocess
