@@ -195,6 +195,77 @@ struct Passes<LD, 0> {
   static __device__ __forceinline__ void run(float2*, const float*, int) {}
 };
 
+// The same passes with every pass's twiddles in registers one pass ahead of their use (callers with registers to spare: a
+// workgroup whose occupancy is set by LDS, not by VGPRs): the L2 round trip of a pass's table is hidden behind the arithmetic
+// of the pass in front of it instead of standing at its head.  Same loads, same arithmetic, same order as Passes<>.
+template <int LD, int REMAIN>
+struct PassesPF {
+  using G = Geo<LD>;
+  static constexpr int R = REMAIN >= 3 ? 3 : REMAIN;
+  static constexpr int S = 8 << (REMAIN - R);
+  static constexpr int K = 1 << R;
+  static constexpr int NSETS = G::N >> R;
+  static constexpr int ITER = (NSETS + 63) / 64;
+  static constexpr int NTW = 2 * (K - 1);
+  static __device__ __forceinline__ void load(const float* __restrict__ TW, int lane, float (&tw)[ITER * NTW]) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int s = lane + 64 * it;
+      const int sc = s < NSETS ? s : NSETS - 1;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) tw[it * NTW + j] = TW[j * NSETS + sc];
+    }
+  }
+  static __device__ __forceinline__ void compute(float2* __restrict__ l2, const float (&tw)[ITER * NTW], int lane) {
+    constexpr bool ROT_OUT = (REMAIN - R == 0);  // the last pass leaves the rotated layout (phys_rot)
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int s = lane + 64 * it;
+      if (s >= NSETS) continue;
+      const int r = s & (S - 1);
+      const int blk = s / S;
+      const int base = blk * (S << R) + r;
+      float2 v[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) v[k] = l2[phys(base + S * k)];
+#pragma unroll
+      for (int st = R - 1; st >= 0; --st) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (k & (1 << st)) continue;
+          const int lo = k, hi = k | (1 << st);
+          const int pi = (K - (2 << st)) + (k & ((1 << st) - 1));
+          const float a0 = tw[it * NTW + 2 * pi], a1 = tw[it * NTW + 2 * pi + 1];
+          // Mdct.cs:324-329: k00 = e[ee0]-e[ee2] (odd slot), k01 = e[ee0-1]-e[ee2-1] (even slot)
+          const float d1 = v[hi].y - v[lo].y;
+          const float d0 = v[hi].x - v[lo].x;
+          v[hi].y = v[hi].y + v[lo].y;
+          v[hi].x = v[hi].x + v[lo].x;
+          v[lo].y = d1 * a0 - d0 * a1;
+          v[lo].x = d0 * a0 + d1 * a1;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) l2[ROT_OUT ? phys_rot(base + S * k) : phys(base + S * k)] = v[k];
+    }
+  }
+  // tw: this pass's twiddles, already in registers
+  static __device__ __forceinline__ void run(float2* l2, const float* TW, int lane, const float (&tw)[ITER * NTW]) {
+    using Next = PassesPF<LD, REMAIN - R>;
+    const float* TWn = TW + NTW * NSETS;
+    if constexpr (REMAIN - R > 0) {
+      float twn[Next::ITER * Next::NTW];
+      Next::load(TWn, lane, twn);
+      compute(l2, tw, lane);
+      wave_sync();
+      Next::run(l2, TWn, lane, twn);
+    } else {
+      compute(l2, tw, lane);
+      wave_sync();
+    }
+  }
+};
+
 // Full IMDCT of one channel-frame by one wavefront.  X: n/2 spectrum floats (global), out: n floats (global),
 // w: window (n floats) applied on the way out (Mode.cs:160-166).
 // sink(slot, idx, v): receives the 8 float4 output chunks a lane produces per pair index (slot 0..7 is a
@@ -206,7 +277,7 @@ struct Passes<LD, 0> {
 // passes exactly one __syncthreads; those without a transform of their own call it themselves).
 // PRESYNC (with INPLACE): the caller's workgroup barrier in front of the transform (the spectrum is other wavefronts' work too) is
 // taken HERE, after the step-0 twiddle loads have been issued, so that their L2 round trip overlaps the wait.
-template <int LD, bool WIN, typename Sink, bool INPLACE = false, bool WGSYNC = false, bool PRESYNC = false>
+template <int LD, bool WIN, typename Sink, bool INPLACE = false, bool WGSYNC = false, bool PRESYNC = false, bool PF = false>
 __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __restrict__ w, float* lds,
                                                 const float* __restrict__ A, const float* __restrict__ B,
                                                 const float* __restrict__ C, const float* __restrict__ TW, int lane,
@@ -229,6 +300,9 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
     l2[phys(j)] = lo;
   };
   const float2* A2 = reinterpret_cast<const float2*>(A);  // a_lo = A[2j], A[2j+1]; a_hi = A[n2-2-2j], A[n2-1-2j]
+  using PF1 = PassesPF<LD, LD - 5>;
+  float tw_first[PF ? PF1::ITER * PF1::NTW : 1];
+  if constexpr (PF) PF1::load(TW, lane, tw_first);  // in flight across the barrier and step 0
   if constexpr (INPLACE) {
     constexpr int J = (G::n8 + 63) / 64;
     static_assert(J <= (WGSYNC ? 8 : 4), "in-place form keeps the spectrum in registers");
@@ -261,21 +335,31 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
   IMDCT_T(1);
 
   // radix-2 stages D = N/2 ... 8, three per register pass (dbg_skip: profiling builds time the kernel without them)
-  if (!(dbg_skip & 1)) Passes<LD, LD - 5>::run(l2, TW, lane);
+  if constexpr (PF) {
+    PF1::run(l2, TW, lane, tw_first);
+  } else {
+    if (!(dbg_skip & 1)) Passes<LD, LD - 5>::run(l2, TW, lane);
+  }
   IMDCT_T(2);
 
-  // the output stage's tables (_c, _b): with one pair index per lane they are fetched here, a phase ahead of their use
-  constexpr bool kPre = INPLACE && !WGSYNC && (G::n >> 5) <= 64;
-  float4 pcc[2], pbl[2], pbh[2];
+  // the output stage's tables (_c, _b): fetched here, a phase ahead of their use -- with one pair index per lane in the
+  // register-lean form, for every pair index of the lane where registers are plentiful (PF)
+  constexpr bool kPre = (INPLACE && !WGSYNC && (G::n >> 5) <= 64) || PF;
+  constexpr int ITERO = kPre ? (((G::n >> 5) + 63) / 64) : 1;
+  float4 pcc[ITERO][2], pbl[ITERO][2], pbh[ITERO][2];
   if constexpr (kPre) {
-    const int pp = lane < (G::n >> 5) ? lane : (G::n >> 5) - 1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      pcc[h] = reinterpret_cast<const float4*>(C)[2 * pp + h];
-      const int i8 = h == 0 ? pp : (G::n >> 4) - 1 - pp;
-      const int b = G::n2 - 8 - 8 * i8;
-      pbl[h] = *reinterpret_cast<const float4*>(B + b);
-      pbh[h] = *reinterpret_cast<const float4*>(B + b + 4);
+    for (int it = 0; it < ITERO; ++it) {
+      const int pq = lane + 64 * it;
+      const int pp = pq < (G::n >> 5) ? pq : (G::n >> 5) - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        pcc[it][h] = reinterpret_cast<const float4*>(C)[2 * pp + h];
+        const int i8 = h == 0 ? pp : (G::n >> 4) - 1 - pp;
+        const int b = G::n2 - 8 - 8 * i8;
+        pbl[it][h] = *reinterpret_cast<const float4*>(B + b);
+        pbh[it][h] = *reinterpret_cast<const float4*>(B + b + 4);
+      }
     }
   }
   // D = 4, 2, 1
@@ -286,8 +370,10 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
   // steps 4-6 (bit reversal), 7 and 8 fused.  Pair index p covers step-7 iterations 2p and 2p+1, whose
   // results are exactly the inputs of step-8 iterations p and n/16-1-p.
   const float* lf = lds;
-#pragma unroll 1
-  for (int p = lane; p < (G::n >> 5); p += 64) {
+#pragma unroll
+  for (int it = 0; it < (((G::n >> 5) + 63) / 64); ++it) {
+    const int p = lane + 64 * it;
+    if (p >= (G::n >> 5)) continue;
     float vd[8], ve[8];  // v[8p .. 8p+7] and v[n2-8-8p .. n2-1-8p]
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -308,7 +394,7 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       float vE0 = e1.y, vE1 = e1.x, vE2 = e0.y, vE3 = e0.x;  // v[n2-4-4i .. n2-1-4i]
       // step 7 (Mdct.cs:217-258) for iteration i: c = d = 4i, e = n2-4-4i
       float4 cc;
-      if constexpr (kPre) cc = pcc[h]; else cc = reinterpret_cast<const float4*>(C)[i];
+      if constexpr (kPre) cc = pcc[it < ITERO ? it : 0][h]; else cc = reinterpret_cast<const float4*>(C)[i];
       float a02, a11, b0, b1, b2, b3;
       a02 = vD0 - vE2;
       a11 = vD1 + vE3;
@@ -336,8 +422,8 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       const int b = G::n2 - 8 - 8 * i8;
       float4 b_lo, b_hi;  // B[b .. b+3], B[b+4 .. b+7]
       if constexpr (kPre) {
-        b_lo = pbl[h];
-        b_hi = pbh[h];
+        b_lo = pbl[it < ITERO ? it : 0][h];
+        b_hi = pbh[it < ITERO ? it : 0][h];
       } else {
         b_lo = *reinterpret_cast<const float4*>(B + b);
         b_hi = *reinterpret_cast<const float4*>(B + b + 4);
@@ -614,7 +700,7 @@ __device__ __forceinline__ void imdct_wave_fast(const float* X, const float* __r
 // and are rebuilt, windowed, by k_ola_compact.  Halves the bytes this kernel writes and the next one reads.
 // LEAN: the looped form with the spectrum preloaded (fits 64 VGPRs; X may alias the wavefront's LDS slice) instead
 // of the everything-prefetched form (~100 VGPRs): for callers that bring their own occupancy (kernels_spectrum.hip).
-template <int LD, bool WIN, bool COMPACT = false, bool LEAN = false, bool WGSYNC = false, bool PRESYNC = false>
+template <int LD, bool WIN, bool COMPACT = false, bool LEAN = false, bool WGSYNC = false, bool PRESYNC = false, bool PF = false>
 __device__ __forceinline__ void imdct_wave(const float* X, float* out, const float* __restrict__ w, float* lds,
                                            const float* __restrict__ A, const float* __restrict__ B,
                                            const float* __restrict__ C, const float* __restrict__ TW, int lane,
@@ -623,7 +709,7 @@ __device__ __forceinline__ void imdct_wave(const float* X, float* out, const flo
     if (!COMPACT || (slot & 1) == 0) *reinterpret_cast<float4*>(out + idx) = v;
   };
   if constexpr (LEAN)
-    imdct_wave_sink<LD, WIN, decltype(sink), true, WGSYNC, PRESYNC>(X, w, lds, A, B, C, TW, lane, sink, stamp, dbg_skip);
+    imdct_wave_sink<LD, WIN, decltype(sink), true, WGSYNC, PRESYNC, PF>(X, w, lds, A, B, C, TW, lane, sink, stamp, dbg_skip);
   else if constexpr (LD <= 11)
     imdct_wave_fast<LD, WIN>(X, w, lds, A, B, C, TW, lane, sink);
   else

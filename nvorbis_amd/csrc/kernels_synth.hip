@@ -473,6 +473,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   {
     const int v = tid;  // 16-byte unit handled by this lane: wavefront w moves units [64 w, 64 w + 64)
     if (v < A.cap_vecs) dma16(gslab + v, slab + wv * 256);
+    if (MAXCH > 2 && NT + v < A.cap_vecs) dma16(gslab + NT + v, slab + (NT / 64 + wv) * 256);  // big slabs: 16 KB up front
     for (int c0 = wv * 64; c0 < A.const_vecs; c0 += NT)
       if (c0 + lane < A.const_vecs) dma16(A.consts + c0 + lane, smem + c0 * 4);
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -496,8 +497,9 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   const uint32_t* s_chan = reinterpret_cast<const uint32_t*>(slab) + 8;  // per channel: mode | nseg << 8 | off_seg << 16
   const int half = n >> 1;
   if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
-  if (vecs > (unsigned)NT) {  // a slab beyond the speculative piece: fetch the rest
-    for (unsigned c0 = NT + wv * 64; c0 < vecs; c0 += NT)
+  constexpr unsigned kSpec = MAXCH > 2 ? 2 * NT : NT;  // 16-byte units fetched before the header was known
+  if (vecs > kSpec) {  // a slab beyond the speculative piece: fetch the rest
+    for (unsigned c0 = kSpec + wv * 64; c0 < vecs; c0 += NT)
       if (c0 + lane < vecs) dma16(gslab + c0 + lane, slab + c0 * 4);
     __syncthreads();
   }
@@ -631,11 +633,11 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
       float* out = planes + (long long)wv * A.block1;
       float* scratch = smem + wv * (half + (n >> 4));
       switch (n) {
-        case 256: imdct_wave<8, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-        case 512: imdct_wave<9, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-        case 1024: imdct_wave<10, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-        case 2048: imdct_wave<11, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-        case 4096: imdct_wave<12, false, true, true, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 256: imdct_wave<8, false, true, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 512: imdct_wave<9, false, true, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 1024: imdct_wave<10, false, true, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 2048: imdct_wave<11, false, true, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 4096: imdct_wave<12, false, true, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
         default: __builtin_trap();  // host launches this kernel for block sizes up to 4096 only
       }
     }

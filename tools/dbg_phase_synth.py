@@ -8,7 +8,17 @@ import nvorbis_amd as nv
 import bench
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 ctx = nv.Context(0)
-if len(sys.argv) > 1 and sys.argv[1] == "grand":
+nframes, nchan = 4096, 2
+if len(sys.argv) > 1 and sys.argv[1] == "c4":
+    from tests import vorbis_encode as ve
+    hdr3 = ve.shipped_headers(open(os.path.join(root, "tests", "golden", "3test.ogg"), "rb").read())
+    h4 = ve.c4_headers(hdr3, psize=48)
+    S4 = ve.setup_of(h4)
+    pool4 = ve.packet_pool(S4, 148, per_kind=128, class_weights=[0] + [1] * 9)
+    p, _ = ve.stream_from_pool(S4, h4, pool4, np.ones(2100, dtype=bool), np.random.default_rng(7))
+    headers, audio = p[:3], p[3:]
+    nframes, nchan = 2048, 6
+elif len(sys.argv) > 1 and sys.argv[1] == "grand":
     from tests import vorbis_encode as ve
     hdr = ve.shipped_headers(open(os.path.join(root, "tests", "golden", "3test.ogg"), "rb").read())
     S3 = ve.setup_of(hdr)
@@ -17,10 +27,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "grand":
     headers, audio = p[:3], p[3:]
 else:
     headers, audio, ch = bench.ll_packets(nv, os.path.join(root, "tests", "golden", "3test.ogg"))
-st, bl = bench.make_batches(nv, torch, ctx, headers, audio, 2, 4096, 1)
+st, bl = bench.make_batches(nv, torch, ctx, headers, audio, nchan, nframes, 1)
 b, pcm = bl[0]
 print(b.stats())
-dbg = torch.zeros(4096 * 24, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(nframes * 24, dtype=torch.int64, device="cuda")
 L = nv.lib(); L.nvh_debug_set_buffer.argtypes = [ctypes.c_void_p]
 for _ in range(3): b.synth(pcm.data_ptr(), pcm.numel())
 ctx.synchronize()
@@ -29,8 +39,8 @@ b.synth(pcm.data_ptr(), pcm.numel())
 ctx.synchronize(); torch.cuda.synchronize()
 L.nvh_debug_set_buffer(None)
 print(b.kernels())
-d = dbg.cpu().numpy().reshape(4096, 24)
-names = ["DMA round trip + clear + barrier", "header (+ rest of a big slab)", "residue walk + barrier", "floor multiply", "inverse MDCT + store"]
+d = dbg.cpu().numpy().reshape(nframes, 24)
+names = ["DMA round trip + clear + barrier", "header (+ rest of a big slab)", "residue walk", "(coupling +) floor multiply", "inverse MDCT + store"]
 for k in range(5):
     dt = d[:, k + 1] - d[:, k]
     print("%-34s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (names[k], dt.mean(), np.median(dt), np.percentile(dt, 90)))
