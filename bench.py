@@ -187,7 +187,8 @@ def config_lines(nv, torch, ctx, root):
                     "us_per_batch": pass_ms * 1e3, "kernels_us": {names[i]: km[i] * 1e3 for i in live},
                     "algorithmic_bytes_per_batch": alg, "frac_of_hbm_peak_pipeline": alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "frac_of_hbm_peak_dominant_kernel": alg / (km[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                    "descriptor_bytes_per_frame": b.descriptor_bytes / max(b.frames, 1)}
+                    "descriptor_bytes_per_frame": b.descriptor_bytes / max(b.frames, 1),
+                    "prepare_us_per_batch": b.stats().get("prepare_ns", 0) / 1e3}
         b.free()
         st.close()
 
@@ -402,6 +403,9 @@ def main():
                                          "frac": alg_bytes / (km_l3[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                          "whole_pass_frac": alg_bytes / (l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                          "copy_ceiling_GBps": ceiling},
+            # once per upload, outside the timed region: descriptors -> per-frame slabs (integer work only: Floor1 unwrap, segment
+            # lists, chain-major pair records), what the timed kernels then fetch by LDS-DMA
+            "prepare": {"kernels": "k_rank_frames + k_prepare_slabs", "us_per_batch": batch.stats().get("prepare_ns", 0) / 1e3},
             "build": nv.native.build_id(),
         }
         if world == 1 and not args.no_configs:

@@ -257,7 +257,7 @@ int nvh_batch_upload(nvh_stream *s, nvh_batch **out);
 int nvh_batch_info(const nvh_batch *b, int *frames, int *chan_frames, int64_t *pcm_samples_per_channel,
                    int64_t *descriptor_bytes);
 /* Descriptor element counts: frames, channel-frames, residue passes, residue ops, VQ entries, floor1 posts,
- * floor0 coefficients, reserved. */
+ * floor0 coefficients, nanoseconds the descriptor -> slab conversion of this upload took on the GPU (0: none). */
 int nvh_batch_stats(const nvh_batch *b, int64_t *out8);
 /* Names of the kernels behind the four timing slots of nvh_batch_time, as launched last (comma separated,
  * "-" = empty slot): which of the kernel variants ran depends on the stream shape. */
