@@ -87,6 +87,9 @@ namespace NVorbis.Hip
             vendor = ReadString();
             if (pos + 4 > p.Length) throw new System.IO.InvalidDataException("Could not read full string!");
             int n = BitConverter.ToInt32(p, pos); pos += 4;
+            // every comment needs at least its 4-byte length: an untrusted count beyond that (or negative) is a broken header,
+            // not an OverflowException / a gigabyte allocation
+            if (n < 0 || (long)n * 4 > p.Length - pos) throw new System.IO.InvalidDataException("Could not read full string!");
             comments = new string[n];
             for (int i = 0; i < n; i++) comments[i] = ReadString();
         }
