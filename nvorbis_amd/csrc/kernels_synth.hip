@@ -254,11 +254,16 @@ k_rank_frames(NvhDevBatch Bt, uint32_t* __restrict__ rank, int identity) {
 
 // ---- integer side: descriptors -> slabs, one wavefront per frame, once per batch -----------------------------------------
 extern "C" __global__ void __launch_bounds__(64)
-k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int stride_vecs, const uint32_t* __restrict__ rank) {
+k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int stride_vecs, const uint32_t* __restrict__ rank,
+                int cap_ops) {
+  // dynamic LDS: the frame's vector writes (8 B each), their links (2 B each) and the codebook directory, fetched in one
+  // coalesced round trip: walking the chains (link -> link -> link, op -> book) through global memory is six to eight
+  // dependent L2 / HBM round trips per frame
+  extern __shared__ __attribute__((aligned(16))) uint4 s_stage[];
   __shared__ __attribute__((aligned(16))) FloorScratch Q;
   __shared__ int s_err;
   const int f = blockIdx.x, lane = threadIdx.x, nch = S.channels;
-  uint4* slab = slabs + (long long)rank[f] * stride_vecs;  // launch order: k_rank_frames
+  uint4* slab = slabs + (long long)(rank ? rank[f] : (uint32_t)f) * stride_vecs;  // frame order, or k_rank_frames' launch order
   const NvhFrame fr = Bt.frames[f];
   NvhSlabHdr H;
   H.n = 0; H.exec_mask = 0; H.flags = 0; H.nheads = 0; H.nrec = 0;
@@ -340,8 +345,21 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
       H.lpc_magic = lpc > 1 ? (uint32_t)((0x100000000ull + lpc - 1) / lpc) : 0u;
     }
     const int nops = (int)fr.op_count;
-    const NvhResOp* ops = Bt.ops + fr.op_begin;
-    const uint16_t* links = Bt.op_link + fr.op_begin;
+    NvhResOp* ops = reinterpret_cast<NvhResOp*>(s_stage);
+    uint16_t* links = reinterpret_cast<uint16_t*>(ops + cap_ops);
+    NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(links + ((cap_ops + 7) & ~7));
+    if (nops > cap_ops) __builtin_trap();  // host: the batch's largest frame
+    {
+      const uint2* go = reinterpret_cast<const uint2*>(Bt.ops + fr.op_begin);
+      const uint16_t* gl = Bt.op_link + fr.op_begin;
+      for (int i = lane; i < nops; i += 64) {
+        reinterpret_cast<uint2*>(ops)[i] = go[i];
+        links[i] = gl[i];
+      }
+      const uint4* gb = reinterpret_cast<const uint4*>(S.books);
+      for (int i = lane; i < S.nbooks * 2; i += 64) reinterpret_cast<uint4*>(s_books)[i] = gb[i];
+      sp_wave_sync();
+    }
     // pass A: how many chains
     int nheads = 0;
     for (int base = 0; base < nops; base += 64) {
@@ -375,7 +393,7 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
         int q = o;
         for (unsigned k = 0; k < len; ++k) {
           const NvhResOp op = ops[q];
-          const NvhDevBook bk = S.books[op.book];
+          const NvhDevBook bk = s_books[op.book];
           const unsigned offset = rbegin + (unsigned)op.partition * psz;
           const unsigned xbase = (rtype == 2 && rch > 1) ? __umulhi(offset, rch_magic) : offset;
           uint4 rec;

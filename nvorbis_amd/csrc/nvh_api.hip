@@ -17,7 +17,7 @@ const NvhToggles& nvh_toggles() {
     x.unfused = on("NVH_UNFUSED");
     x.no_pair = on("NVH_NO_PAIR");
     x.no_slab = on("NVH_NO_SLAB");
-    x.no_lpt = on("NVH_NO_LPT");
+    x.lpt = on("NVH_LPT");
     x.no_ola_sym = on("NVH_NO_OLA_SYM");
     x.debug_occ = on("NVH_DEBUG_OCC");
     x.gpu_parse_default = on("NVH_GPU_PARSE");

@@ -63,7 +63,7 @@ __global__ void k_run4_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArg
 __global__ void k_run6_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 #endif
-__global__ void k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* slabs, int stride_vecs, const uint32_t* rank);
+__global__ void k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* slabs, int stride_vecs, const uint32_t* rank, int cap_ops);
 __global__ void k_rank_frames(NvhDevBatch Bt, uint32_t* rank, int identity);
 __global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_synth8(NvhSynthArgs A NVH_DBG_PARAMS);
@@ -119,7 +119,7 @@ static inline void nvh_guard_void(F&& body) noexcept {
 struct NvhToggles {
   bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
   bool no_ola_sym;  // NVH_NO_OLA_SYM: k_ola_compact without its read-once steady-state path (test / A-B aid)
-  bool no_lpt;    // NVH_NO_LPT: slabs in frame order instead of costliest-first (A-B aid)
+  bool lpt;       // NVH_LPT: slabs in costliest-first launch order (k_rank_frames) instead of frame order
   bool no_slab;   // NVH_NO_SLAB: k_spectrum_imdct instead of k_prepare_slabs + k_synth (test / A-B aid)
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
   bool run;       // NVH_RUN: the run kernel (kernels_run.hip) instead of k_spectrum_imdct + k_ola_compact -- opt-in, it measured slower
