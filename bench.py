@@ -239,6 +239,12 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Development aid (the builder has no multi-GPU box): NVH_BENCH_SHARE_GPU=1 puts every rank on device 0 and rendezvouses
+    # over gloo, so that the N > 1 code path -- barriers, MAX over ranks, rank-0 reporting -- can be exercised on one GPU.
+    # The line it prints says so in `data`; it is not a scaling measurement.
+    share_gpu = bool(os.environ.get("NVH_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU path to measure")
@@ -249,7 +255,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     headers, ll, ch = ll_packets(nv, os.path.join(ROOT, "tests", "golden", "3test.ogg"))
     assert ch == 2 and len(ll) > 0
@@ -382,7 +391,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (3test.ogg long/long packets tiled to %d resident batches of 4096 frames per GPU)" % (nin * reps),
+            "data": "synthetic (3test.ogg long/long packets tiled to %d resident batches of 4096 frames per GPU)" % (nin * reps) +
+                    (" -- NVH_BENCH_SHARE_GPU: all %d ranks on ONE GPU over gloo, a code-path check, not a scaling number" % world if share_gpu else ""),
             "config": {"workload": "C2: 4096 stereo long-block (n=2048) frames, Floor1+Residue2+coupling, IMDCT+window+OLA",
                        "frames_per_gpu": FRAMES, "channels": ch, "block": BLOCK,
                        "parallelism": "frame-parallel x%d, %d HIP streams per GPU x %d resident batches each" % (world, nin, reps),

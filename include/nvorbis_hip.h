@@ -231,8 +231,10 @@ int nvh_stream_synth(nvh_stream *s, float *pcm_host, float *d_pcm, int64_t capac
 /* Pipelined form for a destination in page-locked host memory (nvh_pinned_alloc): nvh_stream_synth_begin queues the upload, the
  * synthesis and -- on a copy stream of its own -- the transfer of the PCM and returns (*expected = floats the batch will
  * deliver); nvh_stream_synth_end waits for the OLDEST outstanding batch and reports what nvh_stream_synth would have (error
- * codes, *written, nvh_stream_parse_errors).  Up to two batches may be outstanding, so the transfer of one overlaps the pushes,
- * the parse and the kernels of the next; each needs its own destination buffer until its end call returns.  No counterpart in the
+ * codes, *written, nvh_stream_parse_errors).  Up to two batches may be outstanding: the PCIe transfer of batch i overlaps the
+ * upload, the parse and the kernels of batch i+1 (begin itself first waits for the kernels of the batch before it -- both flights
+ * share one scratch batch -- so what overlaps batch i's kernels is the pushing of batch i+1, which happens before its begin);
+ * each needs its own destination buffer until its end call returns.  No counterpart in the
  * reference (its Read is synchronous); nvh_stream_synth must not be mixed in while batches are outstanding (NVH_ERR_ARGUMENT). */
 int nvh_stream_synth_begin(nvh_stream *s, float *pcm_host, int64_t capacity, int64_t *expected);
 int nvh_stream_synth_end(nvh_stream *s, int64_t *written);
