@@ -140,10 +140,13 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
     if (interleaved) {
       // a[2m] / a[2m + 1] = bin xb + m of channel 0 / 1
       const unsigned xb = xbase + (i0 >> 1);
-      if (sweep_couples) {  // Mapping.cs:137-182 on the pair a lane holds anyway
+      if (sweep_couples) {  // Mapping.cs:137-182 on the pair a lane holds anyway (one uniform branch, not one per bin)
+        if (!mg1) {
 #pragma unroll
-        for (int m = 0; m < G / 2; ++m) {
-          if (!mg1) couple1(a[2 * m], a[2 * m + 1]); else couple1(a[2 * m + 1], a[2 * m]);
+          for (int m = 0; m < G / 2; ++m) couple1(a[2 * m], a[2 * m + 1]);
+        } else {
+#pragma unroll
+          for (int m = 0; m < G / 2; ++m) couple1(a[2 * m + 1], a[2 * m]);
         }
       }
       float* p0 = spec + xb;
