@@ -19,6 +19,7 @@ const NvhToggles& nvh_toggles() {
     x.no_slab = on("NVH_NO_SLAB");
     x.lpt = on("NVH_LPT");
     x.no_ola_sym = on("NVH_NO_OLA_SYM");
+    x.slab_stream = on("NVH_SLAB_STREAM");
     x.debug_occ = on("NVH_DEBUG_OCC");
     x.gpu_parse_default = on("NVH_GPU_PARSE");
     x.lds_pad = num("NVH_LDS_PAD");

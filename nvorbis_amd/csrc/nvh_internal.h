@@ -118,6 +118,7 @@ static inline void nvh_guard_void(F&& body) noexcept {
 // Test / experiment switches from the environment, read once per process (before the first context exists).
 struct NvhToggles {
   bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
+  bool slab_stream; // NVH_SLAB_STREAM: streaming (one-shot) batches take the slab synthesis kernels too (default: resident batches only)
   bool no_ola_sym;  // NVH_NO_OLA_SYM: k_ola_compact without its read-once steady-state path (test / A-B aid)
   bool lpt;       // NVH_LPT: slabs in costliest-first launch order (k_rank_frames) instead of frame order
   bool no_slab;   // NVH_NO_SLAB: k_spectrum_imdct instead of k_prepare_slabs + k_synth (test / A-B aid)

@@ -331,6 +331,12 @@ static bool slab_path(const nvh_batch* b) {
   const NvhToggles& T = nvh_toggles();
   if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->max_pass > 1) return false;
   if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact) return false;
+  // The descriptor -> slab conversion (k_prepare_slabs, 31 us per 4096 stereo frames) pays when a batch is synthesised more
+  // than once: resident batches (nvh_batch_upload).  A streaming batch (the stream's scratch batch: uploaded, synthesised
+  // once, gone) is cheaper through the classic kernels, which do the same integer work inline: 35.6 us against 31 + 25 for
+  // 4096 frames, and one launch fewer per small batch (file-parallel transcode of short files: 3450 against 3100 files/s).
+  // NVH_SLAB_STREAM=1 sends streaming batches through the slabs as well (the parity suite replays itself that way).
+  if (b == &s->scratch && !T.slab_stream) return false;
   if (slab_wide(s) && T.no_gen8) return false;  // NVH_NO_GEN8 keeps its meaning: more than four channels through k_spectrum_gen
   if (slab_bound_vecs(b) > 0xFFFFu) return false;
   return slab_lds_bytes(b) + (size_t)T.lds_pad <= (slab_wide(s) ? (size_t)160 * 1024 - 1024 : (size_t)64 * 1024);

@@ -4,6 +4,7 @@ Markov chain with random transition rates, random look-ahead batch sizes (1 ... 
 packet parser, plus the four shipped files with random batch sizes; every PCM must equal the oracle's bit for bit.
   python tools/stress_slab.py [seconds]"""
 import os, sys, time
+os.environ["NVH_SLAB_STREAM"] = "1"  # streaming batches through the slab kernels (by default they serve resident batches only)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import nvorbis_amd as nv
