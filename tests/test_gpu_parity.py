@@ -229,7 +229,8 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
     assert exact > 0.99, exact
 
 
-@pytest.mark.parametrize("toggle", ["NVH_SLAB_STREAM", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE"])
+@pytest.mark.parametrize("toggle", ["NVH_SLAB_STREAM", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
+                                    "NVH_SLAB_STREAM+NVH_GPU_PARSE"])
 def test_fallback_kernel_paths_bit_exact(toggle):
     """The library picks kernel variants by stream shape.  Each environment toggle disables one
     level of fusion, so the whole parity suite above is replayed through the general kernels in a child process:
@@ -244,7 +245,8 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     if os.environ.get("NVH_TEST_CHILD"):
         pytest.skip("already inside a fallback-path run")
     env = dict(os.environ)
-    env[toggle] = "1"
+    for t in toggle.split("+"):  # "A+B": both switches (slab kernels fed by the GPU packet parser)
+        env[t] = "1"
     env["NVH_TEST_CHILD"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = [os.path.join(root, "tests", "test_gpu_parity.py")]
