@@ -415,7 +415,7 @@ def main():
                          "copy_ceiling_GBps": ceiling},
             # once per upload, outside the timed region: descriptors -> per-frame slabs (integer work only: Floor1 unwrap, segment
             # lists, chain-major pair records), what the timed kernels then fetch by LDS-DMA
-            "prepare": {"kernels": "k_prepare_slabs", "us_per_batch": batches0[-1][0].stats().get("prepare_ns", 0) / 1e3}  # a later upload: the first one pays the code load,
+            "prepare": {"kernels": "k_prepare_slabs", "us_per_batch": batches0[-1][0].stats().get("prepare_ns", 0) / 1e3},  # a later upload: the first pays the code load
             "build": nv.native.build_id(),
         }
         if world == 1 and not args.no_configs:
