@@ -215,8 +215,10 @@ def test_synthetic_configs_bit_exact(oracle, gpu_ctx, name, consistent):
 
 
 def test_floor0_within_tolerance(oracle, gpu_ctx):
-    """Floor0 evaluates cos / sqrt / exp in double precision (Floor0.cs:167,198,201); the GPU uses the device
-    math library, the oracle glibc, so parity is the stated 1e-6 absolute rather than bit-exact."""
+    """Floor0 evaluates cos / sqrt / exp in double precision (Floor0.cs:167,198,201); the GPU uses the device math library
+    (ocml), the oracle glibc.  Nothing guarantees that the two agree in the last bit of a double, but after the cast to float
+    they do -- tools/ubench/f0_math.hip: 0 of 4.2 M arguments differ for each of the three functions on MI355X -- so the
+    stream is asserted bit-exact like every other (the 1e-6 bound of the north star first, for a readable failure)."""
     import nvorbis_amd as nv
     from tests import synth_stream as ss
     pk, gr, fl = ss.filtered_stream(oracle, "floor0_stereo", 200, 5)
@@ -225,8 +227,7 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
     assert got.size == ref.size
     assert np.isfinite(got).all()
     assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) <= 1e-6
-    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
-    assert exact > 0.99, exact
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), float((got.view(np.uint32) == ref.view(np.uint32)).mean())
 
 
 @pytest.mark.parametrize("toggle", ["NVH_SLAB_STREAM", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
@@ -751,8 +752,8 @@ def test_window_overlap_copy_operators(oracle, gpu_ctx, ogg_bytes, name):
 
 def test_floor0_apply_operator(oracle, gpu_ctx):
     """Fine-grained ABI: IFloor.Apply for Floor0 (Floor0.cs:152-212) on random LSP coefficients; double-precision
-    cos/sqrt/exp rounded to float on both sides: almost every value identical, the rest within the last-ulp differences
-    of the two math libraries (a 1-ulp coefficient moves the exponent's argument); empty floors cleared."""
+    cos/sqrt/exp rounded to float on both sides (device ocml, host glibc): identical bit for bit on this device (see
+    test_floor0_within_tolerance); empty floors cleared."""
     import ctypes as C
     import nvorbis_amd as nv
     from tests import synth_stream as ss
@@ -798,7 +799,7 @@ def test_floor0_apply_operator(oracle, gpu_ctx):
                     exact += int((got[b].view(np.uint32) == r.view(np.uint32)).sum())
                     total += half
                     done += 1
-                assert exact >= 0.95 * total, (exact, total)
+                assert exact == total, (exact, total)
         assert done > 40
     finally:
         st.close()
