@@ -25,12 +25,20 @@ ap.add_argument("--synthetic", action="store_true")
 ap.add_argument("--scale", type=float, default=0.05, help="length scale of the synthetic corpus (1.0 = 5-300 s per file)")
 a = ap.parse_args()
 rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+# development aid (no multi-GPU box at hand): NVH_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses gloo, so that the
+# shard + device-to-device gather code path runs with world > 1 on one GPU; not a scaling measurement
+share_gpu = bool(os.environ.get("NVH_BENCH_SHARE_GPU"))
+if share_gpu:
+    local = 0
 torch.cuda.set_device(local)
 dist = None
 if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if share_gpu:
+        dist.init_process_group(backend="gloo")
+    else:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if a.dir:
     names = sorted(glob.glob(os.path.join(a.dir, "*.ogg")))
