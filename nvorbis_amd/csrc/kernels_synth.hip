@@ -1,5 +1,7 @@
-// kernels_synth.hip -- the slab synthesis kernel (round 3): residue adds + inverse coupling + Floor1 multiply + inverse MDCT
-// of one frame per workgroup, fed by ONE LDS-DMA round trip.
+// kernels_synth.hip -- the slab synthesis kernels (round 3): residue adds + inverse coupling + Floor1 multiply + inverse MDCT
+// of one frame per workgroup, fed by ONE LDS-DMA round trip.  k_synth: mono / stereo, blocks up to 2048; k_synth8: up to eight
+// channels, blocks up to 4096; k_prepare_slabs: the integer side, once per upload.  They serve resident batches
+// (nvh_batch_upload); a streaming batch, synthesised once, keeps k_spectrum_imdct (nvh_launch.hip: slab_path says why).
 //
 //   Array.Clear + IResidue.Decode adds   Mapping.cs:108,133; Residue1.cs:8-26, Residue2.cs:23-47
 //   inverse square-polar coupling         Mapping.cs:137-182
@@ -8,8 +10,8 @@
 //   (integer side, k_prepare_slabs)       Floor1.UnwrapPosts :224-297, the sorted / flagged post walk :196-216,
 //                                         the (stage, partition, channel) geometry of Residue0.cs:157-170, Residue2.cs:23-47
 //
-// Why a second form of k_spectrum_imdct (kernels_spectrum.hip), same arithmetic, same stream shapes (<= 2 channels, Floor1,
-// lattice books, <= 1 coupling step, blocks 256..2048, one residue pass per frame): that kernel's workgroup spent 10.8 k of its
+// Why a second form of k_spectrum_imdct (kernels_spectrum.hip), same arithmetic (stream shapes: Floor1, lattice books of even
+// dimension, no aliasing partitions, one residue pass per frame, <= 8 channels, blocks 256..4096): that kernel's workgroup spent 10.8 k of its
 // 29.8 k cycles before its first useful instruction -- frame record, then the slices the record points to, then the setup
 // records those point to (three dependent global round trips), then copies of all of it into LDS through registers, pair
 // records, chain-head compaction, and the Floor1 unwrap (a chain of dependent LDS round trips on two otherwise idle
@@ -20,10 +22,10 @@
 //     stream constants (inverse_dB_table + lattice pool) before it knows anything about the frame, clears the spectrum
 //     while they fly, and passes one barrier: ONE memory round trip, no staging instructions, no VGPR round trip;
 //   * the header then comes out of LDS; only frames whose slab exceeds 4 KB fetch the rest (second round trip);
-//   * the residue walk follows chain-major records (one ds_read_b128 per cascade stage, no link array), the floor multiply
-//     reads the segment list straight from the slab.
-// From the floor multiply on the kernel is k_spectrum_imdct's: same fused tail, same in-place wavefront IMDCT, same compact
-// output for k_ola_compact.  Bit-exactness: the additions of a partition happen in stage order inside the owning lane,
+//   * the residue walk follows chain-major records (one ds_read_b128 per cascade stage, no link array); a lane owns eight
+//     consecutive vector components of a chain through all cascade stages and, for mono / stereo, multiplies them by the floor
+//     curve (segment list and per-four-bins segment table straight from the slab) before its one store.
+// The transform is k_spectrum_imdct's (imdct_wave.h), the output the compact form k_ola_compact reads.  Bit-exactness: the additions of a partition happen in stage order inside the owning lane,
 // every float expression is one rounded operation (-ffp-contract=off).
 #include <hip/hip_runtime.h>
 
