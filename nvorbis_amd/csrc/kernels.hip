@@ -789,6 +789,64 @@ __device__ __forceinline__ int ola_sym(const NvhDevSetup& S, const NvhFrame& fr,
   return clipped;
 }
 
+// ola_sym for more than two channels: the same arithmetic, the work split per (group, channel) -- CH times the lanes of
+// ola_sym, each with two 16-byte loads in flight instead of 2 CH, ~30 instead of ~100 registers -- and the interleave done
+// through LDS: a lane's eight results go to channel-planar rows of the workgroup's two runs of sample times (the forward run
+// [4 g0, 4 g0 + 4 GW) and the mirrored run [n/2 - 4 (g0 + GW), n/2 - 4 g0)), and after one barrier the runs leave as whole
+// 16-byte vectors of interleaved, clipped PCM.  Workgroup blockIdx.y owns groups [GW y, GW y + GW).
+template <int CH>
+__device__ __forceinline__ int ola_sym_lds(const NvhDevSetup& S, const NvhFrame& fr, const float* cur, const float* prev,
+                                           const float* __restrict__ w, const float* __restrict__ wp, float* out, int clip,
+                                           float* s_run /* [2][CH][4 * NVH_OLA_GW] */) {
+  constexpr int GW = NVH_OLA_GW, RUN = 4 * GW;
+  const int n = fr.n, n2 = n >> 1;
+  const int groups = n >> 4;
+  const int g0 = (int)blockIdx.y * GW;
+  if (g0 >= groups) return 0;
+  const int gw = groups - g0 < GW ? groups - g0 : GW;  // groups of this workgroup (a short block has fewer than GW)
+  float* sF = s_run;
+  float* sM = s_run + CH * RUN;
+  for (int task = threadIdx.x; task < gw * CH; task += blockDim.x) {
+    const int c = task / gw, gl = task - c * gw;
+    const int i0 = 4 * (g0 + gl);
+    const float4 wf = *reinterpret_cast<const float4*>(w + i0);
+    const float4 wm = *reinterpret_cast<const float4*>(w + (n2 - 4 - i0));
+    const float4 pf = *reinterpret_cast<const float4*>(wp + (n2 + i0));
+    const float4 pm = *reinterpret_cast<const float4*>(wp + (n - 4 - i0));
+    const float4 a = *reinterpret_cast<const float4*>(cur + (long long)c * S.block1 + i0);
+    const float4 b = *reinterpret_cast<const float4*>(prev + (long long)c * S.block1 + n2 + i0);
+    float4 v = make_float4(a.x * wf.x, a.y * wf.y, a.z * wf.z, a.w * wf.w);
+    const float4 t = make_float4(b.x * pf.x, b.y * pf.y, b.z * pf.z, b.w * pf.w);
+    v.x = v.x + t.x; v.y = v.y + t.y; v.z = v.z + t.z; v.w = v.w + t.w;
+    float4 u = make_float4(-a.w * wm.x, -a.z * wm.y, -a.y * wm.z, -a.x * wm.w);
+    const float4 r = make_float4(b.w * pm.x, b.z * pm.y, b.y * pm.z, b.x * pm.w);
+    u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
+    *reinterpret_cast<float4*>(sF + c * RUN + 4 * gl) = v;              // sample times 4 g0 + 4 gl ..
+    *reinterpret_cast<float4*>(sM + c * RUN + 4 * (gw - 1 - gl)) = u;   // sample times n/2 - 4 (g0 + gw) + 4 (gw - 1 - gl) ..
+  }
+  __syncthreads();
+  int clipped = 0;
+  const int nvec = gw * CH;  // 16-byte vectors per run: 4 gw sample times x CH channels
+  float4* oF = reinterpret_cast<float4*>(out + (long long)(4 * g0) * CH);
+  float4* oM = reinterpret_cast<float4*>(out + (long long)(n2 - 4 * (g0 + gw)) * CH);
+  for (int j = threadIdx.x; j < 2 * nvec; j += blockDim.x) {
+    const bool mir = j >= nvec;
+    const int jj = mir ? j - nvec : j;
+    const float* sr = mir ? sM : sF;
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = 4 * jj + k;      // position in the run's interleaved floats
+      const int tt = idx / CH, c = idx - tt * CH;
+      float x = sr[c * RUN + tt];
+      if (clip) x = clip_value(x, &clipped);
+      e[k] = x;
+    }
+    (mir ? oM : oF)[jj] = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  return clipped;
+}
+
 // A frame may be shared by gridDim.y workgroups (large frames: six channels at n = 4096 are 48 KB of PCM, and 128 lanes
 // per frame leave the CUs with four wavefronts each): lane `OLA_TID` of `NVH_OLA_THREADS`.
 #define NVH_OLA_THREADS ((int)(blockDim.x * gridDim.y))
@@ -832,6 +890,21 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
   const bool sym = vec && prev && !prev_full && fr.ov_n == fr.n && fr.start == 0 && fr.emit_start == 0 && fr.emit_count == (fr.n >> 1) &&
                    fr.ov_src == (fr.n >> 1) && fr.ov_len == (fr.n >> 1) && (fr.exec_mask & all_ch) == all_ch &&
                    (fr.ov_exec_mask & all_ch) == all_ch && !nosym;
+  if (sym && ch > 2 && gridDim.y * NVH_OLA_GW >= (unsigned)(fr.n >> 4)) {
+    // more than two channels: per-(group, channel) lanes, interleave through LDS (the launch gives every frame gridDim.y
+    // workgroups of NVH_OLA_GW groups each: nvh_launch.hip)
+    __shared__ __attribute__((aligned(16))) float s_run[2 * 8 * 4 * NVH_OLA_GW];
+    switch (ch) {
+      case 3: clipped = ola_sym_lds<3>(S, fr, cur, prev, w, wp, out, clip, s_run); break;
+      case 4: clipped = ola_sym_lds<4>(S, fr, cur, prev, w, wp, out, clip, s_run); break;
+      case 5: clipped = ola_sym_lds<5>(S, fr, cur, prev, w, wp, out, clip, s_run); break;
+      case 6: clipped = ola_sym_lds<6>(S, fr, cur, prev, w, wp, out, clip, s_run); break;
+      case 7: clipped = ola_sym_lds<7>(S, fr, cur, prev, w, wp, out, clip, s_run); break;
+      default: clipped = ola_sym_lds<8>(S, fr, cur, prev, w, wp, out, clip, s_run); break;
+    }
+    report_clipped(clipped, clipped_flag);
+    return;
+  }
   if (sym) {
     switch (ch) {
       case 1: clipped = ola_sym<1>(S, fr, cur, prev, w, wp, out, clip, NVH_OLA_TID, NVH_OLA_THREADS); break;

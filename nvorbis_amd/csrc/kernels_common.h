@@ -78,6 +78,9 @@ struct NvhRunArgs {
 };
 
 // Arguments of the slab synthesis kernel (kernels_synth.hip).
+// groups of four sample times per workgroup of k_ola_compact's LDS-interleaving path (more than two channels)
+#define NVH_OLA_GW 64
+
 struct NvhSynthArgs {
   const uint4* consts;      // inverse_dB_table (256 floats) followed by the lattice pool, const_vecs 16-byte units
   const uint4* slabs;       // nframes slabs at stride_vecs

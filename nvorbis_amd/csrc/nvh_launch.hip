@@ -683,6 +683,9 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       if (segs > 8) segs = 8;
       if (segs > (s->setup.block1 / 8) / ola_threads) segs = (s->setup.block1 / 8) / ola_threads;
       if (segs < 1) segs = 1;
+      // more than two channels: the steady-state path splits a frame into runs of NVH_OLA_GW groups of four sample times, one
+      // workgroup each, and interleaves through LDS (ola_sym_lds)
+      if (ch > 2 && !T.no_ola_sym && T.ola_segs <= 0) segs = ((s->setup.block1 / 16) + NVH_OLA_GW - 1) / NVH_OLA_GW;
       hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
                          (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded, T.no_ola_sym ? 1 : 0);
     } else if (!b->sequential_ola)

@@ -214,6 +214,22 @@ def test_synthetic_configs_bit_exact(oracle, gpu_ctx, name, consistent):
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, clip, bf, float(np.abs(got - ref).max()))
 
 
+@pytest.mark.parametrize("name", ["ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"])
+def test_channel_counts_4_5_7_8_bit_exact(oracle, gpu_ctx, name):
+    """Every channel count has its own instantiation of the overlap-add kernels (ola_vec / ola_sym_lds<CH>) and of the
+    eight-channel synthesis kernel's coupling and floor loops; 1, 2, 3 and 6 channels come with the configs above, these
+    are the other four -- streaming (classic kernels) and resident (slab kernels, NVH_SLAB_STREAM replay below)."""
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    pk, gr, fl = ss.filtered_stream(oracle, name, 120, 23)
+    for clip in (True, False):
+        ref, info = oracle.decode_packets(pk, gr, fl, clip=clip)
+        for bf in (1024, 13):
+            got = _decode_gpu(nv, gpu_ctx, pk, gr, fl, clip, bf)
+            assert got.size == ref.size, (name, clip, bf)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, clip, bf, float(np.abs(got - ref).max()))
+
+
 def test_floor0_within_tolerance(oracle, gpu_ctx):
     """Floor0 evaluates cos / sqrt / exp in double precision (Floor0.cs:167,198,201); the GPU uses the device math library
     (ocml), the oracle glibc.  Nothing guarantees that the two agree in the last bit of a double, but after the cast to float
