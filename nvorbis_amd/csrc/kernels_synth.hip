@@ -58,12 +58,42 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
 // stage's vector list as component i % dim; the entry's components are the base-lat_values digits of the entry number,
 // peeled two at a time with exact reciprocal multiplies (consecutive pairs of one entry continue from the previous quotient).
 struct FloorRef {  // the frame's floor curves as they lie in the slab (both channels), for the fused multiply
-  const FloorSeg* seg[2];
-  const uint32_t* magic[2];
+  const uint4* seg[2];
   const uint8_t* tab[2];
   int md[2];
   const float* s_db;
 };
+
+// One line segment of a rendered Floor1 curve as the slab holds it: x = x0 | xend << 16, y = the curve at x0, (w:z) = the
+// curve's step per bin as a signed 32.32 fixed-point number.  Floor1.cs:316-340 draws y(x0 + k) = y0 + k b + sy floor(k r / adx)
+// (b = dy / adx truncated, r = |dy| mod adx, sy = sign dy) with an error-term recurrence; k_prepare_slabs stores
+// F = |b| 2^32 + ceil(2^32 r / adx), negated for a falling line, and the walk keeps (y : fraction) in one 64-bit register that
+// it adds the step to: the carry out of the fraction is the recurrence's "err >= adx".  Exact: the fraction overestimates
+// k r / adx by less than k 2^-32 <= 2^-19, and k r / adx is either an integer or at least 1 / adx >= 2^-13 below the next one.
+// A falling line starts its fraction at 2^32 - 1, so that the borrow comes exactly where the rising line's carry would.
+template <int NB>
+__device__ __forceinline__ void floor_walk_fx(const uint4* __restrict__ seg, const uint8_t* __restrict__ segtab,
+                                              const float* __restrict__ s_db, int x0, float m[NB]) {
+  int sg = segtab[x0 >> 2];  // the last segment that starts at or before x0 (k_prepare_slabs)
+  uint4 s = seg[sg];
+  unsigned long long step = ((unsigned long long)s.w << 32) | s.z;
+  const unsigned t = (unsigned)x0 - (s.x & 0xFFFFu);
+  unsigned long long st = (((unsigned long long)s.y << 32) | (unsigned)((int)s.w >> 31)) + step * t;
+  int xend = (int)(s.x >> 16);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    // the next segment starts exactly here; the last segment ends at or beyond n/2, so x < n/2 never runs off the list
+    if (x0 + q >= xend) {
+      s = seg[++sg];
+      step = ((unsigned long long)s.w << 32) | s.z;
+      st = ((unsigned long long)s.y << 32) | (unsigned)((int)s.w >> 31);
+      xend = (int)(s.x >> 16);
+    }
+    const int y = (int)(st >> 32);
+    m[q] = s_db[y < 0 ? 0 : (y > 255 ? 255 : y)];  // out-of-range values were reported by floor_prepare (quirk B-7)
+    st += step;
+  }
+}
 
 // FUSE: the floor multiply (Floor1.cs:196-222) happens here, on the registers that hold a chain's finished sums, and only
 // for bins some chain covers: every other bin of the cleared spectrum stays +0.0f, which is what 0 * curve gives anyway.
@@ -159,7 +189,7 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
           for (int c = 0; c < 2; ++c) {
             if (F->md[c] == 1) {
               float m[4];
-              floor_walk_seg<4>(F->seg[c], F->magic[c], 0, F->s_db, (int)xb, m, F->tab[c]);
+              floor_walk_fx<4>(F->seg[c], F->tab[c], F->s_db, (int)xb, m);
 #pragma unroll
               for (int q = 0; q < 4; ++q) a[2 * q + c] = a[2 * q + c] * m[q];
             } else if (F->md[c] == 2) {
@@ -192,7 +222,7 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
           const int md = c1 ? F->md[1] : F->md[0];
           if (md == 1) {
             float m[8];
-            floor_walk_seg<8>(c1 ? F->seg[1] : F->seg[0], c1 ? F->magic[1] : F->magic[0], 0, F->s_db, (int)xb, m, c1 ? F->tab[1] : F->tab[0]);
+            floor_walk_fx<8>(c1 ? F->seg[1] : F->seg[0], c1 ? F->tab[1] : F->tab[0], F->s_db, (int)xb, m);
 #pragma unroll
             for (int q = 0; q < 8; ++q) a[q % G] = a[q % G] * m[q];
           } else if (md == 2) {
@@ -301,10 +331,18 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
     const int ns = mode == 1 ? Q.nseg : 0;
     H.chan[c] = (uint32_t)mode | ((uint32_t)ns << 8) | ((uint32_t)off << 16);
     if (mode == 1) {
-      for (int i = lane; i < ns; i += 64) slab[off + i] = *reinterpret_cast<const uint4*>(&Q.seg[i]);
-      uint32_t* mg = reinterpret_cast<uint32_t*>(slab + off + ns);
-      for (int i = lane; i < ((ns + 3) & ~3); i += 64) mg[i] = i < ns ? Q.magic[i] : 0u;
-      off += (unsigned)ns + (unsigned)((ns + 3) >> 2);
+      for (int i = lane; i < ns; i += 64) {
+        // (x, xend, y, b, |dy| mod adx, +-adx) -> (x, xend, y, signed 32.32 step per bin): floor_walk_fx
+        const FloorSeg q = Q.seg[i];
+        const int sadx = (int)q.ady_adx >> 16;
+        const unsigned adx = (unsigned)(sadx < 0 ? -sadx : sadx), r = q.ady_adx & 0xFFFFu;
+        const unsigned ab = (unsigned)(q.b < 0 ? -q.b : q.b);
+        const unsigned long long fr32 = adx ? (((unsigned long long)r << 32) + adx - 1) / adx : 0ull;  // r < adx: below 2^32
+        unsigned long long F = ((unsigned long long)ab << 32) + fr32;
+        if (sadx < 0) F = 0ull - F;
+        slab[off + i] = make_uint4(q.x_xend, (unsigned)q.y, (unsigned)F, (unsigned)(F >> 32));
+      }
+      off += (unsigned)ns;
       // segment index of every group of four bins (the last segment that starts at or before the group's first bin): the
       // floor multiply starts its walk there instead of searching the list
       uint8_t* tab = reinterpret_cast<uint8_t*>(slab + off);
@@ -530,11 +568,10 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   SY_T(2);
 
   // the floor curve of channel c as it lies in the slab
-  auto floor_of = [&](unsigned cw, const FloorSeg*& seg, const uint32_t*& magic, const uint8_t*& tab) {
+  auto floor_of = [&](unsigned cw, const uint4*& seg, const uint8_t*& tab) {
     const unsigned ns = (cw >> 8) & 0xFFu, oseg = cw >> 16;
-    seg = reinterpret_cast<const FloorSeg*>(slab + oseg * 4);
-    magic = reinterpret_cast<const uint32_t*>(slab + (oseg + ns) * 4);
-    tab = reinterpret_cast<const uint8_t*>(slab + (oseg + ns + ((ns + 3) >> 2)) * 4);
+    seg = reinterpret_cast<const uint4*>(slab + oseg * 4);
+    tab = reinterpret_cast<const uint8_t*>(slab + (oseg + ns) * 4);
   };
 
   // ---- residue: one lane per GROUP of consecutive vector components of one chain, all cascade stages with the sums in
@@ -546,8 +583,8 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     if (MAXCH <= 2 && (flags & NVH_SLAB_FUSE_FLOOR)) {
       FloorRef F;
       const unsigned c0w = __builtin_amdgcn_readfirstlane(s_chan[0]), c1w = __builtin_amdgcn_readfirstlane(s_chan[1]);
-      floor_of(c0w, F.seg[0], F.magic[0], F.tab[0]);
-      floor_of(c1w, F.seg[1], F.magic[1], F.tab[1]);
+      floor_of(c0w, F.seg[0], F.tab[0]);
+      floor_of(c1w, F.seg[1], F.tab[1]);
       F.md[0] = (int)(c0w & 0xFFu); F.md[1] = (int)(c1w & 0xFFu);
       F.s_db = s_db;
       NVH_WALK(8, true, 0, &F);
@@ -572,6 +609,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   SY_T(3);
   if (!(MAXCH <= 2 && (flags & NVH_SLAB_FUSE_FLOOR))) {
     __syncthreads();
+    SY_T(6);
     if (flags & NVH_SLAB_COUPLE_PASS) {
       // inverse coupling as passes of their own (Mapping.cs:137-182), in the order k_prepare_slabs stored them (last step first)
       const unsigned cnt = cpl_word & 0xFu;
@@ -588,23 +626,24 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
         __syncthreads();
       }
     }
+    SY_T(7);
     // ---- floor multiply in place (Floor1.cs:196-222): 8 bins of one channel per lane ----
     {
-      const int per_ch = half >> 3;
+      const int per_ch = half >> 3, per_sh = 31 - __clz(per_ch);  // half is a power of two
       for (int t = tid; t < nch * per_ch; t += NT) {
-        const int c = t / per_ch, x0 = (t - c * per_ch) << 3;
+        const int c = t >> per_sh, x0 = (t - (c << per_sh)) << 3;
         const unsigned cw = s_chan[c];
         const int md = (int)(cw & 0xFFu);
         if (md == 0) continue;  // the channel does not execute: its residue stays (quirk B-4)
         float* sp = spec + c * half + x0;
         float r[8];
         if (md == 1) {
-          const FloorSeg* seg; const uint32_t* magic; const uint8_t* tab;
-          floor_of(cw, seg, magic, tab);
+          const uint4* seg; const uint8_t* tab;
+          floor_of(cw, seg, tab);
           float m[8];
           *reinterpret_cast<float4*>(r) = *reinterpret_cast<const float4*>(sp);
           *reinterpret_cast<float4*>(r + 4) = *reinterpret_cast<const float4*>(sp + 4);
-          floor_walk_seg<8>(seg, magic, 0, s_db, x0, m, tab);
+          floor_walk_fx<8>(seg, tab, s_db, x0, m);
 #pragma unroll
           for (int q = 0; q < 8; ++q) r[q] = r[q] * m[q];
         } else {

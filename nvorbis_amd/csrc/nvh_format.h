@@ -142,7 +142,7 @@ struct NvhFrame {
 // of dependent loads, no staging copies, no unwrap in the kernel).  Written by k_prepare_slabs from the descriptors above
 // (integer work only: Floor1.UnwrapPosts + the segment list of the sorted, flagged posts, Floor1.cs:196-297; the
 // residue geometry of Residue0.cs:157-170 / Residue2.cs:23-47 resolved per vector write).  Sections, 16-byte aligned:
-//   NvhSlabHdr | per channel: FloorSeg[nseg], uint32 magic[nseg], uint8 first_segment[n / 8] (one per four bins) |
+//   NvhSlabHdr | per channel: uint4 segment[nseg] (x | xend << 16, y, signed 32.32 step per bin), uint8 first_segment[n / 8] (one per four bins) |
 //   uint16 heads[nheads] | uint4 rec[nrec] | uint16 entries[]
 // rec = one (stage, partition, channel) vector write in the pair-path form of kernels_spectrum.hip,
 //   x: entry offset (frame relative) | first bin << 16      y: lattice pool offset | lat_values << 16

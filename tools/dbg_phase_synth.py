@@ -44,6 +44,10 @@ names = ["DMA round trip + clear + barrier", "header (+ rest of a big slab)", "r
 for k in range(5):
     dt = d[:, k + 1] - d[:, k]
     print("%-34s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (names[k], dt.mean(), np.median(dt), np.percentile(dt, 90)))
+if d[:, 6].any():  # k_synth8 / unfused floor: the wait for the slowest walker, the coupling passes, the floor multiply
+    for nm, a, b_ in (("  wait for the slowest walker", 3, 6), ("  coupling passes", 6, 7), ("  floor multiply", 7, 4)):
+        dt = d[:, b_] - d[:, a]
+        print("%-34s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (nm, dt.mean(), np.median(dt), np.percentile(dt, 90)))
 life = d[:, 5] - d[:, 0]
 print("WG lifetime mean %.0f p50 %.0f p90 %.0f cycles" % (life.mean(), np.median(life), np.percentile(life, 90)))
 w0 = d[:, 22].min()
