@@ -529,8 +529,15 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
 #ifdef NVH_DEBUG
   if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 22] = wall_clock64();
 #endif
-  // ---- one round trip: constants + the first NT * 16 bytes of the slab by LDS-DMA, the spectrum cleared meanwhile ----
+  // ---- one round trip: constants + the first NT * 16 bytes of the slab by LDS-DMA, the slab's header by a scalar load next to
+  // them (the slabs are constant for the life of the kernel: address space 4 makes the load an s_load), the spectrum cleared
+  // meanwhile; a slab beyond the speculative piece has its rest fetched as soon as the header is there -- in front of the ONE
+  // barrier, not behind a second round trip ----
   const uint4* gslab = A.slabs + (long long)f * A.stride_vecs;
+  typedef const __attribute__((address_space(4))) uint32_t* const_words;
+  const_words gh = (const_words)(unsigned long long)gslab;
+  const unsigned w0 = gh[0], w1 = gh[1], w2 = gh[2], w3 = gh[3], w4 = gh[4], w5 = gh[5], frame = gh[6], cpl_word = gh[7];
+  constexpr unsigned kSpec = MAXCH > 2 ? 2 * NT : NT;  // 16-byte units fetched before the header is known
   {
     const int v = tid;  // 16-byte unit handled by this lane: wavefront w moves units [64 w, 64 w + 64)
     if (v < A.cap_vecs) dma16(gslab + v, slab + wv * 256);
@@ -540,30 +547,24 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int i = tid; i < (nch * half_max) >> 2; i += NT) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
   }
+  const unsigned vecs = w3 >> 16;
+  if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
+  if (vecs > kSpec) {
+    for (unsigned c0 = kSpec + wv * 64; c0 < vecs; c0 += NT)
+      if (c0 + lane < vecs) dma16(gslab + c0 + lane, slab + c0 * 4);
+  }
   __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
   SY_T(1);
-  const uint4 h0 = reinterpret_cast<const uint4*>(slab)[0], h1 = reinterpret_cast<const uint4*>(slab)[1];
-  const unsigned w0 = __builtin_amdgcn_readfirstlane(h0.x), w1 = __builtin_amdgcn_readfirstlane(h0.y);
-  const unsigned w2 = __builtin_amdgcn_readfirstlane(h0.z), w3 = __builtin_amdgcn_readfirstlane(h0.w);
-  const unsigned w4 = __builtin_amdgcn_readfirstlane(h1.x), w5 = __builtin_amdgcn_readfirstlane(h1.y);
-  const unsigned frame = __builtin_amdgcn_readfirstlane(h1.z), cpl_word = __builtin_amdgcn_readfirstlane(h1.w);
   const int n = (int)(w0 & 0xFFFFu);
   if (n == 0) return;
   const unsigned exec_mask = (w0 >> 16) & 0xFFu, flags = w0 >> 24;
   const unsigned nheads = w1 & 0xFFFFu;
   const unsigned off_heads = w2 & 0xFFFFu, off_rec = w2 >> 16;
-  const unsigned off_ent = w3 & 0xFFFFu, vecs = w3 >> 16;
+  const unsigned off_ent = w3 & 0xFFFFu;
   const unsigned lpc = w4 & 0xFFFFu, rgeom = (w4 >> 16) & 0xFFu, group = w4 >> 24;
   const unsigned lpc_magic = w5;
   const uint32_t* s_chan = reinterpret_cast<const uint32_t*>(slab) + 8;  // per channel: mode | nseg << 8 | off_seg << 16
   const int half = n >> 1;
-  if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
-  constexpr unsigned kSpec = MAXCH > 2 ? 2 * NT : NT;  // 16-byte units fetched before the header was known
-  if (vecs > kSpec) {  // a slab beyond the speculative piece: fetch the rest
-    for (unsigned c0 = kSpec + wv * 64; c0 < vecs; c0 += NT)
-      if (c0 + lane < vecs) dma16(gslab + c0 + lane, slab + c0 * 4);
-    __syncthreads();
-  }
   if ((flags & NVH_SLAB_FLOOR_FAULT) && tid == 0) atomicOr(A.err, NVH_DEVERR_FLOOR1_Y);
   SY_T(2);
 
