@@ -581,11 +581,6 @@ k_couple_floor(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, int* __r
 // Overlap-add + interleave + clip
 // ================================================================================================
 
-__device__ __forceinline__ float clip_value(float v, int* clipped) {  // Utils.cs:30-43
-  if (v > .99999994f) { *clipped = 1; return 0.99999994f; }
-  if (v < -.99999994f) { *clipped = 1; return -0.99999994f; }
-  return v;
-}
 
 // Parallel form: valid when no overlap region reaches into a tail (FrameBatch::sequential_ola == false),
 // i.e. every tail read here is an untouched windowed block.  One workgroup per frame.
@@ -854,8 +849,10 @@ __device__ __forceinline__ int ola_sym_lds(const NvhDevSetup& S, const NvhFrame&
 extern "C" __global__ void __launch_bounds__(256)
 k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const float* __restrict__ carry,
               float* __restrict__ pcm, int clip, int* __restrict__ clipped_flag, float* __restrict__ carry_out, int last_decoded,
-              int nosym) {
-  const int f = blockIdx.x;
+              int nosym, const int* __restrict__ list, int emitted) {
+  // list: the frames paired emission left to this kernel (nvh_launch.hip); emitted: k_synth wrote the PCM of every frame with
+  // NVH_EMIT_DONE (such a frame is on the list only as the block that becomes the carried tail)
+  const int f = list ? list[blockIdx.x] : (int)blockIdx.x;
   const NvhFrame fr = Bt.frames[f];
   const int ch = S.channels;
   if (f == last_decoded && carry_out) {
@@ -870,6 +867,7 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
   }
   const int total = fr.emit_count * ch;
   if (total <= 0) return;
+  if (emitted && (fr.emit_flags & NVH_EMIT_DONE)) return;
   const float* cur = work + (long long)f * ch * S.block1;
   const float* prev = nullptr;
   if (fr.ov_len > 0) prev = (fr.ov_frame == -2) ? carry : (fr.ov_frame >= 0 ? work + (long long)fr.ov_frame * ch * S.block1 : nullptr);

@@ -90,11 +90,24 @@ struct NvhSynthArgs {
   const float* mdct_b[2];
   const float* mdct_c[2];
   const float* mdct_tw[2];
-  int const_vecs, stride_vecs, cap_vecs;  // cap_vecs: largest slab of the batch = the LDS slab area
+  int const_vecs, stride_vecs, cap_vecs;  // cap_vecs: largest slab of the batch
+  int lds_vecs;             // the LDS slab area (>= cap_vecs; paired emission stages the neighbours' quarters over constants + slab)
   int channels, block1;
+  int f0, fstep;            // workgroup b synthesises frame f0 + b * fstep (paired emission: odd frames, then even frames)
+  // paired emission (nvh_format.h: NVH_EMIT_*); pcm == nullptr: off, every frame leaves its plane for k_ola_compact
+  float* pcm;
+  const float* windows;
+  int clip;
+  int* clipped_flag;
 };
 
 #ifdef __HIPCC__
+__device__ __forceinline__ float clip_value(float v, int* clipped) {  // Utils.cs:30-43
+  if (v > .99999994f) { *clipped = 1; return 0.99999994f; }
+  if (v < -.99999994f) { *clipped = 1; return -0.99999994f; }
+  return v;
+}
+
 // HasClipped (StreamDecoder.cs:728) is sticky: one lane per wavefront that clipped looks at the flag and only sets it
 // while it is still clear.  A stream that clips everywhere (loud material; Floor0 curves on random bits) otherwise
 // serialises one atomic per lane -- or still 8192 per launch with one per wavefront, ~35 us -- on a single address.

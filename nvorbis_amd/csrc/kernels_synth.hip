@@ -499,7 +499,148 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
   if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) &&
       (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
     H.flags |= NVH_SLAB_FUSE_FLOOR;
+  // paired emission (nvh_format.h: NVH_EMIT_*; the host decided at upload): the parameters k_synth needs about the overlaps
+  if (nch <= 2 && (fr.emit_flags & (NVH_EMIT_SELF | NVH_EMIT_NEXT))) {
+    H.chan[2] = fr.window_off; H.chan[3] = fr.ov_window_off; H.chan[6] = (uint32_t)fr.out_pos;
+    if (fr.emit_flags & NVH_EMIT_SELF) H.flags |= NVH_SLAB_EMIT_SELF;
+    if (fr.emit_flags & NVH_EMIT_NEXT) {
+      const NvhFrame nx = Bt.frames[f + 1];
+      H.chan[4] = nx.window_off; H.chan[5] = nx.ov_window_off; H.chan[7] = (uint32_t)nx.out_pos;
+      H.flags |= NVH_SLAB_EMIT_NEXT;
+    }
+  }
   put_header();
+}
+
+// ---- paired emission (nvh_format.h: NVH_EMIT_*) ---------------------------------------------------------------------------
+// An even frame of the second launch: inverse MDCT into registers, then the overlap-add, interleave and clip of the steady-state
+// overlaps it takes part in -- Mode.cs:160-166 windows, StreamDecoder.cs:532-541 adds, StreamDecoder.cs:391-415 / Utils.cs:30-43
+// interleave + clip, with ola_sym's arithmetic (kernels.hip: sample times i and n/2 - 1 - i of an overlap need exactly the first
+// quarter A[i] of the later block and the third quarter B[i] of the earlier one, Mdct.cs:275-303):
+//   SELF: PCM of this frame      = A(this) windowed + B(frame - 1) windowed
+//   NEXT: PCM of the next frame  = A(frame + 1) windowed + B(this) windowed
+// A(frame + 1) and B(frame - 1) lie in the work planes since the first launch; they come in by LDS-DMA over the constants and
+// the slab -- dead once the chain walk is through -- while the transform runs; the frame's own quarters go from the transform's
+// registers into the channel's dead transform slice, and every lane of the workgroup then overlap-adds, clips and interleaves
+// one group of sample times of one overlap, straight into 16-byte vectors of PCM.
+// The frame's own plane is written only when k_ola_compact still needs it (not both overlaps emitted here).
+template <int NT>
+__device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, float* spec, const uint32_t* s_chan, int n, int nch,
+                                           unsigned frame, int sl, bool emit_self, bool emit_next, float* planes,
+                                           const float* Aa, const float* Bb, const float* Cc, const float* TW, int tid) {
+  const int wv = tid >> 6, lane = tid & 63, half = n >> 1;
+  // parameters of the overlaps, out of the slab before the staging overwrites it
+  const unsigned w_self = __builtin_amdgcn_readfirstlane(s_chan[2]), wp_self = __builtin_amdgcn_readfirstlane(s_chan[3]);
+  const unsigned w_next = __builtin_amdgcn_readfirstlane(s_chan[4]), wp_next = __builtin_amdgcn_readfirstlane(s_chan[5]);
+  const unsigned out_self = __builtin_amdgcn_readfirstlane(s_chan[6]), out_next = __builtin_amdgcn_readfirstlane(s_chan[7]);
+  __syncthreads();  // the chain walk is through everywhere: constants and slab are dead, the spectra complete (the transform
+                    // below is in place over the wavefront's own channel and needs no workgroup barrier of its own)
+  // ---- stage the neighbours' quarters: per channel n/8 16-byte units, B(frame - 1) then A(frame + 1) ----
+  float* stage = smem;
+  {
+    const int per_ch = n >> 3, q16 = n >> 4, sh = 28 - __clz(n);  // per_ch = 1 << sh
+    const int units = nch * per_ch;
+    for (int u0 = wv * 64; u0 < units; u0 += NT) {
+      const int u = u0 + lane;
+      if (u < units) {
+        const int c = u >> sh, r = u & (per_ch - 1);
+        const bool is_a = r >= q16;
+        if (is_a ? emit_next : emit_self) {
+          const float* src = is_a ? A.work + ((long long)(frame + 1) * nch + c) * A.block1 + 4 * (r - q16)
+                                  : A.work + ((long long)(frame - 1) * nch + c) * A.block1 + half + 4 * r;
+          dma16(reinterpret_cast<const uint4*>(src), stage + 4 * u0);
+        }
+      }
+    }
+  }
+  // ---- inverse MDCT of this wavefront's channel, the two independent quarters kept in registers ----
+  float4 ca[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, cb[2] = {ca[0], ca[0]};
+  const bool pon = lane < (n >> 5);  // lanes with output: four values of each quarter at 4 i8, i8 = lane and i8 = n/16 - 1 - lane
+  const int i8a = lane, i8b = (n >> 4) - 1 - lane;
+  const bool xform = wv < nch;  // every channel of an emitting frame executes (host: steady)
+  if (xform) {
+    const float* X = spec + wv * half;
+    float* scratch = spec + wv * half - (nch - 1 - wv) * (n >> 4);
+    auto sink = [&](int slot, int, float4 v) {  // slot = 4 h + q: q = 0 first quarter, q = 2 third quarter (1, 3: their mirrors)
+      if (slot == 0) ca[0] = v; else if (slot == 2) cb[0] = v; else if (slot == 4) ca[1] = v; else if (slot == 6) cb[1] = v;
+    };
+    switch (n) {
+      case 256: imdct_wave_sink<8, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink); break;
+      case 512: imdct_wave_sink<9, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink); break;
+      case 1024: imdct_wave_sink<10, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink); break;
+      case 2048: imdct_wave_sink<11, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink); break;
+      default: __builtin_trap();
+    }
+    if (pon) {
+      if (!(emit_self && emit_next)) {  // k_ola_compact (or the carried tail) still reads this frame's plane
+        float* plane = planes + (long long)wv * A.block1;
+        *reinterpret_cast<float4*>(plane + 4 * i8a) = ca[0];
+        *reinterpret_cast<float4*>(plane + 4 * i8b) = ca[1];
+        *reinterpret_cast<float4*>(plane + half + 4 * i8a) = cb[0];
+        *reinterpret_cast<float4*>(plane + half + 4 * i8b) = cb[1];
+      }
+      // the channel's own quarters, for the overlap-add below: A(this) in [0, n/4), B(this) in [n/4, n/2) of its dead slice
+      float* own = spec + wv * half;
+      *reinterpret_cast<float4*>(own + 4 * i8a) = ca[0];
+      *reinterpret_cast<float4*>(own + 4 * i8b) = ca[1];
+      *reinterpret_cast<float4*>(own + (half >> 1) + 4 * i8a) = cb[0];
+      *reinterpret_cast<float4*>(own + (half >> 1) + 4 * i8b) = cb[1];
+    }
+  }
+  __syncthreads();  // drains the staging DMA (vmcnt(0) in front of the barrier): all four quarters of every channel are in LDS
+  // ---- overlap-add + interleave + clip, every lane of the workgroup: lane task = (overlap, group of four compact indices i0);
+  // it produces sample times i0 .. i0 + 3 and n/2 - 4 - i0 .. n/2 - 1 - i0 of every channel (kernels.hip: ola_sym) ----
+  int clipped = 0;
+  const int groups = n >> 4;  // per overlap
+  for (int t = tid; t < 2 * groups; t += NT) {
+    const bool nx = t >= groups;
+    if (nx ? !emit_next : !emit_self) continue;
+    const int g = nx ? t - groups : t, i0 = 4 * g;
+    const float* __restrict__ w = A.windows + (nx ? w_next : w_self);
+    const float* __restrict__ wp = A.windows + (nx ? wp_next : wp_self);
+    const float4 wf = *reinterpret_cast<const float4*>(w + i0);
+    const float4 wm = *reinterpret_cast<const float4*>(w + (half - 4 - i0));
+    const float4 pf = *reinterpret_cast<const float4*>(wp + (half + i0));
+    const float4 pm = *reinterpret_cast<const float4*>(wp + (n - 4 - i0));
+    float fwd[8], mir[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < nch) {
+        // SELF: a = A(this), b = B(frame - 1);  NEXT: a = A(frame + 1), b = B(this)
+        const float* pa = nx ? stage + c * half + (half >> 1) : spec + c * half;
+        const float* pb = nx ? spec + c * half + (half >> 1) : stage + c * half;
+        const float4 a = *reinterpret_cast<const float4*>(pa + i0);
+        const float4 b = *reinterpret_cast<const float4*>(pb + i0);
+        float4 v = make_float4(a.x * wf.x, a.y * wf.y, a.z * wf.z, a.w * wf.w);
+        const float4 tt = make_float4(b.x * pf.x, b.y * pf.y, b.z * pf.z, b.w * pf.w);
+        v.x = v.x + tt.x; v.y = v.y + tt.y; v.z = v.z + tt.z; v.w = v.w + tt.w;
+        float4 u = make_float4(-a.w * wm.x, -a.z * wm.y, -a.y * wm.z, -a.x * wm.w);
+        const float4 r = make_float4(b.w * pm.x, b.z * pm.y, b.y * pm.z, b.x * pm.w);
+        u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
+        if (A.clip) {
+          v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
+          v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
+          u.x = clip_value(u.x, &clipped); u.y = clip_value(u.y, &clipped);
+          u.z = clip_value(u.z, &clipped); u.w = clip_value(u.w, &clipped);
+        }
+        fwd[c] = v.x; fwd[2 + c] = v.y; fwd[4 + c] = v.z; fwd[6 + c] = v.w;
+        mir[c] = u.x; mir[2 + c] = u.y; mir[4 + c] = u.z; mir[6 + c] = u.w;
+      }
+    }
+    float* out = A.pcm + (long long)(nx ? out_next : out_self) * nch;
+    if (nch == 2) {
+      float4* of = reinterpret_cast<float4*>(out) + 2 * (long long)g;
+      float4* om = reinterpret_cast<float4*>(out) + 2 * (long long)((n >> 3) - 1 - g);
+      of[0] = make_float4(fwd[0], fwd[1], fwd[2], fwd[3]);
+      of[1] = make_float4(fwd[4], fwd[5], fwd[6], fwd[7]);
+      om[0] = make_float4(mir[0], mir[1], mir[2], mir[3]);
+      om[1] = make_float4(mir[4], mir[5], mir[6], mir[7]);
+    } else {
+      reinterpret_cast<float4*>(out)[g] = make_float4(fwd[0], fwd[2], fwd[4], fwd[6]);
+      reinterpret_cast<float4*>(out)[(n >> 3) - 1 - g] = make_float4(mir[0], mir[2], mir[4], mir[6]);
+    }
+  }
+  if (A.clip) report_clipped(clipped, A.clipped_flag);
 }
 
 // ---- float side ------------------------------------------------------------------------------------------------------------
@@ -513,21 +654,21 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
 template <int NT, int MAXCH>
 __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int f = blockIdx.x;
+  const int f = A.f0 + (int)blockIdx.x * A.fstep;
   const int nch = A.channels;
   float* s_db = smem;
   const uint32_t* s_lat = reinterpret_cast<const uint32_t*>(smem + 256);
   float* slab = smem + A.const_vecs * 4;
-  float* spec = slab + A.cap_vecs * 4;
+  float* spec = slab + A.lds_vecs * 4;
   const int half_max = A.block1 >> 1;
 #ifdef NVH_DEBUG
-#define SY_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + (k)] = clock64(); } while (0)
+#define SY_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)f * 24 + (k)] = clock64(); } while (0)
 #else
 #define SY_T(k) do { } while (0)
 #endif
   SY_T(0);
 #ifdef NVH_DEBUG
-  if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 22] = wall_clock64();
+  if (dbg && threadIdx.x == 0) dbg[(long long)f * 24 + 22] = wall_clock64();
 #endif
   // ---- one round trip: constants + the first NT * 16 bytes of the slab by LDS-DMA, the slab's header by a scalar load next to
   // them (the slabs are constant for the life of the kernel: address space 4 makes the load an s_load), the spectrum cleared
@@ -669,6 +810,15 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   const float* Cc = A.mdct_c[sl];
   const float* TW = A.mdct_tw[sl];
   const bool xform = wv < nch && ((exec_mask >> wv) & 1u);
+  bool emit_self = false, emit_next = false;
+  if constexpr (MAXCH <= 2) {
+    emit_self = A.pcm != nullptr && (flags & NVH_SLAB_EMIT_SELF);
+    emit_next = A.pcm != nullptr && (flags & NVH_SLAB_EMIT_NEXT);
+  }
+  if (MAXCH <= 2 && (emit_self || emit_next)) {
+    if constexpr (MAXCH <= 2)
+      synth_emit<NT>(A, smem, spec, s_chan, n, nch, frame, sl, emit_self, emit_next, planes, Aa, Bb, Cc, TW, tid);
+  } else
   if (MAXCH <= 2) {
     // in place over the channel's own spectrum (the transform's slice = n/2 floats + n/16 of padding: channel nch-1 spills its
     // padding past the end of the spectrum area, the one before it into the dead slab area in front of it; the workgroup
@@ -716,7 +866,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   if (MAXCH > 2 && !xform) __syncthreads();  // the one barrier every transforming wavefront passes inside imdct_wave<.., WGSYNC>
   SY_T(5);
 #ifdef NVH_DEBUG
-  if (dbg && threadIdx.x == 0) dbg[(long long)blockIdx.x * 24 + 23] = wall_clock64();
+  if (dbg && threadIdx.x == 0) dbg[(long long)f * 24 + 23] = wall_clock64();
 #endif
 #undef SY_T
 }

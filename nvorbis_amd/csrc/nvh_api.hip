@@ -20,6 +20,7 @@ const NvhToggles& nvh_toggles() {
     x.lpt = on("NVH_LPT");
     x.no_ola_sym = on("NVH_NO_OLA_SYM");
     x.slab_stream = on("NVH_SLAB_STREAM");
+    x.no_emit = on("NVH_NO_EMIT");
     x.debug_occ = on("NVH_DEBUG_OCC");
     x.gpu_parse_default = on("NVH_GPU_PARSE");
     x.lds_pad = num("NVH_LDS_PAD");

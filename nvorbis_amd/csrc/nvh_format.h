@@ -132,8 +132,17 @@ struct NvhFrame {
   uint32_t ov_window_off;         // window of that frame (its tail is stored un-windowed in the compact layout)
   uint32_t exec_mask;             // bit c = channel c executes (first 32 channels; mirrors NvhChan::exec)
   uint32_t ov_exec_mask;          // same for the overlap source frame (mirrors NvhChan::ov_exec)
-  uint32_t pad;
+  uint32_t emit_flags;            // NVH_EMIT_*: who overlap-adds this frame's PCM (set by the host at upload; 0 = k_ola_compact)
 };
+
+// In-kernel overlap-add of the slab synthesis kernel (kernels_synth.hip, "paired emission"): even frames of a batch are
+// synthesised in a second launch, behind the odd ones, and emit the PCM of the steady-state overlaps they take part in --
+// their own first half over frame f - 1's second half (SELF), and their second half under frame f + 1's first half (NEXT) --
+// from registers and the odd frames' work planes, so that neither their own plane nor a k_ola_compact pass over those samples
+// is needed.  DONE marks every frame whose PCM comes out of k_synth: k_ola_compact skips its overlap-add.
+#define NVH_EMIT_SELF 1u
+#define NVH_EMIT_NEXT 2u
+#define NVH_EMIT_DONE 4u
 
 // ---- per-frame slabs of the slab synthesis kernel (kernels_synth.hip) ------------------------------------------------
 //
@@ -155,6 +164,8 @@ struct NvhFrame {
 #define NVH_SLAB_FLOOR_FAULT 8u    // a curve value outside inverse_dB_table (quirk B-7): the kernel raises NVH_DEVERR_FLOOR1_Y
 #define NVH_SLAB_MDCT_SLOT 16u     // block1 tables (else block0)
 #define NVH_SLAB_FUSE_FLOOR 32u    // the lane that finishes a chain multiplies its bins by the floor curve before its one store
+#define NVH_SLAB_EMIT_SELF 64u     // NVH_EMIT_SELF of the frame (mono / stereo slabs only: chan[2..7] carry the parameters)
+#define NVH_SLAB_EMIT_NEXT 128u    // NVH_EMIT_NEXT
 #define NVH_SLAB_HDR_VECS 4
 #define NVH_SLAB_MAX_CH 8          // channels a slab describes (k_synth: 2, k_synth8: 8)
 #define NVH_SLAB_MAX_COUPLE 4      // coupling steps of a pass of its own (3 + 3 bits each in NvhSlabHdr::coupling)
@@ -174,5 +185,7 @@ struct NvhSlabHdr {      // 64 bytes
   uint32_t frame;        // the frame this slab belongs to: slabs are laid out in launch order (costliest frames first), not in frame order
   uint32_t coupling;     // NVH_SLAB_COUPLE_PASS: step count | (magnitude | angle << 3) << (4 + 6 k) for step k (Mapping.cs:137-182)
   uint32_t chan[NVH_SLAB_MAX_CH];  // per channel: floor mode (0 none, 1 curve, 2 clear; Floor1.cs:218-221) | nseg << 8 | off_seg << 16
+                                   // NVH_SLAB_EMIT_* (at most two channels): chan[2..7] = window_off, ov_window_off, the next
+                                   // frame's window_off and ov_window_off, out_pos, the next frame's out_pos
 };
 

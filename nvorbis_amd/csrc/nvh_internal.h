@@ -33,7 +33,7 @@ __global__ void k_imdct_wave(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_imdct_compact(NvhDevSetup S, NvhDevBatch Bt, float* work);
 __global__ void k_expand_carry(NvhDevSetup S, NvhDevBatch Bt, const float* work, float* carry_out, int f);
 __global__ void k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry, float* pcm, int clip,
-                              int* clipped_flag, float* carry_out, int last_decoded, int nosym);
+                              int* clipped_flag, float* carry_out, int last_decoded, int nosym, const int* list, int emitted);
 __global__ void k_spectrum(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_spectrum_f0(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_spectrum_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
@@ -120,6 +120,7 @@ struct NvhToggles {
   bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
   bool slab_stream; // NVH_SLAB_STREAM: streaming (one-shot) batches take the slab synthesis kernels too (default: resident batches only)
   bool no_ola_sym;  // NVH_NO_OLA_SYM: k_ola_compact without its read-once steady-state path (test / A-B aid)
+  bool no_emit;     // NVH_NO_EMIT: no paired emission -- every frame's PCM through k_ola_compact (test / A-B aid)
   bool lpt;       // NVH_LPT: slabs in costliest-first launch order (k_rank_frames) instead of frame order
   bool no_slab;   // NVH_NO_SLAB: k_spectrum_imdct instead of k_prepare_slabs + k_synth (test / A-B aid)
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
@@ -277,6 +278,10 @@ struct nvh_batch {
   DevBuf slab3;
   int slab_stride_vecs = 0;   // 16-byte units between slabs = upper bound of the batch's largest slab
   bool slabs_ready = false;
+  // paired emission (nvh_format.h: NVH_EMIT_*): frames whose PCM k_synth writes itself, and the frames left to k_ola_compact
+  int emit_frames = 0;           // frames with NVH_EMIT_DONE
+  int ola_count = 0;             // entries of d_ola_list
+  const int* d_ola_list = nullptr;  // inside the descriptor blob
   bool prepare_events_pending = false;  // prep_e0 / prep_e1 bracket k_prepare_slabs of this upload (read by nvh_batch_stats[7], ns)
   hipEvent_t prep_e0 = nullptr, prep_e1 = nullptr;
   ~nvh_batch() {

@@ -216,6 +216,51 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       break;
     }
 
+  // ---- paired emission (nvh_format.h: NVH_EMIT_*): which steady-state overlaps the slab synthesis kernel emits itself ----
+  // g "steady": its whole first half lies over the whole second half of frame g - 1, same size, every channel executing in
+  // both, whole groups of four samples (k_ola_compact's read-once path has the same contract: kernels.hip, ola_sym).  Even
+  // frames emit; an odd steady frame's PCM comes from the even frame in front of it.  Host-parsed batches of mono / stereo
+  // streams with blocks 256..2048 only (the execute flags of a GPU-parsed batch are not known here).
+  std::vector<int> ola_list;
+  b->emit_frames = 0;
+  {
+    const int ch = s->setup.channels;
+    const bool can = !s->gpu_parse && !nvh_toggles().no_emit && ch <= 2 && !P.sequential_ola && s->setup.block0 >= 256 &&
+                     s->setup.block1 <= 2048;
+    const unsigned all_ch = (1u << ch) - 1u;
+    const int nf = (int)P.frames.size();
+    auto steady = [&](int g) {
+      if (!can || g < 1 || g >= nf) return false;
+      const NvhFrame& fr = P.frames[(size_t)g];
+      const NvhFrame& pv = P.frames[(size_t)g - 1];
+      const int half = fr.n >> 1;
+      return fr.n >= 256 && pv.n == fr.n && fr.ov_frame == g - 1 && fr.ov_n == fr.n && fr.start == 0 && fr.emit_start == 0 &&
+             fr.emit_count == half && fr.ov_src == half && fr.ov_len == half && (fr.exec_mask & all_ch) == all_ch &&
+             (fr.ov_exec_mask & all_ch) == all_ch && (pv.exec_mask & all_ch) == all_ch && ((fr.out_pos * ch) & 3) == 0 &&
+             fr.out_pos >= 0 && fr.out_pos < 0x7FFFFFFFll && fr.window_off < 0x7FFFFFFFu;
+    };
+    for (int g = 0; g < nf; g++) {
+      NvhFrame& fr = P.frames[(size_t)g];
+      fr.emit_flags = 0;
+      if (steady(g)) {
+        fr.emit_flags |= NVH_EMIT_DONE;
+        if ((g & 1) == 0) fr.emit_flags |= NVH_EMIT_SELF;
+        b->emit_frames++;
+      }
+      if ((g & 1) == 0 && steady(g + 1)) fr.emit_flags |= NVH_EMIT_NEXT;
+    }
+    // what is left for k_ola_compact: every other frame that emits samples, and the block that becomes the carried tail
+    int last = -1;
+    for (int i = nf - 1; i >= 0; --i)
+      if (P.frames[(size_t)i].n != 0) { last = i; break; }
+    for (int g = 0; g < nf; g++) {
+      const NvhFrame& fr = P.frames[(size_t)g];
+      if ((fr.emit_count > 0 && !(fr.emit_flags & NVH_EMIT_DONE)) || g == last) ola_list.push_back(g);
+    }
+  }
+  b->ola_count = (int)ola_list.size();
+  b->d_ola_list = nullptr;
+
   b->stats[0] = (int64_t)P.frames.size(); b->stats[1] = (int64_t)P.chans.size(); b->stats[2] = (int64_t)P.passes.size();
   b->stats[3] = (int64_t)P.ops.size(); b->stats[4] = (int64_t)P.entries.size(); b->stats[5] = (int64_t)P.posts.size();
   b->stats[6] = (int64_t)P.coeffs.size();
@@ -254,6 +299,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   size_t o_en = add(P.entries.data(), P.entries.size(), sizeof(uint16_t));
   size_t o_po = add(P.posts.data(), P.posts.size(), sizeof(uint16_t));
   size_t o_co = add(P.coeffs.data(), P.coeffs.size(), sizeof(float));
+  size_t o_ol = add(ola_list.data(), ola_list.size(), sizeof(int));
   total += 64;  // k_spectrum copies entry slices in whole 16-byte vectors
   b->descriptor_bytes = (int64_t)(P.frames.size() * sizeof(NvhFrame) + P.chans.size() * sizeof(NvhChan) +
                                   P.passes.size() * sizeof(NvhResPass) + P.ops.size() * (sizeof(NvhResOp) + sizeof(uint16_t)) +
@@ -273,6 +319,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->dev.entries = (const uint16_t*)(base + o_en);
   b->dev.posts = (const uint16_t*)(base + o_po);
   b->dev.coeffs = (const float*)(base + o_co);
+  b->d_ola_list = (const int*)(base + o_ol);
   b->dev.nframes = b->nframes;
   b->dev.pad = 0;
   b->dev_copy_valid = false;
@@ -312,12 +359,26 @@ static size_t slab_bound_vecs(const nvh_batch* b) {
   return (v + 3) & ~(size_t)3;
 }
 
+// The LDS slab area in 16-byte units: the batch's largest slab -- and, for a batch with paired emission (k_synth only), room
+// for the neighbours' quarters that are staged over constants + slab in front of the first transform slice's padding
+// (kernels_synth.hip: synth_emit).
+static size_t slab_lds_vecs(const nvh_batch* b) {
+  const nvh_stream* s = b->s;
+  size_t v = slab_bound_vecs(b);
+  if (!slab_wide(s) && b->emit_frames > 0) {
+    const size_t ch = (size_t)s->setup.channels, b1 = (size_t)s->setup.block1;
+    const size_t need_words = ch * (b1 / 2) + b1 / 16, have = (size_t)s->shared->synth_const_vecs * 4;
+    if (need_words > have) v = std::max(v, (need_words - have + 3) / 4);
+  }
+  return (v + 3) & ~(size_t)3;
+}
+
 // Dynamic LDS of the slab synthesis kernel for this batch (kernels_synth.hip: LDS map): constants + the largest slab + the
 // spectra, and room for the transforms' slices where they are laid over everything (k_synth8).
 static size_t slab_lds_bytes(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   const size_t ch = (size_t)s->setup.channels, b1 = (size_t)s->setup.block1;
-  size_t words = (size_t)s->shared->synth_const_vecs * 4 + slab_bound_vecs(b) * 4 + ch * (b1 / 2) + b1 / 16;
+  size_t words = (size_t)s->shared->synth_const_vecs * 4 + slab_lds_vecs(b) * 4 + ch * (b1 / 2) + b1 / 16;
   if (slab_wide(s)) words = std::max(words, ch * (b1 / 2 + b1 / 16));
   return words * sizeof(float);
 }
@@ -496,6 +557,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   bool fuse_gen8 = false;  // k_spectrum_gen8_imdct (below)
   // ---- slab synthesis kernels (kernels_synth.hip): spectrum + inverse MDCT from per-frame slabs fetched by LDS-DMA ----
   bool slab_done = false;
+  bool emitted = false;  // paired emission ran: k_synth wrote the PCM of the frames marked NVH_EMIT_DONE
   if (b->slabs_ready && compact && !no_fused_imdct) {
     NvhSynthArgs A;
     A.consts = s->shared->synth_consts;
@@ -507,9 +569,18 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     }
     A.const_vecs = s->shared->synth_const_vecs;
     A.stride_vecs = A.cap_vecs = b->slab_stride_vecs;
+    A.lds_vecs = (int)slab_lds_vecs(b);
     A.channels = ch;
     A.block1 = s->setup.block1;
+    A.f0 = 0; A.fstep = 1;
     const bool wide = slab_wide(s);
+    // paired emission (nvh_format.h: NVH_EMIT_*): the host marked the frames at upload; it needs the PCM buffer and the slabs
+    // in frame order
+    emitted = !wide && b->emit_frames > 0 && d_pcm != nullptr && !b->block_only && !T.no_emit && !T.lpt;
+    A.pcm = emitted ? d_pcm : nullptr;
+    A.windows = s->dev.windows;
+    A.clip = s->clip;
+    A.clipped_flag = flags + 1;
     const size_t synth_lds = slab_lds_bytes(b) + (size_t)T.lds_pad;
     if (synth_lds > 64 * 1024 && !s->ctx->synth_lds_attr_set) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_synth8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -519,7 +590,15 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     b->slot_name[0] = "-";
     b->slot_name[1] = wide ? "k_synth8" : "k_synth";
     if (wide) hipLaunchKernelGGL(k_synth8, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
-    else hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+    else if (!emitted) hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+    else {
+      // odd frames first (their planes are what the even frames overlap-add with), then the even frames, which emit
+      A.fstep = 2;
+      A.f0 = 1;
+      if (b->nframes > 1) hipLaunchKernelGGL(k_synth, dim3((unsigned)(b->nframes / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+      A.f0 = 0;
+      hipLaunchKernelGGL(k_synth, dim3((unsigned)((b->nframes + 1) / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+    }
     slab_done = true;
     fuse_gen8 = true;  // the inverse MDCT is inside: no transform kernel behind it
   }
@@ -686,8 +765,14 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       // more than two channels: the steady-state path splits a frame into runs of NVH_OLA_GW groups of four sample times, one
       // workgroup each, and interleaves through LDS (ola_sym_lds)
       if (ch > 2 && !T.no_ola_sym && T.ola_segs <= 0) segs = ((s->setup.block1 / 16) + NVH_OLA_GW - 1) / NVH_OLA_GW;
-      hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
-                         (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded, T.no_ola_sym ? 1 : 0);
+      if (!emitted)
+        hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
+                           (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded, T.no_ola_sym ? 1 : 0,
+                           (const int*)nullptr, 0);
+      else if (b->ola_count > 0)  // paired emission: only the frames k_synth left over (and the block that becomes the carried tail)
+        hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->ola_count, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
+                           (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded, T.no_ola_sym ? 1 : 0,
+                           b->d_ola_list, 1);
     } else if (!b->sequential_ola)
       hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
                          d_pcm, s->clip, flags + 1);
