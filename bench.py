@@ -212,11 +212,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 G-rand / C3 / C4 kernel-only lines")
     ap.add_argument("--no-check", action="store_true", help="profiling builds with phases masked out produce garbage PCM")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent decoder instances (own nvh_ctx / HIP stream) the passes rotate over")
     ap.add_argument("--working-set-mib", type=float, default=512.0,
                     help="lower bound of what the rotating passes touch (resident batches per stream follow from it)")
     ap.add_argument("--min-timed-ms", type=float, default=2000.0, help="lower bound of the timed region (sets passes_per_step)")
+    ap.add_argument("--no-unfused", action="store_true",
+                    help="skip the short NVH_NO_EMIT=1 run (overlap-add in k_ola_compact) that roofline.unfused reports beside the fused kernels")
     args = ap.parse_args()
 
     import torch
@@ -268,13 +270,19 @@ def main():
     # overlaps the tail of one batch's kernels with the head of the next one's (what a corpus transcoder does with
     # independent files), and a batch is revisited only after everything else -- > 2x the Infinity Cache -- went by.
     nin = max(1, args.streams)
-    per_batch_bytes = FRAMES * (2200 + 2 * ch * (BLOCK // 2) * 4)  # descriptors + compact work planes + PCM, touched per pass
+    # descriptors / slabs + compact work planes + PCM, touched per pass; with paired emission (kernels_synth.hip: the even frames
+    # overlap-add from registers) only the odd frames' planes are written and read
+    fused = not os.environ.get("NVH_NO_EMIT")
+    per_batch_bytes = FRAMES * (2200 + (ch * (BLOCK // 2) * 4) * (3 if fused else 4) // 2)
     reps = max(1, int(args.working_set_mib * (1 << 20) / (nin * per_batch_bytes) + 0.999))
     insts = []
     for k in range(nin):
-        ts = torch.cuda.Stream()  # never the legacy default stream: it serialises against every other stream
+        # the context's own HIP stream (hipStreamNonBlocking, created by nvh_ctx_create): never the legacy default stream, which
+        # serialises against every other stream.  Three instances: sustained (>= 1.5 s) HBM-resident rates measured with paired
+        # emission 135 / 155 / 135 / 148 / 148 M frames/s for 2 / 3 / 4 / 6 / 8 streams (tools/sweep_streams.sh), without it
+        # 129 / 132 / 124 / 129 / 129 M.
+        ts = None
         ctx_k = nv.Context(local_rank)
-        ctx_k.set_hip_stream(ts.cuda_stream)
         stream_k, batches_k = make_batches(nv, torch, ctx_k, headers, ll, ch, FRAMES, reps, seed_off=rank * 7 + k * 13)
         for b, _ in batches_k:
             assert b.frames == FRAMES and b.samples == FRAMES * (BLOCK // 2), (b.frames, b.samples)
@@ -282,7 +290,7 @@ def main():
     _, ctx, stream, batches0 = insts[0]
     batch, pcm = batches0[0]
     cap = pcm.numel()
-    touched = sum(b.descriptor_bytes + 2 * b.samples * ch * 4 for _, _, _, bk in insts for b, _ in bk)
+    touched = sum(b.descriptor_bytes + (3 if fused else 4) * b.samples * ch * 4 // 2 for _, _, _, bk in insts for b, _ in bk)
 
     def barrier():
         if dist is not None:
@@ -377,6 +385,24 @@ def main():
             except Exception:
                 traffic = None
         ceiling = copy_ceiling(torch, nv, ctx, insts[0][0])
+        # the same workload with the overlap-add left to k_ola_compact (NVH_NO_EMIT=1: the library reads its switches once, so
+        # a child process), short: per-kernel durations of the unfused chain next to the fused kernel's
+        unfused = None
+        if fused and world == 1 and not args.no_unfused:
+            import subprocess
+            env = dict(os.environ)
+            env["NVH_NO_EMIT"] = "1"
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "4", "--min-timed-ms", "400",
+                                    "--streams", str(nin), "--working-set-mib", str(args.working_set_mib), "--no-configs",
+                                    "--no-cpu-baseline", "--no-unfused"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                   text=True, timeout=600)
+                uj = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                unfused = {"what": "NVH_NO_EMIT=1: every overlap-add in k_ola_compact (the path of GPU-parsed batches and of more than two channels); same loop, 40 steps",
+                           "frames_per_s": uj["value"], "ms_per_pass": uj["config"]["ms_per_pass"], "kernels_ms": uj["kernels_ms"],
+                           "frac": uj["roofline"]["frac"], "whole_pass_frac": uj["roofline"]["whole_pass_frac"]}
+            except Exception as e:  # the headline does not depend on it
+                unfused = {"error": repr(e)[:200]}
         step_ms = elapsed / total_passes * 1e3
         l3_ms = el_l3 / passes_l3 * 1e3
         out = {
@@ -405,6 +431,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_build_matches": (traffic_build == nv.native.build_id()) if traffic is not None else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                         "kernel_scope": ("k_synth = residue + floor + inverse MDCT + (paired emission) window / overlap-add / clip / interleave of the "
+                                          "steady-state frames, two launches per pass (odd frames, then the emitting even frames), timed together, one stream"
+                                          if fused else "k_synth = residue + floor + inverse MDCT; overlap-add in k_ola_compact"),
+                         "unfused": unfused,
                          "working_set_MiB": touched / (1 << 20), "regime": "HBM-resident: a batch is revisited after %.0f MiB went by (Infinity Cache: 256 MiB)" % (touched / (1 << 20)),
                          # the same bytes over one whole pass of the pipeline (all kernels, the batches of the streams overlapped)
                          "whole_pass_GBps": alg_bytes / (step_ms * 1e-3) / 1e9, "whole_pass_frac": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

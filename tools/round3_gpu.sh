@@ -8,3 +8,5 @@ tail -5 gpurun_out/${TAG}_pytest.log
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 3000 gpurun_out/${TAG}_bench.json
 bash tools/profile_round.sh $TAG "round 3 ($TAG): headline loop, one stream, working set past the Infinity Cache"
+# the same loop with the overlap-add left to k_ola_compact (no paired emission): k_synth and k_ola_compact on their own
+NVH_NO_EMIT=1 bash tools/profile_round.sh ${TAG}_unfused "round 3 ($TAG, NVH_NO_EMIT=1): headline loop without paired emission, one stream"
