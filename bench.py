@@ -189,6 +189,44 @@ def config_lines(nv, torch, ctx, root):
                     "frac_of_hbm_peak_dominant_kernel": alg / (km[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "descriptor_bytes_per_frame": b.descriptor_bytes / max(b.frames, 1),
                     "prepare_us_per_batch": b.stats().get("prepare_ns", 0) / 1e3}
+        # the same batch on three decoder instances (own HIP streams), passes rotating without synchronisation as in the
+        # headline loop: what the GPU sustains when batches of independent streams follow each other (>= 0.5 s, L3-resident)
+        extra = []
+        for _ in range(2):
+            c2 = nv.Context(ctx.device)
+            s2 = nv.Stream(c2, hdr[0], hdr[1], hdr[2])
+            s2.push_packet(audio[0], -1, 0)
+            s2.synth_host()
+            for j in range(k):
+                s2.push_packet(audio[1 + j], -1, 0)
+            b2 = s2.upload_batch()
+            extra.append((c2, s2, b2, torch.empty_like(pcm)))
+        ring = [(b, pcm)] + [(e[2], e[3]) for e in extra]
+
+        def sync_all():
+            ctx.synchronize()
+            for e in extra:
+                e[0].synchronize()
+
+        def passes(n):
+            for i in range(n):
+                bb, pp = ring[i % 3]
+                bb.synth(pp.data_ptr(), pp.numel())
+            sync_all()
+
+        passes(30)
+        t0 = time.perf_counter()
+        passes(300)
+        n3 = max(300, int(0.6 / max(time.perf_counter() - t0, 1e-6) * 300))
+        t0 = time.perf_counter()
+        passes(n3)
+        el3 = time.perf_counter() - t0
+        out[key]["frames_per_s_3_streams"] = b.frames * n3 / el3
+        out[key]["us_per_batch_3_streams"] = el3 / n3 * 1e6
+        for c2, s2, b2, _ in extra:
+            b2.free()
+            s2.close()
+            c2.close()
         b.free()
         st.close()
 
@@ -322,7 +360,7 @@ def main():
             t = torch.tensor([pass_ms], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pass_ms = float(t.item())
-        pps = max(1, int(1.15 * min_ms / max(steps, 1) / max(pass_ms, 1e-6) + 0.999))  # 15 % margin: the calibration pass is slower than steady state
+        pps = max(1, int(1.35 * min_ms / max(steps, 1) / max(pass_ms, 1e-6) + 0.999))  # 35 % margin: the calibration passes are slower than steady state
         for _ in range(warmup):
             run_passes(pps)
         barrier()

@@ -121,6 +121,8 @@ struct NvhToggles {
   bool slab_stream; // NVH_SLAB_STREAM: streaming (one-shot) batches take the slab synthesis kernels too (default: resident batches only)
   bool no_ola_sym;  // NVH_NO_OLA_SYM: k_ola_compact without its read-once steady-state path (test / A-B aid)
   bool no_emit;     // NVH_NO_EMIT: no paired emission -- every frame's PCM through k_ola_compact (test / A-B aid)
+  bool emit_always; // NVH_EMIT_ALWAYS: paired emission for every batch that has a steady-state frame (default: batches that are
+                    // at least 7/8 steady state; the parity suite replays itself with this switch to cover the mixed cases)
   bool lpt;       // NVH_LPT: slabs in costliest-first launch order (k_rank_frames) instead of frame order
   bool no_slab;   // NVH_NO_SLAB: k_spectrum_imdct instead of k_prepare_slabs + k_synth (test / A-B aid)
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;

@@ -249,6 +249,17 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       }
       if ((g & 1) == 0 && steady(g + 1)) fr.emit_flags |= NVH_EMIT_NEXT;
     }
+    // Worth it for batches that are mostly steady state: the second launch and the list-driven k_ola_compact cost a stream of
+    // mixed block sizes more than the emission saves when it runs alone (C3, 256/2048 Markov chain, one HIP stream: 45.0 us
+    // per 4096 frames against 41.6 us; three streams: 24.5 against 25.1).  NVH_EMIT_ALWAYS lifts the threshold.
+    {
+      int decoded = 0;
+      for (const NvhFrame& fr : P.frames) decoded += fr.n != 0;
+      if (!nvh_toggles().emit_always && (long long)b->emit_frames * 8 < (long long)decoded * 7) {
+        for (NvhFrame& fr : P.frames) fr.emit_flags = 0;
+        b->emit_frames = 0;
+      }
+    }
     // what is left for k_ola_compact: every other frame that emits samples, and the block that becomes the carried tail
     int last = -1;
     for (int i = nf - 1; i >= 0; --i)

@@ -90,6 +90,7 @@ class Context:
 
     def __init__(self, device=0, hip_stream=None):
         self._h = C.c_void_p()
+        self.device = int(device)
         check(lib().nvh_ctx_create(int(device), C.byref(self._h)), "nvh_ctx_create")
         if hip_stream is not None:
             self.set_hip_stream(hip_stream)

@@ -246,12 +246,13 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), float((got.view(np.uint32) == ref.view(np.uint32)).mean())
 
 
-@pytest.mark.parametrize("toggle", ["NVH_SLAB_STREAM", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
+@pytest.mark.parametrize("toggle", ["NVH_SLAB_STREAM+NVH_EMIT_ALWAYS", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
                                     "NVH_SLAB_STREAM+NVH_GPU_PARSE", "NVH_SLAB_STREAM+NVH_NO_EMIT"])
 def test_fallback_kernel_paths_bit_exact(toggle):
     """The library picks kernel variants by stream shape.  Each environment toggle disables one
     level of fusion, so the whole parity suite above is replayed through the general kernels in a child process:
-    NVH_SLAB_STREAM -> streaming batches (everything the reader decodes) through the slab synthesis kernels k_prepare_slabs +
+    NVH_SLAB_STREAM (+ NVH_EMIT_ALWAYS: paired emission for every batch with a steady-state frame, not only those that are 7/8
+    steady state) -> streaming batches (everything the reader decodes) through the slab synthesis kernels k_prepare_slabs +
     k_synth / k_synth8, which by default serve resident batches only (nvh_batch_upload: the conversion pays when a batch is
     synthesised more than once) -- this replay also takes tests/test_full_depth.py (C2 / C3 / C4 / C5 on full-depth packets)
     along, so that every parity test of the suite has run through both kernel families; NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact,
@@ -269,7 +270,7 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     env["NVH_TEST_CHILD"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = [os.path.join(root, "tests", "test_gpu_parity.py")]
-    if toggle in ("NVH_SLAB_STREAM", "NVH_SLAB_STREAM+NVH_NO_EMIT"):
+    if toggle in ("NVH_SLAB_STREAM+NVH_EMIT_ALWAYS", "NVH_SLAB_STREAM+NVH_NO_EMIT"):
         files.append(os.path.join(root, "tests", "test_full_depth.py"))
     r = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)

@@ -5,6 +5,7 @@ packet parser, plus the four shipped files with random batch sizes; every PCM mu
   python tools/stress_slab.py [seconds]"""
 import os, sys, time
 os.environ["NVH_SLAB_STREAM"] = "1"  # streaming batches through the slab kernels (by default they serve resident batches only)
+os.environ["NVH_EMIT_ALWAYS"] = "1"  # ... with paired emission whenever a batch has a steady-state frame (default: 7/8 of its frames)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import nvorbis_amd as nv

@@ -9,6 +9,14 @@ import bench
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 headers, audio, ch = bench.ll_packets(nv, os.path.join(root, "tests", "golden", "3test.ogg"))
+if len(sys.argv) > 3 and sys.argv[3] == "c3":  # block kinds from the 256/2048 Markov chain, full depth (bench.py: C3_markov)
+    import numpy as np
+    from tests import vorbis_encode as ve
+    hdr3 = ve.shipped_headers(open(os.path.join(root, "tests", "golden", "3test.ogg"), "rb").read())
+    S3 = ve.setup_of(hdr3)
+    pool3 = ve.packet_pool(S3, 20260928, per_kind=256)
+    p, _ = ve.stream_from_pool(S3, hdr3, pool3, ve.markov_kinds(np.random.default_rng(7), 4700), np.random.default_rng(7))
+    headers, audio = p[:3], p[3:]
 nctx = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ctxs = [nv.Context(0) for _ in range(nctx)]
 sets = []
