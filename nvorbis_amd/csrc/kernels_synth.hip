@@ -21,12 +21,20 @@
 //   * the workgroup issues the slab's first 4 KB (global_load_lds_dwordx4, 1 KB per wavefront-instruction) and the
 //     stream constants (inverse_dB_table + lattice pool) before it knows anything about the frame, clears the spectrum
 //     while they fly, and passes one barrier: ONE memory round trip, no staging instructions, no VGPR round trip;
-//   * the header then comes out of LDS; only frames whose slab exceeds 4 KB fetch the rest (second round trip);
+//   * the header arrives by a scalar load issued next to the DMA; a slab beyond 4 KB has its rest fetched in front of that
+//     same barrier;
 //   * the residue walk follows chain-major records (one ds_read_b128 per cascade stage, no link array); a lane owns eight
 //     consecutive vector components of a chain through all cascade stages and, for mono / stereo, multiplies them by the floor
 //     curve (segment list and per-four-bins segment table straight from the slab) before its one store.
-// The transform is k_spectrum_imdct's (imdct_wave.h), the output the compact form k_ola_compact reads.  Bit-exactness: the additions of a partition happen in stage order inside the owning lane,
-// every float expression is one rounded operation (-ffp-contract=off).
+// The transform is k_spectrum_imdct's (imdct_wave.h), the output the compact form k_ola_compact reads -- or, for mono / stereo
+// batches in the steady state of a stream, no plane at all: PAIRED EMISSION (synth_emit below; nvh_format.h: NVH_EMIT_*).  The
+// odd frames of a batch are synthesised first and leave their planes; the even frames follow in a second launch, keep their
+// transform output in registers and do the window / overlap-add / clip / interleave (Mode.cs:160-166, StreamDecoder.cs:532-541,
+// :391-415, Utils.cs:30-43) of both overlaps they take part in, with the neighbours' quarters fetched by LDS-DMA from the odd
+// planes: half the planes are never written, none is read by a second kernel pass, and k_ola_compact runs only over the frames
+// outside the steady state (block-size switches, the first frame of a batch, the block that becomes the carried tail).
+// Bit-exactness: the additions of a partition happen in stage order inside the owning lane, the overlap-add is ola_sym's
+// arithmetic (kernels.hip), every float expression is one rounded operation (-ffp-contract=off).
 #include <hip/hip_runtime.h>
 
 #include "imdct_wave.h"
