@@ -407,6 +407,9 @@ def main():
         # SURVEY 8d / DESIGN.md: algorithmic bytes of one ch-frame = n/2*4 B spectrum in + n/2*4 B PCM out = 4n B ... per
         # pipeline stage that means: every kernel of the chain moves one n/2-float vector in and one out per ch-frame
         alg_bytes = FRAMES * ch * 4 * BLOCK
+        # paired emission: k_synth runs twice per pass, each launch over half of the batch's frames (the library times the two
+        # together); per LAUNCH, like rocprofv3's average and the PMC traffic: half the bytes, half the duration
+        launches = 2 if (fused and names[dom] == "k_synth") else 1
         dom_ms = km[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh);
@@ -468,7 +471,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_build_matches": (traffic_build == nv.native.build_id()) if traffic is not None else None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes // launches, "avg_launch_ms": dom_ms / launches,
+                         "launches_per_pass": launches,
                          "kernel_scope": ("k_synth = residue + floor + inverse MDCT + (paired emission) window / overlap-add / clip / interleave of the "
                                           "steady-state frames, two launches per pass (odd frames, then the emitting even frames), timed together, one stream"
                                           if fused else "k_synth = residue + floor + inverse MDCT; overlap-add in k_ola_compact"),
