@@ -102,10 +102,12 @@ struct NvhSynthArgs {
 };
 
 #ifdef __HIPCC__
-__device__ __forceinline__ float clip_value(float v, int* clipped) {  // Utils.cs:30-43
-  if (v > .99999994f) { *clipped = 1; return 0.99999994f; }
-  if (v < -.99999994f) { *clipped = 1; return -0.99999994f; }
-  return v;
+// Utils.cs:30-43, without branches (two compares, two selects; the flag is an OR of the compare masks): the early-return form
+// compiles to two exec-mask regions per sample.  A NaN compares false twice and passes through, as in the reference.
+__device__ __forceinline__ float clip_value(float v, int* clipped) {
+  const bool hi = v > .99999994f, lo = v < -.99999994f;
+  *clipped |= (int)(hi | lo);
+  return hi ? 0.99999994f : (lo ? -0.99999994f : v);
 }
 
 // HasClipped (StreamDecoder.cs:728) is sticky: one lane per wavefront that clipped looks at the flag and only sets it
