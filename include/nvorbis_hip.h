@@ -276,7 +276,8 @@ void nvh_batch_free(nvh_batch *b);
 /* ---- container helper (minimal forward-only demux so .ogg files can feed the path) ----
  * Splits the first logical stream of an Ogg file into packets the way NVorbis' seekable reader
  * delivers them (Ogg/PageReader.cs:27-93, Ogg/PacketProvider.cs:324-438).  Call with NULL outputs to
- * size, then again with buffers. */
+ * size, then again with buffers: the sizing call keeps its result for the fill call that follows on the same
+ * thread with the same bytes (the file is demultiplexed once; any other call sequence simply demultiplexes again). */
 int nvh_ogg_demux(const uint8_t *bytes, size_t len, uint8_t *pkt_bytes, int64_t pkt_bytes_cap, int64_t *offsets,
                   int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets, int64_t *total_bytes);
 /* The same for logical stream `stream_index` of a multiplexed or chained file; *nstreams (may be NULL) = number of

@@ -229,9 +229,14 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
             st.close()
         arrays[i] = pa
 
+    import os
+    import time
+    timing = bool(os.environ.get("NVH_CORPUS_TIMING"))
+    t_start = time.perf_counter()
     errors = _run_pool(n, workers, device, index_one)
     if errors:
         raise RuntimeError("index failed for files %s: %r" % ([i for i, _ in errors], errors[0][1]))
+    t_index = time.perf_counter()
     offs = np.zeros(n + 1, np.int64)
     offs[1:] = np.cumsum(totals)
     arena = torch.empty(max(int(offs[-1]), 1), dtype=torch.float32, device="cuda:%d" % device)
@@ -264,9 +269,14 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
         finally:
             st.close()
 
+    t_alloc = time.perf_counter()
     errors = _run_pool(n, workers, device, decode_one)
     if errors:
         raise RuntimeError("decode failed for files %s: %r" % ([order[k] for k, _ in errors], errors[0][1]))
+    if timing:
+        import sys
+        sys.stderr.write("decode_files_to_device: demux + index pass %.3f s, arena %.3f s, decode pass %.3f s (%d workers)\n" % (
+            t_index - t_start, t_alloc - t_index, time.perf_counter() - t_alloc, workers))
     views = [arena[int(offs[i]):int(offs[i + 1])] for i in range(n)]
     return arena, views
 

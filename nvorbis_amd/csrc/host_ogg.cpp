@@ -31,24 +31,47 @@ struct Page {
   std::vector<int> pk_off, pk_len;
 };
 
+// CRC-32 of an Ogg page (polynomial 0x04c11db7, most significant bit first, no reflection, initial value 0: Ogg/Crc.cs:5-40),
+// eight bytes per step: t[k][b] = the CRC register after byte b and k zero bytes.
 struct CrcTable {
-  uint32_t t[256];
+  uint32_t t[8][256];
   CrcTable() {
     for (uint32_t i = 0; i < 256; i++) {
       uint32_t s = i << 24;
       for (int j = 0; j < 8; ++j) s = (s << 1) ^ (s >= (1u << 31) ? 0x04c11db7u : 0u);
-      t[i] = s;
+      t[0][i] = s;
     }
+    for (int k = 1; k < 8; k++)
+      for (uint32_t i = 0; i < 256; i++) t[k][i] = (t[k - 1][i] << 8) ^ t[0][t[k - 1][i] >> 24];
   }
 };
 
-bool page_crc_ok(const uint8_t* pg, size_t total) {
+inline uint32_t be32(const uint8_t* p) {
+  return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+uint32_t crc_update(uint32_t crc, const uint8_t* p, size_t n) {
   static const CrcTable tab;
-  uint32_t crc = 0;
-  for (size_t i = 0; i < total; i++) {
-    uint8_t b = (i >= 22 && i < 26) ? 0 : pg[i];
-    crc = (crc << 8) ^ tab.t[b ^ (crc >> 24)];
+  while (n >= 8) {
+    const uint32_t a = crc ^ be32(p), b = be32(p + 4);
+    crc = tab.t[7][a >> 24] ^ tab.t[6][(a >> 16) & 255u] ^ tab.t[5][(a >> 8) & 255u] ^ tab.t[4][a & 255u] ^
+          tab.t[3][b >> 24] ^ tab.t[2][(b >> 16) & 255u] ^ tab.t[1][(b >> 8) & 255u] ^ tab.t[0][b & 255u];
+    p += 8;
+    n -= 8;
   }
+  while (n--) crc = (crc << 8) ^ tab.t[0][*p++ ^ (crc >> 24)];
+  return crc;
+}
+
+// The page's checksum field (bytes 22..25) counts as zero (Ogg/PageReaderBase.cs:33-70): the header -- 27 bytes + the segment
+// table, total >= that by the caller's bounds check -- goes through a copy with the field cleared, the body as it lies.
+bool page_crc_ok(const uint8_t* pg, size_t total) {
+  uint8_t hdr[27 + 255];
+  const size_t hlen = 27 + (size_t)pg[26];
+  std::memcpy(hdr, pg, hlen);
+  hdr[22] = hdr[23] = hdr[24] = hdr[25] = 0;
+  uint32_t crc = crc_update(0, hdr, hlen);
+  crc = crc_update(crc, pg + hlen, total - hlen);
   uint32_t want = (uint32_t)pg[22] | ((uint32_t)pg[23] << 8) | ((uint32_t)pg[24] << 16) | ((uint32_t)pg[25] << 24);
   return crc == want;
 }

@@ -799,27 +799,87 @@ extern "C" void nvh_batch_free(nvh_batch* b) {
 // container helper
 // ------------------------------------------------------------------------------------------------
 
+// The two-call protocol (sizing call, then the call that fills the caller's arrays) would demultiplex a file twice: the
+// sizing call parks its result here, per thread, and the fill call that follows on the same bytes takes it.  "The same bytes"
+// is checked by address, length, stream and a fingerprint of 64-bit words sampled across the buffer (every 4 KB and both
+// ends), so a caller that reuses a buffer for another file of the same length is not handed the old packets.
+namespace {
+struct DemuxMemo {
+  const uint8_t* bytes = nullptr;
+  size_t len = 0;
+  int stream = -1, nstreams = 0;
+  bool forward = false;
+  uint64_t print = 0;
+  nvh::OggPackets pk;
+};
+thread_local DemuxMemo g_demux_memo;
+
+uint64_t demux_fingerprint(const uint8_t* bytes, size_t len) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)len;
+  auto word = [&](size_t off) {
+    uint64_t w = 0;
+    std::memcpy(&w, bytes + off, len - off >= 8 ? 8 : len - off);
+    h = (h ^ w) * 0x100000001B3ull;
+    h ^= h >> 29;
+  };
+  for (size_t off = 0; off < len; off += 4096) word(off);
+  if (len > 8) word(len - 8);
+  return h;
+}
+
+template <typename Demux>
+int demux_two_call(bool forward, Demux demux, const uint8_t* bytes, size_t len, int stream_index, uint8_t* pkt_bytes,
+                   int64_t pkt_bytes_cap, int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
+                   int64_t* total_bytes, int* nstreams) {
+  if (!bytes || !npackets || !total_bytes || stream_index < 0) return NVH_ERR_ARGUMENT;
+  DemuxMemo& M = g_demux_memo;
+  const bool sizing = !pkt_bytes && !offsets && !granules && !flags;
+  const uint64_t print = demux_fingerprint(bytes, len);
+  nvh::OggPackets local;
+  nvh::OggPackets* pk = &local;
+  int ns = 0;
+  if (!sizing && M.bytes == bytes && M.len == len && M.stream == stream_index && M.forward == forward && M.print == print) {
+    pk = &M.pk;  // the sizing call's result
+    ns = M.nstreams;
+  } else {
+    if (sizing) pk = &M.pk;
+    M.bytes = nullptr;
+    int rc = demux(bytes, len, *pk, stream_index, &ns);
+    if (rc != NVH_OK) return rc;
+    if (sizing) {
+      M.bytes = bytes; M.len = len; M.stream = stream_index; M.forward = forward; M.print = print; M.nstreams = ns;
+    }
+  }
+  if (nstreams) *nstreams = ns;
+  const int n = (int)pk->granule.size();
+  *npackets = n;
+  *total_bytes = (int64_t)pk->bytes.size();
+  if (sizing) return NVH_OK;
+  int rc = NVH_OK;
+  if (pkt_cap < n || pkt_bytes_cap < (int64_t)pk->bytes.size() || !pkt_bytes || !offsets || !granules || !flags) {
+    rc = NVH_ERR_ARGUMENT;
+  } else {
+    if (!pk->bytes.empty()) std::memcpy(pkt_bytes, pk->bytes.data(), pk->bytes.size());
+    std::memcpy(offsets, pk->offs.data(), sizeof(int64_t) * (size_t)(n + 1));
+    if (n) {
+      std::memcpy(granules, pk->granule.data(), sizeof(int64_t) * (size_t)n);
+      std::memcpy(flags, pk->flags.data(), (size_t)n);
+    }
+  }
+  if (pk == &M.pk) {  // taken: release the memory (a thread that decodes one big file does not keep a copy of it)
+    M.bytes = nullptr;
+    nvh::OggPackets().bytes.swap(M.pk.bytes);
+  }
+  return rc;
+}
+}  // namespace
+
 extern "C" int nvh_ogg_demux_stream(const uint8_t* bytes, size_t len, int stream_index, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
                                     int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
                                     int64_t* total_bytes, int* nstreams) {
   return nvh_guard([&]() -> int {
-    if (!bytes || !npackets || !total_bytes || stream_index < 0) return NVH_ERR_ARGUMENT;
-    nvh::OggPackets pk;
-    int rc = nvh::ogg_demux(bytes, len, pk, stream_index, nstreams);
-    if (rc != NVH_OK) return rc;
-    int n = (int)pk.granule.size();
-    *npackets = n;
-    *total_bytes = (int64_t)pk.bytes.size();
-    if (!pkt_bytes && !offsets && !granules && !flags) return NVH_OK;  // sizing call
-    if (pkt_cap < n || pkt_bytes_cap < (int64_t)pk.bytes.size() || !pkt_bytes || !offsets || !granules || !flags)
-      return NVH_ERR_ARGUMENT;
-    if (!pk.bytes.empty()) std::memcpy(pkt_bytes, pk.bytes.data(), pk.bytes.size());
-    std::memcpy(offsets, pk.offs.data(), sizeof(int64_t) * (size_t)(n + 1));
-    if (n) {
-      std::memcpy(granules, pk.granule.data(), sizeof(int64_t) * (size_t)n);
-      std::memcpy(flags, pk.flags.data(), (size_t)n);
-    }
-    return NVH_OK;
+    return demux_two_call(false, [](const uint8_t* b, size_t l, nvh::OggPackets& o, int si, int* ns) { return nvh::ogg_demux(b, l, o, si, ns); },
+                          bytes, len, stream_index, pkt_bytes, pkt_bytes_cap, offsets, granules, flags, pkt_cap, npackets, total_bytes, nstreams);
   });
 }
 
@@ -828,23 +888,8 @@ extern "C" int nvh_ogg_demux_forward(const uint8_t* bytes, size_t len, int strea
                                      int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
                                      int64_t* total_bytes, int* nstreams) {
   return nvh_guard([&]() -> int {
-    if (!bytes || !npackets || !total_bytes || stream_index < 0) return NVH_ERR_ARGUMENT;
-    nvh::OggPackets pk;
-    int rc = nvh::ogg_demux_forward(bytes, len, pk, stream_index, nstreams);
-    if (rc != NVH_OK) return rc;
-    int n = (int)pk.granule.size();
-    *npackets = n;
-    *total_bytes = (int64_t)pk.bytes.size();
-    if (!pkt_bytes && !offsets && !granules && !flags) return NVH_OK;  // sizing call
-    if (pkt_cap < n || pkt_bytes_cap < (int64_t)pk.bytes.size() || !pkt_bytes || !offsets || !granules || !flags)
-      return NVH_ERR_ARGUMENT;
-    if (!pk.bytes.empty()) std::memcpy(pkt_bytes, pk.bytes.data(), pk.bytes.size());
-    std::memcpy(offsets, pk.offs.data(), sizeof(int64_t) * (size_t)(n + 1));
-    if (n) {
-      std::memcpy(granules, pk.granule.data(), sizeof(int64_t) * (size_t)n);
-      std::memcpy(flags, pk.flags.data(), (size_t)n);
-    }
-    return NVH_OK;
+    return demux_two_call(true, [](const uint8_t* b, size_t l, nvh::OggPackets& o, int si, int* ns) { return nvh::ogg_demux_forward(b, l, o, si, ns); },
+                          bytes, len, stream_index, pkt_bytes, pkt_bytes_cap, offsets, granules, flags, pkt_cap, npackets, total_bytes, nstreams);
   });
 }
 
