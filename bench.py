@@ -117,6 +117,54 @@ def cpu_baseline(headers, ll, seconds=12.0):
     return out
 
 
+def end_to_end(nv, ctx, headers, ll, frames=32768, rounds=6):
+    """The PCIe-inclusive rate of the boundary on the same workload, one host thread (never `value`): packets
+    in host memory -> parse -> kernels -> PCM in page-locked host memory, `frames` packets per look-ahead batch.  Host parser with
+    a blocking read-back, and GPU packet parser (kernels_parse.hip) with the pipelined read-back (two batches outstanding)."""
+    import numpy as np
+    pk = [ll[(i + 1) % len(ll)] for i in range(frames)]
+    offs = np.zeros(frames + 1, np.int64)
+    offs[1:] = np.cumsum([len(p) for p in pk])
+    pa = nv.PacketArray(np.frombuffer(b"".join(pk), np.uint8), offs, np.full(frames, -1, np.int64), np.zeros(frames, np.uint8))
+    out = {"what": "packets in host memory -> PCM in page-locked host memory, one host thread, %d packets per batch; not `value`" % frames}
+    st = nv.Stream(ctx, *headers)
+    st.push_packet(ll[0], -1, 0)
+    st.synth_host()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        assert st.push_packets(pa, 0, frames) == frames
+        st.synth_host(pinned=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    out["host_parser_frames_per_s"] = frames / best
+    st.close()
+    st = nv.Stream(ctx, *headers)
+    st.set_gpu_parse(True)
+    st.push_packet(ll[0], -1, 0)
+    st.synth_host()
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        outstanding = 0
+        for _r in range(rounds):
+            assert st.push_packets(pa, 0, frames) == frames
+            st.synth_begin()
+            outstanding += 1
+            if outstanding == 2:
+                st.synth_end()
+                outstanding -= 1
+        while outstanding:
+            st.synth_end()
+            outstanding -= 1
+        dt = (time.perf_counter() - t0) / rounds
+        best = dt if best is None or dt < best else best
+    out["gpu_parser_pipelined_frames_per_s"] = frames / best
+    out["gpu_parser_pcm_GBps_over_pcie"] = frames * (BLOCK // 2) * 2 * 4 / best / 1e9
+    st.close()
+    return out
+
+
 def copy_ceiling(torch, nv, ctx, ts, mib=1024, iters=20):
     """Measured HBM ceiling of this GPU: the library's float4 copy kernel (nvh_measure_copy) over buffers well past the
     256 MiB Infinity Cache; bytes read + bytes written per second, hipEvents on the context's stream."""
@@ -493,6 +541,10 @@ def main():
         if world == 1 and not args.no_configs:
             out["configs"] = config_lines(nv, torch, ctx, ROOT)
         if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["end_to_end"] = end_to_end(nv, ctx, headers, ll)
+            except Exception as e:  # reported beside the headline, never part of it
+                out["end_to_end"] = {"error": repr(e)[:200]}
             out["cpu_baseline"] = cpu_baseline(headers, ll)
         print(json.dumps(out), flush=True)
     for _, ctx_k, stream_k, batches_k in insts:
