@@ -163,6 +163,57 @@ def test_batch_repeat_and_periodicity_full_size(gpu_ctx, ogg_bytes):
     st.close()
 
 
+@pytest.mark.parametrize("workload", ["greal", "c3_markov", "grand_mono_tail"])
+def test_resident_batches_vs_oracle(oracle, gpu_ctx, ogg_bytes, workload):
+    """The path bench.py times -- packets parsed once, the batch resident in HBM (nvh_batch_upload), synthesised by the slab
+    kernels with paired emission (even frames overlap-add, clip and interleave in k_synth; k_ola_compact only over the frames
+    outside the steady state) -- against the oracle, bit for bit: the bench workload, a 256 / 2048 Markov stream on full-depth
+    packets (block-size switches inside the batch), and batches cut at odd / even lengths so that the last frame is an emitter
+    once and a plane writer once.  Synthesised twice into different buffers (resident means repeatable)."""
+    torch = _torch()
+    import bench
+    import nvorbis_amd as nv
+    import os
+    from tests import vorbis_encode as ve
+    if workload == "greal":
+        headers, ll, ch = bench.ll_packets(nv, os.path.join(bench.ROOT, "tests", "golden", "3test.ogg"))
+        audio = [ll[i % len(ll)] for i in range(701)]
+        cuts = [700]
+    else:
+        hdr3 = ve.shipped_headers(ogg_bytes["3test"])
+        S3 = ve.setup_of(hdr3)
+        pool3 = ve.packet_pool(S3, 20260928, per_kind=64)
+        kinds = ve.markov_kinds(np.random.default_rng(11), 1300) if workload == "c3_markov" else np.ones(1300, dtype=bool)
+        p, _ = ve.stream_from_pool(S3, hdr3, pool3, kinds, np.random.default_rng(5))
+        headers, audio, ch = p[:3], p[3:], 2
+        cuts = [1200] if workload == "c3_markov" else [511, 512]
+    packets = list(headers) + list(audio)
+    ref, info = oracle.decode_packets(packets, [-1] * len(packets), [0] * len(packets))
+    for cut in cuts:
+        st = nv.Stream(gpu_ctx, headers[0], headers[1], headers[2])
+        st.push_packet(audio[0], -1, 0)
+        first = st.synth_host()  # the first packet primes the overlap and emits nothing (StreamDecoder.cs:446-450)
+        assert first.size == 0
+        for i in range(cut):
+            st.push_packet(audio[1 + i], -1, 0)
+        b = st.upload_batch()
+        assert b.frames == cut
+        n = b.samples * ch
+        pcm1 = torch.zeros(n, dtype=torch.float32, device="cuda")
+        pcm2 = torch.full_like(pcm1, 7.0)
+        torch.cuda.synchronize()
+        b.synth(pcm1.data_ptr(), n)
+        b.synth(pcm2.data_ptr(), n)
+        gpu_ctx.synchronize()
+        torch.cuda.synchronize()
+        got = pcm1.cpu().numpy()
+        assert n <= ref.size
+        assert np.array_equal(got.view(np.uint32), ref[:n].view(np.uint32)), (workload, cut, float(np.abs(got - ref[:n]).max()))
+        assert torch.equal(pcm1, pcm2)
+        b.free()
+        st.close()
+
+
 def test_bench_workload_prefix_vs_oracle(oracle, gpu_ctx):
     """First 600 frames of the bench workload against the oracle, bit-exact."""
     import bench
