@@ -382,6 +382,14 @@ def config(name):
                  mappings=[lambda w: write_mapping(w, 1, 1, [], None, [(0, 0)]),
                            lambda w: write_mapping(w, 1, 1, [], None, [(1, 1)])],
                  modes=[(0, 0), (1, 1)])
+    elif name == "mono_res1_2048":            # mono through the slab kernels (blocks 256 / 2048): paired emission with one channel
+        c.update(channels=1, block0=256, block1=2048,
+                 floors=[_floor1_small(0, 1), _floor1_long(0, 1, 10)],
+                 residues=[lambda w: write_residue(w, 1, 0, 128, 16, 2, [1, 2, 7, 0], [3, 4, 3, 4, 5]),
+                           lambda w: write_residue(w, 1, 8, 1000, 32, 2, [3, 1, 4, 6], [3, 4, 5, 5, 4, 3])],
+                 mappings=[lambda w: write_mapping(w, 1, 1, [], None, [(0, 0)]),
+                           lambda w: write_mapping(w, 1, 1, [], None, [(1, 1)])],
+                 modes=[(0, 0), (1, 1)])
     elif name in ("ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"):   # the channel counts no other config has
         nch, rtype = int(name[2]), int(name[-1])
         couple = [(0, 1), (2, 3)] if nch == 4 else [(0, 2), (3, 4)] if nch == 5 else [(0, 1), (2, 3), (5, 6)] if nch == 7 else [(0, 7), (1, 6), (2, 5)]
@@ -399,7 +407,7 @@ def config(name):
 
 
 CONFIG_NAMES = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
-                "floor0_stereo", "two_submaps", "equal_blocks_overrun", "mono_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"]
+                "floor0_stereo", "two_submaps", "equal_blocks_overrun", "mono_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2", "mono_res1_2048"]
 
 
 def filtered_stream(oracle, name, npackets, seed, consistent_windows=True):
