@@ -672,28 +672,6 @@ __device__ __forceinline__ float compact_value(const float* __restrict__ plane, 
   return y * w[idx];
 }
 
-// Four consecutive block positions idx0 .. idx0+3 (idx0 a multiple of 4: a group never straddles a quarter).
-__device__ __forceinline__ float4 compact_value4(const float* __restrict__ plane, const float* __restrict__ w, int n,
-                                                 int exec, int idx0) {
-  const int n2 = n >> 1, n4 = n >> 2;
-  float4 y;
-  if (exec) {
-    if (idx0 < n4 || (idx0 >= n2 && idx0 < n2 + n4)) {
-      y = *reinterpret_cast<const float4*>(plane + idx0);
-    } else if (idx0 < n2) {
-      const float4 r = *reinterpret_cast<const float4*>(plane + (n2 - 4 - idx0));
-      y = make_float4(-r.w, -r.z, -r.y, -r.x);
-    } else {
-      const float4 r = *reinterpret_cast<const float4*>(plane + (n + n2 - 4 - idx0));
-      y = make_float4(r.w, r.z, r.y, r.x);
-    }
-  } else {
-    y = idx0 < n2 ? *reinterpret_cast<const float4*>(plane + idx0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const float4 ww = *reinterpret_cast<const float4*>(w + idx0);
-  return make_float4(y.x * ww.x, y.y * ww.y, y.z * ww.z, y.w * ww.w);
-}
-
 // Overlap-add of one frame, CH channels, everything in units of four samples: a lane produces four consecutive
 // sample times of every channel and writes them as CH 16-byte stores (its 4*CH interleaved floats are contiguous).
 template <int CH>

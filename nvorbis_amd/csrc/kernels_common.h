@@ -99,6 +99,8 @@ struct NvhSynthArgs {
   const float* windows;
   int clip;
   int* clipped_flag;
+  const float* carry;       // the carried tail this batch's first frame overlaps with (fully windowed), NVH_EMIT_SELF_CARRY
+  float* carry_out;         // receives the last decoded block, fully windowed (NVH_EMIT_CARRY_OUT); nullptr: k_ola_compact writes it
 };
 
 #ifdef __HIPCC__
@@ -108,6 +110,31 @@ __device__ __forceinline__ float clip_value(float v, int* clipped) {
   const bool hi = v > .99999994f, lo = v < -.99999994f;
   *clipped |= (int)(hi | lo);
   return hi ? 0.99999994f : (lo ? -0.99999994f : v);
+}
+
+// Four consecutive positions idx0 .. idx0+3 of a block (idx0 a multiple of 4: a group never straddles a quarter) from its compact
+// plane -- the two independent quarters y[0, n/4) and y[n/2, 3n/4) of the inverse MDCT, the others follow from
+// y[n/2-1-x] = -y[x] and y[n-1-x] = y[n/2+x] (Mdct.cs:275-303); a channel that does not execute keeps its residue in
+// [0, n/2) and zeros behind it (Mapping.cs:192-196) -- times the window (Mode.cs:160-166).
+__device__ __forceinline__ float4 compact_value4(const float* __restrict__ plane, const float* __restrict__ w, int n,
+                                                 int exec, int idx0) {
+  const int n2 = n >> 1, n4 = n >> 2;
+  float4 y;
+  if (exec) {
+    if (idx0 < n4 || (idx0 >= n2 && idx0 < n2 + n4)) {
+      y = *reinterpret_cast<const float4*>(plane + idx0);
+    } else if (idx0 < n2) {
+      const float4 r = *reinterpret_cast<const float4*>(plane + (n2 - 4 - idx0));
+      y = make_float4(-r.w, -r.z, -r.y, -r.x);
+    } else {
+      const float4 r = *reinterpret_cast<const float4*>(plane + (n + n2 - 4 - idx0));
+      y = make_float4(r.w, r.z, r.y, r.x);
+    }
+  } else {
+    y = idx0 < n2 ? *reinterpret_cast<const float4*>(plane + idx0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float4 ww = *reinterpret_cast<const float4*>(w + idx0);
+  return make_float4(y.x * ww.x, y.y * ww.y, y.z * ww.z, y.w * ww.w);
 }
 
 // HasClipped (StreamDecoder.cs:728) is sticky: one lane per wavefront that clipped looks at the flag and only sets it

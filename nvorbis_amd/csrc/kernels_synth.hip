@@ -508,6 +508,11 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
       (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
     H.flags |= NVH_SLAB_FUSE_FLOOR;
   // paired emission (nvh_format.h: NVH_EMIT_*; the host decided at upload): the parameters k_synth needs about the overlaps
+  if (nch <= 2 && (fr.emit_flags & NVH_EMIT_CARRY_OUT)) {
+    H.exec_mask |= NVH_SLABX_CARRY_OUT;
+    H.chan[2] = fr.window_off;
+  }
+  if (nch <= 2 && (fr.emit_flags & NVH_EMIT_SELF_CARRY)) H.exec_mask |= NVH_SLABX_SELF_CARRY;
   if (nch <= 2 && (fr.emit_flags & (NVH_EMIT_SELF | NVH_EMIT_NEXT))) {
     H.chan[2] = fr.window_off; H.chan[3] = fr.ov_window_off; H.chan[6] = (uint32_t)fr.out_pos;
     if (fr.emit_flags & NVH_EMIT_SELF) H.flags |= NVH_SLAB_EMIT_SELF;
@@ -518,6 +523,74 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
     }
   }
   put_header();
+}
+
+// NVH_EMIT_CARRY_OUT: the block that becomes the carried tail of the next batch (StreamDecoder's _prevPacketBuf), stored fully
+// windowed like k_ola_compact stores it -- from the frame's own plane, which its wavefronts have just written: the caller's
+// __syncthreads() is the workgroup-scope release / acquire between those stores and these loads (one CU, one L1).  One
+// workgroup per batch.
+template <int NT>
+__device__ __forceinline__ void synth_carry_out(const NvhSynthArgs& A, const float* plane0, int n, int nch, unsigned exec_mask,
+                                                unsigned window_off, int tid) {
+  const float* __restrict__ w = A.windows + window_off;
+  const int quads = n >> 2;
+  for (int o = tid; o < quads * nch; o += NT) {
+    const int c = o >= quads ? 1 : 0, g = o - c * quads;  // at most two channels
+    *reinterpret_cast<float4*>(A.carry_out + (long long)c * A.block1 + 4 * g) =
+        compact_value4(plane0 + (long long)c * A.block1, w, n, (int)((exec_mask >> c) & 1u), 4 * g);
+  }
+}
+
+// NVH_EMIT_SELF_CARRY: the batch's first frame over the carried tail of the batch before, which was windowed when it was stored
+// (k_ola_compact's prev_full case: no second window multiply, the tail in time order).  The frame's own first quarter A lies in
+// its channel's dead transform slice (synth_emit).  One workgroup per batch: out of line, so that the steady-state loop keeps
+// its registers.
+template <int NT>
+__device__ __forceinline__ void synth_self_carry(const NvhSynthArgs& A, const float* spec, int n, int nch, unsigned window_off,
+                                              unsigned out_pos, int tid) {
+  const int half = n >> 1;
+  const float* __restrict__ w = A.windows + window_off;
+  float* out = A.pcm + (long long)out_pos * nch;
+  int clipped = 0;
+  for (int g = tid; g < (n >> 4); g += NT) {
+    const int i0 = 4 * g;
+    const float4 wf = *reinterpret_cast<const float4*>(w + i0);
+    const float4 wm = *reinterpret_cast<const float4*>(w + (half - 4 - i0));
+    float fwd[8], mir[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < nch) {
+        const float4 a = *reinterpret_cast<const float4*>(spec + c * half + i0);
+        const float* cp = A.carry + (long long)c * A.block1;
+        const float4 tt = *reinterpret_cast<const float4*>(cp + half + i0);
+        const float4 r = *reinterpret_cast<const float4*>(cp + (n - 4 - i0));
+        float4 v = make_float4(a.x * wf.x, a.y * wf.y, a.z * wf.z, a.w * wf.w);
+        v.x = v.x + tt.x; v.y = v.y + tt.y; v.z = v.z + tt.z; v.w = v.w + tt.w;
+        float4 u = make_float4(-a.w * wm.x, -a.z * wm.y, -a.y * wm.z, -a.x * wm.w);
+        u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
+        if (A.clip) {
+          v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
+          v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
+          u.x = clip_value(u.x, &clipped); u.y = clip_value(u.y, &clipped);
+          u.z = clip_value(u.z, &clipped); u.w = clip_value(u.w, &clipped);
+        }
+        fwd[c] = v.x; fwd[2 + c] = v.y; fwd[4 + c] = v.z; fwd[6 + c] = v.w;
+        mir[c] = u.x; mir[2 + c] = u.y; mir[4 + c] = u.z; mir[6 + c] = u.w;
+      }
+    }
+    if (nch == 2) {
+      float4* of = reinterpret_cast<float4*>(out) + 2 * (long long)g;
+      float4* om = reinterpret_cast<float4*>(out) + 2 * (long long)((n >> 3) - 1 - g);
+      of[0] = make_float4(fwd[0], fwd[1], fwd[2], fwd[3]);
+      of[1] = make_float4(fwd[4], fwd[5], fwd[6], fwd[7]);
+      om[0] = make_float4(mir[0], mir[1], mir[2], mir[3]);
+      om[1] = make_float4(mir[4], mir[5], mir[6], mir[7]);
+    } else {
+      reinterpret_cast<float4*>(out)[g] = make_float4(fwd[0], fwd[2], fwd[4], fwd[6]);
+      reinterpret_cast<float4*>(out)[(n >> 3) - 1 - g] = make_float4(mir[0], mir[2], mir[4], mir[6]);
+    }
+  }
+  if (A.clip) report_clipped(clipped, A.clipped_flag);
 }
 
 // ---- paired emission (nvh_format.h: NVH_EMIT_*) ---------------------------------------------------------------------------
@@ -534,7 +607,8 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
 // The frame's own plane is written only when k_ola_compact still needs it (not both overlaps emitted here).
 template <int NT>
 __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, float* spec, const uint32_t* s_chan, int n, int nch,
-                                           unsigned frame, int sl, bool emit_self, bool emit_next, float* planes,
+                                           unsigned frame, int sl, bool emit_self, bool emit_next, bool self_carry, bool carry_out,
+                                           unsigned exec_mask, float* planes,
                                            const float* Aa, const float* Bb, const float* Cc, const float* TW, int tid) {
   const int wv = tid >> 6, lane = tid & 63, half = n >> 1;
   // parameters of the overlaps, out of the slab before the staging overwrites it
@@ -553,7 +627,7 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
       if (u < units) {
         const int c = u >> sh, r = u & (per_ch - 1);
         const bool is_a = r >= q16;
-        if (is_a ? emit_next : emit_self) {
+        if (is_a ? emit_next : (emit_self && !self_carry)) {
           const float* src = is_a ? A.work + ((long long)(frame + 1) * nch + c) * A.block1 + 4 * (r - q16)
                                   : A.work + ((long long)(frame - 1) * nch + c) * A.block1 + half + 4 * r;
           dma16(reinterpret_cast<const uint4*>(src), stage + 4 * u0);
@@ -596,13 +670,15 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
     }
   }
   __syncthreads();  // drains the staging DMA (vmcnt(0) in front of the barrier): all four quarters of every channel are in LDS
+  if (carry_out) synth_carry_out<NT>(A, planes, n, nch, exec_mask, w_self, tid);  // (such a frame has no NEXT: its plane was written)
+  if (self_carry) synth_self_carry<NT>(A, spec, n, nch, w_self, out_self, tid);    // the batch's first frame
   // ---- overlap-add + interleave + clip, every lane of the workgroup: lane task = (overlap, group of four compact indices i0);
   // it produces sample times i0 .. i0 + 3 and n/2 - 4 - i0 .. n/2 - 1 - i0 of every channel (kernels.hip: ola_sym) ----
   int clipped = 0;
   const int groups = n >> 4;  // per overlap
   for (int t = tid; t < 2 * groups; t += NT) {
     const bool nx = t >= groups;
-    if (nx ? !emit_next : !emit_self) continue;
+    if (nx ? !emit_next : (!emit_self || self_carry)) continue;
     const int g = nx ? t - groups : t, i0 = 4 * g;
     const float* __restrict__ w = A.windows + (nx ? w_next : w_self);
     const float* __restrict__ wp = A.windows + (nx ? wp_next : wp_self);
@@ -818,14 +894,18 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   const float* Cc = A.mdct_c[sl];
   const float* TW = A.mdct_tw[sl];
   const bool xform = wv < nch && ((exec_mask >> wv) & 1u);
-  bool emit_self = false, emit_next = false;
+  bool emit_self = false, emit_next = false, self_carry = false, carry_out = false;
   if constexpr (MAXCH <= 2) {
     emit_self = A.pcm != nullptr && (flags & NVH_SLAB_EMIT_SELF);
     emit_next = A.pcm != nullptr && (flags & NVH_SLAB_EMIT_NEXT);
+    self_carry = emit_self && (exec_mask & NVH_SLABX_SELF_CARRY);
+    carry_out = A.carry_out != nullptr && (exec_mask & NVH_SLABX_CARRY_OUT);
   }
+  const unsigned carry_window = carry_out ? __builtin_amdgcn_readfirstlane(s_chan[2]) : 0u;  // before anything overlays the slab
   if (MAXCH <= 2 && (emit_self || emit_next)) {
     if constexpr (MAXCH <= 2)
-      synth_emit<NT>(A, smem, spec, s_chan, n, nch, frame, sl, emit_self, emit_next, planes, Aa, Bb, Cc, TW, tid);
+      synth_emit<NT>(A, smem, spec, s_chan, n, nch, frame, sl, emit_self, emit_next, self_carry, carry_out, exec_mask, planes,
+                     Aa, Bb, Cc, TW, tid);
   } else
   if (MAXCH <= 2) {
     // in place over the channel's own spectrum (the transform's slice = n/2 floats + n/16 of padding: channel nch-1 spills its
@@ -872,6 +952,12 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   if (MAXCH > 2 && !xform) __syncthreads();  // the one barrier every transforming wavefront passes inside imdct_wave<.., WGSYNC>
+  if constexpr (MAXCH <= 2) {
+    if (carry_out && !(emit_self || emit_next)) {  // (an emitting frame has done it inside synth_emit)
+      __syncthreads();  // every wavefront's plane stores are complete
+      synth_carry_out<NT>(A, planes, n, nch, exec_mask, carry_window, tid);
+    }
+  }
   SY_T(5);
 #ifdef NVH_DEBUG
   if (dbg && threadIdx.x == 0) dbg[(long long)f * 24 + 23] = wall_clock64();

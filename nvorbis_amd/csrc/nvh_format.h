@@ -143,6 +143,12 @@ struct NvhFrame {
 #define NVH_EMIT_SELF 1u
 #define NVH_EMIT_NEXT 2u
 #define NVH_EMIT_DONE 4u
+// The two frames a steady-state batch would still leave to k_ola_compact: the batch's first frame, whose predecessor is the
+// carried tail of the batch before (stored fully windowed: StreamDecoder's _prevPacketBuf) -- SELF_CARRY: the emitter adds the
+// carried samples instead of a neighbour's quarter --, and the last decoded block, which becomes the next carried tail --
+// CARRY_OUT: its workgroup writes the windowed block itself.  With both, a steady-state batch needs no k_ola_compact launch.
+#define NVH_EMIT_SELF_CARRY 8u
+#define NVH_EMIT_CARRY_OUT 16u
 
 // ---- per-frame slabs of the slab synthesis kernel (kernels_synth.hip) ------------------------------------------------
 //
@@ -166,6 +172,9 @@ struct NvhFrame {
 #define NVH_SLAB_FUSE_FLOOR 32u    // the lane that finishes a chain multiplies its bins by the floor curve before its one store
 #define NVH_SLAB_EMIT_SELF 64u     // NVH_EMIT_SELF of the frame (mono / stereo slabs only: chan[2..7] carry the parameters)
 #define NVH_SLAB_EMIT_NEXT 128u    // NVH_EMIT_NEXT
+// mono / stereo slabs: bits 6 and 7 of NvhSlabHdr::exec_mask (two channels need two bits)
+#define NVH_SLABX_SELF_CARRY 0x40u // NVH_EMIT_SELF_CARRY (together with NVH_SLAB_EMIT_SELF)
+#define NVH_SLABX_CARRY_OUT 0x80u  // NVH_EMIT_CARRY_OUT (chan[2] = window_off)
 #define NVH_SLAB_HDR_VECS 4
 #define NVH_SLAB_MAX_CH 8          // channels a slab describes (k_synth: 2, k_synth8: 8)
 #define NVH_SLAB_MAX_COUPLE 4      // coupling steps of a pass of its own (3 + 3 bits each in NvhSlabHdr::coupling)

@@ -249,6 +249,17 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       }
       if ((g & 1) == 0 && steady(g + 1)) fr.emit_flags |= NVH_EMIT_NEXT;
     }
+    // the batch's first frame over the carried tail of the batch before (same geometry, the tail stored fully windowed)
+    if (can && nf > 0) {
+      NvhFrame& fr = P.frames[0];
+      const int half = fr.n >> 1;
+      if (fr.n >= 256 && fr.ov_frame == -2 && fr.ov_n == fr.n && fr.start == 0 && fr.emit_start == 0 && fr.emit_count == half &&
+          fr.ov_src == half && fr.ov_len == half && (fr.exec_mask & all_ch) == all_ch && ((fr.out_pos * ch) & 3) == 0 &&
+          fr.out_pos >= 0 && fr.out_pos < 0x7FFFFFFFll) {
+        fr.emit_flags |= NVH_EMIT_SELF | NVH_EMIT_SELF_CARRY | NVH_EMIT_DONE;
+        b->emit_frames++;
+      }
+    }
     // Worth it for batches that are mostly steady state: the second launch and the list-driven k_ola_compact cost a stream of
     // mixed block sizes more than the emission saves when it runs alone (C3, 256/2048 Markov chain, one HIP stream: 45.0 us
     // per 4096 frames against 41.6 us; three streams: 24.5 against 25.1).  NVH_EMIT_ALWAYS lifts the threshold.
@@ -260,13 +271,15 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
         b->emit_frames = 0;
       }
     }
-    // what is left for k_ola_compact: every other frame that emits samples, and the block that becomes the carried tail
+    // what is left for k_ola_compact: every other frame that emits samples.  The block that becomes the carried tail is written
+    // by its own workgroup (whole groups of four samples per channel: always, n >= 256).
     int last = -1;
     for (int i = nf - 1; i >= 0; --i)
       if (P.frames[(size_t)i].n != 0) { last = i; break; }
+    if (b->emit_frames > 0 && last >= 0 && P.frames[(size_t)last].n >= 256) P.frames[(size_t)last].emit_flags |= NVH_EMIT_CARRY_OUT;
     for (int g = 0; g < nf; g++) {
       const NvhFrame& fr = P.frames[(size_t)g];
-      if ((fr.emit_count > 0 && !(fr.emit_flags & NVH_EMIT_DONE)) || g == last) ola_list.push_back(g);
+      if ((fr.emit_count > 0 && !(fr.emit_flags & NVH_EMIT_DONE)) || (g == last && !(fr.emit_flags & NVH_EMIT_CARRY_OUT))) ola_list.push_back(g);
     }
   }
   b->ola_count = (int)ola_list.size();
@@ -592,6 +605,8 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     A.windows = s->dev.windows;
     A.clip = s->clip;
     A.clipped_flag = flags + 1;
+    A.carry = carry;
+    A.carry_out = emitted ? carry_out : nullptr;
     const size_t synth_lds = slab_lds_bytes(b) + (size_t)T.lds_pad;
     if (synth_lds > 64 * 1024 && !s->ctx->synth_lds_attr_set) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_synth8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -780,10 +795,12 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
         hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
                            (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded, T.no_ola_sym ? 1 : 0,
                            (const int*)nullptr, 0);
-      else if (b->ola_count > 0)  // paired emission: only the frames k_synth left over (and the block that becomes the carried tail)
+      else if (b->ola_count == 0)
+        b->slot_name[3] = "-";  // paired emission covered every frame, the carried tail included: no launch
+      else  // paired emission: only the frames k_synth left over
         hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->ola_count, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
-                           (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded, T.no_ola_sym ? 1 : 0,
-                           b->d_ola_list, 1);
+                           (const float*)work, carry, d_pcm, s->clip, flags + 1, (float*)nullptr /* k_synth wrote the carried tail */,
+                           b->last_decoded, T.no_ola_sym ? 1 : 0, b->d_ola_list, 1);
     } else if (!b->sequential_ola)
       hipLaunchKernelGGL(k_ola_emit, dim3((unsigned)b->nframes), dim3(256), 0, st, s->dev, b->dev, (const float*)work, carry,
                          d_pcm, s->clip, flags + 1);
