@@ -16,13 +16,20 @@ A step is `passes_per_step` passes, chosen from a calibration run so that the ti
 --steps says (a 20-step run of one 45 us pass each would time 0.9 ms of launch jitter, and an outside observer sampling GPU
 activity would see nothing); the line states it in config, and `value` counts every pass.
 
-Working set: the passes rotate over `--streams` decoder instances (own nvh_ctx / HIP stream) x R resident 4096-frame batches
-each, R chosen so that what the passes touch (descriptors + work planes + PCM, ~76 MB per batch) exceeds `--working-set-mib`
-(default 512 MiB, twice the 256 MiB Infinity Cache): `value` and `roofline` are the HBM-resident regime.  The same loop over
-one batch per stream (working set ~150 MB, L3-resident -- what rounds 1 and 2 reported) is in `roofline.l3_resident`.
+Working set: the passes rotate over `--streams` decoder instances (default 3; own nvh_ctx / HIP stream each, as a corpus
+transcoder's workers have) x R resident 4096-frame batches each, R chosen so that what the passes touch (slabs + the odd frames'
+work planes + PCM, ~57 MB per batch) exceeds `--working-set-mib` (default 512 MiB, twice the 256 MiB Infinity Cache): `value`
+and `roofline` are the HBM-resident regime.  The same loop over one batch per stream (working set ~170 MB, L3-resident -- what
+rounds 1 and 2 reported) is in `roofline.l3_resident`.
+
+`roofline`: the dominant kernel per LAUNCH by hipEvents on its own stream (one stream, outside the overlapped loop), algorithmic
+bytes of that launch, HBM traffic from the committed PMC passes; `roofline.unfused`: the same loop in a child process with
+NVH_NO_EMIT=1 (the overlap-add in k_ola_compact instead of inside k_synth).  `end_to_end`: the PCIe-inclusive rate of the
+boundary, never `value`.
 
 `configs`: the other BASELINE.json workloads on full-depth packets (C2 G-rand, C3 Markov 256/2048, C4 six channels n = 4096
-psize 48), kernel-only, one stream, hipEvents -- parity-test cases timed for the record, not the headline.
+psize 48), kernel-only: one stream by hipEvents, and the sustained rate over three streams -- parity-test cases timed for the
+record, not the headline.
 """
 import argparse
 import json
