@@ -474,7 +474,15 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                traffic = tj.get("kernels", {}).get(names[dom], {}).get("hbm_bytes")
+                tk = tj.get("kernels", {})
+                if launches == 2:
+                    # paired emission: the pass is one launch over the odd frames (k_synth_tail when the last block is odd,
+                    # else k_synth) and one of k_synth_emit over the even frames; per launch = their mean
+                    odd = tk.get("k_synth_tail") or tk.get("k_synth")
+                    even = tk.get("k_synth_emit")
+                    traffic = (odd["hbm_bytes"] + even["hbm_bytes"]) / 2 if odd and even else None
+                else:
+                    traffic = tk.get(names[dom], {}).get("hbm_bytes")
                 traffic_build = tj.get("build")
                 if traffic is not None:
                     traffic_source = "profiles/traffic.json: %s (committed rocprofv3 --pmc passes of this command, not measured in this run)" % tj.get("source", "?")

@@ -735,7 +735,10 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
 // NT = 512, MAXCH = 8 (k_synth8): up to eight channels (one wavefront per channel in the transform), blocks up to 4096; coupling
 //   as passes of their own, the floor multiply as a pass over all channels, the transforms' slices laid over everything
 //   that is dead by then (imdct_wave<.., WGSYNC>).
-template <int NT, int MAXCH>
+// MODE (k_synth only): 0 = synthesis alone, 1 = + the carried tail written by the last decoded block's workgroup, 2 = + paired
+// emission.  Three instantiations, so that the launches that never emit keep the registers of the kernel that cannot (62 instead
+// of 64 VGPRs at the 64-VGPR cap: 24.4 against 25.1 us for 4096 frames).
+template <int NT, int MAXCH, int MODE = 0>
 __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int f = A.f0 + (int)blockIdx.x * A.fstep;
@@ -895,15 +898,16 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   const float* TW = A.mdct_tw[sl];
   const bool xform = wv < nch && ((exec_mask >> wv) & 1u);
   bool emit_self = false, emit_next = false, self_carry = false, carry_out = false;
-  if constexpr (MAXCH <= 2) {
+  if constexpr (MAXCH <= 2 && MODE >= 2) {
     emit_self = A.pcm != nullptr && (flags & NVH_SLAB_EMIT_SELF);
     emit_next = A.pcm != nullptr && (flags & NVH_SLAB_EMIT_NEXT);
     self_carry = emit_self && (exec_mask & NVH_SLABX_SELF_CARRY);
-    carry_out = A.carry_out != nullptr && (exec_mask & NVH_SLABX_CARRY_OUT);
   }
-  const unsigned carry_window = carry_out ? __builtin_amdgcn_readfirstlane(s_chan[2]) : 0u;  // before anything overlays the slab
-  if (MAXCH <= 2 && (emit_self || emit_next)) {
-    if constexpr (MAXCH <= 2)
+  if constexpr (MAXCH <= 2 && MODE >= 1) carry_out = A.carry_out != nullptr && (exec_mask & NVH_SLABX_CARRY_OUT);
+  unsigned carry_window = 0u;
+  if constexpr (MAXCH <= 2 && MODE >= 1) carry_window = carry_out ? __builtin_amdgcn_readfirstlane(s_chan[2]) : 0u;  // before anything overlays the slab
+  if (MAXCH <= 2 && MODE >= 2 && (emit_self || emit_next)) {
+    if constexpr (MAXCH <= 2 && MODE >= 2)
       synth_emit<NT>(A, smem, spec, s_chan, n, nch, frame, sl, emit_self, emit_next, self_carry, carry_out, exec_mask, planes,
                      Aa, Bb, Cc, TW, tid);
   } else
@@ -952,7 +956,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   if (MAXCH > 2 && !xform) __syncthreads();  // the one barrier every transforming wavefront passes inside imdct_wave<.., WGSYNC>
-  if constexpr (MAXCH <= 2) {
+  if constexpr (MAXCH <= 2 && MODE >= 1) {
     if (carry_out && !(emit_self || emit_next)) {  // (an emitting frame has done it inside synth_emit)
       __syncthreads();  // every wavefront's plane stores are complete
       synth_carry_out<NT>(A, planes, n, nch, exec_mask, carry_window, tid);
@@ -970,6 +974,20 @@ extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_w
 k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   synth_body<SP_THREADS, 2>(A, smem NVH_DBG_ARGS);
+}
+
+// up to eight channels, blocks up to 4096: 8 wavefronts per workgroup, the CU's LDS decides how many are resident
+extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_synth_tail(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_body<SP_THREADS, 2, 1>(A, smem NVH_DBG_ARGS);
+}
+
+// up to eight channels, blocks up to 4096: 8 wavefronts per workgroup, the CU's LDS decides how many are resident
+extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_synth_emit(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_body<SP_THREADS, 2, 2>(A, smem NVH_DBG_ARGS);
 }
 
 // up to eight channels, blocks up to 4096: 8 wavefronts per workgroup, the CU's LDS decides how many are resident

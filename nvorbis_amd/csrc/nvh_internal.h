@@ -66,6 +66,8 @@ __global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArg
 __global__ void k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* slabs, int stride_vecs, const uint32_t* rank, int cap_ops);
 __global__ void k_rank_frames(NvhDevBatch Bt, uint32_t* rank, int identity);
 __global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
+__global__ void k_synth_tail(NvhSynthArgs A NVH_DBG_PARAMS);  // + the carried tail written in place (kernels_synth.hip: MODE 1)
+__global__ void k_synth_emit(NvhSynthArgs A NVH_DBG_PARAMS);  // + paired emission (MODE 2)
 __global__ void k_synth8(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
 __global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,

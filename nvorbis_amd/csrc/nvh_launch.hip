@@ -619,11 +619,17 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     else if (!emitted) hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     else {
       // odd frames first (their planes are what the even frames overlap-add with), then the even frames, which emit
+      // (the odd frames never emit: the plain kernel, or the one that can write the carried tail when the last decoded block is odd)
       A.fstep = 2;
       A.f0 = 1;
-      if (b->nframes > 1) hipLaunchKernelGGL(k_synth, dim3((unsigned)(b->nframes / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+      if (b->nframes > 1) {
+        if (b->last_decoded >= 0 && (b->last_decoded & 1))
+          hipLaunchKernelGGL(k_synth_tail, dim3((unsigned)(b->nframes / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+        else
+          hipLaunchKernelGGL(k_synth, dim3((unsigned)(b->nframes / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+      }
       A.f0 = 0;
-      hipLaunchKernelGGL(k_synth, dim3((unsigned)((b->nframes + 1) / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+      hipLaunchKernelGGL(k_synth_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     }
     slab_done = true;
     fuse_gen8 = true;  // the inverse MDCT is inside: no transform kernel behind it
