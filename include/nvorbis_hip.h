@@ -223,6 +223,14 @@ int nvh_stream_push_end(nvh_stream *s);
  * emit_start, emit_count, overlap source frame (-1 none, -2 carried tail), overlap length. */
 int nvh_stream_pending_geometry(const nvh_stream *s, int32_t *out, int cap_frames);
 int nvh_stream_pending(const nvh_stream *s, int *frames, int64_t *pcm_samples_per_channel);
+/* The pending frames in the form the synthesis kernels fetch (per-frame slabs: the integer half of Floor1.Apply --
+ * UnwrapPosts and the walk over the sorted posts, Floor1.cs:196-297 -- as line segments, the vector writes of
+ * Residue0.cs:132-175 / Residue2.cs:23-47 as chain-major records), written by the host parser's thread.  Host only, for
+ * tests and tools: buf receives the slabs back to back, first_unit[f] the first 16-byte unit of frame f's slab
+ * (first_unit[frames] = total units).  NVH_ERR_UNSUPPORTED: the stream shape is outside the slab kernels' contract.
+ * *bytes is set even when cap is too small (NVH_ERR_ARGUMENT then). */
+int nvh_stream_pending_slabs(const nvh_stream *s, uint8_t *buf, int64_t cap, int64_t *bytes, uint32_t *first_unit,
+                             int cap_frames);
 
 /* Synthesise the pending batch: H2D descriptors -> kernels -> interleaved PCM.  Exactly one of
  * pcm_host / d_pcm is non-NULL; capacity is in floats and must hold pending samples * channels.

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnvorbis_hip.so")
-SOURCES = ["nvh_api.hip", "nvh_setup.hip", "nvh_launch.hip", "nvh_ops.hip", "kernels.hip", "kernels_imdct.hip", "kernels_spectrum.hip", "kernels_synth.hip", "kernels_parse.hip", "host_setup.cpp", "host_parse.cpp", "host_ogg.cpp"]
+SOURCES = ["nvh_api.hip", "nvh_setup.hip", "nvh_launch.hip", "nvh_ops.hip", "kernels.hip", "kernels_imdct.hip", "kernels_spectrum.hip", "kernels_synth.hip", "kernels_parse.hip", "host_setup.cpp", "host_parse.cpp", "host_slab.cpp", "host_ogg.cpp"]
 # Kernels that measured slower than the default path and are kept for the record: the run kernel, the
 # frame-loop kernel, k_imdct_ola.  They are compiled only into the experiments library (build.py --experiments,
 # -DNVH_EXPERIMENTS), never into libnvorbis_hip.so.
@@ -36,8 +36,8 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     files = []
-    for root, _, names in os.walk(CSRC):
-        files += [os.path.join(root, f) for f in names]
+    for root, _, names in os.walk(CSRC):  # sources only: editor backups and stray objects do not make a library stale
+        files += [os.path.join(root, f) for f in names if f.endswith((".hip", ".cpp", ".h", ".inc"))]
     files.append(os.path.join(HERE, "..", "include", "nvorbis_hip.h"))
     for f in sorted(files):
         h.update(os.path.relpath(f, HERE).encode())
@@ -67,14 +67,55 @@ def _hash_flag():
     return ['-DNVH_SRC_HASH="%s"' % source_hash()]
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return OUT
-    cmd = [hipcc()] + FLAGS + _hash_flag() + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+def _compile_link(sources, out, extra, verbose=False):
+    """Every source to its own object (in parallel, cached under csrc/.obj by a hash of the file, the headers and the flags),
+    then one link.  The kernels of a .hip file are reached from the other files through their host-side launch stubs, which
+    are ordinary symbols: no relocatable device code is needed."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".h", ".inc")):
+            hdr.update(f.encode())
+            hdr.update(open(os.path.join(CSRC, f), "rb").read())
+    hdr.update(open(os.path.join(HERE, "..", "include", "nvorbis_hip.h"), "rb").read())
+    cflags = [f for f in FLAGS if f != "-shared"] + extra
+    hdr.update(repr(cflags).encode())
+    hash_flag = _hash_flag()
+
+    def one(src):
+        path = os.path.join(CSRC, src)
+        h = hashlib.sha256(hdr.digest())
+        h.update(open(path, "rb").read())
+        # the embedded source hash lives in nvh_api.hip only: the other objects do not change with it
+        if src == "nvh_api.hip":
+            h.update(hash_flag[0].encode())
+        obj = os.path.join(objdir, "%s.%s.o" % (src, h.hexdigest()[:16]))
+        if not os.path.exists(obj):
+            for old in os.listdir(objdir):
+                if old.startswith(src + "."):
+                    os.remove(os.path.join(objdir, old))
+            cmd = [hipcc()] + cflags + hash_flag + ["-x", "hip", "-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max(1, min(len(sources), os.cpu_count() or 1))) as ex:
+        objs = list(ex.map(one, sources))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    return _compile_link(SOURCES, OUT, [], verbose)
 
 
 DEBUG_OUT = os.path.join(HERE, "libnvorbis_hip_dbg.so")
@@ -85,22 +126,14 @@ def build_experiments(verbose=False):
     """The experiments build (-DNVH_EXPERIMENTS): the release library plus the quarantined kernels behind their opt-in
     switches (NVH_RUN=1, NVH_MULTI=1, NVH_FUSED_OLA=1).  Load it with NVH_LIB=nvorbis_amd/libnvorbis_hip_exp.so; the tests
     marked `experiments` do (and skip when it has not been built)."""
-    cmd = [hipcc()] + FLAGS + _hash_flag() + ["-DNVH_EXPERIMENTS", "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES + EXPERIMENT_SOURCES] + ["-o", EXPERIMENTS_OUT]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return EXPERIMENTS_OUT
+    return _compile_link(SOURCES + EXPERIMENT_SOURCES, EXPERIMENTS_OUT, ["-DNVH_EXPERIMENTS"], verbose)
 
 
 def build_debug(verbose=False):
     """The profiling build (-DNVH_DEBUG): the spectrum kernels take a timestamp buffer and a phase mask
     (nvh_debug_set_buffer, NVH_DEBUG_SPECTRUM_MASK; tools/dbg_phase*.py, tools/pmc_phases.sh).  Load it with
     NVH_LIB=nvorbis_amd/libnvorbis_hip_dbg.so.  The release library has neither the parameters nor the export."""
-    cmd = [hipcc()] + FLAGS + _hash_flag() + ["-DNVH_DEBUG", "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", DEBUG_OUT]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return DEBUG_OUT
+    return _compile_link(SOURCES, DEBUG_OUT, ["-DNVH_DEBUG"], verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,348 @@
+// host_slab.cpp -- per-frame slabs written by the host packet parser's thread (see host_slab.h).
+//
+// Reference behaviour followed (file:line under /root/reference/NVorbis/):
+//   Floor1.cs:196-216  Apply's walk over the posts in X order: a line from the last flagged post to the next, its far end
+//                      clamped to n/2 (Math.Min(hx, n)), a flat run to n/2 behind the last one
+//   Floor1.cs:224-297  UnwrapPosts (neighbour prediction, room arithmetic, step flags)
+//   Floor1.cs:299-314  RenderPoint (int arithmetic, the product may wrap)
+//   Floor1.cs:316-341  RenderLineMulti: y(x0 + k) = y0 + k b + sy floor(k r / adx) -- stored as a 32.32 fixed-point step
+//   Residue0.cs:132-175, Residue2.cs:23-47  which bins a (stage, partition, channel) vector write touches
+//   Mapping.cs:137-182  which coupling steps run (either channel executes), last step first
+#include "host_slab.h"
+
+#include <cstring>
+
+namespace nvh {
+
+namespace {
+
+inline int render_point(int x0, int y0, int x1, int y1, int X) {  // Floor1.cs:299-314
+  const int dy = y1 - y0, adx = x1 - x0;
+  const int ady = dy < 0 ? -dy : dy;
+  const int err = (int)((uint32_t)ady * (uint32_t)(X - x0));  // unchecked int multiply
+  const int off = err / adx;                                  // truncating, like C#
+  return dy < 0 ? y0 - off : y0 + off;
+}
+
+}  // namespace
+
+int floor1_segments(const Floor1& f, const uint16_t* posts, int post_count, int half, SlabVec* seg, bool* fault) {
+  const int cnt = (int)f.x_list.size();
+  const int pc = post_count < cnt ? post_count : cnt;
+  int final_y[NVH_MAX_POSTS];
+  bool step[NVH_MAX_POSTS];
+  for (int i = 0; i < NVH_MAX_POSTS; i++) { final_y[i] = 0; step[i] = false; }
+  if (pc < 2) return 0;
+  step[0] = step[1] = true;
+  final_y[0] = posts[0];
+  final_y[1] = posts[1];
+  for (int i = 2; i < pc; i++) {
+    const int lo = f.l_neigh[(size_t)i], hi = f.h_neigh[(size_t)i];
+    const int predicted = render_point(f.x_list[(size_t)lo], final_y[lo], f.x_list[(size_t)hi], final_y[hi], f.x_list[(size_t)i]);
+    const int val = posts[i];
+    const int highroom = f.range - predicted, lowroom = predicted;
+    const int room = (highroom < lowroom ? highroom : lowroom) * 2;
+    if (val != 0) {
+      step[lo] = step[hi] = step[i] = true;
+      if (val >= room) final_y[i] = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
+      else final_y[i] = (val % 2) == 1 ? predicted - ((val + 1) / 2) : predicted + (val / 2);
+    } else {
+      final_y[i] = predicted;
+    }
+  }
+  // the flagged posts in X order; the walk ends with the first line whose far end reaches n/2
+  int px[NVH_MAX_POSTS + 1], py[NVH_MAX_POSTS + 1];
+  int np = 0;
+  px[np] = 0;  // lx = 0 whatever _xList[_sortIdx[0]] is (it is 0 for every valid header)
+  py[np++] = final_y[0] * f.multiplier;
+  bool reached = false;
+  for (int i = 1; i < pc && !reached; i++) {
+    const int idx = f.sort_idx[(size_t)i];
+    if (idx >= pc || !step[idx]) continue;
+    px[np] = f.x_list[(size_t)idx];
+    py[np++] = final_y[idx] * f.multiplier;
+    if (px[np - 1] >= half) reached = true;
+  }
+  if (!reached) {  // RenderLineMulti(lx, ly, n, ly)
+    px[np] = half;
+    py[np] = py[np - 1];
+    np++;
+  }
+  const int ns = np - 1;
+  for (int k = 0; k < ns; k++) {
+    const int x0 = px[k], y0 = py[k], x1n = px[k + 1], y1 = py[k + 1];
+    const int x1 = x1n < half ? x1n : half;
+    const int dy = y1 - y0, adx = x1 - x0;
+    if (adx <= 0 || x0 > 0xFFFF || x1n > 0xFFFF) return -1;  // not a curve the kernels can walk (headers with such X lists are refused)
+    const uint32_t ady = (uint32_t)(dy < 0 ? -dy : dy);
+    const uint32_t ab = ady / (uint32_t)adx, r = ady - ab * (uint32_t)adx;
+    const uint64_t frac = ((uint64_t)r << 32) / (uint64_t)adx + ((((uint64_t)r << 32) % (uint64_t)adx) ? 1u : 0u);  // ceil, r < adx: below 2^32
+    uint64_t F = ((uint64_t)ab << 32) + frac;
+    if (dy < 0) F = 0ull - F;
+    seg[k].x = (uint32_t)x0 | ((uint32_t)x1n << 16);
+    seg[k].y = (uint32_t)y0;
+    seg[k].z = (uint32_t)F;
+    seg[k].w = (uint32_t)(F >> 32);
+    // inverse_dB_table[y] (Floor1.cs:330,339) throws outside 0..255; the line is monotone, so its ends decide
+    const int tl = adx - 1;
+    const int b = dy < 0 ? -(int)ab : (int)ab;
+    const int yl = y0 + b * tl + (dy < 0 ? -1 : 1) * (int)(((uint64_t)r * (uint64_t)tl) / (uint64_t)adx);
+    if (y0 < 0 || y0 > 255 || yl < 0 || yl > 255) *fault = true;
+  }
+  return ns;
+}
+
+int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBatch& out) {
+  out.clear();
+  const int nch = S.channels;
+  if (nch > NVH_SLAB_MAX_CH) return NVH_ERR_UNSUPPORTED;
+  const size_t nf = P.frames.size();
+  out.first.reserve(nf + 1);
+  out.data.reserve(nf * 256);
+  std::vector<SlabVec> segs((size_t)NVH_MAX_POSTS + 2);
+  for (size_t f = 0; f < nf; f++) {
+    const NvhFrame& fr = P.frames[f];
+    const size_t base = out.data.size();
+    out.first.push_back((uint32_t)base);
+    NvhSlabHdr H;
+    std::memset(&H, 0, sizeof H);
+    H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS;
+    H.vecs = NVH_SLAB_HDR_VECS;
+    H.group = 2;
+    H.frame = (uint32_t)f;
+    for (int c = 0; c < NVH_SLAB_MAX_CH; c++) H.chan[c] = (uint32_t)NVH_SLAB_HDR_VECS << 16;
+    out.data.resize(base + NVH_SLAB_HDR_VECS);
+    auto put_header = [&]() {
+      static_assert(sizeof(NvhSlabHdr) == NVH_SLAB_HDR_VECS * 16, "header size");
+      std::memcpy(&out.data[base], &H, sizeof H);
+      const uint32_t v = (uint32_t)(out.data.size() - base);
+      if (v > out.max_vecs) out.max_vecs = v;
+    };
+    if (fr.n == 0) {
+      put_header();
+      continue;
+    }
+    const int half = fr.n >> 1;
+    if (fr.mapping < 0 || (size_t)fr.mapping >= S.mappings.size()) return NVH_ERR_RUNTIME;
+    const Mapping& mp = S.mappings[(size_t)fr.mapping];
+    const NvhChan* chans = &P.chans[f * (size_t)nch];
+    H.n = (uint16_t)fr.n;
+    H.exec_mask = (uint8_t)(fr.exec_mask & 0xFFu);
+    if (fr.mdct_slot) H.flags |= NVH_SLAB_MDCT_SLOT;
+    bool fault = false;
+    // ---- floors ----
+    for (int c = 0; c < nch; c++) {
+      const NvhChan& cn = chans[c];
+      const Floor& fl = S.floors[cn.floor];
+      if (fl.type != 1) return NVH_ERR_UNSUPPORTED;
+      const int mode = cn.exec ? (cn.post_count > 0 ? 1 : 2) : 0;
+      const uint32_t off = (uint32_t)(out.data.size() - base);
+      int ns = 0;
+      if (mode == 1) {
+        ns = floor1_segments(fl.f1, &P.posts[cn.data_off], cn.post_count, half, segs.data(), &fault);
+        if (ns <= 0 || ns > 255) return NVH_ERR_UNSUPPORTED;
+        out.data.insert(out.data.end(), segs.begin(), segs.begin() + ns);
+        // segment index of every group of four bins: the last segment that starts at or before the group's first bin
+        const int ngroups = half >> 2, padded = (ngroups + 15) & ~15;
+        const size_t t0 = out.data.size();
+        out.data.resize(t0 + (size_t)padded / 16);
+        uint8_t* tab = reinterpret_cast<uint8_t*>(&out.data[t0]);
+        int sg = 0;
+        for (int gq = 0; gq < padded; gq++) {
+          if (gq < ngroups) {
+            const int x0 = gq << 2;
+            while (sg + 1 < ns && (int)(segs[(size_t)sg + 1].x & 0xFFFFu) <= x0) ++sg;
+            tab[gq] = (uint8_t)sg;
+          } else {
+            tab[gq] = 0;
+          }
+        }
+      }
+      H.chan[c] = (uint32_t)mode | ((uint32_t)ns << 8) | (off << 16);
+    }
+    if (fault) H.flags |= NVH_SLAB_FLOOR_FAULT;
+    // ---- residue: chains of vector writes, chain-major ----
+    const int npass = (int)(fr.pass_end - fr.pass_begin);
+    if (npass > 1) return NVH_ERR_UNSUPPORTED;
+    int rtype = 0, rch = 1;
+    unsigned rbegin_al = 0;
+    H.off_heads = (uint16_t)(out.data.size() - base);
+    if (npass == 1) {
+      const NvhResPass& gp = P.passes[fr.pass_begin];
+      const Residue& R = S.residues[(size_t)gp.residue];
+      rtype = R.type;
+      rch = R.real_channels;
+      const unsigned psz = (unsigned)R.partition_size, rbegin = (unsigned)R.begin;
+      rbegin_al = rbegin;
+      unsigned group = (psz & 7u) == 0 ? 8u : 2u;
+      if (rtype == 2 && rch > 2) group = (psz % (2u * (unsigned)rch)) == 0 ? 2u * (unsigned)rch : 0u;
+      if (group == 0 || (psz % group) != 0) return NVH_ERR_UNSUPPORTED;
+      const unsigned lpc = psz / group;
+      H.group = (uint8_t)group;
+      H.lpc = (uint16_t)lpc;
+      H.lpc_magic = lpc > 1 ? (uint32_t)((0x100000000ull + lpc - 1) / lpc) : 0u;
+      const uint32_t nops = fr.op_count;
+      const NvhResOp* ops = P.ops.data() + fr.op_begin;
+      const uint16_t* links = P.op_link.data() + fr.op_begin;
+      // heads in op order, each chain's records consecutive
+      uint32_t nheads = 0, nrec = 0;
+      for (uint32_t o = 0; o < nops; o++) nheads += (links[o] & 0x8000u) ? 0u : 1u;
+      const uint32_t off_heads = (uint32_t)(out.data.size() - base);
+      const uint32_t off_rec = off_heads + ((nheads + 7) >> 3);
+      out.data.resize(base + off_rec + nops);
+      uint16_t* heads = reinterpret_cast<uint16_t*>(&out.data[base + off_heads]);
+      SlabVec* recs = &out.data[base + off_rec];
+      uint32_t hk = 0;
+      for (uint32_t o = 0; o < nops; o++) {
+        if (links[o] & 0x8000u) continue;
+        heads[hk++] = (uint16_t)nrec;
+        uint32_t q = o;
+        for (;;) {
+          if (q >= nops || nrec >= nops) return NVH_ERR_RUNTIME;
+          const NvhResOp& op = ops[q];
+          const NvhDevBook& bk = X.books[op.book];
+          const unsigned offset = rbegin + (unsigned)op.partition * psz;
+          const unsigned xbase = (rtype == 2 && rch > 1) ? offset / (unsigned)rch : offset;
+          const uint32_t rel = op.ent_off - fr.ent_begin;
+          if (rel > 0xFFFFu || xbase > 0xFFFFu) return NVH_ERR_UNSUPPORTED;
+          const uint32_t l = links[q] & 0x7FFFu;
+          SlabVec rec;
+          rec.x = rel | (xbase << 16);
+          rec.y = bk.lat_off | (bk.lat_values << 16);
+          rec.z = bk.lat_magic;
+          rec.w = bk.dim | ((uint32_t)op.channel << 8) | (l != NVH_LINK_NONE ? 0x8000u : 0u) | (bk.dim_magic16 << 16);
+          recs[nrec++] = rec;
+          if (l == NVH_LINK_NONE) break;
+          q = l;
+        }
+      }
+      for (uint32_t i = nheads; i < ((nheads + 7) & ~7u); i++) heads[i] = 0;
+      if (nrec != nops) return NVH_ERR_RUNTIME;  // every op belongs to exactly one chain
+      H.nheads = (uint16_t)nheads;
+      H.nrec = (uint16_t)nrec;
+      H.off_rec = (uint16_t)off_rec;
+    } else {
+      H.off_rec = (uint16_t)(out.data.size() - base);
+    }
+    H.rgeom = (uint8_t)(rtype | (rch << 4));
+    // ---- entries of the frame, padded with "no vector" to a whole 16-byte unit ----
+    H.off_ent = (uint16_t)(out.data.size() - base);
+    {
+      const uint32_t ne = fr.ent_count, padded = (ne + 7) & ~7u;
+      const size_t e0 = out.data.size();
+      out.data.resize(e0 + padded / 8);
+      uint16_t* dst = reinterpret_cast<uint16_t*>(&out.data[e0]);
+      if (ne) std::memcpy(dst, P.entries.data() + fr.ent_begin, (size_t)ne * 2);
+      for (uint32_t i = ne; i < padded; i++) dst[i] = (uint16_t)NVH_ENTRY_SKIP;
+    }
+    const size_t vecs = out.data.size() - base;
+    if (vecs > 0xFFFFu) return NVH_ERR_UNSUPPORTED;
+    H.vecs = (uint16_t)vecs;
+    // ---- inverse coupling: in the chain walk when one lane holds both channels of a bin, else passes, last step first ----
+    const int csteps = (int)mp.coupling_angle.size();
+    if (nch == 2 && csteps == 1 && npass == 1 && rtype == 2 && rch == 2) {
+      if ((fr.exec_mask & 3u) != 0) {
+        if (mp.coupling_magnitude[0] == 1) H.flags |= NVH_SLAB_MG1;
+        H.flags |= NVH_SLAB_SWEEP_COUPLES;
+      }
+    } else if (csteps > 0) {
+      if (csteps > NVH_SLAB_MAX_COUPLE) return NVH_ERR_UNSUPPORTED;
+      unsigned word = 0, cnt = 0;
+      for (int st = csteps - 1; st >= 0; --st) {
+        const unsigned mg = (unsigned)mp.coupling_magnitude[(size_t)st], an = (unsigned)mp.coupling_angle[(size_t)st];
+        if (((fr.exec_mask >> mg) | (fr.exec_mask >> an)) & 1u) {
+          word |= (mg | (an << 3)) << (4 + 6 * cnt);
+          ++cnt;
+        }
+      }
+      if (cnt) {
+        H.coupling = word | cnt;
+        H.flags |= NVH_SLAB_COUPLE_PASS;
+      }
+    }
+    if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) &&
+        (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
+      H.flags |= NVH_SLAB_FUSE_FLOOR;
+    // ---- paired emission (nvh_format.h: NVH_EMIT_*): what k_synth needs to know about the overlaps ----
+    if (nch <= 2 && (fr.emit_flags & NVH_EMIT_CARRY_OUT)) {
+      H.exec_mask |= NVH_SLABX_CARRY_OUT;
+      H.chan[2] = fr.window_off;
+    }
+    if (nch <= 2 && (fr.emit_flags & NVH_EMIT_SELF_CARRY)) H.exec_mask |= NVH_SLABX_SELF_CARRY;
+    if (nch <= 2 && (fr.emit_flags & (NVH_EMIT_SELF | NVH_EMIT_NEXT))) {
+      H.chan[2] = fr.window_off; H.chan[3] = fr.ov_window_off; H.chan[6] = (uint32_t)fr.out_pos;
+      if (fr.emit_flags & NVH_EMIT_SELF) H.flags |= NVH_SLAB_EMIT_SELF;
+      if ((fr.emit_flags & NVH_EMIT_NEXT) && f + 1 < nf) {
+        const NvhFrame& nx = P.frames[f + 1];
+        H.chan[4] = nx.window_off; H.chan[5] = nx.ov_window_off; H.chan[7] = (uint32_t)nx.out_pos;
+        H.flags |= NVH_SLAB_EMIT_NEXT;
+      }
+    }
+    put_header();
+  }
+  out.first.push_back((uint32_t)out.data.size());
+  return NVH_OK;
+}
+
+
+// The codebook directory as the device holds it (NvhDevBook), the lattice pool (per lattice book: its distinct component values,
+// then the reciprocal magics of lat_values^i) and the pool of VQ lookup tables (Codebook.cs:222-283 built them: host_setup.cpp).
+void build_book_directory(const Setup& S, SlabSetup& X, std::vector<float>& vq, std::vector<uint32_t>& lattice) {
+  vq.clear();
+  lattice.clear();
+  std::vector<NvhDevBook>& books = X.books;
+  books.assign(S.books.size(), NvhDevBook{});
+  for (size_t i = 0; i < S.books.size(); i++) {
+    const Codebook& b = S.books[i];
+    books[i].lat_values = 0;
+    books[i].lat_magic = 0;
+    books[i].lat_off = 0;
+    books[i].dim_magic16 = b.dimensions >= 1 ? (uint32_t)((65536u + (uint32_t)b.dimensions - 1u) / (uint32_t)b.dimensions) : 0u;
+    // lattice fast path: digits via exact reciprocal multiplies (entry < 2^16, powers <= entries)
+    if (b.lattice_values >= 1 && b.dimensions >= 1 && b.dimensions <= 16 && b.entries <= 0xFFFF) {
+      bool ok = true;
+      std::vector<uint32_t> magics;
+      uint64_t pw = 1;
+      for (int d = 0; d < b.dimensions && ok; d++) {
+        if (pw > 0xFFFF) { ok = false; break; }
+        magics.push_back(pw > 1 ? (uint32_t)((0x100000000ull + pw - 1) / pw) : 0u);  // 0: divisor 1
+        pw *= (uint64_t)b.lattice_values;
+      }
+      // self-check against the table the reference algorithm builds
+      for (int e = 0; ok && e < b.entries; e++) {
+        int q = e;
+        for (int d = 0; d < b.dimensions; d++) {
+          uint32_t bits_t, bits_l;
+          float tv = b.lookup[(size_t)e * b.dimensions + d], lv = b.lattice[(size_t)(q % b.lattice_values)];
+          std::memcpy(&bits_t, &tv, 4);
+          std::memcpy(&bits_l, &lv, 4);
+          if (bits_t != bits_l) { ok = false; break; }
+          q /= b.lattice_values;
+        }
+      }
+      if (ok) {
+        books[i].lat_values = (uint32_t)b.lattice_values;
+        books[i].lat_magic = b.lattice_values > 1 ? (uint32_t)((0x100000000ull + (uint64_t)b.lattice_values - 1) / (uint64_t)b.lattice_values) : 0u;
+        books[i].lat_off = (uint32_t)lattice.size();
+        for (float v : b.lattice) {
+          uint32_t bits;
+          std::memcpy(&bits, &v, 4);
+          lattice.push_back(bits);
+        }
+        lattice.insert(lattice.end(), magics.begin(), magics.end());
+      }
+    }
+    books[i].entries = (uint32_t)b.entries;
+    books[i].dim = (uint32_t)b.dimensions;
+    books[i].dim_magic = b.dimensions > 1 ? (uint32_t)((0x100000000ull + (uint64_t)b.dimensions - 1) / (uint64_t)b.dimensions) : 0u;
+    if (b.map_type == 0) {
+      books[i].tab_off = 0xFFFFFFFFu;
+    } else {
+      books[i].tab_off = (uint32_t)vq.size();
+      vq.insert(vq.end(), b.lookup.begin(), b.lookup.end());
+    }
+  }
+
+}
+
+}  // namespace nvh

@@ -1,0 +1,48 @@
+// host_slab.h -- the host packet parser's output in the form the slab synthesis kernels read (nvh_format.h: NvhSlabHdr).
+//
+// Everything about a frame that does not depend on a float is settled at parse time, on the host thread that walked the
+// packet anyway: Floor1.UnwrapPosts and the walk over the sorted, flagged posts (Floor1.cs:196-297) become the segment list
+// + the per-four-bins segment table of each channel, the (stage, partition, channel) geometry of every vector write
+// (Residue0.cs:132-175, Residue2.cs:23-47) becomes chain-major pair records.  k_synth / k_synth8 then fetch one contiguous
+// slab per frame by LDS-DMA and start on floats with their first instruction; no integer kernel runs between the parser
+// and the synthesis (round 3 had k_prepare_slabs there, once per upload).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "host_parse.h"
+#include "host_setup.h"
+#include "nvh_format.h"
+
+namespace nvh {
+
+struct SlabVec { uint32_t x, y, z, w; };  // one 16-byte unit
+static_assert(sizeof(SlabVec) == 16, "slabs are addressed in 16-byte units");
+
+// What the slab records need to know about the setup beyond nvh::Setup: the codebook directory as the device holds it
+// (lattice pool offsets, reciprocal magics; nvh_setup.hip builds it).
+struct SlabSetup {
+  std::vector<NvhDevBook> books;
+};
+
+struct SlabBatch {
+  std::vector<SlabVec> data;      // the slabs back to back (frame order), each a whole number of 16-byte units
+  std::vector<uint32_t> first;    // first unit of frame f's slab in `data`; first[nframes] = data.size()
+  uint32_t max_vecs = 0;          // the largest slab
+  void clear() { data.clear(); first.clear(); max_vecs = 0; }
+};
+
+// Fills X.books (+ the lattice pool and the VQ table pool the device image is made of; nvh_setup.hip uploads them).
+void build_book_directory(const Setup& S, SlabSetup& X, std::vector<float>& vq, std::vector<uint32_t>& lattice);
+
+// Writes the slabs of every frame of P (frames[].emit_flags decided by the caller).  The stream shape must be inside the slab
+// kernels' contract (nvh_launch.hip: slab_path); returns NVH_ERR_UNSUPPORTED when a frame is not (the caller falls back to
+// the descriptor kernels), NVH_OK otherwise.
+int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBatch& out);
+
+// One channel's Floor1 curve as segments: UnwrapPosts + the sorted walk.  `posts` = the raw values Floor1.Unpack read
+// (post_count of them).  seg receives (x | xend << 16, y, step lo, step hi) per segment; returns the segment count, sets
+// *fault when a drawn value falls outside inverse_dB_table (quirk B-7).  Exposed for the unit tests.
+int floor1_segments(const Floor1& f, const uint16_t* posts, int post_count, int half, SlabVec* seg, bool* fault);
+
+}  // namespace nvh

@@ -179,6 +179,11 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
     if (!s) return NVH_ERR_NOMEM;
     s->parser.reset(new nvh::StreamParser(&s->setup));
     if (!c) {
+      if (!cached) {  // host-only stream: the codebook directory the host slab writer needs (nvh_stream_pending_slabs)
+        std::vector<float> vq;
+        std::vector<uint32_t> lattice;
+        nvh::build_book_directory(sh->setup, sh->slab, vq, lattice);
+      }
       *out = s.release();
       return NVH_OK;
     }
@@ -475,6 +480,23 @@ extern "C" int nvh_stream_pending_geometry(const nvh_stream* s, int32_t* out, in
       o[0] = f.n; o[1] = f.start; o[2] = f.valid; o[3] = f.total;
       o[4] = f.emit_start; o[5] = f.emit_count; o[6] = f.ov_frame; o[7] = f.ov_len;
     }
+    return NVH_OK;
+  });
+}
+
+extern "C" int nvh_stream_pending_slabs(const nvh_stream* s, uint8_t* buf, int64_t cap, int64_t* bytes, uint32_t* first_unit,
+                                        int cap_frames) {
+  return nvh_guard([&]() -> int {
+    if (!s || !bytes || cap < 0 || (cap > 0 && !buf)) return NVH_ERR_ARGUMENT;
+    if (s->parser->light()) return NVH_ERR_UNSUPPORTED;  // GPU-parse mode: the host never sees floors and residues
+    nvh::SlabBatch sb;
+    int rc = nvh::build_slabs(s->setup, s->shared->slab, s->pending, sb);
+    if (rc != NVH_OK) return rc;
+    *bytes = (int64_t)sb.data.size() * 16;
+    const int nf = (int)s->pending.frames.size();
+    if (*bytes > cap || (first_unit && cap_frames < nf + 1)) return NVH_ERR_ARGUMENT;
+    if (*bytes) std::memcpy(buf, sb.data.data(), (size_t)*bytes);
+    if (first_unit) std::memcpy(first_unit, sb.first.data(), (size_t)(nf + 1) * sizeof(uint32_t));
     return NVH_OK;
   });
 }

@@ -22,6 +22,7 @@
 #include "host_ogg.h"
 #include "host_parse.h"
 #include "host_setup.h"
+#include "host_slab.h"
 #include "kernels_common.h"
 #include "nvh_parse_format.h"
 
@@ -230,6 +231,7 @@ struct SharedSetup {
   const uint4* synth_consts = nullptr;  // inverse_dB_table + lattice pool in 16-byte units (kernels_synth.hip), inside `arena`
   int synth_const_vecs = 0;
   int max_posts = 0;            // largest Floor1 post count of the setup (bounds a slab's segment lists)
+  nvh::SlabSetup slab;          // host copy of the codebook directory: what host_slab.cpp needs to write pair records
   bool slab_setup_ok = false;   // the setup is inside the slab synthesis kernels' contract (nvh_launch.hip: slab_path)
   bool has_sequential = false;  // some residue replays the reference's partition order (quirk B-1 / vector overrun)
   // GPU packet parser (kernels_parse.hip): its tables, and whether this stream shape is inside its limits
@@ -282,6 +284,8 @@ struct nvh_batch {
   DevBuf slab3;
   int slab_stride_vecs = 0;   // 16-byte units between slabs = upper bound of the batch's largest slab
   bool slabs_ready = false;
+  bool slab_host = false;          // the slabs were written by the host parser's thread (host_slab.cpp) and lie inside `blob`
+  const uint4* d_slabs = nullptr;  // ... here
   // paired emission (nvh_format.h: NVH_EMIT_*): frames whose PCM k_synth writes itself, and the frames left to k_ola_compact
   int emit_frames = 0;           // frames with NVH_EMIT_DONE
   int ola_count = 0;             // entries of d_ola_list
@@ -317,6 +321,7 @@ struct nvh_stream {
   bool& has_floor0;
   std::unique_ptr<nvh::StreamParser> parser;
   nvh::FrameBatch pending;
+  nvh::SlabBatch slab_build;  // scratch of host_slab.cpp, reused from batch to batch
   DevBuf carry[2];  // [ch][block1] windowed block of the last decoded frame (ping-pong: read one, write the other)
   int carry_cur = 0;
   DevBuf flags;  // int[2]: device error word, clipped flag

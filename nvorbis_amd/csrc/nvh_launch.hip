@@ -2,6 +2,8 @@
 #include "nvh_internal.h"
 
 static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResult* d_res);
+static bool slab_shape_ok(const nvh_batch* b);
+static bool slab_size_ok(const nvh_batch* b);
 
 void replay_note(nvh_stream* s, int kind, const uint8_t* data, int len, int64_t granule, int flags) {
   if (!s->gpu_parse) return;
@@ -171,6 +173,8 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->last_decoded = -1;
   b->max_ops = b->max_ent = b->max_pass = 0;
   b->slabs_ready = false;
+  b->slab_host = false;
+  b->d_slabs = nullptr;
   b->links_ok = P.links_ok && P.op_link.size() == P.ops.size();
   for (const NvhFrame& fr : P.frames) {
     if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
@@ -301,6 +305,60 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
     s->replay.clear();
     return rc;
   }
+  // ---- host-parsed batches inside the slab kernels' contract: the parser's thread writes the slabs themselves (host_slab.cpp:
+  // Floor1 unwrap + segment lists, chain-major pair records) and only they travel -- with the frame / channel records, which
+  // k_ola_compact reads for the frames outside the steady state.  No descriptor arrays, no conversion kernel.
+  if (slab_shape_ok(b)) {
+    nvh::SlabBatch& SB = s->slab_build;
+    int rc = nvh::build_slabs(s->setup, s->shared->slab, P, SB);
+    if (rc != NVH_OK && rc != NVH_ERR_UNSUPPORTED) return rc;
+    if (rc == NVH_OK) {
+      size_t stride = std::max<size_t>(SB.max_vecs, (size_t)s->setup.block1 / 64 + 8);  // the IMDCT padding of channel 0 overlays the slab area
+      stride = (stride + 3) & ~(size_t)3;
+      b->slab_stride_vecs = (int)stride;
+      b->slab_host = true;
+      if (!slab_size_ok(b)) b->slab_host = false;
+    }
+    if (b->slab_host) {
+      const size_t nf = P.frames.size(), stride = (size_t)b->slab_stride_vecs;
+      auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+      const size_t o_fr = 0;
+      const size_t o_ch = al(o_fr + std::max<size_t>(nf, 1) * sizeof(NvhFrame));
+      const size_t o_ol = al(o_ch + std::max<size_t>(P.chans.size(), 1) * sizeof(NvhChan));
+      const size_t o_sl = al(o_ol + std::max<size_t>(ola_list.size(), 1) * sizeof(int));
+      const size_t total = al(o_sl + nf * stride * 16 + 4096);  // the speculative first DMA piece of the last slab stays inside the allocation
+      if ((rc = b->blob.reserve(total)) != NVH_OK) return rc;
+      if ((rc = b->h_blob.reserve(total)) != NVH_OK) return rc;
+      uint8_t* h = (uint8_t*)b->h_blob.p;
+      if (nf) std::memcpy(h + o_fr, P.frames.data(), nf * sizeof(NvhFrame));
+      if (!P.chans.empty()) std::memcpy(h + o_ch, P.chans.data(), P.chans.size() * sizeof(NvhChan));
+      if (!ola_list.empty()) std::memcpy(h + o_ol, ola_list.data(), ola_list.size() * sizeof(int));
+      int64_t slab_bytes = 0;
+      for (size_t f = 0; f < nf; f++) {
+        const size_t v = (size_t)(SB.first[f + 1] - SB.first[f]);
+        std::memcpy(h + o_sl + f * stride * 16, &SB.data[SB.first[f]], v * 16);
+        slab_bytes += (int64_t)v * 16;
+      }
+      b->descriptor_bytes = (int64_t)(nf * sizeof(NvhFrame) + P.chans.size() * sizeof(NvhChan)) + slab_bytes;
+      hipStream_t st = s->ctx->stream;
+      HIP_TRY(hipMemcpyAsync(b->blob.p, h, o_sl + nf * stride * 16, hipMemcpyHostToDevice, st));
+      const uint8_t* base = (const uint8_t*)b->blob.p;
+      b->dev.frames = (const NvhFrame*)(base + o_fr);
+      b->dev.chans = (const NvhChan*)(base + o_ch);
+      b->dev.passes = nullptr; b->dev.ops = nullptr; b->dev.op_link = nullptr; b->dev.entries = nullptr; b->dev.posts = nullptr; b->dev.coeffs = nullptr;
+      b->d_ola_list = (const int*)(base + o_ol);
+      b->d_slabs = (const uint4*)(base + o_sl);
+      b->dev.nframes = b->nframes;
+      b->dev.pad = 0;
+      b->dev_copy_valid = false;
+      b->slabs_ready = true;
+      const size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
+      if ((rc = b->work.reserve(std::max<size_t>((size_t)b->nframes, 1) * plane)) != NVH_OK) return rc;
+      P.clear();
+      s->parser->begin_batch();
+      return NVH_OK;
+    }
+  }
   // the descriptor arrays are laid out back to back (16-byte aligned) in one pinned staging block and go to the
   // device with one asynchronous copy; the caller decides when the stream is synchronised
   auto pad1 = [](size_t n) { return n ? n : (size_t)1; };
@@ -376,6 +434,7 @@ static bool slab_wide(const nvh_stream* s) { return s->setup.channels > 2 || s->
 // (nvh_format.h: NvhSlabHdr).
 static size_t slab_bound_vecs(const nvh_batch* b) {
   const nvh_stream* s = b->s;
+  if (b->slab_host) return (size_t)b->slab_stride_vecs;  // written by the host parser's thread: the batch's largest slab, exactly
   const size_t P = (size_t)s->shared->max_posts + 2;
   size_t v = NVH_SLAB_HDR_VECS + (size_t)s->setup.channels * (P + ((size_t)s->setup.block1 / 8 + 15) / 16) + ((size_t)b->max_ops + 7) / 8 +
              (size_t)b->max_ops + ((size_t)b->max_ent + 7) / 8 + 1;
@@ -411,25 +470,26 @@ static size_t slab_lds_bytes(const nvh_batch* b) {
 // books of even dimension, no aliasing partitions), Residue2 over more than two channels only with partitions that are whole
 // multiples of two bins of every channel, at most NVH_SLAB_MAX_COUPLE coupling steps, at most one residue pass per frame,
 // up to eight channels, blocks 256..4096, slabs within 16-bit section offsets and the CU's LDS.
-static bool slab_path(const nvh_batch* b) {
+static bool slab_shape_ok(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   const NvhToggles& T = nvh_toggles();
   if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->max_pass > 1) return false;
-  if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact) return false;
-  // The descriptor -> slab conversion (k_prepare_slabs, 31 us per 4096 stereo frames) pays when a batch is synthesised more
-  // than once: resident batches (nvh_batch_upload).  A streaming batch (the stream's scratch batch: uploaded, synthesised
-  // once, gone) is cheaper through the classic kernels, which do the same integer work inline: 35.6 us against 31 + 25 for
-  // 4096 frames, and one launch fewer per small batch (file-parallel transcode of short files: 3450 against 3100 files/s).
-  // NVH_SLAB_STREAM=1 sends streaming batches through the slabs as well (the parity suite replays itself that way).
-  if (b == &s->scratch && !T.slab_stream) return false;
+  if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact || T.fused_ola || T.run || T.multi) return false;
   if (slab_wide(s) && T.no_gen8) return false;  // NVH_NO_GEN8 keeps its meaning: more than four channels through k_spectrum_gen
-  if (slab_bound_vecs(b) > 0xFFFFu) return false;
-  return slab_lds_bytes(b) + (size_t)T.lds_pad <= (slab_wide(s) ? (size_t)160 * 1024 - 1024 : (size_t)64 * 1024);
+  return true;
 }
+
+static bool slab_size_ok(const nvh_batch* b) {
+  const nvh_stream* s = b->s;
+  if (slab_bound_vecs(b) > 0xFFFFu) return false;
+  return slab_lds_bytes(b) + (size_t)nvh_toggles().lds_pad <= (slab_wide(s) ? (size_t)160 * 1024 - 1024 : (size_t)64 * 1024);
+}
+
+static bool slab_path(const nvh_batch* b) { return slab_shape_ok(b) && slab_size_ok(b); }
 
 // k_prepare_slabs once per upload: descriptors -> per-frame slabs (integer work: floor unwrap, chain-major pair records).
 int ensure_slabs(nvh_batch* b) {
-  if (b->slabs_ready || b->nframes == 0 || !slab_path(b)) return NVH_OK;
+  if (b->slabs_ready || b->slab_host || b->nframes == 0 || !slab_path(b)) return NVH_OK;
   nvh_stream* s = b->s;
   hipStream_t st = s->ctx->stream;
   const size_t stride = slab_bound_vecs(b);
@@ -585,7 +645,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   if (b->slabs_ready && compact && !no_fused_imdct) {
     NvhSynthArgs A;
     A.consts = s->shared->synth_consts;
-    A.slabs = (const uint4*)b->slab3.p;
+    A.slabs = b->slab_host ? b->d_slabs : (const uint4*)b->slab3.p;
     A.work = work;
     A.err = flags;
     for (int w = 0; w < 2; w++) {

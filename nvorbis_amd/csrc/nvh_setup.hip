@@ -27,59 +27,11 @@ int upload_setup(nvh_stream* s) {
   if (S.channels > 255) return NVH_ERR_UNSUPPORTED;
   if (S.books.size() > 256) return NVH_ERR_UNSUPPORTED;
 
+  // codebook directory + lattice pool + VQ table pool (host_slab.cpp: the host slab writer uses the same directory)
   std::vector<float> vq;
   std::vector<uint32_t> lattice;
-  std::vector<NvhDevBook> books(S.books.size());
-  for (size_t i = 0; i < S.books.size(); i++) {
-    const nvh::Codebook& b = S.books[i];
-    books[i].lat_values = 0;
-    books[i].lat_magic = 0;
-    books[i].lat_off = 0;
-    books[i].dim_magic16 = b.dimensions >= 1 ? (uint32_t)((65536u + (uint32_t)b.dimensions - 1u) / (uint32_t)b.dimensions) : 0u;
-    // lattice fast path: digits via exact reciprocal multiplies (entry < 2^16, powers <= entries)
-    if (b.lattice_values >= 1 && b.dimensions >= 1 && b.dimensions <= 16 && b.entries <= 0xFFFF) {
-      bool ok = true;
-      std::vector<uint32_t> magics;
-      uint64_t pw = 1;
-      for (int d = 0; d < b.dimensions && ok; d++) {
-        if (pw > 0xFFFF) { ok = false; break; }
-        magics.push_back(pw > 1 ? (uint32_t)((0x100000000ull + pw - 1) / pw) : 0u);  // 0: divisor 1
-        pw *= (uint64_t)b.lattice_values;
-      }
-      // self-check against the table the reference algorithm builds
-      for (int e = 0; ok && e < b.entries; e++) {
-        int q = e;
-        for (int d = 0; d < b.dimensions; d++) {
-          uint32_t bits_t, bits_l;
-          float tv = b.lookup[(size_t)e * b.dimensions + d], lv = b.lattice[(size_t)(q % b.lattice_values)];
-          std::memcpy(&bits_t, &tv, 4);
-          std::memcpy(&bits_l, &lv, 4);
-          if (bits_t != bits_l) { ok = false; break; }
-          q /= b.lattice_values;
-        }
-      }
-      if (ok) {
-        books[i].lat_values = (uint32_t)b.lattice_values;
-        books[i].lat_magic = b.lattice_values > 1 ? (uint32_t)((0x100000000ull + (uint64_t)b.lattice_values - 1) / (uint64_t)b.lattice_values) : 0u;
-        books[i].lat_off = (uint32_t)lattice.size();
-        for (float v : b.lattice) {
-          uint32_t bits;
-          std::memcpy(&bits, &v, 4);
-          lattice.push_back(bits);
-        }
-        lattice.insert(lattice.end(), magics.begin(), magics.end());
-      }
-    }
-    books[i].entries = (uint32_t)b.entries;
-    books[i].dim = (uint32_t)b.dimensions;
-    books[i].dim_magic = b.dimensions > 1 ? (uint32_t)((0x100000000ull + (uint64_t)b.dimensions - 1) / (uint64_t)b.dimensions) : 0u;
-    if (b.map_type == 0) {
-      books[i].tab_off = 0xFFFFFFFFu;
-    } else {
-      books[i].tab_off = (uint32_t)vq.size();
-      vq.insert(vq.end(), b.lookup.begin(), b.lookup.end());
-    }
-  }
+  nvh::build_book_directory(S, s->shared->slab, vq, lattice);
+  const std::vector<NvhDevBook>& books = s->shared->slab.books;
 
   std::vector<int32_t> ipool;
   std::vector<float> fpool;

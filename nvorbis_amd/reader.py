@@ -235,6 +235,20 @@ class Stream:
         check(lib().nvh_stream_pending_geometry(self._h, out.ctypes.data, max(fr, 1)), "nvh_stream_pending_geometry")
         return out[:fr]
 
+    def pending_slabs(self):
+        """The pending frames as the synthesis kernels fetch them (per-frame slabs, nvh_format.h: NvhSlabHdr), written on the
+        host: (uint32 words of all slabs back to back, first 16-byte unit of every frame's slab [frames + 1])."""
+        fr, _ = self.pending()
+        need = C.c_int64(0)
+        first = np.zeros(fr + 1, dtype=np.uint32)
+        rc = lib().nvh_stream_pending_slabs(self._h, None, 0, C.byref(need), first.ctypes.data, fr + 1)
+        if rc not in (0, -2):
+            check(rc, "nvh_stream_pending_slabs")
+        buf = np.zeros(max(need.value // 4, 4), dtype=np.uint32)
+        check(lib().nvh_stream_pending_slabs(self._h, buf.ctypes.data, buf.nbytes, C.byref(need), first.ctypes.data, fr + 1),
+              "nvh_stream_pending_slabs")
+        return buf[:need.value // 4], first
+
     def position(self):
         pos, em, eos = C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(lib().nvh_stream_position(self._h, C.byref(pos), C.byref(em), C.byref(eos)), "nvh_stream_position")
