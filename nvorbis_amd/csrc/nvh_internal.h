@@ -272,6 +272,7 @@ struct nvh_batch {
   int max_ops = 0, max_ent = 0, max_pass = 0;  // largest per-frame op / entry / pass slice (LDS staging capacity of k_spectrum)
   bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
   bool block_only = false;       // nvh_mode_decode: stop after the windowed IMDCT (full blocks in the work planes, no overlap-add)
+  bool descriptors_only = false; // nvh_residue_decode: the caller launches a descriptor kernel itself (no slabs)
   bool has_carry_in = false;
   // run kernel (kernels_run.hip): the batch's geometry is inside its contract; hand-off flags and their epoch
   bool run_ok = false;

@@ -473,7 +473,7 @@ static size_t slab_lds_bytes(const nvh_batch* b) {
 static bool slab_shape_ok(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   const NvhToggles& T = nvh_toggles();
-  if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->max_pass > 1) return false;
+  if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->descriptors_only || b->max_pass > 1) return false;
   if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact || T.fused_ola || T.run || T.multi) return false;
   if (slab_wide(s) && T.no_gen8) return false;  // NVH_NO_GEN8 keeps its meaning: more than four channels through k_spectrum_gen
   return true;

@@ -447,6 +447,7 @@ extern "C" int nvh_residue_decode(nvh_stream* s, int residue_index, const uint8_
     b.blob.pool = b.work.pool = b.carry_in.pool = b.slabs.pool = b.run_flags.pool = b.dev_copy.pool = &s->ctx->pool;
     b.h_blob.host = true;
     b.h_blob.pool = &s->ctx->hpool;
+    b.descriptors_only = true;  // k_residue below reads the op list
     const bool was_gpu = s->gpu_parse;
     s->gpu_parse = false;
     std::swap(s->pending, fb);
