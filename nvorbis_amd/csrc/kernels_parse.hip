@@ -526,12 +526,16 @@ k_parse_g(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRe
                     scratch_words, pkt_words);
 }
 
-// Second pass: what a frame needs from its overlap source (known only after every lane has parsed its packet):
-// the source frame's execute flags (NvhChan::ov_exec / NvhFrame::ov_exec_mask).  carry_exec_in: flags of the block
-// carried in from the previous batch; the last decoded frame's flags go out for the next one.
+// Second pass: what a frame needs from its neighbours (known only after every lane has parsed its packet): the overlap source's
+// execute flags (NvhChan::ov_exec / NvhFrame::ov_exec_mask) -- carry_exec_in: flags of the block carried in from the previous
+// batch; the last decoded frame's flags go out for the next one -- and the final word on paired emission (nvh_format.h:
+// NVH_EMIT_*).  The host marked the candidates from the geometry alone; a steady-state overlap also needs every channel of both
+// blocks to execute (Mapping.cs:104-131 decided that inside k_parse).  A candidate that fails is handed back to k_ola_compact and
+// reported (emit_ok = 0: the host then runs k_ola_compact over every frame instead of over its list).
 extern "C" __global__ void __launch_bounds__(64)
 k_parse_links(int nframes, int channels, NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans,
-              const uint32_t* __restrict__ carry_exec_in, uint32_t* __restrict__ carry_exec_out, int last_decoded) {
+              const uint32_t* __restrict__ carry_exec_in, uint32_t* __restrict__ carry_exec_out, int last_decoded,
+              NvhParseResult* __restrict__ result) {
   const int f = blockIdx.x * 64 + threadIdx.x;
   if (f >= nframes) return;
   const NvhFrame fr = frames[f];
@@ -543,4 +547,22 @@ k_parse_links(int nframes, int channels, NvhFrame* __restrict__ frames, NvhChan*
     for (int c = 0; c < channels; c++) chans[(long long)f * channels + c].ov_exec = (m >> c) & 1u;
   }
   if (f == last_decoded) carry_exec_out[0] = fr.exec_mask;  // ping-pong with the carried block itself (nvh_api.hip)
+  const uint32_t all_ch = channels >= 32 ? 0xFFFFFFFFu : (1u << channels) - 1u;
+  auto full = [&](uint32_t x) { return (x & all_ch) == all_ch; };
+  uint32_t ef = fr.emit_flags;
+  if (ef & (NVH_EMIT_DONE | NVH_EMIT_NEXT)) {
+    const bool me = full(fr.exec_mask);
+    if (ef & NVH_EMIT_SELF_CARRY) {
+      if (!me) ef &= ~(NVH_EMIT_SELF | NVH_EMIT_SELF_CARRY | NVH_EMIT_DONE);
+    } else if (ef & NVH_EMIT_DONE) {  // steady: this block over the whole second half of frame f - 1
+      if (!(me && f >= 1 && full(frames[f - 1].exec_mask))) ef &= ~(NVH_EMIT_SELF | NVH_EMIT_DONE);
+    }
+    if (ef & NVH_EMIT_NEXT) {  // frame f + 1 steady over this one
+      if (!(me && f + 1 < nframes && full(frames[f + 1].exec_mask))) ef &= ~NVH_EMIT_NEXT;
+    }
+    if (ef != fr.emit_flags) {
+      frames[f].emit_flags = ef;
+      atomicAnd(&result->emit_ok, 0);
+    }
+  }
 }

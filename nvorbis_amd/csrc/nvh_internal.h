@@ -51,7 +51,7 @@ __global__ void k_parse_g(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacke
                           NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
                           NvhParseResult* result, int lanes, int scratch_words, int pkt_words);
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
-                              uint32_t* carry_exec_out, int last_decoded);
+                              uint32_t* carry_exec_out, int last_decoded, NvhParseResult* result);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
 __global__ void k_copy_f4(const float4* src, float4* dst, long long n4);
 #ifdef NVH_EXPERIMENTS  // measured slower than the default path: build.py --experiments only
@@ -289,6 +289,7 @@ struct nvh_batch {
   const uint4* d_slabs = nullptr;  // ... here
   // paired emission (nvh_format.h: NVH_EMIT_*): frames whose PCM k_synth writes itself, and the frames left to k_ola_compact
   int emit_frames = 0;           // frames with NVH_EMIT_DONE
+  bool ola_all = false;          // GPU-parsed batch in which k_parse_links withdrew an emission candidate: k_ola_compact over every frame
   int ola_count = 0;             // entries of d_ola_list
   const int* d_ola_list = nullptr;  // inside the descriptor blob
   bool prepare_events_pending = false;  // prep_e0 / prep_e1 bracket k_prepare_slabs of this upload (read by nvh_batch_stats[7], ns)

@@ -43,7 +43,7 @@ static int replay_on_host(nvh_stream* s) {
 }
 
 // GPU-parse mode: upload frame geometry + packets, let k_parse produce the descriptors into per-frame slabs.
-static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
+static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>& ola_list) {
   nvh::FrameBatch& P = s->pending;
   const NvhDevParse& T = s->shared->parse;
   const int ch = s->setup.channels;
@@ -55,7 +55,8 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   const size_t o_fr = 0;
   const size_t o_ch = al(o_fr + std::max<size_t>(nf, 1) * sizeof(NvhFrame));
   const size_t o_rf = al(o_ch + std::max<size_t>(nf * ch, 1) * sizeof(NvhChan));
-  const size_t o_pk = al(o_rf + std::max<size_t>(nf, 1) * sizeof(NvhPacketRef));
+  const size_t o_ol = al(o_rf + std::max<size_t>(nf, 1) * sizeof(NvhPacketRef));
+  const size_t o_pk = al(o_ol + std::max<size_t>(ola_list.size(), 1) * sizeof(int));
   const size_t host_bytes = al(o_pk + P.pkt_pool.size() + 8);
   // ... and the device-only slabs behind it
   const size_t o_ps = host_bytes;
@@ -73,6 +74,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   if (nf) std::memcpy(h + o_fr, P.frames.data(), nf * sizeof(NvhFrame));
   if (nf) std::memcpy(h + o_ch, P.chans.data(), std::min(P.chans.size(), nf * (size_t)ch) * sizeof(NvhChan));
   if (nf) std::memcpy(h + o_rf, P.pkt_refs.data(), nf * sizeof(NvhPacketRef));
+  if (!ola_list.empty()) std::memcpy(h + o_ol, ola_list.data(), ola_list.size() * sizeof(int));
   std::memcpy(h + o_pk, P.pkt_pool.data(), P.pkt_pool.size());
   std::memset(h + o_pk + P.pkt_pool.size(), 0, 8);
   b->descriptor_bytes = (int64_t)(nf * (sizeof(NvhFrame) + sizeof(NvhPacketRef)) + P.pkt_pool.size());
@@ -82,6 +84,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   NvhParseResult init{};
   init.err_frame = 0x7FFFFFFF;
   init.links_ok = 1;
+  init.emit_ok = 1;
   // (a 32-byte pageable source: staged by the runtime before the call returns)
   HIP_TRY(hipMemcpyAsync(base + o_rs, &init, sizeof init, hipMemcpyHostToDevice, st));
   b->dev.frames = (const NvhFrame*)(base + o_fr);
@@ -95,6 +98,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   b->dev.nframes = b->nframes;
   b->dev.pad = 0;
   b->dev_copy_valid = false;
+  b->d_ola_list = (const int*)(base + o_ol);
   if (nf) {
     const unsigned blocks = (unsigned)((nf + 63) / 64);
     // Launch shape.  Packets take different paths through the parser, so the lanes of a wavefront mostly run one after
@@ -132,7 +136,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
     // the carried block's execute flags ping-pong together with the carried block (nvh_stream_synth flips carry_cur)
     uint32_t* ce = (uint32_t*)s->carry_exec.p;
     hipLaunchKernelGGL(k_parse_links, dim3(blocks), dim3(64), 0, st, (int)nf, ch, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch),
-                       (const uint32_t*)(ce + s->carry_cur), ce + (s->carry_cur ^ 1), b->last_decoded);
+                       (const uint32_t*)(ce + s->carry_cur), ce + (s->carry_cur ^ 1), b->last_decoded, (NvhParseResult*)(base + o_rs));
     HIP_TRY(hipGetLastError());
   }
   rc = collect_parse_result(s, b, (const NvhParseResult*)(base + o_rs));
@@ -140,6 +144,9 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b) {
   size_t plane = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
   rc = b->work.reserve(std::max<size_t>((size_t)b->nframes, 1) * plane);
   if (rc != NVH_OK) return rc;
+  // second phase of the GPU parser: the descriptors k_parse wrote become the slabs the synthesis kernels fetch (the same
+  // integer work host_slab.cpp does on the host parser's thread), still part of the parse step
+  if ((rc = ensure_slabs(b)) != NVH_OK) return rc;
   P.clear();
   s->parser->begin_batch();
   return NVH_OK;
@@ -158,6 +165,7 @@ static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResul
   b->max_ent = r->max_ent;
   b->max_pass = r->max_pass;
   b->links_ok = r->links_ok != 0;
+  b->ola_all = r->emit_ok == 0;  // k_parse_links withdrew an emission candidate: the host's list of left-over frames is short
   // some packet of the batch would have made the managed decoder throw: the batch is parsed again on the host
   if (r->err_frame != 0x7FFFFFFF) return NVH_INTERNAL_REPLAY;
   return NVH_OK;
@@ -229,9 +237,12 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->emit_frames = 0;
   {
     const int ch = s->setup.channels;
-    const bool can = !s->gpu_parse && !nvh_toggles().no_emit && ch <= 2 && !P.sequential_ola && s->setup.block0 >= 256 &&
-                     s->setup.block1 <= 2048;
+    const bool can = !nvh_toggles().no_emit && ch <= 2 && !P.sequential_ola && s->setup.block0 >= 256 && s->setup.block1 <= 2048;
     const unsigned all_ch = (1u << ch) - 1u;
+    // GPU-parse mode: the execute flags are decided inside k_parse (Mapping.cs:104-131); the host marks the candidates from the
+    // geometry and k_parse_links has the last word (kernels_parse.hip)
+    const bool gp = s->gpu_parse;
+    auto full = [&](uint32_t m) { return gp || (m & all_ch) == all_ch; };
     const int nf = (int)P.frames.size();
     auto steady = [&](int g) {
       if (!can || g < 1 || g >= nf) return false;
@@ -239,8 +250,8 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       const NvhFrame& pv = P.frames[(size_t)g - 1];
       const int half = fr.n >> 1;
       return fr.n >= 256 && pv.n == fr.n && fr.ov_frame == g - 1 && fr.ov_n == fr.n && fr.start == 0 && fr.emit_start == 0 &&
-             fr.emit_count == half && fr.ov_src == half && fr.ov_len == half && (fr.exec_mask & all_ch) == all_ch &&
-             (fr.ov_exec_mask & all_ch) == all_ch && (pv.exec_mask & all_ch) == all_ch && ((fr.out_pos * ch) & 3) == 0 &&
+             fr.emit_count == half && fr.ov_src == half && fr.ov_len == half && full(fr.exec_mask) &&
+             full(fr.ov_exec_mask) && full(pv.exec_mask) && ((fr.out_pos * ch) & 3) == 0 &&
              fr.out_pos >= 0 && fr.out_pos < 0x7FFFFFFFll && fr.window_off < 0x7FFFFFFFu;
     };
     for (int g = 0; g < nf; g++) {
@@ -258,7 +269,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       NvhFrame& fr = P.frames[0];
       const int half = fr.n >> 1;
       if (fr.n >= 256 && fr.ov_frame == -2 && fr.ov_n == fr.n && fr.start == 0 && fr.emit_start == 0 && fr.emit_count == half &&
-          fr.ov_src == half && fr.ov_len == half && (fr.exec_mask & all_ch) == all_ch && ((fr.out_pos * ch) & 3) == 0 &&
+          fr.ov_src == half && fr.ov_len == half && full(fr.exec_mask) && ((fr.out_pos * ch) & 3) == 0 &&
           fr.out_pos >= 0 && fr.out_pos < 0x7FFFFFFFll) {
         fr.emit_flags |= NVH_EMIT_SELF | NVH_EMIT_SELF_CARRY | NVH_EMIT_DONE;
         b->emit_frames++;
@@ -288,12 +299,13 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   }
   b->ola_count = (int)ola_list.size();
   b->d_ola_list = nullptr;
+  b->ola_all = false;
 
   b->stats[0] = (int64_t)P.frames.size(); b->stats[1] = (int64_t)P.chans.size(); b->stats[2] = (int64_t)P.passes.size();
   b->stats[3] = (int64_t)P.ops.size(); b->stats[4] = (int64_t)P.entries.size(); b->stats[5] = (int64_t)P.posts.size();
   b->stats[6] = (int64_t)P.coeffs.size();
   if (s->gpu_parse) {
-    int rc = batch_upload_gpu(s, b);
+    int rc = batch_upload_gpu(s, b, ola_list);
     if (rc != NVH_INTERNAL_REPLAY) {
       if (rc == NVH_OK) s->replay.clear();
       return rc;
@@ -861,6 +873,10 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
         hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
                            (const float*)work, carry, d_pcm, s->clip, flags + 1, carry_out, b->last_decoded, T.no_ola_sym ? 1 : 0,
                            (const int*)nullptr, 0);
+      else if (b->ola_all)  // GPU-parsed batch, some candidate withdrawn on the device: every frame, the emitted ones return at once
+        hipLaunchKernelGGL(k_ola_compact, dim3((unsigned)b->nframes, (unsigned)segs), dim3((unsigned)ola_threads), 0, st, s->dev, b->dev,
+                           (const float*)work, carry, d_pcm, s->clip, flags + 1, (float*)nullptr /* k_synth wrote the carried tail */,
+                           b->last_decoded, T.no_ola_sym ? 1 : 0, (const int*)nullptr, 1);
       else if (b->ola_count == 0)
         b->slot_name[3] = "-";  // paired emission covered every frame, the carried tail included: no launch
       else  // paired emission: only the frames k_synth left over

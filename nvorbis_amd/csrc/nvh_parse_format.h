@@ -99,5 +99,6 @@ struct NvhParseResult {
   int32_t err_frame;   // first frame (lowest index) whose packet would have made the reference throw, or 0x7FFFFFFF
   int32_t err_code;    // its NVH_ERR_* code
   int32_t links_ok;
-  int32_t pad[2];
+  int32_t emit_ok;     // 1: every paired-emission candidate the host marked stands (all channels execute in the frames involved)
+  int32_t pad;
 };

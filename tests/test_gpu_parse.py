@@ -157,3 +157,32 @@ def test_exceptions_surface_where_the_reference_throws(oracle, gpu_ctx, gpu_pars
     assert got_err == ref_err
     a, b = np.concatenate(got), np.concatenate(ref)
     assert a.size == b.size and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("gpu_parse", [False, True])
+def test_paired_emission_with_silent_channels(oracle, gpu_ctx, ogg_bytes, gpu_parse):
+    """A steady long/long run in which now and then a channel has no floor (ExecuteChannel false, Mapping.cs:104-131).  The host
+    marks paired-emission candidates from the geometry; for GPU-parsed batches the execute flags exist only on the device, so
+    k_parse_links withdraws the candidates that involve such a frame and k_ola_compact takes those frames back
+    (nvh_launch.hip: ola_all).  Both parsers, bit-exact against the oracle; batches of 512 are > 7/8 steady state, so the
+    emission is on."""
+    import nvorbis_amd as nv
+    from tests import vorbis_encode as ve
+    hdr = ve.shipped_headers(ogg_bytes["3test"])
+    S = ve.setup_of(hdr)
+    enc = ve.PacketEncoder(S)
+    rng = np.random.default_rng(5)
+    long_mode = next(i for i, (f, _) in enumerate(S.modes) if f)
+    n = 1200
+    pk = list(hdr)
+    for i in range(n):
+        # (a silent magnitude / angle channel of a coupled pair executes anyway when its partner does, Mapping.cs:112-119:
+        # both silent is what switches the pair off)
+        silent = (0, 1) if i % 97 == 40 else ((1,) if i % 151 == 75 else ())
+        pk.append(enc.packet(rng, long_mode, 1, 1, silent=silent))
+    gr = [-1, -1, -1] + ve.granules_for(S, np.ones(n, dtype=bool))
+    fl = [0] * len(pk)
+    ref, _ = oracle.decode_packets(pk, gr, fl, clip=True)
+    for bf in (512, 100):
+        got = _decode(nv, gpu_ctx, pk, gr, fl, gpu_parse, bf)
+        assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (gpu_parse, bf)
