@@ -9,6 +9,13 @@ IMDCT + window -> overlap-add + interleave + clip) over that batch, descriptors 
 HBM, PCM written to HBM.  Weak scaling: every rank owns one GPU and one such batch, no collective in
 the data path.
 
+What is resident when the clock starts is the packet parser's output: since round 4 the parser's own thread writes the per-frame
+slabs the synthesis kernels fetch (nvorbis_amd/csrc/host_slab.cpp: Floor1 unwrap + segment lists, chain-major vector-write
+records), so a pass is ALL the GPU work a once-synthesised batch needs -- the same launches the streaming reader runs for every
+look-ahead batch (k_synth over the odd frames, k_synth_emit over the even ones); nothing is converted or prepared outside the
+timed region.  After the timed region the PCM of every resident batch is hashed and compared with the digest the CPU oracle
+produced for the same packets (tests/golden/bench_pcm_digests.json, tools/gen_bench_digests.py): `pcm_digest_ok`.
+
 Launch: python bench.py --gpus N --steps K --warmup W.  For N > 1 the script starts its own ranks (it re-executes
 itself under torch.distributed.run, one rank per GPU over RCCL) unless it already runs as a rank (WORLD_SIZE set).
 
@@ -145,6 +152,7 @@ def end_to_end(nv, ctx, headers, ll, frames=32768, rounds=6):
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     out["host_parser_frames_per_s"] = frames / best
+    out["host_parser_kernels"] = [k for k in st.kernels() if k != "-"]
     st.close()
     st = nv.Stream(ctx, *headers)
     st.set_gpu_parse(True)
@@ -167,6 +175,7 @@ def end_to_end(nv, ctx, headers, ll, frames=32768, rounds=6):
         dt = (time.perf_counter() - t0) / rounds
         best = dt if best is None or dt < best else best
     out["gpu_parser_pipelined_frames_per_s"] = frames / best
+    out["gpu_parser_kernels"] = ["k_parse", "k_parse_links", "k_prepare_slabs"] + [k for k in st.kernels() if k != "-"]
     out["gpu_parser_pcm_GBps_over_pcie"] = frames * (BLOCK // 2) * 2 * 4 / best / 1e9
     st.close()
     return out
@@ -203,6 +212,28 @@ def make_batches(nv, torch, ctx, headers, audio, ch, frames, count, seed_off=0):
         pcm = torch.empty(max(b.samples * ch, 1), dtype=torch.float32, device="cuda")
         out.append((b, pcm))
     return stream, out
+
+
+def check_digests(insts, seeds, no_check=False):
+    """Hash the PCM every resident batch wrote last and compare with the CPU oracle's digest of the same packets
+    (tests/golden/bench_pcm_digests.json; the oracle itself is not run here).  Returns (ok, batches compared)."""
+    import hashlib
+    path = os.path.join(ROOT, "tests", "golden", "bench_pcm_digests.json")
+    want = json.load(open(path))["digests"]
+    ok, n = True, 0
+    for (_, _, _, batches_k), seed in zip(insts, seeds):
+        ref = want.get("seed%d" % seed)
+        if ref is None:
+            continue
+        for j, (b, pcm) in enumerate(batches_k):
+            if j >= len(ref):
+                break
+            got = hashlib.sha256(pcm.cpu().numpy().tobytes()).hexdigest()
+            n += 1
+            if got != ref[j]:
+                ok = False
+                sys.stderr.write("bench.py: PCM digest mismatch (seed %d, batch %d)\n" % (seed, j))
+    return ok, n
 
 
 def config_lines(nv, torch, ctx, root):
@@ -243,7 +274,7 @@ def config_lines(nv, torch, ctx, root):
                     "algorithmic_bytes_per_batch": alg, "frac_of_hbm_peak_pipeline": alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "frac_of_hbm_peak_dominant_kernel": alg / (km[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "descriptor_bytes_per_frame": b.descriptor_bytes / max(b.frames, 1),
-                    "prepare_us_per_batch": b.stats().get("prepare_ns", 0) / 1e3}
+                    }
         # the same batch on three decoder instances (own HIP streams), passes rotating without synchronisation as in the
         # headline loop: what the GPU sustains when batches of independent streams follow each other (>= 0.5 s, L3-resident)
         extra = []
@@ -319,7 +350,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started plainly with --gpus N: become N ranks (one per GPU of this node, RCCL over xGMI)
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
+        if have < args.gpus and not os.environ.get("NVH_BENCH_SHARE_GPU"):
             sys.stderr.write("bench.py --gpus %d: this node shows %d HIP device(s); the multi-GPU run needs %d\n" % (args.gpus, have, args.gpus))
             raise SystemExit(2)
         import socket
@@ -366,9 +397,9 @@ def main():
     # descriptors / slabs + compact work planes + PCM, touched per pass; with paired emission (kernels_synth.hip: the even frames
     # overlap-add from registers) only the odd frames' planes are written and read
     fused = not os.environ.get("NVH_NO_EMIT")
-    per_batch_bytes = FRAMES * (2200 + (ch * (BLOCK // 2) * 4) * (3 if fused else 4) // 2)
+    per_batch_bytes = FRAMES * (4400 + (ch * (BLOCK // 2) * 4) * (3 if fused else 4) // 2)
     reps = max(1, int(args.working_set_mib * (1 << 20) / (nin * per_batch_bytes) + 0.999))
-    insts = []
+    insts, seeds = [], []
     for k in range(nin):
         # the context's own HIP stream (hipStreamNonBlocking, created by nvh_ctx_create): never the legacy default stream, which
         # serialises against every other stream.  Three instances: sustained (>= 1.5 s) HBM-resident rates measured with paired
@@ -376,7 +407,8 @@ def main():
         # 129 / 132 / 124 / 129 / 129 M.
         ts = None
         ctx_k = nv.Context(local_rank)
-        stream_k, batches_k = make_batches(nv, torch, ctx_k, headers, ll, ch, FRAMES, reps, seed_off=rank * 7 + k * 13)
+        seeds.append(rank * 7 + k * 13)
+        stream_k, batches_k = make_batches(nv, torch, ctx_k, headers, ll, ch, FRAMES, reps, seed_off=seeds[-1])
         for b, _ in batches_k:
             assert b.frames == FRAMES and b.samples == FRAMES * (BLOCK // 2), (b.frames, b.samples)
         insts.append((ts, ctx_k, stream_k, batches_k))
@@ -453,6 +485,16 @@ def main():
     total_l3, km_l3 = batch.time(pcm.data_ptr(), cap, 50)
     checksum = float(pcm.double().abs().sum().item())
     assert args.no_check or (checksum > 0 and bool(torch.isfinite(pcm).all().item()))
+    # every resident batch's PCM against the CPU oracle's digest of the same packets: a line cannot come from kernels that write
+    # wrong samples (every rank checks its own; rank 0 reports the AND)
+    torch.cuda.synchronize()
+    digest_ok, digest_n = check_digests(insts, seeds)
+    if dist is not None:
+        t = torch.tensor([1.0 if digest_ok else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        digest_ok = bool(t.item() > 0.5)
+    if not (digest_ok and digest_n > 0) and not args.no_check:
+        raise SystemExit("bench.py: the PCM of the timed batches does not match the oracle's digests -- no line")
 
     if rank == 0:
         # the library says which kernel variant sits behind each timing slot ("-" = empty: only event overhead)
@@ -464,7 +506,7 @@ def main():
         alg_bytes = FRAMES * ch * 4 * BLOCK
         # paired emission: k_synth runs twice per pass, each launch over half of the batch's frames (the library times the two
         # together); per LAUNCH, like rocprofv3's average and the PMC traffic: half the bytes, half the duration
-        launches = 2 if (fused and names[dom] == "k_synth") else 1
+        launches = 2 if names[dom] == "k_synth+k_synth_emit" else 1
         dom_ms = km[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh);
@@ -536,7 +578,7 @@ def main():
                          "traffic_build_matches": (traffic_build == nv.native.build_id()) if traffic is not None else None,
                          "algorithmic_bytes_per_launch": alg_bytes // launches, "avg_launch_ms": dom_ms / launches,
                          "launches_per_pass": launches,
-                         "kernel_scope": ("k_synth = residue + floor + inverse MDCT + (paired emission) window / overlap-add / clip / interleave of the "
+                         "kernel_scope": ("k_synth+k_synth_emit = residue + floor + inverse MDCT + (paired emission) window / overlap-add / clip / interleave of the "
                                           "steady-state frames, two launches per pass (odd frames, then the emitting even frames), timed together, one stream"
                                           if fused else "k_synth = residue + floor + inverse MDCT; overlap-add in k_ola_compact"),
                          "unfused": unfused,
@@ -548,9 +590,10 @@ def main():
                                          "frac": alg_bytes / (km_l3[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                          "whole_pass_frac": alg_bytes / (l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                          "copy_ceiling_GBps": ceiling},
-            # once per upload, outside the timed region: descriptors -> per-frame slabs (integer work only: Floor1 unwrap, segment
-            # lists, chain-major pair records), what the timed kernels then fetch by LDS-DMA
-            "prepare": {"kernels": "k_prepare_slabs", "us_per_batch": batches0[-1][0].stats().get("prepare_ns", 0) / 1e3},  # a later upload: the first pays the code load
+            "pcm_digest_ok": digest_ok, "pcm_digests_checked": digest_n,
+            "decode_path": "resident input = the host packet parser's output (per-frame slabs, host_slab.cpp); a pass = every kernel a "
+                           "once-synthesised batch needs (the streaming reader runs the same launches per look-ahead batch); no prepare / "
+                           "conversion kernel exists for host-parsed batches",
             "build": nv.native.build_id(),
         }
         if world == 1 and not args.no_configs:

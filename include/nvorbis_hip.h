@@ -272,6 +272,8 @@ int nvh_batch_stats(const nvh_batch *b, int64_t *out8);
 /* Names of the kernels behind the four timing slots of nvh_batch_time, as launched last (comma separated,
  * "-" = empty slot): which of the kernel variants ran depends on the stream shape. */
 int nvh_batch_kernels(const nvh_batch *b, char *buf, int cap);
+/* The same for the batch nvh_stream_synth / nvh_stream_synth_begin launched last (the stream's own look-ahead batch). */
+int nvh_stream_kernels(const nvh_stream *s, char *buf, int cap);
 /* Launch the synthesis kernels for a resident batch (asynchronous on the context's stream);
  * may be repeated, results are identical each time.  d_pcm holds samples*channels floats. */
 int nvh_batch_synth(nvh_batch *b, float *d_pcm, int64_t capacity);

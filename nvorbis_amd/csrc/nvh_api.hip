@@ -743,6 +743,10 @@ extern "C" int nvh_batch_kernels(const nvh_batch* b, char* buf, int cap) {
   });
 }
 
+extern "C" int nvh_stream_kernels(const nvh_stream* s, char* buf, int cap) {
+  return nvh_batch_kernels(s ? &s->scratch : nullptr, buf, cap);
+}
+
 extern "C" int nvh_batch_synth(nvh_batch* b, float* d_pcm, int64_t capacity) {
   return nvh_guard([&]() -> int {
     if (!b || !b->s) return NVH_ERR_ARGUMENT;

@@ -703,6 +703,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       A.f0 = 0;
       hipLaunchKernelGGL(k_synth_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     }
+    if (emitted) b->slot_name[1] = "k_synth+k_synth_emit";  // odd frames, then the emitting even frames
     slab_done = true;
     fuse_gen8 = true;  // the inverse MDCT is inside: no transform kernel behind it
   }

@@ -93,6 +93,7 @@ SIGNATURES = {
     "nvh_batch_info": (C.c_int, [_vp, _ip, _ip, _i64p, _i64p]),
     "nvh_batch_stats": (C.c_int, [_vp, _i64p]),
     "nvh_batch_kernels": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "nvh_stream_kernels": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "nvh_batch_synth": (C.c_int, [_vp, _vp, C.c_int64]),
     "nvh_batch_time": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _f32p, _f32p]),
     "nvh_batch_free": (None, [_vp]),

@@ -235,6 +235,12 @@ class Stream:
         check(lib().nvh_stream_pending_geometry(self._h, out.ctypes.data, max(fr, 1)), "nvh_stream_pending_geometry")
         return out[:fr]
 
+    def kernels(self):
+        """Kernel names behind the four timing slots of the stream's last synthesis launch ("-" = empty slot)."""
+        buf = C.create_string_buffer(256)
+        check(lib().nvh_stream_kernels(self._h, buf, 256), "nvh_stream_kernels")
+        return buf.value.decode().split(",")
+
     def pending_slabs(self):
         """The pending frames as the synthesis kernels fetch them (per-frame slabs, nvh_format.h: NvhSlabHdr), written on the
         host: (uint32 words of all slabs back to back, first 16-byte unit of every frame's slab [frames + 1])."""

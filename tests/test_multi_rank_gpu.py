@@ -1,0 +1,52 @@
+"""The N > 1 code paths on the one GPU a test box has: bench.py's rank launch, barriers, MAX-over-ranks timing and
+rank-0 reporting, and the corpus transcoder's LPT shard + gather of device-resident PCM -- two ranks on device 0 over gloo
+(NVH_BENCH_SHARE_GPU=1).  Not a scaling measurement (the 8-GPU run is the driver's): it checks that the line is well formed,
+that the PCM digests hold on every rank, and that the gathered corpus PCM is byte-identical to the single-rank run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_two_ranks_share_one_gpu():
+    env = dict(os.environ)
+    env["NVH_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--min-timed-ms", "60",
+                        "--working-set-mib", "64", "--no-configs", "--no-cpu-baseline", "--no-unfused"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["pcm_digest_ok"] is True and d["pcm_digests_checked"] >= 3
+    assert d["value"] > 1e6 and "NVH_BENCH_SHARE_GPU" in d["data"]
+    # value = frames of all ranks / the slowest rank's time
+    assert abs(d["value"] - 2 * 4096 * d["config"]["passes_per_step"] * d["steps"] / d["config"]["timed_region_s"]) < 1e-6 * d["value"]
+
+
+def test_corpus_transcode_two_ranks_equals_one_rank():
+    def run(world):
+        env = dict(os.environ)
+        env["NVH_BENCH_SHARE_GPU"] = "1"
+        cmd = [sys.executable]
+        if world > 1:
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                    "--master-port", "29731"]
+        cmd += [os.path.join(ROOT, "tools", "corpus_transcode.py"), "--files", "13", "--workers", "4"]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        return _last_json(r.stdout)
+    one, two = run(1), run(2)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert one["pcm_floats"] == two["pcm_floats"] > 0
+    assert one["pcm_sha256"] == two["pcm_sha256"]

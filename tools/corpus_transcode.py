@@ -66,7 +66,11 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 if rank == 0:
     samples = sum(int(o.numel()) for o in out)
-    print(json.dumps({"files": len(files), "n_gpus": world, "workers_per_gpu": a.workers, "decode_s": t1 - t0, "gather_s": t2 - t1,
+    import hashlib
+    hh = hashlib.sha256()
+    for o in out:  # every file's PCM in file order, as gathered on rank 0
+        hh.update(o.cpu().numpy().tobytes())
+    print(json.dumps({"pcm_sha256": hh.hexdigest(), "files": len(files), "n_gpus": world, "workers_per_gpu": a.workers, "decode_s": t1 - t0, "gather_s": t2 - t1,
                       "files_per_s": len(files) / (t2 - t0), "pcm_floats": int(samples),
                       "long_frame_equivalents_per_s": samples / 2 / 1024 / (t2 - t0)}), flush=True)
 if dist is not None:
