@@ -943,7 +943,15 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
         case 1024: imdct_wave<10, false, true, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
         case 2048: imdct_wave<11, false, true, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
         case 4096: imdct_wave<12, false, true, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-        default: __builtin_trap();  // host launches this kernel for block sizes up to 4096 only
+        case 8192: {
+          // 4096 bins per channel do not fit the registers of the in-place form: the looped transform reads the spectrum where it
+          // lies and works in a slice of its own behind the spectra (mono / stereo only: the host checks the LDS budget)
+          __syncthreads();  // the one barrier of the other sizes' WGSYNC form (the non-transforming wavefronts pass it below)
+          float* own = spec + nch * half_max + wv * (half + (n >> 4));
+          imdct_wave<13, false, true>(X, out, nullptr, own, Aa, Bb, Cc, TW, lane);
+          break;
+        }
+        default: __builtin_trap();  // host launches this kernel for block sizes up to 8192 only
       }
     }
   }

@@ -475,6 +475,7 @@ static size_t slab_lds_bytes(const nvh_batch* b) {
   const size_t ch = (size_t)s->setup.channels, b1 = (size_t)s->setup.block1;
   size_t words = (size_t)s->shared->synth_const_vecs * 4 + slab_lds_vecs(b) * 4 + ch * (b1 / 2) + b1 / 16;
   if (slab_wide(s)) words = std::max(words, ch * (b1 / 2 + b1 / 16));
+  if (b1 > 4096) words += ch * (b1 / 2 + b1 / 16);  // n = 8192: the transforms' slices lie behind the spectra, not over them
   return words * sizeof(float);
 }
 

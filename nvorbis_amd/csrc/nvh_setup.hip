@@ -211,7 +211,7 @@ int upload_setup(nvh_stream* s) {
     for (const NvhDevResidue& r : residues) all_pairs = all_pairs && r.pair_path != 0;
     s->fast_spectrum = ok && all_pairs;
     // slab synthesis kernels (kernels_synth.hip; nvh_launch.hip: slab_path)
-    bool slab_ok = !s->has_floor0 && all_pairs && S.channels <= NVH_SLAB_MAX_CH && S.block0 >= 256 && S.block1 <= 4096 &&
+    bool slab_ok = !s->has_floor0 && all_pairs && S.channels <= NVH_SLAB_MAX_CH && S.block0 >= 256 && S.block1 <= 8192 &&
                    s->shared->synth_consts != nullptr;
     for (const nvh::Mapping& m : S.mappings) slab_ok = slab_ok && m.coupling_angle.size() <= (size_t)NVH_SLAB_MAX_COUPLE;
     for (const NvhDevResidue& r : residues)

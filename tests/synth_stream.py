@@ -382,6 +382,14 @@ def config(name):
                  mappings=[lambda w: write_mapping(w, 1, 1, [], None, [(0, 0)]),
                            lambda w: write_mapping(w, 1, 1, [], None, [(1, 1)])],
                  modes=[(0, 0), (1, 1)])
+    elif name == "stereo_8192":               # largest block size, two coupled channels: the slab kernels' non-in-place transform
+        c.update(channels=2, block0=512, block1=8192,
+                 floors=[_floor1_long(0, 1, 9, n_parts=3), _floor1_long(0, 1, 13, n_parts=10)],
+                 residues=[lambda w: write_residue(w, 1, 0, 240, 16, 2, [1, 3, 0, 2], [3, 4, 3, 3]),
+                           lambda w: write_residue(w, 2, 0, 7936, 64, 2, [1, 3, 5, 7], [4, 3, 5, 3, 4, 5, 3, 4])],
+                 mappings=[lambda w: write_mapping(w, 2, 1, [(1, 0)], None, [(0, 0)]),
+                           lambda w: write_mapping(w, 2, 1, [(0, 1)], None, [(1, 1)])],
+                 modes=[(0, 0), (1, 1)])
     elif name == "mono_res1_2048":            # mono through the slab kernels (blocks 256 / 2048): paired emission with one channel
         c.update(channels=1, block0=256, block1=2048,
                  floors=[_floor1_small(0, 1), _floor1_long(0, 1, 10)],
@@ -407,7 +415,7 @@ def config(name):
 
 
 CONFIG_NAMES = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
-                "floor0_stereo", "two_submaps", "equal_blocks_overrun", "mono_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2", "mono_res1_2048"]
+                "floor0_stereo", "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2", "mono_res1_2048"]
 
 
 def filtered_stream(oracle, name, npackets, seed, consistent_windows=True):

@@ -247,7 +247,7 @@ def _decode_gpu(nv, ctx, pk, gr, fl, clip, batch_frames):
 
 
 @pytest.mark.parametrize("name", ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
-                                  "two_submaps", "equal_blocks_overrun", "mono_8192", "mono_res1_2048"])
+                                  "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "mono_res1_2048"])
 @pytest.mark.parametrize("consistent", [True, False])
 def test_synthetic_configs_bit_exact(oracle, gpu_ctx, name, consistent):
     """Paths no shipped file reaches -- Residue0, Residue1 with coupling, 3 and 6 channels (incl. the Residue2
