@@ -188,36 +188,45 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
       uint32_t nheads = 0, nrec = 0;
       for (uint32_t o = 0; o < nops; o++) nheads += (links[o] & 0x8000u) ? 0u : 1u;
       const uint32_t off_heads = (uint32_t)(out.data.size() - base);
-      const uint32_t off_rec = off_heads + ((nheads + 7) >> 3);
-      out.data.resize(base + off_rec + nops);
-      uint16_t* heads = reinterpret_cast<uint16_t*>(&out.data[base + off_heads]);
-      SlabVec* recs = &out.data[base + off_rec];
+      const uint32_t off_rec = off_heads + ((nheads + 3) >> 2);
+      out.data.resize(base + off_rec + ((nops + 1) >> 1));
+      uint32_t* heads = reinterpret_cast<uint32_t*>(&out.data[base + off_heads]);
+      uint32_t* recs = reinterpret_cast<uint32_t*>(&out.data[base + off_rec]);  // two words per record
+      // the cascade stage of op o: ops are stage-major, pass.op_begin[] (batch-wide op indices) delimits the stages
+      auto stage_of = [&](uint32_t o) {
+        const uint32_t abs_o = fr.op_begin + o;
+        unsigned st = 0;
+        while (st + 1 < NVH_MAX_STAGES && abs_o >= gp.op_begin[st + 1]) ++st;
+        return st;
+      };
       uint32_t hk = 0;
       for (uint32_t o = 0; o < nops; o++) {
         if (links[o] & 0x8000u) continue;
-        heads[hk++] = (uint16_t)nrec;
+        const unsigned offset0 = rbegin + (unsigned)ops[o].partition * psz;
+        const unsigned xbase = (rtype == 2 && rch > 1) ? offset0 / (unsigned)rch : offset0;
+        if (xbase > 0xFFFFu || nrec > 0xFFFFu) return NVH_ERR_UNSUPPORTED;
+        heads[hk++] = nrec | (xbase << 16);
         uint32_t q = o;
         for (;;) {
           if (q >= nops || nrec >= nops) return NVH_ERR_RUNTIME;
           const NvhResOp& op = ops[q];
           const NvhDevBook& bk = X.books[op.book];
-          const unsigned offset = rbegin + (unsigned)op.partition * psz;
-          const unsigned xbase = (rtype == 2 && rch > 1) ? offset / (unsigned)rch : offset;
           const uint32_t rel = op.ent_off - fr.ent_begin;
-          if (rel > 0xFFFFu || xbase > 0xFFFFu) return NVH_ERR_UNSUPPORTED;
+          if (rel > 0xFFFFu || bk.lat_off > NVH_SLAB_MAX_LAT_OFF || bk.lat_values > 0xFFu || bk.dim > 31u || op.channel > 7u ||
+              op.partition != ops[o].partition)
+            return NVH_ERR_UNSUPPORTED;
           const uint32_t l = links[q] & 0x7FFFu;
-          SlabVec rec;
-          rec.x = rel | (xbase << 16);
-          rec.y = bk.lat_off | (bk.lat_values << 16);
-          rec.z = bk.lat_magic;
-          rec.w = bk.dim | ((uint32_t)op.channel << 8) | (l != NVH_LINK_NONE ? 0x8000u : 0u) | (bk.dim_magic16 << 16);
-          recs[nrec++] = rec;
+          const uint32_t rw[2] = {NVH_SLAB_REC(rel, bk.dim_magic16, bk.lat_off, bk.lat_values, bk.dim, op.channel, stage_of(q), l != NVH_LINK_NONE)};
+          recs[2 * nrec] = rw[0];
+          recs[2 * nrec + 1] = rw[1];
+          ++nrec;
           if (l == NVH_LINK_NONE) break;
           q = l;
         }
       }
-      for (uint32_t i = nheads; i < ((nheads + 7) & ~7u); i++) heads[i] = 0;
+      for (uint32_t i = nheads; i < ((nheads + 3) & ~3u); i++) heads[i] = 0;
       if (nrec != nops) return NVH_ERR_RUNTIME;  // every op belongs to exactly one chain
+      if (nrec & 1u) recs[2 * nrec] = recs[2 * nrec + 1] = 0;
       H.nheads = (uint16_t)nheads;
       H.nrec = (uint16_t)nrec;
       H.off_rec = (uint16_t)off_rec;

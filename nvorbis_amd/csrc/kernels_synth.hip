@@ -113,8 +113,8 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
                                              unsigned lpc, unsigned lpc_magic, bool interleaved, unsigned flags, int tid,
                                              const FloorRef* F = nullptr) {
   static_assert(RCH == 0 || G == 2 * RCH, "two bins of every channel per lane");
-  const uint16_t* heads = reinterpret_cast<const uint16_t*>(slab + off_heads * 4);
-  const uint4* recs = reinterpret_cast<const uint4*>(slab + off_rec * 4);
+  const uint32_t* heads = reinterpret_cast<const uint32_t*>(slab + off_heads * 4);
+  const uint2* recs = reinterpret_cast<const uint2*>(slab + off_rec * 4);
   const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
   const bool sweep_couples = (flags & NVH_SLAB_SWEEP_COUPLES) != 0;
   const bool mg1 = (flags & NVH_SLAB_MG1) != 0;
@@ -122,16 +122,18 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
   for (unsigned idx = tid; idx < total; idx += NT) {
     const unsigned oq = lpc > 1 ? __umulhi(idx, lpc_magic) : idx;
     const unsigned g = idx - oq * lpc, i0 = g * G;  // first component of this lane's group inside the partition
-    unsigned o = heads[oq];
-    uint4 rec = recs[o];
-    const unsigned xbase = rec.x >> 16;
+    const unsigned hd = heads[oq];
+    unsigned o = hd & 0xFFFFu;
+    uint2 rec = recs[o];
+    const unsigned xbase = hd >> 16;
     float a[G];
 #pragma unroll
     for (int k = 0; k < G; ++k) a[k] = 0.0f;  // the spectrum was cleared and every bin belongs to one chain
     for (;;) {
-      const unsigned dims = rec.w & 0xFFu, lv = rec.y >> 16, dm16 = rec.w >> 16;
-      const uint32_t* lat = s_lat + (rec.y & 0xFFFFu);
+      const unsigned dims = (rec.y >> 20) & 31u, lv = (rec.y >> 12) & 0xFFu, dm16 = rec.x >> 16;
+      const uint32_t* lat = s_lat + (rec.y & 0xFFFu);
       const uint16_t* eb = ent + (rec.x & 0xFFFFu);
+      const unsigned lvm = lat[lv + 1];  // ceil(2^32 / lv): the second of the book's power magics (dims >= 2)
       // Branch-free on purpose: every entry of the group is fetched first, then the digits, then the lattice values, so
       // that the LDS round trips of the group overlap instead of queueing behind exec-mask regions.  A skipped entry
       // ("no vector was added here", quirks B-14 / B-16) adds +0.0f, which is the identity on these sums: they start at
@@ -154,9 +156,9 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
         if (k == 0) q = comp[0] ? __umulhi(e[0], pw) : e[0];
         else q = comp[k / 2] ? q2 : e[k / 2];  // the same entry continues from the previous quotient, or the next one begins
         // two base-lv digits (lv == 1: the magic is 0 and so are q and both digits)
-        const unsigned q1 = __umulhi(q, rec.z);
+        const unsigned q1 = __umulhi(q, lvm);
         d[k] = q - __umul24(q1, lv);
-        q2 = __umulhi(q1, rec.z);
+        q2 = __umulhi(q1, lvm);
         d[k + 1] = q1 - __umul24(q2, lv);
       }
       float v[G];
@@ -164,7 +166,7 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
       for (int k = 0; k < G; ++k) v[k] = __uint_as_float(lat[d[k]]);
 #pragma unroll
       for (int k = 0; k < G; ++k) a[k] = a[k] + (e[k / 2] != NVH_ENTRY_SKIP ? v[k] : 0.0f);
-      if (!(rec.w & 0x8000u)) break;
+      if (!(rec.y & 0x80000000u)) break;
       rec = recs[++o];
     }
     if constexpr (RCH >= 3) {
@@ -221,7 +223,7 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
           }
       }
     } else {
-      const unsigned c = (rec.w >> 8) & 0x7Fu;
+      const unsigned c = (rec.y >> 25) & 7u;
       const unsigned xb = xbase + i0;
       float* p = spec + c * (unsigned)half + xb;
       if constexpr (FUSE && G == 8) {  // xb is a multiple of 4
@@ -417,9 +419,9 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
       const int o = base + lane;
       nheads += __popcll(__ballot(o < nops && !(links[o < nops ? o : 0] & 0x8000u)));
     }
-    uint16_t* heads = reinterpret_cast<uint16_t*>(slab + off);
-    const unsigned off_rec = off + (unsigned)((nheads + 7) >> 3);
-    uint4* recs = slab + off_rec;
+    uint32_t* heads = reinterpret_cast<uint32_t*>(slab + off);
+    const unsigned off_rec = off + (unsigned)((nheads + 3) >> 2);
+    uint2* recs = reinterpret_cast<uint2*>(slab + off_rec);
     // pass B: chain lengths -> record positions; every head lane then writes its chain
     int hcount = 0, rpos = 0;
     for (int base = 0; base < nops; base += 64) {
@@ -440,31 +442,32 @@ k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int st
       const unsigned long long m = __ballot(head);
       if (head) {
         const unsigned first = (unsigned)rpos + incl - len;
-        heads[hcount + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)first;
+        const unsigned offset0 = rbegin + (unsigned)ops[o].partition * psz;
+        const unsigned xbase0 = (rtype == 2 && rch > 1) ? __umulhi(offset0, rch_magic) : offset0;
+        heads[hcount + __popcll(m & ((1ull << lane) - 1ull))] = first | (xbase0 << 16);
         int q = o;
         for (unsigned k = 0; k < len; ++k) {
           const NvhResOp op = ops[q];
           const NvhDevBook bk = s_books[op.book];
-          const unsigned offset = rbegin + (unsigned)op.partition * psz;
-          const unsigned xbase = (rtype == 2 && rch > 1) ? __umulhi(offset, rch_magic) : offset;
-          uint4 rec;
-          rec.x = (op.ent_off - fr.ent_begin) | (xbase << 16);
-          rec.y = bk.lat_off | (bk.lat_values << 16);
-          rec.z = bk.lat_magic;
-          rec.w = bk.dim | ((unsigned)op.channel << 8) | (k + 1 < len ? 0x8000u : 0u) | (bk.dim_magic16 << 16);
-          recs[first + k] = rec;
+          // the cascade stage of this write: ops are stage-major, the pass's op_begin[] delimits the stages
+          unsigned stage = 0;
+          const unsigned abs_o = fr.op_begin + (unsigned)q;
+          for (int st = 1; st < NVH_MAX_STAGES; ++st) stage += abs_o >= gp->op_begin[st] ? 1u : 0u;
+          const uint32_t rw[2] = {NVH_SLAB_REC(op.ent_off - fr.ent_begin, bk.dim_magic16, bk.lat_off, bk.lat_values, bk.dim, op.channel, stage, k + 1 < len)};
+          recs[first + k] = make_uint2(rw[0], rw[1]);
           q = (int)(links[q] & 0x7FFFu);
         }
       }
       hcount += __popcll(m);
       rpos += (int)total;
     }
-    // pad the head list to whole vectors (read by nobody, but keep the slab deterministic)
-    for (int i = nheads + lane; i < ((nheads + 7) & ~7); i += 64) heads[i] = 0;
+    // pad the head list and the records to whole vectors (read by nobody, but keep the slab deterministic)
+    for (int i = nheads + lane; i < ((nheads + 3) & ~3); i += 64) heads[i] = 0;
+    if ((rpos & 1) && lane == 0) recs[rpos] = make_uint2(0u, 0u);
     H.nheads = (uint16_t)nheads;
     H.nrec = (uint16_t)rpos;
     H.off_rec = (uint16_t)off_rec;
-    off = off_rec + (unsigned)rpos;
+    off = off_rec + (unsigned)((rpos + 1) >> 1);
   } else {
     H.off_rec = (uint16_t)off;
   }

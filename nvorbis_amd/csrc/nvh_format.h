@@ -158,12 +158,18 @@ struct NvhFrame {
 // (integer work only: Floor1.UnwrapPosts + the segment list of the sorted, flagged posts, Floor1.cs:196-297; the
 // residue geometry of Residue0.cs:157-170 / Residue2.cs:23-47 resolved per vector write).  Sections, 16-byte aligned:
 //   NvhSlabHdr | per channel: uint4 segment[nseg] (x | xend << 16, y, signed 32.32 step per bin), uint8 first_segment[n / 8] (one per four bins) |
-//   uint16 heads[nheads] | uint4 rec[nrec] | uint16 entries[]
-// rec = one (stage, partition, channel) vector write in the pair-path form of kernels_spectrum.hip,
-//   x: entry offset (frame relative) | first bin << 16      y: lattice pool offset | lat_values << 16
-//   z: ceil(2^32 / lat_values)        w: dim | channel << 8 | more << 15 | ceil(2^16 / dim) << 16
+//   uint32 heads[nheads] | uint2 rec[nrec] | uint16 entries[]
+// rec = one (stage, partition, channel) vector write, 8 bytes (round 4; 16 before):
+//   x: entry offset (frame relative) | ceil(2^16 / dim) << 16
+//   y: lattice pool offset (12 bits) | lat_values << 12 (8) | dim << 20 (5) | channel << 25 (3) | stage << 28 (3) | more << 31
+// (the reciprocal ceil(2^32 / lat_values) is the second of the book's power magics in the lattice pool: lat[lat_values + 1])
 // laid out chain-major: the writes to one partition / channel through the cascade stages are consecutive records, in
-// stage order, `more` set on all but the last; heads[k] = index of chain k's first record.
+// stage order, `more` set on all but the last; heads[k] = index of chain k's first record | the partition's first bin << 16.
+#define NVH_SLAB_REC(ent_off, dm16, lat_off, lat_values, dim, channel, stage, more)                                              \
+  ((uint32_t)(ent_off) | ((uint32_t)(dm16) << 16)),                                                                               \
+      ((uint32_t)(lat_off) | ((uint32_t)(lat_values) << 12) | ((uint32_t)(dim) << 20) | ((uint32_t)(channel) << 25) |             \
+       ((uint32_t)(stage) << 28) | ((more) ? 0x80000000u : 0u))
+#define NVH_SLAB_MAX_LAT_OFF 0xFFFu  // lattice pool words a record can address
 #define NVH_SLAB_SWEEP_COUPLES 1u  // stereo Residue2: the chain walk holds both channels of a bin and couples before its store
 #define NVH_SLAB_MG1 2u            // the magnitude channel of the coupling step is channel 1
 #define NVH_SLAB_COUPLE_PASS 4u    // inverse coupling as a pass of its own between the residue walk and the floor multiply

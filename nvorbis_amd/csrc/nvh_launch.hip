@@ -448,8 +448,8 @@ static size_t slab_bound_vecs(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   if (b->slab_host) return (size_t)b->slab_stride_vecs;  // written by the host parser's thread: the batch's largest slab, exactly
   const size_t P = (size_t)s->shared->max_posts + 2;
-  size_t v = NVH_SLAB_HDR_VECS + (size_t)s->setup.channels * (P + ((size_t)s->setup.block1 / 8 + 15) / 16) + ((size_t)b->max_ops + 7) / 8 +
-             (size_t)b->max_ops + ((size_t)b->max_ent + 7) / 8 + 1;
+  size_t v = NVH_SLAB_HDR_VECS + (size_t)s->setup.channels * (P + ((size_t)s->setup.block1 / 8 + 15) / 16) + ((size_t)b->max_ops + 3) / 4 +
+             ((size_t)b->max_ops + 1) / 2 + ((size_t)b->max_ent + 7) / 8 + 1;
   if (v < (size_t)s->setup.block1 / 64 + 8) v = (size_t)s->setup.block1 / 64 + 8;  // the IMDCT padding of channel 0 overlays the slab area
   return (v + 3) & ~(size_t)3;
 }

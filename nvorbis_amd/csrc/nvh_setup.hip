@@ -216,6 +216,7 @@ int upload_setup(nvh_stream* s) {
     for (const nvh::Mapping& m : S.mappings) slab_ok = slab_ok && m.coupling_angle.size() <= (size_t)NVH_SLAB_MAX_COUPLE;
     for (const NvhDevResidue& r : residues)
       if (r.type == 2 && r.real_channels > 2) slab_ok = slab_ok && (r.partition_size % (2 * r.real_channels)) == 0;
+    slab_ok = slab_ok && lattice.size() <= (size_t)NVH_SLAB_MAX_LAT_OFF;  // a record addresses the lattice pool with 12 bits
     s->shared->slab_setup_ok = slab_ok;
   }
   D.books = (const NvhDevBook*)(base + o_books);

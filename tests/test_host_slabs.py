@@ -207,22 +207,25 @@ def test_slab_residue_records_structure(ogg_bytes):
             words, _ = s.pending_slabs()
             h = parse_slab(words)
             assert h["off_heads"] <= h["off_rec"] <= h["off_ent"] <= h["vecs"]
-            assert h["off_rec"] == h["off_heads"] + (h["nheads"] + 7) // 8 and h["off_ent"] == h["off_rec"] + h["nrec"]
-            heads = words[h["off_heads"] * 4:h["off_rec"] * 4].view(np.uint16)[:h["nheads"]]
-            recs = words[h["off_rec"] * 4:h["off_ent"] * 4].reshape(h["nrec"], 4)
+            assert h["off_rec"] == h["off_heads"] + (h["nheads"] + 3) // 4 and h["off_ent"] == h["off_rec"] + (h["nrec"] + 1) // 2
+            hw = words[h["off_heads"] * 4:h["off_rec"] * 4][:h["nheads"]]
+            heads, xb = hw & 0xFFFF, hw >> 16
+            recs = words[h["off_rec"] * 4:h["off_ent"] * 4][:2 * h["nrec"]].reshape(h["nrec"], 2)
             nent = (h["vecs"] - h["off_ent"]) * 8
-            more = (recs[:, 3] >> 15) & 1
+            more = recs[:, 1] >> 31
             # a head is a record whose predecessor does not continue into it
-            starts = np.flatnonzero(np.concatenate(([1], 1 - more[:-1]))) if h["nrec"] else np.zeros(0, np.int64)
+            starts = np.flatnonzero(np.concatenate(([1], 1 - more[:-1].astype(np.int64)))) if h["nrec"] else np.zeros(0, np.int64)
             assert np.array_equal(starts, heads.astype(np.int64))
             if h["nrec"]:
                 assert more[-1] == 0
-                dims = recs[:, 3] & 0xFF
+                dims = (recs[:, 1] >> 20) & 31
                 assert (dims >= 2).all() and ((dims & 1) == 0).all()
+                assert (recs[:, 0] >> 16 == (65536 + dims - 1) // dims).all()
                 assert ((recs[:, 0] & 0xFFFF) < nent).all()
-                xb = recs[:, 0] >> 16
+                stage = (recs[:, 1] >> 28) & 7
                 for a, b in zip(starts, np.append(starts[1:], h["nrec"])):
-                    assert (xb[a:b] == xb[a]).all()  # one chain, one partition
+                    assert (np.diff(stage[a:b].astype(np.int64)) > 0).all()  # one chain: strictly rising cascade stages
+                assert np.unique(xb).size == xb.size  # one chain per partition (Residue2: one channel); heads follow the op order
                 seen += h["nrec"]
         assert seen > 500
     finally:
