@@ -10,6 +10,7 @@
 //   Mapping.cs:137-182  which coupling steps run (either channel executes), last step first
 #include "host_slab.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace nvh {
@@ -92,6 +93,21 @@ int floor1_segments(const Floor1& f, const uint16_t* posts, int post_count, int 
   return ns;
 }
 
+bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r) {
+  (void)S;
+  if (r.type != 2 || r.real_channels < 3 || r.real_channels > NVH_SLAB_MAX_CH) return false;
+  if (r.begin % r.real_channels == 0 && r.partition_size % r.real_channels == 0) return false;  // no aliasing at all
+  if (r.partition_size < 2 * r.real_channels || r.partition_size > 4096) return false;
+  for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++)
+    for (int k = 0; k < NVH_MAX_STAGES; k++) {
+      const int b = r.books[c][k];
+      if (b < 0) continue;
+      const NvhDevBook& bk = X.books[(size_t)b];
+      if (bk.lat_values == 0 || bk.dim == 0 || (bk.dim & 1u) || (uint32_t)r.partition_size % bk.dim != 0) return false;
+    }
+  return true;
+}
+
 int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBatch& out) {
   out.clear();
   const int nch = S.channels;
@@ -100,6 +116,7 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
   out.first.reserve(nf + 1);
   out.data.reserve(nf * 256);
   std::vector<SlabVec> segs((size_t)NVH_MAX_POSTS + 2);
+  std::vector<uint32_t> head_scratch;  // op index of every chain head of the frame, in the order the heads are stored
   for (size_t f = 0; f < nf; f++) {
     const NvhFrame& fr = P.frames[f];
     const size_t base = out.data.size();
@@ -174,10 +191,13 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
       rch = R.real_channels;
       const unsigned psz = (unsigned)R.partition_size, rbegin = (unsigned)R.begin;
       rbegin_al = rbegin;
+      // quirk B-1 (partitions sharing a bin): the kernel walks bin by bin (group 0), chains in partition order
+      const bool bins = (size_t)gp.residue < X.residue_b1.size() && X.residue_b1[(size_t)gp.residue] != 0;
       unsigned group = (psz & 7u) == 0 ? 8u : 2u;
       if (rtype == 2 && rch > 2) group = (psz % (2u * (unsigned)rch)) == 0 ? 2u * (unsigned)rch : 0u;
-      if (group == 0 || (psz % group) != 0) return NVH_ERR_UNSUPPORTED;
-      const unsigned lpc = psz / group;
+      if (bins) group = 0;
+      else if (group == 0 || (psz % group) != 0) return NVH_ERR_UNSUPPORTED;
+      const unsigned lpc = bins ? 0u : psz / group;
       H.group = (uint8_t)group;
       H.lpc = (uint16_t)lpc;
       H.lpc_magic = lpc > 1 ? (uint32_t)((0x100000000ull + lpc - 1) / lpc) : 0u;
@@ -200,8 +220,13 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
         return st;
       };
       uint32_t hk = 0;
-      for (uint32_t o = 0; o < nops; o++) {
-        if (links[o] & 0x8000u) continue;
+      std::vector<uint32_t>& head_ops = head_scratch;
+      head_ops.clear();
+      for (uint32_t o = 0; o < nops; o++)
+        if (!(links[o] & 0x8000u)) head_ops.push_back(o);
+      if (bins)  // (Residue2: one chain per partition)
+        std::stable_sort(head_ops.begin(), head_ops.end(), [&](uint32_t a, uint32_t b) { return ops[a].partition < ops[b].partition; });
+      for (uint32_t o : head_ops) {
         const unsigned offset0 = rbegin + (unsigned)ops[o].partition * psz;
         const unsigned xbase = (rtype == 2 && rch > 1) ? offset0 / (unsigned)rch : offset0;
         if (xbase > 0xFFFFu || nrec > 0xFFFFu) return NVH_ERR_UNSUPPORTED;
@@ -243,6 +268,33 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
       uint16_t* dst = reinterpret_cast<uint16_t*>(&out.data[e0]);
       if (ne) std::memcpy(dst, P.entries.data() + fr.ent_begin, (size_t)ne * 2);
       for (uint32_t i = ne; i < padded; i++) dst[i] = (uint16_t)NVH_ENTRY_SKIP;
+    }
+    // ---- bin-by-bin walk (quirk B-1): the residue's geometry and which chain belongs to which partition ----
+    if (npass == 1 && H.group == 0) {
+      const NvhResPass& gp = P.passes[fr.pass_begin];
+      const Residue& R = S.residues[(size_t)gp.residue];
+      const int bs = fr.n * R.real_channels;                       // Residue2.cs:16-21
+      const int end = R.end < bs / 2 ? R.end : bs / 2;             // Residue0.cs:122-123
+      const int nn = end - R.begin;
+      const uint32_t nparts = nn > 0 ? (uint32_t)(nn / R.partition_size) : 0u;
+      const uint32_t psz = (uint32_t)R.partition_size, rchu = (uint32_t)R.real_channels;
+      const uint32_t off_bins = (uint32_t)(out.data.size() - base);
+      const size_t b0 = out.data.size();
+      out.data.resize(b0 + 1 + (nparts + 7) / 8);
+      uint32_t* prm = reinterpret_cast<uint32_t*>(&out.data[b0]);
+      prm[0] = (uint32_t)R.begin; prm[1] = psz; prm[2] = nparts; prm[3] = (psz + rchu - 1) / rchu;  // bins a partition touches
+      uint16_t* pchain = reinterpret_cast<uint16_t*>(&out.data[b0 + 1]);
+      for (uint32_t i = 0; i < ((nparts + 7) & ~7u); i++) pchain[i] = 0xFFFFu;
+      const uint32_t* heads = reinterpret_cast<const uint32_t*>(&out.data[base + H.off_heads]);
+      const NvhResOp* ops = P.ops.data() + fr.op_begin;
+      for (uint32_t k = 0; k < H.nheads; k++) {
+        const uint32_t p = ops[head_scratch[k]].partition;
+        if (p >= nparts) return NVH_ERR_RUNTIME;
+        pchain[p] = (uint16_t)k;
+      }
+      (void)heads;
+      H.lpc = (uint16_t)off_bins;
+      H.lpc_magic = (uint32_t)((0x100000000ull + psz - 1) / psz);
     }
     const size_t vecs = out.data.size() - base;
     if (vecs > 0xFFFFu) return NVH_ERR_UNSUPPORTED;

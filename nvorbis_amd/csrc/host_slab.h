@@ -23,7 +23,13 @@ static_assert(sizeof(SlabVec) == 16, "slabs are addressed in 16-byte units");
 // (lattice pool offsets, reciprocal magics; nvh_setup.hip builds it).
 struct SlabSetup {
   std::vector<NvhDevBook> books;
+  std::vector<uint8_t> residue_b1;  // per residue: quirk B-1 aliasing only (residue_alias_b1): its frames are walked bin by bin
 };
+
+// Quirk B-1 on its own: a Residue2 over 3..8 channels whose partitions do not start on a bin boundary (`offset /= channels`
+// truncates and chPtr restarts at 0, Residue2.cs:25-27, so neighbouring partitions share a bin), every book a lattice book of
+// even dimension that divides the partition, at least two bins per partition (a bin then belongs to at most two partitions).
+bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r);
 
 struct SlabBatch {
   std::vector<SlabVec> data;      // the slabs back to back (frame order), each a whole number of 16-byte units

@@ -257,6 +257,84 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
   }
 }
 
+
+// Residue2 whose partitions share bins (quirk B-1: `offset /= channels` truncates and chPtr restarts at 0 for every partition,
+// Residue2.cs:25-27): component q of partition p lands in channel q % rch, bin (begin + p psz) / rch + q / rch, so
+// when psz is not a multiple of rch the last bin of a partition is the first bin of the next one, and an element receives the
+// vectors of both -- in the reference's order: stage by stage, and inside a stage the lower partition first (Residue0.cs:132-175).
+// A lane owns one BIN (all rch channels of it) and merges the chains of the (at most two) partitions that touch it by cascade
+// stage; chains lie in partition order, pchain[p] = chain of partition p (0xFFFF: none).  Slab section `bins`:
+// uint32 begin, psz, nparts, bins a partition touches | uint16 pchain[nparts].
+template <int NT>
+__device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
+                                                  unsigned off_bins, unsigned psz_magic, const uint32_t* __restrict__ s_lat,
+                                                  float* spec, int half, unsigned rch, int tid) {
+  const uint32_t* heads = reinterpret_cast<const uint32_t*>(slab + off_heads * 4);
+  const uint2* recs = reinterpret_cast<const uint2*>(slab + off_rec * 4);
+  const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
+  const uint32_t* prm = reinterpret_cast<const uint32_t*>(slab + off_bins * 4);
+  const unsigned rbegin = __builtin_amdgcn_readfirstlane(prm[0]), psz = __builtin_amdgcn_readfirstlane(prm[1]);
+  const unsigned nparts = __builtin_amdgcn_readfirstlane(prm[2]), cover = __builtin_amdgcn_readfirstlane(prm[3]);
+  const uint16_t* pchain = reinterpret_cast<const uint16_t*>(prm + 4);
+  if (nparts == 0) return;
+  const unsigned rch_magic = (unsigned)((0x100000000ull + rch - 1) / rch);  // uniform, once per wavefront
+  auto base_of = [&](unsigned p) { return __umulhi(rbegin + p * psz, rch_magic); };  // (begin + p psz) / rch: below 2^16 * 8
+  const unsigned xfirst = base_of(0), xend = base_of(nparts - 1) + cover;
+  for (unsigned X = xfirst + (unsigned)tid; X < xend; X += NT) {
+    // the largest p whose first bin is at or before X
+    unsigned phi = __umulhi((X + 1) * rch - 1 - rbegin, psz_magic);
+    if (phi >= nparts) phi = nparts - 1;
+    unsigned cb = pchain[phi], ca = 0xFFFFu;
+    if (X >= base_of(phi) + cover) cb = 0xFFFFu;  // behind the last partition's bins
+    if (phi >= 1 && X < base_of(phi - 1) + cover) ca = pchain[phi - 1];
+    unsigned oa = 0, ob = 0, xa = 0, xbb = 0;
+    uint2 ra = make_uint2(0u, 0u), rb = ra;
+    bool va = ca != 0xFFFFu, vb = cb != 0xFFFFu;
+    if (va) { const unsigned hd = heads[ca]; oa = hd & 0xFFFFu; xa = hd >> 16; ra = recs[oa]; }
+    if (vb) { const unsigned hd = heads[cb]; ob = hd & 0xFFFFu; xbb = hd >> 16; rb = recs[ob]; }
+    float a[NVH_SLAB_MAX_CH];
+#pragma unroll
+    for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) a[c] = 0.0f;
+    while (va || vb) {
+      // the next vector write in the reference's order: the lower cascade stage, the lower partition (chain A) on a tie
+      const bool take_a = va && (!vb || ((ra.y >> 28) & 7u) <= ((rb.y >> 28) & 7u));
+      const uint2 rec = take_a ? ra : rb;
+      const unsigned q0 = (X - (take_a ? xa : xbb)) * rch;  // first component of this bin inside the partition
+      const unsigned dims = (rec.y >> 20) & 31u, lv = (rec.y >> 12) & 0xFFu, dm16 = rec.x >> 16;
+      const uint32_t* lat = s_lat + (rec.y & 0xFFFu);
+      const uint16_t* eb = ent + (rec.x & 0xFFFFu);
+      const unsigned lvm = lat[lv + 1];
+#pragma unroll
+      for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) {
+        if ((unsigned)c < rch) {  // uniform
+          const unsigned q = q0 + (unsigned)c;
+          const bool in = q < psz;  // a partition's last bin may hold fewer than rch components
+          const unsigned qq = in ? q : 0u;
+          const unsigned j = (qq * dm16) >> 16, comp = qq - j * dims;
+          const unsigned e = eb[j];
+          const unsigned pw = lat[lv + comp];
+          const unsigned qv = comp ? __umulhi(e, pw) : e;
+          const unsigned dgt = qv - __umul24(__umulhi(qv, lvm), lv);
+          const float v = __uint_as_float(lat[dgt]);
+          a[c] = a[c] + ((in && e != NVH_ENTRY_SKIP) ? v : 0.0f);  // +0.0f is the identity on these sums (they start at +0.0f)
+        }
+      }
+      if (take_a) {
+        va = (ra.y & 0x80000000u) != 0;
+        if (va) ra = recs[++oa];
+      } else {
+        vb = (rb.y & 0x80000000u) != 0;
+        if (vb) rb = recs[++ob];
+      }
+    }
+    if (X < (unsigned)half) {
+#pragma unroll
+      for (int c = 0; c < NVH_SLAB_MAX_CH; ++c)
+        if ((unsigned)c < rch) spec[(unsigned)c * (unsigned)half + X] = a[c];
+    }
+  }
+}
+
 }  // namespace
 
 // ---- launch order: costliest frames first ---------------------------------------------------------------------------------
@@ -823,6 +901,8 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     } else if (!interleaved || rch == 2) {
       if (group == 8) NVH_WALK(8, false, 0, nullptr);
       else NVH_WALK(2, false, 0, nullptr);
+    } else if (MAXCH > 2 && group == 0) {
+      residue_walk_bins<NT>(slab, off_heads, off_rec, off_ent, lpc, lpc_magic, s_lat, spec, half, rch, tid);  // quirk B-1
     } else if (MAXCH > 2) {
       switch (rch) {  // group == 2 * rch (k_prepare_slabs)
         case 3: NVH_WALK(6, false, 3, nullptr); break;

@@ -183,6 +183,7 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
         std::vector<float> vq;
         std::vector<uint32_t> lattice;
         nvh::build_book_directory(sh->setup, sh->slab, vq, lattice);
+        for (const nvh::Residue& r : sh->setup.residues) sh->slab.residue_b1.push_back(nvh::residue_alias_b1(sh->setup, sh->slab, r) ? 1 : 0);
       }
       *out = s.release();
       return NVH_OK;

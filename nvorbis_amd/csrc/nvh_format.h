@@ -79,7 +79,9 @@ struct NvhDevResidue {   // Residue0.cs:21-33
   int32_t fast;          // 1 => the reciprocal-multiply index path is exact for every index of this residue
   int32_t pair_path;     // 1 => fast, not sequential, every book a lattice book of even dimension: two bins per lane
   uint32_t hp_magic;     // ceil(2^32 / (partition_size / 2)) for the pair path, 0 when partition_size / 2 <= 1
-  int32_t pad[3];
+  int32_t alias_b1;      // 1 => sequential only because of quirk B-1 (Residue2 partitions sharing a bin), lattice books of even
+                         // dimension dividing the partition: the slab kernels walk it bin by bin (kernels_synth.hip: residue_walk_bins)
+  int32_t pad[2];
 };
 
 struct NvhDevMapping {   // Mapping.cs:9-14

@@ -128,8 +128,9 @@ int upload_setup(nvh_stream* s) {
           if (r.books[c][k] >= 0 && (books[(size_t)r.books[c][k]].lat_values == 0 || (books[(size_t)r.books[c][k]].dim & 1u))) pairs = false;
       if (nvh_toggles().no_pair) pairs = false;  // A/B aid
       d.pair_path = pairs ? 1 : 0;
+      d.alias_b1 = (seq && d.fast != 0 && !nvh_toggles().no_pair && lattice.size() <= 0xFFFFu && nvh::residue_alias_b1(S, s->shared->slab, r)) ? 1 : 0;
       d.hp_magic = r.partition_size / 2 > 1 ? (uint32_t)((0x100000000ull + (uint64_t)(r.partition_size / 2) - 1) / (uint64_t)(r.partition_size / 2)) : 0u;
-      d.pad[0] = d.pad[1] = d.pad[2] = 0;
+      d.pad[0] = d.pad[1] = 0;
     }
   }
 
@@ -211,11 +212,15 @@ int upload_setup(nvh_stream* s) {
     for (const NvhDevResidue& r : residues) all_pairs = all_pairs && r.pair_path != 0;
     s->fast_spectrum = ok && all_pairs;
     // slab synthesis kernels (kernels_synth.hip; nvh_launch.hip: slab_path)
-    bool slab_ok = !s->has_floor0 && all_pairs && S.channels <= NVH_SLAB_MAX_CH && S.block0 >= 256 && S.block1 <= 8192 &&
+    bool slab_res = true;  // every residue either on the pair path or aliasing in the B-1 way only
+    for (const NvhDevResidue& r : residues) slab_res = slab_res && (r.pair_path != 0 || r.alias_b1 != 0);
+    bool slab_ok = !s->has_floor0 && slab_res && S.channels <= NVH_SLAB_MAX_CH && S.block0 >= 256 && S.block1 <= 8192 &&
                    s->shared->synth_consts != nullptr;
     for (const nvh::Mapping& m : S.mappings) slab_ok = slab_ok && m.coupling_angle.size() <= (size_t)NVH_SLAB_MAX_COUPLE;
     for (const NvhDevResidue& r : residues)
-      if (r.type == 2 && r.real_channels > 2) slab_ok = slab_ok && (r.partition_size % (2 * r.real_channels)) == 0;
+      if (r.type == 2 && r.real_channels > 2 && !r.alias_b1) slab_ok = slab_ok && (r.partition_size % (2 * r.real_channels)) == 0;
+    s->shared->slab.residue_b1.assign(residues.size(), 0);
+    for (size_t i = 0; i < residues.size(); i++) s->shared->slab.residue_b1[i] = residues[i].alias_b1 ? 1 : 0;
     slab_ok = slab_ok && lattice.size() <= (size_t)NVH_SLAB_MAX_LAT_OFF;  // a record addresses the lattice pool with 12 bits
     s->shared->slab_setup_ok = slab_ok;
   }
