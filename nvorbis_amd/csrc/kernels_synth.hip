@@ -763,6 +763,8 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
     const int g = nx ? t - groups : t, i0 = 4 * g;
     const float* __restrict__ w = A.windows + (nx ? w_next : w_self);
     const float* __restrict__ wp = A.windows + (nx ? wp_next : wp_self);
+    // (fetching these in front of the barrier above, next to the staging DMA, was tried: the kernel sits at its 64-VGPR cap and
+    // spills 32-48 registers for it)
     const float4 wf = *reinterpret_cast<const float4*>(w + i0);
     const float4 wm = *reinterpret_cast<const float4*>(w + (half - 4 - i0));
     const float4 pf = *reinterpret_cast<const float4*>(wp + (half + i0));
@@ -856,6 +858,17 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int i = tid; i < (nch * half_max) >> 2; i += NT) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
   }
+  if constexpr (MAXCH <= 2 && MODE < 2) {
+    // the even launch's slab of the frame in front of this one: one dword per 128-byte line brings it into this XCD's L2 (the
+    // value is not used; the load is volatile so that it is issued)
+    if (A.prefetch_prev && wv == NT / 64 - 1 && f >= 1) {
+      const int lines = (A.cap_vecs < NT ? A.cap_vecs : NT) >> 3;
+      if (lane < lines) {
+        const volatile unsigned* pp = reinterpret_cast<const volatile unsigned*>(A.slabs + (long long)(f - 1) * A.stride_vecs) + lane * 32;
+        (void)*pp;
+      }
+    }
+  }
   const unsigned vecs = w3 >> 16;
   if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
   if (vecs > kSpec) {
@@ -942,6 +955,8 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     // ---- floor multiply in place (Floor1.cs:196-222): 8 bins of one channel per lane ----
     {
       const int per_ch = half >> 3, per_sh = 31 - __clz(per_ch);  // half is a power of two
+      // (three tasks of a lane side by side -- the task is a chain of dependent LDS round trips -- measured no gain in k_synth8:
+      // 87.8 -> 88.4 us on C4, 54.4 -> 57.3 us on three channels)
       for (int t = tid; t < nch * per_ch; t += NT) {
         const int c = t >> per_sh, x0 = (t - (c << per_sh)) << 3;
         const unsigned cw = s_chan[c];

@@ -21,6 +21,7 @@ const NvhToggles& nvh_toggles() {
     x.no_ola_sym = on("NVH_NO_OLA_SYM");
     x.slab_stream = on("NVH_SLAB_STREAM");
     x.no_emit = on("NVH_NO_EMIT");
+    x.no_prefetch = on("NVH_NO_PREFETCH");
     x.emit_always = on("NVH_EMIT_ALWAYS");
     x.debug_occ = on("NVH_DEBUG_OCC");
     x.gpu_parse_default = on("NVH_GPU_PARSE");

@@ -675,6 +675,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     A.channels = ch;
     A.block1 = s->setup.block1;
     A.f0 = 0; A.fstep = 1;
+    A.prefetch_prev = 0;
     const bool wide = slab_wide(s);
     // paired emission (nvh_format.h: NVH_EMIT_*): the host marked the frames at upload; it needs the PCM buffer and the slabs
     // in frame order
@@ -700,6 +701,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       // (the odd frames never emit: the plain kernel, or the one that can write the carried tail when the last decoded block is odd)
       A.fstep = 2;
       A.f0 = 1;
+      A.prefetch_prev = nvh_toggles().no_prefetch ? 0 : 1;
       if (b->nframes > 1) {
         if (b->last_decoded >= 0 && (b->last_decoded & 1))
           hipLaunchKernelGGL(k_synth_tail, dim3((unsigned)(b->nframes / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
@@ -707,6 +709,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
           hipLaunchKernelGGL(k_synth, dim3((unsigned)(b->nframes / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
       }
       A.f0 = 0;
+      A.prefetch_prev = 0;
       hipLaunchKernelGGL(k_synth_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     }
     if (emitted) b->slot_name[1] = "k_synth+k_synth_emit";  // odd frames, then the emitting even frames
