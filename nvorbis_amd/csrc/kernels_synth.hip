@@ -824,7 +824,16 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
 template <int NT, int MAXCH, int MODE = 0>
 __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int f = A.f0 + (int)blockIdx.x * A.fstep;
+  // Which frame this workgroup takes.  Workgroups go round the eight XCDs by index (workgroup b runs on XCD b % 8, each XCD
+  // with an L2 of its own), so with A.xcd_map the launch's frame list is cut into eight contiguous runs, one per XCD: frame
+  // 2k of the even launch and frames 2k - 1, 2k + 1 of the odd launch then ran on the same XCD (except at the seven cuts), and
+  // the quarters an emitting workgroup stages come out of that XCD's L2 instead of the memory side.
+  int slot = (int)blockIdx.x;
+  if (A.xcd_map) {
+    const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, x = slot & 7;
+    slot = x * q + (x < r ? x : r) + (slot >> 3);
+  }
+  const int f = A.f0 + slot * A.fstep;
   const int nch = A.channels;
   float* s_db = smem;
   const uint32_t* s_lat = reinterpret_cast<const uint32_t*>(smem + 256);

@@ -22,6 +22,7 @@ const NvhToggles& nvh_toggles() {
     x.slab_stream = on("NVH_SLAB_STREAM");
     x.no_emit = on("NVH_NO_EMIT");
     x.no_prefetch = on("NVH_NO_PREFETCH");
+    x.xcd_map = on("NVH_XCD_MAP");
     x.emit_always = on("NVH_EMIT_ALWAYS");
     x.debug_occ = on("NVH_DEBUG_OCC");
     x.gpu_parse_default = on("NVH_GPU_PARSE");

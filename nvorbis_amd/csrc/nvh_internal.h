@@ -126,6 +126,7 @@ struct NvhToggles {
   bool no_emit;     // NVH_NO_EMIT: no paired emission -- every frame's PCM through k_ola_compact (test / A-B aid)
   bool emit_always; // NVH_EMIT_ALWAYS: paired emission for every batch that has a steady-state frame (default: batches that are
                     // at least 7/8 steady state; the parity suite replays itself with this switch to cover the mixed cases)
+  bool xcd_map;      // NVH_XCD_MAP: paired-emission launches take their frames in eight per-XCD runs instead of workgroup order (A/B aid)
   bool no_prefetch;  // NVH_NO_PREFETCH: the odd launch of a paired-emission pass does not touch the even launch's slabs (A/B aid)
   bool lpt;       // NVH_LPT: slabs in costliest-first launch order (k_rank_frames) instead of frame order
   bool no_slab;   // NVH_NO_SLAB: k_spectrum_imdct instead of k_prepare_slabs + k_synth (test / A-B aid)
