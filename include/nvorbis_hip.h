@@ -82,8 +82,10 @@ int nvh_floor1_apply(nvh_stream *s, int floor_index, int block_size, int batch, 
 /* IFloor.Apply for a Floor0 (Floor0.cs:152-212): item b scales d_residue[b*stride .. +block_size/2) by the curve of
  * its LSP coefficients (coeffs: host, [batch][coeff_stride], the first `order` of each row as Floor0.Unpack leaves
  * them in Data.Coeff, :98-150) and amplitude amps[b] (Data.Amp), or clears it when amps[b] <= 0 (:208-211).
- * Floating point: cos / sqrt / exp are evaluated in double and rounded to float as in the reference; values differ
- * from it only where the math libraries' last ulp does.  status as for nvh_floor1_apply. */
+ * Floating point: the curve's value per Bark section (cos / sqrt / exp in double, rounded to float, Floor0.cs:167,198,201) is
+ * evaluated on the calling thread with the host's math library and only gathered and multiplied on the device; values
+ * differ from the managed reference only where the two platforms' libm differ in the last ulp of a double.  status as for
+ * nvh_floor1_apply. */
 int nvh_floor0_apply(nvh_stream *s, int floor_index, int block_size, int batch, const float *amps, const float *coeffs,
                      int coeff_stride, float *d_residue, int64_t stride, int32_t *status);
 /* type (0/1), number of posts (Floor1: _xList.Length, Floor1.cs:93-107; Floor0: _order) and _range (Floor1.cs:76)

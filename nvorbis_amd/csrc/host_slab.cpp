@@ -11,6 +11,7 @@
 #include "host_slab.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace nvh {
@@ -108,6 +109,42 @@ bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r) {
   return true;
 }
 
+bool floor0_section_values(const Floor0& f, int slot, int half, float amp, const float* coeff, float* qk) {
+  const std::vector<int>& bark = f.bark_map[slot];
+  const std::vector<float>& wmap = f.w_map[slot];
+  const int K = f.bark_map_size;
+  for (int k = 0; k < K; k++) qk[k] = 0.0f;
+  if ((int)bark.size() < half || (int)wmap.size() < half) return false;
+  std::vector<float> c2((size_t)f.order > 0 ? (size_t)f.order : 1);
+  for (int i = 0; i < f.order; i++) c2[(size_t)i] = 2.0f * (float)std::cos((double)coeff[i]);  // Floor0.cs:165-168
+  std::vector<uint8_t> done((size_t)(K > 0 ? K : 1), 0);
+  for (int i = 0; i < half; i++) {
+    const int k = bark[(size_t)i];
+    if (k < 0 || k >= half || k >= K) return false;  // wMap[k] out of range (the Bark map's last entry is never written: quirk)
+    if (done[(size_t)k]) continue;
+    done[(size_t)k] = 1;
+    float p = .5f, q = .5f;
+    const float w = wmap[(size_t)k];
+    int j;
+    for (j = 1; j < f.order; j += 2) {
+      q = q * (w - c2[(size_t)j - 1]);
+      p = p * (w - c2[(size_t)j]);
+    }
+    if (j == f.order) {  // odd order
+      q = q * (w - c2[(size_t)j - 1]);
+      p = p * (p * (4.0f - w * w));
+      q = q * q;
+    } else {
+      p = p * (p * (2.0f - w));
+      q = q * (q * (2.0f + w));
+    }
+    q = amp / (float)std::sqrt((double)(p + q)) - (float)f.amp_ofs;
+    q = (float)std::exp((double)(q * 0.11512925f));
+    qk[k] = q;
+  }
+  return true;
+}
+
 int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBatch& out) {
   out.clear();
   const int nch = S.channels;
@@ -146,14 +183,34 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
     H.n = (uint16_t)fr.n;
     H.exec_mask = (uint8_t)(fr.exec_mask & 0xFFu);
     if (fr.mdct_slot) H.flags |= NVH_SLAB_MDCT_SLOT;
-    bool fault = false;
+    bool fault = false, any_floor0 = false;
     // ---- floors ----
     for (int c = 0; c < nch; c++) {
       const NvhChan& cn = chans[c];
       const Floor& fl = S.floors[cn.floor];
-      if (fl.type != 1) return NVH_ERR_UNSUPPORTED;
-      const int mode = cn.exec ? (cn.post_count > 0 ? 1 : 2) : 0;
       const uint32_t off = (uint32_t)(out.data.size() - base);
+      if (fl.type == 0) {
+        // Floor0: one value per Bark section, evaluated here; the kernel multiplies bin i by value[barkMap[i]]
+        const int mode0 = cn.exec ? (cn.amp > 0.0f ? 3 : 2) : 0;
+        int nv = 0;
+        if (mode0 == 3) {
+          const int K = fl.f0.bark_map_size, slot = fr.mdct_slot ? 1 : 0;
+          nv = 1 + (K + 3) / 4;
+          if (nv > 255 || cn.floor >= X.floor0_bark_off[slot].size()) return NVH_ERR_UNSUPPORTED;
+          any_floor0 = true;
+          const size_t s0 = out.data.size();
+          out.data.resize(s0 + (size_t)nv);
+          out.data[s0].x = X.floor0_bark_off[slot][cn.floor];
+          out.data[s0].y = (uint32_t)K;
+          out.data[s0].z = out.data[s0].w = 0;
+          float* qk = reinterpret_cast<float*>(&out.data[s0 + 1]);
+          for (int k = K; k < 4 * (nv - 1); k++) qk[k] = 0.0f;
+          if (!floor0_section_values(fl.f0, slot, half, cn.amp, &P.coeffs[cn.data_off], qk)) fault = true;
+        }
+        H.chan[c] = (uint32_t)mode0 | ((uint32_t)nv << 8) | (off << 16);
+        continue;
+      }
+      const int mode = cn.exec ? (cn.post_count > 0 ? 1 : 2) : 0;
       int ns = 0;
       if (mode == 1) {
         ns = floor1_segments(fl.f1, &P.posts[cn.data_off], cn.post_count, half, segs.data(), &fault);
@@ -321,7 +378,7 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
         H.flags |= NVH_SLAB_COUPLE_PASS;
       }
     }
-    if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) &&
+    if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) && !any_floor0 &&
         (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
       H.flags |= NVH_SLAB_FUSE_FLOOR;
     // ---- paired emission (nvh_format.h: NVH_EMIT_*): what k_synth needs to know about the overlaps ----

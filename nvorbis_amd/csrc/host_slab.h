@@ -24,7 +24,17 @@ static_assert(sizeof(SlabVec) == 16, "slabs are addressed in 16-byte units");
 struct SlabSetup {
   std::vector<NvhDevBook> books;
   std::vector<uint8_t> residue_b1;  // per residue: quirk B-1 aliasing only (residue_alias_b1): its frames are walked bin by bin
+  // Floor0: where the Bark map of floor i for block0 / block1 lies in the device's int pool (nvh_setup.hip lays the maps out in
+  // floor order, block0 then block1), 0xFFFFFFFF for a Floor1
+  std::vector<uint32_t> floor0_bark_off[2];
 };
+
+// A Floor0 curve takes one value per Bark section (Floor0.cs:176-204: the value depends on barkMap[i] only): q[k] for every k a
+// bin of this block size maps to, evaluated here with the reference's expression shapes -- 2 cos(coeff), the p / q products in
+// float, amp / (float)sqrt((double)(p + q)) - ampOfs, (float)exp((double)(q * 0.11512925f)) -- so that the kernel only gathers
+// (no double precision, no device math library: the same libm as the CPU oracle's, bit for bit by construction).
+// qk receives bark_map_size floats (unused k: 0); returns false when a bin maps outside wMap (the reference would throw).
+bool floor0_section_values(const Floor0& f, int slot, int half, float amp, const float* coeff, float* qk);
 
 // Quirk B-1 on its own: a Residue2 over 3..8 channels whose partitions do not start on a bin boundary (`offset /= channels`
 // truncates and chPtr restarts at 0, Residue2.cs:25-27, so neighbouring partitions share a bin), every book a lattice book of

@@ -752,19 +752,20 @@ k_floor1_apply(NvhDevSetup S, int floor_idx, const uint16_t* __restrict__ posts,
   }
 }
 
-// IFloor.Apply for Floor0 (Floor0.cs:152-212) as an operator: item b scales data[b*stride .. +n/2) by the LSP curve of
-// its coefficients, or clears it when its amplitude is not positive (:208-211).
+// IFloor.Apply for Floor0 (Floor0.cs:152-212) as an operator: item b scales data[b*stride .. +n/2) by the LSP curve of its
+// coefficients, or clears it when its amplitude is not positive (:208-211).  The curve's value per Bark section comes from the
+// host (host_slab.cpp: floor0_section_values -- the reference's expression shapes evaluated with the host's libm, the same the
+// CPU oracle uses); here the gather by barkMap[i] and the multiply.  skip[b] != 0: the reference would throw, nothing is done.
 extern "C" __global__ void __launch_bounds__(SP_THREADS)
-k_floor0_apply(NvhDevSetup S, int floor_idx, const float* __restrict__ amps, const float* __restrict__ coeffs, int coeff_stride,
-               int n, float* __restrict__ data, long long stride, int* __restrict__ status) {
-  __shared__ float s_coeff[256];
+k_floor0_apply(const int32_t* __restrict__ bark, const float* __restrict__ qk, int K, const float* __restrict__ amps,
+               const int32_t* __restrict__ skip, int n, float* __restrict__ data, long long stride) {
   const int item = (int)blockIdx.x, tid = (int)threadIdx.x, half = n >> 1;
+  if (skip[item]) return;
   float* res = data + (long long)item * stride;
-  const float amp = amps[item];
-  if (!(amp > 0.0f)) {
+  if (!(amps[item] > 0.0f)) {
     for (int i = tid; i < half; i += SP_THREADS) res[i] = 0.0f;
     return;
   }
-  floor0_curve<SP_THREADS>(S, &S.floors[floor_idx].f0, coeffs + (long long)item * coeff_stride, amp, n == S.block1 ? 1 : 0, res,
-                           half, s_coeff, tid, status + item);
+  const float* q = qk + (long long)item * K;
+  for (int i = tid; i < half; i += SP_THREADS) res[i] = res[i] * q[bark[i]];
 }

@@ -982,9 +982,23 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
           floor_walk_fx<8>(seg, tab, s_db, x0, m);
 #pragma unroll
           for (int q = 0; q < 8; ++q) r[q] = r[q] * m[q];
+        } else if (md == 3) {
+          // Floor0 (Floor0.cs:176-204): the curve's value depends on the bin's Bark section only; the host parser's thread
+          // evaluated one value per section (host_slab.cpp: floor0_section_values), here the gather and the multiply
+          const unsigned oseg = cw >> 16;
+          const unsigned bark_off = reinterpret_cast<const uint32_t*>(slab + oseg * 4)[0];
+          const float* qk = slab + (oseg + 1) * 4;
+          const int32_t* __restrict__ bark = A.ipool + bark_off + x0;
+          *reinterpret_cast<float4*>(r) = *reinterpret_cast<const float4*>(sp);
+          *reinterpret_cast<float4*>(r + 4) = *reinterpret_cast<const float4*>(sp + 4);
+          int kk[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) kk[q] = bark[q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r[q] = r[q] * qk[kk[q]];
         } else {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) r[q] = 0.0f;  // Floor1.cs:218-221
+          for (int q = 0; q < 8; ++q) r[q] = 0.0f;  // Floor1.cs:218-221, Floor0.cs:208-211
         }
         *reinterpret_cast<float4*>(sp) = *reinterpret_cast<float4*>(r);
         *reinterpret_cast<float4*>(sp + 4) = *reinterpret_cast<float4*>(r + 4);

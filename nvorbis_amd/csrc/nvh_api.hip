@@ -185,6 +185,16 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
         std::vector<float> vq;
         std::vector<uint32_t> lattice;
         nvh::build_book_directory(sh->setup, sh->slab, vq, lattice);
+        {  // the int pool's layout (nvh_setup.hip): Floor0 Bark maps in floor order, block0 then block1
+          uint32_t at = 0;
+          for (int w = 0; w < 2; w++) sh->slab.floor0_bark_off[w].assign(sh->setup.floors.size(), 0xFFFFFFFFu);
+          for (size_t i = 0; i < sh->setup.floors.size(); i++)
+            if (sh->setup.floors[i].type == 0)
+              for (int w = 0; w < 2; w++) {
+                sh->slab.floor0_bark_off[w][i] = at;
+                at += (uint32_t)sh->setup.floors[i].f0.bark_map[w].size();
+              }
+        }
         for (const nvh::Residue& r : sh->setup.residues) sh->slab.residue_b1.push_back(nvh::residue_alias_b1(sh->setup, sh->slab, r) ? 1 : 0);
       }
       *out = s.release();

@@ -75,8 +75,8 @@ __global__ void k_overlap_buffers(const float* previous, float* next, int prev_s
                                   long long plane_stride);
 __global__ void k_copy_buffer(const float* planes, int start, int count, int channels, long long plane_stride, float* target,
                               int clip, int* clipped_flag);
-__global__ void k_floor0_apply(NvhDevSetup S, int floor_idx, const float* amps, const float* coeffs, int coeff_stride, int n,
-                               float* data, long long stride, int* status);
+__global__ void k_floor0_apply(const int32_t* bark, const float* qk, int K, const float* amps, const int32_t* skip, int n, float* data,
+                               long long stride);
 __global__ void k_floor1_apply(NvhDevSetup S, int floor_idx, const uint16_t* posts, const int32_t* counts, int n, float* data,
                                long long stride, int* status);
 __global__ void k_residue(NvhDevSetup S, NvhDevBatch Bt, float* work, int clear);

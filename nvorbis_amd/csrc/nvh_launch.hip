@@ -669,6 +669,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     for (int w = 0; w < 2; w++) {
       A.mdct_a[w] = s->dev.mdct_a[w]; A.mdct_b[w] = s->dev.mdct_b[w]; A.mdct_c[w] = s->dev.mdct_c[w]; A.mdct_tw[w] = s->dev.mdct_tw[w];
     }
+    A.ipool = s->dev.ipool;
     A.const_vecs = s->shared->synth_const_vecs;
     A.stride_vecs = A.cap_vecs = b->slab_stride_vecs;
     A.lds_vecs = (int)slab_lds_vecs(b);

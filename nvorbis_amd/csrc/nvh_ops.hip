@@ -249,25 +249,30 @@ extern "C" int nvh_floor0_apply(nvh_stream* s, int floor_index, int block_size, 
     if (batch == 0) return NVH_OK;
     HIP_TRY(hipSetDevice(s->ctx->device));
     hipStream_t st = s->ctx->stream;
-    DevBuf d_amps, d_coeffs, d_status;
-    d_amps.pool = d_coeffs.pool = d_status.pool = &s->ctx->pool;
-    const size_t ncoef = (size_t)batch * (size_t)coeff_stride;
+    // one value per Bark section and item, evaluated here (the reference's float / double expression shapes on the host's
+    // libm: bit-exact with the CPU restatement by construction); the kernel gathers by barkMap[i] and multiplies
+    const int K = f.f0.bark_map_size, slot = block_size == s->setup.block1 ? 1 : 0, half = block_size / 2;
+    std::vector<float> qk((size_t)batch * (size_t)std::max(K, 1), 0.0f);
+    std::vector<int32_t> skip((size_t)batch, 0);
+    for (int b = 0; b < batch; ++b)
+      if (amps[b] > 0.0f && !nvh::floor0_section_values(f.f0, slot, half, amps[b], coeffs + (size_t)b * (size_t)coeff_stride, &qk[(size_t)b * (size_t)K]))
+        skip[(size_t)b] = 1;  // wMap index out of range (Floor0.cs:90, :163)
+    DevBuf d_amps, d_qk, d_skip;
+    d_amps.pool = d_qk.pool = d_skip.pool = &s->ctx->pool;
     int rc;
     if ((rc = d_amps.reserve((size_t)batch * sizeof(float))) != NVH_OK) return rc;
-    if ((rc = d_coeffs.reserve(ncoef * sizeof(float))) != NVH_OK) return rc;
-    if ((rc = d_status.reserve((size_t)batch * sizeof(int32_t))) != NVH_OK) return rc;
+    if ((rc = d_qk.reserve(qk.size() * sizeof(float))) != NVH_OK) return rc;
+    if ((rc = d_skip.reserve((size_t)batch * sizeof(int32_t))) != NVH_OK) return rc;
     HIP_TRY(hipMemcpyAsync(d_amps.p, amps, (size_t)batch * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_coeffs.p, coeffs, ncoef * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_status.p, 0, (size_t)batch * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_floor0_apply, dim3((unsigned)batch), dim3(256), 0, st, s->dev, floor_index, (const float*)d_amps.p,
-                       (const float*)d_coeffs.p, coeff_stride, block_size, d_residue, (long long)stride, (int*)d_status.p);
+    HIP_TRY(hipMemcpyAsync(d_qk.p, qk.data(), qk.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_skip.p, skip.data(), (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_floor0_apply, dim3((unsigned)batch), dim3(256), 0, st, s->dev.ipool + s->shared->slab.floor0_bark_off[slot][(size_t)floor_index],
+                       (const float*)d_qk.p, K, (const float*)d_amps.p, (const int32_t*)d_skip.p, block_size, d_residue, (long long)stride);
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> h_status((size_t)batch, 0);
-    HIP_TRY(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(st));  // (the staging vectors above are pageable)
     int any = NVH_OK;
     for (int b = 0; b < batch; ++b) {
-      const int code = h_status[(size_t)b] ? NVH_ERR_RUNTIME : NVH_OK;  // wMap index out of range (Floor0.cs:90, :163)
+      const int code = skip[(size_t)b] ? NVH_ERR_RUNTIME : NVH_OK;
       if (status) status[b] = code;
       if (code != NVH_OK && any == NVH_OK) any = code;
     }

@@ -35,6 +35,8 @@ int upload_setup(nvh_stream* s) {
 
   std::vector<int32_t> ipool;
   std::vector<float> fpool;
+  bool slab_floor0_ok = true;
+  for (int w = 0; w < 2; w++) s->shared->slab.floor0_bark_off[w].assign(S.floors.size(), 0xFFFFFFFFu);
   std::vector<NvhDevFloor> floors(S.floors.size());
   for (size_t i = 0; i < S.floors.size(); i++) {
     const nvh::Floor& f = S.floors[i];
@@ -76,7 +78,10 @@ int upload_setup(nvh_stream* s) {
       d.f0.amp_ofs = f.f0.amp_ofs;
       d.f0.bark_map_size = f.f0.bark_map_size;
       if (f.f0.order > 255) return NVH_ERR_UNSUPPORTED;
+      if (f.f0.bark_map_size > 1016) slab_floor0_ok = false;  // a slab's floor section holds the per-section values in <= 254 vectors
       for (int w = 0; w < 2; w++) {
+        s->shared->slab.floor0_bark_off[w].resize(S.floors.size(), 0xFFFFFFFFu);
+        s->shared->slab.floor0_bark_off[w][i] = (uint32_t)ipool.size();
         d.f0.bark_off[w] = (uint32_t)ipool.size();
         ipool.insert(ipool.end(), f.f0.bark_map[w].begin(), f.f0.bark_map[w].end());
         d.f0.wmap_off[w] = (uint32_t)fpool.size();
@@ -214,7 +219,7 @@ int upload_setup(nvh_stream* s) {
     // slab synthesis kernels (kernels_synth.hip; nvh_launch.hip: slab_path)
     bool slab_res = true;  // every residue either on the pair path or aliasing in the B-1 way only
     for (const NvhDevResidue& r : residues) slab_res = slab_res && (r.pair_path != 0 || r.alias_b1 != 0);
-    bool slab_ok = !s->has_floor0 && slab_res && S.channels <= NVH_SLAB_MAX_CH && S.block0 >= 256 && S.block1 <= 8192 &&
+    bool slab_ok = slab_floor0_ok && slab_res && S.channels <= NVH_SLAB_MAX_CH && S.block0 >= 256 && S.block1 <= 8192 &&
                    s->shared->synth_consts != nullptr;
     for (const nvh::Mapping& m : S.mappings) slab_ok = slab_ok && m.coupling_angle.size() <= (size_t)NVH_SLAB_MAX_COUPLE;
     for (const NvhDevResidue& r : residues)

@@ -359,6 +359,17 @@ def config(name):
                  mappings=[lambda w: write_mapping(w, 2, 1, [(0, 1)], None, [(0, 0)]),
                            lambda w: write_mapping(w, 2, 1, [], None, [(1, 0)])],
                  modes=[(0, 0), (1, 1)])
+    elif name == "floor0_slab":               # Floor0 (even and odd order) and a Floor1 mode, residues the slab kernels take
+        c.update(channels=2, block0=256, block1=2048,
+                 floors=[lambda w: write_floor0(w, 8, 22050, 64, 5, 40, [10]),
+                         lambda w: write_floor0(w, 7, 22050, 128, 6, 30, [10]),
+                         _floor1_long(0, 1, 10)],
+                 residues=[lambda w: write_residue(w, 2, 0, 200, 16, 2, [1, 2, 7, 0], [3, 4, 3, 4, 5]),
+                           lambda w: write_residue(w, 2, 0, 1800, 32, 2, [3, 1, 4, 6], [3, 4, 5, 5, 4, 3])],
+                 mappings=[lambda w: write_mapping(w, 2, 1, [(0, 1)], None, [(0, 0)]),
+                           lambda w: write_mapping(w, 2, 1, [(1, 0)], None, [(1, 1)]),
+                           lambda w: write_mapping(w, 2, 1, [(0, 1)], None, [(2, 1)])],
+                 modes=[(0, 0), (1, 1), (1, 2)])
     elif name == "two_submaps":               # quirk B-3: every channel ends up ForceNoEnergy
         c.update(channels=2, block0=256, block1=512,
                  floors=[_floor1_small(0, 1), _floor1_small(0, 1)],
@@ -415,7 +426,7 @@ def config(name):
 
 
 CONFIG_NAMES = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
-                "floor0_stereo", "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2", "mono_res1_2048"]
+                "floor0_stereo", "floor0_slab", "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2", "mono_res1_2048"]
 
 
 def filtered_stream(oracle, name, npackets, seed, consistent_windows=True):

@@ -247,7 +247,7 @@ def _decode_gpu(nv, ctx, pk, gr, fl, clip, batch_frames):
 
 
 @pytest.mark.parametrize("name", ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
-                                  "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "mono_res1_2048"])
+                                  "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "mono_res1_2048", "floor0_slab"])
 @pytest.mark.parametrize("consistent", [True, False])
 def test_synthetic_configs_bit_exact(oracle, gpu_ctx, name, consistent):
     """Paths no shipped file reaches -- Residue0, Residue1 with coupling, 3 and 6 channels (incl. the Residue2
@@ -282,19 +282,26 @@ def test_channel_counts_4_5_7_8_bit_exact(oracle, gpu_ctx, name):
 
 
 def test_floor0_within_tolerance(oracle, gpu_ctx):
-    """Floor0 evaluates cos / sqrt / exp in double precision (Floor0.cs:167,198,201); the GPU uses the device math library
-    (ocml), the oracle glibc.  Nothing guarantees that the two agree in the last bit of a double, but after the cast to float
-    they do -- tools/ubench/f0_math.hip: 0 of 4.2 M arguments differ for each of the three functions on MI355X -- so the
-    stream is asserted bit-exact like every other (the 1e-6 bound of the north star first, for a readable failure)."""
+    """Floor0 evaluates cos / sqrt / exp in double precision (Floor0.cs:167,198,201).  On the default path the host parser's
+    thread evaluates the curve's value per Bark section with the same libm the oracle uses (host_slab.cpp:
+    floor0_section_values) and the kernel only gathers and multiplies: bit-exact by construction.  The descriptor kernels
+    (k_spectrum_f0: the replays of this suite with NVH_UNFUSED / NVH_NO_FUSED_IMDCT / NVH_NO_COMPACT / NVH_NO_SLAB) use the device
+    math library, for which nothing guarantees the last bit of a double: the north star's 1e-6 is what is asserted there."""
+    import os
     import nvorbis_amd as nv
     from tests import synth_stream as ss
-    pk, gr, fl = ss.filtered_stream(oracle, "floor0_stereo", 200, 5)
-    ref, info = oracle.decode_packets(pk, gr, fl, clip=True)
-    got = _decode_gpu(nv, gpu_ctx, pk, gr, fl, True, 64)
-    assert got.size == ref.size
-    assert np.isfinite(got).all()
-    assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) <= 1e-6
-    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    for name in ("floor0_stereo", "floor0_slab"):  # (odd-dimension books: descriptor kernels; lattice books: the slab kernels)
+        pk, gr, fl = ss.filtered_stream(oracle, name, 200, 5)
+        ref, info = oracle.decode_packets(pk, gr, fl, clip=True)
+        got = _decode_gpu(nv, gpu_ctx, pk, gr, fl, True, 64)
+        assert got.size == ref.size
+        assert np.isfinite(got).all()
+        assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) <= 1e-6
+        exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+        if name == "floor0_slab" and not any(os.environ.get(t) for t in ("NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_NO_SLAB")):
+            assert exact == 1.0, exact
+        else:
+            assert exact > 0.99, (name, exact)
 
 
 @pytest.mark.parametrize("toggle", ["NVH_SLAB_STREAM+NVH_EMIT_ALWAYS", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
