@@ -810,6 +810,117 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
   if (A.clip) report_clipped(clipped, A.clipped_flag);
 }
 
+// ---- paired emission for more than two channels (k_synth8_emit) ------------------------------------------------------------
+// The even frames of a wide batch: a frame's compact planes are 48 KB for six channels at n = 4096, so neither the neighbours'
+// quarters nor the frame's own fit the LDS next to the transforms' slices, and nothing stays in registers.  The workgroup stores
+// its planes like every other, and then -- the slices are dead -- does what k_ola_compact would do for the two steady-state
+// overlaps it takes part in (its own first half over frame f - 1's second half: SELF; frame f + 1's first half over its own
+// second half: NEXT; Mode.cs:160-166 windows, StreamDecoder.cs:532-541 adds, :391-415 / Utils.cs:30-43 interleave + clip,
+// kernels.hip: ola_sym_lds's arithmetic): a lane takes one (channel, group of four sample times), reads the later block's first
+// quarter and the earlier block's third quarter -- its own from the L2 it has just written, the neighbour's from the odd launch --
+// and puts its eight results into channel-planar LDS rows; behind a barrier the rows leave as 16-byte vectors of interleaved,
+// clipped PCM.  The overlap-add's memory phase then runs inside the synthesis kernel, next to other workgroups' arithmetic,
+// instead of as a launch of its own (k_ola_compact: 42 us per 2048 six-channel frames), and half the planes are read from L2.
+template <int NT>
+__device__ __forceinline__ void synth_emit8(const NvhSynthArgs& A, float* s_run, int n, int nch, unsigned frame, unsigned ef,
+                                            unsigned exec_mask, int tid) {
+  // One round per overlap: the rows of ALL groups fit the dead slices (2 x nch x n/4 floats: 48 KB for six channels at 4096),
+  // so an overlap costs two barriers, and a lane's K tasks have their loads in flight together -- with one run of 64 groups
+  // per round (k_ola_compact's shape) the eight rounds' round trips stood one behind the other: 87 -> 141 us for the pair of
+  // launches on C4, more than the k_ola_compact launch they replace.
+  constexpr int K = 3;
+  const int half = n >> 1, groups = n >> 4, gsh = 31 - __clz(groups), RUN = n >> 2;  // RUN = 4 * groups
+  const unsigned ch_magic = (unsigned)((0x100000000ull + (unsigned)nch - 1) / (unsigned)nch);
+  const int total = groups * nch;
+  int clipped = 0;
+  for (int ov = 0; ov < 2; ++ov) {
+    if (ov == 0 ? !(ef & NVH_EMIT_SELF) : !(ef & NVH_EMIT_NEXT)) continue;  // uniform
+    const NvhFrame* fr = A.frames + frame + ov;  // the frame whose PCM this overlap is
+    const bool from_carry = ov == 0 && (ef & NVH_EMIT_SELF_CARRY);  // the batch's first frame over the carried tail (stored windowed)
+    const float* cur = A.work + (long long)(frame + ov) * nch * A.block1;  // the later block: its first quarter
+    const float* prev = from_carry ? A.carry : A.work + (long long)(frame + ov - 1) * nch * A.block1;  // the earlier block
+    const float* __restrict__ w = A.windows + fr->window_off;
+    const float* __restrict__ wp = A.windows + fr->ov_window_off;
+    float* out = A.pcm + fr->out_pos * nch;
+    float* sF = s_run;
+    float* sM = s_run + nch * RUN;
+    for (int t0 = tid; t0 < total; t0 += K * NT) {
+      float4 wf[K], wm[K], pf[K], pm[K], a[K], b[K], bm[K];
+      int cc[K], gl[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int t = t0 + k * NT < total ? t0 + k * NT : total - 1;  // (a lane without a k-th task repeats the last one: same values)
+        cc[k] = t >> gsh;
+        gl[k] = t - (cc[k] << gsh);
+        const int i0 = 4 * gl[k];
+        wf[k] = *reinterpret_cast<const float4*>(w + i0);
+        wm[k] = *reinterpret_cast<const float4*>(w + (half - 4 - i0));
+        a[k] = *reinterpret_cast<const float4*>(cur + (long long)cc[k] * A.block1 + i0);
+        if (from_carry) {  // time order, already windowed: samples half + i0 .. and n - 4 - i0 ..
+          b[k] = *reinterpret_cast<const float4*>(prev + (long long)cc[k] * A.block1 + half + i0);
+          bm[k] = *reinterpret_cast<const float4*>(prev + (long long)cc[k] * A.block1 + (n - 4 - i0));
+        } else {
+          pf[k] = *reinterpret_cast<const float4*>(wp + (half + i0));
+          pm[k] = *reinterpret_cast<const float4*>(wp + (n - 4 - i0));
+          b[k] = *reinterpret_cast<const float4*>(prev + (long long)cc[k] * A.block1 + half + i0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float4 v = make_float4(a[k].x * wf[k].x, a[k].y * wf[k].y, a[k].z * wf[k].z, a[k].w * wf[k].w);
+        float4 u = make_float4(-a[k].w * wm[k].x, -a[k].z * wm[k].y, -a[k].y * wm[k].z, -a[k].x * wm[k].w);
+        if (from_carry) {
+          v.x = v.x + b[k].x; v.y = v.y + b[k].y; v.z = v.z + b[k].z; v.w = v.w + b[k].w;
+          u.x = u.x + bm[k].x; u.y = u.y + bm[k].y; u.z = u.z + bm[k].z; u.w = u.w + bm[k].w;
+        } else {
+          const float4 t = make_float4(b[k].x * pf[k].x, b[k].y * pf[k].y, b[k].z * pf[k].z, b[k].w * pf[k].w);
+          v.x = v.x + t.x; v.y = v.y + t.y; v.z = v.z + t.z; v.w = v.w + t.w;
+          const float4 r = make_float4(b[k].w * pm[k].x, b[k].z * pm[k].y, b[k].y * pm[k].z, b[k].x * pm[k].w);
+          u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
+        }
+        *reinterpret_cast<float4*>(sF + cc[k] * RUN + 4 * gl[k]) = v;                 // sample times 4 gl ..
+        *reinterpret_cast<float4*>(sM + cc[k] * RUN + 4 * (groups - 1 - gl[k])) = u;  // sample times n/2 - 4 - 4 gl ..
+      }
+    }
+    __syncthreads();
+    // the forward rows hold sample times [0, n/4), the mirrored rows [n/4, n/2): together the frame's n/2 samples in time order
+    const int nvec = total;  // 16-byte vectors per half: n/4 sample times x nch channels / 4
+    float4* oF = reinterpret_cast<float4*>(out);
+    float4* oM = reinterpret_cast<float4*>(out + (long long)(half >> 1) * nch);
+    for (int j = tid; j < 2 * nvec; j += NT) {
+      const bool mir = j >= nvec;
+      const int jj = mir ? j - nvec : j;
+      const float* sr = mir ? sM : sF;
+      float e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned idx = 4u * (unsigned)jj + (unsigned)k;  // position in the half's interleaved floats
+        const unsigned tt = __umulhi(idx, ch_magic), c = idx - tt * (unsigned)nch;  // idx < 2^16, nch <= 8: exact
+        float x = sr[c * (unsigned)RUN + tt];
+        if (A.clip) x = clip_value(x, &clipped);
+        e[k] = x;
+      }
+      (mir ? oM : oF)[jj] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    __syncthreads();
+  }
+  if (A.clip) report_clipped(clipped, A.clipped_flag);
+}
+
+// NVH_EMIT_CARRY_OUT for wide frames: the block that becomes the carried tail of the next batch, fully windowed, from the frame's
+// own planes (the caller's barrier orders the plane stores in front of these loads).
+template <int NT>
+__device__ __forceinline__ void synth_carry_out8(const NvhSynthArgs& A, const float* plane0, int n, int nch, unsigned exec_mask,
+                                                 unsigned window_off, int tid) {
+  const float* __restrict__ w = A.windows + window_off;
+  const int quads = n >> 2, qsh = 31 - __clz(quads);
+  for (int o = tid; o < quads * nch; o += NT) {
+    const int c = o >> qsh, g = o - (c << qsh);
+    *reinterpret_cast<float4*>(A.carry_out + (long long)c * A.block1 + 4 * g) =
+        compact_value4(plane0 + (long long)c * A.block1, w, n, (int)((exec_mask >> c) & 1u), 4 * g);
+  }
+}
+
 // ---- float side ------------------------------------------------------------------------------------------------------------
 // LDS map (dynamic, floats): [ inverse_dB_table 256 | lattice pool (const_vecs * 4 - 256) | slab image cap_vecs * 4 |
 //                              spectrum channels * block1 / 2 | block1 / 16 of IMDCT padding (k_synth) ]
@@ -1085,6 +1196,23 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(out + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   if (MAXCH > 2 && !xform) __syncthreads();  // the one barrier every transforming wavefront passes inside imdct_wave<.., WGSYNC>
+  if constexpr (MAXCH > 2 && MODE >= 2) {
+    // paired emission for wide frames: which overlaps this frame emits is read from its frame record (the slab header's
+    // per-channel words are all taken); every wavefront's plane stores are complete behind the barrier
+    const unsigned ef = A.pcm != nullptr ? A.frames[frame].emit_flags : 0u;  // uniform
+    if (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT | NVH_EMIT_CARRY_OUT)) {
+      __syncthreads();
+      if ((ef & NVH_EMIT_CARRY_OUT) && A.carry_out) synth_carry_out8<NT>(A, planes, n, nch, exec_mask, A.frames[frame].window_off, tid);
+      if (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT)) synth_emit8<NT>(A, smem, n, nch, frame, ef, exec_mask, tid);
+    }
+  }
+  if constexpr (MAXCH > 2 && MODE < 2) {
+    // the odd launch of a wide batch with paired emission: the last decoded block may be odd
+    if (A.carry_out != nullptr && (A.frames[frame].emit_flags & NVH_EMIT_CARRY_OUT)) {  // uniform
+      __syncthreads();
+      synth_carry_out8<NT>(A, planes, n, nch, exec_mask, A.frames[frame].window_off, tid);
+    }
+  }
   if constexpr (MAXCH <= 2 && MODE >= 1) {
     if (carry_out && !(emit_self || emit_next)) {  // (an emitting frame has done it inside synth_emit)
       __syncthreads();  // every wavefront's plane stores are complete
@@ -1124,4 +1252,11 @@ extern "C" __global__ void __launch_bounds__(512)
 k_synth8(NvhSynthArgs A NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   synth_body<512, NVH_SLAB_MAX_CH>(A, smem NVH_DBG_ARGS);
+}
+
+// the even frames of a wide batch with paired emission: + the overlap-add of the steady-state overlaps (synth_emit8)
+extern "C" __global__ void __launch_bounds__(512)
+k_synth8_emit(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_body<512, NVH_SLAB_MAX_CH, 2>(A, smem NVH_DBG_ARGS);
 }

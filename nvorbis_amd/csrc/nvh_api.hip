@@ -19,8 +19,8 @@ const NvhToggles& nvh_toggles() {
     x.no_slab = on("NVH_NO_SLAB");
     x.lpt = on("NVH_LPT");
     x.no_ola_sym = on("NVH_NO_OLA_SYM");
-    x.slab_stream = on("NVH_SLAB_STREAM");
     x.no_emit = on("NVH_NO_EMIT");
+    x.emit8 = on("NVH_EMIT8");
     x.no_prefetch = on("NVH_NO_PREFETCH");
     x.xcd_map = on("NVH_XCD_MAP");
     x.emit_always = on("NVH_EMIT_ALWAYS");

@@ -70,6 +70,7 @@ __global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_synth_tail(NvhSynthArgs A NVH_DBG_PARAMS);  // + the carried tail written in place (kernels_synth.hip: MODE 1)
 __global__ void k_synth_emit(NvhSynthArgs A NVH_DBG_PARAMS);  // + paired emission (MODE 2)
 __global__ void k_synth8(NvhSynthArgs A NVH_DBG_PARAMS);
+__global__ void k_synth8_emit(NvhSynthArgs A NVH_DBG_PARAMS);  // wide frames + paired emission through LDS (synth_emit8)
 __global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
 __global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,
                                   long long plane_stride);
@@ -121,8 +122,8 @@ static inline void nvh_guard_void(F&& body) noexcept {
 // Test / experiment switches from the environment, read once per process (before the first context exists).
 struct NvhToggles {
   bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
-  bool slab_stream; // NVH_SLAB_STREAM: streaming (one-shot) batches take the slab synthesis kernels too (default: resident batches only)
   bool no_ola_sym;  // NVH_NO_OLA_SYM: k_ola_compact without its read-once steady-state path (test / A-B aid)
+  bool emit8;       // NVH_EMIT8: paired emission also for more than two channels / blocks beyond 2048 (k_synth8_emit) -- opt-in, it measured no gain
   bool no_emit;     // NVH_NO_EMIT: no paired emission -- every frame's PCM through k_ola_compact (test / A-B aid)
   bool emit_always; // NVH_EMIT_ALWAYS: paired emission for every batch that has a steady-state frame (default: batches that are
                     // at least 7/8 steady state; the parity suite replays itself with this switch to cover the mixed cases)

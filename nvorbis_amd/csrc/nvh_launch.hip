@@ -237,7 +237,14 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->emit_frames = 0;
   {
     const int ch = s->setup.channels;
-    const bool can = !nvh_toggles().no_emit && ch <= 2 && !P.sequential_ola && s->setup.block0 >= 256 && s->setup.block1 <= 2048;
+    // mono / stereo with blocks up to 2048 (k_synth_emit: from registers and LDS-staged quarters), or the wide kernel's shapes --
+    // up to eight channels, blocks up to 4096 (k_synth8_emit: through the planes and LDS rows)
+    const bool narrow = ch <= 2 && s->setup.block1 <= 2048;
+    // (the wide form is opt-in, NVH_EMIT8=1: bit-exact, but on C4 -- six channels, n = 4096 -- the pair of launches measured 123.5 us
+    // per 2048 frames against 116.5 us for k_synth8 + k_ola_compact on one stream, 113.5 against 111.3 us over three: with two
+    // workgroups per CU the overlap-add's memory phases run in lockstep bursts instead of hiding behind other workgroups' arithmetic)
+    const bool wide_emit = !narrow && ch <= NVH_SLAB_MAX_CH && s->setup.block1 <= 4096 && nvh_toggles().emit8;
+    const bool can = !nvh_toggles().no_emit && (narrow || wide_emit) && !P.sequential_ola && s->setup.block0 >= 256;
     const unsigned all_ch = (1u << ch) - 1u;
     // GPU-parse mode: the execute flags are decided inside k_parse (Mapping.cs:104-131); the host marks the candidates from the
     // geometry and k_parse_links has the last word (kernels_parse.hip)
@@ -681,22 +688,31 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     const bool wide = slab_wide(s);
     // paired emission (nvh_format.h: NVH_EMIT_*): the host marked the frames at upload; it needs the PCM buffer and the slabs
     // in frame order
-    emitted = !wide && b->emit_frames > 0 && d_pcm != nullptr && !b->block_only && !T.no_emit && !T.lpt;
+    emitted = b->emit_frames > 0 && d_pcm != nullptr && !b->block_only && !T.no_emit && !T.lpt;
     A.pcm = emitted ? d_pcm : nullptr;
     A.windows = s->dev.windows;
     A.clip = s->clip;
     A.clipped_flag = flags + 1;
     A.carry = carry;
     A.carry_out = emitted ? carry_out : nullptr;
+    A.frames = b->dev.frames;
     const size_t synth_lds = slab_lds_bytes(b) + (size_t)T.lds_pad;
     if (synth_lds > 64 * 1024 && !s->ctx->synth_lds_attr_set) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_synth8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_synth8_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       s->ctx->synth_lds_attr_set = true;
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = the synthesis kernel
     b->slot_name[0] = "-";
     b->slot_name[1] = wide ? "k_synth8" : "k_synth";
-    if (wide) hipLaunchKernelGGL(k_synth8, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
+    if (wide && emitted) {
+      // odd frames first, then the even frames, which overlap-add the steady-state overlaps they take part in (synth_emit8)
+      A.fstep = 2;
+      A.f0 = 1;
+      if (b->nframes > 1) hipLaunchKernelGGL(k_synth8, dim3((unsigned)(b->nframes / 2)), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
+      A.f0 = 0;
+      hipLaunchKernelGGL(k_synth8_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
+    } else if (wide) hipLaunchKernelGGL(k_synth8, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
     else if (!emitted) hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     else {
       // odd frames first (their planes are what the even frames overlap-add with), then the even frames, which emit
@@ -715,7 +731,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       A.prefetch_prev = 0;
       hipLaunchKernelGGL(k_synth_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     }
-    if (emitted) b->slot_name[1] = "k_synth+k_synth_emit";  // odd frames, then the emitting even frames
+    if (emitted) b->slot_name[1] = wide ? "k_synth8+k_synth8_emit" : "k_synth+k_synth_emit";  // odd frames, then the emitting even frames
     slab_done = true;
     fuse_gen8 = true;  // the inverse MDCT is inside: no transform kernel behind it
   }

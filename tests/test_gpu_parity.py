@@ -269,7 +269,7 @@ def test_synthetic_configs_bit_exact(oracle, gpu_ctx, name, consistent):
 def test_channel_counts_4_5_7_8_bit_exact(oracle, gpu_ctx, name):
     """Every channel count has its own instantiation of the overlap-add kernels (ola_vec / ola_sym_lds<CH>) and of the
     eight-channel synthesis kernel's coupling and floor loops; 1, 2, 3 and 6 channels come with the configs above, these
-    are the other four -- streaming (classic kernels) and resident (slab kernels, NVH_SLAB_STREAM replay below)."""
+    are the other four (k_synth8 by default; the descriptor kernels in the NVH_NO_SLAB replay below)."""
     import nvorbis_amd as nv
     from tests import synth_stream as ss
     pk, gr, fl = ss.filtered_stream(oracle, name, 120, 23)
@@ -304,19 +304,18 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
             assert exact > 0.99, (name, exact)
 
 
-@pytest.mark.parametrize("toggle", ["NVH_SLAB_STREAM+NVH_EMIT_ALWAYS", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
-                                    "NVH_SLAB_STREAM+NVH_GPU_PARSE", "NVH_SLAB_STREAM+NVH_NO_EMIT"])
+@pytest.mark.parametrize("toggle", ["NVH_EMIT8+NVH_EMIT_ALWAYS", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
+                                    "NVH_EMIT8+NVH_GPU_PARSE", "NVH_NO_EMIT", "NVH_NO_SLAB"])
 def test_fallback_kernel_paths_bit_exact(toggle):
-    """The library picks kernel variants by stream shape.  Each environment toggle disables one
-    level of fusion, so the whole parity suite above is replayed through the general kernels in a child process:
-    NVH_SLAB_STREAM (+ NVH_EMIT_ALWAYS: paired emission for every batch with a steady-state frame, not only those that are 7/8
-    steady state) -> streaming batches (everything the reader decodes) through the slab synthesis kernels k_prepare_slabs +
-    k_synth / k_synth8, which by default serve resident batches only (nvh_batch_upload: the conversion pays when a batch is
-    synthesised more than once) -- this replay also takes tests/test_full_depth.py (C2 / C3 / C4 / C5 on full-depth packets)
-    along, so that every parity test of the suite has run through both kernel families; NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact,
-    NVH_NO_COMPACT -> k_imdct_wave + k_ola_emit; NVH_GPU_PARSE -> packets parsed by k_parse instead of the host parser;
-    NVH_NO_EMIT -> the slab kernels without paired emission (every frame's overlap-add in k_ola_compact: what a GPU-parsed batch, a
-    batch of more than two channels or a frame outside the steady state gets anyway)."""
+    """The library picks kernel variants by stream shape.  The default path of every stream the slab
+    kernels take is host-written (or GPU-parsed) slabs -> k_synth / k_synth8 with paired emission; each environment toggle
+    switches one level of that off or an opt-in on, and the whole parity suite above is replayed that way in a child process:
+    NVH_EMIT8 + NVH_EMIT_ALWAYS -> paired emission also for wide frames (k_synth8_emit, opt-in) and for every batch with a
+    steady-state frame, not only those that are 7/8 steady state; NVH_NO_EMIT -> the slab kernels without paired emission (every
+    overlap-add in k_ola_compact); NVH_NO_SLAB -> the descriptor kernels (k_spectrum_imdct & co.) that serve the shapes outside the
+    slab contract -- these three replays take tests/test_full_depth.py (C2 / C3 / C4 / C5 on full-depth packets) along;
+    NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact, NVH_NO_COMPACT -> k_imdct_wave +
+    k_ola_emit; NVH_GPU_PARSE -> packets parsed by k_parse instead of the host parser (k_prepare_slabs as its second phase)."""
     import os
     import subprocess
     import sys
@@ -328,7 +327,7 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     env["NVH_TEST_CHILD"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = [os.path.join(root, "tests", "test_gpu_parity.py")]
-    if toggle in ("NVH_SLAB_STREAM+NVH_EMIT_ALWAYS", "NVH_SLAB_STREAM+NVH_NO_EMIT"):
+    if toggle in ("NVH_EMIT8+NVH_EMIT_ALWAYS", "NVH_NO_EMIT", "NVH_NO_SLAB"):
         files.append(os.path.join(root, "tests", "test_full_depth.py"))
     r = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)

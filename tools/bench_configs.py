@@ -12,7 +12,10 @@ from tests import oracle_py
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 orc = oracle_py.load()
 ctx = nv.Context(0)
+ONLY = os.environ.get("NVH_BENCH_ONLY")  # run only the lines whose name contains this
 def run(name, packets, target_frames=4096):
+    if ONLY and ONLY not in name:
+        return
     hdr, audio = packets[:3], packets[3:]
     st = nv.Stream(ctx, hdr[0], hdr[1], hdr[2])
     st.push_packet(audio[0], -1, 0); st.synth_host()

@@ -4,7 +4,6 @@ Markov chain with random transition rates, random look-ahead batch sizes (1 ... 
 packet parser, plus the four shipped files with random batch sizes; every PCM must equal the oracle's bit for bit.
   python tools/stress_slab.py [seconds]"""
 import os, sys, time
-os.environ["NVH_SLAB_STREAM"] = "1"  # streaming batches through the slab kernels (by default they serve resident batches only)
 os.environ["NVH_EMIT_ALWAYS"] = "1"  # ... with paired emission whenever a batch has a steady-state frame (default: 7/8 of its frames)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
