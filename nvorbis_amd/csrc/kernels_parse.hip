@@ -209,17 +209,109 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_
 
 }  // namespace
 
+// floor((n) / d) from m = floor((2^32 - 1) / d), n <= 2^31, d <= 2^16: the estimate is at most one short (spectrum_dev.h)
+__device__ __forceinline__ unsigned pdiv(unsigned n, unsigned d, unsigned m) {
+  const unsigned q = __umulhi(n, m);
+  return (n - q * d >= d) ? q + 1 : q;
+}
+
+// Slab mode: one channel's Floor1 curve as the synthesis kernels read it -- Floor1.UnwrapPosts (Floor1.cs:224-297), the walk
+// over the sorted, flagged posts (:196-216) as line segments with a signed 32.32 step per bin (kernels_synth.hip:
+// floor_walk_fx; host_slab.cpp writes the same for the host parser), then the segment of every group of four bins.  One lane
+// does this for its own packet, serially; the 64 lanes of the wavefront run it side by side behind the parse (same instruction
+// stream: the post geometry comes from the setup, only the values differ).  row: per-lane scratch words (LDS or global).
+// Returns the segment count (0: not a curve the kernels can walk); *fault: a drawn value leaves inverse_dB_table (quirk B-7).
+template <class RowGet, class RowSet>
+__device__ __forceinline__ int floor_to_slab(const NvhDevFloor1* __restrict__ F, const uint16_t* __restrict__ posts, int pc, int half,
+                                             const uint32_t* __restrict__ recip, RowGet row_get, RowSet row_set,
+                                             uint4* __restrict__ out, bool* fault) {
+  // row words [0, 64): final Y per post; [64, 130): the segments' first bins
+  unsigned long long step = 3ull;
+  row_set(0, (int)posts[0]);
+  row_set(1, (int)posts[1]);
+  const int range = F->range, mult = F->multiplier;
+  for (int i = 2; i < pc; ++i) {
+    const int lo = F->l_neigh[i], hi = F->h_neigh[i];
+    const int y0 = row_get(lo), y1 = row_get(hi);
+    const int dy = y1 - y0, adx = (int)F->x_hi[i] - (int)F->x_lo[i];
+    const int ady = dy < 0 ? -dy : dy;
+    const int er = (int)((unsigned)ady * (unsigned)((int)F->x_list[i] - (int)F->x_lo[i]));  // the managed product wraps
+    const unsigned aer = er < 0 ? 0u - (unsigned)er : (unsigned)er;
+    const int qa = (int)pdiv(aer, (unsigned)adx, F->adx_magic[i]);
+    const int off = er < 0 ? -qa : qa;
+    const int predicted = dy < 0 ? y0 - off : y0 + off;
+    const int val = posts[i];
+    const int highroom = range - predicted, lowroom = predicted;
+    const int room = (highroom < lowroom ? highroom : lowroom) * 2;
+    int fy = predicted;
+    if (val != 0) {
+      step |= (1ull << lo) | (1ull << hi) | (1ull << i);
+      if (val >= room) fy = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
+      else fy = (val % 2) == 1 ? predicted - ((val + 1) / 2) : predicted + (val / 2);
+    }
+    row_set(i, fy);
+  }
+  int ns = 0, lx = 0, ly = row_get(0) * mult;
+  bool bad = false;
+  auto emit = [&](int x1n, int y1) {
+    const int x1 = x1n < half ? x1n : half;  // Math.Min(hx, n) (quirk B-6)
+    const int dy = y1 - ly, adx = x1 - lx;
+    if (adx <= 0 || ns > NVH_MAX_POSTS) { bad = true; return; }
+    const unsigned udx = (unsigned)adx, mg = recip[udx];
+    const unsigned ady = (unsigned)(dy < 0 ? -dy : dy);
+    const unsigned ab = pdiv(ady, udx, mg), r = ady - ab * udx;
+    // ceil(r 2^32 / adx), r < adx <= 2^16: two 16-bit quotient steps
+    const unsigned n1 = r << 16, q1 = pdiv(n1, udx, mg), r1 = n1 - q1 * udx;
+    const unsigned n2 = r1 << 16, q2 = pdiv(n2, udx, mg), r2 = n2 - q2 * udx;
+    unsigned long long Fx = ((unsigned long long)ab << 32) + ((((unsigned long long)q1 << 16) | q2) + (r2 ? 1u : 0u));
+    if (dy < 0) Fx = 0ull - Fx;
+    out[ns] = make_uint4((unsigned)lx | ((unsigned)x1n << 16), (unsigned)ly, (unsigned)Fx, (unsigned)(Fx >> 32));
+    row_set(64 + ns, lx);
+    const int tl = adx - 1, b = dy < 0 ? -(int)ab : (int)ab;
+    const int yl = ly + b * tl + (dy < 0 ? -1 : 1) * (int)pdiv(r * (unsigned)tl, udx, mg);
+    if (ly < 0 || ly > 255 || yl < 0 || yl > 255) *fault = true;
+    ++ns;
+  };
+  for (int i = 1; i < pc; ++i) {
+    const int idx = F->sort_idx[i];
+    if (!((step >> idx) & 1ull)) continue;
+    const int hx = F->x_list[idx], hy = row_get(idx) * mult;
+    emit(hx, hy);
+    lx = hx;
+    ly = hy;
+    if (lx >= half || bad) break;
+  }
+  if (lx < half && !bad) emit(half, ly);
+  if (bad) return 0;
+  // segment index of every group of four bins: groups [ceil(x_k / 4), ceil(x_{k+1} / 4)) belong to segment k
+  uint8_t* tab = reinterpret_cast<uint8_t*>(out + ns);
+  const int ngroups = half >> 2, padded = (ngroups + 15) & ~15;
+  int g = 0;
+  for (int k = 0; k < ns; ++k) {
+    int g_hi = k + 1 < ns ? (row_get(64 + k + 1) + 3) >> 2 : ngroups;
+    if (g_hi > ngroups) g_hi = ngroups;
+    for (; g < g_hi; ++g) tab[g] = (uint8_t)k;
+  }
+  for (; g < padded; ++g) tab[g] = 0;
+  return ns;
+}
+
 // One lane per frame of the batch.  Frames with n == 0 (drain pseudo-frames) have no packet.
 // Slab layout: frame f owns passes [f*cap_pass, +cap_pass), ops / op_link [f*cap_ops, +cap_ops), entries
 // [f*cap_ent, +cap_ent), posts [(f*channels + c) * NVH_MAX_POSTS, +NVH_MAX_POSTS), and two int scratch rows of cap_parts.
 #define NVH_PARSE_MAX_WAVES 16  // wavefronts per k_parse workgroup (they share the LDS tables): blockDim.x / 64
 // LDS: the packets and the residue walk's scratch rows of this workgroup live in LDS (k_parse), else in global memory
 // (k_parse_g: batches with a packet too long for that).  A compile-time switch, so that no pointer is ever generic.
-template <bool LDS>
+// SLAB: the lane writes the synthesis kernels' slab of its frame itself (nvh_format.h: NvhSlabHdr; section order header | records
+// | heads | entries | floors): every vector write goes straight to its chain-major record, and behind the parse -- the lanes of
+// the wavefront together again -- the floors (floor_to_slab), the heads, the entries and the header follow.  `ops` then only
+// lends its per-frame area to the list of chain heads until they are copied, `op_link` is not used.  Without SLAB: the
+// descriptors of rounds 1-3, for the stream shapes the descriptor kernels serve.
+template <bool LDS, bool SLAB>
 __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
-        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words) {
+        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs) {
   // hot Huffman tables into LDS (every lane of the wavefront helps, then lanes without a frame leave)
   extern __shared__ __attribute__((aligned(16))) uint32_t s_prefix[];
   uint32_t* s_meta = s_prefix + T.lds_words;  // books | floors | residues | mappings, as in the arena
@@ -255,6 +347,16 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   uint32_t nops = 0, nent = 0, npass = 0;
   uint32_t exec_mask = 0;
   bool links_ok = true;
+  // slab mode: this frame's slab, its record area (right behind the header), the chains allocated so far
+  uint4* const slab = SLAB ? slabs + (long long)f * T.slab_stride_vecs : nullptr;
+  uint2* const recs = SLAB ? reinterpret_cast<uint2*>(slab + NVH_SLAB_HDR_VECS) : nullptr;
+  uint32_t* const heads_tmp = reinterpret_cast<uint32_t*>(ops + op_base);  // (slab mode: the op area is free)
+  uint32_t nrec_alloc = 0, nheads = 0;
+  unsigned long long pcs = 0;  // post count of every channel, 7 bits each (at most eight channels)
+  int s_rtype = 0, s_rch = 1, s_psz = 0, s_rbegin = 0, s_npass = 0;
+  const int row_words = scratch_words > 0 ? scratch_words : (2 * T.cap_parts > 132 ? 2 * T.cap_parts : 132);
+  int* const g_rows_base = scratch + (long long)f * row_words;
+  int* const l_rows_base = reinterpret_cast<int*>(s_meta + T.meta_words) + slot * scratch_words;
 
   if (fr.n != 0) {
     const NvhPacketRef ref = refs[f];
@@ -285,6 +387,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       cn.amp = 0.0f;
       ch_out[c] = cn;
       if (pc > 0) energy |= 1u << c;
+      pcs |= (unsigned long long)(pc & 0x7F) << (7 * c);
     }
     const bool any_execute = energy != 0;  // computed before ForceEnergy (quirk B-5)
     uint32_t force_e = 0, force_no = 0;
@@ -321,8 +424,8 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         }
         const int partition_words = (partition_count + cdim - 1) / cdim;
         // the two scratch rows of the walk: class word per [channel][word], last op per [partition][channel]
-        int* g_rows = scratch + (long long)f * 2 * T.cap_parts;
-        int* l_rows = s_lane + slot * scratch_words;
+        int* g_rows = g_rows_base;
+        int* l_rows = l_rows_base;
         auto row_get = [&](int i) { return LDS ? l_rows[i] : g_rows[i]; };
         auto row_set = [&](int i, int v) { if (LDS) l_rows[i] = v; else g_rows[i] = v; };
         const int last_base = T.cap_parts;  // last_op row behind the part_word row
@@ -331,6 +434,8 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         for (int i = 0; i < r.channels * (partition_count > 0 ? partition_count : 1); i++) row_set(last_base + i, -1);
         const int buflen = T.block1;  // float[ch][block1Size] (StreamDecoder.cs:498-505)
         bool stop = false;
+        int stop_p = 0, stop_c = 0;  // slab mode: where the packet ran out (partition, channel), and whether that vector write was kept
+        bool stop_pushed = false;
         for (; stage < r.max_stages && !stop && !err; stage++) {
           pass.op_begin[stage] = op_base + nops;
           for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count && !stop && !err; entry_idx++) {
@@ -345,6 +450,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   row_set(c * pw_stride + entry_idx, idx);
                 } else {
                   stop = true;
+                  stop_p = partition_idx; stop_c = 0; stop_pushed = false;
                   break;
                 }
               }
@@ -360,6 +466,23 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   break;
                 }
                 const int cls = T.ipool[r.decode_map_off + (uint32_t)(word * cdim + dimension_idx)];
+                if (SLAB && stage == 0) {
+                  // the chain of this partition / channel: one record per cascade stage that has a book, consecutive, allocated
+                  // now that its class is known (stage 0 visits every partition in order)
+                  const unsigned cm = r.book_mask[cls];
+                  int start = -1;
+                  if (cm) {
+                    start = (int)nrec_alloc;
+                    const unsigned xb0 = (r.type == 2 && r.real_channels > 1) ? (unsigned)offset / (unsigned)r.real_channels : (unsigned)offset;
+                    if (nheads >= (uint32_t)T.cap_ops * 2u || nrec_alloc + (uint32_t)__popc(cm) > (uint32_t)T.cap_ops || xb0 > 0xFFFFu) {
+                      err = kErrRuntime;
+                      break;
+                    }
+                    heads_tmp[nheads++] = nrec_alloc | (xb0 << 16);
+                    nrec_alloc += (uint32_t)__popc(cm);
+                  }
+                  row_set(last_base + partition_idx * r.channels + c, start);
+                }
                 if ((r.cascade[cls] & (1 << stage)) == 0) continue;
                 const int book_idx = r.books[cls][stage];
                 if (book_idx < 0) continue;
@@ -403,6 +526,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   if (bad) {
                     nent = mark;
                     stop = true;
+                    stop_p = partition_idx; stop_c = c; stop_pushed = false;
                     break;
                   }
                   if (offset + steps * dims > buflen) {
@@ -450,28 +574,73 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     err = kErrRuntime;
                     break;
                   }
-                  const uint32_t rel = nops;
-                  ops[op_base + rel] = op;
-                  uint16_t lk = (uint16_t)NVH_LINK_NONE;
-                  if (rel >= (uint32_t)NVH_LINK_NONE) links_ok = false;
-                  const int last_i = last_base + partition_idx * r.channels + c;
-                  const int last = row_get(last_i);
-                  if (last >= 0 && rel < (uint32_t)NVH_LINK_NONE) {
-                    op_link[op_base + (uint32_t)last] = (uint16_t)((op_link[op_base + (uint32_t)last] & 0x8000u) | (uint16_t)rel);
-                    lk |= 0x8000u;
+                  if constexpr (SLAB) {
+                    const unsigned cm = r.book_mask[cls];
+                    const int start = row_get(last_base + partition_idx * r.channels + c);
+                    const unsigned rank = (unsigned)__popc(cm & ((1u << stage) - 1u));
+                    const uint32_t rw[2] = {NVH_SLAB_REC(op.ent_off - ent_base, book.slab_dm16, book.slab_lat & 0xFFFFu, book.slab_lat >> 16, dims, c,
+                                                         stage, (cm >> (stage + 1)) != 0)};
+                    recs[(uint32_t)start + rank] = make_uint2(rw[0], rw[1]);
+                  } else {
+                    const uint32_t rel = nops;
+                    ops[op_base + rel] = op;
+                    uint16_t lk = (uint16_t)NVH_LINK_NONE;
+                    if (rel >= (uint32_t)NVH_LINK_NONE) links_ok = false;
+                    const int last_i = last_base + partition_idx * r.channels + c;
+                    const int last = row_get(last_i);
+                    if (last >= 0 && rel < (uint32_t)NVH_LINK_NONE) {
+                      op_link[op_base + (uint32_t)last] = (uint16_t)((op_link[op_base + (uint32_t)last] & 0x8000u) | (uint16_t)rel);
+                      lk |= 0x8000u;
+                    }
+                    op_link[op_base + rel] = lk;
+                    row_set(last_i, (int)rel);
                   }
-                  op_link[op_base + rel] = lk;
-                  row_set(last_i, (int)rel);
                   ++nops;
                 }
                 if (bad) {
                   stop = true;
+                  stop_p = partition_idx; stop_c = c; stop_pushed = true;
                   break;
                 }
               }
             }
           }
         }
+        if (SLAB && stop && !err) {
+          // The packet ran out (Residue0.cs:160-168): the vector writes behind that point never happened, but their records are
+          // part of chains that were allocated by class -- they get entries that say "no vector" (quirks B-14 / B-16), so that the
+          // synthesis kernel needs no notion of a truncated chain.  `stage` is one past the stage the packet ended in.
+          const int stop_stage = stage - 1;
+          for (int pi = 0; pi < partition_count && !err; ++pi)
+            for (int c = 0; c < r.channels && !err; ++c) {
+              const int start = row_get(last_base + pi * r.channels + c);
+              if (start < 0) continue;
+              const int word = row_get(c * pw_stride + pi / cdim);
+              const int cls = T.ipool[r.decode_map_off + (uint32_t)(word * cdim + pi % cdim)];
+              const unsigned cm = r.book_mask[cls];
+              for (int st = 0; st < r.max_stages; ++st) {
+                if (!((cm >> st) & 1u)) continue;
+                const bool written = st < stop_stage ||
+                                     (st == stop_stage && (pi < stop_p || (pi == stop_p && (c < stop_c || (c == stop_c && stop_pushed)))));
+                if (written) continue;
+                const NvhPBook book = books[r.books[cls][st]];
+                const int dims = book.dims;
+                const int slots = r.type == 0 ? r.partition_size / dims : (r.partition_size + dims - 1) / dims;
+                if (nent + (uint32_t)slots > (uint32_t)T.cap_ent) {
+                  err = kErrRuntime;
+                  break;
+                }
+                const uint32_t rw[2] = {NVH_SLAB_REC(nent, book.slab_dm16, book.slab_lat & 0xFFFFu, book.slab_lat >> 16, dims, c, st, (cm >> (st + 1)) != 0)};
+                recs[(uint32_t)start + (unsigned)__popc(cm & ((1u << st) - 1u))] = make_uint2(rw[0], rw[1]);
+                for (int i = 0; i < slots; ++i) entries[ent_base + nent++] = (uint16_t)NVH_ENTRY_SKIP;
+              }
+            }
+        }
+        s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin;
+      }
+      if (SLAB) {
+        s_npass = 1;
+        if (!ran) { s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin; }
       }
       // stages not reached keep empty ranges
       if (!err) {
@@ -489,6 +658,112 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
     }
   }
 
+  uint32_t slab_vecs = 0;
+  if constexpr (SLAB) {
+    // ---- behind the parse, the lanes of the wavefront side by side: the rest of the slab ----
+    NvhSlabHdr H;
+    H.n = 0; H.exec_mask = 0; H.flags = 0; H.nheads = 0; H.nrec = 0;
+    H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS; H.vecs = NVH_SLAB_HDR_VECS;
+    H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0; H.frame = (uint32_t)f; H.coupling = 0;
+    for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) H.chan[c] = (uint32_t)NVH_SLAB_HDR_VECS << 16;
+    if (fr.n != 0 && !err) {
+      const NvhPMapping& map = mappings[fr.mapping];
+      const int half = fr.n >> 1;
+      H.n = (uint16_t)fr.n;
+      H.exec_mask = (uint8_t)(exec_mask & 0xFFu);
+      if (fr.mdct_slot) H.flags |= NVH_SLAB_MDCT_SLOT;
+      // records (written during the parse) | heads | entries | floors
+      const uint32_t off_rec = NVH_SLAB_HDR_VECS;
+      const uint32_t off_heads = off_rec + ((nrec_alloc + 1) >> 1);
+      const uint32_t off_ent = off_heads + ((nheads + 3) >> 2);
+      uint32_t off = off_ent + ((nent + 7) >> 3);
+      if (nrec_alloc & 1u) recs[nrec_alloc] = make_uint2(0u, 0u);
+      {
+        uint32_t* hd = reinterpret_cast<uint32_t*>(slab + off_heads);
+        for (uint32_t i = 0; i < nheads; ++i) hd[i] = heads_tmp[i];
+        for (uint32_t i = nheads; i < ((nheads + 3) & ~3u); ++i) hd[i] = 0;
+      }
+      {
+        // the frame's entries from their per-frame area (16-byte aligned: cap_ent is a multiple of eight), the tail padded with
+        // "no vector"
+        const uint4* src = reinterpret_cast<const uint4*>(entries + ent_base);
+        uint4* dst = slab + off_ent;
+        const uint32_t full = nent >> 3;
+        for (uint32_t i = 0; i < full; ++i) dst[i] = src[i];
+        if (nent & 7u) {
+          uint16_t* d16 = reinterpret_cast<uint16_t*>(dst + full);
+          const uint16_t* s16 = entries + ent_base + 8 * full;
+          for (uint32_t i = 0; i < 8; ++i) d16[i] = i < (nent & 7u) ? s16[i] : (uint16_t)NVH_ENTRY_SKIP;
+        }
+      }
+      H.nheads = (uint16_t)nheads;
+      H.nrec = (uint16_t)nrec_alloc;
+      H.off_rec = (uint16_t)off_rec;
+      H.off_heads = (uint16_t)off_heads;
+      H.off_ent = (uint16_t)off_ent;
+      // floors: Floor1.UnwrapPosts + the segment list of every executing channel that has posts
+      bool fault = false;
+      auto row_get = [&](int i) { return LDS ? l_rows_base[i] : g_rows_base[i]; };
+      auto row_set = [&](int i, int v) { if (LDS) l_rows_base[i] = v; else g_rows_base[i] = v; };
+      for (int c = 0; c < nch && !err; ++c) {
+        const int pc = (int)((pcs >> (7 * c)) & 0x7Fu);
+        const int mode = ((exec_mask >> c) & 1u) ? (pc > 0 ? 1 : 2) : 0;
+        int ns = 0;
+        if (mode == 1) {
+          const NvhDevFloor1* F1 = &T.dfloors[map.chan_floor[c]].f1;
+          ns = floor_to_slab(F1, posts + ((long long)f * nch + c) * NVH_MAX_POSTS, pc, half, T.recip, row_get, row_set, slab + off, &fault);
+          if (ns <= 0) {
+            err = kErrUnsupported;  // (the host writer refuses the same curves: the batch goes to the descriptor kernels)
+            break;
+          }
+        }
+        H.chan[c] = (uint32_t)mode | ((uint32_t)ns << 8) | (off << 16);
+        if (mode == 1) off += (uint32_t)ns + (uint32_t)(((half >> 2) + 15) >> 4);
+      }
+      if (fault) H.flags |= NVH_SLAB_FLOOR_FAULT;
+      // residue geometry (Residue0.cs:157-170, Residue2.cs:23-47): components a lane of the synthesis kernel owns
+      if (s_npass == 1) {
+        unsigned group = ((unsigned)s_psz & 7u) == 0 ? 8u : 2u;
+        if (s_rtype == 2 && s_rch > 2) group = ((unsigned)s_psz % (2u * (unsigned)s_rch)) == 0 ? 2u * (unsigned)s_rch : 2u;  // (host: slab setups only)
+        const unsigned lpc = (unsigned)s_psz / group;
+        H.group = (uint8_t)group;
+        H.lpc = (uint16_t)lpc;
+        H.lpc_magic = lpc > 1 ? (uint32_t)((0x100000000ull + lpc - 1) / lpc) : 0u;
+      }
+      H.rgeom = (uint8_t)(s_rtype | (s_rch << 4));
+      // inverse coupling (Mapping.cs:137-182): in the chain walk when one lane holds both channels of a bin, else passes
+      if (nch == 2 && map.coupling_steps == 1 && s_npass == 1 && s_rtype == 2 && s_rch == 2) {
+        if ((exec_mask & 3u) != 0) {
+          if (map.coupling_mag[0] == 1) H.flags |= NVH_SLAB_MG1;
+          H.flags |= NVH_SLAB_SWEEP_COUPLES;
+        }
+      } else if (map.coupling_steps > 0) {
+        unsigned word = 0, cnt = 0;
+        for (int st = map.coupling_steps - 1; st >= 0; --st) {
+          const unsigned mg = map.coupling_mag[st], an = map.coupling_ang[st];
+          if (((exec_mask >> mg) | (exec_mask >> an)) & 1u) {
+            word |= (mg | (an << 3)) << (4 + 6 * cnt);
+            ++cnt;
+          }
+        }
+        if (cnt) {
+          H.coupling = word | cnt;
+          H.flags |= NVH_SLAB_COUPLE_PASS;
+        }
+      }
+      if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) &&
+          (s_npass == 0 || (H.group == 8 && ((unsigned)s_rbegin & ((s_rtype == 2 && s_rch == 2) ? 7u : 3u)) == 0)))
+        H.flags |= NVH_SLAB_FUSE_FLOOR;
+      if (off > (uint32_t)T.slab_stride_vecs || off > 0xFFFFu) err = kErrRuntime;
+      H.vecs = (uint16_t)off;
+    }
+    if (!err) {
+      // (paired emission is entered into the header by k_parse_links, which knows the neighbours' execute flags)
+      const uint4* hv = reinterpret_cast<const uint4*>(&H);
+      for (int i = 0; i < NVH_SLAB_HDR_VECS; ++i) slab[i] = hv[i];
+      slab_vecs = H.vecs;
+    }
+  }
   frames[f].pass_begin = pass_base;
   frames[f].pass_end = pass_base + npass;
   frames[f].op_begin = op_base;
@@ -501,6 +776,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   if ((int)nops > __atomic_load_n(&result->max_ops, __ATOMIC_RELAXED)) atomicMax(&result->max_ops, (int)nops);
   if ((int)nent > __atomic_load_n(&result->max_ent, __ATOMIC_RELAXED)) atomicMax(&result->max_ent, (int)nent);
   if ((int)npass > __atomic_load_n(&result->max_pass, __ATOMIC_RELAXED)) atomicMax(&result->max_pass, (int)npass);
+  if (SLAB && (int)slab_vecs > __atomic_load_n(&result->max_vecs, __ATOMIC_RELAXED)) atomicMax(&result->max_vecs, (int)slab_vecs);
   if (!links_ok) atomicAnd(&result->links_ok, 0);
   if (err) {
     const int prev = atomicMin(&result->err_frame, f);
@@ -508,23 +784,19 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   }
 }
 
-extern "C" __global__ void __launch_bounds__(64 * NVH_PARSE_MAX_WAVES)
-k_parse(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
-        NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
-        uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
-        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words) {
-  parse_body<true>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,
-                   scratch_words, pkt_words);
-}
-
-extern "C" __global__ void __launch_bounds__(64 * NVH_PARSE_MAX_WAVES)
-k_parse_g(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
-          NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
-          uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
-          NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words) {
-  parse_body<false>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,
-                    scratch_words, pkt_words);
-}
+#define NVH_PARSE_KERNEL(NAME, LDSV, SLABV)                                                                                              \
+  extern "C" __global__ void __launch_bounds__(64 * NVH_PARSE_MAX_WAVES)                                                                  \
+  NAME(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,                          \
+       NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,          \
+       uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,          \
+       NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs) {                    \
+    parse_body<LDSV, SLABV>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,      \
+                            scratch_words, pkt_words, slabs);                                                                             \
+  }
+NVH_PARSE_KERNEL(k_parse, true, false)       // descriptors out, packets and scratch rows in LDS
+NVH_PARSE_KERNEL(k_parse_g, false, false)    // ... in global memory (a packet too long for the LDS budget)
+NVH_PARSE_KERNEL(k_parse_slab, true, true)   // slabs out (the stream shapes the slab synthesis kernels take)
+NVH_PARSE_KERNEL(k_parse_slab_g, false, true)
 
 // Second pass: what a frame needs from its neighbours (known only after every lane has parsed its packet): the overlap source's
 // execute flags (NvhChan::ov_exec / NvhFrame::ov_exec_mask) -- carry_exec_in: flags of the block carried in from the previous
@@ -535,7 +807,7 @@ k_parse_g(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRe
 extern "C" __global__ void __launch_bounds__(64)
 k_parse_links(int nframes, int channels, NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans,
               const uint32_t* __restrict__ carry_exec_in, uint32_t* __restrict__ carry_exec_out, int last_decoded,
-              NvhParseResult* __restrict__ result) {
+              NvhParseResult* __restrict__ result, uint4* __restrict__ slabs, int stride_vecs) {
   const int f = blockIdx.x * 64 + threadIdx.x;
   if (f >= nframes) return;
   const NvhFrame fr = frames[f];
@@ -564,5 +836,26 @@ k_parse_links(int nframes, int channels, NvhFrame* __restrict__ frames, NvhChan*
       frames[f].emit_flags = ef;
       atomicAnd(&result->emit_ok, 0);
     }
+  }
+  // slab mode, mono / stereo: what k_synth_emit needs to know about the overlaps this frame emits goes into its slab's header
+  // (k_parse left those fields clear; host_slab.cpp writes the same for host-parsed batches)
+  if (slabs && channels <= 2 && fr.n != 0 && (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT | NVH_EMIT_CARRY_OUT))) {
+    uint32_t* H = reinterpret_cast<uint32_t*>(slabs + (long long)f * stride_vecs);
+    uint32_t w0 = H[0];
+    if (ef & NVH_EMIT_CARRY_OUT) {
+      w0 |= (uint32_t)NVH_SLABX_CARRY_OUT << 16;
+      H[8 + 2] = fr.window_off;
+    }
+    if (ef & NVH_EMIT_SELF_CARRY) w0 |= (uint32_t)NVH_SLABX_SELF_CARRY << 16;
+    if (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT)) {
+      H[8 + 2] = fr.window_off; H[8 + 3] = fr.ov_window_off; H[8 + 6] = (uint32_t)fr.out_pos;
+      if (ef & NVH_EMIT_SELF) w0 |= (uint32_t)NVH_SLAB_EMIT_SELF << 24;
+      if ((ef & NVH_EMIT_NEXT) && f + 1 < nframes) {
+        const NvhFrame nx = frames[f + 1];
+        H[8 + 4] = nx.window_off; H[8 + 5] = nx.ov_window_off; H[8 + 7] = (uint32_t)nx.out_pos;
+        w0 |= (uint32_t)NVH_SLAB_EMIT_NEXT << 24;
+      }
+    }
+    H[0] = w0;
   }
 }

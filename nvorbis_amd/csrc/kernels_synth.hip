@@ -1,13 +1,14 @@
 // kernels_synth.hip -- the slab synthesis kernels (round 3): residue adds + inverse coupling + Floor1 multiply + inverse MDCT
 // of one frame per workgroup, fed by ONE LDS-DMA round trip.  k_synth: mono / stereo, blocks up to 2048; k_synth8: up to eight
-// channels, blocks up to 4096; k_prepare_slabs: the integer side, once per upload.  They serve resident batches
-// (nvh_batch_upload); a streaming batch, synthesised once, keeps k_spectrum_imdct (nvh_launch.hip: slab_path says why).
+// channels, blocks up to 8192.  They are the decode path of every batch inside their contract (nvh_launch.hip: slab_path); their
+// input -- one slab per frame -- is written by the packet parsers themselves: host_slab.cpp on the host parser's thread,
+// kernels_parse.hip (parse_body<.., SLAB>) in GPU-parse mode.
 //
 //   Array.Clear + IResidue.Decode adds   Mapping.cs:108,133; Residue1.cs:8-26, Residue2.cs:23-47
 //   inverse square-polar coupling         Mapping.cs:137-182
 //   IFloor.Apply (the multiply)           Floor1.cs:196-222, RenderLineMulti :316-341, inverse_dB_table :345-410
 //   IMdct.Reverse                         Mdct.cs:65-313 (imdct_wave.h)
-//   (integer side, k_prepare_slabs)       Floor1.UnwrapPosts :224-297, the sorted / flagged post walk :196-216,
+//   (integer side: the packet parsers)    Floor1.UnwrapPosts :224-297, the sorted / flagged post walk :196-216,
 //                                         the (stage, partition, channel) geometry of Residue0.cs:157-170, Residue2.cs:23-47
 //
 // Why a second form of k_spectrum_imdct (kernels_spectrum.hip), same arithmetic (stream shapes: Floor1, lattice books of even
@@ -15,7 +16,7 @@
 // 29.8 k cycles before its first useful instruction -- frame record, then the slices the record points to, then the setup
 // records those point to (three dependent global round trips), then copies of all of it into LDS through registers, pair
 // records, chain-head compaction, and the Floor1 unwrap (a chain of dependent LDS round trips on two otherwise idle
-// wavefronts).  None of that depends on a float.  Here it is done once per batch by k_prepare_slabs (one wavefront per frame,
+// wavefronts).  None of that depends on a float.  It is done by the packet parsers (host_slab.cpp; kernels_parse.hip in slab mode;
 // integer work only), which leaves every frame's side information as one contiguous slab in its final LDS layout
 // (nvh_format.h: NvhSlabHdr), at a fixed stride:
 //   * the workgroup issues the slab's first 4 KB (global_load_lds_dwordx4, 1 KB per wavefront-instruction) and the
@@ -74,7 +75,7 @@ struct FloorRef {  // the frame's floor curves as they lie in the slab (both cha
 
 // One line segment of a rendered Floor1 curve as the slab holds it: x = x0 | xend << 16, y = the curve at x0, (w:z) = the
 // curve's step per bin as a signed 32.32 fixed-point number.  Floor1.cs:316-340 draws y(x0 + k) = y0 + k b + sy floor(k r / adx)
-// (b = dy / adx truncated, r = |dy| mod adx, sy = sign dy) with an error-term recurrence; k_prepare_slabs stores
+// (b = dy / adx truncated, r = |dy| mod adx, sy = sign dy) with an error-term recurrence; the slab stores
 // F = |b| 2^32 + ceil(2^32 r / adx), negated for a falling line, and the walk keeps (y : fraction) in one 64-bit register that
 // it adds the step to: the carry out of the fraction is the recurrence's "err >= adx".  Exact: the fraction overestimates
 // k r / adx by less than k 2^-32 <= 2^-19, and k r / adx is either an integer or at least 1 / adx >= 2^-13 below the next one.
@@ -82,7 +83,7 @@ struct FloorRef {  // the frame's floor curves as they lie in the slab (both cha
 template <int NB>
 __device__ __forceinline__ void floor_walk_fx(const uint4* __restrict__ seg, const uint8_t* __restrict__ segtab,
                                               const float* __restrict__ s_db, int x0, float m[NB]) {
-  int sg = segtab[x0 >> 2];  // the last segment that starts at or before x0 (k_prepare_slabs)
+  int sg = segtab[x0 >> 2];  // the last segment that starts at or before x0 (the slab writers)
   uint4 s = seg[sg];
   unsigned long long step = ((unsigned long long)s.w << 32) | s.z;
   const unsigned t = (unsigned)x0 - (s.x & 0xFFFFu);
@@ -193,7 +194,7 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
       }
       float* p0 = spec + xb;
       float* p1 = spec + (unsigned)half + xb;
-      if constexpr (FUSE && G == 8) {  // xb is a multiple of 4 (k_prepare_slabs checked the residue's geometry)
+      if constexpr (FUSE && G == 8) {  // xb is a multiple of 4 (the slab writers checked the residue's geometry)
         if (xb + 4 <= (unsigned)half) {
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
@@ -336,275 +337,6 @@ __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned of
 }
 
 }  // namespace
-
-// ---- launch order: costliest frames first ---------------------------------------------------------------------------------
-// A batch is two occupancy rounds of workgroups (4096 frames over 2048 resident slots); the kernel ends when the last
-// workgroup of the second round does.  Frames differ in work (real material: 20..180 vector writes per frame), and the
-// dispatcher hands the next workgroup to whichever slot frees first -- so with the costly frames in front the slots that
-// free late receive the cheapest frames (longest-processing-time-first list scheduling).  Counting sort by the frame's
-// number of vector writes, one workgroup; rank[f] = position of frame f's slab.  Which of two equally costly frames comes
-// first depends on the order of the atomics; the PCM does not.
-extern "C" __global__ void __launch_bounds__(1024)
-k_rank_frames(NvhDevBatch Bt, uint32_t* __restrict__ rank, int identity) {
-  __shared__ unsigned hist[1024];
-  __shared__ unsigned wsum[16];
-  const int tid = threadIdx.x, n = Bt.nframes;
-  if (identity) {
-    for (int f = tid; f < n; f += 1024) rank[f] = (uint32_t)f;
-    return;
-  }
-  hist[tid] = 0;
-  __syncthreads();
-  auto key = [&](int f) -> unsigned {
-    const NvhFrame* fr = Bt.frames + f;
-    const unsigned c = fr->n == 0 ? 0u : fr->op_count + 1u;
-    return 1023u - (c < 1023u ? c : 1023u);  // descending cost
-  };
-  for (int f = tid; f < n; f += 1024) atomicAdd(&hist[key(f)], 1u);
-  __syncthreads();
-  // exclusive prefix sum over the 1024 bins
-  const unsigned mine = hist[tid];
-  unsigned incl = wave_incl_scan(mine, tid & 63);
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
-  unsigned base = 0;
-  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
-  __syncthreads();
-  hist[tid] = base + incl - mine;
-  __syncthreads();
-  for (int f = tid; f < n; f += 1024) rank[f] = atomicAdd(&hist[key(f)], 1u);
-}
-
-// ---- integer side: descriptors -> slabs, one wavefront per frame, once per batch -----------------------------------------
-extern "C" __global__ void __launch_bounds__(64)
-k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* __restrict__ slabs, int stride_vecs, const uint32_t* __restrict__ rank,
-                int cap_ops) {
-  // dynamic LDS: the frame's vector writes (8 B each), their links (2 B each) and the codebook directory, fetched in one
-  // coalesced round trip: walking the chains (link -> link -> link, op -> book) through global memory is six to eight
-  // dependent L2 / HBM round trips per frame
-  extern __shared__ __attribute__((aligned(16))) uint4 s_stage[];
-  __shared__ __attribute__((aligned(16))) FloorScratch Q;
-  __shared__ int s_err;
-  const int f = blockIdx.x, lane = threadIdx.x, nch = S.channels;
-  uint4* slab = slabs + (long long)(rank ? rank[f] : (uint32_t)f) * stride_vecs;  // frame order, or k_rank_frames' launch order
-  const NvhFrame fr = Bt.frames[f];
-  NvhSlabHdr H;
-  H.n = 0; H.exec_mask = 0; H.flags = 0; H.nheads = 0; H.nrec = 0;
-  H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS; H.vecs = NVH_SLAB_HDR_VECS;
-  H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0; H.frame = (uint32_t)f; H.coupling = 0;
-  for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) H.chan[c] = (uint32_t)NVH_SLAB_HDR_VECS << 16;
-  auto put_header = [&]() {
-    if (lane < NVH_SLAB_HDR_VECS) slab[lane] = reinterpret_cast<const uint4*>(&H)[lane];
-  };
-  if (fr.n == 0) {
-    put_header();
-    return;
-  }
-  if (nch > NVH_SLAB_MAX_CH) __builtin_trap();  // host: slab_path
-  const int half = fr.n >> 1;
-  const NvhDevMapping mp = S.mappings[fr.mapping];
-  const NvhChan* chans = Bt.chans + (long long)f * nch;  // every frame owns exactly `channels` records (host_parse.cpp)
-  if (lane == 0) s_err = 0;
-  sp_wave_sync();
-  unsigned off = NVH_SLAB_HDR_VECS;
-  H.n = (uint16_t)fr.n;
-  H.exec_mask = (uint8_t)(fr.exec_mask & 0xFFu);
-  if (fr.mdct_slot) H.flags |= NVH_SLAB_MDCT_SLOT;
-  // ---- floors: Floor1.UnwrapPosts + the segment list of the flagged posts in X order (spectrum_dev.h: floor_prepare) ----
-  for (int c = 0; c < nch; ++c) {
-    const FloorLane L = load_floor_lane(S, Bt, chans, c, nch, lane);
-    floor_prepare(&Q, L, lane, half, &s_err, S.recip);
-    sp_wave_sync();
-    const int mode = L.mode;  // uniform
-    const int ns = mode == 1 ? Q.nseg : 0;
-    H.chan[c] = (uint32_t)mode | ((uint32_t)ns << 8) | ((uint32_t)off << 16);
-    if (mode == 1) {
-      for (int i = lane; i < ns; i += 64) {
-        // (x, xend, y, b, |dy| mod adx, +-adx) -> (x, xend, y, signed 32.32 step per bin): floor_walk_fx
-        const FloorSeg q = Q.seg[i];
-        const int sadx = (int)q.ady_adx >> 16;
-        const unsigned adx = (unsigned)(sadx < 0 ? -sadx : sadx), r = q.ady_adx & 0xFFFFu;
-        const unsigned ab = (unsigned)(q.b < 0 ? -q.b : q.b);
-        const unsigned long long fr32 = adx ? (((unsigned long long)r << 32) + adx - 1) / adx : 0ull;  // r < adx: below 2^32
-        unsigned long long F = ((unsigned long long)ab << 32) + fr32;
-        if (sadx < 0) F = 0ull - F;
-        slab[off + i] = make_uint4(q.x_xend, (unsigned)q.y, (unsigned)F, (unsigned)(F >> 32));
-      }
-      off += (unsigned)ns;
-      // segment index of every group of four bins (the last segment that starts at or before the group's first bin): the
-      // floor multiply starts its walk there instead of searching the list
-      uint8_t* tab = reinterpret_cast<uint8_t*>(slab + off);
-      const int ngroups = half >> 2;
-      for (int gq = lane; gq < ((ngroups + 15) & ~15); gq += 64) {
-        int sg = 0;
-        if (gq < ngroups) {
-          const int x0 = gq << 2;
-          for (int step = 64; step > 0; step >>= 1) {
-            const int cand = sg + step;
-            if (cand < ns && (int)(Q.seg[cand].x_xend & 0xFFFFu) <= x0) sg = cand;
-          }
-        }
-        tab[gq] = (uint8_t)sg;
-      }
-      off += (unsigned)((ngroups + 15) >> 4);
-    }
-    sp_wave_sync();  // the next channel reuses the scratch block
-  }
-  if (s_err) H.flags |= NVH_SLAB_FLOOR_FAULT;
-  // ---- residue: chains of vector writes, chain-major, every write resolved to its pair record ----
-  const int npass = (int)(fr.pass_end - fr.pass_begin);
-  if (npass > 1) __builtin_trap();  // the host launches this path for batches with at most one residue pass per frame
-  int rtype = 0, rch = 1;
-  unsigned rbegin_al = 0;  // the residue's `begin`
-  H.off_heads = (uint16_t)off;
-  if (npass == 1) {
-    const NvhResPass* gp = Bt.passes + fr.pass_begin;
-    const NvhDevResidue* R = &S.residues[gp->residue];
-    rtype = R->type;
-    rch = R->real_channels;
-    const unsigned psz = (unsigned)R->partition_size, rbegin = (unsigned)R->begin, rch_magic = R->rch_magic;
-    rbegin_al = rbegin;
-    {
-      // components one lane owns: two bins of every channel for Residue2 over more than two channels (the host checked that
-      // partitions are whole multiples of that), else eight when partitions are, else the pair
-      unsigned group = (psz & 7u) == 0 ? 8u : 2u;
-      if (rtype == 2 && rch > 2) group = (psz % (2u * (unsigned)rch)) == 0 ? 2u * (unsigned)rch : 0u;
-      if (group == 0) __builtin_trap();  // host: slab_path
-      const unsigned lpc = psz / group;
-      H.group = (uint8_t)group;
-      H.lpc = (uint16_t)lpc;
-      H.lpc_magic = lpc > 1 ? (uint32_t)((0x100000000ull + lpc - 1) / lpc) : 0u;
-    }
-    const int nops = (int)fr.op_count;
-    NvhResOp* ops = reinterpret_cast<NvhResOp*>(s_stage);
-    uint16_t* links = reinterpret_cast<uint16_t*>(ops + cap_ops);
-    NvhDevBook* s_books = reinterpret_cast<NvhDevBook*>(links + ((cap_ops + 7) & ~7));
-    if (nops > cap_ops) __builtin_trap();  // host: the batch's largest frame
-    {
-      const uint2* go = reinterpret_cast<const uint2*>(Bt.ops + fr.op_begin);
-      const uint16_t* gl = Bt.op_link + fr.op_begin;
-      for (int i = lane; i < nops; i += 64) {
-        reinterpret_cast<uint2*>(ops)[i] = go[i];
-        links[i] = gl[i];
-      }
-      const uint4* gb = reinterpret_cast<const uint4*>(S.books);
-      for (int i = lane; i < S.nbooks * 2; i += 64) reinterpret_cast<uint4*>(s_books)[i] = gb[i];
-      sp_wave_sync();
-    }
-    // pass A: how many chains
-    int nheads = 0;
-    for (int base = 0; base < nops; base += 64) {
-      const int o = base + lane;
-      nheads += __popcll(__ballot(o < nops && !(links[o < nops ? o : 0] & 0x8000u)));
-    }
-    uint32_t* heads = reinterpret_cast<uint32_t*>(slab + off);
-    const unsigned off_rec = off + (unsigned)((nheads + 3) >> 2);
-    uint2* recs = reinterpret_cast<uint2*>(slab + off_rec);
-    // pass B: chain lengths -> record positions; every head lane then writes its chain
-    int hcount = 0, rpos = 0;
-    for (int base = 0; base < nops; base += 64) {
-      const int o = base + lane;
-      const bool head = o < nops && !(links[o < nops ? o : 0] & 0x8000u);
-      unsigned len = 0;
-      if (head) {
-        int q = o;
-        for (;;) {
-          ++len;
-          const unsigned l = links[q] & 0x7FFFu;
-          if (l == NVH_LINK_NONE) break;
-          q = (int)l;
-        }
-      }
-      const unsigned incl = wave_incl_scan(len, lane);
-      const unsigned total = __shfl(incl, 63);
-      const unsigned long long m = __ballot(head);
-      if (head) {
-        const unsigned first = (unsigned)rpos + incl - len;
-        const unsigned offset0 = rbegin + (unsigned)ops[o].partition * psz;
-        const unsigned xbase0 = (rtype == 2 && rch > 1) ? __umulhi(offset0, rch_magic) : offset0;
-        heads[hcount + __popcll(m & ((1ull << lane) - 1ull))] = first | (xbase0 << 16);
-        int q = o;
-        for (unsigned k = 0; k < len; ++k) {
-          const NvhResOp op = ops[q];
-          const NvhDevBook bk = s_books[op.book];
-          // the cascade stage of this write: ops are stage-major, the pass's op_begin[] delimits the stages
-          unsigned stage = 0;
-          const unsigned abs_o = fr.op_begin + (unsigned)q;
-          for (int st = 1; st < NVH_MAX_STAGES; ++st) stage += abs_o >= gp->op_begin[st] ? 1u : 0u;
-          const uint32_t rw[2] = {NVH_SLAB_REC(op.ent_off - fr.ent_begin, bk.dim_magic16, bk.lat_off, bk.lat_values, bk.dim, op.channel, stage, k + 1 < len)};
-          recs[first + k] = make_uint2(rw[0], rw[1]);
-          q = (int)(links[q] & 0x7FFFu);
-        }
-      }
-      hcount += __popcll(m);
-      rpos += (int)total;
-    }
-    // pad the head list and the records to whole vectors (read by nobody, but keep the slab deterministic)
-    for (int i = nheads + lane; i < ((nheads + 3) & ~3); i += 64) heads[i] = 0;
-    if ((rpos & 1) && lane == 0) recs[rpos] = make_uint2(0u, 0u);
-    H.nheads = (uint16_t)nheads;
-    H.nrec = (uint16_t)rpos;
-    H.off_rec = (uint16_t)off_rec;
-    off = off_rec + (unsigned)((rpos + 1) >> 1);
-  } else {
-    H.off_rec = (uint16_t)off;
-  }
-  H.rgeom = (uint8_t)(rtype | (rch << 4));
-  // ---- entries of the frame, from their 2-byte offset to a 16-byte boundary ----
-  H.off_ent = (uint16_t)off;
-  {
-    uint16_t* dst = reinterpret_cast<uint16_t*>(slab + off);
-    const uint16_t* src = Bt.entries + fr.ent_begin;
-    const int ne = (int)fr.ent_count;
-    for (int i = lane; i < ((ne + 7) & ~7); i += 64) dst[i] = i < ne ? src[i] : (uint16_t)NVH_ENTRY_SKIP;
-    off += (unsigned)((ne + 7) >> 3);
-  }
-  if ((int)off > stride_vecs || off > 0xFFFFu) __builtin_trap();  // the host sizes the stride from the batch's largest frame
-  H.vecs = (uint16_t)off;
-  // ---- inverse coupling (Mapping.cs:137-182): in the chain walk when one lane holds both channels of a bin (stereo
-  // Residue2), else passes of their own, last step first, for the steps either of whose channels executes ----
-  if (nch == 2 && mp.coupling_steps == 1 && npass == 1 && rtype == 2 && rch == 2) {
-    if ((fr.exec_mask & 3u) != 0) {
-      if (S.coupling[mp.coupling_off] == 1) H.flags |= NVH_SLAB_MG1;
-      H.flags |= NVH_SLAB_SWEEP_COUPLES;
-    }
-  } else if (mp.coupling_steps > 0) {
-    if (mp.coupling_steps > NVH_SLAB_MAX_COUPLE) __builtin_trap();  // host: slab_path
-    unsigned word = 0, cnt = 0;
-    for (int st = mp.coupling_steps - 1; st >= 0; --st) {  // stored in the order they are applied
-      const unsigned mg = S.coupling[mp.coupling_off + 2 * st], an = S.coupling[mp.coupling_off + 2 * st + 1];
-      if (((fr.exec_mask >> mg) | (fr.exec_mask >> an)) & 1u) {
-        word |= (mg | (an << 3)) << (4 + 6 * cnt);
-        ++cnt;
-      }
-    }
-    if (cnt) {
-      H.coupling = word | cnt;
-      H.flags |= NVH_SLAB_COUPLE_PASS;
-    }
-  }
-  // The floor multiply moves into the chain walk when a lane's group of eight components is whole groups of four bins
-  // (segment table, 16-byte stores), no coupling pass stands between the two, and the stream has at most two channels.
-  if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) &&
-      (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
-    H.flags |= NVH_SLAB_FUSE_FLOOR;
-  // paired emission (nvh_format.h: NVH_EMIT_*; the host decided at upload): the parameters k_synth needs about the overlaps
-  if (nch <= 2 && (fr.emit_flags & NVH_EMIT_CARRY_OUT)) {
-    H.exec_mask |= NVH_SLABX_CARRY_OUT;
-    H.chan[2] = fr.window_off;
-  }
-  if (nch <= 2 && (fr.emit_flags & NVH_EMIT_SELF_CARRY)) H.exec_mask |= NVH_SLABX_SELF_CARRY;
-  if (nch <= 2 && (fr.emit_flags & (NVH_EMIT_SELF | NVH_EMIT_NEXT))) {
-    H.chan[2] = fr.window_off; H.chan[3] = fr.ov_window_off; H.chan[6] = (uint32_t)fr.out_pos;
-    if (fr.emit_flags & NVH_EMIT_SELF) H.flags |= NVH_SLAB_EMIT_SELF;
-    if (fr.emit_flags & NVH_EMIT_NEXT) {
-      const NvhFrame nx = Bt.frames[f + 1];
-      H.chan[4] = nx.window_off; H.chan[5] = nx.ov_window_off; H.chan[7] = (uint32_t)nx.out_pos;
-      H.flags |= NVH_SLAB_EMIT_NEXT;
-    }
-  }
-  put_header();
-}
 
 // NVH_EMIT_CARRY_OUT: the block that becomes the carried tail of the next batch (StreamDecoder's _prevPacketBuf), stored fully
 // windowed like k_ola_compact stores it -- from the frame's own plane, which its wavefronts have just written: the caller's
@@ -1037,7 +769,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     } else if (MAXCH > 2 && group == 0) {
       residue_walk_bins<NT>(slab, off_heads, off_rec, off_ent, lpc, lpc_magic, s_lat, spec, half, rch, tid);  // quirk B-1
     } else if (MAXCH > 2) {
-      switch (rch) {  // group == 2 * rch (k_prepare_slabs)
+      switch (rch) {  // group == 2 * rch (the slab writers)
         case 3: NVH_WALK(6, false, 3, nullptr); break;
         case 4: NVH_WALK(8, false, 4, nullptr); break;
         case 5: NVH_WALK(10, false, 5, nullptr); break;
@@ -1056,7 +788,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     __syncthreads();
     SY_T(6);
     if (flags & NVH_SLAB_COUPLE_PASS) {
-      // inverse coupling as passes of their own (Mapping.cs:137-182), in the order k_prepare_slabs stored them (last step first)
+      // inverse coupling as passes of their own (Mapping.cs:137-182), in the order the slab writers stored them (last step first)
       const unsigned cnt = cpl_word & 0xFu;
       for (unsigned k = 0; k < cnt; ++k) {
         const unsigned pr = (cpl_word >> (4 + 6 * k)) & 0x3Fu;

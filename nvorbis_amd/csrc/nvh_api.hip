@@ -17,7 +17,6 @@ const NvhToggles& nvh_toggles() {
     x.unfused = on("NVH_UNFUSED");
     x.no_pair = on("NVH_NO_PAIR");
     x.no_slab = on("NVH_NO_SLAB");
-    x.lpt = on("NVH_LPT");
     x.no_ola_sym = on("NVH_NO_OLA_SYM");
     x.no_emit = on("NVH_NO_EMIT");
     x.emit8 = on("NVH_EMIT8");
@@ -707,8 +706,6 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
     rc = batch_upload(s, b.get());
     if (rc != NVH_OK) return rc;
     if (s->replay_error != NVH_OK) return s->replay_error;  // resident batches are all-or-nothing
-    // the per-frame slabs of the slab synthesis kernel are part of the resident image (k_prepare_slabs, once per upload)
-    if ((rc = ensure_slabs(b.get())) != NVH_OK) return rc;
     *out = b.release();
     return NVH_OK;
   });
@@ -729,14 +726,6 @@ extern "C" int nvh_batch_info(const nvh_batch* b, int* frames, int* chan_frames,
 extern "C" int nvh_batch_stats(const nvh_batch* b, int64_t* out8) {
   return nvh_guard([&]() -> int {
     if (!b || !out8) return NVH_ERR_ARGUMENT;
-    if (b->prepare_events_pending) {  // k_prepare_slabs of this upload: nanoseconds between its two events
-      nvh_batch* mb = const_cast<nvh_batch*>(b);
-      float ms = 0;
-      HIP_TRY(hipEventSynchronize(b->prep_e1));
-      HIP_TRY(hipEventElapsedTime(&ms, b->prep_e0, b->prep_e1));
-      mb->stats[7] = (int64_t)(ms * 1e6f);
-      mb->prepare_events_pending = false;
-    }
     for (int i = 0; i < 8; i++) out8[i] = b->stats[i];
     return NVH_OK;
   });

@@ -156,7 +156,7 @@ struct NvhFrame {
 //
 // Everything k_synth needs about one frame, in its final LDS form, as ONE contiguous block at a fixed stride per batch,
 // so that the workgroup fetches it with LDS-DMA in a single round trip (no frame record -> slices -> setup records chain
-// of dependent loads, no staging copies, no unwrap in the kernel).  Written by k_prepare_slabs from the descriptors above
+// of dependent loads, no staging copies, no unwrap in the kernel).  Written by the packet parsers (host_slab.cpp, kernels_parse.hip)
 // (integer work only: Floor1.UnwrapPosts + the segment list of the sorted, flagged posts, Floor1.cs:196-297; the
 // residue geometry of Residue0.cs:157-170 / Residue2.cs:23-47 resolved per vector write).  Sections, 16-byte aligned:
 //   NvhSlabHdr | per channel: uint4 segment[nseg] (x | xend << 16, y, signed 32.32 step per bin), uint8 first_segment[n / 8] (one per four bins) |

@@ -44,14 +44,16 @@ __global__ void k_spectrum_gen_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work,
 __global__ void k_spectrum_gen8_imdct(NvhDevSetup S, NvhDevBatch Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
 __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const float* A, const float* B, const float* C,
                                     const float* TW);
-__global__ void k_parse(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
-                        NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
-                        NvhParseResult* result, int lanes, int scratch_words, int pkt_words);
-__global__ void k_parse_g(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,
-                          NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,
-                          NvhParseResult* result, int lanes, int scratch_words, int pkt_words);
+#define NVH_PARSE_DECL(NAME)                                                                                                         \
+  __global__ void NAME(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,   \
+                       NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,            \
+                       NvhParseResult* result, int lanes, int scratch_words, int pkt_words, uint4* slabs)
+NVH_PARSE_DECL(k_parse);         // descriptors out; packets and scratch rows in LDS
+NVH_PARSE_DECL(k_parse_g);       // ... in global memory
+NVH_PARSE_DECL(k_parse_slab);    // slabs out (kernels_parse.hip: parse_body<.., SLAB>)
+NVH_PARSE_DECL(k_parse_slab_g);
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
-                              uint32_t* carry_exec_out, int last_decoded, NvhParseResult* result);
+                              uint32_t* carry_exec_out, int last_decoded, NvhParseResult* result, uint4* slabs, int stride_vecs);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
 __global__ void k_copy_f4(const float4* src, float4* dst, long long n4);
 #ifdef NVH_EXPERIMENTS  // measured slower than the default path: build.py --experiments only
@@ -64,8 +66,6 @@ __global__ void k_run4_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArg
 __global__ void k_run6_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 __global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 #endif
-__global__ void k_prepare_slabs(NvhDevSetup S, NvhDevBatch Bt, uint4* slabs, int stride_vecs, const uint32_t* rank, int cap_ops);
-__global__ void k_rank_frames(NvhDevBatch Bt, uint32_t* rank, int identity);
 __global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_synth_tail(NvhSynthArgs A NVH_DBG_PARAMS);  // + the carried tail written in place (kernels_synth.hip: MODE 1)
 __global__ void k_synth_emit(NvhSynthArgs A NVH_DBG_PARAMS);  // + paired emission (MODE 2)
@@ -129,8 +129,7 @@ struct NvhToggles {
                     // at least 7/8 steady state; the parity suite replays itself with this switch to cover the mixed cases)
   bool xcd_map;      // NVH_XCD_MAP: paired-emission launches take their frames in eight per-XCD runs instead of workgroup order (A/B aid)
   bool no_prefetch;  // NVH_NO_PREFETCH: the odd launch of a paired-emission pass does not touch the even launch's slabs (A/B aid)
-  bool lpt;       // NVH_LPT: slabs in costliest-first launch order (k_rank_frames) instead of frame order
-  bool no_slab;   // NVH_NO_SLAB: k_spectrum_imdct instead of k_prepare_slabs + k_synth (test / A-B aid)
+  bool no_slab;   // NVH_NO_SLAB: the descriptor kernels (k_spectrum_imdct & co.) instead of the slab kernels (test / A-B aid)
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
   bool run;       // NVH_RUN: the run kernel (kernels_run.hip) instead of k_spectrum_imdct + k_ola_compact -- opt-in, it measured slower
   int run_waves;  // NVH_RUN_WAVES = 4 | 6
@@ -273,6 +272,7 @@ struct nvh_batch {
   const char* slot_name[4] = {"-", "-", "-", "-"};  // kernels behind the four timing slots of the last launch
   bool links_ok = false;  // op_link chains usable (every frame has < 32767 ops): k_spectrum's chain walk
   int max_ops = 0, max_ent = 0, max_pass = 0;  // largest per-frame op / entry / pass slice (LDS staging capacity of k_spectrum)
+  int max_vecs = 0;     // GPU-parsed batch in slab mode: its largest slab, as k_parse reported it
   bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
   bool block_only = false;       // nvh_mode_decode: stop after the windowed IMDCT (full blocks in the work planes, no overlap-add)
   bool descriptors_only = false; // nvh_residue_decode: the caller launches a descriptor kernel itself (no slabs)
@@ -284,9 +284,10 @@ struct nvh_batch {
   unsigned run_epoch = 0;
   DevBuf dev_copy;  // the NvhDevBatch block in device memory
   bool dev_copy_valid = false;
-  // slab synthesis kernel (kernels_synth.hip): per-frame slabs written once per upload by k_prepare_slabs
+  // slab synthesis kernel (kernels_synth.hip): per-frame slabs, written by the packet parser (host_slab.cpp into `blob`, k_parse into `slab3`)
   DevBuf slab3;
-  int slab_stride_vecs = 0;   // 16-byte units between slabs = upper bound of the batch's largest slab
+  int slab_stride_vecs = 0;   // 16-byte units between slabs (host-written: the batch's largest slab; GPU-written: the setup's worst case)
+  int slab_cap_vecs = 0;      // the batch's largest slab: what the synthesis kernels' LDS slab area holds
   bool slabs_ready = false;
   bool slab_host = false;          // the slabs were written by the host parser's thread (host_slab.cpp) and lie inside `blob`
   const uint4* d_slabs = nullptr;  // ... here
@@ -295,12 +296,6 @@ struct nvh_batch {
   bool ola_all = false;          // GPU-parsed batch in which k_parse_links withdrew an emission candidate: k_ola_compact over every frame
   int ola_count = 0;             // entries of d_ola_list
   const int* d_ola_list = nullptr;  // inside the descriptor blob
-  bool prepare_events_pending = false;  // prep_e0 / prep_e1 bracket k_prepare_slabs of this upload (read by nvh_batch_stats[7], ns)
-  hipEvent_t prep_e0 = nullptr, prep_e1 = nullptr;
-  ~nvh_batch() {
-    if (prep_e0) (void)hipEventDestroy(prep_e0);
-    if (prep_e1) (void)hipEventDestroy(prep_e1);
-  }  // ... and whether it holds the current upload's pointers
 };
 
 // GPU-parse mode: everything pushed since the last batch boundary, so that a batch in which k_parse found a packet the
@@ -398,6 +393,5 @@ int upload_parse_tables(nvh_stream* s);                          // nvh_setup.hi
 int batch_upload(nvh_stream* s, nvh_batch* b);                   // nvh_launch.hip
 int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms,
                  hipEvent_t* ext_ev = nullptr);  // nvh_launch.hip
-int ensure_slabs(nvh_batch* b);                                  // nvh_launch.hip
 int collect_flags(nvh_stream* s);                                // nvh_launch.hip
 void replay_note(nvh_stream* s, int kind, const uint8_t* data, int len, int64_t granule, int flags);  // nvh_launch.hip

@@ -65,8 +65,18 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   const size_t o_en = al(o_lk + nf * (size_t)T.cap_ops * sizeof(uint16_t));
   const size_t o_po = al(o_en + nf * (size_t)T.cap_ent * sizeof(uint16_t) + 64);
   const size_t o_sc = al(o_po + nf * (size_t)ch * NVH_MAX_POSTS * sizeof(uint16_t));
-  const size_t o_rs = al(o_sc + nf * 2 * (size_t)T.cap_parts * sizeof(int));
+  const size_t row_words = std::max<size_t>(2 * (size_t)T.cap_parts, 132);  // the residue walk's rows; the floors' final Y + segment starts
+  const size_t o_rs = al(o_sc + nf * row_words * sizeof(int));
   const size_t total = al(o_rs + sizeof(NvhParseResult));
+  // Slab mode: k_parse writes the synthesis kernels' slabs itself (kernels_parse.hip: parse_body<.., SLAB>), at the stride of the
+  // setup's worst case; the LDS the synthesis kernels need is sized from the batch's largest slab, reported with the result.
+  b->slab_stride_vecs = T.slab_stride_vecs;
+  b->slab_cap_vecs = T.slab_stride_vecs;  // for the pre-launch size check: the bound
+  const bool slab_mode = T.slab_stride_vecs > 0 && slab_shape_ok(b) && slab_size_ok(b);
+  if (slab_mode) {
+    int rcs = b->slab3.reserve(((size_t)std::max<size_t>(nf, 1) * (size_t)T.slab_stride_vecs * 16 + 4096 + 255) & ~(size_t)255);
+    if (rcs != NVH_OK) return rcs;
+  }
   int rc = b->blob.reserve(total);
   if (rc != NVH_OK) return rc;
   if ((rc = b->h_blob.reserve(host_bytes)) != NVH_OK) return rc;
@@ -120,23 +130,27 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     int scratch_words = 2 * T.cap_parts, pkt_words = (int)max_pkt_words;
     // LDS variant only when both the rows and the longest packet of the batch fit for every lane; else everything per-lane
     // stays in global memory (k_parse_g)
+    if (slab_mode && scratch_words < 132) scratch_words = 132;
     const bool in_lds = table_words + per_wg * (size_t)(scratch_words + pkt_words) <= lds_cap_words;
     if (!in_lds) scratch_words = pkt_words = 0;
     const size_t parse_lds = (table_words + per_wg * (size_t)(scratch_words + pkt_words)) * sizeof(uint32_t);
     if (!s->ctx->parse_lds_attr_set) {  // the opt-in is per device: once per context (contexts are single-threaded)
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_g, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_g, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       s->ctx->parse_lds_attr_set = true;
     }
-    hipLaunchKernelGGL(in_lds ? k_parse : k_parse_g, dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
+    hipLaunchKernelGGL(slab_mode ? (in_lds ? k_parse_slab : k_parse_slab_g) : (in_lds ? k_parse : k_parse_g), dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
                        (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
                        (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
-                       (NvhParseResult*)(base + o_rs), lanes, scratch_words, pkt_words);
+                       (NvhParseResult*)(base + o_rs), lanes, scratch_words, pkt_words, slab_mode ? (uint4*)b->slab3.p : (uint4*)nullptr);
     // the carried block's execute flags ping-pong together with the carried block (nvh_stream_synth flips carry_cur)
     uint32_t* ce = (uint32_t*)s->carry_exec.p;
     hipLaunchKernelGGL(k_parse_links, dim3(blocks), dim3(64), 0, st, (int)nf, ch, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch),
-                       (const uint32_t*)(ce + s->carry_cur), ce + (s->carry_cur ^ 1), b->last_decoded, (NvhParseResult*)(base + o_rs));
+                       (const uint32_t*)(ce + s->carry_cur), ce + (s->carry_cur ^ 1), b->last_decoded, (NvhParseResult*)(base + o_rs),
+                       slab_mode ? (uint4*)b->slab3.p : (uint4*)nullptr, (int)T.slab_stride_vecs);
     HIP_TRY(hipGetLastError());
   }
   rc = collect_parse_result(s, b, (const NvhParseResult*)(base + o_rs));
@@ -144,9 +158,13 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   size_t plane = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
   rc = b->work.reserve(std::max<size_t>((size_t)b->nframes, 1) * plane);
   if (rc != NVH_OK) return rc;
-  // second phase of the GPU parser: the descriptors k_parse wrote become the slabs the synthesis kernels fetch (the same
-  // integer work host_slab.cpp does on the host parser's thread), still part of the parse step
-  if ((rc = ensure_slabs(b)) != NVH_OK) return rc;
+  if (slab_mode) {
+    size_t cap = std::max<size_t>((size_t)b->max_vecs, (size_t)s->setup.block1 / 64 + 8);  // the IMDCT padding of channel 0 overlays the slab area
+    b->slab_cap_vecs = (int)((cap + 3) & ~(size_t)3);
+    b->slabs_ready = true;
+  } else {
+    b->slab_stride_vecs = b->slab_cap_vecs = 0;
+  }
   P.clear();
   s->parser->begin_batch();
   return NVH_OK;
@@ -165,6 +183,7 @@ static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResul
   b->max_ent = r->max_ent;
   b->max_pass = r->max_pass;
   b->links_ok = r->links_ok != 0;
+  b->max_vecs = r->max_vecs;
   b->ola_all = r->emit_ok == 0;  // k_parse_links withdrew an emission candidate: the host's list of left-over frames is short
   // some packet of the batch would have made the managed decoder throw: the batch is parsed again on the host
   if (r->err_frame != 0x7FFFFFFF) return NVH_INTERNAL_REPLAY;
@@ -183,6 +202,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->slabs_ready = false;
   b->slab_host = false;
   b->d_slabs = nullptr;
+  b->slab_stride_vecs = b->slab_cap_vecs = 0;
   b->links_ok = P.links_ok && P.op_link.size() == P.ops.size();
   for (const NvhFrame& fr : P.frames) {
     if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
@@ -334,7 +354,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
     if (rc == NVH_OK) {
       size_t stride = std::max<size_t>(SB.max_vecs, (size_t)s->setup.block1 / 64 + 8);  // the IMDCT padding of channel 0 overlays the slab area
       stride = (stride + 3) & ~(size_t)3;
-      b->slab_stride_vecs = (int)stride;
+      b->slab_stride_vecs = b->slab_cap_vecs = (int)stride;
       b->slab_host = true;
       if (!slab_size_ok(b)) b->slab_host = false;
     }
@@ -448,18 +468,9 @@ static int upload_dev_copy(nvh_batch* b, hipStream_t st) {
 // blocks up to 2048, 8 workgroups per CU).
 static bool slab_wide(const nvh_stream* s) { return s->setup.channels > 2 || s->setup.block1 > 2048; }
 
-// Upper bound of a slab of this batch in 16-byte units: header, per channel a segment list of at most max_posts segments
-// + their magics + the per-four-bins segment table, the chain heads, one record per vector write, the entries
-// (nvh_format.h: NvhSlabHdr).
-static size_t slab_bound_vecs(const nvh_batch* b) {
-  const nvh_stream* s = b->s;
-  if (b->slab_host) return (size_t)b->slab_stride_vecs;  // written by the host parser's thread: the batch's largest slab, exactly
-  const size_t P = (size_t)s->shared->max_posts + 2;
-  size_t v = NVH_SLAB_HDR_VECS + (size_t)s->setup.channels * (P + ((size_t)s->setup.block1 / 8 + 15) / 16) + ((size_t)b->max_ops + 3) / 4 +
-             ((size_t)b->max_ops + 1) / 2 + ((size_t)b->max_ent + 7) / 8 + 1;
-  if (v < (size_t)s->setup.block1 / 64 + 8) v = (size_t)s->setup.block1 / 64 + 8;  // the IMDCT padding of channel 0 overlays the slab area
-  return (v + 3) & ~(size_t)3;
-}
+// The batch's largest slab in 16-byte units (nvh_format.h: NvhSlabHdr): known exactly for slabs the host parser's thread wrote,
+// reported by k_parse for GPU-parsed batches (before its launch: the setup's worst case, for the size check).
+static size_t slab_bound_vecs(const nvh_batch* b) { return (size_t)b->slab_cap_vecs; }
 
 // The LDS slab area in 16-byte units: the batch's largest slab -- and, for a batch with paired emission (k_synth only), room
 // for the neighbours' quarters that are staged over constants + slab in front of the first transform slice's padding
@@ -496,8 +507,8 @@ static bool slab_shape_ok(const nvh_batch* b) {
   if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->descriptors_only || b->max_pass > 1) return false;
   if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact || T.fused_ola || T.run || T.multi) return false;
   if (slab_wide(s) && T.no_gen8) return false;  // NVH_NO_GEN8 keeps its meaning: more than four channels through k_spectrum_gen
-  // residues that are walked bin by bin (quirk B-1) get their slabs from the host parser's thread only: k_prepare_slabs, the
-  // GPU parser's second phase, does not write the partition table that walk needs
+  // residues that are walked bin by bin (quirk B-1) get their slabs from the host parser's thread only: k_parse does not write
+  // the partition table that walk needs
   if (s->gpu_parse)
     for (uint8_t b1 : s->shared->slab.residue_b1)
       if (b1) return false;
@@ -512,49 +523,10 @@ static bool slab_size_ok(const nvh_batch* b) {
 
 static bool slab_path(const nvh_batch* b) { return slab_shape_ok(b) && slab_size_ok(b); }
 
-// k_prepare_slabs once per upload: descriptors -> per-frame slabs (integer work: floor unwrap, chain-major pair records).
-int ensure_slabs(nvh_batch* b) {
-  if (b->slabs_ready || b->slab_host || b->nframes == 0 || !slab_path(b)) return NVH_OK;
-  nvh_stream* s = b->s;
-  hipStream_t st = s->ctx->stream;
-  const size_t stride = slab_bound_vecs(b);
-  const size_t slab_bytes = ((size_t)b->nframes * stride * 16 + 4096 + 255) & ~(size_t)255;
-  int rc = b->slab3.reserve(slab_bytes + (size_t)b->nframes * sizeof(uint32_t));
-  uint32_t* rank = (uint32_t*)((uint8_t*)b->slab3.p + slab_bytes);
-  if (rc != NVH_OK) return rc;
-  b->slab_stride_vecs = (int)stride;
-  // resident batches (nvh_batch_upload) time the conversion for nvh_batch_stats; the stream's own scratch batch does not
-  const bool timed = b != &s->scratch;
-  if (timed) {
-    if (!b->prep_e0) HIP_TRY(hipEventCreate(&b->prep_e0));
-    if (!b->prep_e1) HIP_TRY(hipEventCreate(&b->prep_e1));
-    HIP_TRY(hipEventRecord(b->prep_e0, st));
-  }
-  // costliest-first launch order (k_rank_frames) measured 1 % on the bench workload and costs a 15 us single-workgroup
-  // kernel in front of every prepare: opt-in (NVH_LPT=1), frame order otherwise
-  const bool lpt = nvh_toggles().lpt;
-  if (lpt) hipLaunchKernelGGL(k_rank_frames, dim3(1), dim3(1024), 0, st, b->dev, rank, 0);
-  const int cap_ops = (b->max_ops + 7) & ~7;
-  const size_t stage_bytes = (size_t)cap_ops * 10 + s->setup.books.size() * sizeof(NvhDevBook) + 16;  // ops + links + codebook directory
-  hipLaunchKernelGGL(k_prepare_slabs, dim3((unsigned)b->nframes), dim3(64), stage_bytes, st, s->dev, b->dev, (uint4*)b->slab3.p, (int)stride,
-                     lpt ? (const uint32_t*)rank : (const uint32_t*)nullptr, cap_ops);
-  if (timed) {
-    HIP_TRY(hipEventRecord(b->prep_e1, st));
-    b->prepare_events_pending = true;
-  }
-  HIP_TRY(hipGetLastError());
-  b->slabs_ready = true;
-  return NVH_OK;
-}
-
 int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pcm, bool timing, float* kernel_ms, hipEvent_t* ext_ev) {
   nvh_stream* s = b->s;
   hipStream_t st = s->ctx->stream;
   if (b->nframes == 0) return NVH_OK;
-  {
-    int rc = ensure_slabs(b);  // no-op after the first launch of an upload
-    if (rc != NVH_OK) return rc;
-  }
   const int ch = s->setup.channels;
   float* work = (float*)b->work.p;
   int* flags = (int*)s->flags.p;
@@ -678,7 +650,8 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     }
     A.ipool = s->dev.ipool;
     A.const_vecs = s->shared->synth_const_vecs;
-    A.stride_vecs = A.cap_vecs = b->slab_stride_vecs;
+    A.stride_vecs = b->slab_stride_vecs;
+    A.cap_vecs = b->slab_cap_vecs;
     A.lds_vecs = (int)slab_lds_vecs(b);
     A.channels = ch;
     A.block1 = s->setup.block1;
@@ -688,7 +661,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     const bool wide = slab_wide(s);
     // paired emission (nvh_format.h: NVH_EMIT_*): the host marked the frames at upload; it needs the PCM buffer and the slabs
     // in frame order
-    emitted = b->emit_frames > 0 && d_pcm != nullptr && !b->block_only && !T.no_emit && !T.lpt;
+    emitted = b->emit_frames > 0 && d_pcm != nullptr && !b->block_only && !T.no_emit;
     A.pcm = emitted ? d_pcm : nullptr;
     A.windows = s->dev.windows;
     A.clip = s->clip;

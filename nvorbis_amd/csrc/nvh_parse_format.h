@@ -28,7 +28,10 @@ struct NvhPBook {
   uint8_t has_tree, has_overflow;  // Codebook.cs:294-320: `_prefixList != null`, `_overflowList != null`
   uint8_t pad[2];
   uint32_t lds_off;       // word offset of this book's prefix table inside the LDS image, 0xFFFFFFFF: read it from global memory
-  uint32_t pad2[3];
+  // what a slab record says about the book (nvh_format.h: NVH_SLAB_REC; NvhDevBook has the same fields for the host writer)
+  uint32_t slab_lat;      // lattice pool offset | lat_values << 16
+  uint32_t slab_dm16;     // ceil(2^16 / dims)
+  uint32_t pad2;
 };
 
 struct NvhPOverflow {
@@ -57,6 +60,7 @@ struct NvhPResidue {  // Residue0.cs:21-33
   uint32_t pad2[3];
   uint8_t cascade[NVH_MAX_CLASSES];
   int16_t books[NVH_MAX_CLASSES][NVH_MAX_STAGES];
+  uint8_t book_mask[NVH_MAX_CLASSES];  // per class: the cascade stages that have a book (a chain of the slab has one record per set bit)
 };
 
 struct NvhPMapping {  // Mapping.cs:16-78
@@ -83,6 +87,11 @@ struct NvhDevParse {
   // are copied into LDS too, the three offsets locate the other arrays inside that copy
   int32_t meta_words;
   int32_t meta_floors_off, meta_residues_off, meta_mappings_off, pad;  // byte offsets from `books`
+  // slab mode (the parser writes the synthesis kernels' slabs itself): the synthesis setup's floor records and reciprocal table,
+  // the slab stride (the setup's worst case, 16-byte units; 0: this setup's batches take the descriptor kernels)
+  const NvhDevFloor* dfloors;
+  const uint32_t* recip;
+  int32_t slab_stride_vecs, max_posts;
 };
 
 // One packet's location for k_parse (its frame record carries the geometry).
@@ -100,5 +109,5 @@ struct NvhParseResult {
   int32_t err_code;    // its NVH_ERR_* code
   int32_t links_ok;
   int32_t emit_ok;     // 1: every paired-emission candidate the host marked stands (all channels execute in the frames involved)
-  int32_t pad;
+  int32_t max_vecs;    // slab mode: the batch's largest slab in 16-byte units (sizes the LDS slab area of the synthesis kernels)
 };

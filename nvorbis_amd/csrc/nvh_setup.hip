@@ -284,6 +284,11 @@ int upload_parse_tables(nvh_stream* s) {
     d.max_bits = (uint8_t)b.max_bits;
     d.has_tree = b.has_tree ? 1 : 0;
     d.has_overflow = b.has_overflow ? 1 : 0;
+    if (i < sh.slab.books.size()) {
+      const NvhDevBook& db = sh.slab.books[i];
+      d.slab_lat = db.lat_off | (db.lat_values << 16);
+      d.slab_dm16 = db.dim_magic16;
+    }
     // prefix[slot]: a short code, or (for slots only longer codes start with) that slot's group of overflow nodes
     //   present: (value << 8) | 0x80 | length        absent: (group begin << 8) | group count (0x7F = scan the whole list)
     for (size_t k = 0; k < b.prefix.size(); k++) {
@@ -380,6 +385,7 @@ int upload_parse_tables(nvh_stream* s) {
       d.cascade[c] = (uint8_t)r.cascade[c];
       for (int k = 0; k < NVH_MAX_STAGES; k++) {
         d.books[c][k] = (int16_t)r.books[c][k];
+        if (k < r.max_stages && (r.cascade[c] & (1 << k)) && r.books[c][k] >= 0) d.book_mask[c] |= (uint8_t)(1u << k);
         if (c < r.classifications && r.books[c][k] >= 0) {
           const int dm = S.books[(size_t)r.books[c][k]].dimensions;
           if (dm > 0 && dm < min_dims) min_dims = dm;
@@ -472,6 +478,23 @@ int upload_parse_tables(nvh_stream* s) {
   P.meta_residues_off = (int32_t)(o_rs - o_bk);
   P.meta_mappings_off = (int32_t)(o_mp - o_bk);
   P.pad = 0;
+  // slab mode: setups inside the slab kernels' contract whose frames have one residue pass, no partition-sharing residue (quirk
+  // B-1: the host writer's bin walk), lattice offsets and values a record can hold
+  P.dfloors = sh.dev.floors;
+  P.recip = sh.dev.recip;
+  P.max_posts = sh.max_posts;
+  P.slab_stride_vecs = 0;
+  {
+    bool ok = sh.slab_setup_ok && cap_pass <= 1 && S.channels <= NVH_SLAB_MAX_CH;
+    for (uint8_t b1 : sh.slab.residue_b1) ok = ok && !b1;
+    for (const NvhDevBook& db : sh.slab.books) ok = ok && db.lat_off <= NVH_SLAB_MAX_LAT_OFF && db.lat_values <= 0xFFu;
+    const size_t Pn = (size_t)sh.max_posts + 2;
+    size_t v = NVH_SLAB_HDR_VECS + (size_t)S.channels * (Pn + ((size_t)S.block1 / 8 + 15) / 16) + ((size_t)cap_ops + 3) / 4 + ((size_t)cap_ops + 1) / 2 +
+               ((size_t)cap_ent + 7) / 8 + 1;
+    if (v < (size_t)S.block1 / 64 + 8) v = (size_t)S.block1 / 64 + 8;
+    v = (v + 3) & ~(size_t)3;
+    if (ok && v <= 0xFFFFu && cap_ops <= 0xFFFF && cap_ent <= 0xFFFF) P.slab_stride_vecs = (int32_t)v;
+  }
   sh.gpu_parse_ok = true;
   return NVH_OK;
 }

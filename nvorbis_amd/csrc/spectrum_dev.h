@@ -324,7 +324,7 @@ template <int NB>
 __device__ __forceinline__ void floor_walk_seg(const FloorSeg* __restrict__ seg, const uint32_t* __restrict__ magic, int ns,
                                                const float* __restrict__ s_db, int x0, float m[NB],
                                                const uint8_t* __restrict__ segtab = nullptr) {
-  // last segment whose start is <= x0: from the per-four-bins table when the caller has one (k_prepare_slabs), else a
+  // last segment whose start is <= x0: from the per-four-bins table when the caller has one, else a
   // fixed-trip binary search (the trip count depends on ns only, so the loop control is scalar; the data-dependent form
   // costs an exec-mask loop per lane)
   int sg = 0;
