@@ -175,7 +175,7 @@ def end_to_end(nv, ctx, headers, ll, frames=32768, rounds=6):
         dt = (time.perf_counter() - t0) / rounds
         best = dt if best is None or dt < best else best
     out["gpu_parser_pipelined_frames_per_s"] = frames / best
-    out["gpu_parser_kernels"] = ["k_parse", "k_parse_links", "k_prepare_slabs"] + [k for k in st.kernels() if k != "-"]
+    out["gpu_parser_kernels"] = ["k_parse_slab", "k_parse_links"] + [k for k in st.kernels() if k != "-"]
     out["gpu_parser_pcm_GBps_over_pcie"] = frames * (BLOCK // 2) * 2 * 4 / best / 1e9
     st.close()
     return out

@@ -18,6 +18,7 @@
 
 #include "kernels_common.h"
 #include "nvh_parse_format.h"
+#include "spectrum_dev.h"
 
 namespace {
 
@@ -209,90 +210,51 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_
 
 }  // namespace
 
-// floor((n) / d) from m = floor((2^32 - 1) / d), n <= 2^31, d <= 2^16: the estimate is at most one short (spectrum_dev.h)
-__device__ __forceinline__ unsigned pdiv(unsigned n, unsigned d, unsigned m) {
-  const unsigned q = __umulhi(n, m);
-  return (n - q * d >= d) ? q + 1 : q;
-}
-
-// Slab mode: one channel's Floor1 curve as the synthesis kernels read it -- Floor1.UnwrapPosts (Floor1.cs:224-297), the walk
-// over the sorted, flagged posts (:196-216) as line segments with a signed 32.32 step per bin (kernels_synth.hip:
-// floor_walk_fx; host_slab.cpp writes the same for the host parser), then the segment of every group of four bins.  One lane
-// does this for its own packet, serially; the 64 lanes of the wavefront run it side by side behind the parse (same instruction
-// stream: the post geometry comes from the setup, only the values differ).  row: per-lane scratch words (LDS or global).
-// Returns the segment count (0: not a curve the kernels can walk); *fault: a drawn value leaves inverse_dB_table (quirk B-7).
-template <class RowGet, class RowSet>
-__device__ __forceinline__ int floor_to_slab(const NvhDevFloor1* __restrict__ F, const uint16_t* __restrict__ posts, int pc, int half,
-                                             const uint32_t* __restrict__ recip, RowGet row_get, RowSet row_set,
-                                             uint4* __restrict__ out, bool* fault) {
-  // row words [0, 64): final Y per post; [64, 130): the segments' first bins
-  unsigned long long step = 3ull;
-  row_set(0, (int)posts[0]);
-  row_set(1, (int)posts[1]);
-  const int range = F->range, mult = F->multiplier;
-  for (int i = 2; i < pc; ++i) {
-    const int lo = F->l_neigh[i], hi = F->h_neigh[i];
-    const int y0 = row_get(lo), y1 = row_get(hi);
-    const int dy = y1 - y0, adx = (int)F->x_hi[i] - (int)F->x_lo[i];
-    const int ady = dy < 0 ? -dy : dy;
-    const int er = (int)((unsigned)ady * (unsigned)((int)F->x_list[i] - (int)F->x_lo[i]));  // the managed product wraps
-    const unsigned aer = er < 0 ? 0u - (unsigned)er : (unsigned)er;
-    const int qa = (int)pdiv(aer, (unsigned)adx, F->adx_magic[i]);
-    const int off = er < 0 ? -qa : qa;
-    const int predicted = dy < 0 ? y0 - off : y0 + off;
-    const int val = posts[i];
-    const int highroom = range - predicted, lowroom = predicted;
-    const int room = (highroom < lowroom ? highroom : lowroom) * 2;
-    int fy = predicted;
-    if (val != 0) {
-      step |= (1ull << lo) | (1ull << hi) | (1ull << i);
-      if (val >= room) fy = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
-      else fy = (val % 2) == 1 ? predicted - ((val + 1) / 2) : predicted + (val / 2);
-    }
-    row_set(i, fy);
+// Slab mode: one channel's Floor1 curve as the synthesis kernels read it -- Floor1.UnwrapPosts (Floor1.cs:224-297) and the walk
+// over the sorted, flagged posts (:196-216) by the whole wavefront (lane = post; spectrum_dev.h: floor_prepare, the unwrap the
+// descriptor kernels run per frame), then the segments with their signed 32.32 step per bin (kernels_synth.hip: floor_walk_fx;
+// host_slab.cpp writes the same for the host parser) and the segment of every group of four bins.  Returns the segment count.
+__device__ __forceinline__ int floor_to_slab_wave(FloorScratch* Q, const NvhDevFloor1* __restrict__ F, const uint16_t* __restrict__ posts,
+                                                  int pc, int half, const uint32_t* __restrict__ recip, int* err_word,
+                                                  uint4* __restrict__ out, int lane) {
+  FloorLane L;
+  L.mode = 1; L.pc = pc; L.levels = F->levels; L.level = 0; L.lo = 0; L.hi = 1; L.x = 0; L.x_lo = 0; L.x_hi = 1; L.val = 0;
+  L.sorted = 0; L.x_sorted = 0; L.range = F->range; L.mult = F->multiplier; L.adx_magic = 0;
+  if (lane < pc) {
+    L.lo = F->l_neigh[lane]; L.hi = F->h_neigh[lane]; L.level = F->level[lane]; L.x = F->x_list[lane];
+    L.val = posts[lane];
+    L.sorted = F->sort_idx[lane]; L.x_lo = F->x_lo[lane]; L.x_hi = F->x_hi[lane]; L.x_sorted = F->x_sorted[lane];
+    L.adx_magic = F->adx_magic[lane];
   }
-  int ns = 0, lx = 0, ly = row_get(0) * mult;
-  bool bad = false;
-  auto emit = [&](int x1n, int y1) {
-    const int x1 = x1n < half ? x1n : half;  // Math.Min(hx, n) (quirk B-6)
-    const int dy = y1 - ly, adx = x1 - lx;
-    if (adx <= 0 || ns > NVH_MAX_POSTS) { bad = true; return; }
-    const unsigned udx = (unsigned)adx, mg = recip[udx];
-    const unsigned ady = (unsigned)(dy < 0 ? -dy : dy);
-    const unsigned ab = pdiv(ady, udx, mg), r = ady - ab * udx;
-    // ceil(r 2^32 / adx), r < adx <= 2^16: two 16-bit quotient steps
-    const unsigned n1 = r << 16, q1 = pdiv(n1, udx, mg), r1 = n1 - q1 * udx;
-    const unsigned n2 = r1 << 16, q2 = pdiv(n2, udx, mg), r2 = n2 - q2 * udx;
-    unsigned long long Fx = ((unsigned long long)ab << 32) + ((((unsigned long long)q1 << 16) | q2) + (r2 ? 1u : 0u));
-    if (dy < 0) Fx = 0ull - Fx;
-    out[ns] = make_uint4((unsigned)lx | ((unsigned)x1n << 16), (unsigned)ly, (unsigned)Fx, (unsigned)(Fx >> 32));
-    row_set(64 + ns, lx);
-    const int tl = adx - 1, b = dy < 0 ? -(int)ab : (int)ab;
-    const int yl = ly + b * tl + (dy < 0 ? -1 : 1) * (int)pdiv(r * (unsigned)tl, udx, mg);
-    if (ly < 0 || ly > 255 || yl < 0 || yl > 255) *fault = true;
-    ++ns;
-  };
-  for (int i = 1; i < pc; ++i) {
-    const int idx = F->sort_idx[i];
-    if (!((step >> idx) & 1ull)) continue;
-    const int hx = F->x_list[idx], hy = row_get(idx) * mult;
-    emit(hx, hy);
-    lx = hx;
-    ly = hy;
-    if (lx >= half || bad) break;
+  floor_prepare(Q, L, lane, half, err_word, recip);
+  sp_wave_sync();
+  const int ns = Q->nseg;
+  for (int i = lane; i < ns; i += 64) {
+    // (x, xend, y, b, |dy| mod adx, +-adx) -> (x, xend, y, signed 32.32 step per bin)
+    const FloorSeg q = Q->seg[i];
+    const int sadx = (int)q.ady_adx >> 16;
+    const unsigned adx = (unsigned)(sadx < 0 ? -sadx : sadx), r = q.ady_adx & 0xFFFFu;
+    const unsigned ab = (unsigned)(q.b < 0 ? -q.b : q.b);
+    const unsigned long long fr32 = adx ? (((unsigned long long)r << 32) + adx - 1) / adx : 0ull;  // r < adx: below 2^32
+    unsigned long long Fx = ((unsigned long long)ab << 32) + fr32;
+    if (sadx < 0) Fx = 0ull - Fx;
+    out[i] = make_uint4(q.x_xend, (unsigned)q.y, (unsigned)Fx, (unsigned)(Fx >> 32));
   }
-  if (lx < half && !bad) emit(half, ly);
-  if (bad) return 0;
-  // segment index of every group of four bins: groups [ceil(x_k / 4), ceil(x_{k+1} / 4)) belong to segment k
+  // segment index of every group of four bins: the last segment that starts at or before the group's first bin
   uint8_t* tab = reinterpret_cast<uint8_t*>(out + ns);
-  const int ngroups = half >> 2, padded = (ngroups + 15) & ~15;
-  int g = 0;
-  for (int k = 0; k < ns; ++k) {
-    int g_hi = k + 1 < ns ? (row_get(64 + k + 1) + 3) >> 2 : ngroups;
-    if (g_hi > ngroups) g_hi = ngroups;
-    for (; g < g_hi; ++g) tab[g] = (uint8_t)k;
+  const int ngroups = half >> 2;
+  for (int gq = lane; gq < ((ngroups + 15) & ~15); gq += 64) {
+    int sg = 0;
+    if (gq < ngroups) {
+      const int x0 = gq << 2;
+      for (int step = 64; step > 0; step >>= 1) {
+        const int cand = sg + step;
+        if (cand < ns && (int)(Q->seg[cand].x_xend & 0xFFFFu) <= x0) sg = cand;
+      }
+    }
+    tab[gq] = (uint8_t)sg;
   }
-  for (; g < padded; ++g) tab[g] = 0;
+  sp_wave_sync();  // the next channel reuses the scratch block
   return ns;
 }
 
@@ -305,13 +267,18 @@ __device__ __forceinline__ int floor_to_slab(const NvhDevFloor1* __restrict__ F,
 // SLAB: the lane writes the synthesis kernels' slab of its frame itself (nvh_format.h: NvhSlabHdr; section order header | records
 // | heads | entries | floors): every vector write goes straight to its chain-major record, and behind the parse -- the lanes of
 // the wavefront together again -- the floors (floor_to_slab), the heads, the entries and the header follow.  `ops` then only
-// lends its per-frame area to the list of chain heads until they are copied, `op_link` is not used.  Without SLAB: the
+// and `op_link` are not used.  Without SLAB: the
 // descriptors of rounds 1-3, for the stream shapes the descriptor kernels serve.
 template <bool LDS, bool SLAB>
 __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
-        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs) {
+        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs NVH_DBG_PARAMS) {
+#ifdef NVH_DEBUG
+#define PM(bit) (!(phase_mask & ((bit) << 8)))  // profiling builds: NVH_DEBUG_SPECTRUM_MASK = 15 + 256 * (pieces to leave out)
+#else
+#define PM(bit) true
+#endif
   // hot Huffman tables into LDS (every lane of the wavefront helps, then lanes without a frame leave)
   extern __shared__ __attribute__((aligned(16))) uint32_t s_prefix[];
   uint32_t* s_meta = s_prefix + T.lds_words;  // books | floors | residues | mappings, as in the arena
@@ -334,11 +301,17 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   // every ~5 cycles at best: the host picks few packets per wavefront and ~2 wavefronts per SIMD for small batches
   // (a 4096-packet batch at 64 per wavefront would sit on 64 of 1024 SIMDs) and fills wavefronts up for large ones.
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-  if (lane >= lanes) return;
-  const int slot = wave * lanes + lane;  // packet of this workgroup
-  const int f = blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot;
-  if (f >= nframes) return;
-  NvhFrame fr = frames[f];
+  // slab mode keeps the lanes without a packet alive: behind the parse the whole wavefront works on the floors of its packets
+  const bool active = lane < lanes && blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + wave * lanes + lane < nframes;
+  if (!SLAB && !active) return;
+  const int slot = wave * lanes + (active ? lane : 0);  // packet of this workgroup
+  const int f = active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0;
+  NvhFrame fr;
+  if (active) {
+    fr = frames[f];
+  } else {
+    fr.n = 0; fr.mapping = 0; fr.mdct_slot = 0;
+  }
   const int nch = T.channels;
   NvhChan* ch_out = chans + (long long)f * nch;
   const uint32_t op_base = (uint32_t)f * (uint32_t)T.cap_ops, ent_base = (uint32_t)f * (uint32_t)T.cap_ent;
@@ -350,12 +323,10 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   // slab mode: this frame's slab, its record area (right behind the header), the chains allocated so far
   uint4* const slab = SLAB ? slabs + (long long)f * T.slab_stride_vecs : nullptr;
   uint2* const recs = SLAB ? reinterpret_cast<uint2*>(slab + NVH_SLAB_HDR_VECS) : nullptr;
-  uint32_t* const heads_tmp = reinterpret_cast<uint32_t*>(ops + op_base);  // (slab mode: the op area is free)
   uint32_t nrec_alloc = 0, nheads = 0;
   unsigned long long pcs = 0;  // post count of every channel, 7 bits each (at most eight channels)
-  int s_rtype = 0, s_rch = 1, s_psz = 0, s_rbegin = 0, s_npass = 0;
-  const int row_words = scratch_words > 0 ? scratch_words : (2 * T.cap_parts > 132 ? 2 * T.cap_parts : 132);
-  int* const g_rows_base = scratch + (long long)f * row_words;
+  int s_rtype = 0, s_rch = 1, s_psz = 0, s_rbegin = 0, s_npass = 0, s_parts = 0, s_chs = 1;
+  int* const g_rows_base = scratch + (long long)f * 2 * T.cap_parts;
   int* const l_rows_base = reinterpret_cast<int*>(s_meta + T.meta_words) + slot * scratch_words;
 
   if (fr.n != 0) {
@@ -469,19 +440,15 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                 if (SLAB && stage == 0) {
                   // the chain of this partition / channel: one record per cascade stage that has a book, consecutive, allocated
                   // now that its class is known (stage 0 visits every partition in order)
+                  // (only the allocation happens here, where the lanes of the wavefront run one after the other; the list of
+                  // chain heads is written behind the parse, from these rows)
                   const unsigned cm = r.book_mask[cls];
-                  int start = -1;
-                  if (cm) {
-                    start = (int)nrec_alloc;
-                    const unsigned xb0 = (r.type == 2 && r.real_channels > 1) ? (unsigned)offset / (unsigned)r.real_channels : (unsigned)offset;
-                    if (nheads >= (uint32_t)T.cap_ops * 2u || nrec_alloc + (uint32_t)__popc(cm) > (uint32_t)T.cap_ops || xb0 > 0xFFFFu) {
-                      err = kErrRuntime;
-                      break;
-                    }
-                    heads_tmp[nheads++] = nrec_alloc | (xb0 << 16);
-                    nrec_alloc += (uint32_t)__popc(cm);
+                  row_set(last_base + partition_idx * r.channels + c, cm ? (int)nrec_alloc : -1);
+                  nrec_alloc += (uint32_t)__popc(cm);
+                  if (nrec_alloc > (uint32_t)T.cap_ops) {
+                    err = kErrRuntime;
+                    break;
                   }
-                  row_set(last_base + partition_idx * r.channels + c, start);
                 }
                 if ((r.cascade[cls] & (1 << stage)) == 0) continue;
                 const int book_idx = r.books[cls][stage];
@@ -580,7 +547,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     const unsigned rank = (unsigned)__popc(cm & ((1u << stage) - 1u));
                     const uint32_t rw[2] = {NVH_SLAB_REC(op.ent_off - ent_base, book.slab_dm16, book.slab_lat & 0xFFFFu, book.slab_lat >> 16, dims, c,
                                                          stage, (cm >> (stage + 1)) != 0)};
-                    recs[(uint32_t)start + rank] = make_uint2(rw[0], rw[1]);
+                    if (PM(1)) recs[(uint32_t)start + rank] = make_uint2(rw[0], rw[1]);
                   } else {
                     const uint32_t rel = nops;
                     ops[op_base + rel] = op;
@@ -637,6 +604,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
             }
         }
         s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin;
+        s_parts = err ? 0 : partition_count; s_chs = r.channels;
       }
       if (SLAB) {
         s_npass = 1;
@@ -666,29 +634,41 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
     H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS; H.vecs = NVH_SLAB_HDR_VECS;
     H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0; H.frame = (uint32_t)f; H.coupling = 0;
     for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) H.chan[c] = (uint32_t)NVH_SLAB_HDR_VECS << 16;
-    if (fr.n != 0 && !err) {
-      const NvhPMapping& map = mappings[fr.mapping];
-      const int half = fr.n >> 1;
+    uint32_t off = NVH_SLAB_HDR_VECS;
+    bool fault = false;
+    const bool mine = active && fr.n != 0 && !err;  // this lane has a frame to finish
+    if (mine) {
       H.n = (uint16_t)fr.n;
       H.exec_mask = (uint8_t)(exec_mask & 0xFFu);
       if (fr.mdct_slot) H.flags |= NVH_SLAB_MDCT_SLOT;
       // records (written during the parse) | heads | entries | floors
       const uint32_t off_rec = NVH_SLAB_HDR_VECS;
       const uint32_t off_heads = off_rec + ((nrec_alloc + 1) >> 1);
-      const uint32_t off_ent = off_heads + ((nheads + 3) >> 2);
-      uint32_t off = off_ent + ((nent + 7) >> 3);
       if (nrec_alloc & 1u) recs[nrec_alloc] = make_uint2(0u, 0u);
       {
+        // the chain heads, from the rows of the walk: first record | the partition's first bin << 16, partition by partition
         uint32_t* hd = reinterpret_cast<uint32_t*>(slab + off_heads);
-        for (uint32_t i = 0; i < nheads; ++i) hd[i] = heads_tmp[i];
+        const unsigned rchm = s_rch > 1 ? (unsigned)((0x100000000ull + (unsigned)s_rch - 1) / (unsigned)s_rch) : 0u;
+        auto row_get = [&](int i) { return LDS ? l_rows_base[i] : g_rows_base[i]; };
+        for (int pi = 0; pi < (PM(2) ? s_parts : 0); ++pi) {
+          const unsigned offset = (unsigned)s_rbegin + (unsigned)pi * (unsigned)s_psz;
+          const unsigned xb0 = (s_rtype == 2 && s_rch > 1) ? __umulhi(offset, rchm) : offset;
+          for (int c = 0; c < s_chs; ++c) {
+            const int start = row_get(T.cap_parts + pi * s_chs + c);
+            if (start >= 0) hd[nheads++] = (uint32_t)start | (xb0 << 16);
+          }
+          if (xb0 > 0xFFFFu) err = kErrUnsupported;
+        }
         for (uint32_t i = nheads; i < ((nheads + 3) & ~3u); ++i) hd[i] = 0;
       }
+      const uint32_t off_ent = off_heads + ((nheads + 3) >> 2);
+      off = off_ent + ((nent + 7) >> 3);
       {
         // the frame's entries from their per-frame area (16-byte aligned: cap_ent is a multiple of eight), the tail padded with
         // "no vector"
         const uint4* src = reinterpret_cast<const uint4*>(entries + ent_base);
         uint4* dst = slab + off_ent;
-        const uint32_t full = nent >> 3;
+        const uint32_t full = PM(4) ? nent >> 3 : 0;
         for (uint32_t i = 0; i < full; ++i) dst[i] = src[i];
         if (nent & 7u) {
           uint16_t* d16 = reinterpret_cast<uint16_t*>(dst + full);
@@ -701,25 +681,48 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       H.off_rec = (uint16_t)off_rec;
       H.off_heads = (uint16_t)off_heads;
       H.off_ent = (uint16_t)off_ent;
-      // floors: Floor1.UnwrapPosts + the segment list of every executing channel that has posts
-      bool fault = false;
-      auto row_get = [&](int i) { return LDS ? l_rows_base[i] : g_rows_base[i]; };
-      auto row_set = [&](int i, int v) { if (LDS) l_rows_base[i] = v; else g_rows_base[i] = v; };
-      for (int c = 0; c < nch && !err; ++c) {
-        const int pc = (int)((pcs >> (7 * c)) & 0x7Fu);
-        const int mode = ((exec_mask >> c) & 1u) ? (pc > 0 ? 1 : 2) : 0;
-        int ns = 0;
-        if (mode == 1) {
-          const NvhDevFloor1* F1 = &T.dfloors[map.chan_floor[c]].f1;
-          ns = floor_to_slab(F1, posts + ((long long)f * nch + c) * NVH_MAX_POSTS, pc, half, T.recip, row_get, row_set, slab + off, &fault);
-          if (ns <= 0) {
-            err = kErrUnsupported;  // (the host writer refuses the same curves: the batch goes to the descriptor kernels)
-            break;
+    }
+    // ---- floors, the wavefront together: the packets of its lanes one after the other, lane = post (floor_to_slab_wave) ----
+    {
+      // one floor scratch block per wavefront behind the per-lane areas (16-byte aligned), then one error word each
+      const int nwaves = (int)(blockDim.x >> 6);
+      const int fs_word = (T.lds_words + T.meta_words + nwaves * lanes * (scratch_words + pkt_words) + 3) & ~3;
+      FloorScratch* Q = reinterpret_cast<FloorScratch*>(s_prefix + fs_word) + wave;
+      int* s_err = reinterpret_cast<int*>(s_prefix + fs_word + nwaves * NVH_SP_FLOOR_SCRATCH_WORDS) + wave;
+      for (int j = 0; j < (PM(8) ? lanes : 0); ++j) {
+        const int jn = __shfl(mine ? fr.n : 0, j);
+        if (jn == 0) continue;  // uniform
+        const unsigned jexec = (unsigned)__shfl((int)exec_mask, j);
+        const unsigned jpl = (unsigned)__shfl((int)(unsigned)(pcs & 0xFFFFFFFFull), j), jph = (unsigned)__shfl((int)(unsigned)(pcs >> 32), j);
+        const unsigned long long jpcs = ((unsigned long long)jph << 32) | jpl;
+        const int jf = __shfl(f, j), jmap = __shfl(fr.mapping, j);
+        unsigned joff = (unsigned)__shfl((int)off, j);
+        const NvhPMapping& map = mappings[jmap];
+        uint4* jslab = slabs + (long long)jf * T.slab_stride_vecs;
+        const int half = jn >> 1;
+        for (int c = 0; c < nch; ++c) {
+          const int pc = (int)((jpcs >> (7 * c)) & 0x7Fu);
+          const int mode = ((jexec >> c) & 1u) ? (pc > 0 ? 1 : 2) : 0;
+          int ns = 0;
+          const unsigned coff = joff;
+          if (mode == 1) {
+            if (lane == 0) *s_err = 0;
+            sp_wave_sync();
+            // (room for the segments: at most posts + 1 of them, plus the table -- the stride is the setup's worst case)
+            ns = floor_to_slab_wave(Q, &T.dfloors[map.chan_floor[c]].f1, posts + ((long long)jf * nch + c) * NVH_MAX_POSTS, pc, half, T.recip, s_err,
+                                    jslab + joff, lane);
+            joff += (unsigned)ns + (unsigned)(((half >> 2) + 15) >> 4);
+          }
+          if (lane == j) {
+            H.chan[c] = (uint32_t)mode | ((uint32_t)ns << 8) | (coff << 16);
+            if (mode == 1 && *s_err) fault = true;
           }
         }
-        H.chan[c] = (uint32_t)mode | ((uint32_t)ns << 8) | (off << 16);
-        if (mode == 1) off += (uint32_t)ns + (uint32_t)(((half >> 2) + 15) >> 4);
+        if (lane == j) off = joff;
       }
+    }
+    if (mine) {
+      const NvhPMapping& map = mappings[fr.mapping];
       if (fault) H.flags |= NVH_SLAB_FLOOR_FAULT;
       // residue geometry (Residue0.cs:157-170, Residue2.cs:23-47): components a lane of the synthesis kernel owns
       if (s_npass == 1) {
@@ -757,13 +760,14 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       if (off > (uint32_t)T.slab_stride_vecs || off > 0xFFFFu) err = kErrRuntime;
       H.vecs = (uint16_t)off;
     }
-    if (!err) {
+    if (active && !err) {
       // (paired emission is entered into the header by k_parse_links, which knows the neighbours' execute flags)
       const uint4* hv = reinterpret_cast<const uint4*>(&H);
       for (int i = 0; i < NVH_SLAB_HDR_VECS; ++i) slab[i] = hv[i];
       slab_vecs = H.vecs;
     }
   }
+  if (!active) return;
   frames[f].pass_begin = pass_base;
   frames[f].pass_end = pass_base + npass;
   frames[f].op_begin = op_base;
@@ -789,9 +793,9 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   NAME(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,                          \
        NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,          \
        uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,          \
-       NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs) {                    \
+       NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs NVH_DBG_PARAMS) {     \
     parse_body<LDSV, SLABV>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,      \
-                            scratch_words, pkt_words, slabs);                                                                             \
+                            scratch_words, pkt_words, slabs NVH_DBG_ARGS);                                                                \
   }
 NVH_PARSE_KERNEL(k_parse, true, false)       // descriptors out, packets and scratch rows in LDS
 NVH_PARSE_KERNEL(k_parse_g, false, false)    // ... in global memory (a packet too long for the LDS budget)

@@ -47,7 +47,7 @@ __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const f
 #define NVH_PARSE_DECL(NAME)                                                                                                         \
   __global__ void NAME(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,   \
                        NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,            \
-                       NvhParseResult* result, int lanes, int scratch_words, int pkt_words, uint4* slabs)
+                       NvhParseResult* result, int lanes, int scratch_words, int pkt_words, uint4* slabs NVH_DBG_PARAMS)
 NVH_PARSE_DECL(k_parse);         // descriptors out; packets and scratch rows in LDS
 NVH_PARSE_DECL(k_parse_g);       // ... in global memory
 NVH_PARSE_DECL(k_parse_slab);    // slabs out (kernels_parse.hip: parse_body<.., SLAB>)

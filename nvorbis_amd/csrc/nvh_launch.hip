@@ -65,7 +65,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   const size_t o_en = al(o_lk + nf * (size_t)T.cap_ops * sizeof(uint16_t));
   const size_t o_po = al(o_en + nf * (size_t)T.cap_ent * sizeof(uint16_t) + 64);
   const size_t o_sc = al(o_po + nf * (size_t)ch * NVH_MAX_POSTS * sizeof(uint16_t));
-  const size_t row_words = std::max<size_t>(2 * (size_t)T.cap_parts, 132);  // the residue walk's rows; the floors' final Y + segment starts
+  const size_t row_words = 2 * (size_t)T.cap_parts;  // the residue walk's rows
   const size_t o_rs = al(o_sc + nf * row_words * sizeof(int));
   const size_t total = al(o_rs + sizeof(NvhParseResult));
   // Slab mode: k_parse writes the synthesis kernels' slabs itself (kernels_parse.hip: parse_body<.., SLAB>), at the stride of the
@@ -130,10 +130,11 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     int scratch_words = 2 * T.cap_parts, pkt_words = (int)max_pkt_words;
     // LDS variant only when both the rows and the longest packet of the batch fit for every lane; else everything per-lane
     // stays in global memory (k_parse_g)
-    if (slab_mode && scratch_words < 132) scratch_words = 132;
-    const bool in_lds = table_words + per_wg * (size_t)(scratch_words + pkt_words) <= lds_cap_words;
+    // slab mode: + one floor scratch block and an error word per wavefront (kernels_parse.hip: floor_to_slab_wave)
+    const size_t floor_words = slab_mode ? (size_t)kParseWaves * (NVH_SP_FLOOR_SCRATCH_WORDS + 1) + 8 : 0;
+    const bool in_lds = table_words + per_wg * (size_t)(scratch_words + pkt_words) + floor_words <= lds_cap_words;
     if (!in_lds) scratch_words = pkt_words = 0;
-    const size_t parse_lds = (table_words + per_wg * (size_t)(scratch_words + pkt_words)) * sizeof(uint32_t);
+    const size_t parse_lds = (table_words + per_wg * (size_t)(scratch_words + pkt_words) + floor_words) * sizeof(uint32_t);
     if (!s->ctx->parse_lds_attr_set) {  // the opt-in is per device: once per context (contexts are single-threaded)
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_g, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -145,7 +146,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
                        (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
                        (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
-                       (NvhParseResult*)(base + o_rs), lanes, scratch_words, pkt_words, slab_mode ? (uint4*)b->slab3.p : (uint4*)nullptr);
+                       (NvhParseResult*)(base + o_rs), lanes, scratch_words, pkt_words, slab_mode ? (uint4*)b->slab3.p : (uint4*)nullptr NVH_DBG_LAUNCH);
     // the carried block's execute flags ping-pong together with the carried block (nvh_stream_synth flips carry_cur)
     uint32_t* ce = (uint32_t*)s->carry_exec.p;
     hipLaunchKernelGGL(k_parse_links, dim3(blocks), dim3(64), 0, st, (int)nf, ch, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch),
