@@ -10,7 +10,7 @@ orc = oracle_py.load()
 ctx = nv.Context(0)
 rng = np.random.default_rng(77)
 names = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096", "two_submaps",
-         "equal_blocks_overrun", "mono_8192", "floor0_stereo"]
+         "equal_blocks_overrun", "mono_8192", "stereo_8192", "floor0_stereo", "floor0_slab", "ch5_res2", "mono_res1_2048"]
 
 
 def _decode_pipelined(pk, gr, fl, gpu_parse, per_batch, clip):
@@ -50,7 +50,7 @@ for name in names:
         clip = bool(seed & 2)
         ref, _ = orc.decode_packets(pk, gr, fl, clip=clip)
         bf = int(rng.choice([1, 2, 5, 13, 64, 1000]))
-        gp = bool(seed & 4) and name != "floor0_stereo"
+        gp = bool(seed & 4) and not name.startswith("floor0")
         got = _decode(nv, ctx, pk, gr, fl, gp, bf, clip)
         assert got.size == ref.size, (name, seed)
         if name == "floor0_stereo":

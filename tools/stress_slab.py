@@ -1,5 +1,6 @@
-"""Stress of the slab synthesis kernels (k_prepare_slabs + k_synth / k_synth8) against the CPU oracle: full-depth encoded streams
-(tests/vorbis_encode.py) on the stereo 3test setup and the six-channel C4 setup (psize 48), random lengths, block kinds from a
+"""Stress of the slab synthesis kernels (parser-written slabs -> k_synth / k_synth8) against the CPU oracle: full-depth encoded streams
+(tests/vorbis_encode.py) on the stereo 3test setup and the six-channel C4 setup (psize 48, and psize 32: the bin walk of quirk B-1),
+random lengths, block kinds from a
 Markov chain with random transition rates, random look-ahead batch sizes (1 ... 700 frames), clipping on / off, host and GPU
 packet parser, plus the four shipped files with random batch sizes; every PCM must equal the oracle's bit for bit.
   python tools/stress_slab.py [seconds]"""
@@ -21,6 +22,9 @@ pool3 = ve.packet_pool(S3, 11, per_kind=96)
 h4 = ve.c4_headers(hdr3, psize=48)
 S4 = ve.setup_of(h4)
 pool4 = ve.packet_pool(S4, 12, per_kind=48, class_weights=[0] + [1] * 9)
+h5 = ve.c4_headers(hdr3, psize=32)
+S5 = ve.setup_of(h5)
+pool5 = ve.packet_pool(S5, 13, per_kind=48, class_weights=[0] + [1] * 9)
 
 
 def decode_gpu(pk, gr, fl, clip, bf, gpu_parse):
@@ -41,19 +45,19 @@ def decode_gpu(pk, gr, fl, clip, bf, gpu_parse):
 t0 = time.time()
 runs = frames = bad = 0
 while time.time() - t0 < budget:
-    which = int(rng.integers(0, 3))
+    which = int(rng.integers(0, 4))
     if which == 2:
         name = list(files)[int(rng.integers(0, 4))]
         pk, gr, fl = nv.demux_ogg(files[name])
         gr, fl = gr.tolist(), fl.tolist()
         what = name
     else:
-        S, hdr, pool = (S3, hdr3, pool3) if which == 0 else (S4, h4, pool4)
+        S, hdr, pool = (S3, hdr3, pool3) if which == 0 else ((S4, h4, pool4) if which == 1 else (S5, h5, pool5))
         nfr = int(rng.integers(8, 500 if which == 0 else 160))
         kinds = ve.markov_kinds(rng, nfr, float(rng.uniform(0.0, 0.3)), float(rng.uniform(0.05, 0.6)))
         pk, gr = ve.stream_from_pool(S, hdr, pool, kinds, rng)
         fl = [0] * len(pk)
-        what = "stereo" if which == 0 else "six_ch"
+        what = "stereo" if which == 0 else ("six_ch" if which == 1 else "six_ch_psize32")
     clip = bool(rng.integers(0, 2))
     bf = int(rng.integers(1, 700))
     gp = bool(rng.integers(0, 2))
