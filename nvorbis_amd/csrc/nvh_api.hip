@@ -829,8 +829,8 @@ extern "C" void nvh_batch_free(nvh_batch* b) {
 
 // The two-call protocol (sizing call, then the call that fills the caller's arrays) would demultiplex a file twice: the
 // sizing call parks its result here, per thread, and the fill call that follows on the same bytes takes it.  "The same bytes"
-// is checked by address, length, stream and a fingerprint of 64-bit words sampled across the buffer (every 4 KB and both
-// ends), so a caller that reuses a buffer for another file of the same length is not handed the old packets.
+// is checked by address, length, stream and a hash of the whole buffer, so a caller that reuses or edits a buffer is not handed
+// the old packets.
 namespace {
 struct DemuxMemo {
   const uint8_t* bytes = nullptr;
@@ -843,16 +843,23 @@ struct DemuxMemo {
 thread_local DemuxMemo g_demux_memo;
 
 uint64_t demux_fingerprint(const uint8_t* bytes, size_t len) {
-  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)len;
-  auto word = [&](size_t off) {
+  // every byte of the buffer (four independent multiply chains; well under the cost of the demultiplex, which checksums every
+  // page): a caller that edits a buffer in place between the sizing call and the fill call is not handed the old packets
+  uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ (uint64_t)len, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  size_t off = 0;
+  for (; off + 32 <= len; off += 32) {
+    uint64_t w[4];
+    std::memcpy(w, bytes + off, 32);
+    for (int k = 0; k < 4; k++) h[k] = (h[k] ^ w[k]) * 0x100000001B3ull;
+  }
+  for (; off < len; off += 8) {
     uint64_t w = 0;
     std::memcpy(&w, bytes + off, len - off >= 8 ? 8 : len - off);
-    h = (h ^ w) * 0x100000001B3ull;
-    h ^= h >> 29;
-  };
-  for (size_t off = 0; off < len; off += 4096) word(off);
-  if (len > 8) word(len - 8);
-  return h;
+    h[0] = (h[0] ^ w) * 0x100000001B3ull;
+  }
+  uint64_t r = h[0];
+  for (int k = 1; k < 4; k++) r = (r ^ (h[k] >> 29) ^ h[k]) * 0x9E3779B97F4A7C15ull;
+  return r ^ (r >> 31);
 }
 
 template <typename Demux>
