@@ -325,7 +325,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   uint2* const recs = SLAB ? reinterpret_cast<uint2*>(slab + NVH_SLAB_HDR_VECS) : nullptr;
   uint32_t nrec_alloc = 0, nheads = 0;
   unsigned long long pcs = 0;  // post count of every channel, 7 bits each (at most eight channels)
-  int s_rtype = 0, s_rch = 1, s_psz = 0, s_rbegin = 0, s_npass = 0, s_parts = 0, s_chs = 1;
+  int s_rtype = 0, s_rch = 1, s_psz = 0, s_rbegin = 0, s_npass = 0, s_parts = 0, s_chs = 1, s_b1 = 0;
   int* const g_rows_base = scratch + (long long)f * 2 * T.cap_parts;
   int* const l_rows_base = reinterpret_cast<int*>(s_meta + T.meta_words) + slot * scratch_words;
 
@@ -604,11 +604,11 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
             }
         }
         s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin;
-        s_parts = err ? 0 : partition_count; s_chs = r.channels;
+        s_parts = err ? 0 : partition_count; s_chs = r.channels; s_b1 = r.alias_b1;
       }
       if (SLAB) {
         s_npass = 1;
-        if (!ran) { s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin; }
+        if (!ran) { s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin; s_b1 = r.alias_b1; }
       }
       // stages not reached keep empty ranges
       if (!err) {
@@ -634,7 +634,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
     H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS; H.vecs = NVH_SLAB_HDR_VECS;
     H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0; H.frame = (uint32_t)f; H.coupling = 0;
     for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) H.chan[c] = (uint32_t)NVH_SLAB_HDR_VECS << 16;
-    uint32_t off = NVH_SLAB_HDR_VECS;
+    uint32_t off = NVH_SLAB_HDR_VECS, b1_bins = 0;
     bool fault = false;
     const bool mine = active && fr.n != 0 && !err;  // this lane has a frame to finish
     if (mine) {
@@ -645,11 +645,11 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       const uint32_t off_rec = NVH_SLAB_HDR_VECS;
       const uint32_t off_heads = off_rec + ((nrec_alloc + 1) >> 1);
       if (nrec_alloc & 1u) recs[nrec_alloc] = make_uint2(0u, 0u);
+      auto row_get = [&](int i) { return LDS ? l_rows_base[i] : g_rows_base[i]; };
       {
         // the chain heads, from the rows of the walk: first record | the partition's first bin << 16, partition by partition
         uint32_t* hd = reinterpret_cast<uint32_t*>(slab + off_heads);
         const unsigned rchm = s_rch > 1 ? (unsigned)((0x100000000ull + (unsigned)s_rch - 1) / (unsigned)s_rch) : 0u;
-        auto row_get = [&](int i) { return LDS ? l_rows_base[i] : g_rows_base[i]; };
         for (int pi = 0; pi < (PM(2) ? s_parts : 0); ++pi) {
           const unsigned offset = (unsigned)s_rbegin + (unsigned)pi * (unsigned)s_psz;
           const unsigned xb0 = (s_rtype == 2 && s_rch > 1) ? __umulhi(offset, rchm) : offset;
@@ -663,6 +663,19 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       }
       const uint32_t off_ent = off_heads + ((nheads + 3) >> 2);
       off = off_ent + ((nent + 7) >> 3);
+      if (s_b1) {
+        // quirk B-1 (kernels_synth.hip: residue_walk_bins): the residue's geometry and the chain of every partition -- the heads
+        // above are in partition order, one per partition that has a chain (Residue2: a single channel)
+        uint32_t* prm = reinterpret_cast<uint32_t*>(slab + off);
+        prm[0] = (uint32_t)s_rbegin; prm[1] = (uint32_t)s_psz; prm[2] = (uint32_t)s_parts;
+        prm[3] = ((uint32_t)s_psz + (uint32_t)s_rch - 1u) / (uint32_t)s_rch;
+        uint16_t* pchain = reinterpret_cast<uint16_t*>(prm + 4);
+        uint32_t k = 0;
+        for (int pi = 0; pi < s_parts; ++pi) pchain[pi] = row_get(T.cap_parts + pi) >= 0 ? (uint16_t)k++ : (uint16_t)0xFFFFu;
+        for (int pi = s_parts; pi < ((s_parts + 7) & ~7); ++pi) pchain[pi] = 0xFFFFu;
+        b1_bins = off;
+        off += 1u + (uint32_t)((s_parts + 7) >> 3);
+      }
       {
         // the frame's entries from their per-frame area (16-byte aligned: cap_ent is a multiple of eight), the tail padded with
         // "no vector"
@@ -732,6 +745,11 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         H.group = (uint8_t)group;
         H.lpc = (uint16_t)lpc;
         H.lpc_magic = lpc > 1 ? (uint32_t)((0x100000000ull + lpc - 1) / lpc) : 0u;
+        if (s_b1) {  // the bin walk: group 0, the section's offset and the partition size's reciprocal in the lane-count fields
+          H.group = 0;
+          H.lpc = (uint16_t)b1_bins;
+          H.lpc_magic = (uint32_t)((0x100000000ull + (unsigned)s_psz - 1) / (unsigned)s_psz);
+        }
       }
       H.rgeom = (uint8_t)(s_rtype | (s_rch << 4));
       // inverse coupling (Mapping.cs:137-182): in the chain walk when one lane holds both channels of a bin, else passes

@@ -508,11 +508,6 @@ static bool slab_shape_ok(const nvh_batch* b) {
   if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->descriptors_only || b->max_pass > 1) return false;
   if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact || T.fused_ola || T.run || T.multi) return false;
   if (slab_wide(s) && T.no_gen8) return false;  // NVH_NO_GEN8 keeps its meaning: more than four channels through k_spectrum_gen
-  // residues that are walked bin by bin (quirk B-1) get their slabs from the host parser's thread only: k_parse does not write
-  // the partition table that walk needs
-  if (s->gpu_parse)
-    for (uint8_t b1 : s->shared->slab.residue_b1)
-      if (b1) return false;
   return true;
 }
 

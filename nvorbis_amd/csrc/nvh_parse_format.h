@@ -55,7 +55,8 @@ struct NvhPFloor1 {  // Floor1.cs:21-25 as Unpack uses it
 struct NvhPResidue {  // Residue0.cs:21-33
   int32_t type, begin, end, partition_size;
   int32_t classifications, class_book, channels, real_channels;
-  int32_t max_stages, partvals, class_dims, pad;
+  int32_t max_stages, partvals, class_dims;
+  int32_t alias_b1;         // quirk B-1 on its own (NvhDevResidue::alias_b1): the slab carries the partition table of the bin walk
   uint32_t decode_map_off;  // into the int pool: partvals * class_dims class numbers
   uint32_t pad2[3];
   uint8_t cascade[NVH_MAX_CLASSES];

@@ -378,6 +378,7 @@ int upload_parse_tables(nvh_stream* s) {
     d.classifications = r.classifications; d.class_book = r.class_book; d.channels = r.channels;
     d.real_channels = r.real_channels; d.max_stages = r.max_stages; d.partvals = r.partvals;
     d.class_dims = S.books[(size_t)r.class_book].dimensions;
+    d.alias_b1 = (i < sh.slab.residue_b1.size() && sh.slab.residue_b1[i]) ? 1 : 0;
     d.decode_map_off = (uint32_t)ipool.size();
     ipool.insert(ipool.end(), r.decode_map.begin(), r.decode_map.end());
     int min_dims = 1 << 30;
@@ -478,19 +479,18 @@ int upload_parse_tables(nvh_stream* s) {
   P.meta_residues_off = (int32_t)(o_rs - o_bk);
   P.meta_mappings_off = (int32_t)(o_mp - o_bk);
   P.pad = 0;
-  // slab mode: setups inside the slab kernels' contract whose frames have one residue pass, no partition-sharing residue (quirk
-  // B-1: the host writer's bin walk), lattice offsets and values a record can hold
+  // slab mode: setups inside the slab kernels' contract whose frames have one residue pass, lattice offsets and values a record
+  // can hold (+ room for the partition table of a quirk-B-1 residue)
   P.dfloors = sh.dev.floors;
   P.recip = sh.dev.recip;
   P.max_posts = sh.max_posts;
   P.slab_stride_vecs = 0;
   {
     bool ok = sh.slab_setup_ok && cap_pass <= 1 && S.channels <= NVH_SLAB_MAX_CH;
-    for (uint8_t b1 : sh.slab.residue_b1) ok = ok && !b1;
     for (const NvhDevBook& db : sh.slab.books) ok = ok && db.lat_off <= NVH_SLAB_MAX_LAT_OFF && db.lat_values <= 0xFFu;
     const size_t Pn = (size_t)sh.max_posts + 2;
     size_t v = NVH_SLAB_HDR_VECS + (size_t)S.channels * (Pn + ((size_t)S.block1 / 8 + 15) / 16) + ((size_t)cap_ops + 3) / 4 + ((size_t)cap_ops + 1) / 2 +
-               ((size_t)cap_ent + 7) / 8 + 1;
+               ((size_t)cap_ent + 7) / 8 + 1 + 1 + ((size_t)cap_parts + 7) / 8;
     if (v < (size_t)S.block1 / 64 + 8) v = (size_t)S.block1 / 64 + 8;
     v = (v + 3) & ~(size_t)3;
     if (ok && v <= 0xFFFFu && cap_ops <= 0xFFFF && cap_ent <= 0xFFFF) P.slab_stride_vecs = (int32_t)v;

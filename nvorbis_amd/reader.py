@@ -148,9 +148,7 @@ class Batch:
     def stats(self):
         out = (C.c_int64 * 8)()
         check(lib().nvh_batch_stats(self._h, out), "nvh_batch_stats")
-        # prepare_ns: duration of the descriptor -> slab conversion of this upload (k_prepare_slabs, hipEvents;
-        # 0 for batches that do not take the slab synthesis kernels)
-        keys = ["frames", "chan_frames", "passes", "ops", "entries", "posts", "coeffs", "prepare_ns"]
+        keys = ["frames", "chan_frames", "passes", "ops", "entries", "posts", "coeffs", "reserved"]
         return {k: out[i] for i, k in enumerate(keys)}
 
     def kernels(self):

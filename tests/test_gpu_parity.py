@@ -315,7 +315,8 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     overlap-add in k_ola_compact); NVH_NO_SLAB -> the descriptor kernels (k_spectrum_imdct & co.) that serve the shapes outside the
     slab contract -- these three replays take tests/test_full_depth.py (C2 / C3 / C4 / C5 on full-depth packets) along;
     NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact, NVH_NO_COMPACT -> k_imdct_wave +
-    k_ola_emit; NVH_GPU_PARSE -> packets parsed by k_parse instead of the host parser (k_prepare_slabs as its second phase)."""
+    k_ola_emit; NVH_GPU_PARSE -> packets parsed on the GPU (k_parse_slab writes the slabs; k_parse's descriptors for the shapes outside the slab
+    contract) instead of by the host parser."""
     import os
     import subprocess
     import sys
