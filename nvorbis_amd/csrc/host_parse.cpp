@@ -8,9 +8,38 @@
 #include "host_parse.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace nvh {
+
+void PacketPool::release() {
+  if (base) {
+    if (grow) (void)grow(owner, base, cap, 0);
+    else std::free(base);
+  }
+  base = nullptr;
+  size = cap = 0;
+}
+
+uint8_t* PacketPool::append(size_t n) {
+  if (size + n > cap) {
+    size_t want = cap ? cap * 2 : (size_t)1 << 16;
+    while (want < size + n) want *= 2;
+    uint8_t* nb = grow ? grow(owner, nullptr, 0, want) : static_cast<uint8_t*>(std::malloc(want));
+    if (!nb) return nullptr;
+    if (size) std::memcpy(nb, base, size);
+    if (base) {
+      if (grow) (void)grow(owner, base, cap, 0);
+      else std::free(base);
+    }
+    base = nb;
+    cap = want;
+  }
+  uint8_t* p = base + size;
+  size += n;
+  return p;
+}
 
 // ---------------------------------------------------------------------------------------------
 // floors
@@ -312,13 +341,16 @@ int StreamParser::parse_audio(BitReader& p, FrameBatch& out, int* decoded) {
     if (nch > NVH_PARSE_MAX_CH) return NVH_ERR_UNSUPPORTED;
     out.pkt_refs.resize(out.frames.size());  // pseudo-frames carry empty references
     NvhPacketRef ref;
-    ref.byte_off = (uint32_t)out.pkt_pool.size();
+    ref.byte_off = (uint32_t)out.pkt_pool.size;
     ref.bit_len = (uint32_t)p.total_bits;
     ref.bit_pos = (uint32_t)p.pos;
     ref.pad = 0;
     const size_t nbytes = (size_t)(p.total_bits >> 3);
-    out.pkt_pool.insert(out.pkt_pool.end(), p.data, p.data + nbytes);
-    out.pkt_pool.resize((out.pkt_pool.size() + 7) & ~(size_t)3, 0);  // >= 4 bytes of zeros behind every packet
+    const size_t padded = ((out.pkt_pool.size + nbytes + 7) & ~(size_t)3) - out.pkt_pool.size;  // >= 4 bytes of zeros behind every packet
+    uint8_t* dst = out.pkt_pool.append(padded);
+    if (!dst) return NVH_ERR_NOMEM;
+    if (nbytes) std::memcpy(dst, p.data, nbytes);
+    std::memset(dst + nbytes, 0, padded - nbytes);
     out.pkt_refs.push_back(ref);
     for (int i = 0; i < nch; i++) {
       NvhChan ch;
@@ -465,11 +497,11 @@ int StreamParser::push_packet(const uint8_t* data, int len, int64_t granule, int
   // transactional append: a packet that makes the reference throw leaves the batch untouched
   const size_t m_frames = out.frames.size(), m_chans = out.chans.size(), m_passes = out.passes.size(),
                m_ops = out.ops.size(), m_entries = out.entries.size(), m_posts = out.posts.size(),
-               m_coeffs = out.coeffs.size(), m_pool = out.pkt_pool.size(), m_refs = out.pkt_refs.size();
+               m_coeffs = out.coeffs.size(), m_pool = out.pkt_pool.size, m_refs = out.pkt_refs.size();
   auto rollback = [&]() {
     out.frames.resize(m_frames); out.chans.resize(m_chans); out.passes.resize(m_passes); out.ops.resize(m_ops); out.op_link.resize(m_ops);
     out.entries.resize(m_entries); out.posts.resize(m_posts); out.coeffs.resize(m_coeffs);
-    out.pkt_pool.resize(m_pool); out.pkt_refs.resize(m_refs);
+    out.pkt_pool.size = m_pool; out.pkt_refs.resize(m_refs);
   };
 
   int decoded = 0;

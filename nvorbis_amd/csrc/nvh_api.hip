@@ -21,6 +21,7 @@ const NvhToggles& nvh_toggles() {
     x.no_emit = on("NVH_NO_EMIT");
     x.emit8 = on("NVH_EMIT8");
     x.no_prefetch = on("NVH_NO_PREFETCH");
+    x.copy_upload = on("NVH_COPY_UPLOAD");
     x.xcd_map = on("NVH_XCD_MAP");
     x.emit_always = on("NVH_EMIT_ALWAYS");
     x.debug_occ = on("NVH_DEBUG_OCC");

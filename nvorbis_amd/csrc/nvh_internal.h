@@ -52,6 +52,9 @@ NVH_PARSE_DECL(k_parse);         // descriptors out; packets and scratch rows in
 NVH_PARSE_DECL(k_parse_g);       // ... in global memory
 NVH_PARSE_DECL(k_parse_slab);    // slabs out (kernels_parse.hip: parse_body<.., SLAB>)
 NVH_PARSE_DECL(k_parse_slab_g);
+__global__ void k_parse_result_out(const NvhParseResult* dev, NvhParseResult* host);
+__global__ void k_parse_fetch(const uint4* stage_h, uint4* stage_d, long long stage_n16, const uint8_t* pool_h, uint8_t* pool_d,
+                              long long pool_bytes, NvhParseResult* result);
 __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhChan* chans, const uint32_t* carry_exec_in,
                               uint32_t* carry_exec_out, int last_decoded, NvhParseResult* result, uint4* slabs, int stride_vecs);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
@@ -128,6 +131,7 @@ struct NvhToggles {
   bool emit_always; // NVH_EMIT_ALWAYS: paired emission for every batch that has a steady-state frame (default: batches that are
                     // at least 7/8 steady state; the parity suite replays itself with this switch to cover the mixed cases)
   bool xcd_map;      // NVH_XCD_MAP: paired-emission launches take their frames in eight per-XCD runs instead of workgroup order (A/B aid)
+  bool copy_upload;  // NVH_COPY_UPLOAD: a GPU-parse batch's input goes up by copy commands instead of k_parse_fetch (A/B aid)
   bool no_prefetch;  // NVH_NO_PREFETCH: the odd launch of a paired-emission pass does not touch the even launch's slabs (A/B aid)
   bool no_slab;   // NVH_NO_SLAB: the descriptor kernels (k_spectrum_imdct & co.) instead of the slab kernels (test / A-B aid)
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
@@ -369,6 +373,22 @@ struct nvh_stream {
     h_pcm.host = scratch.h_blob.host = true;
     h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;
     scratch.s = this;
+    if (c) {  // GPU-parse batches: the packet bytes straight into page-locked memory (host_parse.h: PacketPool)
+      pending.pkt_pool.owner = c;
+      pending.pkt_pool.grow = &pinned_pool_grow;
+    }
+  }
+  // PacketPool storage from the context's pool of page-locked blocks; new_cap == 0: give `old` (of old_cap bytes) back
+  static uint8_t* pinned_pool_grow(void* owner, uint8_t* old, size_t old_cap, size_t new_cap) {
+    nvh_ctx* c = static_cast<nvh_ctx*>(owner);
+    if (new_cap == 0) {
+      if (old) c->hpool.give(old, old_cap);
+      return nullptr;
+    }
+    if (BufPool::size_class(new_cap) != new_cap) return nullptr;  // (the pool asks for powers of two >= 64 KB: size classes of their own)
+    void* p = c->hpool.take(new_cap);
+    if (!p && hipHostMalloc(&p, new_cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return static_cast<uint8_t*>(p);
   }
 };
 

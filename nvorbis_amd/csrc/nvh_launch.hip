@@ -43,13 +43,24 @@ static int replay_on_host(nvh_stream* s) {
 }
 
 // GPU-parse mode: upload frame geometry + packets, let k_parse produce the descriptors into per-frame slabs.
+#include <chrono>
 static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>& ola_list) {
+  static const bool tprint = std::getenv("NVH_TIME_UPLOAD") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_a = tnow();
   nvh::FrameBatch& P = s->pending;
   const NvhDevParse& T = s->shared->parse;
   const int ch = s->setup.channels;
   const size_t nf = P.frames.size();
   P.pkt_refs.resize(nf);  // trailing pseudo-frames
-  if (P.pkt_pool.empty()) P.pkt_pool.resize(8, 0);
+  if (P.pkt_pool.empty()) {
+    uint8_t* z = P.pkt_pool.append(8);
+    if (!z) return NVH_ERR_NOMEM;
+    std::memset(z, 0, 8);
+  }
+  // the packets lie in page-locked memory when the stream placed the pool there (nvh_api.hip): they go up from where the
+  // parser wrote them; otherwise through the staging block like the records
+  const bool pool_pinned = P.pkt_pool.grow != nullptr;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
   // host-written prefix of the blob ...
   const size_t o_fr = 0;
@@ -57,9 +68,10 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   const size_t o_rf = al(o_ch + std::max<size_t>(nf * ch, 1) * sizeof(NvhChan));
   const size_t o_ol = al(o_rf + std::max<size_t>(nf, 1) * sizeof(NvhPacketRef));
   const size_t o_pk = al(o_ol + std::max<size_t>(ola_list.size(), 1) * sizeof(int));
-  const size_t host_bytes = al(o_pk + P.pkt_pool.size() + 8);
+  const size_t pool_bytes = P.pkt_pool.size;
+  const size_t host_bytes = pool_pinned ? al(o_pk) : al(o_pk + pool_bytes + 8);  // what the staging block holds
   // ... and the device-only slabs behind it
-  const size_t o_ps = host_bytes;
+  const size_t o_ps = al(o_pk + pool_bytes + 8);
   const size_t o_op = al(o_ps + nf * (size_t)T.cap_pass * sizeof(NvhResPass));
   const size_t o_lk = al(o_op + nf * (size_t)T.cap_ops * sizeof(NvhResOp));
   const size_t o_en = al(o_lk + nf * (size_t)T.cap_ops * sizeof(uint16_t));
@@ -85,18 +97,40 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   if (nf) std::memcpy(h + o_ch, P.chans.data(), std::min(P.chans.size(), nf * (size_t)ch) * sizeof(NvhChan));
   if (nf) std::memcpy(h + o_rf, P.pkt_refs.data(), nf * sizeof(NvhPacketRef));
   if (!ola_list.empty()) std::memcpy(h + o_ol, ola_list.data(), ola_list.size() * sizeof(int));
-  std::memcpy(h + o_pk, P.pkt_pool.data(), P.pkt_pool.size());
-  std::memset(h + o_pk + P.pkt_pool.size(), 0, 8);
-  b->descriptor_bytes = (int64_t)(nf * (sizeof(NvhFrame) + sizeof(NvhPacketRef)) + P.pkt_pool.size());
+  if (!pool_pinned) {
+    std::memcpy(h + o_pk, P.pkt_pool.base, pool_bytes);
+    std::memset(h + o_pk + pool_bytes, 0, 8);
+  }
+  b->descriptor_bytes = (int64_t)(nf * (sizeof(NvhFrame) + sizeof(NvhPacketRef)) + pool_bytes);
   hipStream_t st = s->ctx->stream;
   uint8_t* base = (uint8_t*)b->blob.p;
-  HIP_TRY(hipMemcpyAsync(base, h, host_bytes, hipMemcpyHostToDevice, st));
-  NvhParseResult init{};
-  init.err_frame = 0x7FFFFFFF;
-  init.links_ok = 1;
-  init.emit_ok = 1;
-  // (a 32-byte pageable source: staged by the runtime before the call returns)
-  HIP_TRY(hipMemcpyAsync(base + o_rs, &init, sizeof init, hipMemcpyHostToDevice, st));
+  auto t_b = tnow();
+  if (nvh_toggles().copy_upload) {
+    HIP_TRY(hipMemcpyAsync(base, h, host_bytes, hipMemcpyHostToDevice, st));
+    if (pool_pinned) {
+      // (the pool is not touched again before collect_parse_result below has synchronised the stream)
+      HIP_TRY(hipMemcpyAsync(base + o_pk, P.pkt_pool.base, pool_bytes, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemsetAsync(base + o_pk + pool_bytes, 0, 8, st));
+    }
+    NvhParseResult init{};
+    init.err_frame = 0x7FFFFFFF;
+    init.links_ok = 1;
+    init.emit_ok = 1;
+    // (a 32-byte pageable source: staged by the runtime before the call returns)
+    HIP_TRY(hipMemcpyAsync(base + o_rs, &init, sizeof init, hipMemcpyHostToDevice, st));
+  } else {
+    // the device fetches its input itself (kernels_parse.hip: k_parse_fetch); both host blocks are page-locked and mapped
+    void *h_dev = nullptr, *pool_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&h_dev, h, 0));
+    if (pool_pinned) HIP_TRY(hipHostGetDevicePointer(&pool_dev, P.pkt_pool.base, 0));
+    const long long n16 = (long long)(host_bytes / 16);  // (offsets are multiples of 256)
+    const long long work16 = n16 + (long long)(pool_pinned ? pool_bytes / 16 : 0);
+    const unsigned fblocks = (unsigned)std::min<long long>(2048, std::max<long long>(1, (work16 + 255) / 256));
+    hipLaunchKernelGGL(k_parse_fetch, dim3(fblocks), dim3(256), 0, st, (const uint4*)h_dev, (uint4*)base, n16,
+                       (const uint8_t*)pool_dev, pool_pinned ? base + o_pk : (uint8_t*)nullptr, (long long)pool_bytes,
+                       (NvhParseResult*)(base + o_rs));
+    HIP_TRY(hipGetLastError());
+  }
   b->dev.frames = (const NvhFrame*)(base + o_fr);
   b->dev.chans = (const NvhChan*)(base + o_ch);
   b->dev.passes = (const NvhResPass*)(base + o_ps);
@@ -154,7 +188,15 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
                        slab_mode ? (uint4*)b->slab3.p : (uint4*)nullptr, (int)T.slab_stride_vecs);
     HIP_TRY(hipGetLastError());
   }
+  auto t_c = tnow();
   rc = collect_parse_result(s, b, (const NvhParseResult*)(base + o_rs));
+  auto t_d = tnow();
+  if (tprint) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    fprintf(stderr, "batch_upload_gpu: host prep %.2f ms, enqueue %.2f ms, wait for k_parse %.2f ms\n", ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d));
+  }
   if (rc != NVH_OK) return rc;
   size_t plane = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
   rc = b->work.reserve(std::max<size_t>((size_t)b->nframes, 1) * plane);
@@ -178,7 +220,15 @@ static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResul
   int rc = s->h_pcm.reserve(sizeof(NvhParseResult));
   if (rc != NVH_OK) return rc;
   NvhParseResult* r = (NvhParseResult*)s->h_pcm.p;
-  HIP_TRY(hipMemcpyAsync(r, d_res, sizeof *r, hipMemcpyDeviceToHost, st));
+  if (nvh_toggles().copy_upload) {
+    HIP_TRY(hipMemcpyAsync(r, d_res, sizeof *r, hipMemcpyDeviceToHost, st));
+  } else {
+    static_assert(sizeof(NvhParseResult) % 4 == 0 && sizeof(NvhParseResult) <= 256, "k_parse_result_out: one word per lane");
+    void* r_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&r_dev, r, 0));
+    hipLaunchKernelGGL(k_parse_result_out, dim3(1), dim3(64), 0, st, d_res, (NvhParseResult*)r_dev);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipStreamSynchronize(st));
   b->max_ops = r->max_ops;
   b->max_ent = r->max_ent;
@@ -821,7 +871,6 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     }
   }
   if (timing) HIP_TRY(hipEventRecord(ev[2], st));
-  const int run_len_env = T.run_len;
   const size_t plane_bytes = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
 #ifdef NVH_EXPERIMENTS
   if (use_fused_ola) {
