@@ -119,6 +119,61 @@ bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r) {
   return true;
 }
 
+bool residue_pair_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
+  if (r.type == 0 || r.partition_size < 2 || (r.partition_size & 1) || r.partition_size > 4096 || r.real_channels < 1) return false;
+  if (r.type == 2 && (r.begin % r.real_channels != 0 || r.partition_size % r.real_channels != 0)) return false;  // aliasing partitions
+  uint64_t max_div = (uint64_t)std::max(r.partition_size, r.real_channels);
+  for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++)
+    for (int k = 0; k < NVH_MAX_STAGES; k++) {
+      const int b = r.books[c][k];
+      if (b < 0) continue;
+      const NvhDevBook& bk = X.books[(size_t)b];
+      if (bk.lat_values == 0 || bk.dim == 0 || (bk.dim & 1u) || (uint32_t)r.partition_size % bk.dim != 0) return false;
+      max_div = std::max<uint64_t>(max_div, bk.dim);
+    }
+  // (the reciprocal multiplies of the walk are exact while index * divisor < 2^32: nvh_setup.hip, NvhDevResidue::fast)
+  const uint64_t max_index = (uint64_t)(S.block1 / 2 + r.partition_size) * (uint64_t)r.real_channels;
+  return max_index * max_div < 0x100000000ull;
+}
+
+void classify_residues(const Setup& S, SlabSetup& X, bool no_pair) {
+  const size_t n = S.residues.size();
+  X.residue_pair.assign(n, 0);
+  X.residue_b1.assign(n, 0);
+  X.residue_general.assign(n, 0);
+  for (size_t i = 0; i < n; i++) {
+    const Residue& r = S.residues[i];
+    // (Residue2 over more than two channels: a lane of the pair walk owns two bins of every channel)
+    const bool whole_groups = !(r.type == 2 && r.real_channels > 2) || r.partition_size % (2 * r.real_channels) == 0;
+    X.residue_pair[i] = (!no_pair && whole_groups && residue_pair_ok(S, X, r)) ? 1 : 0;
+    X.residue_b1[i] = (!no_pair && !X.residue_pair[i] && residue_alias_b1(S, X, r)) ? 1 : 0;
+    X.residue_general[i] = (!no_pair && residue_general_ok(S, X, r)) ? 1 : 0;
+  }
+}
+
+bool residue_general_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
+  (void)S;
+  const int rch = r.type == 2 ? r.real_channels : 1;
+  if (rch < 1 || r.real_channels > NVH_SLAB_MAX_CH || r.partition_size < 2 || r.partition_size > 4096) return false;
+  if (r.type == 2 && rch > 1 && (r.begin % rch != 0 || r.partition_size % rch != 0) && r.partition_size < 2 * rch) return false;
+  const uint32_t psz = (uint32_t)r.partition_size;
+  const uint32_t psz_magic = (uint32_t)((0x100000000ull + psz - 1) / psz);
+  for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++)
+    for (int k = 0; k < NVH_MAX_STAGES; k++) {
+      const int b = r.books[c][k];
+      if (b < 0) continue;
+      const NvhDevBook& bk = X.books[(size_t)b];
+      if (bk.lat_values == 0 || bk.lat_values > 0xFFu || bk.dim == 0 || bk.dim > 16u || psz % bk.dim != 0) return false;
+      // the walk's divisions: i / dim by the 16-bit reciprocal, and (Residue0) i dim / partition_size by the 32-bit one
+      if (((psz * bk.dim_magic16) >> 16) != psz / bk.dim) return false;
+      for (uint32_t i = 0; i < psz; i++) {
+        if (((i * bk.dim_magic16) >> 16) != i / bk.dim) return false;
+        if (r.type == 0 && (uint32_t)(((uint64_t)(i * bk.dim) * psz_magic) >> 32) != i * bk.dim / psz) return false;
+      }
+    }
+  return true;
+}
+
 bool floor0_section_values(const Floor0& f, int slot, int half, float amp, const float* coeff, float* qk) {
   const std::vector<int>& bark = f.bark_map[slot];
   const std::vector<float>& wmap = f.w_map[slot];
@@ -154,6 +209,131 @@ bool floor0_section_values(const Floor0& f, int slot, int half, float amp, const
   }
   return true;
 }
+
+namespace {
+
+// The residue sections of a frame in the general form (NvhSlabHdr::group == 1): chains of every pass (heads, records), the
+// frame's entries, and the group list -- one group per (pass, channel) of a per-channel residue, one per pass of a Residue2 --
+// that tells the bin walk which chain covers which partition.  Returns NVH_OK with H's section fields set.
+int residue_general(const Setup& S, const SlabSetup& X, const FrameBatch& P, const NvhFrame& fr, int nch, size_t base,
+                    std::vector<SlabVec>& data, NvhSlabHdr& H, std::vector<uint32_t>& head_ops) {
+  const int npass = (int)(fr.pass_end - fr.pass_begin);
+  const uint32_t nops = fr.op_count;
+  const NvhResOp* ops = P.ops.data() + fr.op_begin;
+  const uint16_t* links = P.op_link.data() + fr.op_begin;
+  uint32_t nheads = 0;
+  for (uint32_t o = 0; o < nops; o++) nheads += (links[o] & 0x8000u) ? 0u : 1u;
+  const uint32_t off_heads = (uint32_t)(data.size() - base);
+  const uint32_t off_rec = off_heads + ((nheads + 3) >> 2);
+  data.resize(base + off_rec + ((nops + 1) >> 1));
+  uint32_t* heads = reinterpret_cast<uint32_t*>(&data[base + off_heads]);
+  uint32_t* recs = reinterpret_cast<uint32_t*>(&data[base + off_rec]);
+  struct Group { uint32_t rbegin, psz, nparts, cover, geom, psz_magic, pchain_off; };
+  std::vector<Group> groups;
+  std::vector<uint16_t> pchain;
+  uint32_t hk = 0, nrec = 0;
+  for (int pi = 0; pi < npass; pi++) {
+    const NvhResPass& gp = P.passes[fr.pass_begin + (uint32_t)pi];
+    if (gp.residue < 0 || (size_t)gp.residue >= S.residues.size() || (size_t)gp.residue >= X.residue_general.size()) return NVH_ERR_RUNTIME;
+    if (!X.residue_general[(size_t)gp.residue]) return NVH_ERR_UNSUPPORTED;
+    const Residue& R = S.residues[(size_t)gp.residue];
+    const uint32_t psz = (uint32_t)R.partition_size, rbegin = (uint32_t)R.begin;
+    const int rch = R.type == 2 ? R.real_channels : 1;
+    const int bs = R.type == 2 ? fr.n * R.real_channels : fr.n;  // Residue2.cs:16-21
+    const int end = R.end < bs / 2 ? R.end : bs / 2;                 // Residue0.cs:122-123
+    const int nn = end - R.begin;
+    const uint32_t nparts = nn > 0 ? (uint32_t)(nn / R.partition_size) : 0u;
+    // this pass's ops: [lo, hi) frame-relative
+    const uint32_t lo = gp.op_begin[0] - fr.op_begin, hi = gp.op_begin[NVH_MAX_STAGES] - fr.op_begin;
+    if (lo > hi || hi > nops) return NVH_ERR_RUNTIME;
+    auto stage_of = [&](uint32_t o) {
+      const uint32_t abs_o = fr.op_begin + o;
+      unsigned st = 0;
+      while (st + 1 < NVH_MAX_STAGES && abs_o >= gp.op_begin[st + 1]) ++st;
+      return st;
+    };
+    const int pass_ch = R.channels;  // chains exist per (partition, channel); Residue2 decodes one interleaved vector: 1
+    if (pass_ch < 1 || pass_ch > nch) return NVH_ERR_RUNTIME;
+    const size_t pc0 = pchain.size();
+    pchain.resize(pc0 + (size_t)pass_ch * nparts, (uint16_t)0xFFFFu);
+    head_ops.clear();
+    for (uint32_t o = lo; o < hi; o++)
+      if (!(links[o] & 0x8000u)) head_ops.push_back(o);
+    for (uint32_t o : head_ops) {
+      const uint32_t part = ops[o].partition, c = ops[o].channel;
+      if (part >= nparts || c >= (uint32_t)pass_ch) return NVH_ERR_RUNTIME;
+      const uint32_t offset0 = rbegin + part * psz;
+      const uint32_t xbase = rch > 1 ? offset0 / (uint32_t)rch : offset0;
+      if (xbase > 0xFFFFu || nrec > 0xFFFFu || hk > 0xFFFEu) return NVH_ERR_UNSUPPORTED;
+      pchain[pc0 + (size_t)c * nparts + part] = (uint16_t)hk;
+      heads[hk++] = nrec | (xbase << 16);
+      uint32_t q = o;
+      for (;;) {
+        if (q >= hi || nrec >= nops) return NVH_ERR_RUNTIME;
+        const NvhResOp& op = ops[q];
+        const NvhDevBook& bk = X.books[op.book];
+        const uint32_t rel = op.ent_off - fr.ent_begin;
+        if (rel > 0xFFFFu || bk.lat_off > NVH_SLAB_MAX_LAT_OFF || bk.lat_values > 0xFFu || bk.dim > 31u || op.channel > 7u ||
+            op.partition != part || op.channel != c)
+          return NVH_ERR_UNSUPPORTED;
+        const uint32_t l = links[q] & 0x7FFFu;
+        const uint32_t rw[2] = {NVH_SLAB_REC(rel, bk.dim_magic16, bk.lat_off, bk.lat_values, bk.dim, op.channel, stage_of(q), l != NVH_LINK_NONE)};
+        recs[2 * nrec] = rw[0];
+        recs[2 * nrec + 1] = rw[1];
+        ++nrec;
+        if (l == NVH_LINK_NONE) break;
+        q = l;
+      }
+    }
+    for (int c = 0; c < pass_ch; c++) {
+      Group g;
+      g.rbegin = rbegin; g.psz = psz; g.nparts = nparts;
+      g.cover = (psz + (uint32_t)rch - 1) / (uint32_t)rch;
+      g.geom = (uint32_t)R.type | ((uint32_t)rch << 4) | ((uint32_t)pi << 8) | ((uint32_t)(R.type == 2 ? 0 : c) << 12);
+      g.psz_magic = (uint32_t)((0x100000000ull + psz - 1) / psz);
+      g.pchain_off = (uint32_t)(pc0 + (size_t)c * nparts);
+      if (g.pchain_off > 0xFFFFFFu || pi > 15) return NVH_ERR_UNSUPPORTED;
+      groups.push_back(g);
+    }
+  }
+  for (uint32_t i = nheads; i < ((nheads + 3) & ~3u); i++) heads[i] = 0;
+  if (nrec != nops || hk != nheads) return NVH_ERR_RUNTIME;  // every op belongs to exactly one chain
+  if (nrec & 1u) recs[2 * nrec] = recs[2 * nrec + 1] = 0;
+  H.off_heads = (uint16_t)off_heads;
+  H.nheads = (uint16_t)nheads;
+  H.nrec = (uint16_t)nrec;
+  H.off_rec = (uint16_t)off_rec;
+  H.rgeom = (uint8_t)(1 | (1 << 4));
+  H.group = 1;
+  // entries, padded with "no vector" to a whole 16-byte unit
+  H.off_ent = (uint16_t)(data.size() - base);
+  {
+    const uint32_t ne = fr.ent_count, padded = (ne + 7) & ~7u;
+    const size_t e0 = data.size();
+    data.resize(e0 + padded / 8);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(&data[e0]);
+    if (ne) std::memcpy(dst, P.entries.data() + fr.ent_begin, (size_t)ne * 2);
+    for (uint32_t i = ne; i < padded; i++) dst[i] = (uint16_t)NVH_ENTRY_SKIP;
+  }
+  // the group list: count | per group two 16-byte units | uint16 pchain[]
+  const size_t g0 = data.size();
+  if (g0 - base > 0xFFFFu) return NVH_ERR_UNSUPPORTED;
+  H.lpc = (uint16_t)(g0 - base);
+  H.lpc_magic = 0;
+  data.resize(g0 + 1 + 2 * groups.size() + (pchain.size() + 7) / 8);
+  uint32_t* w = reinterpret_cast<uint32_t*>(&data[g0]);
+  w[0] = (uint32_t)groups.size(); w[1] = w[2] = w[3] = 0;
+  for (size_t i = 0; i < groups.size(); i++) {
+    uint32_t* q = w + 4 + 8 * i;
+    q[0] = groups[i].rbegin; q[1] = groups[i].psz; q[2] = groups[i].nparts; q[3] = groups[i].cover;
+    q[4] = groups[i].geom; q[5] = groups[i].psz_magic; q[6] = groups[i].pchain_off; q[7] = 0;
+  }
+  uint16_t* pc = reinterpret_cast<uint16_t*>(w + 4 + 8 * groups.size());
+  for (size_t i = 0; i < ((pchain.size() + 7) & ~(size_t)7); i++) pc[i] = i < pchain.size() ? pchain[i] : (uint16_t)0xFFFFu;
+  return NVH_OK;
+}
+
+}  // namespace
 
 int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBatch& out) {
   out.clear();
@@ -247,11 +427,19 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
     if (fault) H.flags |= NVH_SLAB_FLOOR_FAULT;
     // ---- residue: chains of vector writes, chain-major ----
     const int npass = (int)(fr.pass_end - fr.pass_begin);
-    if (npass > 1) return NVH_ERR_UNSUPPORTED;
     int rtype = 0, rch = 1;
     unsigned rbegin_al = 0;
     H.off_heads = (uint16_t)(out.data.size() - base);
+    bool general = npass > 1;
     if (npass == 1) {
+      const size_t ri = (size_t)P.passes[fr.pass_begin].residue;
+      general = ri < X.residue_general.size() && X.residue_general[ri] != 0 && !(ri < X.residue_b1.size() && X.residue_b1[ri]) &&
+                !(ri < X.residue_pair.size() && X.residue_pair[ri]);
+    }
+    if (general) {
+      const int rcg = residue_general(S, X, P, fr, nch, base, out.data, H, head_scratch);
+      if (rcg != NVH_OK) return rcg;
+    } else if (npass == 1) {
       const NvhResPass& gp = P.passes[fr.pass_begin];
       const Residue& R = S.residues[(size_t)gp.residue];
       rtype = R.type;
@@ -325,10 +513,10 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
     } else {
       H.off_rec = (uint16_t)(out.data.size() - base);
     }
-    H.rgeom = (uint8_t)(rtype | (rch << 4));
+    if (!general) H.rgeom = (uint8_t)(rtype | (rch << 4));
     // ---- entries of the frame, padded with "no vector" to a whole 16-byte unit ----
-    H.off_ent = (uint16_t)(out.data.size() - base);
-    {
+    if (!general) {
+      H.off_ent = (uint16_t)(out.data.size() - base);
       const uint32_t ne = fr.ent_count, padded = (ne + 7) & ~7u;
       const size_t e0 = out.data.size();
       out.data.resize(e0 + padded / 8);
@@ -337,7 +525,7 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
       for (uint32_t i = ne; i < padded; i++) dst[i] = (uint16_t)NVH_ENTRY_SKIP;
     }
     // ---- bin-by-bin walk (quirk B-1): the residue's geometry and which chain belongs to which partition ----
-    if (npass == 1 && H.group == 0) {
+    if (!general && npass == 1 && H.group == 0) {
       const NvhResPass& gp = P.passes[fr.pass_begin];
       const Residue& R = S.residues[(size_t)gp.residue];
       const int bs = fr.n * R.real_channels;                       // Residue2.cs:16-21
@@ -368,7 +556,7 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
     H.vecs = (uint16_t)vecs;
     // ---- inverse coupling: in the chain walk when one lane holds both channels of a bin, else passes, last step first ----
     const int csteps = (int)mp.coupling_angle.size();
-    if (nch == 2 && csteps == 1 && npass == 1 && rtype == 2 && rch == 2) {
+    if (nch == 2 && csteps == 1 && npass == 1 && rtype == 2 && rch == 2 && !general) {
       if ((fr.exec_mask & 3u) != 0) {
         if (mp.coupling_magnitude[0] == 1) H.flags |= NVH_SLAB_MG1;
         H.flags |= NVH_SLAB_SWEEP_COUPLES;
@@ -389,7 +577,7 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
       }
     }
     if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) && !any_floor0 &&
-        (npass == 0 || (H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
+        (npass == 0 || (!general && H.group == 8 && (rbegin_al & ((rtype == 2 && rch == 2) ? 7u : 3u)) == 0)))
       H.flags |= NVH_SLAB_FUSE_FLOOR;
     // ---- paired emission (nvh_format.h: NVH_EMIT_*): what k_synth needs to know about the overlaps ----
     if (nch <= 2 && (fr.emit_flags & NVH_EMIT_CARRY_OUT)) {

@@ -24,6 +24,11 @@ static_assert(sizeof(SlabVec) == 16, "slabs are addressed in 16-byte units");
 struct SlabSetup {
   std::vector<NvhDevBook> books;
   std::vector<uint8_t> residue_b1;  // per residue: quirk B-1 aliasing only (residue_alias_b1): its frames are walked bin by bin
+  // per residue: neither on the pair path nor a B-1 residue, but inside the general bin walk's contract (residue_general_ok):
+  // Residue0, books of odd dimension, Residue2 over one or two channels with aliasing partitions.  Frames of such a residue,
+  // and frames with more than one residue pass (several submaps), carry a group list (nvh_format.h: NvhSlabHdr::group == 1).
+  std::vector<uint8_t> residue_general;
+  std::vector<uint8_t> residue_pair;  // per residue: on the pair path (NvhDevResidue::pair_path)
   // Floor0: where the Bark map of floor i for block0 / block1 lies in the device's int pool (nvh_setup.hip lays the maps out in
   // floor order, block0 then block1), 0xFFFFFFFF for a Floor1
   std::vector<uint32_t> floor0_bark_off[2];
@@ -40,6 +45,17 @@ bool floor0_section_values(const Floor0& f, int slot, int half, float amp, const
 // truncates and chPtr restarts at 0, Residue2.cs:25-27, so neighbouring partitions share a bin), every book a lattice book of
 // even dimension that divides the partition, at least two bins per partition (a bin then belongs to at most two partitions).
 bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r);
+
+// The general bin walk (kernels_synth.hip: residue_walk_general) takes a residue when every book it uses is a lattice book whose
+// dimension divides the partition size (no vector overrun; Residue0: partition_size / dimensions whole steps), partitions of 2
+// ... 4096 components, and -- Residue2 over several channels with partitions off the bin grid (quirk B-1) -- at least two bins
+// per partition.  The 16-bit reciprocals the walk divides with are checked over every index it can see.
+bool residue_general_ok(const Setup& S, const SlabSetup& X, const Residue& r);
+// The pair path (kernels_synth.hip: residue_walk): Residue1 / Residue2 without aliasing partitions, an even partition size,
+// every book a lattice book of even dimension that divides it.
+bool residue_pair_ok(const Setup& S, const SlabSetup& X, const Residue& r);
+// Fills X.residue_pair / residue_b1 / residue_general (X.books must be there).  no_pair: the NVH_NO_PAIR A/B switch.
+void classify_residues(const Setup& S, SlabSetup& X, bool no_pair);
 
 struct SlabBatch {
   std::vector<SlabVec> data;      // the slabs back to back (frame order), each a whole number of 16-byte units

@@ -336,6 +336,106 @@ __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned of
   }
 }
 
+// The general bin walk (NvhSlabHdr::group == 1): everything the two walks above leave out -- Residue0 (entry j of a partition adds
+// component d at offset j + d steps, Residue0.cs:180-201), books of odd dimension, Residue2 over one or two channels with
+// partitions off the bin grid, several residue passes per frame (one per submap, each over every channel: Mapping.cs:122-134).
+// The slab carries a group list (host_slab.cpp: residue_general): per (pass, channel) of a per-channel residue, or per pass of
+// a Residue2, the residue's geometry and pchain[p] = the chain of partition p.  A lane owns one bin of one group and adds the
+// vectors that land there in the reference's order (stage by stage, the lower partition first where two share a bin); a
+// later pass continues from the sums the earlier one stored, behind a barrier.
+template <int NT, int MAXC>
+__device__ __forceinline__ void residue_walk_general(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
+                                                     unsigned off_gen, const uint32_t* __restrict__ s_lat, float* spec, int half,
+                                                     int tid) {
+  const uint32_t* heads = reinterpret_cast<const uint32_t*>(slab + off_heads * 4);
+  const uint2* recs = reinterpret_cast<const uint2*>(slab + off_rec * 4);
+  const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
+  const uint32_t* prm = reinterpret_cast<const uint32_t*>(slab + off_gen * 4);
+  const unsigned ngroups = __builtin_amdgcn_readfirstlane(prm[0]);
+  const uint16_t* pchain_all = reinterpret_cast<const uint16_t*>(prm + 4 + 8 * ngroups);
+  unsigned cur_pass = 0;
+  for (unsigned gi = 0; gi < ngroups; ++gi) {
+    const uint32_t* G = prm + 4 + 8 * gi;
+    const unsigned rbegin = __builtin_amdgcn_readfirstlane(G[0]), psz = __builtin_amdgcn_readfirstlane(G[1]);
+    const unsigned nparts = __builtin_amdgcn_readfirstlane(G[2]), cover = __builtin_amdgcn_readfirstlane(G[3]);
+    const unsigned geom = __builtin_amdgcn_readfirstlane(G[4]), psz_magic = __builtin_amdgcn_readfirstlane(G[5]);
+    const uint16_t* pchain = pchain_all + __builtin_amdgcn_readfirstlane(G[6]);
+    const unsigned rtype = geom & 15u, rch = (geom >> 4) & 15u, pass = (geom >> 8) & 15u, chan0 = (geom >> 12) & 15u;
+    if (pass != cur_pass) {  // (uniform) the sums of the pass before are in the spectra
+      __syncthreads();
+      cur_pass = pass;
+    }
+    if (nparts == 0) continue;
+    const unsigned rch_magic = rch > 1 ? (unsigned)((0x100000000ull + rch - 1) / rch) : 0u;
+    auto base_of = [&](unsigned p) { const unsigned o = rbegin + p * psz; return rch > 1 ? __umulhi(o, rch_magic) : o; };
+    const unsigned xfirst = base_of(0), xend = base_of(nparts - 1) + cover;
+    for (unsigned X = xfirst + (unsigned)tid; X < xend; X += NT) {
+      unsigned phi = __umulhi((X + 1) * rch - 1 - rbegin, psz_magic);  // the largest p whose first bin is at or before X
+      if (phi >= nparts) phi = nparts - 1;
+      unsigned cb = pchain[phi], ca = 0xFFFFu;
+      if (X >= base_of(phi) + cover) cb = 0xFFFFu;
+      if (phi >= 1 && X < base_of(phi - 1) + cover) ca = pchain[phi - 1];
+      unsigned oa = 0, ob = 0, xa = 0, xbb = 0;
+      uint2 ra = make_uint2(0u, 0u), rb = ra;
+      bool va = ca != 0xFFFFu, vb = cb != 0xFFFFu;
+      if (va) { const unsigned hd = heads[ca]; oa = hd & 0xFFFFu; xa = hd >> 16; ra = recs[oa]; }
+      if (vb) { const unsigned hd = heads[cb]; ob = hd & 0xFFFFu; xbb = hd >> 16; rb = recs[ob]; }
+      if (!va && !vb) continue;  // nothing lands here: the bin keeps what it holds
+      float a[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        a[c] = 0.0f;
+        if (pass != 0 && (unsigned)c < rch && X < (unsigned)half) a[c] = spec[(chan0 + (unsigned)c) * (unsigned)half + X];
+      }
+      while (va || vb) {
+        const bool take_a = va && (!vb || ((ra.y >> 28) & 7u) <= ((rb.y >> 28) & 7u));
+        const uint2 rec = take_a ? ra : rb;
+        const unsigned q0 = (X - (take_a ? xa : xbb)) * rch;
+        const unsigned dims = (rec.y >> 20) & 31u, lv = (rec.y >> 12) & 0xFFu, dm16 = rec.x >> 16;
+        const uint32_t* lat = s_lat + (rec.y & 0xFFFu);
+        const uint16_t* eb = ent + (rec.x & 0xFFFFu);
+        const unsigned lvm = dims > 1 ? lat[lv + 1] : 0u;  // (a book of dimension 1 has no second power: the entry is the digit)
+        // partition_size / dims (host_slab.cpp checked the reciprocal; dimension 1: the record's 16-bit field cannot hold 2^16)
+        const unsigned steps = dims > 1 ? (psz * dm16) >> 16 : psz;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          if ((unsigned)c < rch) {  // uniform
+            const unsigned q = q0 + (unsigned)c;
+            const bool in = q < psz;
+            const unsigned qq = in ? q : 0u;
+            unsigned j, comp;
+            if (rtype == 0) {  // component comp of entry j lies at j + comp * steps
+              comp = __umulhi(qq * dims, psz_magic);
+              j = qq - comp * steps;
+            } else {
+              j = dims > 1 ? (qq * dm16) >> 16 : qq;
+              comp = qq - j * dims;
+            }
+            const unsigned e = eb[j];
+            const unsigned pw = lat[lv + comp];
+            const unsigned qv = comp ? __umulhi(e, pw) : e;
+            const unsigned dgt = qv - __umul24(__umulhi(qv, lvm), lv);
+            const float v = __uint_as_float(lat[dgt]);
+            a[c] = a[c] + ((in && e != NVH_ENTRY_SKIP) ? v : 0.0f);
+          }
+        }
+        if (take_a) {
+          va = (ra.y & 0x80000000u) != 0;
+          if (va) ra = recs[++oa];
+        } else {
+          vb = (rb.y & 0x80000000u) != 0;
+          if (vb) rb = recs[++ob];
+        }
+      }
+      if (X < (unsigned)half) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if ((unsigned)c < rch) spec[(chan0 + (unsigned)c) * (unsigned)half + X] = a[c];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // NVH_EMIT_CARRY_OUT: the block that becomes the carried tail of the next batch (StreamDecoder's _prevPacketBuf), stored fully
@@ -664,7 +764,7 @@ __device__ __forceinline__ void synth_carry_out8(const NvhSynthArgs& A, const fl
 // MODE (k_synth only): 0 = synthesis alone, 1 = + the carried tail written by the last decoded block's workgroup, 2 = + paired
 // emission.  Three instantiations, so that the launches that never emit keep the registers of the kernel that cannot (62 instead
 // of 64 VGPRs at the 64-VGPR cap: 24.4 against 25.1 us for 4096 frames).
-template <int NT, int MAXCH, int MODE = 0>
+template <int NT, int MAXCH, int MODE = 0, bool GENERAL = false>
 __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   // Which frame this workgroup takes.  Workgroups go round the eight XCDs by index (workgroup b runs on XCD b % 8, each XCD
@@ -755,7 +855,9 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     const unsigned rtype = rgeom & 0xFu, rch = rgeom >> 4;
     const bool interleaved = !(rtype == 1 || rch == 1);  // Residue2 over several channels: component k = bin k / rch of channel k % rch
 #define NVH_WALK(G, FUSE, RCH, FP) residue_walk<G, FUSE, RCH, NT>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP)
-    if (MAXCH <= 2 && (flags & NVH_SLAB_FUSE_FLOOR)) {
+    if (GENERAL && group == 1) {
+      residue_walk_general<NT, MAXCH>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid);
+    } else if (MAXCH <= 2 && (flags & NVH_SLAB_FUSE_FLOOR)) {
       FloorRef F;
       const unsigned c0w = __builtin_amdgcn_readfirstlane(s_chan[0]), c1w = __builtin_amdgcn_readfirstlane(s_chan[1]);
       floor_of(c0w, F.seg[0], F.tab[0]);
@@ -979,11 +1081,25 @@ k_synth_emit(NvhSynthArgs A NVH_DBG_PARAMS) {
   synth_body<SP_THREADS, 2, 2>(A, smem NVH_DBG_ARGS);
 }
 
+// mono / stereo streams some of whose frames need the general bin walk (never with paired emission)
+extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_synth_g(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_body<SP_THREADS, 2, 0, true>(A, smem NVH_DBG_ARGS);
+}
+
 // up to eight channels, blocks up to 4096: 8 wavefronts per workgroup, the CU's LDS decides how many are resident
 extern "C" __global__ void __launch_bounds__(512)
 k_synth8(NvhSynthArgs A NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   synth_body<512, NVH_SLAB_MAX_CH>(A, smem NVH_DBG_ARGS);
+}
+
+// ... + the general bin walk
+extern "C" __global__ void __launch_bounds__(512)
+k_synth8_g(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_body<512, NVH_SLAB_MAX_CH, 0, true>(A, smem NVH_DBG_ARGS);
 }
 
 // the even frames of a wide batch with paired emission: + the overlap-add of the steady-state overlaps (synth_emit8)

@@ -195,7 +195,7 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
                 at += (uint32_t)sh->setup.floors[i].f0.bark_map[w].size();
               }
         }
-        for (const nvh::Residue& r : sh->setup.residues) sh->slab.residue_b1.push_back(nvh::residue_alias_b1(sh->setup, sh->slab, r) ? 1 : 0);
+        nvh::classify_residues(sh->setup, sh->slab, nvh_toggles().no_pair || lattice.size() > 0xFFFFu);
       }
       *out = s.release();
       return NVH_OK;

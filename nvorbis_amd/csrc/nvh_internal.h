@@ -70,9 +70,11 @@ __global__ void k_run6_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArg
 __global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
 #endif
 __global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
+__global__ void k_synth_g(NvhSynthArgs A NVH_DBG_PARAMS);     // + the general bin walk (Residue0, odd dimensions, several passes)
 __global__ void k_synth_tail(NvhSynthArgs A NVH_DBG_PARAMS);  // + the carried tail written in place (kernels_synth.hip: MODE 1)
 __global__ void k_synth_emit(NvhSynthArgs A NVH_DBG_PARAMS);  // + paired emission (MODE 2)
 __global__ void k_synth8(NvhSynthArgs A NVH_DBG_PARAMS);
+__global__ void k_synth8_g(NvhSynthArgs A NVH_DBG_PARAMS);    // + the general bin walk
 __global__ void k_synth8_emit(NvhSynthArgs A NVH_DBG_PARAMS);  // wide frames + paired emission through LDS (synth_emit8)
 __global__ void k_window_apply(float* buf, const float* window, int n, long long stride, int batch);
 __global__ void k_overlap_buffers(const float* previous, float* next, int prev_start, int len, int next_start, int channels,
@@ -238,6 +240,7 @@ struct SharedSetup {
   int synth_const_vecs = 0;
   int max_posts = 0;            // largest Floor1 post count of the setup (bounds a slab's segment lists)
   nvh::SlabSetup slab;          // host copy of the codebook directory: what host_slab.cpp needs to write pair records
+  bool slab_general = false;    // ... and some of its frames need the general bin walk (k_synth_g / k_synth8, no paired emission)
   bool slab_setup_ok = false;   // the setup is inside the slab synthesis kernels' contract (nvh_launch.hip: slab_path)
   bool has_sequential = false;  // some residue replays the reference's partition order (quirk B-1 / vector overrun)
   // GPU packet parser (kernels_parse.hip): its tables, and whether this stream shape is inside its limits

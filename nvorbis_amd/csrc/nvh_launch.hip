@@ -310,11 +310,12 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
     const int ch = s->setup.channels;
     // mono / stereo with blocks up to 2048 (k_synth_emit: from registers and LDS-staged quarters), or the wide kernel's shapes --
     // up to eight channels, blocks up to 4096 (k_synth8_emit: through the planes and LDS rows)
-    const bool narrow = ch <= 2 && s->setup.block1 <= 2048;
+    // (streams whose frames need the general bin walk run k_synth_g / k_synth8 without paired emission)
+    const bool narrow = ch <= 2 && s->setup.block1 <= 2048 && !s->shared->slab_general;
     // (the wide form is opt-in, NVH_EMIT8=1: bit-exact, but on C4 -- six channels, n = 4096 -- the pair of launches measured 123.5 us
     // per 2048 frames against 116.5 us for k_synth8 + k_ola_compact on one stream, 113.5 against 111.3 us over three: with two
     // workgroups per CU the overlap-add's memory phases run in lockstep bursts instead of hiding behind other workgroups' arithmetic)
-    const bool wide_emit = !narrow && ch <= NVH_SLAB_MAX_CH && s->setup.block1 <= 4096 && nvh_toggles().emit8;
+    const bool wide_emit = !narrow && !s->shared->slab_general && ch <= NVH_SLAB_MAX_CH && s->setup.block1 <= 4096 && nvh_toggles().emit8;
     const bool can = !nvh_toggles().no_emit && (narrow || wide_emit) && !P.sequential_ola && s->setup.block0 >= 256;
     const unsigned all_ch = (1u << ch) - 1u;
     // GPU-parse mode: the execute flags are decided inside k_parse (Mapping.cs:104-131); the host marks the candidates from the
@@ -555,7 +556,7 @@ static size_t slab_lds_bytes(const nvh_batch* b) {
 static bool slab_shape_ok(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   const NvhToggles& T = nvh_toggles();
-  if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->descriptors_only || b->max_pass > 1) return false;
+  if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->descriptors_only || (b->max_pass > 1 && !s->shared->slab_general)) return false;
   if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact || T.fused_ola || T.run || T.multi) return false;
   if (slab_wide(s) && T.no_gen8) return false;  // NVH_NO_GEN8 keeps its meaning: more than four channels through k_spectrum_gen
   return true;
@@ -707,7 +708,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     const bool wide = slab_wide(s);
     // paired emission (nvh_format.h: NVH_EMIT_*): the host marked the frames at upload; it needs the PCM buffer and the slabs
     // in frame order
-    emitted = b->emit_frames > 0 && d_pcm != nullptr && !b->block_only && !T.no_emit;
+    emitted = b->emit_frames > 0 && d_pcm != nullptr && !b->block_only && !T.no_emit && !s->shared->slab_general;
     A.pcm = emitted ? d_pcm : nullptr;
     A.windows = s->dev.windows;
     A.clip = s->clip;
@@ -719,11 +720,14 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     if (synth_lds > 64 * 1024 && !s->ctx->synth_lds_attr_set) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_synth8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_synth8_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_synth8_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       s->ctx->synth_lds_attr_set = true;
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], st));  // slot 0 stays empty: slot 1 = the synthesis kernel
     b->slot_name[0] = "-";
-    b->slot_name[1] = wide ? "k_synth8" : "k_synth";
+    const bool narrow_general = !wide && s->shared->slab_general;  // (never with paired emission: batch_upload)
+    const bool wide_general = wide && s->shared->slab_general;
+    b->slot_name[1] = wide ? (wide_general ? "k_synth8_g" : "k_synth8") : (narrow_general ? "k_synth_g" : "k_synth");
     if (wide && emitted) {
       // odd frames first, then the even frames, which overlap-add the steady-state overlaps they take part in (synth_emit8)
       A.fstep = 2;
@@ -731,7 +735,9 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       if (b->nframes > 1) hipLaunchKernelGGL(k_synth8, dim3((unsigned)(b->nframes / 2)), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
       A.f0 = 0;
       hipLaunchKernelGGL(k_synth8_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
-    } else if (wide) hipLaunchKernelGGL(k_synth8, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
+    } else if (wide_general) hipLaunchKernelGGL(k_synth8_g, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
+    else if (wide) hipLaunchKernelGGL(k_synth8, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
+    else if (narrow_general) hipLaunchKernelGGL(k_synth_g, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     else if (!emitted) hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     else {
       // odd frames first (their planes are what the even frames overlap-add with), then the even frames, which emit

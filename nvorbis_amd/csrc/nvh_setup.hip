@@ -31,6 +31,7 @@ int upload_setup(nvh_stream* s) {
   std::vector<float> vq;
   std::vector<uint32_t> lattice;
   nvh::build_book_directory(S, s->shared->slab, vq, lattice);
+  nvh::classify_residues(S, s->shared->slab, nvh_toggles().no_pair || lattice.size() > 0xFFFFu);
   const std::vector<NvhDevBook>& books = s->shared->slab.books;
 
   std::vector<int32_t> ipool;
@@ -126,14 +127,11 @@ int upload_setup(nvh_stream* s) {
           if (r.books[c][k] >= 0 && (uint64_t)S.books[(size_t)r.books[c][k]].dimensions > max_div)
             max_div = (uint64_t)S.books[(size_t)r.books[c][k]].dimensions;
       d.fast = (r.type != 0 && r.partition_size > 1 && max_index * max_div < 0x100000000ull) ? 1 : 0;
-      // pair records pack LDS offsets / bin indices into 16 bits and use a 16-bit reciprocal of the book dimension
-      bool pairs = d.fast != 0 && !seq && (r.partition_size % 2) == 0 && r.partition_size <= 4096 && lattice.size() <= 0xFFFFu;
-      for (int c = 0; c < r.classifications; c++)
-        for (int k = 0; k < NVH_MAX_STAGES; k++)
-          if (r.books[c][k] >= 0 && (books[(size_t)r.books[c][k]].lat_values == 0 || (books[(size_t)r.books[c][k]].dim & 1u))) pairs = false;
-      if (nvh_toggles().no_pair) pairs = false;  // A/B aid
-      d.pair_path = pairs ? 1 : 0;
-      d.alias_b1 = (seq && d.fast != 0 && !nvh_toggles().no_pair && lattice.size() <= 0xFFFFu && nvh::residue_alias_b1(S, s->shared->slab, r)) ? 1 : 0;
+      // the pair path and the B-1 bin walk (host_slab.cpp: residue_pair_ok, residue_alias_b1; pair records pack LDS offsets /
+      // bin indices into 16 bits and use a 16-bit reciprocal of the book dimension)
+      d.pair_path = (!nvh_toggles().no_pair && lattice.size() <= 0xFFFFu && nvh::residue_pair_ok(S, s->shared->slab, r)) ? 1 : 0;
+      d.alias_b1 = (seq && d.fast != 0 && s->shared->slab.residue_b1[i]) ? 1 : 0;
+      s->shared->slab.residue_b1[i] = (uint8_t)d.alias_b1;
       d.hp_magic = r.partition_size / 2 > 1 ? (uint32_t)((0x100000000ull + (uint64_t)(r.partition_size / 2) - 1) / (uint64_t)(r.partition_size / 2)) : 0u;
       d.pad[0] = d.pad[1] = 0;
     }
@@ -217,15 +215,23 @@ int upload_setup(nvh_stream* s) {
     for (const NvhDevResidue& r : residues) all_pairs = all_pairs && r.pair_path != 0;
     s->fast_spectrum = ok && all_pairs;
     // slab synthesis kernels (kernels_synth.hip; nvh_launch.hip: slab_path)
-    bool slab_res = true;  // every residue either on the pair path or aliasing in the B-1 way only
-    for (const NvhDevResidue& r : residues) slab_res = slab_res && (r.pair_path != 0 || r.alias_b1 != 0);
+    // every residue on the pair path, aliasing in the B-1 way only, or inside the general bin walk's contract; a stream that
+    // needs the general walk anywhere (or has several submaps: more than one residue pass per frame) runs the wide kernel
+    bool slab_res = true, general = false;
+    const nvh::SlabSetup& X = s->shared->slab;
+    for (size_t i = 0; i < residues.size(); i++) {
+      slab_res = slab_res && (X.residue_pair[i] != 0 || X.residue_b1[i] != 0 || X.residue_general[i] != 0);
+      general = general || (X.residue_pair[i] == 0 && X.residue_b1[i] == 0);
+    }
+    for (const nvh::Mapping& m : S.mappings)
+      if (m.submap_floor.size() > 1) {
+        general = true;
+        for (int ri : m.submap_residue) slab_res = slab_res && ri >= 0 && (size_t)ri < residues.size() && X.residue_general[(size_t)ri] != 0;
+      }
+    s->shared->slab_general = general;
     bool slab_ok = slab_floor0_ok && slab_res && S.channels <= NVH_SLAB_MAX_CH && S.block0 >= 256 && S.block1 <= 8192 &&
                    s->shared->synth_consts != nullptr;
     for (const nvh::Mapping& m : S.mappings) slab_ok = slab_ok && m.coupling_angle.size() <= (size_t)NVH_SLAB_MAX_COUPLE;
-    for (const NvhDevResidue& r : residues)
-      if (r.type == 2 && r.real_channels > 2 && !r.alias_b1) slab_ok = slab_ok && (r.partition_size % (2 * r.real_channels)) == 0;
-    s->shared->slab.residue_b1.assign(residues.size(), 0);
-    for (size_t i = 0; i < residues.size(); i++) s->shared->slab.residue_b1[i] = residues[i].alias_b1 ? 1 : 0;
     slab_ok = slab_ok && lattice.size() <= (size_t)NVH_SLAB_MAX_LAT_OFF;  // a record addresses the lattice pool with 12 bits
     s->shared->slab_setup_ok = slab_ok;
   }
@@ -486,7 +492,7 @@ int upload_parse_tables(nvh_stream* s) {
   P.max_posts = sh.max_posts;
   P.slab_stride_vecs = 0;
   {
-    bool ok = sh.slab_setup_ok && cap_pass <= 1 && S.channels <= NVH_SLAB_MAX_CH;
+    bool ok = sh.slab_setup_ok && !sh.slab_general && cap_pass <= 1 && S.channels <= NVH_SLAB_MAX_CH;
     for (const NvhDevBook& db : sh.slab.books) ok = ok && db.lat_off <= NVH_SLAB_MAX_LAT_OFF && db.lat_values <= 0xFFu;
     const size_t Pn = (size_t)sh.max_posts + 2;
     size_t v = NVH_SLAB_HDR_VECS + (size_t)S.channels * (Pn + ((size_t)S.block1 / 8 + 15) / 16) + ((size_t)cap_ops + 3) / 4 + ((size_t)cap_ops + 1) / 2 +

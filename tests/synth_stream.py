@@ -409,6 +409,34 @@ def config(name):
                  mappings=[lambda w: write_mapping(w, 1, 1, [], None, [(0, 0)]),
                            lambda w: write_mapping(w, 1, 1, [], None, [(1, 1)])],
                  modes=[(0, 0), (1, 1)])
+    elif name in ("res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"):
+        # the slab kernels' general bin walk (kernels_synth.hip: residue_walk_general): Residue0; lattice books of dimension
+        # 1 / 3 / 5; Residue2 over two channels whose partitions (15 components) share bins (quirk B-1); two residue passes
+        # per frame (two submaps with the same floor and residue, so that quirk B-3 leaves the channels their energy)
+        c["books"] = books + [
+            Book(6, dims=3, lookup=1, min_me=(-4, -3), delta_me=(1, -2), value_bits=3, mults=[0, 1, 3, 5]),   # 11
+            Book(5, dims=5, lookup=1, min_me=(-2, -3), delta_me=(3, -3), value_bits=2, mults=[0, 3]),         # 12
+        ]
+        if name in ("res0_slab", "res0_3ch"):  # (res0_3ch: the same through the wide kernel, k_synth8_g)
+            res = [lambda w: write_residue(w, 0, 0, 120, 24, 2, [1, 2, 7, 0], [3, 11, 4, 5, 8]),
+                   lambda w: write_residue(w, 0, 8, 992, 24, 2, [3, 1, 4, 6], [3, 4, 5, 5, 11, 8])]
+        elif name == "odd_dims_slab":
+            res = [lambda w: write_residue(w, 1, 0, 120, 15, 2, [1, 2, 7, 0], [8, 11, 12, 11, 8]),
+                   lambda w: write_residue(w, 1, 5, 995, 30, 2, [3, 1, 4, 6], [11, 12, 8, 3, 12, 11])]
+        elif name == "res2_alias_stereo":
+            res = [lambda w: write_residue(w, 2, 3, 243, 15, 2, [1, 2, 7, 0], [8, 11, 12, 11, 8]),
+                   lambda w: write_residue(w, 2, 9, 1989, 30, 2, [3, 1, 4, 6], [11, 12, 8, 3, 12, 11])]
+        else:
+            res = [lambda w: write_residue(w, 1, 0, 128, 16, 2, [1, 2, 7, 0], [3, 4, 3, 4, 5]),
+                   lambda w: write_residue(w, 2, 0, 1800, 32, 2, [3, 1, 4, 6], [3, 4, 5, 5, 4, 3])]
+        two = name == "two_pass_slab"
+        nch = 3 if name == "res0_3ch" else 2
+        c.update(channels=nch, block0=256, block1=2048,
+                 floors=[_floor1_small(0, 1), _floor1_long(0, 1, 10)],
+                 residues=res,
+                 mappings=[lambda w: write_mapping(w, nch, 2 if two else 1, [(0, 1)], [0, 1] if two else None, [(0, 0)] * (2 if two else 1)),
+                           lambda w: write_mapping(w, nch, 2 if two else 1, [(nch - 1, 0)], [1, 0] if two else None, [(1, 1)] * (2 if two else 1))],
+                 modes=[(0, 0), (1, 1)])
     elif name in ("ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"):   # the channel counts no other config has
         nch, rtype = int(name[2]), int(name[-1])
         couple = [(0, 1), (2, 3)] if nch == 4 else [(0, 2), (3, 4)] if nch == 5 else [(0, 1), (2, 3), (5, 6)] if nch == 7 else [(0, 7), (1, 6), (2, 5)]
@@ -426,7 +454,8 @@ def config(name):
 
 
 CONFIG_NAMES = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
-                "floor0_stereo", "floor0_slab", "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2", "mono_res1_2048"]
+                "floor0_stereo", "floor0_slab", "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2", "mono_res1_2048",
+                "res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"]
 
 
 def filtered_stream(oracle, name, npackets, seed, consistent_windows=True):

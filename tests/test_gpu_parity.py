@@ -265,6 +265,38 @@ def test_synthetic_configs_bit_exact(oracle, gpu_ctx, name, consistent):
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, clip, bf, float(np.abs(got - ref).max()))
 
 
+@pytest.mark.parametrize("name", ["res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"])
+@pytest.mark.parametrize("consistent", [True, False])
+def test_general_bin_walk_bit_exact(oracle, gpu_ctx, name, consistent):
+    """The slab kernels' general bin walk (kernels_synth.hip: residue_walk_general; host_slab.cpp: residue_general): Residue0,
+    lattice books of dimension 1 / 3 / 5, Residue2 over two channels whose 15-component partitions share bins (quirk B-1), two
+    residue passes per frame (Mapping.cs:122-134 calls every submap's residue over every channel).  Bit-exact against the
+    oracle, and -- on the default path -- synthesised by k_synth_g / k_synth8_g (k_synth / k_synth8 + the general walk) rather than the descriptor kernels."""
+    import os
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    pk, gr, fl = ss.filtered_stream(oracle, name, 150, 31 + int(consistent), consistent_windows=consistent)
+    for clip in (True, False):
+        ref, info = oracle.decode_packets(pk, gr, fl, clip=clip)
+        for bf in (1024, 13):
+            got = _decode_gpu(nv, gpu_ctx, pk, gr, fl, clip, bf)
+            assert got.size == ref.size, (name, clip, bf)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, clip, bf, float(np.abs(got - ref).max()))
+    toggles = ("NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_NO_SLAB", "NVH_GPU_PARSE")
+    if consistent and not any(os.environ.get(t) for t in toggles):
+        torch = _torch()
+        st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+        for p in pk[3:40]:
+            st.push_packet(p, -1, 0)
+        b = st.upload_batch()
+        pcm = torch.empty(max(b.samples * st.channels, 1), dtype=torch.float32, device="cuda")
+        b.synth(pcm.data_ptr(), pcm.numel())
+        names = [k for k in b.kernels() if k != "-"]
+        b.free(); st.close()
+        kn = "k_synth8_g" if name == "res0_3ch" else "k_synth_g"
+        assert names and names[0] == kn and all(k in (kn, "k_ola_compact") for k in names), names
+
+
 @pytest.mark.parametrize("name", ["ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"])
 def test_channel_counts_4_5_7_8_bit_exact(oracle, gpu_ctx, name):
     """Every channel count has its own instantiation of the overlap-add kernels (ola_vec / ola_sym_lds<CH>) and of the

@@ -230,3 +230,56 @@ def test_slab_residue_records_structure(ogg_bytes):
         assert seen > 500
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("name", ["res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"])
+def test_slab_general_group_list(oracle, name):
+    """Frames outside the pair walk (Residue0, books of odd dimension, Residue2 over two channels with aliasing partitions, two
+    residue passes) carry a group list (NvhSlabHdr::group == 1): per (pass, channel) -- per pass for a Residue2 -- the residue's
+    geometry and the chain of every partition.  Checked here: the list tiles the slab's tail, every chain of the frame is some
+    group's partition chain exactly once, a chain's head offset is the partition's first bin, partitions of one group share a
+    bin only where the geometry says so (quirk B-1), passes are numbered in order."""
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    pk, gr, fl = ss.filtered_stream(oracle, name, 60, 5)
+    s = nv.Stream(None, pk[0], pk[1], pk[2])
+    try:
+        general = chains = 0
+        for i in range(3, len(pk)):
+            s.drop_pending()
+            s.push_packet(pk[i], -1, 0)
+            if s.pending()[0] != 1 or int(s.pending_geometry()[-1][0]) == 0:
+                continue
+            words, _ = s.pending_slabs()
+            h = parse_slab(words)
+            if h["nrec"] == 0:
+                continue
+            assert h["group"] == 1, (name, h["group"])
+            general += 1
+            hw = words[h["off_heads"] * 4:h["off_rec"] * 4][:h["nheads"]]
+            xb = hw >> 16
+            g = words[h["lpc"] * 4:h["vecs"] * 4]
+            ng = int(g[0])
+            assert 1 <= ng <= 16 and h["lpc"] > h["off_ent"]
+            pchain = g[4 + 8 * ng:].view(np.uint16)
+            used = []
+            last_pass = 0
+            for k in range(ng):
+                rbegin, psz, nparts, cover, geom, magic, pco = (int(x) for x in g[4 + 8 * k:4 + 8 * k + 7])
+                rtype, rch, pss, ch0 = geom & 15, (geom >> 4) & 15, (geom >> 8) & 15, (geom >> 12) & 15
+                assert pss in (last_pass, last_pass + 1)
+                last_pass = pss
+                assert magic == (2 ** 32 + psz - 1) // psz and cover == (psz + rch - 1) // rch and ch0 + rch <= (3 if name == "res0_3ch" else 2)
+                assert (rtype == 2) == (name in ("res2_alias_stereo",) or (name == "two_pass_slab" and rch == 2))
+                pc = pchain[pco:pco + nparts]
+                for p, cix in enumerate(pc):
+                    if cix != 0xFFFF:
+                        assert int(xb[cix]) == (rbegin + p * psz) // rch
+                        used.append(int(cix))
+            assert sorted(used) == list(range(h["nheads"]))  # every chain belongs to exactly one (group, partition)
+            chains += h["nheads"]
+            if name == "two_pass_slab":
+                assert last_pass == 1
+        assert general > 20 and chains > 200
+    finally:
+        s.close()

@@ -64,6 +64,7 @@ for ps in (48, 32):
     pool4 = ve.packet_pool(S4, 100 + ps, per_kind=128, class_weights=[0] + [1] * 9)
     p, g = ve.stream_from_pool(S4, h4, pool4, np.ones(2100, dtype=bool), rng)
     run("C4 6ch n=4096 psize %d full depth" % ps, p, target_frames=2048)
-for name in ("six_ch_res2_4096", "stereo_res1_coupled", "three_ch_res2_misaligned", "two_submaps", "mono_8192", "stereo_8192", "floor0_stereo", "floor0_slab", "mono_res0_small_blocks"):
+for name in ("six_ch_res2_4096", "stereo_res1_coupled", "three_ch_res2_misaligned", "two_submaps", "mono_8192", "stereo_8192", "floor0_stereo", "floor0_slab", "mono_res0_small_blocks",
+             "res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"):
     p, g, f = ss.filtered_stream(orc, name, 300, 3, True)
     run(name, p)
