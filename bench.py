@@ -131,7 +131,7 @@ def cpu_baseline(headers, ll, seconds=12.0):
     return out
 
 
-def end_to_end(nv, ctx, headers, ll, frames=32768, rounds=6):
+def end_to_end(nv, ctx, headers, ll, frames=32768, rounds=16):
     """The PCIe-inclusive rate of the boundary on the same workload, one host thread (never `value`): packets
     in host memory -> parse -> kernels -> PCM in page-locked host memory, `frames` packets per look-ahead batch.  Host parser with
     a blocking read-back, and GPU packet parser (kernels_parse.hip) with the pipelined read-back (two batches outstanding)."""

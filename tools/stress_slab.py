@@ -1,5 +1,6 @@
 """Stress of the slab synthesis kernels (parser-written slabs -> k_synth / k_synth8) against the CPU oracle: full-depth encoded streams
 (tests/vorbis_encode.py) on the stereo 3test setup and the six-channel C4 setup (psize 48, and psize 32: the bin walk of quirk B-1),
+plus the synthetic setups of the general bin walk (Residue0, odd dimensions, aliasing stereo Residue2, two passes) on random-bit packets;
 random lengths, block kinds from a
 Markov chain with random transition rates, random look-ahead batch sizes (1 ... 700 frames), clipping on / off, host and GPU
 packet parser, plus the four shipped files with random batch sizes; every PCM must equal the oracle's bit for bit.
@@ -9,7 +10,8 @@ os.environ["NVH_EMIT_ALWAYS"] = "1"  # ... with paired emission whenever a batch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import nvorbis_amd as nv
-from tests import oracle_py, vorbis_encode as ve
+from tests import oracle_py, synth_stream as ss, vorbis_encode as ve
+GENERAL = ["res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch", "two_submaps", "floor0_stereo"]
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 orc = oracle_py.load()
@@ -45,8 +47,12 @@ def decode_gpu(pk, gr, fl, clip, bf, gpu_parse):
 t0 = time.time()
 runs = frames = bad = 0
 while time.time() - t0 < budget:
-    which = int(rng.integers(0, 4))
-    if which == 2:
+    which = int(rng.integers(0, 5))
+    if which == 4:  # the general bin walk: random-bit packets on the synthetic setups (tests/synth_stream.py), random seeds
+        what = GENERAL[int(rng.integers(0, len(GENERAL)))]
+        pk, gr, fl = ss.filtered_stream(orc, what, int(rng.integers(20, 200)), int(rng.integers(0, 1 << 30)), bool(rng.integers(0, 2)))
+        gr, fl = list(gr), list(fl)
+    elif which == 2:
         name = list(files)[int(rng.integers(0, 4))]
         pk, gr, fl = nv.demux_ogg(files[name])
         gr, fl = gr.tolist(), fl.tolist()
@@ -60,7 +66,7 @@ while time.time() - t0 < budget:
         what = "stereo" if which == 0 else ("six_ch" if which == 1 else "six_ch_psize32")
     clip = bool(rng.integers(0, 2))
     bf = int(rng.integers(1, 700))
-    gp = bool(rng.integers(0, 2))
+    gp = bool(rng.integers(0, 2)) and what != "floor0_stereo"  # (the GPU packet parser refuses Floor0 streams)
     ref, _ = orc.decode_packets(pk, gr, fl, clip=clip)
     got = decode_gpu(pk, gr, fl, clip, bf, gp)
     ok = got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
