@@ -36,16 +36,23 @@ struct BitR {
   uint32_t total, pos;
   uint64_t buf;
   uint32_t avail;
+  uint32_t ahead;      // word `next` of the packet, fetched when word next - 1 went into the buffer: a refill never waits for memory
   bool is_short;
 };
 
 template <bool LDS>
+__device__ __forceinline__ uint32_t br_word(const BitR& b, const uint32_t* __restrict__ s_pkt, uint32_t i) {
+  if (i >= b.nwords) return 0u;
+  if (LDS) return s_pkt[b.lds_word + (int)i];  // compile-time choice: never a generic pointer
+  return b.w[i];
+}
+
+template <bool LDS>
 __device__ __forceinline__ void br_fill(BitR& b, const uint32_t* __restrict__ s_pkt) {
   while (b.avail <= 32 && b.next < b.nwords) {
-    uint32_t word;
-    if (LDS) word = s_pkt[b.lds_word + (int)b.next];  // compile-time choice: never a generic pointer
-    else word = b.w[b.next];
+    const uint32_t word = b.ahead;
     b.next++;
+    b.ahead = br_word<LDS>(b, s_pkt, b.next);
     b.buf |= (uint64_t)word << b.avail;
     b.avail += 32;
   }
@@ -61,6 +68,7 @@ __device__ __forceinline__ void br_init(BitR& b, const uint32_t* words, int lds_
   b.pos = start < total_bits ? start : total_bits;
   b.is_short = false;
   b.next = b.pos >> 5;
+  b.ahead = br_word<LDS>(b, s_pkt, b.next);
   b.buf = 0;
   b.avail = 0;
   br_fill<LDS>(b, s_pkt);
@@ -119,6 +127,21 @@ __device__ __attribute__((noinline)) uint32_t prefix_from_global(const uint32_t*
 template <bool LDS>
 __device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const uint32_t* __restrict__ s_pkt,
                                              const NvhPBook bk, BitR& p) {
+  // The common case first: at least 32 bits left in the packet, the prefix table in LDS, the code no longer than the prefix.
+  // Then TryPeekBits returns all the bits asked for, SkipBits cannot run off the end (a code has at most 32 bits), the low
+  // word of the buffer is valid (br_fill keeps more than 32 bits there while words remain), and a symbol is one ds_read
+  // between a mask and a 64-bit shift -- the general form below spends most of its instructions on the end-of-packet rules.
+  if (p.total - p.pos >= 32u && bk.has_tree && bk.lds_off != 0xFFFFFFFFu) {
+    const uint32_t node = s_prefix[bk.lds_off + ((uint32_t)p.buf & ((1u << bk.prefix_bits) - 1u))];
+    if (node & 0x80u) {
+      const uint32_t len = node & 0x7Fu;
+      p.buf >>= len;
+      p.avail -= len;
+      p.pos += len;
+      br_fill<LDS>(p, s_pkt);
+      return (int)(node >> 8);
+    }
+  }
   int got;
   uint32_t data = br_peek(p, bk.prefix_bits, &got);
   if (got == 0) return -1;
@@ -306,6 +329,12 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   if (!SLAB && !active) return;
   const int slot = wave * lanes + (active ? lane : 0);  // packet of this workgroup
   const int f = active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0;
+#ifdef NVH_DEBUG
+#define PT_T(k) do { if (dbg && active) dbg[(long long)f * 24 + (k)] = clock64(); } while (0)
+#else
+#define PT_T(k) do { } while (0)
+#endif
+  PT_T(0);
   NvhFrame fr;
   if (active) {
     fr = frames[f];
@@ -341,6 +370,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
     }
     br_init<LDS>(p, pw, lds_word, s_pkt, ref.bit_len, ref.bit_pos);
     const NvhPMapping& map = mappings[fr.mapping];
+    PT_T(1);
 
     // ---- floors (Mapping.cs:95-111) ----
     uint32_t energy = 0;
@@ -368,6 +398,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         if (((force_e | energy) & ~force_no) & (a | m)) force_e |= a | m;
       }
     }
+    PT_T(2);
     // ---- residues (Mapping.cs:122-134; Residue0.Decode :119-178) ----
     for (int sm = 0; sm < map.submaps && !err; sm++) {
       for (int j = 0; j < nch; j++)
@@ -510,7 +541,36 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     break;
                   }
                   int done = 0;
-                  for (int i = 0; i < r.partition_size; i += dims) {
+                  // The vector's entries, fast form: while the packet has 32 bits left, the code resolves in the book's LDS prefix
+                  // table and slots remain, a symbol is a masked ds_read, a 64-bit shift and a 16-bit store in a loop with one
+                  // exit test.  (The general loop below, with the reference's end-of-packet and null-list rules inlined into a
+                  // four-deep nest of divergent loops, compiled to some hundred mostly scalar exec-mask instructions per symbol:
+                  // 145 M SALU + 127 M VALU per 4096 packets.)  Whatever this loop leaves -- the last bits of a packet, a long
+                  // code, a book whose table lies in global memory -- the general loop takes up where it stopped.
+                  if (book.has_tree && book.lds_off != 0xFFFFFFFFu) {
+                    const uint32_t pmask = (1u << book.prefix_bits) - 1u, toff = book.lds_off;
+                    uint16_t* __restrict__ eout = entries + ent_base + nent;
+                    // (one exit test: the table read is always in range, so it is not guarded)
+                    uint32_t node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                    while ((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)((node >> 7) & 1u)) {
+                      const uint32_t len = node & 0x7Fu;
+                      p.buf >>= len;
+                      p.avail -= len;
+                      p.pos += len;
+                      if (p.avail <= 32u && p.next < p.nwords) {  // (one word restores br_fill's invariant: len <= 32)
+                        const uint32_t word = p.ahead;
+                        p.next++;
+                        p.ahead = br_word<LDS>(p, s_pkt, p.next);
+                        p.buf |= (uint64_t)word << p.avail;
+                        p.avail += 32u;
+                      }
+                      eout[done] = (uint16_t)(node >> 8);
+                      ++done;
+                      node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                    }
+                    nent += (uint32_t)done;
+                  }
+                  for (int i = done * dims; i < r.partition_size; i += dims) {
                     const int e = decode_scalar<LDS>(T, s_prefix, s_pkt, book, p);
                     if (e == -2) {
                       err = kErrRuntime;
@@ -626,6 +686,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
     }
   }
 
+  PT_T(3);
   uint32_t slab_vecs = 0;
   if constexpr (SLAB) {
     // ---- behind the parse, the lanes of the wavefront side by side: the rest of the slab ----
@@ -695,6 +756,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       H.off_heads = (uint16_t)off_heads;
       H.off_ent = (uint16_t)off_ent;
     }
+    PT_T(4);
     // ---- floors, the wavefront together: the packets of its lanes one after the other, lane = post (floor_to_slab_wave) ----
     {
       // one floor scratch block per wavefront behind the per-lane areas (16-byte aligned), then one error word each
@@ -785,6 +847,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       slab_vecs = H.vecs;
     }
   }
+  PT_T(5);
   if (!active) return;
   frames[f].pass_begin = pass_base;
   frames[f].pass_end = pass_base + npass;
