@@ -315,6 +315,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   const NvhPFloor1* floors = reinterpret_cast<const NvhPFloor1*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_floors_off);
   const NvhPResidue* residues = reinterpret_cast<const NvhPResidue*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_residues_off);
   const NvhPMapping* mappings = reinterpret_cast<const NvhPMapping*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_mappings_off);
+  auto ipool_at = [&](uint32_t i) { return (int)T.ipool[i]; };
   // per-lane LDS (when the host found room): the residue walk's two scratch rows, and the packet itself -- the bit
   // reader and the class words are on every symbol's dependency chain, and a global round trip costs ~10x an LDS one
   int* s_lane = reinterpret_cast<int*>(s_meta + T.meta_words);          // [packets per workgroup][scratch_words]
@@ -331,8 +332,13 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   const int f = active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0;
 #ifdef NVH_DEBUG
 #define PT_T(k) do { if (dbg && active) dbg[(long long)f * 24 + (k)] = clock64(); } while (0)
+#define PT_ACC_BEGIN() const long long pt_t0 = clock64()
+#define PT_ACC_END(k) pt_acc[k] += clock64() - pt_t0
+  long long pt_acc[3] = {0, 0, 0};  // cycles inside: the entry loops of the vectors, the class words, (spare)
 #else
 #define PT_T(k) do { } while (0)
+#define PT_ACC_BEGIN() do { } while (0)
+#define PT_ACC_END(k) do { } while (0)
 #endif
   PT_T(0);
   NvhFrame fr;
@@ -442,6 +448,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
           pass.op_begin[stage] = op_base + nops;
           for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count && !stop && !err; entry_idx++) {
             if (stage == 0) {
+              PT_ACC_BEGIN();
               for (int c = 0; c < r.channels; c++) {
                 const int idx = decode_scalar<LDS>(T, s_prefix, s_pkt, class_book, p);
                 if (idx == -2) {
@@ -456,6 +463,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   break;
                 }
               }
+              PT_ACC_END(1);
               if (stop || err) break;
             }
             for (int dimension_idx = 0; partition_idx < partition_count && dimension_idx < cdim && !stop && !err;
@@ -467,7 +475,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   err = kErrRuntime;  // NullReferenceException on partWordCache
                   break;
                 }
-                const int cls = T.ipool[r.decode_map_off + (uint32_t)(word * cdim + dimension_idx)];
+                const int cls = ipool_at(r.decode_map_off + (uint32_t)(word * cdim + dimension_idx));
                 if (SLAB && stage == 0) {
                   // the chain of this partition / channel: one record per cascade stage that has a book, consecutive, allocated
                   // now that its class is known (stage 0 visits every partition in order)
@@ -535,12 +543,14 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                 } else {
                   // Residue1.WriteVectors (Residue1.cs:8-26) / Residue2.WriteVectors (Residue2.cs:23-47):
                   // vectors are added as they are decoded; a failed decode keeps what was added so far
-                  const int slots = (r.partition_size + dims - 1) / dims;
+                  // (partition_size + dims - 1) / dims by the book's reciprocal (exact: nvh_setup.hip checked the range)
+                  const int slots = dims > 1 ? (int)__umulhi((uint32_t)(r.partition_size + dims - 1), book.dim_magic) : r.partition_size;
                   if (nent + (uint32_t)slots > (uint32_t)T.cap_ent) {
                     err = kErrRuntime;
                     break;
                   }
                   int done = 0;
+                  PT_ACC_BEGIN();
                   // The vector's entries, fast form: while the packet has 32 bits left, the code resolves in the book's LDS prefix
                   // table and slots remain, a symbol is a masked ds_read, a 64-bit shift and a 16-bit store in a loop with one
                   // exit test.  (The general loop below, with the reference's end-of-packet and null-list rules inlined into a
@@ -583,13 +593,17 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     entries[ent_base + nent++] = (uint16_t)e;
                     ++done;
                   }
+                  PT_ACC_END(0);
                   if (err) break;
                   if (done > 0) {  // bounds of the adds the reference performed
                     const int last = done * dims - 1;
                     if (r.type == 1) {
                       if (offset + last >= buflen) err = kErrRuntime;
                     } else {
-                      if (offset / r.real_channels + last / r.real_channels >= buflen) err = kErrRuntime;
+                      // offset / real_channels + last / real_channels (Residue2.cs:27, :30-45) by the residue's reciprocal
+                      const int ob = r.real_channels > 1 ? (int)__umulhi((uint32_t)offset, r.rch_magic) : offset;
+                      const int lb = r.real_channels > 1 ? (int)__umulhi((uint32_t)last, r.rch_magic) : last;
+                      if (ob + lb >= buflen) err = kErrRuntime;
                     }
                     if (err) break;
                   }
@@ -643,7 +657,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
               const int start = row_get(last_base + pi * r.channels + c);
               if (start < 0) continue;
               const int word = row_get(c * pw_stride + pi / cdim);
-              const int cls = T.ipool[r.decode_map_off + (uint32_t)(word * cdim + pi % cdim)];
+              const int cls = ipool_at(r.decode_map_off + (uint32_t)(word * cdim + pi % cdim));
               const unsigned cm = r.book_mask[cls];
               for (int st = 0; st < r.max_stages; ++st) {
                 if (!((cm >> st) & 1u)) continue;
@@ -687,6 +701,9 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   }
 
   PT_T(3);
+#ifdef NVH_DEBUG
+  if (dbg && active) { dbg[(long long)f * 24 + 8] = pt_acc[0]; dbg[(long long)f * 24 + 9] = pt_acc[1]; }
+#endif
   uint32_t slab_vecs = 0;
   if constexpr (SLAB) {
     // ---- behind the parse, the lanes of the wavefront side by side: the rest of the slab ----

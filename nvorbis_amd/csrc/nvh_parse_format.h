@@ -31,7 +31,7 @@ struct NvhPBook {
   // what a slab record says about the book (nvh_format.h: NVH_SLAB_REC; NvhDevBook has the same fields for the host writer)
   uint32_t slab_lat;      // lattice pool offset | lat_values << 16
   uint32_t slab_dm16;     // ceil(2^16 / dims)
-  uint32_t pad2;
+  uint32_t dim_magic;     // ceil(2^32 / dims), 0 for dims <= 1: partition_size / dims without a division (nvh_setup.hip checks the range)
 };
 
 struct NvhPOverflow {
@@ -58,7 +58,8 @@ struct NvhPResidue {  // Residue0.cs:21-33
   int32_t max_stages, partvals, class_dims;
   int32_t alias_b1;         // quirk B-1 on its own (NvhDevResidue::alias_b1): the slab carries the partition table of the bin walk
   uint32_t decode_map_off;  // into the int pool: partvals * class_dims class numbers
-  uint32_t pad2[3];
+  uint32_t rch_magic;       // ceil(2^32 / real_channels), 0 for one channel
+  uint32_t pad2[2];
   uint8_t cascade[NVH_MAX_CLASSES];
   int16_t books[NVH_MAX_CLASSES][NVH_MAX_STAGES];
   uint8_t book_mask[NVH_MAX_CLASSES];  // per class: the cascade stages that have a book (a chain of the slab has one record per set bit)

@@ -290,6 +290,7 @@ int upload_parse_tables(nvh_stream* s) {
     d.max_bits = (uint8_t)b.max_bits;
     d.has_tree = b.has_tree ? 1 : 0;
     d.has_overflow = b.has_overflow ? 1 : 0;
+    d.dim_magic = b.dimensions > 1 ? (uint32_t)((0x100000000ull + (uint64_t)b.dimensions - 1) / (uint64_t)b.dimensions) : 0u;
     if (i < sh.slab.books.size()) {
       const NvhDevBook& db = sh.slab.books[i];
       d.slab_lat = db.lat_off | (db.lat_values << 16);
@@ -385,6 +386,8 @@ int upload_parse_tables(nvh_stream* s) {
     d.real_channels = r.real_channels; d.max_stages = r.max_stages; d.partvals = r.partvals;
     d.class_dims = S.books[(size_t)r.class_book].dimensions;
     d.alias_b1 = (i < sh.slab.residue_b1.size() && sh.slab.residue_b1[i]) ? 1 : 0;
+    d.rch_magic = r.real_channels > 1 ? (uint32_t)((0x100000000ull + (uint64_t)r.real_channels - 1) / (uint64_t)r.real_channels) : 0u;
+    if ((uint64_t)S.block1 * (uint64_t)std::max(S.channels, 1) * (uint64_t)std::max(r.real_channels, 1) >= 0x100000000ull) return NVH_OK;
     d.decode_map_off = (uint32_t)ipool.size();
     ipool.insert(ipool.end(), r.decode_map.begin(), r.decode_map.end());
     int min_dims = 1 << 30;
@@ -395,6 +398,8 @@ int upload_parse_tables(nvh_stream* s) {
         if (k < r.max_stages && (r.cascade[c] & (1 << k)) && r.books[c][k] >= 0) d.book_mask[c] |= (uint8_t)(1u << k);
         if (c < r.classifications && r.books[c][k] >= 0) {
           const int dm = S.books[(size_t)r.books[c][k]].dimensions;
+          // k_parse divides (partition_size + dims - 1) by dims with the book's 32-bit reciprocal: exact below 2^32 / dims
+          if (dm > 1 && ((uint64_t)r.partition_size + (uint64_t)dm) * (uint64_t)dm >= 0x100000000ull) return NVH_OK;
           if (dm > 0 && dm < min_dims) min_dims = dm;
         }
       }

@@ -28,6 +28,8 @@ names = ["frame record + packet into LDS + bit reader", "floors (Floor1.Unpack x
 for k in range(5):
     dt = d[:, k + 1] - d[:, k]
     print("%-48s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (names[k], dt.mean(), np.median(dt), np.percentile(dt, 90)))
+for nm, k in (("  inside residue: entry loops of the vectors", 8), ("  inside residue: class words", 9)):
+    print("%-48s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (nm, d[:, k].mean(), np.median(d[:, k]), np.percentile(d[:, k], 90)))
 life = d[:, 5] - d[:, 0]
 print("lane lifetime mean %.0f p50 %.0f p90 %.0f cycles" % (life.mean(), np.median(life), np.percentile(life, 90)))
 b.free(); st.close()
