@@ -233,6 +233,11 @@ int nvh_stream_pending(const nvh_stream *s, int *frames, int64_t *pcm_samples_pe
  * *bytes is set even when cap is too small (NVH_ERR_ARGUMENT then). */
 int nvh_stream_pending_slabs(const nvh_stream *s, uint8_t *buf, int64_t cap, int64_t *bytes, uint32_t *first_unit,
                              int cap_frames);
+/* The setup's lattice pool as the synthesis kernels hold it: per lattice codebook (Codebook.cs:222-283, lookup type 1 without
+ * sequence_p) its distinct component values as float bits, then the reciprocals ceil(2^32 / lat_values^i) for i < dimensions;
+ * a slab record's lattice offset points at a book's first value.  Host only, for tests and tools.  *words is set even when
+ * cap_words is too small (NVH_ERR_ARGUMENT then). */
+int nvh_stream_lattice_pool(const nvh_stream *s, uint32_t *out, int64_t cap_words, int64_t *words);
 
 /* Synthesise the pending batch: H2D descriptors -> kernels -> interleaved PCM.  Exactly one of
  * pcm_host / d_pcm is non-NULL; capacity is in floats and must hold pending samples * channels.

@@ -29,6 +29,9 @@ struct SlabSetup {
   // and frames with more than one residue pass (several submaps), carry a group list (nvh_format.h: NvhSlabHdr::group == 1).
   std::vector<uint8_t> residue_general;
   std::vector<uint8_t> residue_pair;  // per residue: on the pair path (NvhDevResidue::pair_path)
+  // the lattice pool as the device holds it (build_book_directory), kept for nvh_stream_lattice_pool: what a record's lattice
+  // offset points into
+  std::vector<uint32_t> lattice;
   // Floor0: where the Bark map of floor i for block0 / block1 lies in the device's int pool (nvh_setup.hip lays the maps out in
   // floor order, block0 then block1), 0xFFFFFFFF for a Floor1
   std::vector<uint32_t> floor0_bark_off[2];

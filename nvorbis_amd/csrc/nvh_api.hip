@@ -196,6 +196,7 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
               }
         }
         nvh::classify_residues(sh->setup, sh->slab, nvh_toggles().no_pair || lattice.size() > 0xFFFFu);
+        sh->slab.lattice = lattice;
       }
       *out = s.release();
       return NVH_OK;
@@ -510,6 +511,17 @@ extern "C" int nvh_stream_pending_slabs(const nvh_stream* s, uint8_t* buf, int64
     if (*bytes > cap || (first_unit && cap_frames < nf + 1)) return NVH_ERR_ARGUMENT;
     if (*bytes) std::memcpy(buf, sb.data.data(), (size_t)*bytes);
     if (first_unit) std::memcpy(first_unit, sb.first.data(), (size_t)(nf + 1) * sizeof(uint32_t));
+    return NVH_OK;
+  });
+}
+
+extern "C" int nvh_stream_lattice_pool(const nvh_stream* s, uint32_t* out, int64_t cap_words, int64_t* words) {
+  return nvh_guard([&]() -> int {
+    if (!s || !words || cap_words < 0 || (cap_words > 0 && !out)) return NVH_ERR_ARGUMENT;
+    const std::vector<uint32_t>& L = s->shared->slab.lattice;
+    *words = (int64_t)L.size();
+    if (*words > cap_words) return NVH_ERR_ARGUMENT;
+    if (!L.empty()) std::memcpy(out, L.data(), L.size() * sizeof(uint32_t));
     return NVH_OK;
   });
 }

@@ -32,6 +32,7 @@ int upload_setup(nvh_stream* s) {
   std::vector<uint32_t> lattice;
   nvh::build_book_directory(S, s->shared->slab, vq, lattice);
   nvh::classify_residues(S, s->shared->slab, nvh_toggles().no_pair || lattice.size() > 0xFFFFu);
+  s->shared->slab.lattice = lattice;
   const std::vector<NvhDevBook>& books = s->shared->slab.books;
 
   std::vector<int32_t> ipool;

@@ -253,6 +253,15 @@ class Stream:
               "nvh_stream_pending_slabs")
         return buf[:need.value // 4], first
 
+    def lattice_pool(self):
+        """The setup's lattice pool (uint32 words: per lattice codebook its component values as float bits, then its power
+        reciprocals): what the lattice offset of a slab record points into."""
+        need = C.c_int64(0)
+        lib().nvh_stream_lattice_pool(self._h, None, 0, C.byref(need))
+        buf = np.zeros(max(int(need.value), 1), np.uint32)
+        check(lib().nvh_stream_lattice_pool(self._h, buf.ctypes.data, buf.size, C.byref(need)), "nvh_stream_lattice_pool")
+        return buf[:int(need.value)]
+
     def position(self):
         pos, em, eos = C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(lib().nvh_stream_position(self._h, C.byref(pos), C.byref(em), C.byref(eos)), "nvh_stream_position")

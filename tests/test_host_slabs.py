@@ -283,3 +283,109 @@ def test_slab_general_group_list(oracle, name):
         assert general > 20 and chains > 200
     finally:
         s.close()
+
+
+def _slab_residue_sums(words, h, lat, nch, half):
+    """The residue sums [nch][half] a slab's chains encode, added in the reference's order (cascade stage by stage, inside a
+    stage the partitions in order; Residue0.cs:132-175), for every walk of the synthesis kernels: the pair walk (group 2 / 8 /
+    2 * channels), the quirk-B-1 bin walk (group 0) and the general one (group 1, with its group list)."""
+    spec = np.zeros((nch, half), np.float32)
+    if h["nrec"] == 0:
+        return spec
+    hw = words[h["off_heads"] * 4:h["off_rec"] * 4][:h["nheads"]]
+    first, xb = (hw & 0xFFFF).astype(np.int64), (hw >> 16).astype(np.int64)
+    recs = words[h["off_rec"] * 4:][:2 * h["nrec"]].reshape(h["nrec"], 2)
+    ent = words[h["off_ent"] * 4:].view(np.uint16)
+    # (pass, type, channels of a Residue2 interleave, partition size) of every chain
+    geo = [None] * h["nheads"]
+    if h["group"] == 1:
+        g = words[h["lpc"] * 4:h["vecs"] * 4]
+        ng = int(g[0])
+        pchain = g[4 + 8 * ng:].view(np.uint16)
+        for k in range(ng):
+            rbegin, psz, nparts, cover, geom, magic, pco = (int(x) for x in g[4 + 8 * k:4 + 8 * k + 7])
+            for cix in pchain[pco:pco + nparts]:
+                if cix != 0xFFFF:
+                    geo[int(cix)] = ((geom >> 8) & 15, geom & 15, (geom >> 4) & 15, psz)
+    else:
+        rtype, rch = h["rgeom"] & 15, h["rgeom"] >> 4
+        psz = int(words[h["lpc"] * 4 + 1]) if h["group"] == 0 else h["lpc"] * h["group"]
+        geo = [(0, rtype, rch if rtype == 2 else 1, psz)] * h["nheads"]
+    writes = []  # (pass, stage, first bin, chain, record)
+    for cix in range(h["nheads"]):
+        o = int(first[cix])
+        while True:
+            x, y = int(recs[o, 0]), int(recs[o, 1])
+            writes.append((geo[cix][0], (y >> 28) & 7, int(xb[cix]), cix, x, y))
+            if not (y >> 31):
+                break
+            o += 1
+    writes.sort(key=lambda w: (w[0], w[1], w[2]))
+    for pss, stage, x0, cix, x, y in writes:
+        _, rtype, rch, psz = geo[cix]
+        dims, lv, lat_off, chan = (y >> 20) & 31, (y >> 12) & 0xFF, y & 0xFFF, (y >> 25) & 7
+        eb = ent[(x & 0xFFFF):]
+        steps = psz // dims
+        for q in range(psz):
+            j, comp = (q % steps, q // steps) if rtype == 0 else (q // dims, q % dims)
+            e = int(eb[j])
+            if e == 0xFFFF:
+                continue
+            v = lat[lat_off + (e // lv ** comp) % lv: lat_off + (e // lv ** comp) % lv + 1].view(np.float32)[0]
+            c, b = (q % rch, x0 + q // rch) if (rtype == 2 and rch > 1) else (chan, x0 + q)
+            if b < half:
+                spec[c, b] = np.float32(spec[c, b] + v)
+    return spec
+
+
+@pytest.mark.parametrize("name", ["3test", "2test", "stereo_res1_coupled", "six_ch_res2_4096", "three_ch_res2_misaligned", "res0_slab",
+                                  "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch", "floor0_slab"])
+def test_slab_residue_sums_match_oracle(oracle, ogg_bytes, name):
+    """The residue half of the host-written slabs against the oracle's IResidue.Decode (oracle/orc_residue.c), without a GPU: the
+    chains, records and entries of a frame, walked here in the reference's order of additions, must give the oracle's residue
+    vectors bit for bit -- for the pair walk (shipped files, coupled stereo, six channels), the quirk-B-1 bin walk and the general
+    walk (Residue0, odd dimensions, aliasing stereo Residue2, two passes, three channels)."""
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    from tests.test_gpu_parity import _open_headers
+    if name in ogg_bytes:
+        pk, _, _ = nv.demux_ogg(ogg_bytes[name])
+        ids = list(range(3, 40)) + list(range(40, len(pk), max(1, (len(pk) - 40) // 12)))
+    else:
+        pk, _, _ = ss.filtered_stream(oracle, name, 40, 9)
+        ids = range(3, len(pk))
+    d = _open_headers(oracle, pk)
+    s = nv.Stream(None, pk[0], pk[1], pk[2])
+    try:
+        lat = s.lattice_pool()
+        nch, b1 = s.channels, s.block1
+        scratch = np.zeros(nch * b1, np.float32)
+        frames = vectors = 0
+        for i in ids:
+            a, b, c, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            if oracle.L.orc_decode_packet_block(d, pk[i], len(pk[i]), scratch.ctypes.data, C.byref(a), C.byref(b), C.byref(c), C.byref(e)) != 1:
+                continue
+            s.drop_pending()
+            s.push_packet(pk[i], -1, 0)
+            if s.pending()[0] != 1 or int(s.pending_geometry()[-1][0]) == 0:
+                continue
+            words, _ = s.pending_slabs()
+            h = parse_slab(words)
+            n = e.value
+            assert h["n"] == n
+            pos, idx, anyx = np.zeros(16, np.int32), np.zeros(16, np.int32), C.c_int()
+            ncall = oracle.L.orc_last_residue_calls(d, pos.ctypes.data, idx.ctypes.data, 16, C.byref(anyx))
+            ref = np.zeros(nch * b1, np.float32)
+            for k in range(ncall):
+                bits = C.c_int()
+                assert oracle.L.orc_residue_decode_at(d, int(idx[k]), pk[i], len(pk[i]), int(pos[k]), anyx.value, n, ref.ctypes.data,
+                                                      C.byref(bits)) == 0
+            got = _slab_residue_sums(words, h, lat, nch, n // 2)
+            want = ref.reshape(nch, b1)[:, :n // 2]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, i, float(np.abs(got - want).max()))
+            frames += 1
+            vectors += h["nrec"]
+        assert frames >= 10 and vectors > 100, (frames, vectors)
+    finally:
+        oracle.L.orc_close(d)
+        s.close()
