@@ -10,7 +10,7 @@ orc = oracle_py.load()
 ctx = nv.Context(0)
 rng = np.random.default_rng(2026)
 names = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096", "two_submaps",
-         "equal_blocks_overrun", "mono_8192"]
+         "equal_blocks_overrun", "mono_8192", "stereo_8192", "res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"]
 t0 = time.time(); n = 0; frames = 0
 seeds = int(os.environ.get("SEEDS", "12"))
 for name in names:

@@ -10,7 +10,8 @@ orc = oracle_py.load()
 ctx = nv.Context(0)
 rng = np.random.default_rng(77)
 names = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096", "two_submaps",
-         "equal_blocks_overrun", "mono_8192", "stereo_8192", "floor0_stereo", "floor0_slab", "ch5_res2", "mono_res1_2048"]
+         "equal_blocks_overrun", "mono_8192", "stereo_8192", "floor0_stereo", "floor0_slab", "ch5_res2", "mono_res1_2048",
+         "res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"]
 
 
 def _decode_pipelined(pk, gr, fl, gpu_parse, per_batch, clip):
