@@ -28,6 +28,27 @@ def hipcc():
     return exe
 
 
+_COMPILER_ID = None
+
+
+def _compiler_id():
+    """`hipcc --version`, once: part of every object's cache key."""
+    global _COMPILER_ID
+    if _COMPILER_ID is None:
+        try:
+            _COMPILER_ID = subprocess.check_output([hipcc(), "--version"], stderr=subprocess.STDOUT).decode("utf-8", "replace")
+        except (OSError, subprocess.CalledProcessError):
+            _COMPILER_ID = "unknown"
+    return _COMPILER_ID
+
+
+def _mtime(path):
+    try:
+        return os.path.getmtime(path)
+    except OSError:
+        return 0.0
+
+
 def source_hash():
     """SHA-256 (first 16 hex digits) over everything the binary is made from: every file under csrc/, the public header,
     the source list and the compiler flags.  It is compiled into the library (-DNVH_SRC_HASH, reported by nvh_version())
@@ -83,6 +104,7 @@ def _compile_link(sources, out, extra, verbose=False):
     hdr.update(open(os.path.join(HERE, "..", "include", "nvorbis_hip.h"), "rb").read())
     cflags = [f for f in FLAGS if f != "-shared"] + extra
     hdr.update(repr(cflags).encode())
+    hdr.update(_compiler_id().encode())  # a ROCm upgrade must not reuse objects of the old compiler
     hash_flag = _hash_flag()
 
     def one(src):
@@ -94,21 +116,32 @@ def _compile_link(sources, out, extra, verbose=False):
             h.update(hash_flag[0].encode())
         obj = os.path.join(objdir, "%s.%s.o" % (src, h.hexdigest()[:16]))
         if not os.path.exists(obj):
-            for old in os.listdir(objdir):
-                if old.startswith(src + "."):
-                    os.remove(os.path.join(objdir, old))
-            cmd = [hipcc()] + cflags + hash_flag + ["-x", "hip", "-c", path, "-o", obj]
+            # keep a few older objects of this source (A/B variant builds alternate between flag sets), drop the rest; other
+            # builders may be at work in the same directory (the multi-rank tests): a file that is already gone is fine
+            mine = sorted((o for o in os.listdir(objdir) if o.startswith(src + ".")),
+                          key=lambda o: _mtime(os.path.join(objdir, o)), reverse=True)
+            for stale in mine[6:]:
+                try:
+                    os.remove(os.path.join(objdir, stale))
+                except FileNotFoundError:
+                    pass
+            tmp = "%s.%d.tmp" % (obj, os.getpid())
+            cmd = [hipcc()] + cflags + hash_flag + ["-x", "hip", "-c", path, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            os.replace(tmp, obj)  # (atomic: a concurrent builder never links a half-written object)
         return obj
 
     with ThreadPoolExecutor(max(1, min(len(sources), os.cpu_count() or 1))) as ex:
         objs = list(ex.map(one, sources))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out]
+    link_flags = [f for f in FLAGS if f.startswith("--offload-arch=") or f in ("-fPIC", "-shared")]
+    tmp_out = "%s.%d.tmp" % (out, os.getpid())
+    cmd = [hipcc()] + link_flags + objs + ["-o", tmp_out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp_out, out)
     return out
 
 

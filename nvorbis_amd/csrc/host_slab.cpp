@@ -28,6 +28,50 @@ inline int render_point(int x0, int y0, int x1, int y1, int X) {  // Floor1.cs:2
   return dy < 0 ? y0 - off : y0 + off;
 }
 
+// The digit bytes of one vector write (nvh_format.h: NVH_SLAB_RGEOM_DIGITS): n_ent entries of a book of dimension dim, appended to
+// `out`; an entry that says "no vector" becomes dim bytes that point at the book's +0.0f slot.
+inline void append_digits(const SlabSetup& X, uint32_t book, uint32_t dim, uint32_t lat_values, const uint16_t* e, uint32_t n_ent,
+                          std::vector<uint8_t>& out) {
+  const size_t o = out.size();
+  out.resize(o + (size_t)n_ent * dim);
+  uint8_t* d = out.data() + o;
+  const uint8_t* tab = X.dig_tab.data() + X.dig_off[book];
+  const uint8_t skip = (uint8_t)(lat_values * 4u);
+  switch (dim) {
+    case 2:
+      for (uint32_t j = 0; j < n_ent; j++, d += 2)
+        if (e[j] == NVH_ENTRY_SKIP) d[0] = d[1] = skip; else std::memcpy(d, tab + 2u * e[j], 2);
+      break;
+    case 4:
+      for (uint32_t j = 0; j < n_ent; j++, d += 4)
+        if (e[j] == NVH_ENTRY_SKIP) std::memset(d, skip, 4); else std::memcpy(d, tab + 4u * e[j], 4);
+      break;
+    case 8:
+      for (uint32_t j = 0; j < n_ent; j++, d += 8)
+        if (e[j] == NVH_ENTRY_SKIP) std::memset(d, skip, 8); else std::memcpy(d, tab + 8u * e[j], 8);
+      break;
+    default:
+      for (uint32_t j = 0; j < n_ent; j++, d += dim)
+        if (e[j] == NVH_ENTRY_SKIP) std::memset(d, skip, dim); else std::memcpy(d, tab + (size_t)dim * e[j], dim);
+  }
+}
+
+// The entry section of a frame: uint16 entry numbers as the parser left them (padded with "no vector" to a whole 16-byte
+// unit), or -- digit form -- the bytes the records' runs were collected into.
+inline void put_entry_section(std::vector<SlabVec>& data, const FrameBatch& P, const NvhFrame& fr, bool dig, const std::vector<uint8_t>& dg) {
+  const size_t e0 = data.size();
+  if (dig) {
+    data.resize(e0 + (dg.size() + 15) / 16);  // (zeroed by resize: padding bytes are never read)
+    if (!dg.empty()) std::memcpy(&data[e0], dg.data(), dg.size());
+    return;
+  }
+  const uint32_t ne = fr.ent_count, padded = (ne + 7) & ~7u;
+  data.resize(e0 + padded / 8);
+  uint16_t* dst = reinterpret_cast<uint16_t*>(&data[e0]);
+  if (ne) std::memcpy(dst, P.entries.data() + fr.ent_begin, (size_t)ne * 2);
+  for (uint32_t i = ne; i < padded; i++) dst[i] = (uint16_t)NVH_ENTRY_SKIP;
+}
+
 }  // namespace
 
 int floor1_segments(const Floor1& f, const uint16_t* posts, int post_count, int half, SlabVec* seg, bool* fault) {
@@ -105,18 +149,22 @@ int floor1_segments(const Floor1& f, const uint16_t* posts, int post_count, int 
 }
 
 bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r) {
-  (void)S;
   if (r.type != 2 || r.real_channels < 3 || r.real_channels > NVH_SLAB_MAX_CH) return false;
   if (r.begin % r.real_channels == 0 && r.partition_size % r.real_channels == 0) return false;  // no aliasing at all
   if (r.partition_size < 2 * r.real_channels || r.partition_size > 4096) return false;
+  uint64_t max_div = (uint64_t)std::max(r.partition_size, r.real_channels);
   for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++)
     for (int k = 0; k < NVH_MAX_STAGES; k++) {
       const int b = r.books[c][k];
       if (b < 0) continue;
       const NvhDevBook& bk = X.books[(size_t)b];
       if (bk.lat_values == 0 || bk.dim == 0 || (bk.dim & 1u) || (uint32_t)r.partition_size % bk.dim != 0) return false;
+      max_div = std::max<uint64_t>(max_div, bk.dim);
     }
-  return true;
+  // the walk's reciprocal multiplies are exact while index * divisor < 2^32 (nvh_setup.hip: NvhDevResidue::fast -- the same
+  // bound, here so that a stream without a device context classifies its residues exactly as the device build does)
+  const uint64_t max_index = (uint64_t)(S.block1 / 2 + r.partition_size) * (uint64_t)r.real_channels;
+  return max_index * max_div < 0x100000000ull;
 }
 
 bool residue_pair_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
@@ -149,6 +197,18 @@ void classify_residues(const Setup& S, SlabSetup& X, bool no_pair) {
     X.residue_b1[i] = (!no_pair && !X.residue_pair[i] && residue_alias_b1(S, X, r)) ? 1 : 0;
     X.residue_general[i] = (!no_pair && residue_general_ok(S, X, r)) ? 1 : 0;
   }
+  // the digit form of the entry sections: every book of every residue the slab kernels can take has its digit table
+  X.digits_ok = X.val_off.size() == S.books.size() && S.books.size() > 0;
+  for (size_t i = 0; i < n && X.digits_ok; i++) {
+    if (!X.residue_pair[i] && !X.residue_b1[i] && !X.residue_general[i]) continue;
+    const Residue& r = S.residues[i];
+    for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++)
+      for (int k = 0; k < NVH_MAX_STAGES; k++) {
+        const int b = r.books[c][k];
+        if (b >= 0 && ((size_t)b >= X.dig_off.size() || X.dig_off[(size_t)b] == 0xFFFFFFFFu)) X.digits_ok = false;
+      }
+  }
+  if (X.pool_words > (size_t)NVH_SLAB_MAX_LAT_OFF) X.digits_ok = false;  // a record addresses the pools with 12 bits of words
 }
 
 bool residue_general_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
@@ -216,7 +276,9 @@ namespace {
 // frame's entries, and the group list -- one group per (pass, channel) of a per-channel residue, one per pass of a Residue2 --
 // that tells the bin walk which chain covers which partition.  Returns NVH_OK with H's section fields set.
 int residue_general(const Setup& S, const SlabSetup& X, const FrameBatch& P, const NvhFrame& fr, int nch, size_t base,
-                    std::vector<SlabVec>& data, NvhSlabHdr& H, std::vector<uint32_t>& head_ops) {
+                    std::vector<SlabVec>& data, NvhSlabHdr& H, std::vector<uint32_t>& head_ops, std::vector<uint8_t>& dg) {
+  const bool dig = X.digits_ok;
+  dg.clear();
   const int npass = (int)(fr.pass_end - fr.pass_begin);
   const uint32_t nops = fr.op_count;
   const NvhResOp* ops = P.ops.data() + fr.op_begin;
@@ -272,12 +334,19 @@ int residue_general(const Setup& S, const SlabSetup& X, const FrameBatch& P, con
         if (q >= hi || nrec >= nops) return NVH_ERR_RUNTIME;
         const NvhResOp& op = ops[q];
         const NvhDevBook& bk = X.books[op.book];
-        const uint32_t rel = op.ent_off - fr.ent_begin;
-        if (rel > 0xFFFFu || bk.lat_off > NVH_SLAB_MAX_LAT_OFF || bk.lat_values > 0xFFu || bk.dim > 31u || op.channel > 7u ||
+        uint32_t rel = op.ent_off - fr.ent_begin, pool_off = bk.lat_off;
+        if (dig) {  // the record's run of digit bytes: partition_size / dim entries (the general walk's contract: no vector overrun)
+          if (bk.dim == 0 || psz % bk.dim != 0 || rel + psz / bk.dim > fr.ent_count || (dg.size() & 1u)) return NVH_ERR_RUNTIME;
+          rel = (uint32_t)(dg.size() >> 1);
+          pool_off = X.val_off[op.book];
+          append_digits(X, op.book, bk.dim, bk.lat_values, P.entries.data() + op.ent_off, psz / bk.dim, dg);
+          if (dg.size() & 1u) dg.push_back(0);  // (a partition of odd size: runs start on even bytes)
+        }
+        if (rel > 0xFFFFu || pool_off > NVH_SLAB_MAX_LAT_OFF || bk.lat_values > 0xFFu || bk.dim > 31u || op.channel > 7u ||
             op.partition != part || op.channel != c)
           return NVH_ERR_UNSUPPORTED;
         const uint32_t l = links[q] & 0x7FFFu;
-        const uint32_t rw[2] = {NVH_SLAB_REC(rel, bk.dim_magic16, bk.lat_off, bk.lat_values, bk.dim, op.channel, stage_of(q), l != NVH_LINK_NONE)};
+        const uint32_t rw[2] = {NVH_SLAB_REC(rel, bk.dim_magic16, pool_off, bk.lat_values, bk.dim, op.channel, stage_of(q), l != NVH_LINK_NONE)};
         recs[2 * nrec] = rw[0];
         recs[2 * nrec + 1] = rw[1];
         ++nrec;
@@ -303,18 +372,10 @@ int residue_general(const Setup& S, const SlabSetup& X, const FrameBatch& P, con
   H.nheads = (uint16_t)nheads;
   H.nrec = (uint16_t)nrec;
   H.off_rec = (uint16_t)off_rec;
-  H.rgeom = (uint8_t)(1 | (1 << 4));
+  H.rgeom = (uint8_t)(1 | (1 << 4) | (dig ? NVH_SLAB_RGEOM_DIGITS : 0u));
   H.group = 1;
-  // entries, padded with "no vector" to a whole 16-byte unit
   H.off_ent = (uint16_t)(data.size() - base);
-  {
-    const uint32_t ne = fr.ent_count, padded = (ne + 7) & ~7u;
-    const size_t e0 = data.size();
-    data.resize(e0 + padded / 8);
-    uint16_t* dst = reinterpret_cast<uint16_t*>(&data[e0]);
-    if (ne) std::memcpy(dst, P.entries.data() + fr.ent_begin, (size_t)ne * 2);
-    for (uint32_t i = ne; i < padded; i++) dst[i] = (uint16_t)NVH_ENTRY_SKIP;
-  }
+  put_entry_section(data, P, fr, dig, dg);
   // the group list: count | per group two 16-byte units | uint16 pchain[]
   const size_t g0 = data.size();
   if (g0 - base > 0xFFFFu) return NVH_ERR_UNSUPPORTED;
@@ -344,6 +405,8 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
   out.data.reserve(nf * 256);
   std::vector<SlabVec> segs((size_t)NVH_MAX_POSTS + 2);
   std::vector<uint32_t> head_scratch;  // op index of every chain head of the frame, in the order the heads are stored
+  std::vector<uint8_t> dig_scratch;    // digit form: the frame's digit bytes, in record order
+  const bool dig = X.digits_ok;
   for (size_t f = 0; f < nf; f++) {
     const NvhFrame& fr = P.frames[f];
     const size_t base = out.data.size();
@@ -431,13 +494,14 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
     unsigned rbegin_al = 0;
     H.off_heads = (uint16_t)(out.data.size() - base);
     bool general = npass > 1;
+    dig_scratch.clear();
     if (npass == 1) {
       const size_t ri = (size_t)P.passes[fr.pass_begin].residue;
       general = ri < X.residue_general.size() && X.residue_general[ri] != 0 && !(ri < X.residue_b1.size() && X.residue_b1[ri]) &&
                 !(ri < X.residue_pair.size() && X.residue_pair[ri]);
     }
     if (general) {
-      const int rcg = residue_general(S, X, P, fr, nch, base, out.data, H, head_scratch);
+      const int rcg = residue_general(S, X, P, fr, nch, base, out.data, H, head_scratch, dig_scratch);
       if (rcg != NVH_OK) return rcg;
     } else if (npass == 1) {
       const NvhResPass& gp = P.passes[fr.pass_begin];
@@ -491,12 +555,18 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
           if (q >= nops || nrec >= nops) return NVH_ERR_RUNTIME;
           const NvhResOp& op = ops[q];
           const NvhDevBook& bk = X.books[op.book];
-          const uint32_t rel = op.ent_off - fr.ent_begin;
-          if (rel > 0xFFFFu || bk.lat_off > NVH_SLAB_MAX_LAT_OFF || bk.lat_values > 0xFFu || bk.dim > 31u || op.channel > 7u ||
+          uint32_t rel = op.ent_off - fr.ent_begin, pool_off = bk.lat_off;
+          if (dig) {  // the record's run of digit bytes: partition_size / dim entries (residue_pair_ok / residue_alias_b1: dim | size)
+            if (bk.dim == 0 || psz % bk.dim != 0 || rel + psz / bk.dim > fr.ent_count || (dig_scratch.size() & 1u)) return NVH_ERR_RUNTIME;
+            rel = (uint32_t)(dig_scratch.size() >> 1);
+            pool_off = X.val_off[op.book];
+            append_digits(X, op.book, bk.dim, bk.lat_values, P.entries.data() + op.ent_off, psz / bk.dim, dig_scratch);
+          }
+          if (rel > 0xFFFFu || pool_off > NVH_SLAB_MAX_LAT_OFF || bk.lat_values > 0xFFu || bk.dim > 31u || op.channel > 7u ||
               op.partition != ops[o].partition)
             return NVH_ERR_UNSUPPORTED;
           const uint32_t l = links[q] & 0x7FFFu;
-          const uint32_t rw[2] = {NVH_SLAB_REC(rel, bk.dim_magic16, bk.lat_off, bk.lat_values, bk.dim, op.channel, stage_of(q), l != NVH_LINK_NONE)};
+          const uint32_t rw[2] = {NVH_SLAB_REC(rel, bk.dim_magic16, pool_off, bk.lat_values, bk.dim, op.channel, stage_of(q), l != NVH_LINK_NONE)};
           recs[2 * nrec] = rw[0];
           recs[2 * nrec + 1] = rw[1];
           ++nrec;
@@ -513,16 +583,11 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
     } else {
       H.off_rec = (uint16_t)(out.data.size() - base);
     }
-    if (!general) H.rgeom = (uint8_t)(rtype | (rch << 4));
-    // ---- entries of the frame, padded with "no vector" to a whole 16-byte unit ----
+    if (!general) H.rgeom = (uint8_t)(rtype | (rch << 4) | (dig ? NVH_SLAB_RGEOM_DIGITS : 0u));
+    // ---- the frame's vector entries: entry numbers, or the digit bytes of the records' runs ----
     if (!general) {
       H.off_ent = (uint16_t)(out.data.size() - base);
-      const uint32_t ne = fr.ent_count, padded = (ne + 7) & ~7u;
-      const size_t e0 = out.data.size();
-      out.data.resize(e0 + padded / 8);
-      uint16_t* dst = reinterpret_cast<uint16_t*>(&out.data[e0]);
-      if (ne) std::memcpy(dst, P.entries.data() + fr.ent_begin, (size_t)ne * 2);
-      for (uint32_t i = ne; i < padded; i++) dst[i] = (uint16_t)NVH_ENTRY_SKIP;
+      put_entry_section(out.data, P, fr, dig, dig_scratch);
     }
     // ---- bin-by-bin walk (quirk B-1): the residue's geometry and which chain belongs to which partition ----
     if (!general && npass == 1 && H.group == 0) {
@@ -658,7 +723,35 @@ void build_book_directory(const Setup& S, SlabSetup& X, std::vector<float>& vq, 
       vq.insert(vq.end(), b.lookup.begin(), b.lookup.end());
     }
   }
-
+  // the digit form (host_slab.h): value pool behind the lattice pool, digit bytes of every entry
+  X.val_pool.clear();
+  X.dig_tab.clear();
+  X.val_off.assign(S.books.size(), 0xFFFFFFFFu);
+  X.dig_off.assign(S.books.size(), 0xFFFFFFFFu);
+  const size_t val_base = lattice.empty() ? 1 : lattice.size();  // (the device image pads an empty pool to one word)
+  for (size_t i = 0; i < S.books.size(); i++) {
+    const Codebook& b = S.books[i];
+    const uint32_t lv = books[i].lat_values;
+    if (lv == 0 || lv > NVH_SLAB_MAX_DIGIT || b.dimensions < 1 || b.dimensions > 16) continue;
+    X.val_off[i] = (uint32_t)(val_base + X.val_pool.size());
+    for (float v : b.lattice) {
+      uint32_t bits;
+      std::memcpy(&bits, &v, 4);
+      X.val_pool.push_back(bits);
+    }
+    X.val_pool.push_back(0u);  // +0.0f: where the bytes of a vector that was never added point
+    X.dig_off[i] = (uint32_t)X.dig_tab.size();
+    X.dig_tab.resize(X.dig_tab.size() + (size_t)b.entries * (size_t)b.dimensions);
+    uint8_t* t = X.dig_tab.data() + X.dig_off[i];
+    for (int e = 0; e < b.entries; e++) {
+      uint32_t q = (uint32_t)e;
+      for (int d = 0; d < b.dimensions; d++) {
+        *t++ = (uint8_t)((q % lv) * 4u);
+        q /= lv;
+      }
+    }
+  }
+  X.pool_words = val_base + X.val_pool.size();
 }
 
 }  // namespace nvh

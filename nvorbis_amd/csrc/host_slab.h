@@ -32,6 +32,18 @@ struct SlabSetup {
   // the lattice pool as the device holds it (build_book_directory), kept for nvh_stream_lattice_pool: what a record's lattice
   // offset points into
   std::vector<uint32_t> lattice;
+  // Digit form of a slab's vector entries (round 5; nvh_format.h: NVH_SLAB_RGEOM_DIGITS).  A lattice book's entry number is
+  // its components' digits in base lat_values (Codebook.cs:242-260); peeling them is integer work, so the parser does it: the
+  // slab carries one byte per vector component, digit * 4 = the byte offset of the component's value from the book's first word
+  // in the VALUE POOL (per book: its lat_values distinct floats, then +0.0f -- the slot a "no vector was added here" component
+  // points at, quirks B-14 / B-16), and the synthesis kernels' walk is a byte read, an LDS read and an add per component.
+  // val_off[b]: the book's first word, counted from the start of the lattice pool (the value pool follows it in the kernels'
+  // constants block); dig_tab + dig_off[b]: entries * dim bytes, the digit bytes of every entry; 0xFFFFFFFF: not a lattice
+  // book of at most 63 values.  digits_ok: every book a slab residue uses has them (classify_residues).
+  std::vector<uint32_t> val_pool, val_off, dig_off;
+  std::vector<uint8_t> dig_tab;
+  bool digits_ok = false;
+  size_t pool_words = 0;  // lattice pool + value pool, in words: what a record's 12-bit offset must reach
   // Floor0: where the Bark map of floor i for block0 / block1 lies in the device's int pool (nvh_setup.hip lays the maps out in
   // floor order, block0 then block1), 0xFFFFFFFF for a Floor1
   std::vector<uint32_t> floor0_bark_off[2];

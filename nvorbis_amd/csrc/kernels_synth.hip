@@ -108,7 +108,11 @@ __device__ __forceinline__ void floor_walk_fx(const uint4* __restrict__ seg, con
 // for bins some chain covers: every other bin of the cleared spectrum stays +0.0f, which is what 0 * curve gives anyway.
 // RCH >= 3: Residue2 over RCH channels, G = 2 RCH: a lane owns two bins of every channel (component k = channel k % RCH of
 // bin k / RCH, Residue2.cs:25-45).  RCH == 0: the two-channel interleave or a per-channel residue, told apart at run time.
-template <int G, bool FUSE = false, int RCH = 0, int NT = SP_THREADS>
+// DIG: the entry section holds digit bytes (nvh_format.h: NVH_SLAB_RGEOM_DIGITS) -- a lane's G components of a cascade stage are G
+// consecutive bytes of the record's run, each the byte offset of its float from the book's first word in the value pool: the
+// stage is one LDS read of the bytes, then a read and an add per component.  Not DIG: uint16 entry numbers, digits peeled here
+// (the form the GPU parser still writes).
+template <int G, bool FUSE = false, int RCH = 0, int NT = SP_THREADS, bool DIG = false>
 __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
                                              const uint32_t* __restrict__ s_lat, float* spec, int half, unsigned nheads,
                                              unsigned lpc, unsigned lpc_magic, bool interleaved, unsigned flags, int tid,
@@ -131,6 +135,32 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
 #pragma unroll
     for (int k = 0; k < G; ++k) a[k] = 0.0f;  // the spectrum was cleared and every bin belongs to one chain
     for (;;) {
+      if constexpr (DIG) {
+        // the book's values (+0.0f behind them: the slot of a vector that was never added, the identity on these sums)
+        const char* vb = reinterpret_cast<const char*>(s_lat) + ((rec.y & 0xFFFu) << 2);
+        const uint8_t* db = reinterpret_cast<const uint8_t*>(ent) + ((rec.x & 0xFFFFu) << 1) + i0;
+        float v[G];
+        if constexpr (G == 8) {
+          const uint2 w = *reinterpret_cast<const uint2*>(db);  // runs are whole groups of eight: 8-byte aligned
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[k] = *reinterpret_cast<const float*>(vb + ((w.x >> (8 * k)) & 0xFFu));
+            v[4 + k] = *reinterpret_cast<const float*>(vb + ((w.y >> (8 * k)) & 0xFFu));
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < G; k += 2) {
+            const unsigned h = *reinterpret_cast<const uint16_t*>(db + k);
+            v[k] = *reinterpret_cast<const float*>(vb + (h & 0xFFu));
+            v[k + 1] = *reinterpret_cast<const float*>(vb + (h >> 8));
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) a[k] = a[k] + v[k];
+        if (!(rec.y & 0x80000000u)) break;
+        rec = recs[++o];
+        continue;
+      }
       const unsigned dims = (rec.y >> 20) & 31u, lv = (rec.y >> 12) & 0xFFu, dm16 = rec.x >> 16;
       const uint32_t* lat = s_lat + (rec.y & 0xFFFu);
       const uint16_t* eb = ent + (rec.x & 0xFFFFu);
@@ -266,7 +296,7 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
 // A lane owns one BIN (all rch channels of it) and merges the chains of the (at most two) partitions that touch it by cascade
 // stage; chains lie in partition order, pchain[p] = chain of partition p (0xFFFF: none).  Slab section `bins`:
 // uint32 begin, psz, nparts, bins a partition touches | uint16 pchain[nparts].
-template <int NT>
+template <int NT, bool DIG = false>
 __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
                                                   unsigned off_bins, unsigned psz_magic, const uint32_t* __restrict__ s_lat,
                                                   float* spec, int half, unsigned rch, int tid) {
@@ -301,6 +331,20 @@ __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned of
       const bool take_a = va && (!vb || ((ra.y >> 28) & 7u) <= ((rb.y >> 28) & 7u));
       const uint2 rec = take_a ? ra : rb;
       const unsigned q0 = (X - (take_a ? xa : xbb)) * rch;  // first component of this bin inside the partition
+      if constexpr (DIG) {
+        // component q of the partition is byte q of the record's run (nvh_format.h: NVH_SLAB_RGEOM_DIGITS)
+        const char* vb = reinterpret_cast<const char*>(s_lat) + ((rec.y & 0xFFFu) << 2);
+        const uint8_t* db = reinterpret_cast<const uint8_t*>(ent) + ((rec.x & 0xFFFFu) << 1);
+#pragma unroll
+        for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) {
+          if ((unsigned)c < rch) {  // uniform
+            const unsigned q = q0 + (unsigned)c;
+            const bool in = q < psz;  // a partition's last bin may hold fewer than rch components
+            const float v = *reinterpret_cast<const float*>(vb + db[in ? q : 0u]);
+            a[c] = a[c] + (in ? v : 0.0f);
+          }
+        }
+      } else {
       const unsigned dims = (rec.y >> 20) & 31u, lv = (rec.y >> 12) & 0xFFu, dm16 = rec.x >> 16;
       const uint32_t* lat = s_lat + (rec.y & 0xFFFu);
       const uint16_t* eb = ent + (rec.x & 0xFFFFu);
@@ -319,6 +363,7 @@ __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned of
           const float v = __uint_as_float(lat[dgt]);
           a[c] = a[c] + ((in && e != NVH_ENTRY_SKIP) ? v : 0.0f);  // +0.0f is the identity on these sums (they start at +0.0f)
         }
+      }
       }
       if (take_a) {
         va = (ra.y & 0x80000000u) != 0;
@@ -343,7 +388,7 @@ __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned of
 // a Residue2, the residue's geometry and pchain[p] = the chain of partition p.  A lane owns one bin of one group and adds the
 // vectors that land there in the reference's order (stage by stage, the lower partition first where two share a bin); a
 // later pass continues from the sums the earlier one stored, behind a barrier.
-template <int NT, int MAXC>
+template <int NT, int MAXC, bool DIG = false>
 __device__ __forceinline__ void residue_walk_general(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
                                                      unsigned off_gen, const uint32_t* __restrict__ s_lat, float* spec, int half,
                                                      int tid) {
@@ -394,7 +439,7 @@ __device__ __forceinline__ void residue_walk_general(const float* slab, unsigned
         const unsigned dims = (rec.y >> 20) & 31u, lv = (rec.y >> 12) & 0xFFu, dm16 = rec.x >> 16;
         const uint32_t* lat = s_lat + (rec.y & 0xFFFu);
         const uint16_t* eb = ent + (rec.x & 0xFFFFu);
-        const unsigned lvm = dims > 1 ? lat[lv + 1] : 0u;  // (a book of dimension 1 has no second power: the entry is the digit)
+        const unsigned lvm = (!DIG && dims > 1) ? lat[lv + 1] : 0u;  // (a book of dimension 1 has no second power: the entry is the digit)
         // partition_size / dims (host_slab.cpp checked the reciprocal; dimension 1: the record's 16-bit field cannot hold 2^16)
         const unsigned steps = dims > 1 ? (psz * dm16) >> 16 : psz;
 #pragma unroll
@@ -411,12 +456,19 @@ __device__ __forceinline__ void residue_walk_general(const float* slab, unsigned
               j = dims > 1 ? (qq * dm16) >> 16 : qq;
               comp = qq - j * dims;
             }
+            if constexpr (DIG) {  // byte j * dims + comp of the record's run (nvh_format.h: NVH_SLAB_RGEOM_DIGITS)
+              const uint8_t* db = reinterpret_cast<const uint8_t*>(ent) + ((rec.x & 0xFFFFu) << 1);
+              const unsigned pos = rtype == 0 ? j * dims + comp : qq;
+              const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lat) + db[pos]);
+              a[c] = a[c] + (in ? v : 0.0f);
+            } else {
             const unsigned e = eb[j];
             const unsigned pw = lat[lv + comp];
             const unsigned qv = comp ? __umulhi(e, pw) : e;
             const unsigned dgt = qv - __umul24(__umulhi(qv, lvm), lv);
             const float v = __uint_as_float(lat[dgt]);
             a[c] = a[c] + ((in && e != NVH_ENTRY_SKIP) ? v : 0.0f);
+            }
           }
         }
         if (take_a) {
@@ -522,8 +574,12 @@ template <int NT>
 __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, float* spec, const uint32_t* s_chan, int n, int nch,
                                            unsigned frame, int sl, bool emit_self, bool emit_next, bool self_carry, bool carry_out,
                                            unsigned exec_mask, float* planes,
-                                           const float* Aa, const float* Bb, const float* Cc, const float* TW, int tid) {
+                                           const float* Aa, const float* Bb, const float* Cc, const float* TW, int tid,
+                                           long long* stamps = nullptr) {
   const int wv = tid >> 6, lane = tid & 63, half = n >> 1;
+  // profiling builds: shader-clock stamps of thread 0 (15 staging issued, 16 transform done, 17 behind the barrier, 18 emitted;
+  // 10..14: the transform's own, imdct_wave.h)
+#define EM_T(k) do { if (stamps && tid == 0) stamps[k] = clock64(); } while (0)
   // parameters of the overlaps, out of the slab before the staging overwrites it
   const unsigned w_self = __builtin_amdgcn_readfirstlane(s_chan[2]), wp_self = __builtin_amdgcn_readfirstlane(s_chan[3]);
   const unsigned w_next = __builtin_amdgcn_readfirstlane(s_chan[4]), wp_next = __builtin_amdgcn_readfirstlane(s_chan[5]);
@@ -548,6 +604,7 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
       }
     }
   }
+  EM_T(15);
   // ---- inverse MDCT of this wavefront's channel, the two independent quarters kept in registers ----
   float4 ca[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, cb[2] = {ca[0], ca[0]};
   const bool pon = lane < (n >> 5);  // lanes with output: four values of each quarter at 4 i8, i8 = lane and i8 = n/16 - 1 - lane
@@ -560,10 +617,10 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
       if (slot == 0) ca[0] = v; else if (slot == 2) cb[0] = v; else if (slot == 4) ca[1] = v; else if (slot == 6) cb[1] = v;
     };
     switch (n) {
-      case 256: imdct_wave_sink<8, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink); break;
-      case 512: imdct_wave_sink<9, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink); break;
-      case 1024: imdct_wave_sink<10, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink); break;
-      case 2048: imdct_wave_sink<11, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink); break;
+      case 256: imdct_wave_sink<8, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr); break;
+      case 512: imdct_wave_sink<9, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr); break;
+      case 1024: imdct_wave_sink<10, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr); break;
+      case 2048: imdct_wave_sink<11, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr); break;
       default: __builtin_trap();
     }
     if (pon) {
@@ -582,7 +639,9 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
       *reinterpret_cast<float4*>(own + (half >> 1) + 4 * i8b) = cb[1];
     }
   }
+  EM_T(16);
   __syncthreads();  // drains the staging DMA (vmcnt(0) in front of the barrier): all four quarters of every channel are in LDS
+  EM_T(17);
   if (carry_out) synth_carry_out<NT>(A, planes, n, nch, exec_mask, w_self, tid);  // (such a frame has no NEXT: its plane was written)
   if (self_carry) synth_self_carry<NT>(A, spec, n, nch, w_self, out_self, tid);    // the batch's first frame
   // ---- overlap-add + interleave + clip, every lane of the workgroup: lane task = (overlap, group of four compact indices i0);
@@ -640,6 +699,8 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
     }
   }
   if (A.clip) report_clipped(clipped, A.clipped_flag);
+  EM_T(18);
+#undef EM_T
 }
 
 // ---- paired emission for more than two channels (k_synth8_emit) ------------------------------------------------------------
@@ -852,11 +913,17 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   // ---- residue: one lane per GROUP of consecutive vector components of one chain, all cascade stages with the sums in
   // registers (the reference's additions in the reference's order per element) ----
   {
-    const unsigned rtype = rgeom & 0xFu, rch = rgeom >> 4;
+    const unsigned rtype = rgeom & 7u, rch = rgeom >> 4;
+    const bool dig = (rgeom & NVH_SLAB_RGEOM_DIGITS) != 0;  // (uniform: the header came by scalar loads)
     const bool interleaved = !(rtype == 1 || rch == 1);  // Residue2 over several channels: component k = bin k / rch of channel k % rch
-#define NVH_WALK(G, FUSE, RCH, FP) residue_walk<G, FUSE, RCH, NT>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP)
+#define NVH_WALK(G, FUSE, RCH, FP)                                                                                                 \
+  do {                                                                                                                             \
+    if (dig) residue_walk<G, FUSE, RCH, NT, true>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP); \
+    else residue_walk<G, FUSE, RCH, NT, false>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP);    \
+  } while (0)
     if (GENERAL && group == 1) {
-      residue_walk_general<NT, MAXCH>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid);
+      if (dig) residue_walk_general<NT, MAXCH, true>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid);
+      else residue_walk_general<NT, MAXCH, false>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid);
     } else if (MAXCH <= 2 && (flags & NVH_SLAB_FUSE_FLOOR)) {
       FloorRef F;
       const unsigned c0w = __builtin_amdgcn_readfirstlane(s_chan[0]), c1w = __builtin_amdgcn_readfirstlane(s_chan[1]);
@@ -869,7 +936,8 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
       if (group == 8) NVH_WALK(8, false, 0, nullptr);
       else NVH_WALK(2, false, 0, nullptr);
     } else if (MAXCH > 2 && group == 0) {
-      residue_walk_bins<NT>(slab, off_heads, off_rec, off_ent, lpc, lpc_magic, s_lat, spec, half, rch, tid);  // quirk B-1
+      if (dig) residue_walk_bins<NT, true>(slab, off_heads, off_rec, off_ent, lpc, lpc_magic, s_lat, spec, half, rch, tid);  // quirk B-1
+      else residue_walk_bins<NT, false>(slab, off_heads, off_rec, off_ent, lpc, lpc_magic, s_lat, spec, half, rch, tid);
     } else if (MAXCH > 2) {
       switch (rch) {  // group == 2 * rch (the slab writers)
         case 3: NVH_WALK(6, false, 3, nullptr); break;
@@ -974,8 +1042,13 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   if constexpr (MAXCH <= 2 && MODE >= 1) carry_window = carry_out ? __builtin_amdgcn_readfirstlane(s_chan[2]) : 0u;  // before anything overlays the slab
   if (MAXCH <= 2 && MODE >= 2 && (emit_self || emit_next)) {
     if constexpr (MAXCH <= 2 && MODE >= 2)
+#ifdef NVH_DEBUG
+      synth_emit<NT>(A, smem, spec, s_chan, n, nch, frame, sl, emit_self, emit_next, self_carry, carry_out, exec_mask, planes,
+                     Aa, Bb, Cc, TW, tid, dbg ? dbg + (long long)f * 24 : nullptr);
+#else
       synth_emit<NT>(A, smem, spec, s_chan, n, nch, frame, sl, emit_self, emit_next, self_carry, carry_out, exec_mask, planes,
                      Aa, Bb, Cc, TW, tid);
+#endif
   } else
   if (MAXCH <= 2) {
     // in place over the channel's own spectrum (the transform's slice = n/2 floats + n/16 of padding: channel nch-1 spills its
@@ -985,11 +1058,16 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
       const float* X = spec + wv * half;
       float* out = planes + (long long)wv * A.block1;
       float* scratch = spec + wv * half - (nch - 1 - wv) * (n >> 4);
+#ifdef NVH_DEBUG
+      long long* imdct_stamp = (dbg && wv == 0) ? dbg + (long long)f * 24 + 10 : nullptr;  // transform phases of channel 0's wavefront
+#else
+      long long* imdct_stamp = nullptr;
+#endif
       switch (n) {
-        case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-        case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-        case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
-        case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp); break;
+        case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp); break;
+        case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp); break;
+        case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp); break;
         default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
       }
     } else {

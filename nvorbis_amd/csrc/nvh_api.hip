@@ -518,10 +518,15 @@ extern "C" int nvh_stream_pending_slabs(const nvh_stream* s, uint8_t* buf, int64
 extern "C" int nvh_stream_lattice_pool(const nvh_stream* s, uint32_t* out, int64_t cap_words, int64_t* words) {
   return nvh_guard([&]() -> int {
     if (!s || !words || cap_words < 0 || (cap_words > 0 && !out)) return NVH_ERR_ARGUMENT;
+    // lattice pool, then the value pool of the digit form: what a slab record's 12-bit offset points into
     const std::vector<uint32_t>& L = s->shared->slab.lattice;
-    *words = (int64_t)L.size();
+    const std::vector<uint32_t>& V = s->shared->slab.val_pool;
+    const size_t lw = V.empty() ? L.size() : std::max<size_t>(L.size(), 1);  // (the device image pads an empty lattice pool to one word)
+    *words = (int64_t)(lw + V.size());
     if (*words > cap_words) return NVH_ERR_ARGUMENT;
+    if (lw > L.size()) out[0] = 0u;
     if (!L.empty()) std::memcpy(out, L.data(), L.size() * sizeof(uint32_t));
+    if (!V.empty()) std::memcpy(out + lw, V.data(), V.size() * sizeof(uint32_t));
     return NVH_OK;
   });
 }

@@ -172,6 +172,17 @@ struct NvhFrame {
       ((uint32_t)(lat_off) | ((uint32_t)(lat_values) << 12) | ((uint32_t)(dim) << 20) | ((uint32_t)(channel) << 25) |             \
        ((uint32_t)(stage) << 28) | ((more) ? 0x80000000u : 0u))
 #define NVH_SLAB_MAX_LAT_OFF 0xFFFu  // lattice pool words a record can address
+// Digit form of the entry section (round 5; NvhSlabHdr::rgeom bit 3): instead of uint16 entry numbers the section holds ONE BYTE
+// PER VECTOR COMPONENT, record by record (a record's run = the partition's components in entry order: byte j * dim + d is
+// component d of the record's entry j), value = 4 * (entry / lat_values^d % lat_values) -- the byte offset of the component's
+// float from the book's first word in the value pool (host_slab.h: SlabSetup::val_pool; it follows the lattice pool in the
+// kernels' constants block) -- or 4 * lat_values, the book's +0.0f slot, for a vector that was never added (quirks B-14 / B-16).
+// A record's x then holds the run's offset in the section in units of 2 bytes, its y the book's value-pool offset where the
+// entry form holds the lattice-pool offset.  The base-lat_values digit peel (two exact reciprocal multiplies + a multiply and a
+// subtract per digit pair, ~110 VALU instructions per cascade stage of a lane's eight components) is integer work on what the bit
+// parser decoded: it belongs to the parser, and the kernels' walk is a byte read, an LDS read and an add per component.
+#define NVH_SLAB_RGEOM_DIGITS 8u
+#define NVH_SLAB_MAX_DIGIT 63u       // lat_values of a book the digit form takes: 4 * lat_values fits a byte
 #define NVH_SLAB_SWEEP_COUPLES 1u  // stereo Residue2: the chain walk holds both channels of a bin and couples before its store
 #define NVH_SLAB_MG1 2u            // the magnitude channel of the coupling step is channel 1
 #define NVH_SLAB_COUPLE_PASS 4u    // inverse coupling as a pass of its own between the residue walk and the floor multiply
@@ -195,7 +206,7 @@ struct NvhSlabHdr {      // 64 bytes
   uint16_t off_ent;
   uint16_t vecs;         // size of the slab in 16-byte units
   uint16_t lpc;          // lanes per chain = partition_size / group
-  uint8_t rgeom;         // residue type | real channels << 4
+  uint8_t rgeom;         // residue type (bits 0-2) | NVH_SLAB_RGEOM_DIGITS | real channels << 4
   uint8_t group;         // consecutive vector components one lane owns through all cascade stages: 8 (stereo / per-channel
                          // residues, partition_size % 8 == 0), 2 * channels (Residue2 over more than two channels), else 2
   uint32_t lpc_magic;    // ceil(2^32 / lpc), 0 when lpc <= 1

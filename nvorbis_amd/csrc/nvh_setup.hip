@@ -165,6 +165,9 @@ int upload_setup(nvh_stream* s) {
     };
     std::memcpy(synth_consts.data(), db_table, sizeof db_table);
     synth_consts.insert(synth_consts.end(), lattice.begin(), lattice.end());
+    // the value pool of the digit form (host_slab.h: SlabSetup::val_pool): a record's offset counts from the lattice pool's start
+    const std::vector<uint32_t>& vp = s->shared->slab.val_pool;
+    synth_consts.insert(synth_consts.end(), vp.begin(), vp.end());
     while (synth_consts.size() & 3u) synth_consts.push_back(0u);
   }
   size_t o_sc = ab.add(synth_consts.data(), synth_consts.size() * sizeof(uint32_t));

@@ -330,8 +330,11 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
         assert np.isfinite(got).all()
         assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) <= 1e-6
         exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
-        if name == "floor0_slab" and not any(os.environ.get(t) for t in ("NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_NO_SLAB")):
-            assert exact == 1.0, exact
+        # Both configurations take the slab kernels by default (floor0_stereo's odd-dimension books through the general bin walk
+        # since round 4), where Floor0 is host-evaluated: bit-exact.  Only the replays that force the descriptor kernels
+        # (k_spectrum_f0: device cos / sqrt / exp) are held to the tolerance alone.
+        if not any(os.environ.get(t) for t in ("NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_NO_SLAB")):
+            assert exact == 1.0, (name, exact)
         else:
             assert exact > 0.99, (name, exact)
 

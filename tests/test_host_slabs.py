@@ -221,7 +221,12 @@ def test_slab_residue_records_structure(ogg_bytes):
                 dims = (recs[:, 1] >> 20) & 31
                 assert (dims >= 2).all() and ((dims & 1) == 0).all()
                 assert (recs[:, 0] >> 16 == (65536 + dims - 1) // dims).all()
-                assert ((recs[:, 0] & 0xFFFF) < nent).all()
+                if h["rgeom"] & 8:  # digit form: a record's run of partition_size bytes, offset in units of two bytes
+                    psz = h["lpc"] * h["group"]
+                    assert (((recs[:, 0] & 0xFFFF).astype(np.int64) * 2 + psz) <= nent * 2).all()
+                    assert np.unique(recs[:, 0] & 0xFFFF).size == h["nrec"]  # runs do not overlap
+                else:
+                    assert ((recs[:, 0] & 0xFFFF) < nent).all()
                 stage = (recs[:, 1] >> 28) & 7
                 for a, b in zip(starts, np.append(starts[1:], h["nrec"])):
                     assert (np.diff(stage[a:b].astype(np.int64)) > 0).all()  # one chain: strictly rising cascade stages
@@ -296,6 +301,8 @@ def _slab_residue_sums(words, h, lat, nch, half):
     first, xb = (hw & 0xFFFF).astype(np.int64), (hw >> 16).astype(np.int64)
     recs = words[h["off_rec"] * 4:][:2 * h["nrec"]].reshape(h["nrec"], 2)
     ent = words[h["off_ent"] * 4:].view(np.uint16)
+    dig = bool(h["rgeom"] & 8)  # digit form (nvh_format.h: NVH_SLAB_RGEOM_DIGITS): one byte per component, 4 * digit
+    dbytes = words[h["off_ent"] * 4:].view(np.uint8)
     # (pass, type, channels of a Residue2 interleave, partition size) of every chain
     geo = [None] * h["nheads"]
     if h["group"] == 1:
@@ -308,7 +315,7 @@ def _slab_residue_sums(words, h, lat, nch, half):
                 if cix != 0xFFFF:
                     geo[int(cix)] = ((geom >> 8) & 15, geom & 15, (geom >> 4) & 15, psz)
     else:
-        rtype, rch = h["rgeom"] & 15, h["rgeom"] >> 4
+        rtype, rch = h["rgeom"] & 7, h["rgeom"] >> 4
         psz = int(words[h["lpc"] * 4 + 1]) if h["group"] == 0 else h["lpc"] * h["group"]
         geo = [(0, rtype, rch if rtype == 2 else 1, psz)] * h["nheads"]
     writes = []  # (pass, stage, first bin, chain, record)
@@ -325,13 +332,22 @@ def _slab_residue_sums(words, h, lat, nch, half):
         _, rtype, rch, psz = geo[cix]
         dims, lv, lat_off, chan = (y >> 20) & 31, (y >> 12) & 0xFF, y & 0xFFF, (y >> 25) & 7
         eb = ent[(x & 0xFFFF):]
+        db = dbytes[2 * (x & 0xFFFF):]
         steps = psz // dims
         for q in range(psz):
             j, comp = (q % steps, q // steps) if rtype == 0 else (q // dims, q % dims)
-            e = int(eb[j])
-            if e == 0xFFFF:
-                continue
-            v = lat[lat_off + (e // lv ** comp) % lv: lat_off + (e // lv ** comp) % lv + 1].view(np.float32)[0]
+            if dig:
+                b4 = int(db[j * dims + comp])
+                assert b4 % 4 == 0 and b4 // 4 <= lv
+                if b4 // 4 == lv:  # the book's +0.0f slot: no vector was added here
+                    assert lat[lat_off + lv] == 0
+                    continue
+                v = lat[lat_off + b4 // 4: lat_off + b4 // 4 + 1].view(np.float32)[0]
+            else:
+                e = int(eb[j])
+                if e == 0xFFFF:
+                    continue
+                v = lat[lat_off + (e // lv ** comp) % lv: lat_off + (e // lv ** comp) % lv + 1].view(np.float32)[0]
             c, b = (q % rch, x0 + q // rch) if (rtype == 2 and rch > 1) else (chan, x0 + q)
             if b < half:
                 spec[c, b] = np.float32(spec[c, b] + v)

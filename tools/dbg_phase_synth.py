@@ -48,6 +48,22 @@ if d[:, 6].any():  # k_synth8 / unfused floor: the wait for the slowest walker, 
     for nm, a, b_ in (("  wait for the slowest walker", 3, 6), ("  coupling passes", 6, 7), ("  floor multiply", 7, 4)):
         dt = d[:, b_] - d[:, a]
         print("%-34s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (nm, dt.mean(), np.median(dt), np.percentile(dt, 90)))
+# odd frames (first launch: k_synth_tail) and even frames (second launch: k_synth_emit) apart, with the transform's own stamps
+# (imdct_wave.h: 10 entry, 11 step 0 done, 12 radix passes done, 13 D = 4, 2, 1 done, 14 end) and the emission's (15 staging
+# issued, 16 transform done, 17 behind the barrier, 18 emitted)
+def show(tag, sel, pairs):
+    for nm, a, b_ in pairs:
+        ok = sel & (d[:, a] != 0) & (d[:, b_] != 0)
+        if ok.sum() == 0:
+            continue
+        dt = (d[:, b_] - d[:, a])[ok]
+        print("  %-5s %-40s mean %8.0f  p50 %8.0f  p90 %8.0f cycles (n=%d)" % (tag, nm, dt.mean(), np.median(dt), np.percentile(dt, 90), int(ok.sum())))
+fidx = np.arange(nframes)
+odd, even = (fidx & 1) == 1, (fidx & 1) == 0
+common = [("DMA + clear + barrier", 0, 1), ("header", 1, 2), ("walk (+ fused floor)", 2, 3), ("walk end -> transform entry", 3, 10),
+          ("step 0 (incl. barrier, table loads)", 10, 11), ("radix passes", 11, 12), ("D = 4, 2, 1", 12, 13), ("bit reversal + steps 7, 8 (+ stores)", 13, 14)]
+show("odd", odd, common + [("transform end -> WG end", 14, 5), ("lifetime", 0, 5)])
+show("even", even, common + [("walk end -> staging issued", 3, 15), ("transform end -> barrier passed", 16, 17), ("emission", 17, 18), ("lifetime", 0, 5)])
 life = d[:, 5] - d[:, 0]
 print("WG lifetime mean %.0f p50 %.0f p90 %.0f cycles" % (life.mean(), np.median(life), np.percentile(life, 90)))
 w0 = d[:, 22].min()
