@@ -609,7 +609,7 @@ k_ola_emit(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, const 
       if (prev && j >= 0 && j < fr.ov_len) v = v + prev[(long long)c * S.block1 + fr.ov_src + j];  // OverlapBuffers
     }
     if (clip) v = clip_value(v, &clipped);
-    out[o] = v;
+    pcm_store1(out + o, v);
   }
   report_clipped(clipped, clipped_flag);
 }
@@ -641,7 +641,7 @@ k_ola_emit_seq(NvhDevSetup S, NvhDevBatch Bt, float* __restrict__ work, const fl
       int t = o / ch, c = o - t * ch;
       float v = (fr.n == 0) ? prev[(long long)c * S.block1 + fr.ov_src + t] : cur[(long long)c * S.block1 + fr.emit_start + t];
       if (clip) v = clip_value(v, &clipped);
-      out[o] = v;
+      pcm_store1(out + o, v);
     }
     __syncthreads();
   }
@@ -705,7 +705,7 @@ __device__ __forceinline__ int ola_vec(const NvhDevSetup& S, const NvhFrame& fr,
     }
     float4* o4 = reinterpret_cast<float4*>(out) + (long long)g * CH;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) o4[k] = make_float4(flat[4 * k], flat[4 * k + 1], flat[4 * k + 2], flat[4 * k + 3]);
+    for (int k = 0; k < CH; ++k) pcm_store4(o4 + k, flat[4 * k], flat[4 * k + 1], flat[4 * k + 2], flat[4 * k + 3]);
   }
   return clipped;
 }
@@ -755,8 +755,8 @@ __device__ __forceinline__ int ola_sym(const NvhDevSetup& S, const NvhFrame& fr,
     float4* om = reinterpret_cast<float4*>(out) + (long long)((n >> 3) - 1 - g) * CH;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-      of[k] = make_float4(fwd[4 * k], fwd[4 * k + 1], fwd[4 * k + 2], fwd[4 * k + 3]);
-      om[k] = make_float4(mir[4 * k], mir[4 * k + 1], mir[4 * k + 2], mir[4 * k + 3]);
+      pcm_store4(of + k, fwd[4 * k], fwd[4 * k + 1], fwd[4 * k + 2], fwd[4 * k + 3]);
+      pcm_store4(om + k, mir[4 * k], mir[4 * k + 1], mir[4 * k + 2], mir[4 * k + 3]);
     }
   }
   return clipped;
@@ -815,7 +815,7 @@ __device__ __forceinline__ int ola_sym_lds(const NvhDevSetup& S, const NvhFrame&
       if (clip) x = clip_value(x, &clipped);
       e[k] = x;
     }
-    (mir ? oM : oF)[jj] = make_float4(e[0], e[1], e[2], e[3]);
+    pcm_store4((mir ? oM : oF) + jj, e[0], e[1], e[2], e[3]);
   }
   return clipped;
 }
@@ -927,7 +927,7 @@ k_ola_compact(NvhDevSetup S, NvhDevBatch Bt, const float* __restrict__ work, con
       }
     }
     if (clip) v = clip_value(v, &clipped);
-    out[o] = v;
+    pcm_store1(out + o, v);
   }
   report_clipped(clipped, clipped_flag);
 }

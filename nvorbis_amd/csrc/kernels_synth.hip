@@ -44,12 +44,29 @@
 
 namespace {
 
+// Ablation builds (tools/build_variant.py NAME -DNVH_ABL_...): one phase of the slab kernels left out, to read its marginal cost
+// in the regime the headline runs in (three streams, slots always full) -- results are wrong by construction, never shipped.
+#ifdef NVH_ABL_NO_XFORM
+constexpr int kAblSkip = 3;  // the transform without its radix passes and the D = 4, 2, 1 pass
+#else
+constexpr int kAblSkip = 0;
+#endif
+
 // 16 bytes per lane, 1 KB per wavefront-instruction, global -> LDS without a register round trip.  The LDS destination is
 // wave-uniform (M0) + lane * 16; lanes that are switched off move nothing.
+template <int AUX = 0>  // AUX 2: `nt`, for data this launch reads exactly once (the slabs)
 __device__ __forceinline__ void dma16(const uint4* __restrict__ gsrc, float* lds_chunk_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_chunk_base, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_chunk_base, 16, 0, AUX);
 }
+#ifdef NVH_SLAB_NT
+constexpr int kSlabAux = 2, kSlabAuxOdd = 2;
+#elif defined(NVH_SLAB_NT_ODD)
+constexpr int kSlabAux = 0, kSlabAuxOdd = 2;  // the odd launch's own slabs (the even launch's are touched into L2 by the odd one)
+#else
+constexpr int kSlabAux = 0, kSlabAuxOdd = 0;
+#endif
+constexpr int kStageAux = 2;  // the neighbours' quarters are read once, by this workgroup: 22.0 -> 20.8 us per pass (three streams)
 
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
 #pragma unroll
@@ -546,13 +563,13 @@ __device__ __forceinline__ void synth_self_carry(const NvhSynthArgs& A, const fl
     if (nch == 2) {
       float4* of = reinterpret_cast<float4*>(out) + 2 * (long long)g;
       float4* om = reinterpret_cast<float4*>(out) + 2 * (long long)((n >> 3) - 1 - g);
-      of[0] = make_float4(fwd[0], fwd[1], fwd[2], fwd[3]);
-      of[1] = make_float4(fwd[4], fwd[5], fwd[6], fwd[7]);
-      om[0] = make_float4(mir[0], mir[1], mir[2], mir[3]);
-      om[1] = make_float4(mir[4], mir[5], mir[6], mir[7]);
+      pcm_store4(of, fwd[0], fwd[1], fwd[2], fwd[3]);
+      pcm_store4(of + 1, fwd[4], fwd[5], fwd[6], fwd[7]);
+      pcm_store4(om, mir[0], mir[1], mir[2], mir[3]);
+      pcm_store4(om + 1, mir[4], mir[5], mir[6], mir[7]);
     } else {
-      reinterpret_cast<float4*>(out)[g] = make_float4(fwd[0], fwd[2], fwd[4], fwd[6]);
-      reinterpret_cast<float4*>(out)[(n >> 3) - 1 - g] = make_float4(mir[0], mir[2], mir[4], mir[6]);
+      pcm_store4(reinterpret_cast<float4*>(out) + g, fwd[0], fwd[2], fwd[4], fwd[6]);
+      pcm_store4(reinterpret_cast<float4*>(out) + ((n >> 3) - 1 - g), mir[0], mir[2], mir[4], mir[6]);
     }
   }
   if (A.clip) report_clipped(clipped, A.clipped_flag);
@@ -596,10 +613,14 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
       if (u < units) {
         const int c = u >> sh, r = u & (per_ch - 1);
         const bool is_a = r >= q16;
+#ifdef NVH_ABL_NO_STAGE
+        if (false) {
+#else
         if (is_a ? emit_next : (emit_self && !self_carry)) {
+#endif
           const float* src = is_a ? A.work + ((long long)(frame + 1) * nch + c) * A.block1 + 4 * (r - q16)
                                   : A.work + ((long long)(frame - 1) * nch + c) * A.block1 + half + 4 * r;
-          dma16(reinterpret_cast<const uint4*>(src), stage + 4 * u0);
+          dma16<kStageAux>(reinterpret_cast<const uint4*>(src), stage + 4 * u0);
         }
       }
     }
@@ -617,10 +638,10 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
       if (slot == 0) ca[0] = v; else if (slot == 2) cb[0] = v; else if (slot == 4) ca[1] = v; else if (slot == 6) cb[1] = v;
     };
     switch (n) {
-      case 256: imdct_wave_sink<8, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr); break;
-      case 512: imdct_wave_sink<9, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr); break;
-      case 1024: imdct_wave_sink<10, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr); break;
-      case 2048: imdct_wave_sink<11, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr); break;
+      case 256: imdct_wave_sink<8, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
+      case 512: imdct_wave_sink<9, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
+      case 1024: imdct_wave_sink<10, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
+      case 2048: imdct_wave_sink<11, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
       default: __builtin_trap();
     }
     if (pon) {
@@ -648,7 +669,11 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
   // it produces sample times i0 .. i0 + 3 and n/2 - 4 - i0 .. n/2 - 1 - i0 of every channel (kernels.hip: ola_sym) ----
   int clipped = 0;
   const int groups = n >> 4;  // per overlap
+#ifdef NVH_ABL_NO_EMIT_LOOP
+  for (int t = tid; t < 0; t += NT) {
+#else
   for (int t = tid; t < 2 * groups; t += NT) {
+#endif
     const bool nx = t >= groups;
     if (nx ? !emit_next : (!emit_self || self_carry)) continue;
     const int g = nx ? t - groups : t, i0 = 4 * g;
@@ -656,10 +681,15 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
     const float* __restrict__ wp = A.windows + (nx ? wp_next : wp_self);
     // (fetching these in front of the barrier above, next to the staging DMA, was tried: the kernel sits at its 64-VGPR cap and
     // spills 32-48 registers for it)
+#ifdef NVH_ABL_NO_WINDOW_LOAD
+    const float4 wf = make_float4(0.5f, 0.25f, 0.125f, 0.75f), wm = wf, pf = wf, pm = wf;
+    (void)w; (void)wp;
+#else
     const float4 wf = *reinterpret_cast<const float4*>(w + i0);
     const float4 wm = *reinterpret_cast<const float4*>(w + (half - 4 - i0));
     const float4 pf = *reinterpret_cast<const float4*>(wp + (half + i0));
     const float4 pm = *reinterpret_cast<const float4*>(wp + (n - 4 - i0));
+#endif
     float fwd[8], mir[8];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -675,27 +705,35 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
         float4 u = make_float4(-a.w * wm.x, -a.z * wm.y, -a.y * wm.z, -a.x * wm.w);
         const float4 r = make_float4(b.w * pm.x, b.z * pm.y, b.y * pm.z, b.x * pm.w);
         u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
+#ifndef NVH_ABL_NO_CLIP
         if (A.clip) {
           v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
           v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
           u.x = clip_value(u.x, &clipped); u.y = clip_value(u.y, &clipped);
           u.z = clip_value(u.z, &clipped); u.w = clip_value(u.w, &clipped);
         }
+#endif
         fwd[c] = v.x; fwd[2 + c] = v.y; fwd[4 + c] = v.z; fwd[6 + c] = v.w;
         mir[c] = u.x; mir[2 + c] = u.y; mir[4 + c] = u.z; mir[6 + c] = u.w;
       }
     }
     float* out = A.pcm + (long long)(nx ? out_next : out_self) * nch;
+#ifdef NVH_ABL_PCM_SMALL
+    out = A.pcm + (long long)((nx ? out_next : out_self) & 0x7FFF) * nch;  // (ablation build: every frame's PCM into the same 256 KB)
+#endif
+#ifdef NVH_ABL_NO_PCM_STORE
+    if (fwd[0] != 1.2345e-30f) continue;  // (ablation build: the arithmetic kept alive, the stores left out)
+#endif
     if (nch == 2) {
       float4* of = reinterpret_cast<float4*>(out) + 2 * (long long)g;
       float4* om = reinterpret_cast<float4*>(out) + 2 * (long long)((n >> 3) - 1 - g);
-      of[0] = make_float4(fwd[0], fwd[1], fwd[2], fwd[3]);
-      of[1] = make_float4(fwd[4], fwd[5], fwd[6], fwd[7]);
-      om[0] = make_float4(mir[0], mir[1], mir[2], mir[3]);
-      om[1] = make_float4(mir[4], mir[5], mir[6], mir[7]);
+      pcm_store4(of, fwd[0], fwd[1], fwd[2], fwd[3]);
+      pcm_store4(of + 1, fwd[4], fwd[5], fwd[6], fwd[7]);
+      pcm_store4(om, mir[0], mir[1], mir[2], mir[3]);
+      pcm_store4(om + 1, mir[4], mir[5], mir[6], mir[7]);
     } else {
-      reinterpret_cast<float4*>(out)[g] = make_float4(fwd[0], fwd[2], fwd[4], fwd[6]);
-      reinterpret_cast<float4*>(out)[(n >> 3) - 1 - g] = make_float4(mir[0], mir[2], mir[4], mir[6]);
+      pcm_store4(reinterpret_cast<float4*>(out) + g, fwd[0], fwd[2], fwd[4], fwd[6]);
+      pcm_store4(reinterpret_cast<float4*>(out) + ((n >> 3) - 1 - g), mir[0], mir[2], mir[4], mir[6]);
     }
   }
   if (A.clip) report_clipped(clipped, A.clipped_flag);
@@ -793,7 +831,7 @@ __device__ __forceinline__ void synth_emit8(const NvhSynthArgs& A, float* s_run,
         if (A.clip) x = clip_value(x, &clipped);
         e[k] = x;
       }
-      (mir ? oM : oF)[jj] = make_float4(e[0], e[1], e[2], e[3]);
+      pcm_store4((mir ? oM : oF) + jj, e[0], e[1], e[2], e[3]);
     }
     __syncthreads();
   }
@@ -864,8 +902,9 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   constexpr unsigned kSpec = MAXCH > 2 ? 2 * NT : NT;  // 16-byte units fetched before the header is known
   {
     const int v = tid;  // 16-byte unit handled by this lane: wavefront w moves units [64 w, 64 w + 64)
-    if (v < A.cap_vecs) dma16(gslab + v, slab + wv * 256);
-    if (MAXCH > 2 && NT + v < A.cap_vecs) dma16(gslab + NT + v, slab + (NT / 64 + wv) * 256);  // big slabs: 16 KB up front
+    constexpr int kAux = (MAXCH <= 2 && MODE < 2) ? kSlabAuxOdd : kSlabAux;
+    if (v < A.cap_vecs) dma16<kAux>(gslab + v, slab + wv * 256);
+    if (MAXCH > 2 && NT + v < A.cap_vecs) dma16<kSlabAux>(gslab + NT + v, slab + (NT / 64 + wv) * 256);  // big slabs: 16 KB up front
     for (int c0 = wv * 64; c0 < A.const_vecs; c0 += NT)
       if (c0 + lane < A.const_vecs) dma16(A.consts + c0 + lane, smem + c0 * 4);
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -886,7 +925,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
   if (vecs > kSpec) {
     for (unsigned c0 = kSpec + wv * 64; c0 < vecs; c0 += NT)
-      if (c0 + lane < vecs) dma16(gslab + c0 + lane, slab + c0 * 4);
+      if (c0 + lane < vecs) dma16<kSlabAux>(gslab + c0 + lane, slab + c0 * 4);
   }
   __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
   SY_T(1);
@@ -921,6 +960,10 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     if (dig) residue_walk<G, FUSE, RCH, NT, true>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP); \
     else residue_walk<G, FUSE, RCH, NT, false>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP);    \
   } while (0)
+#ifdef NVH_ABL_NO_WALK
+    if (true) {
+    } else
+#endif
     if (GENERAL && group == 1) {
       if (dig) residue_walk_general<NT, MAXCH, true>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid);
       else residue_walk_general<NT, MAXCH, false>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid);
@@ -1064,10 +1107,10 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
       long long* imdct_stamp = nullptr;
 #endif
       switch (n) {
-        case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp); break;
-        case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp); break;
-        case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp); break;
-        case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp); break;
+        case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
+        case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
+        case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
+        case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
         default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
       }
     } else {
