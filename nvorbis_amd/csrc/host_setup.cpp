@@ -615,6 +615,30 @@ void build_mdct_tables(int n, MdctTables& t) {  // Mdct.cs:30-63
       }
       remain -= R;
     }
+    // The output stage's gather addresses (imdct_wave.h: steps 4-6 fused with 7 and 8).  Pair index p reads the four float2 slots
+    // u[BR[2i]], u[BR[2i+1]] (i = 2p + h) and u[BR[2i']+2], u[BR[2i'+1]+2] (i' = n/16 - 1 - i) for h = 0, 1 from the rotated
+    // layout the last pass leaves: eight slot numbers that depend on the lane alone, ~100 integer instructions per lane to
+    // derive -- one 16-byte table entry per pair instead, behind the pass twiddles (16-byte aligned): uint16 x 8 =
+    // e0, e1, g0, g1 of h = 0, then of h = 1.
+    while (t.tw.size() & 3u) t.tw.push_back(0.0f);
+    t.fin_off = t.tw.size();
+    auto phys_rot = [](int c) {
+      const int b = c >> 3, p = c & 7;
+      return ((b + (b >> 3)) << 3) + ((((p >> 1) + (b >> 2)) & 3) << 1) + (p & 1);
+    };
+    const int npairs = n >> 5;
+    t.tw.resize(t.fin_off + (size_t)4 * npairs);
+    uint16_t* f = reinterpret_cast<uint16_t*>(t.tw.data() + t.fin_off);
+    for (int p = 0; p < npairs; ++p)
+      for (int h = 0; h < 2; ++h) {
+        const int i = 2 * p + h, ir = (n >> 4) - 1 - i;
+        const int kE0 = (int)bit_reverse((uint32_t)(2 * i), ld - 3) << 2, kE1 = (int)bit_reverse((uint32_t)(2 * i + 1), ld - 3) << 2;
+        const int kD0 = (int)bit_reverse((uint32_t)(2 * ir), ld - 3) << 2, kD1 = (int)bit_reverse((uint32_t)(2 * ir + 1), ld - 3) << 2;
+        f[8 * p + 4 * h + 0] = (uint16_t)phys_rot(kE0 >> 1);
+        f[8 * p + 4 * h + 1] = (uint16_t)phys_rot(kE1 >> 1);
+        f[8 * p + 4 * h + 2] = (uint16_t)phys_rot((kD0 >> 1) + 1);
+        f[8 * p + 4 * h + 3] = (uint16_t)phys_rot((kD1 >> 1) + 1);
+      }
   }
 }
 

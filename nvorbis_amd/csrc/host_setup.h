@@ -103,6 +103,7 @@ struct MdctTables {                // Mdct.cs:30-63
   // lane needs, laid out [pair component][set] so that the 64 lanes of a wave read consecutive floats.
   // Same float values as `a` (bit copies); empty for n < 256.
   std::vector<float> tw;
+  size_t fin_off = 0;  // float offset inside tw of the output stage's gather-address table (build_mdct_tables)
 };
 
 struct Setup {

@@ -61,6 +61,19 @@ struct Geo {
   static constexpr int LDS_FLOATS = 2 * (N + (N >> 3));  // padded
 };
 
+// Floats of a block size's pass twiddles in the lane-ordered table (host_setup.cpp: build_mdct_tables), rounded up to a 16-byte
+// boundary: where the output stage's gather-address table begins.
+template <int LD>
+constexpr int tw_pass_floats() {
+  int total = 0, remain = LD - 5;
+  while (remain > 0) {
+    const int R = remain >= 3 ? 3 : remain;
+    total += 2 * ((1 << R) - 1) * ((1 << (LD - 2)) >> R);
+    remain -= R;
+  }
+  return (total + 3) & ~3;
+}
+
 // One register pass over R radix-2 stages whose smallest distance is S complex points.
 // TW: this pass's lane-ordered twiddles, [pair component][set] (host_setup.cpp build_mdct_tables).
 template <int LD, int R, int S, bool ROT_OUT = false>
@@ -347,6 +360,14 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
   constexpr bool kPre = (INPLACE && !WGSYNC && (G::n >> 5) <= 64) || PF;
   constexpr int ITERO = kPre ? (((G::n >> 5) + 63) / 64) : 1;
   float4 pcc[ITERO][2], pbl[ITERO][2], pbh[ITERO][2];
+  // ... and, one pair per lane, its eight gather slots from the table behind the pass twiddles instead of ~100 integer
+  // instructions of bit reversal and layout arithmetic
+  constexpr bool kFinTab = kPre && ITERO == 1;
+  uint4 fin = make_uint4(0u, 0u, 0u, 0u);
+  if constexpr (kFinTab) {
+    const int pp = lane < (G::n >> 5) ? lane : (G::n >> 5) - 1;
+    fin = reinterpret_cast<const uint4*>(TW + tw_pass_floats<LD>())[pp];
+  }
   if constexpr (kPre) {
 #pragma unroll
     for (int it = 0; it < ITERO; ++it) {
@@ -385,11 +406,19 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       const int kD0 = (int)(__brev((unsigned)(2 * ir)) >> (32 - (LD - 3))) << 2;
       const int kD1 = (int)(__brev((unsigned)(2 * ir + 1)) >> (32 - (LD - 3))) << 2;
       // v[d1+3]=u[k], v[d1+2]=u[k+1] (k=BR[2i]); v[d1+1]=u[k'], v[d1]=u[k'+1] (k'=BR[2i+1]); d1 = n2-4-4i
-      const float2 e0 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot(kE0 >> 1));
-      const float2 e1 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot(kE1 >> 1));
+      float2 e0, e1, g0, g1;
+      if constexpr (kFinTab) {
+        const unsigned we = h == 0 ? fin.x : fin.z, wg = h == 0 ? fin.y : fin.w;
+        const float2* l2c = reinterpret_cast<const float2*>(lf);
+        e0 = l2c[we & 0xFFFFu]; e1 = l2c[we >> 16];
+        g0 = l2c[wg & 0xFFFFu]; g1 = l2c[wg >> 16];
+      } else {
+      e0 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot(kE0 >> 1));
+      e1 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot(kE1 >> 1));
       // v[d0+3]=u[k+2], v[d0+2]=u[k+3] (k=BR[2i']); v[d0+1]=u[k'+2], v[d0]=u[k'+3]; d0 = n4-4-4i' = 4i
-      const float2 g0 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot((kD0 >> 1) + 1));
-      const float2 g1 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot((kD1 >> 1) + 1));
+      g0 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot((kD0 >> 1) + 1));
+      g1 = *reinterpret_cast<const float2*>(lf + 2 * phys_rot((kD1 >> 1) + 1));
+      }
       float vD0 = g1.y, vD1 = g1.x, vD2 = g0.y, vD3 = g0.x;  // v[4i .. 4i+3]
       float vE0 = e1.y, vE1 = e1.x, vE2 = e0.y, vE3 = e0.x;  // v[n2-4-4i .. n2-1-4i]
       // step 7 (Mdct.cs:217-258) for iteration i: c = d = 4i, e = n2-4-4i

@@ -630,7 +630,11 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
   float4 ca[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, cb[2] = {ca[0], ca[0]};
   const bool pon = lane < (n >> 5);  // lanes with output: four values of each quarter at 4 i8, i8 = lane and i8 = n/16 - 1 - lane
   const int i8a = lane, i8b = (n >> 4) - 1 - lane;
+#ifdef NVH_ABL_NO_XFORM_ALL
+  const bool xform = false;
+#else
   const bool xform = wv < nch;  // every channel of an emitting frame executes (host: steady)
+#endif
   if (xform) {
     const float* X = spec + wv * half;
     float* scratch = spec + wv * half - (nch - 1 - wv) * (n >> 4);
@@ -669,14 +673,10 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
   // it produces sample times i0 .. i0 + 3 and n/2 - 4 - i0 .. n/2 - 1 - i0 of every channel (kernels.hip: ola_sym) ----
   int clipped = 0;
   const int groups = n >> 4;  // per overlap
-#ifdef NVH_ABL_NO_EMIT_LOOP
-  for (int t = tid; t < 0; t += NT) {
-#else
-  for (int t = tid; t < 2 * groups; t += NT) {
-#endif
-    const bool nx = t >= groups;
-    if (nx ? !emit_next : (!emit_self || self_carry)) continue;
-    const int g = nx ? t - groups : t, i0 = 4 * g;
+  // One task: NX = which overlap (a wave-uniform value when a wavefront's 64 tasks lie inside one overlap, i.e. n >= 1024: the
+  // window / output / LDS bases are then scalar selects instead of per-lane 64-bit arithmetic).
+  auto task = [&](const bool nx, const int g) {
+    const int i0 = 4 * g;
     const float* __restrict__ w = A.windows + (nx ? w_next : w_self);
     const float* __restrict__ wp = A.windows + (nx ? wp_next : wp_self);
     // (fetching these in front of the barrier above, next to the staging DMA, was tried: the kernel sits at its 64-VGPR cap and
@@ -706,6 +706,8 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
         const float4 r = make_float4(b.w * pm.x, b.z * pm.y, b.y * pm.z, b.x * pm.w);
         u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
 #ifndef NVH_ABL_NO_CLIP
+        // (a pre-test on the task's largest |x| in front of the compares and selects was tried twice: a wavefront's 1024 samples
+        // of loud material nearly always hold one that clips, so the slow path runs anyway)
         if (A.clip) {
           v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
           v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
@@ -722,7 +724,7 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
     out = A.pcm + (long long)((nx ? out_next : out_self) & 0x7FFF) * nch;  // (ablation build: every frame's PCM into the same 256 KB)
 #endif
 #ifdef NVH_ABL_NO_PCM_STORE
-    if (fwd[0] != 1.2345e-30f) continue;  // (ablation build: the arithmetic kept alive, the stores left out)
+    if (fwd[0] != 1.2345e-30f) return;  // (ablation build: the arithmetic kept alive, the stores left out)
 #endif
     if (nch == 2) {
       float4* of = reinterpret_cast<float4*>(out) + 2 * (long long)g;
@@ -734,6 +736,20 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
     } else {
       pcm_store4(reinterpret_cast<float4*>(out) + g, fwd[0], fwd[2], fwd[4], fwd[6]);
       pcm_store4(reinterpret_cast<float4*>(out) + ((n >> 3) - 1 - g), mir[0], mir[2], mir[4], mir[6]);
+    }
+  };
+  const bool do_self = emit_self && !self_carry;
+#ifdef NVH_ABL_NO_EMIT_LOOP
+  for (int t = tid; t < 0; t += NT) {
+#else
+  for (int t = tid; t < 2 * groups; t += NT) {
+#endif
+    if (groups >= 64) {  // (uniform) a wavefront's tasks belong to one overlap
+      const bool nx = __builtin_amdgcn_readfirstlane((int)(t >= groups)) != 0;
+      if (nx ? emit_next : do_self) task(nx, nx ? t - groups : t);
+    } else {
+      const bool nx = t >= groups;
+      if (nx ? emit_next : do_self) task(nx, nx ? t - groups : t);
     }
   }
   if (A.clip) report_clipped(clipped, A.clipped_flag);
@@ -866,6 +882,9 @@ __device__ __forceinline__ void synth_carry_out8(const NvhSynthArgs& A, const fl
 template <int NT, int MAXCH, int MODE = 0, bool GENERAL = false>
 __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+#ifdef NVH_ABL_EMPTY0
+  if (A.f0 >= 0) return;  // (ablation build: the launch alone)
+#endif
   // Which frame this workgroup takes.  Workgroups go round the eight XCDs by index (workgroup b runs on XCD b % 8, each XCD
   // with an L2 of its own), so with A.xcd_map the launch's frame list is cut into eight contiguous runs, one per XCD: frame
   // 2k of the even launch and frames 2k - 1, 2k + 1 of the odd launch then ran on the same XCD (except at the seven cuts), and
@@ -929,6 +948,9 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   }
   __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
   SY_T(1);
+#ifdef NVH_ABL_EMPTY1
+  if (A.f0 >= 0) return;  // (ablation build: launch + the one round trip)
+#endif
   const int n = (int)(w0 & 0xFFFFu);
   if (n == 0) return;
   const unsigned exec_mask = (w0 >> 16) & 0xFFu, flags = w0 >> 24;
@@ -1073,7 +1095,11 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   const float* Bb = A.mdct_b[sl];
   const float* Cc = A.mdct_c[sl];
   const float* TW = A.mdct_tw[sl];
+#ifdef NVH_ABL_NO_XFORM_ALL
+  const bool xform = false;
+#else
   const bool xform = wv < nch && ((exec_mask >> wv) & 1u);
+#endif
   bool emit_self = false, emit_next = false, self_carry = false, carry_out = false;
   if constexpr (MAXCH <= 2 && MODE >= 2) {
     emit_self = A.pcm != nullptr && (flags & NVH_SLAB_EMIT_SELF);
