@@ -224,20 +224,21 @@ def check_digests(insts, seeds, no_check=False):
     import hashlib
     path = os.path.join(ROOT, "tests", "golden", "bench_pcm_digests.json")
     want = json.load(open(path))["digests"]
-    ok, n = True, 0
+    ok, n, total = True, 0, 0
     for (_, _, _, batches_k), seed in zip(insts, seeds):
-        ref = want.get("seed%d" % seed)
-        if ref is None:
-            continue
+        ref = want.get("seed%d" % seed) or []
+        total += len(batches_k)
         for j, (b, pcm) in enumerate(batches_k):
             if j >= len(ref):
-                break
+                break  # no committed digest for this batch: counted in `total`, not in `n` (the line shows both)
             got = hashlib.sha256(pcm.cpu().numpy().tobytes()).hexdigest()
             n += 1
             if got != ref[j]:
                 ok = False
                 sys.stderr.write("bench.py: PCM digest mismatch (seed %d, batch %d)\n" % (seed, j))
-    return ok, n
+    if n < total:
+        sys.stderr.write("bench.py: %d of %d timed batches have no committed digest (tools/gen_bench_digests.py)\n" % (total - n, total))
+    return ok, n, total
 
 
 def config_lines(nv, torch, ctx, root):
@@ -332,6 +333,92 @@ def config_lines(nv, torch, ctx, root):
     return out
 
 
+def pin_to_gpu_numa(torch, local_rank):
+    """Best effort: this process (and the worker threads it starts) onto the CPUs of the NUMA node the GPU hangs off, so that
+    N ranks x W parser threads do not fight over one socket.  Returns a short description for the line."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return "numa node unknown (%s)" % bdf
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return "numa node %d has no allowed CPU" % node
+        os.sched_setaffinity(0, cpus)
+        return "numa node %d, %d CPUs" % (node, len(cpus))
+    except Exception as e:  # containers without sysfs, torch builds without the PCI fields: stay where we are
+        return "not pinned (%s)" % (repr(e)[:80])
+
+
+def c5_block(nv, torch, dist, rank, world, local_rank, scale, workers, share_gpu):
+    """BASELINE.json configs[4] inside the bench line: the 1004-file corpus (tests/c5_corpus.py, length scale `scale`) sharded
+    file-parallel over the ranks (LPT by compressed size, no data-path collective), decoded by every rank into one device arena
+    with the GPU packet parser, then the north star's ONE collective: the gather of the PCM to rank 0, device to device
+    (nvorbis_amd.corpus.gather_pcm: all_gather of the counts + grouped point-to-point payloads over RCCL / xGMI).  Rank 0 checks
+    every file's PCM against the oracle's committed SHA-256 (tests/golden/c5_digests_scale*.json) outside the timed regions."""
+    from nvorbis_amd import corpus
+    from tests import c5_corpus
+    dig = c5_corpus.load_digests(scale)
+    files = c5_corpus.build_files(scale)
+    shards = corpus.lpt_shards([len(f) for f in files], world)
+    mine = shards[rank]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dev = "cuda:%d" % local_rank
+    barrier()
+    t0 = time.perf_counter()
+    arena, views = corpus.decode_files_to_device([files[i] for i in mine], device=local_rank, workers=workers, gpu_parse=True)
+    torch.cuda.synchronize()
+    decode_s = max_over_ranks(time.perf_counter() - t0)
+    local_map = {i: v for i, v in zip(mine, views)}
+    barrier()
+    t1 = time.perf_counter()
+    out = corpus.gather_pcm(local_map, len(files), rank, world, dist, dev, to_host=False)  # stays in HBM
+    torch.cuda.synchronize()
+    gather_s = max_over_ranks(time.perf_counter() - t1)
+    block = None
+    if rank == 0:
+        floats = sum(int(o.numel()) for o in out)
+        remote = floats - sum(int(v.numel()) for v in views)  # what crossed a link
+        ok, checked = None, 0
+        if dig is not None:
+            ok = True
+            for i, o in enumerate(out):
+                want = dig["digests"][i]
+                if c5_corpus.file_digest(files[i]) != want[0] or int(o.numel()) != want[1] or c5_corpus.pcm_digest(o.cpu().numpy()) != want[2]:
+                    ok = False
+                checked += 1
+        block = {"what": "C5: %d-file corpus at length scale %g, LPT shard over %d rank(s), GPU packet parser, one device arena per rank, "
+                         "then the gather of all PCM to rank 0 (device to device)" % (len(files), scale, world),
+                 "files": len(files), "scale": scale, "workers_per_rank": workers,
+                 "decode_s": decode_s, "gather_s": gather_s, "pcm_bytes": floats * 4, "gathered_bytes_over_links": remote * 4,
+                 "gather_GBps": (remote * 4 / gather_s / 1e9) if (world > 1 and gather_s > 0) else None,
+                 "gather_bound": "each sender's one direct xGMI link to the root, ~153 GB/s; the root receives from all of them at once",
+                 "long_frame_equivalents_per_s": floats / 2 / 1024 / (decode_s + gather_s),
+                 "pcm_sha256_ok": ok, "files_checked": checked,
+                 "digests": os.path.relpath(c5_corpus.digest_path(scale), ROOT) if dig is not None else None,
+                 "note": ("NVH_BENCH_SHARE_GPU: every rank on ONE GPU over gloo -- a code-path check, not a transfer rate" if share_gpu else None)}
+    del out, views, arena
+    barrier()
+    return block
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +427,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 G-rand / C3 / C4 kernel-only lines")
     ap.add_argument("--no-check", action="store_true", help="profiling builds with phases masked out produce garbage PCM")
+    ap.add_argument("--c5-scale", type=float, default=0.1, help="length scale of the corpus block (1.0 = BASELINE's stated size; 0: no block)")
+    ap.add_argument("--c5-workers", type=int, default=0, help="parser threads per rank for the corpus block (0: CPUs this rank may use, at most 16)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent decoder instances (own nvh_ctx / HIP stream) the passes rotate over")
     ap.add_argument("--working-set-mib", type=float, default=512.0,
@@ -381,6 +470,8 @@ def main():
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d (the ranks that actually run)\n" % (args.gpus, world, world))
     torch.cuda.set_device(local_rank)
+    # N ranks on one host: each rank's parser threads (the corpus block) on the CPUs next to its GPU
+    pinned = pin_to_gpu_numa(torch, local_rank) if (world > 1 and not share_gpu) else "not pinned (one rank)"
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -492,13 +583,27 @@ def main():
     # every resident batch's PCM against the CPU oracle's digest of the same packets: a line cannot come from kernels that write
     # wrong samples (every rank checks its own; rank 0 reports the AND)
     torch.cuda.synchronize()
-    digest_ok, digest_n = check_digests(insts, seeds)
+    digest_ok, digest_n, digest_total = check_digests(insts, seeds)
     if dist is not None:
         t = torch.tensor([1.0 if digest_ok else 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         digest_ok = bool(t.item() > 0.5)
     if not (digest_ok and digest_n > 0) and not args.no_check:
         raise SystemExit("bench.py: the PCM of the timed batches does not match the oracle's digests -- no line")
+
+    # ---- BASELINE configs[4] beside the headline: the file-parallel corpus shard and the ONE collective of the north star, the
+    # gather of the PCM (every rank takes part; rank 0 reports).  Never part of `value`.
+    c5 = None
+    if args.c5_scale > 0:
+        workers = args.c5_workers or max(1, min(16, len(os.sched_getaffinity(0))))
+        try:
+            c5 = c5_block(nv, torch, dist, rank, world, local_rank, args.c5_scale, workers, share_gpu)
+            if c5 is not None:
+                c5["cpu_pinning"] = pinned
+        except Exception as e:
+            if dist is not None:
+                raise  # a rank that falls out of the gather must not leave the others waiting
+            c5 = {"error": repr(e)[:300]}
 
     if rank == 0:
         # the library says which kernel variant sits behind each timing slot ("-" = empty: only event overhead)
@@ -594,7 +699,12 @@ def main():
                                          "frac": alg_bytes / (km_l3[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                          "whole_pass_frac": alg_bytes / (l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                          "copy_ceiling_GBps": ceiling},
-            "pcm_digest_ok": digest_ok, "pcm_digests_checked": digest_n,
+            "pcm_digest_ok": digest_ok, "pcm_digests_checked": digest_n, "pcm_batches_timed": digest_total,
+            # what the ranks talked through: barriers / MAX of the timings in the headline, the PCM gather in `c5`
+            "collective": ({"backend": dist.get_backend(), "world": dist.get_world_size(),
+                            "library": "RCCL over xGMI (torch.distributed backend nccl)" if dist.get_backend() == "nccl" else "gloo (CPU): code-path check only"}
+                           if dist is not None else {"backend": None, "world": 1}),
+            "c5": c5,
             "decode_path": "resident input = the host packet parser's output (per-frame slabs, host_slab.cpp); a pass = every kernel a "
                            "once-synthesised batch needs (the streaming reader runs the same launches per look-ahead batch); no prepare / "
                            "conversion kernel exists for host-parsed batches",

@@ -29,6 +29,11 @@ def test_bench_two_ranks_share_one_gpu():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["pcm_digest_ok"] is True and d["pcm_digests_checked"] >= 3
+    # the one collective of the north star is in the line: the corpus shard + gather block, and what the ranks talked through
+    assert d["collective"]["world"] == 2 and d["collective"]["backend"] == "gloo"
+    c5 = d["c5"]
+    assert c5["files"] == 1004 and c5["pcm_sha256_ok"] is True and c5["files_checked"] == 1004
+    assert c5["decode_s"] > 0 and c5["gather_s"] > 0 and 0 < c5["gathered_bytes_over_links"] < c5["pcm_bytes"]
     assert d["value"] > 1e6 and "NVH_BENCH_SHARE_GPU" in d["data"]
     # value = frames of all ranks / the slowest rank's time
     assert abs(d["value"] - 2 * 4096 * d["config"]["passes_per_step"] * d["steps"] / d["config"]["timed_region_s"]) < 1e-6 * d["value"]
