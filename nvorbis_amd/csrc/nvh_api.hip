@@ -17,6 +17,8 @@ const NvhToggles& nvh_toggles() {
     x.unfused = on("NVH_UNFUSED");
     x.no_pair = on("NVH_NO_PAIR");
     x.no_slab = on("NVH_NO_SLAB");
+    x.uncached_planes = on("NVH_UNCACHED_PLANES");
+    x.poison_planes = on("NVH_POISON_PLANES");
     x.no_ola_sym = on("NVH_NO_OLA_SYM");
     x.no_emit = on("NVH_NO_EMIT");
     x.emit8 = on("NVH_EMIT8");
@@ -710,6 +712,7 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
     std::unique_ptr<nvh_batch> b(new (std::nothrow) nvh_batch());
     if (b && s && s->ctx) {
       b->blob.pool = b->work.pool = b->carry_in.pool = b->slabs.pool = b->run_flags.pool = b->dev_copy.pool = b->slab3.pool = &s->ctx->pool;
+      b->work.uncached = nvh_toggles().uncached_planes;
       b->h_blob.host = true;
       b->h_blob.pool = &s->ctx->hpool;
     }

@@ -135,6 +135,9 @@ struct NvhToggles {
   bool xcd_map;      // NVH_XCD_MAP: paired-emission launches take their frames in eight per-XCD runs instead of workgroup order (A/B aid)
   bool copy_upload;  // NVH_COPY_UPLOAD: a GPU-parse batch's input goes up by copy commands instead of k_parse_fetch (A/B aid)
   bool no_prefetch;  // NVH_NO_PREFETCH: the odd launch of a paired-emission pass does not touch the even launch's slabs (A/B aid)
+  bool uncached_planes;  // NVH_UNCACHED_PLANES: a batch's work planes in hipDeviceMallocUncached memory (the round-4 experiment whose
+                         // wrong PCM with GPU-parsed batches was never explained: tools/repro_uncached.py)
+  bool poison_planes;    // NVH_POISON_PLANES: work planes filled with NaN patterns at upload (finds reads of regions a batch never wrote)
   bool no_slab;   // NVH_NO_SLAB: the descriptor kernels (k_spectrum_imdct & co.) instead of the slab kernels (test / A-B aid)
   int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
   bool run;       // NVH_RUN: the run kernel (kernels_run.hip) instead of k_spectrum_imdct + k_ola_compact -- opt-in, it measured slower
@@ -198,10 +201,11 @@ struct DevBuf {  // growable device (or pinned host) allocation, optionally back
   size_t cap = 0;
   BufPool* pool = nullptr;
   bool host = false;  // pinned host memory; must match pool->host
+  bool uncached = false;  // experiment (NVH_UNCACHED_PLANES): device memory that bypasses the L2s (hipDeviceMallocUncached), never pooled
   ~DevBuf() { release(); }
   void release() {
     if (!p) return;
-    if (pool) pool->give(p, cap);
+    if (pool && !uncached) pool->give(p, cap);
     else (void)(host ? hipHostFree(p) : hipFree(p));
     p = nullptr;
     cap = 0;
@@ -210,9 +214,10 @@ struct DevBuf {  // growable device (or pinned host) allocation, optionally back
     if (bytes <= cap) return NVH_OK;
     release();
     const size_t want = BufPool::size_class(bytes + 256);
-    if (pool) p = pool->take(want);
+    if (pool && !uncached) p = pool->take(want);
     if (!p) {
       if (host) HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+      else if (uncached) HIP_TRY(hipExtMallocWithFlags(&p, want, hipDeviceMallocUncached));
       else HIP_TRY(hipMalloc(&p, want));
     }
     cap = want;
@@ -373,6 +378,7 @@ struct nvh_stream {
     h_flags2.host = true;
     h_flags2.pool = c ? &c->hpool : nullptr;
     scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = scratch.run_flags.pool = scratch.dev_copy.pool = scratch.slab3.pool = pool;
+    scratch.work.uncached = nvh_toggles().uncached_planes;
     h_pcm.host = scratch.h_blob.host = true;
     h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;
     scratch.s = this;

@@ -42,6 +42,14 @@ static int replay_on_host(nvh_stream* s) {
   return NVH_OK;
 }
 
+// NVH_POISON_PLANES (test aid): a batch's work planes start out as NaN bit patterns, so that a kernel which reads a plane region
+// nothing wrote in this batch -- and gets by on whatever an earlier decode left in the recycled block -- shows up as NaN PCM.
+static int poison_planes(nvh_stream* s, nvh_batch* b, size_t bytes) {
+  if (!nvh_toggles().poison_planes || !b->work.p || bytes == 0) return NVH_OK;
+  HIP_TRY(hipMemsetAsync(b->work.p, 0xFF, bytes, s->ctx->stream));
+  return NVH_OK;
+}
+
 // GPU-parse mode: upload frame geometry + packets, let k_parse produce the descriptors into per-frame slabs.
 #include <chrono>
 static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>& ola_list) {
@@ -201,6 +209,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   size_t plane = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
   rc = b->work.reserve(std::max<size_t>((size_t)b->nframes, 1) * plane);
   if (rc != NVH_OK) return rc;
+  if ((rc = poison_planes(s, b, std::max<size_t>((size_t)b->nframes, 1) * plane)) != NVH_OK) return rc;
   if (slab_mode) {
     size_t cap = std::max<size_t>((size_t)b->max_vecs, (size_t)s->setup.block1 / 64 + 8);  // the IMDCT padding of channel 0 overlays the slab area
     b->slab_cap_vecs = (int)((cap + 3) & ~(size_t)3);
@@ -445,6 +454,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       b->slabs_ready = true;
       const size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
       if ((rc = b->work.reserve(std::max<size_t>((size_t)b->nframes, 1) * plane)) != NVH_OK) return rc;
+      if ((rc = poison_planes(s, b, std::max<size_t>((size_t)b->nframes, 1) * plane)) != NVH_OK) return rc;
       P.clear();
       s->parser->begin_batch();
       return NVH_OK;
@@ -500,6 +510,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   size_t plane = (size_t)s->setup.channels * (size_t)s->setup.block1 * sizeof(float);
   rc = b->work.reserve(pad1((size_t)b->nframes) * plane);
   if (rc != NVH_OK) return rc;
+  if ((rc = poison_planes(s, b, pad1((size_t)b->nframes) * plane)) != NVH_OK) return rc;
   P.clear();
   s->parser->begin_batch();
   return NVH_OK;

@@ -340,7 +340,8 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
 
 
 @pytest.mark.parametrize("toggle", ["NVH_EMIT8+NVH_EMIT_ALWAYS", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
-                                    "NVH_EMIT8+NVH_GPU_PARSE", "NVH_COPY_UPLOAD+NVH_GPU_PARSE", "NVH_NO_EMIT", "NVH_NO_SLAB"])
+                                    "NVH_EMIT8+NVH_GPU_PARSE", "NVH_COPY_UPLOAD+NVH_GPU_PARSE", "NVH_NO_EMIT", "NVH_NO_SLAB",
+                                    "NVH_POISON_PLANES", "NVH_POISON_PLANES+NVH_GPU_PARSE"])
 def test_fallback_kernel_paths_bit_exact(toggle):
     """The library picks kernel variants by stream shape.  The default path of every stream the slab
     kernels take is host-written (or GPU-parsed) slabs -> k_synth / k_synth8 with paired emission; each environment toggle
@@ -351,7 +352,11 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     slab contract -- these three replays take tests/test_full_depth.py (C2 / C3 / C4 / C5 on full-depth packets) along;
     NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact, NVH_NO_COMPACT -> k_imdct_wave +
     k_ola_emit; NVH_GPU_PARSE -> packets parsed on the GPU (k_parse_slab writes the slabs; k_parse's descriptors for the shapes outside the slab
-    contract) instead of by the host parser; NVH_COPY_UPLOAD -> its input goes up by copy commands instead of k_parse_fetch."""
+    contract) instead of by the host parser; NVH_COPY_UPLOAD -> its input goes up by copy commands instead of k_parse_fetch;
+    NVH_POISON_PLANES -> every batch's work planes start out as NaN bit patterns (hipMemsetAsync at upload): device blocks are
+    recycled through a pool and never cleared, so a kernel that read a plane region nothing wrote in this batch would get by on
+    what an earlier decode left there -- the replay turns that into NaN PCM (round 5: the library has no such read; what
+    round 4 saw with planes in hipDeviceMallocUncached memory was the platform, tools/ubench/uncached_handoff.hip)."""
     import os
     import subprocess
     import sys
