@@ -281,8 +281,8 @@ struct PassesPF {
 
 // Full IMDCT of one channel-frame by one wavefront.  X: n/2 spectrum floats (global), out: n floats (global),
 // w: window (n floats) applied on the way out (Mode.cs:160-166).
-// sink(slot, idx, v): receives the 8 float4 output chunks a lane produces per pair index (slot 0..7 is a
-// compile-time constant after unrolling), idx = position of the chunk inside the n-sample block.
+// sink(slot, idx, v): receives the 8 float4 output chunks a lane produces per pair index (slot = 8 * iteration + 0..7 is a
+// compile-time constant after unrolling; blocks up to 2048 have one iteration), idx = position of the chunk inside the n-sample block.
 // INPLACE: X may be (part of) the wavefront's own LDS slice `lds` -- the whole spectrum is then read into
 // registers before the first store (n <= 2048: at most 4 float4 per lane).
 // WGSYNC (with INPLACE): the slice may overlay OTHER wavefronts' spectra as well -- a workgroup barrier, not the
@@ -362,11 +362,15 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
   float4 pcc[ITERO][2], pbl[ITERO][2], pbh[ITERO][2];
   // ... and, one pair per lane, its eight gather slots from the table behind the pass twiddles instead of ~100 integer
   // instructions of bit reversal and layout arithmetic
-  constexpr bool kFinTab = kPre && ITERO == 1;
-  uint4 fin = make_uint4(0u, 0u, 0u, 0u);
+  constexpr bool kFinTab = kPre && ITERO <= 2;
+  uint4 fin[ITERO];
   if constexpr (kFinTab) {
-    const int pp = lane < (G::n >> 5) ? lane : (G::n >> 5) - 1;
-    fin = reinterpret_cast<const uint4*>(TW + tw_pass_floats<LD>())[pp];
+#pragma unroll
+    for (int it = 0; it < ITERO; ++it) {
+      const int pq = lane + 64 * it;
+      const int pp = pq < (G::n >> 5) ? pq : (G::n >> 5) - 1;
+      fin[it] = reinterpret_cast<const uint4*>(TW + tw_pass_floats<LD>())[pp];
+    }
   }
   if constexpr (kPre) {
 #pragma unroll
@@ -408,7 +412,8 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       // v[d1+3]=u[k], v[d1+2]=u[k+1] (k=BR[2i]); v[d1+1]=u[k'], v[d1]=u[k'+1] (k'=BR[2i+1]); d1 = n2-4-4i
       float2 e0, e1, g0, g1;
       if constexpr (kFinTab) {
-        const unsigned we = h == 0 ? fin.x : fin.z, wg = h == 0 ? fin.y : fin.w;
+        const uint4 ft = fin[it < ITERO ? it : 0];
+        const unsigned we = h == 0 ? ft.x : ft.z, wg = h == 0 ? ft.y : ft.w;
         const float2* l2c = reinterpret_cast<const float2*>(lf);
         e0 = l2c[we & 0xFFFFu]; e1 = l2c[we >> 16];
         g0 = l2c[wg & 0xFFFFu]; g1 = l2c[wg >> 16];
@@ -480,10 +485,11 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
         o2 = make_float4(o2.x * w2.x, o2.y * w2.y, o2.z * w2.z, o2.w * w2.w);
         o3 = make_float4(o3.x * w3.x, o3.y * w3.y, o3.z * w3.z, o3.w * w3.w);
       }
-      sink(4 * h + 0, d0, o0);
-      sink(4 * h + 1, d1, o1);
-      sink(4 * h + 2, d2, o2);
-      sink(4 * h + 3, d3, o3);
+      // (slot = 8 it + 4 h + q: callers that keep chunks in registers tell the pair-index iterations apart; q is slot & 3)
+      sink(8 * it + 4 * h + 0, d0, o0);
+      sink(8 * it + 4 * h + 1, d1, o1);
+      sink(8 * it + 4 * h + 2, d2, o2);
+      sink(8 * it + 4 * h + 3, d3, o3);
     }
   }
   IMDCT_T(4);

@@ -122,6 +122,12 @@ __device__ __forceinline__ void pcm_store4(float4* p, float a, float b, float c,
 #endif
 }
 __device__ __forceinline__ void pcm_store1(float* p, float v) { __builtin_nontemporal_store(v, p); }
+// ... and the streaming load of 16 bytes that exactly one lane reads exactly once (a neighbour frame's quarter)
+__device__ __forceinline__ float4 stream_load4(const float* p) {
+  typedef float nvh_v4f __attribute__((ext_vector_type(4)));
+  const nvh_v4f v = __builtin_nontemporal_load(reinterpret_cast<const nvh_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // Utils.cs:30-43, without branches (two compares, two selects; the flag is an OR of the compare masks): the early-return form
 // compiles to two exec-mask regions per sample.  A NaN compares false twice and passes through, as in the reference.

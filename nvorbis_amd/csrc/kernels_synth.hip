@@ -868,6 +868,148 @@ __device__ __forceinline__ void synth_carry_out8(const NvhSynthArgs& A, const fl
   }
 }
 
+// ---- paired emission for wide frames, direct form (round 5) ------------------------------------------------------------------
+// A steady-state even frame of a wide batch (both of its overlaps emitted here, no carried tail on either side): the transforms
+// keep their two independent quarters in registers until the output stage's gathers are through, then put them into the
+// channel's own -- dead -- slice (A at [0, n/4), B at [n/4, n/2)); behind one barrier every lane of the workgroup takes one
+// (overlap, group of four sample times) for ALL channels: own quarters from LDS, the neighbour's from the odd launch's planes,
+// windows, Mode.cs:160-166 / StreamDecoder.cs:532-541 / :391-415 / Utils.cs:30-43 in ola_sym's arithmetic, and the 4 x CH
+// interleaved samples of each half leave as CH 16-byte streaming stores.  The frame writes no plane, nothing is read back, no
+// LDS rows, no second and third barrier (synth_emit8 keeps the frames with a carried tail or a single overlap).
+template <int LD>
+__device__ __forceinline__ void imdct_keep_quarters(const float* X, float* slice, const float* Aa, const float* Bb, const float* Cc,
+                                                    const float* TW, int lane) {
+  constexpr int n = 1 << LD, ITER = ((n >> 5) + 63) / 64;
+  float4 ka[ITER][2], kb[ITER][2];
+  auto sink = [&](int slot, int, float4 v) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (slot == 8 * i + 4 * h) ka[i][h] = v;
+        else if (slot == 8 * i + 4 * h + 2) kb[i][h] = v;
+      }
+  };
+  imdct_wave_sink<LD, false, decltype(sink), true, true, false, true>(X, nullptr, slice, Aa, Bb, Cc, TW, lane, sink);
+  wave_sync();  // the output stage's gathers are through: the slice is dead
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int p = lane + 64 * i;
+    if (p < (n >> 5)) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i8 = h == 0 ? p : (n >> 4) - 1 - p;
+        *reinterpret_cast<float4*>(slice + 4 * i8) = ka[i][h];
+        *reinterpret_cast<float4*>(slice + (n >> 2) + 4 * i8) = kb[i][h];
+      }
+    }
+  }
+}
+
+template <int NT, int CH>
+__device__ __forceinline__ void synth_emit8_direct(const NvhSynthArgs& A, float* smem, int n, unsigned frame, int tid) {
+  const int half = n >> 1, groups = n >> 4, slice = half + (n >> 4);
+  const NvhFrame* fs = A.frames + frame;
+  const unsigned w_self = fs[0].window_off, wp_self = fs[0].ov_window_off, w_next = fs[1].window_off, wp_next = fs[1].ov_window_off;
+  const long long o_self = fs[0].out_pos, o_next = fs[1].out_pos;
+  int clipped = 0;
+  auto task = [&](const bool nx, const int g, const bool whole_wave) {
+    const int i0 = 4 * g;
+    const float* __restrict__ w = A.windows + (nx ? w_next : w_self);
+    const float* __restrict__ wp = A.windows + (nx ? wp_next : wp_self);
+    const float4 wf = *reinterpret_cast<const float4*>(w + i0);
+    const float4 wm = *reinterpret_cast<const float4*>(w + (half - 4 - i0));
+    const float4 pf = *reinterpret_cast<const float4*>(wp + (half + i0));
+    const float4 pm = *reinterpret_cast<const float4*>(wp + (n - 4 - i0));
+    // the neighbour's quarter of every channel first (one round trip for the lot): SELF: B(frame - 1), NEXT: A(frame + 1)
+    const float* nb = nx ? A.work + (long long)(frame + 1) * CH * A.block1 + i0 : A.work + (long long)(frame - 1) * CH * A.block1 + half + i0;
+    float4 q[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) q[c] = stream_load4(nb + (long long)c * A.block1);  // read once, by this lane
+    float fwd[4 * CH], mir[4 * CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float* own = smem + c * slice;
+      const float4 o = *reinterpret_cast<const float4*>(own + (nx ? (half >> 1) : 0) + i0);  // NEXT: B(this), SELF: A(this)
+      const float4 a = nx ? q[c] : o, b = nx ? o : q[c];
+      float4 v = make_float4(a.x * wf.x, a.y * wf.y, a.z * wf.z, a.w * wf.w);
+      const float4 tt = make_float4(b.x * pf.x, b.y * pf.y, b.z * pf.z, b.w * pf.w);
+      v.x = v.x + tt.x; v.y = v.y + tt.y; v.z = v.z + tt.z; v.w = v.w + tt.w;
+      float4 u = make_float4(-a.w * wm.x, -a.z * wm.y, -a.y * wm.z, -a.x * wm.w);
+      const float4 r = make_float4(b.w * pm.x, b.z * pm.y, b.y * pm.z, b.x * pm.w);
+      u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
+      if (A.clip) {
+        v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
+        v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
+        u.x = clip_value(u.x, &clipped); u.y = clip_value(u.y, &clipped);
+        u.z = clip_value(u.z, &clipped); u.w = clip_value(u.w, &clipped);
+      }
+      fwd[0 * CH + c] = v.x; fwd[1 * CH + c] = v.y; fwd[2 * CH + c] = v.z; fwd[3 * CH + c] = v.w;
+      mir[0 * CH + c] = u.x; mir[1 * CH + c] = u.y; mir[2 * CH + c] = u.z; mir[3 * CH + c] = u.w;
+    }
+    float4* out = reinterpret_cast<float4*>(A.pcm + (nx ? o_next : o_self) * CH);
+    float4* of = out + (long long)g * CH;
+    float4* om = out + (long long)((n >> 3) - 1 - g) * CH;
+    if (whole_wave) {
+      // A lane's CH vectors are consecutive in memory, a store instruction's 64 vectors would lie 16 CH bytes apart.  The 64
+      // tasks of this wavefront cover ONE contiguous 1024 CH bytes per half, so the vectors go through a 64 x CH transposition
+      // first -- in the own-quarter floats these 64 tasks have just read (channel c's piece: 256 floats, nobody else's) -- and
+      // leave as CH fully coalesced streaming stores per half.
+      const int l = tid & 63, g0 = g - l;
+      float* piece0 = smem + (nx ? (half >> 1) : 0) + 4 * g0;
+      float4* rf = out + (long long)g0 * CH;                         // the forward half: groups g0 .. g0 + 63 ascending
+      float4* rm = out + (long long)((n >> 3) - 1 - (g0 + 63)) * CH;  // the mirrored half: the same groups, descending
+      wave_sync();  // every lane's own-quarter reads are through
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int j = l * CH + k;
+        *reinterpret_cast<float4*>(piece0 + (j >> 6) * slice + 4 * (j & 63)) = make_float4(fwd[4 * k], fwd[4 * k + 1], fwd[4 * k + 2], fwd[4 * k + 3]);
+      }
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(piece0 + k * slice + 4 * l);
+        pcm_store4(rf + k * 64 + l, v.x, v.y, v.z, v.w);
+      }
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int j = (63 - l) * CH + k;
+        *reinterpret_cast<float4*>(piece0 + (j >> 6) * slice + 4 * (j & 63)) = make_float4(mir[4 * k], mir[4 * k + 1], mir[4 * k + 2], mir[4 * k + 3]);
+      }
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(piece0 + k * slice + 4 * l);
+        pcm_store4(rm + k * 64 + l, v.x, v.y, v.z, v.w);
+      }
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+#ifdef NVH_DIRECT8_NT
+      pcm_store4(of + k, fwd[4 * k], fwd[4 * k + 1], fwd[4 * k + 2], fwd[4 * k + 3]);
+      pcm_store4(om + k, mir[4 * k], mir[4 * k + 1], mir[4 * k + 2], mir[4 * k + 3]);
+#else
+      // (a lane's CH vectors are consecutive, a store instruction's 64 vectors are 16 CH bytes apart: plain stores, which the
+      // L2 merges into whole lines -- streamed, such partial lines cost 273 us per C4 pass instead of 110)
+      of[k] = make_float4(fwd[4 * k], fwd[4 * k + 1], fwd[4 * k + 2], fwd[4 * k + 3]);
+      om[k] = make_float4(mir[4 * k], mir[4 * k + 1], mir[4 * k + 2], mir[4 * k + 3]);
+#endif
+    }
+  };
+  for (int t = tid; t < 2 * groups; t += NT) {
+    if (groups >= 64) {  // (uniform) a wavefront's tasks belong to one overlap
+      const bool nx = __builtin_amdgcn_readfirstlane((int)(t >= groups)) != 0;
+      task(nx, nx ? t - groups : t, true);
+    } else {
+      const bool nx = t >= groups;
+      task(nx, nx ? t - groups : t, false);
+    }
+  }
+  if (A.clip) report_clipped(clipped, A.clipped_flag);
+}
+
 // ---- float side ------------------------------------------------------------------------------------------------------------
 // LDS map (dynamic, floats): [ inverse_dB_table 256 | lattice pool (const_vecs * 4 - 256) | slab image cap_vecs * 4 |
 //                              spectrum channels * block1 / 2 | block1 / 16 of IMDCT padding (k_synth) ]
@@ -1109,6 +1251,12 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   if constexpr (MAXCH <= 2 && MODE >= 1) carry_out = A.carry_out != nullptr && (exec_mask & NVH_SLABX_CARRY_OUT);
   unsigned carry_window = 0u;
   if constexpr (MAXCH <= 2 && MODE >= 1) carry_window = carry_out ? __builtin_amdgcn_readfirstlane(s_chan[2]) : 0u;  // before anything overlays the slab
+  // wide frames with paired emission: which overlaps this frame emits is read from its frame record (the slab header's per-channel
+  // words are all taken); the direct form (synth_emit8_direct) takes the frames in the middle of the steady state
+  unsigned ef8 = 0u;
+  if constexpr (MAXCH > 2 && MODE >= 2) ef8 = A.pcm != nullptr ? A.frames[frame].emit_flags : 0u;  // uniform
+  const bool direct8 = MAXCH > 2 && MODE >= 2 && n <= 4096 &&
+                       (ef8 & (NVH_EMIT_SELF | NVH_EMIT_NEXT | NVH_EMIT_SELF_CARRY | NVH_EMIT_CARRY_OUT)) == (NVH_EMIT_SELF | NVH_EMIT_NEXT);
   if (MAXCH <= 2 && MODE >= 2 && (emit_self || emit_next)) {
     if constexpr (MAXCH <= 2 && MODE >= 2)
 #ifdef NVH_DEBUG
@@ -1146,7 +1294,21 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     // Every transforming wavefront first takes its channel's whole spectrum into registers; behind the ONE workgroup barrier
     // inside imdct_wave<.., WGSYNC> the constants, the slab and all spectra are dead, and the transforms' slices (n/2 + n/16
     // floats each) are laid out back to back from the start of the LDS area.
-    if (xform) {
+    bool kept = false;
+    if constexpr (MAXCH > 2 && MODE >= 2) kept = xform && direct8;
+    if constexpr (MAXCH > 2 && MODE >= 2) if (kept) {
+      const float* X = spec + wv * half;
+      float* scratch = smem + wv * (half + (n >> 4));
+      switch (n) {  // (blocks up to 4096: the host marks no emission beyond)
+        case 256: imdct_keep_quarters<8>(X, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 512: imdct_keep_quarters<9>(X, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 1024: imdct_keep_quarters<10>(X, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 2048: imdct_keep_quarters<11>(X, scratch, Aa, Bb, Cc, TW, lane); break;
+        case 4096: imdct_keep_quarters<12>(X, scratch, Aa, Bb, Cc, TW, lane); break;
+        default: __builtin_trap();
+      }
+    }
+    if (xform && !kept) {
       const float* X = spec + wv * half;
       float* out = planes + (long long)wv * A.block1;
       float* scratch = smem + wv * (half + (n >> 4));
@@ -1180,7 +1342,21 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   if constexpr (MAXCH > 2 && MODE >= 2) {
     // paired emission for wide frames: which overlaps this frame emits is read from its frame record (the slab header's
     // per-channel words are all taken); every wavefront's plane stores are complete behind the barrier
-    const unsigned ef = A.pcm != nullptr ? A.frames[frame].emit_flags : 0u;  // uniform
+    const unsigned ef = ef8;
+    if (direct8) {
+      __syncthreads();  // every channel's own quarters are in its slice
+      switch (nch) {
+        case 1: synth_emit8_direct<NT, 1>(A, smem, n, frame, tid); break;  // (mono / stereo land here with blocks beyond 2048)
+        case 2: synth_emit8_direct<NT, 2>(A, smem, n, frame, tid); break;
+        case 3: synth_emit8_direct<NT, 3>(A, smem, n, frame, tid); break;
+        case 4: synth_emit8_direct<NT, 4>(A, smem, n, frame, tid); break;
+        case 5: synth_emit8_direct<NT, 5>(A, smem, n, frame, tid); break;
+        case 6: synth_emit8_direct<NT, 6>(A, smem, n, frame, tid); break;
+        case 7: synth_emit8_direct<NT, 7>(A, smem, n, frame, tid); break;
+        case 8: synth_emit8_direct<NT, 8>(A, smem, n, frame, tid); break;
+        default: __builtin_trap();
+      }
+    } else
     if (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT | NVH_EMIT_CARRY_OUT)) {
       __syncthreads();
       if ((ef & NVH_EMIT_CARRY_OUT) && A.carry_out) synth_carry_out8<NT>(A, planes, n, nch, exec_mask, A.frames[frame].window_off, tid);

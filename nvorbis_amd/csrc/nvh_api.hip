@@ -22,6 +22,7 @@ const NvhToggles& nvh_toggles() {
     x.no_ola_sym = on("NVH_NO_OLA_SYM");
     x.no_emit = on("NVH_NO_EMIT");
     x.emit8 = on("NVH_EMIT8");
+    x.no_emit8 = on("NVH_NO_EMIT8");
     x.no_prefetch = on("NVH_NO_PREFETCH");
     x.copy_upload = on("NVH_COPY_UPLOAD");
     x.xcd_map = on("NVH_XCD_MAP");

@@ -128,7 +128,8 @@ static inline void nvh_guard_void(F&& body) noexcept {
 struct NvhToggles {
   bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
   bool no_ola_sym;  // NVH_NO_OLA_SYM: k_ola_compact without its read-once steady-state path (test / A-B aid)
-  bool emit8;       // NVH_EMIT8: paired emission also for more than two channels / blocks beyond 2048 (k_synth8_emit) -- opt-in, it measured no gain
+  bool emit8;       // NVH_EMIT8: accepted, no effect any more (paired emission for wide frames is the default since round 5)
+  bool no_emit8;    // NVH_NO_EMIT8: no paired emission for more than two channels / blocks beyond 2048 (k_synth8 + k_ola_compact; A/B aid)
   bool no_emit;     // NVH_NO_EMIT: no paired emission -- every frame's PCM through k_ola_compact (test / A-B aid)
   bool emit_always; // NVH_EMIT_ALWAYS: paired emission for every batch that has a steady-state frame (default: batches that are
                     // at least 7/8 steady state; the parity suite replays itself with this switch to cover the mixed cases)

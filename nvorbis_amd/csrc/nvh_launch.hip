@@ -321,10 +321,11 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
     // up to eight channels, blocks up to 4096 (k_synth8_emit: through the planes and LDS rows)
     // (streams whose frames need the general bin walk run k_synth_g / k_synth8 without paired emission)
     const bool narrow = ch <= 2 && s->setup.block1 <= 2048 && !s->shared->slab_general;
-    // (the wide form is opt-in, NVH_EMIT8=1: bit-exact, but on C4 -- six channels, n = 4096 -- the pair of launches measured 123.5 us
-    // per 2048 frames against 116.5 us for k_synth8 + k_ola_compact on one stream, 113.5 against 111.3 us over three: with two
-    // workgroups per CU the overlap-add's memory phases run in lockstep bursts instead of hiding behind other workgroups' arithmetic)
-    const bool wide_emit = !narrow && !s->shared->slab_general && ch <= NVH_SLAB_MAX_CH && s->setup.block1 <= 4096 && nvh_toggles().emit8;
+    // (round 4's form -- planes out, read back, LDS rows -- lost to k_synth8 + k_ola_compact on C4, six channels at n = 4096: 123.5 against
+    // 116.5 us per 2048 frames, and stayed opt-in.  Round 5's direct form (kernels_synth.hip: synth_emit8_direct -- own quarters stay
+    // in LDS, the even frames write no plane, PCM leaves in whole lines through a per-wavefront transposition) wins: 110.3 -> 98.8 us
+    // on one stream, 109.8 -> 87.1 us over three; psize 32: 148.7 -> 138.9 / 146.4 -> 119.4.  NVH_NO_EMIT8 switches it off.)
+    const bool wide_emit = !narrow && !s->shared->slab_general && ch <= NVH_SLAB_MAX_CH && s->setup.block1 <= 4096 && !nvh_toggles().no_emit8;
     const bool can = !nvh_toggles().no_emit && (narrow || wide_emit) && !P.sequential_ola && s->setup.block0 >= 256;
     const unsigned all_ch = (1u << ch) - 1u;
     // GPU-parse mode: the execute flags are decided inside k_parse (Mapping.cs:104-131); the host marks the candidates from the

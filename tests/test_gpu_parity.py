@@ -339,16 +339,16 @@ def test_floor0_within_tolerance(oracle, gpu_ctx):
             assert exact > 0.99, (name, exact)
 
 
-@pytest.mark.parametrize("toggle", ["NVH_EMIT8+NVH_EMIT_ALWAYS", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
-                                    "NVH_EMIT8+NVH_GPU_PARSE", "NVH_COPY_UPLOAD+NVH_GPU_PARSE", "NVH_NO_EMIT", "NVH_NO_SLAB",
+@pytest.mark.parametrize("toggle", ["NVH_EMIT_ALWAYS", "NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_GPU_PARSE",
+                                    "NVH_EMIT_ALWAYS+NVH_GPU_PARSE", "NVH_COPY_UPLOAD+NVH_GPU_PARSE", "NVH_NO_EMIT", "NVH_NO_EMIT8", "NVH_NO_SLAB",
                                     "NVH_POISON_PLANES", "NVH_POISON_PLANES+NVH_GPU_PARSE"])
 def test_fallback_kernel_paths_bit_exact(toggle):
     """The library picks kernel variants by stream shape.  The default path of every stream the slab
     kernels take is host-written (or GPU-parsed) slabs -> k_synth / k_synth8 with paired emission; each environment toggle
     switches one level of that off or an opt-in on, and the whole parity suite above is replayed that way in a child process:
-    NVH_EMIT8 + NVH_EMIT_ALWAYS -> paired emission also for wide frames (k_synth8_emit, opt-in) and for every batch with a
-    steady-state frame, not only those that are 7/8 steady state; NVH_NO_EMIT -> the slab kernels without paired emission (every
-    overlap-add in k_ola_compact); NVH_NO_SLAB -> the descriptor kernels (k_spectrum_imdct & co.) that serve the shapes outside the
+    NVH_EMIT_ALWAYS -> paired emission (k_synth_emit; k_synth8_emit for wide frames) for every batch with a steady-state frame,
+    not only those that are 7/8 steady state; NVH_NO_EMIT -> the slab kernels without paired emission (every overlap-add in
+    k_ola_compact), NVH_NO_EMIT8 -> the same for wide frames only; NVH_NO_SLAB -> the descriptor kernels (k_spectrum_imdct & co.) that serve the shapes outside the
     slab contract -- these three replays take tests/test_full_depth.py (C2 / C3 / C4 / C5 on full-depth packets) along;
     NVH_UNFUSED -> k_residue + k_couple_floor, NVH_NO_FUSED_IMDCT -> k_spectrum + k_imdct_compact, NVH_NO_COMPACT -> k_imdct_wave +
     k_ola_emit; NVH_GPU_PARSE -> packets parsed on the GPU (k_parse_slab writes the slabs; k_parse's descriptors for the shapes outside the slab
@@ -368,7 +368,7 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     env["NVH_TEST_CHILD"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = [os.path.join(root, "tests", "test_gpu_parity.py")]
-    if toggle in ("NVH_EMIT8+NVH_EMIT_ALWAYS", "NVH_NO_EMIT", "NVH_NO_SLAB"):
+    if toggle in ("NVH_EMIT_ALWAYS", "NVH_NO_EMIT", "NVH_NO_EMIT8", "NVH_NO_SLAB"):
         files.append(os.path.join(root, "tests", "test_full_depth.py"))
     r = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
