@@ -560,6 +560,9 @@ __device__ __forceinline__ void synth_self_carry(const NvhSynthArgs& A, const fl
         mir[c] = u.x; mir[2 + c] = u.y; mir[4 + c] = u.z; mir[6 + c] = u.w;
       }
     }
+    // (a 64 x 2 transposition through LDS in front of these stores, so that every instruction writes whole lines the way the wide
+    // kernel's emission does, was tried: 202 -> 167 M frames/s -- nine spilled registers and four more wavefront syncs cost more than
+    // half-line streaming stores do)
     if (nch == 2) {
       float4* of = reinterpret_cast<float4*>(out) + 2 * (long long)g;
       float4* om = reinterpret_cast<float4*>(out) + 2 * (long long)((n >> 3) - 1 - g);
