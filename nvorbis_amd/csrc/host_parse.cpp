@@ -45,6 +45,22 @@ uint8_t* PacketPool::append(size_t n) {
 // floors
 // ---------------------------------------------------------------------------------------------
 
+// Codebook.DecodeScalar (Codebook.cs:294-320) with the common case in line: eight bytes of packet behind the cursor's byte and a
+// code the prefix table resolves -- then the peek returns every bit it was asked for and the skip stays inside the packet, which is
+// all the reference's end-of-packet rules are about; everything else goes through Codebook::decode_scalar.
+static inline int decode_scalar_fast(const Codebook& book, BitReader& p) {
+  if (!book.fast.empty() && (p.pos >> 3) + 8 <= (p.total_bits >> 3)) {
+    uint64_t w;
+    std::memcpy(&w, p.data + (p.pos >> 3), 8);
+    const uint32_t node = book.fast[(uint32_t)(w >> (p.pos & 7)) & ((1u << book.prefix_bits) - 1u)];
+    if (node & 0x80u) {
+      p.pos += (int)(node & 0x7Fu);
+      return (int)(node >> 8);
+    }
+  }
+  return book.decode_scalar(p);
+}
+
 int StreamParser::decode_floor(int floor_idx, BitReader& p, FrameBatch& out, NvhChan& ch, bool* energy) {
   const Floor& fl = s_->floors[(size_t)floor_idx];
   ch.floor = (uint8_t)floor_idx;
@@ -68,7 +84,7 @@ int StreamParser::decode_floor(int floor_idx, BitReader& p, FrameBatch& out, Nvh
         int csub = (1 << cbits) - 1;
         uint32_t cval = 0;
         if (cbits > 0) {
-          int r = s_->books[(size_t)f.class_masterbook[cls]].decode_scalar(p);
+          int r = decode_scalar_fast(s_->books[(size_t)f.class_masterbook[cls]], p);
           if (r == -2) return NVH_ERR_RUNTIME;
           cval = (uint32_t)r;
           if (cval == 0xFFFFFFFFu) {
@@ -81,7 +97,7 @@ int StreamParser::decode_floor(int floor_idx, BitReader& p, FrameBatch& out, Nvh
           cval >>= cbits;
           if (book >= 0) {
             if (post_count >= NVH_MAX_POSTS) return NVH_ERR_RUNTIME;  // Posts = new int[64]
-            int r = s_->books[(size_t)book].decode_scalar(p);
+            int r = decode_scalar_fast(s_->books[(size_t)book], p);
             if (r == -2) return NVH_ERR_RUNTIME;
             if ((posts[post_count] = r) == -1) {
               post_count = 0;
@@ -165,11 +181,13 @@ int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, 
   int cdim = class_book.dimensions;
   if (cdim == 0) return NVH_ERR_RUNTIME;
   int partition_words = (partition_count + cdim - 1) / cdim;
-  std::vector<int> part_word((size_t)r.channels * (size_t)std::max(partition_words, 1), -1);
+  std::vector<int>& part_word = scratch_part_word_;  // (members: no allocation per packet)
+  part_word.assign((size_t)r.channels * (size_t)std::max(partition_words, 1), -1);
   const int buflen = s_->block1;  // float[ch][block1Size] (StreamDecoder.cs:498-505)
   bool stop = false;
   // op_link chains: the last op emitted for each (partition, channel) of this pass
-  std::vector<int32_t> last_op((size_t)r.channels * (size_t)std::max(partition_count, 1), -1);
+  std::vector<int32_t>& last_op = scratch_last_op_;
+  last_op.assign((size_t)r.channels * (size_t)std::max(partition_count, 1), -1);
   auto link_op = [&](int partition_idx, int ch) {
     const size_t idx = out.ops.size() - 1;
     out.op_link.resize(out.ops.size(), (uint16_t)NVH_LINK_NONE);
@@ -190,7 +208,7 @@ int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, 
     for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count && !stop; entry_idx++) {
       if (stage == 0) {
         for (int ch = 0; ch < r.channels; ch++) {
-          int idx = class_book.decode_scalar(p);
+          int idx = decode_scalar_fast(class_book, p);
           if (idx == -2) return NVH_ERR_RUNTIME;
           if (idx >= 0 && idx < r.partvals) {
             part_word[(size_t)ch * partition_words + entry_idx] = idx;
@@ -250,15 +268,38 @@ int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, 
             int slots = (r.partition_size + dims - 1) / dims;
             int done = 0;
             bool bad = false;
-            for (int i = 0; i < r.partition_size; i += dims) {
+            const size_t ebase = out.entries.size();
+            out.entries.resize(ebase + (size_t)slots);
+            uint16_t* eo = out.entries.data() + ebase;
+            // The vector's entries, fast form (the GPU parser's loop, kernels_parse.hip): while eight bytes of packet lie behind
+            // the cursor's byte and the prefix table resolves the code, a symbol is an unaligned load, a shift, a table read
+            // and a store.  Codebook.DecodeScalar does exactly that in this situation (the peek returns every bit asked for,
+            // the skip stays inside the packet); whatever the loop leaves -- a long code, the packet's last bytes -- goes
+            // through decode_scalar with the reference's end-of-packet rules.
+            if (book.has_tree && !book.fast.empty()) {
+              const uint32_t* ft = book.fast.data();
+              const uint32_t mask = (1u << book.prefix_bits) - 1u;
+              const uint8_t* bytes = p.data;
+              const int nbytes = p.total_bits >> 3;
+              int pos = p.pos;
+              while (done < slots && (pos >> 3) + 8 <= nbytes) {
+                uint64_t w;
+                std::memcpy(&w, bytes + (pos >> 3), 8);
+                const uint32_t node = ft[(uint32_t)(w >> (pos & 7)) & mask];
+                if (!(node & 0x80u)) break;
+                pos += (int)(node & 0x7Fu);
+                eo[done++] = (uint16_t)(node >> 8);
+              }
+              p.pos = pos;
+            }
+            for (int i = done * dims; i < r.partition_size; i += dims) {
               int e = book.decode_scalar(p);
               if (e == -2) return NVH_ERR_RUNTIME;
               if (e == -1) {
                 bad = true;
                 break;
               }
-              out.entries.push_back((uint16_t)e);
-              ++done;
+              eo[done++] = (uint16_t)e;
             }
             // bounds of the adds the reference performed
             if (done > 0) {
@@ -269,7 +310,7 @@ int StreamParser::decode_residue(int residue_idx, BitReader& p, int block_size, 
                 if (offset / r.real_channels + last / r.real_channels >= buflen) return NVH_ERR_RUNTIME;
               }
             }
-            for (int i = done; i < slots; i++) out.entries.push_back((uint16_t)NVH_ENTRY_SKIP);
+            for (int i = done; i < slots; i++) eo[i] = (uint16_t)NVH_ENTRY_SKIP;
             out.ops.push_back(op);
             link_op(partition_idx, ch);
             if (bad) {

@@ -117,6 +117,8 @@ class StreamParser {
 
   const Setup* s_;
   bool light_ = false;
+  std::vector<int> scratch_part_word_;      // decode_residue's rows, kept between packets
+  std::vector<int32_t> scratch_last_op_;
   // StreamDecoder.cs:30-39 state, integer part
   bool has_prev_buf_ = false;   // _prevPacketBuf != null
   int prev_start_ = 0, prev_end_ = 0, prev_stop_ = 0;

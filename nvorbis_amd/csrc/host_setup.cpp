@@ -77,6 +77,12 @@ static void generate_table(Codebook& cb, const int* values, const int* length_li
   }
   cb.prefix_bits = table_bits;
   cb.has_tree = true;
+  cb.fast.assign(cb.prefix.size(), 0u);
+  for (size_t k = 0; k < cb.prefix.size(); k++) {
+    const HuffNode& nd = cb.prefix[k];
+    if (nd.present && nd.length >= 1 && nd.length <= table_bits && nd.value >= 0 && nd.value <= 0xFFFF)
+      cb.fast[k] = ((uint32_t)nd.value << 8) | 0x80u | (uint32_t)nd.length;
+  }
   // group the overflow list by prefix slot (stable)
   cb.overflow_grouped.clear();
   cb.slot_group.assign(cb.prefix.size(), 0u);

@@ -30,6 +30,9 @@ struct Codebook {
   int lattice_values = 0;         // map type 1 without sequence_p: number of distinct component values, else 0
   std::vector<float> lattice;     // those values: lookup[e*dim+i] == lattice[(e / lattice_values^i) % lattice_values]
   std::vector<HuffNode> prefix;   // 1 << prefix_bits
+  // the same table in the packet parsers' compact form -- (value << 8) | 0x80 | length for a code that the prefix resolves, 0
+  // else (kernels_parse.hip reads the same words from LDS) -- for the host parser's vector loop (host_parse.cpp)
+  std::vector<uint32_t> fast;
   std::vector<HuffNode> overflow;
   // the overflow list regrouped by the first prefix_bits bits of each code (same relative order inside a group): a
   // code can only match a peek whose low bits select its group, so the reference's first-match scan over the whole

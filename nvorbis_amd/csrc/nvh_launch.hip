@@ -168,7 +168,8 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     size_t max_pkt_words = 1;
     for (size_t i = 0; i < nf; i++) max_pkt_words = std::max<size_t>(max_pkt_words, ((size_t)P.pkt_refs[i].bit_len + 31) / 32 + 1);
     const size_t table_words = (size_t)(T.lds_words + T.meta_words);
-    const size_t lds_cap_words = 80 * 1024 / 4;
+    // (workgroups of eight and more wavefronts may take a CU's whole LDS: one workgroup per CU still is 2+ wavefronts per SIMD)
+    const size_t lds_cap_words = (size_t)(kParseWaves >= 8 ? 156 : 80) * 1024 / 4;
     int scratch_words = 2 * T.cap_parts, pkt_words = (int)max_pkt_words;
     // LDS variant only when both the rows and the longest packet of the batch fit for every lane; else everything per-lane
     // stays in global memory (k_parse_g)
@@ -178,10 +179,10 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     if (!in_lds) scratch_words = pkt_words = 0;
     const size_t parse_lds = (table_words + per_wg * (size_t)(scratch_words + pkt_words) + floor_words) * sizeof(uint32_t);
     if (!s->ctx->parse_lds_attr_set) {  // the opt-in is per device: once per context (contexts are single-threaded)
-      HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_g, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_g, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       s->ctx->parse_lds_attr_set = true;
     }
     hipLaunchKernelGGL(slab_mode ? (in_lds ? k_parse_slab : k_parse_slab_g) : (in_lds ? k_parse : k_parse_g), dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
