@@ -498,7 +498,7 @@ def main():
     for k in range(nin):
         # the context's own HIP stream (hipStreamNonBlocking, created by nvh_ctx_create): never the legacy default stream, which
         # serialises against every other stream.  Three instances: sustained (>= 1.5 s) HBM-resident rates measured with paired
-        # emission 135 / 155 / 135 / 148 / 148 M frames/s for 2 / 3 / 4 / 6 / 8 streams (tools/sweep_streams.sh), without it
+        # emission 135 / 155 / 135 / 148 / 148 M frames/s for 2 / 3 / 4 / 6 / 8 streams (round-3 sweep), without it
         # 129 / 132 / 124 / 129 / 129 M.
         ts = None
         ctx_k = nv.Context(local_rank)

@@ -8,10 +8,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnvorbis_hip.so")
 SOURCES = ["nvh_api.hip", "nvh_setup.hip", "nvh_launch.hip", "nvh_ops.hip", "kernels.hip", "kernels_imdct.hip", "kernels_spectrum.hip", "kernels_synth.hip", "kernels_parse.hip", "host_setup.cpp", "host_parse.cpp", "host_slab.cpp", "host_ogg.cpp"]
-# Kernels that measured slower than the default path and are kept for the record: the run kernel, the
-# frame-loop kernel, k_imdct_ola.  They are compiled only into the experiments library (build.py --experiments,
-# -DNVH_EXPERIMENTS), never into libnvorbis_hip.so.
-EXPERIMENT_SOURCES = ["kernels_spectrum2.hip", "kernels_run.hip"]
 # -ffp-contract=off: bit-exact parity with the reference needs separately rounded mul/add (no v_fma_f32);
 # fp32 denormals are preserved by default (no -fgpu-flush-denormals-to-zero).
 # -fno-slp-vectorize: the SLP vectorizer pairs the butterflies of the wavefront IMDCT into v_pk_add_f32 / v_pk_mul_f32;
@@ -152,19 +148,10 @@ def build(force=False, verbose=False):
 
 
 DEBUG_OUT = os.path.join(HERE, "libnvorbis_hip_dbg.so")
-EXPERIMENTS_OUT = os.path.join(HERE, "libnvorbis_hip_exp.so")
-
-
-def build_experiments(verbose=False):
-    """The experiments build (-DNVH_EXPERIMENTS): the release library plus the quarantined kernels behind their opt-in
-    switches (NVH_RUN=1, NVH_MULTI=1, NVH_FUSED_OLA=1).  Load it with NVH_LIB=nvorbis_amd/libnvorbis_hip_exp.so; the tests
-    marked `experiments` do (and skip when it has not been built)."""
-    return _compile_link(SOURCES + EXPERIMENT_SOURCES, EXPERIMENTS_OUT, ["-DNVH_EXPERIMENTS"], verbose)
-
 
 def build_debug(verbose=False):
     """The profiling build (-DNVH_DEBUG): the spectrum kernels take a timestamp buffer and a phase mask
-    (nvh_debug_set_buffer, NVH_DEBUG_SPECTRUM_MASK; tools/dbg_phase*.py, tools/pmc_phases.sh).  Load it with
+    (nvh_debug_set_buffer, NVH_DEBUG_SPECTRUM_MASK; tools/dbg_phase_synth.py, tools/dbg_phase_parse.py).  Load it with
     NVH_LIB=nvorbis_amd/libnvorbis_hip_dbg.so.  The release library has neither the parameters nor the export."""
     return _compile_link(SOURCES, DEBUG_OUT, ["-DNVH_DEBUG"], verbose)
 
@@ -172,8 +159,6 @@ def build_debug(verbose=False):
 if __name__ == "__main__":
     if "--debug" in sys.argv:
         print(build_debug(verbose=True))
-    elif "--experiments" in sys.argv:
-        print(build_experiments(verbose=True))
     else:
         build(force="--force" in sys.argv, verbose=True)
         print(OUT)

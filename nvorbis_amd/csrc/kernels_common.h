@@ -56,26 +56,7 @@ struct NvhDevBatch {
 #endif
 
 // error word written by kernels when the reference would have thrown (index out of range)
-// NVH_DEVERR_HANDOFF: the run kernel (kernels_run.hip) gave up waiting for a neighbouring workgroup's tail; the host repeats
-// the batch through the two-kernel path
-enum { NVH_DEVERR_FLOOR1_Y = 1, NVH_DEVERR_FLOOR0_W = 2, NVH_DEVERR_HANDOFF = 4 };
-
-// Arguments of the run kernel beyond the setup and the batch (kernels_run.hip).
-struct NvhRunArgs {
-  float* tails;          // [frame][channel][block1] planes; positions [n/2, n) of a run's last frame receive its windowed tail
-  unsigned* flags;       // [frame][channel]: == epoch once that tail is complete
-  unsigned epoch;        // > 0, distinct for every launch over the same flag array
-  int run_len;
-  float* pcm;
-  const float* carry;    // [channel][block1]: windowed block the batch's first frame overlaps (StreamDecoder's _prevPacketBuf)
-  float* carry_out;      // the same for the next batch: the last decoded block of this one
-  int clip;
-  int* clipped_flag;
-  int last_decoded;
-#ifdef NVH_DEBUG
-  long long* dbg;        // per-workgroup, per-wavefront phase timestamps (tools/dbg_phase_run.py)
-#endif
-};
+enum { NVH_DEVERR_FLOOR1_Y = 1, NVH_DEVERR_FLOOR0_W = 2 };
 
 // Arguments of the slab synthesis kernel (kernels_synth.hip).
 // groups of four sample times per workgroup of k_ola_compact's LDS-interleaving path (more than two channels)

@@ -11,7 +11,6 @@ const NvhToggles& nvh_toggles() {
     auto num = [](const char* k) { const char* v = std::getenv(k); return v ? std::atoi(v) : 0; };
     NvhToggles x{};
     x.no_compact = on("NVH_NO_COMPACT");
-    x.fused_ola = on("NVH_FUSED_OLA");
     x.no_fused_imdct = on("NVH_NO_FUSED_IMDCT");
     x.no_gen8 = on("NVH_NO_GEN8");
     x.unfused = on("NVH_UNFUSED");
@@ -30,15 +29,10 @@ const NvhToggles& nvh_toggles() {
     x.debug_occ = on("NVH_DEBUG_OCC");
     x.gpu_parse_default = on("NVH_GPU_PARSE");
     x.lds_pad = num("NVH_LDS_PAD");
-    x.run_len = num("NVH_RUN_LEN");
     x.ola_threads = num("NVH_OLA_THREADS");
     x.parse_lanes = num("NVH_PARSE_LANES");
     x.parse_waves = num("NVH_PARSE_WAVES");
-    x.run = on("NVH_RUN");
-    x.run_waves = num("NVH_RUN_WAVES");
-    x.multi = num("NVH_MULTI");
     x.ola_segs = num("NVH_OLA_SEGS");
-    x.multi_wgs = num("NVH_MULTI_WGS");
     x.phase_mask = std::getenv("NVH_DEBUG_SPECTRUM_MASK") ? num("NVH_DEBUG_SPECTRUM_MASK") : 15;
     return x;
   }();
@@ -712,7 +706,7 @@ extern "C" int nvh_batch_upload(nvh_stream* s, nvh_batch** out) {
     HIP_TRY(hipSetDevice(s->ctx->device));
     std::unique_ptr<nvh_batch> b(new (std::nothrow) nvh_batch());
     if (b && s && s->ctx) {
-      b->blob.pool = b->work.pool = b->carry_in.pool = b->slabs.pool = b->run_flags.pool = b->dev_copy.pool = b->slab3.pool = &s->ctx->pool;
+      b->blob.pool = b->work.pool = b->carry_in.pool = b->slabs.pool = b->dev_copy.pool = b->slab3.pool = &s->ctx->pool;
       b->work.uncached = nvh_toggles().uncached_planes;
       b->h_blob.host = true;
       b->h_blob.pool = &s->ctx->hpool;

@@ -59,16 +59,6 @@ __global__ void k_parse_links(int nframes, int channels, NvhFrame* frames, NvhCh
                               uint32_t* carry_exec_out, int last_decoded, NvhParseResult* result, uint4* slabs, int stride_vecs);
 __global__ void k_inverse_couple(float* magnitude, float* angle, int cnt);
 __global__ void k_copy_f4(const float4* src, float4* dst, long long n4);
-#ifdef NVH_EXPERIMENTS  // measured slower than the default path: build.py --experiments only
-__global__ void k_imdct_ola(NvhDevSetup S, NvhDevBatch Bt, const float* work, const float* carry_in, float* carry_out, float* pcm,
-                            int clip, int* clipped_flag, int run_len, int last_decoded);
-__global__ void k_spectrum_imdct2_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
-__global__ void k_spectrum_imdct2_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, float* work, int* err, int cap_pass, int cap_ops, int cap_ent NVH_DBG_PARAMS);
-__global__ void k_run4_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
-__global__ void k_run4_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
-__global__ void k_run6_c1(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
-__global__ void k_run6_c2(const NvhDevSetup* S, const NvhDevBatch* Bt, NvhRunArgs R, int* err, int cap_pass, int cap_ops, int cap_ent);
-#endif
 __global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_synth_g(NvhSynthArgs A NVH_DBG_PARAMS);     // + the general bin walk (Residue0, odd dimensions, several passes)
 __global__ void k_synth_tail(NvhSynthArgs A NVH_DBG_PARAMS);  // + the carried tail written in place (kernels_synth.hip: MODE 1)
@@ -126,7 +116,7 @@ static inline void nvh_guard_void(F&& body) noexcept {
 
 // Test / experiment switches from the environment, read once per process (before the first context exists).
 struct NvhToggles {
-  bool no_compact, fused_ola, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
+  bool no_compact, no_fused_imdct, no_gen8, unfused, no_pair, debug_occ, gpu_parse_default;
   bool no_ola_sym;  // NVH_NO_OLA_SYM: k_ola_compact without its read-once steady-state path (test / A-B aid)
   bool emit8;       // NVH_EMIT8: accepted, no effect any more (paired emission for wide frames is the default since round 5)
   bool no_emit8;    // NVH_NO_EMIT8: no paired emission for more than two channels / blocks beyond 2048 (k_synth8 + k_ola_compact; A/B aid)
@@ -140,12 +130,8 @@ struct NvhToggles {
                          // wrong PCM with GPU-parsed batches was never explained: tools/repro_uncached.py)
   bool poison_planes;    // NVH_POISON_PLANES: work planes filled with NaN patterns at upload (finds reads of regions a batch never wrote)
   bool no_slab;   // NVH_NO_SLAB: the descriptor kernels (k_spectrum_imdct & co.) instead of the slab kernels (test / A-B aid)
-  int lds_pad, run_len, ola_threads, parse_lanes, parse_waves;
-  bool run;       // NVH_RUN: the run kernel (kernels_run.hip) instead of k_spectrum_imdct + k_ola_compact -- opt-in, it measured slower
-  int run_waves;  // NVH_RUN_WAVES = 4 | 6
+  int lds_pad, ola_threads, parse_lanes, parse_waves;
   int ola_segs;   // NVH_OLA_SEGS: workgroups per frame in k_ola_compact (default: by frame size)
-  int multi;      // NVH_MULTI=1: frame loop (k_spectrum_imdct2) instead of one frame per workgroup (k_spectrum_imdct) -- opt-in, it measured slower
-  int multi_wgs;  // NVH_MULTI_WGS: workgroups per CU the frame loop is sized for (default 8)
   int phase_mask;  // debug build only (NVH_DEBUG_SPECTRUM_MASK)
 };
 const NvhToggles& nvh_toggles();
@@ -286,15 +272,9 @@ struct nvh_batch {
   bool links_ok = false;  // op_link chains usable (every frame has < 32767 ops): k_spectrum's chain walk
   int max_ops = 0, max_ent = 0, max_pass = 0;  // largest per-frame op / entry / pass slice (LDS staging capacity of k_spectrum)
   int max_vecs = 0;     // GPU-parsed batch in slab mode: its largest slab, as k_parse reported it
-  bool fused_ola = false;        // geometry admits k_imdct_ola (see its preconditions)
   bool block_only = false;       // nvh_mode_decode: stop after the windowed IMDCT (full blocks in the work planes, no overlap-add)
   bool descriptors_only = false; // nvh_residue_decode: the caller launches a descriptor kernel itself (no slabs)
   bool has_carry_in = false;
-  // run kernel (kernels_run.hip): the batch's geometry is inside its contract; hand-off flags and their epoch
-  bool run_ok = false;
-  bool force_classic = false;  // a hand-off timed out once: this batch object stays on the two-kernel path
-  DevBuf run_flags;
-  unsigned run_epoch = 0;
   DevBuf dev_copy;  // the NvhDevBatch block in device memory
   bool dev_copy_valid = false;
   // slab synthesis kernel (kernels_synth.hip): per-frame slabs, written by the packet parser (host_slab.cpp into `blob`, k_parse into `slab3`)
@@ -378,7 +358,7 @@ struct nvh_stream {
     carry[0].pool = carry[1].pool = flags.pool = pcm.pool = carry_exec.pool = pcm2[0].pool = pcm2[1].pool = pool;
     h_flags2.host = true;
     h_flags2.pool = c ? &c->hpool : nullptr;
-    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = scratch.run_flags.pool = scratch.dev_copy.pool = scratch.slab3.pool = pool;
+    scratch.blob.pool = scratch.work.pool = scratch.carry_in.pool = scratch.slabs.pool = scratch.dev_copy.pool = scratch.slab3.pool = pool;
     scratch.work.uncached = nvh_toggles().uncached_planes;
     h_pcm.host = scratch.h_blob.host = true;
     h_pcm.pool = scratch.h_blob.pool = c ? &c->hpool : nullptr;

@@ -272,37 +272,6 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
     // kernels index channel records by frame: every frame owns exactly `channels` of them (host_parse.cpp)
     if (fr.chan_off != (uint32_t)((size_t)(&fr - P.frames.data()) * (size_t)s->setup.channels)) return NVH_ERR_RUNTIME;
   }
-  {
-    // preconditions of the fused IMDCT + overlap-add kernel (kernels_imdct.hip, k_imdct_ola)
-    bool ok = !P.sequential_ola && s->setup.block0 >= 256 && s->setup.block1 <= 2048 && s->setup.channels <= 4;
-    for (size_t i = 0; ok && i < P.frames.size(); i++) {
-      const NvhFrame& fr = P.frames[i];
-      if (fr.n == 0) {
-        ok = fr.ov_frame == -2;
-        continue;
-      }
-      if (fr.ov_len > 0) {
-        const bool src_ok = fr.ov_frame == -2 || (fr.ov_frame == (int)i - 1 && P.frames[i - 1].n != 0);
-        ok = src_ok && fr.start + fr.ov_len <= fr.n / 2 && fr.ov_src >= fr.ov_n / 2 && fr.ov_src + fr.ov_len <= fr.ov_n &&
-             fr.ov_n >= 256 && fr.ov_n <= 2048;
-      }
-    }
-    b->fused_ola = ok;
-    // contract of the run kernel (kernels_run.hip): the same geometry, whole groups of four samples, a pseudo-frame
-    // (drain of the carried block) only in front
-    bool run = ok && s->fast_spectrum && b->links_ok && s->setup.channels <= 2 && !b->block_only;
-    for (size_t i = 0; run && i < P.frames.size(); i++) {
-      const NvhFrame& fr = P.frames[i];
-      if (fr.n == 0) {
-        run = i == 0 && fr.ov_frame == -2;
-        continue;
-      }
-      run = ((fr.start | fr.emit_start | fr.ov_src | fr.ov_len) & 3) == 0 && fr.emit_start >= 0 && fr.emit_count >= 0 &&
-            fr.emit_start + fr.emit_count <= fr.n;
-      if (fr.ov_len > 0 && fr.ov_frame == -2) run = run && i == 0;  // the carried block is the first frame's source only
-    }
-    b->run_ok = run;
-  }
   for (int i = b->nframes - 1; i >= 0; --i)
     if (P.frames[(size_t)i].n != 0) {
       b->last_decoded = i;
@@ -570,7 +539,7 @@ static bool slab_shape_ok(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   const NvhToggles& T = nvh_toggles();
   if (!s->shared->slab_setup_ok || !b->links_ok || b->sequential_ola || b->block_only || b->descriptors_only || (b->max_pass > 1 && !s->shared->slab_general)) return false;
-  if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact || T.fused_ola || T.run || T.multi) return false;
+  if (T.no_slab || T.unfused || T.no_fused_imdct || T.no_compact) return false;
   if (slab_wide(s) && T.no_gen8) return false;  // NVH_NO_GEN8 keeps its meaning: more than four channels through k_spectrum_gen
   return true;
 }
@@ -610,88 +579,8 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   // compact hand-over (two independent quarters per block, windowed in the overlap kernel) whenever no overlap
   // ever modifies a tail (the in-place sequential form needs the full windowed blocks)
   const NvhToggles& T = nvh_toggles();
-  const bool no_compact = T.no_compact, no_fused_ola = !T.fused_ola /* experimental run-based kernel: opt-in */, no_fused_imdct = T.no_fused_imdct;
-#ifdef NVH_EXPERIMENTS
-  // ---- the run kernel: everything from side information to PCM in one launch (opt-in: NVH_RUN=1; DESIGN.md section 6
-  // has the measurement that keeps it off by default) ----
-  if (b->run_ok && !b->force_classic && T.run && !T.unfused && !no_fused_imdct && !no_compact && !T.fused_ola && d_pcm != nullptr &&
-      s->fast_spectrum && b->links_ok && s->setup.block0 >= 256 && s->setup.block1 <= 2048) {
-    const int waves = T.run_waves == 4 ? 4 : 6;
-    const int cap_pass = b->max_pass, cap_ops = (b->max_ops + 7) & ~7, cap_ent = (b->max_ent + 14) & ~7;
-    const size_t hmax = (size_t)s->setup.block1 / 2;
-    const size_t words = 256 + (size_t)NVH_SP_FLOOR_SCRATCH_WORDS * (size_t)ch + (size_t)cap_pass * 16 + (size_t)s->setup.books.size() * 8 +
-                         (size_t)((s->dev.lattice_words + 3) & ~3) + (size_t)cap_ops * 6 + (size_t)cap_ops / 2 + (size_t)cap_ent / 2 +
-                         2 * ((size_t)s->setup.block1 / 16) + 3 * (size_t)ch * hmax;  // spectrum + two parked heads
-    if (words * 4 <= 64 * 1024) {
-      // every workgroup resident at once: the run length follows from the number of workgroups a CU holds
-      int dev_cus = 256;
-      (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device);
-      size_t per_cu = (160 * 1024) / (words * 4 + 64);
-      const size_t wave_cap = 24 / (size_t)waves;  // the kernels are built for 6 wavefronts per SIMD (80 VGPRs)
-      if (per_cu > wave_cap) per_cu = wave_cap;
-      if (per_cu < 1) per_cu = 1;
-      const size_t slots = per_cu * (size_t)(dev_cus > 0 ? dev_cus : 256);
-      int run_len = (int)(((size_t)b->nframes + slots - 1) / slots);
-      if (run_len < 1) run_len = 1;
-      if (T.run_len > 0) run_len = T.run_len;
-      const int runs = (b->nframes + run_len - 1) / run_len;
-      // hand-off flags: one word per (frame, channel), valid when equal to this launch's epoch
-      const size_t flag_bytes = (size_t)b->nframes * (size_t)ch * sizeof(unsigned);
-      const void* before = b->run_flags.p;
-      int rc = b->run_flags.reserve(flag_bytes);
-      if (rc != NVH_OK) return rc;
-      if (b->run_flags.p != before || b->run_epoch == 0xFFFFFFFFu) {
-        HIP_TRY(hipMemsetAsync(b->run_flags.p, 0, b->run_flags.cap, st));
-        b->run_epoch = 0;
-      }
-      if ((rc = upload_dev_copy(b, st)) != NVH_OK) return rc;
-      NvhRunArgs ra;
-      ra.tails = work;
-      ra.flags = (unsigned*)b->run_flags.p;
-      ra.epoch = ++b->run_epoch;
-      ra.run_len = run_len;
-      ra.pcm = d_pcm;
-      ra.carry = carry;
-      ra.carry_out = carry_out;
-      ra.clip = s->clip;
-      ra.clipped_flag = flags + 1;
-      ra.last_decoded = b->last_decoded;
-#ifdef NVH_DEBUG
-      ra.dbg = (long long*)g_dbg_buf;
-#endif
-      if (timing) HIP_TRY(hipEventRecord(ev[1], st));
-      b->slot_name[0] = "-"; b->slot_name[2] = "-"; b->slot_name[3] = "-";
-      {
-        auto kern = waves == 6 ? (ch == 1 ? k_run6_c1 : k_run6_c2) : (ch == 1 ? k_run4_c1 : k_run4_c2);
-        b->slot_name[1] = waves == 6 ? "k_run6" : "k_run4";
-        hipLaunchKernelGGL(kern, dim3((unsigned)runs), dim3((unsigned)(64 * waves)), words * 4, st,
-                           (const NvhDevSetup*)s->shared->dev_copy.p, (const NvhDevBatch*)b->dev_copy.p, ra, flags, cap_pass, cap_ops, cap_ent);
-      }
-      if (timing) {
-        HIP_TRY(hipEventRecord(ev[2], st));
-        HIP_TRY(hipEventRecord(ev[3], st));
-        HIP_TRY(hipEventRecord(ev[4], st));
-      }
-      HIP_TRY(hipGetLastError());
-      if (timing && !ext_ev) {
-        HIP_TRY(hipEventSynchronize(ev[4]));
-        for (int k = 0; k < 4; k++) {
-          float ms = 0;
-          HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-          kernel_ms[k] += ms;
-        }
-      }
-      return NVH_OK;
-    }
-  }
-#endif  // NVH_EXPERIMENTS
-#ifdef NVH_EXPERIMENTS
-  const bool use_fused_ola = b->fused_ola && !no_fused_ola && !b->block_only;
-#else
-  const bool use_fused_ola = false;  // k_imdct_ola lives in the experiments build only (build.py --experiments)
-  (void)no_fused_ola;
-#endif
-  const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !use_fused_ola && !b->block_only;
+  const bool no_compact = T.no_compact, no_fused_imdct = T.no_fused_imdct;
+  const bool compact = s->setup.block0 >= 256 && !b->sequential_ola && !no_compact && !b->block_only;
   // spectrum + IMDCT in one kernel: pair-path / fused-tail streams with block sizes the single-pass wavefront IMDCT covers
   const bool fast = s->fast_spectrum && b->links_ok;  // k_spectrum proper (pair path by chain walk, fused tail)
   bool fuse_imdct = compact && fast && s->setup.block1 <= 2048 && !no_fused_imdct;  // and the LDS-resident path is taken (below)
@@ -851,27 +740,6 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
           fprintf(stderr, "k_spectrum: lds %zu B, occupancy %d WG/CU (err %d), regs %d, static lds %zu, max dyn lds %d\n", words * 4 + lds_pad, nb,
                   (int)oe, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
         }
-#ifdef NVH_EXPERIMENTS
-        if (fuse_imdct && T.multi && s->setup.block0 >= 256) {
-          // frame loop (kernels_spectrum2.hip): as many workgroups as the device holds at once, each takes every grid-th frame
-          int dev_cus = 256;
-          (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device);
-          const size_t lds_bytes = words * 4 + 2 * (size_t)(s->setup.block1 / 16) * 4 + lds_pad;
-          size_t per_cu = (160 * 1024) / (lds_bytes + 64);
-          const size_t want = T.multi_wgs > 0 ? (size_t)T.multi_wgs : 8;  // 8 x 4 wavefronts: the 64-VGPR budget of the kernel
-          if (per_cu > want) per_cu = want;
-          if (per_cu < 1) per_cu = 1;
-          const size_t slots = per_cu * (size_t)(dev_cus > 0 ? dev_cus : 256);
-          const size_t per_wg = ((size_t)b->nframes + slots - 1) / slots;
-          const unsigned grid = (unsigned)(((size_t)b->nframes + per_wg - 1) / per_wg);
-          int rc = upload_dev_copy(b, st);
-          if (rc != NVH_OK) return rc;
-          b->slot_name[1] = "k_spectrum_imdct2";
-          hipLaunchKernelGGL(ch == 1 ? k_spectrum_imdct2_c1 : k_spectrum_imdct2_c2, dim3(grid), dim3(256), lds_bytes, st,
-                             (const NvhDevSetup*)s->shared->dev_copy.p, (const NvhDevBatch*)b->dev_copy.p, work, flags, cap_pass, cap_ops,
-                             cap_ent NVH_DBG_LAUNCH);
-        } else
-#endif
         if (fuse_imdct) {
           // + the IMDCT padding of the last channel (n/16 floats past the spectrum area)
           b->slot_name[1] = "k_spectrum_imdct";
@@ -891,19 +759,6 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
   }
   if (timing) HIP_TRY(hipEventRecord(ev[2], st));
   const size_t plane_bytes = (size_t)ch * (size_t)s->setup.block1 * sizeof(float);
-#ifdef NVH_EXPERIMENTS
-  if (use_fused_ola) {
-    // one workgroup per run of frames, one wavefront per channel; keep >= ~2048 waves in flight
-    int run_len = run_len_env > 0 ? run_len_env : 4;
-    while (run_len > 1 && (long long)(b->nframes / run_len) * ch < 2048) run_len >>= 1;
-    const int runs = (b->nframes + run_len - 1) / run_len;
-    const size_t ola_lds = (size_t)ch * (wave_lds_bytes(s->setup.block1) + (size_t)(s->setup.block1 / 2) * sizeof(float));
-    b->slot_name[2] = "k_imdct_ola"; b->slot_name[3] = "-";
-    hipLaunchKernelGGL(k_imdct_ola, dim3((unsigned)runs), dim3((unsigned)(64 * ch)), ola_lds, st, s->dev, b->dev, (const float*)work,
-                       carry, carry_out, d_pcm, s->clip, flags + 1, run_len, b->last_decoded);
-    if (timing) HIP_TRY(hipEventRecord(ev[3], st));  // slot 2 = fused IMDCT+OLA, slot 3 empty
-  } else
-#endif
   {
     b->slot_name[2] = (fuse_imdct || fuse_gen8) ? "-" : compact ? "k_imdct_compact" : (s->setup.block0 >= 256 ? "k_imdct_wave" : "k_imdct_window");
     b->slot_name[3] = compact ? "k_ola_compact" : (!b->sequential_ola ? "k_ola_emit" : "k_ola_emit_seq");

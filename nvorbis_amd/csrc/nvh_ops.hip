@@ -402,7 +402,7 @@ extern "C" int nvh_mode_decode(nvh_stream* s, const uint8_t* pkt, int len, float
     if (fb.frames.empty() || fb.frames[0].n == 0) return NVH_OK;
     const NvhFrame f0 = fb.frames[0];
     nvh_batch b;
-    b.blob.pool = b.work.pool = b.carry_in.pool = b.slabs.pool = b.run_flags.pool = b.dev_copy.pool = &s->ctx->pool;
+    b.blob.pool = b.work.pool = b.carry_in.pool = b.slabs.pool = b.dev_copy.pool = &s->ctx->pool;
     b.h_blob.host = true;
     b.h_blob.pool = &s->ctx->hpool;
     b.block_only = true;
@@ -449,7 +449,7 @@ extern "C" int nvh_residue_decode(nvh_stream* s, int residue_index, const uint8_
     int rc = one.parse_residue(residue_index, pkt ? pkt : &empty, len, bit_offset, block_size, fb, bits_consumed);
     if (rc != NVH_OK) return rc;
     nvh_batch b;
-    b.blob.pool = b.work.pool = b.carry_in.pool = b.slabs.pool = b.run_flags.pool = b.dev_copy.pool = &s->ctx->pool;
+    b.blob.pool = b.work.pool = b.carry_in.pool = b.slabs.pool = b.dev_copy.pool = &s->ctx->pool;
     b.h_blob.host = true;
     b.h_blob.pool = &s->ctx->hpool;
     b.descriptors_only = true;  // k_residue below reads the op list

@@ -112,7 +112,7 @@ _lib = None
 
 
 def lib_path():
-    # NVH_LIB: load another build of the library (development aid: same-box A/B runs, tools/ab_git.sh)
+    # NVH_LIB: load another build of the library (development aid: same-box A/B runs, tools/ab_bench.sh)
     return os.environ.get("NVH_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnvorbis_hip.so")
 
 
@@ -131,7 +131,7 @@ def lib():
         # A stale binary must never run (the .so is git-ignored but travels to the GPU box with the snapshot): the
         # library carries the hash of the sources it was built from.  The default library is rebuilt when it does not
         # match; an explicitly chosen one (NVH_LIB: debug / experiments / A-B builds) raises instead, unless
-        # NVH_ALLOW_STALE=1 says the mismatch is intended (tools/ab_git.sh compares builds of older commits).
+        # NVH_ALLOW_STALE=1 says the mismatch is intended (tools/ab_libs.sh compares builds of older commits).
         if os.environ.get("NVH_LIB"):
             if not os.environ.get("NVH_ALLOW_STALE") and _build.embedded_hash(path) != _build.source_hash():
                 raise RuntimeError("%s was built from other sources (has %s, tree is %s): rebuild it or set NVH_ALLOW_STALE=1"

@@ -14,8 +14,6 @@ OGG_FILES = ["1test", "2test", "3test", "issue6test"]
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "experiments: needs nvorbis_amd/libnvorbis_hip_exp.so (python -m nvorbis_amd.build --experiments): "
-                            "the quarantined kernels that measured slower than the default path; skipped when it has not been built")
 
 
 @pytest.fixture(scope="session")

@@ -489,40 +489,6 @@ def test_level1_entries_in_mapping_order_c4_full_depth(oracle, gpu_ctx, ogg_byte
     assert _level1_in_mapping_order(oracle, gpu_ctx, pk, range(3, len(pk))) == 10
 
 
-def _experiments_lib():
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "nvorbis_amd", "libnvorbis_hip_exp.so")
-    if not os.path.exists(path):
-        pytest.skip("experiments library not built (python -m nvorbis_amd.build --experiments)")
-    return root, path
-
-
-@pytest.mark.experiments
-@pytest.mark.parametrize("switch", ["NVH_RUN=1 NVH_RUN_WAVES=6", "NVH_RUN=1 NVH_RUN_WAVES=4", "NVH_MULTI=1", "NVH_FUSED_OLA=1"])
-def test_quarantined_kernels_smoke(switch):
-    """The kernels that measured slower than the default path live in the experiments build only
-    (libnvorbis_hip_exp.so, -DNVH_EXPERIMENTS): the run kernel (kernels_run.hip), the frame-loop kernel
-    (kernels_spectrum2.hip) and k_imdct_ola.  One smoke each: the four shipped files and the bench workload replayed through
-    the switch in a child process that loads that library."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("NVH_TEST_CHILD"):
-        pytest.skip("already inside a fallback-path run")
-    root, lib = _experiments_lib()
-    env = dict(os.environ)
-    for kv in switch.split():
-        k, v = kv.split("=")
-        env[k] = v
-    env["NVH_LIB"] = lib
-    env["NVH_TEST_CHILD"] = "1"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
-                        "-p", "no:cacheprovider", "-k", "ogg_files or bench_workload"],
-                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:]
-
-
 def test_six_channel_four_wavefront_kernel_bit_exact():
     """Streams with more than four channels run k_spectrum_gen8 (8 wavefronts per workgroup); NVH_NO_GEN8 sends them
     through k_spectrum_gen instead: the six-channel cases replayed in a child process."""
