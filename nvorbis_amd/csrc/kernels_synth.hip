@@ -46,6 +46,14 @@ namespace {
 
 // Ablation builds (tools/build_variant.py NAME -DNVH_ABL_...): one phase of the slab kernels left out, to read its marginal cost
 // in the regime the headline runs in (three streams, slots always full) -- results are wrong by construction, never shipped.
+// k_synth's transforms with every pass's twiddles in registers a pass ahead (imdct_wave.h: PassesPF): the kernels have the registers
+// for it since the output stage's addresses come from a table (round 5; k_synth_emit spills six registers and still comes out ahead).
+// Same box, three streams: neither 193.8, the odd launch only 193.9, both 195.3 M frames/s.  NVH_NO_SYNTH_PF: build variants.
+#ifdef NVH_NO_SYNTH_PF
+constexpr bool kSynthPF = false, kSynthPFEmit = false;
+#else
+constexpr bool kSynthPF = true, kSynthPFEmit = true;
+#endif
 #ifdef NVH_ABL_NO_XFORM
 constexpr int kAblSkip = 3;  // the transform without its radix passes and the D = 4, 2, 1 pass
 #else
@@ -645,10 +653,10 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
       if (slot == 0) ca[0] = v; else if (slot == 2) cb[0] = v; else if (slot == 4) ca[1] = v; else if (slot == 6) cb[1] = v;
     };
     switch (n) {
-      case 256: imdct_wave_sink<8, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
-      case 512: imdct_wave_sink<9, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
-      case 1024: imdct_wave_sink<10, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
-      case 2048: imdct_wave_sink<11, false, decltype(sink), true>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
+      case 256: imdct_wave_sink<8, false, decltype(sink), true, false, false, kSynthPFEmit>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
+      case 512: imdct_wave_sink<9, false, decltype(sink), true, false, false, kSynthPFEmit>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
+      case 1024: imdct_wave_sink<10, false, decltype(sink), true, false, false, kSynthPFEmit>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
+      case 2048: imdct_wave_sink<11, false, decltype(sink), true, false, false, kSynthPFEmit>(X, nullptr, scratch, Aa, Bb, Cc, TW, lane, sink, (stamps && wv == 0) ? stamps + 10 : nullptr, kAblSkip); break;
       default: __builtin_trap();
     }
     if (pon) {
@@ -1063,12 +1071,12 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   typedef const __attribute__((address_space(4))) uint32_t* const_words;
   const_words gh = (const_words)(unsigned long long)gslab;
   const unsigned w0 = gh[0], w1 = gh[1], w2 = gh[2], w3 = gh[3], w4 = gh[4], w5 = gh[5], frame = gh[6], cpl_word = gh[7];
-  constexpr unsigned kSpec = MAXCH > 2 ? 2 * NT : NT;  // 16-byte units fetched before the header is known
+  constexpr unsigned kSpec = MAXCH > 2 ? 2 * NT : (NT < 256 ? 256 : NT);  // 16-byte units fetched before the header is known
   {
     const int v = tid;  // 16-byte unit handled by this lane: wavefront w moves units [64 w, 64 w + 64)
     constexpr int kAux = (MAXCH <= 2 && MODE < 2) ? kSlabAuxOdd : kSlabAux;
     if (v < A.cap_vecs) dma16<kAux>(gslab + v, slab + wv * 256);
-    if (MAXCH > 2 && NT + v < A.cap_vecs) dma16<kSlabAux>(gslab + NT + v, slab + (NT / 64 + wv) * 256);  // big slabs: 16 KB up front
+    if ((MAXCH > 2 || NT < 256) && NT + v < A.cap_vecs) dma16<kAux>(gslab + NT + v, slab + (NT / 64 + wv) * 256);  // big slabs: 16 KB up front (two-wavefront workgroups: the same 4 KB)
     for (int c0 = wv * 64; c0 < A.const_vecs; c0 += NT)
       if (c0 + lane < A.const_vecs) dma16(A.consts + c0 + lane, smem + c0 * 4);
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1078,7 +1086,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     // the even launch's slab of the frame in front of this one: one dword per 128-byte line brings it into this XCD's L2 (the
     // value is not used; the load is volatile so that it is issued)
     if (A.prefetch_prev && wv == NT / 64 - 1 && f >= 1) {
-      const int lines = (A.cap_vecs < NT ? A.cap_vecs : NT) >> 3;
+      const int lines = (A.cap_vecs < 256 ? A.cap_vecs : 256) >> 3;
       if (lane < lines) {
         const volatile unsigned* pp = reinterpret_cast<const volatile unsigned*>(A.slabs + (long long)(f - 1) * A.stride_vecs) + lane * 32;
         (void)*pp;
@@ -1284,10 +1292,10 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
       long long* imdct_stamp = nullptr;
 #endif
       switch (n) {
-        case 256: imdct_wave<8, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
-        case 512: imdct_wave<9, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
-        case 1024: imdct_wave<10, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
-        case 2048: imdct_wave<11, false, true, true, false, true>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
+        case 256: imdct_wave<8, false, true, true, false, true, kSynthPF>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
+        case 512: imdct_wave<9, false, true, true, false, true, kSynthPF>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
+        case 1024: imdct_wave<10, false, true, true, false, true, kSynthPF>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
+        case 2048: imdct_wave<11, false, true, true, false, true, kSynthPF>(X, out, nullptr, scratch, Aa, Bb, Cc, TW, lane, imdct_stamp, kAblSkip); break;
         default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
       }
     } else {
@@ -1387,24 +1395,28 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
 }
 
 // 8 waves per SIMD = 8 resident workgroups per CU: the register budget (64 VGPRs) is part of the design
-extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef NVH_SYNTH_NT
+#define NVH_SYNTH_NT SP_THREADS
+#define NVH_SYNTH_WPE 8, 8
+#endif
+extern "C" __global__ void __launch_bounds__(NVH_SYNTH_NT) __attribute__((amdgpu_waves_per_eu(NVH_SYNTH_WPE)))
 k_synth(NvhSynthArgs A NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  synth_body<SP_THREADS, 2>(A, smem NVH_DBG_ARGS);
+  synth_body<NVH_SYNTH_NT, 2>(A, smem NVH_DBG_ARGS);
 }
 
 // up to eight channels, blocks up to 4096: 8 wavefronts per workgroup, the CU's LDS decides how many are resident
-extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+extern "C" __global__ void __launch_bounds__(NVH_SYNTH_NT) __attribute__((amdgpu_waves_per_eu(NVH_SYNTH_WPE)))
 k_synth_tail(NvhSynthArgs A NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  synth_body<SP_THREADS, 2, 1>(A, smem NVH_DBG_ARGS);
+  synth_body<NVH_SYNTH_NT, 2, 1>(A, smem NVH_DBG_ARGS);
 }
 
 // up to eight channels, blocks up to 4096: 8 wavefronts per workgroup, the CU's LDS decides how many are resident
-extern "C" __global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+extern "C" __global__ void __launch_bounds__(NVH_SYNTH_NT) __attribute__((amdgpu_waves_per_eu(NVH_SYNTH_WPE)))
 k_synth_emit(NvhSynthArgs A NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  synth_body<SP_THREADS, 2, 2>(A, smem NVH_DBG_ARGS);
+  synth_body<NVH_SYNTH_NT, 2, 2>(A, smem NVH_DBG_ARGS);
 }
 
 // mono / stereo streams some of whose frames need the general bin walk (never with paired emission)

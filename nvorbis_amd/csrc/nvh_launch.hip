@@ -500,6 +500,9 @@ static int upload_dev_copy(nvh_batch* b, hipStream_t st) {
 
 // The wide form (k_synth8: 512 threads, up to eight channels, blocks up to 4096) against k_synth (256 threads, mono / stereo,
 // blocks up to 2048, 8 workgroups per CU).
+#ifndef NVH_SYNTH_NT
+#define NVH_SYNTH_NT 256  // threads of a k_synth workgroup (kernels_synth.hip; build variants: tools/build_variant.py)
+#endif
 static bool slab_wide(const nvh_stream* s) { return s->setup.channels > 2 || s->setup.block1 > 2048; }
 
 // The batch's largest slab in 16-byte units (nvh_format.h: NvhSlabHdr): known exactly for slabs the host parser's thread wrote,
@@ -640,7 +643,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     } else if (wide_general) hipLaunchKernelGGL(k_synth8_g, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
     else if (wide) hipLaunchKernelGGL(k_synth8, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
     else if (narrow_general) hipLaunchKernelGGL(k_synth_g, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
-    else if (!emitted) hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+    else if (!emitted) hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(NVH_SYNTH_NT), synth_lds, st, A NVH_DBG_LAUNCH);
     else {
       // odd frames first (their planes are what the even frames overlap-add with), then the even frames, which emit
       // (the odd frames never emit: the plain kernel, or the one that can write the carried tail when the last decoded block is odd)
@@ -650,13 +653,13 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       A.xcd_map = nvh_toggles().xcd_map ? 1 : 0;  // opt-in: one stream 36.3 -> 35.6 us per pass, three streams 174 -> 172 M frames/s
       if (b->nframes > 1) {
         if (b->last_decoded >= 0 && (b->last_decoded & 1))
-          hipLaunchKernelGGL(k_synth_tail, dim3((unsigned)(b->nframes / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+          hipLaunchKernelGGL(k_synth_tail, dim3((unsigned)(b->nframes / 2)), dim3(NVH_SYNTH_NT), synth_lds, st, A NVH_DBG_LAUNCH);
         else
-          hipLaunchKernelGGL(k_synth, dim3((unsigned)(b->nframes / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+          hipLaunchKernelGGL(k_synth, dim3((unsigned)(b->nframes / 2)), dim3(NVH_SYNTH_NT), synth_lds, st, A NVH_DBG_LAUNCH);
       }
       A.f0 = 0;
       A.prefetch_prev = 0;
-      hipLaunchKernelGGL(k_synth_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
+      hipLaunchKernelGGL(k_synth_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(NVH_SYNTH_NT), synth_lds, st, A NVH_DBG_LAUNCH);
     }
     if (emitted) b->slot_name[1] = wide ? "k_synth8+k_synth8_emit" : "k_synth+k_synth_emit";  // odd frames, then the emitting even frames
     slab_done = true;
