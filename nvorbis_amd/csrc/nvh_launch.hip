@@ -1,4 +1,6 @@
 // nvh_launch.hip -- moving a parsed batch into HBM and the launch policy: which kernel variants a batch runs through.
+#include <chrono>
+
 #include "nvh_internal.h"
 
 static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResult* d_res);
@@ -51,7 +53,6 @@ static int poison_planes(nvh_stream* s, nvh_batch* b, size_t bytes) {
 }
 
 // GPU-parse mode: upload frame geometry + packets, let k_parse produce the descriptors into per-frame slabs.
-#include <chrono>
 static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>& ola_list) {
   static const bool tprint = std::getenv("NVH_TIME_UPLOAD") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -78,21 +79,25 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   const size_t o_pk = al(o_ol + std::max<size_t>(ola_list.size(), 1) * sizeof(int));
   const size_t pool_bytes = P.pkt_pool.size;
   const size_t host_bytes = pool_pinned ? al(o_pk) : al(o_pk + pool_bytes + 8);  // what the staging block holds
-  // ... and the device-only slabs behind it
+  // Slab mode: k_parse writes the synthesis kernels' slabs itself (kernels_parse.hip: parse_body<.., SLAB>), at the stride of the
+  // setup's worst case; the LDS the synthesis kernels need is sized from the batch's largest slab, reported with the result.
+  // (a setup whose worst-case slabs would not fit a sane allocation for this batch takes the descriptor form instead of failing)
+  b->slab_stride_vecs = T.slab_stride_vecs;
+  b->slab_cap_vecs = T.slab_stride_vecs;  // for the pre-launch size check: the bound
+  const bool slab_fits = (size_t)std::max<size_t>(nf, 1) * (size_t)T.slab_stride_vecs * 16 <= ((size_t)4 << 30);
+  const bool slab_mode = T.slab_stride_vecs > 0 && slab_fits && slab_shape_ok(b) && slab_size_ok(b);
+  // ... and the device-only slabs behind it (slab mode writes no op / op-link descriptors: every vector write goes straight to its
+  // record in the slab, so those two regions shrink to nothing)
+  const size_t ops_per_frame = slab_mode ? 0 : (size_t)T.cap_ops;
   const size_t o_ps = al(o_pk + pool_bytes + 8);
   const size_t o_op = al(o_ps + nf * (size_t)T.cap_pass * sizeof(NvhResPass));
-  const size_t o_lk = al(o_op + nf * (size_t)T.cap_ops * sizeof(NvhResOp));
-  const size_t o_en = al(o_lk + nf * (size_t)T.cap_ops * sizeof(uint16_t));
+  const size_t o_lk = al(o_op + nf * ops_per_frame * sizeof(NvhResOp));
+  const size_t o_en = al(o_lk + nf * ops_per_frame * sizeof(uint16_t));
   const size_t o_po = al(o_en + nf * (size_t)T.cap_ent * sizeof(uint16_t) + 64);
   const size_t o_sc = al(o_po + nf * (size_t)ch * NVH_MAX_POSTS * sizeof(uint16_t));
   const size_t row_words = 2 * (size_t)T.cap_parts;  // the residue walk's rows
   const size_t o_rs = al(o_sc + nf * row_words * sizeof(int));
   const size_t total = al(o_rs + sizeof(NvhParseResult));
-  // Slab mode: k_parse writes the synthesis kernels' slabs itself (kernels_parse.hip: parse_body<.., SLAB>), at the stride of the
-  // setup's worst case; the LDS the synthesis kernels need is sized from the batch's largest slab, reported with the result.
-  b->slab_stride_vecs = T.slab_stride_vecs;
-  b->slab_cap_vecs = T.slab_stride_vecs;  // for the pre-launch size check: the bound
-  const bool slab_mode = T.slab_stride_vecs > 0 && slab_shape_ok(b) && slab_size_ok(b);
   if (slab_mode) {
     int rcs = b->slab3.reserve(((size_t)std::max<size_t>(nf, 1) * (size_t)T.slab_stride_vecs * 16 + 4096 + 255) & ~(size_t)255);
     if (rcs != NVH_OK) return rcs;
