@@ -96,8 +96,10 @@ struct NvhSynthArgs {
 __device__ __forceinline__ void pcm_store4(float4* p, float a, float b, float c, float d) {
   typedef float nvh_v4f __attribute__((ext_vector_type(4)));
   const nvh_v4f v = {a, b, c, d};
-#ifdef NVH_PCM_SC
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+#ifdef NVH_PCM_POLICY
+#define NVH_STR2(x) #x
+#define NVH_STR(x) NVH_STR2(x)
+  asm volatile("global_store_dwordx4 %0, %1, off " NVH_STR(NVH_PCM_POLICY) : : "v"(p), "v"(v) : "memory");
 #else
   __builtin_nontemporal_store(v, reinterpret_cast<nvh_v4f*>(p));
 #endif
