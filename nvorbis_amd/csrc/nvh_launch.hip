@@ -158,13 +158,16 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   b->d_ola_list = (const int*)(base + o_ol);
   if (nf) {
     const unsigned blocks = (unsigned)((nf + 63) / 64);
-    // Launch shape.  Packets take different paths through the parser, so the lanes of a wavefront mostly run one after
-    // the other, and one wavefront alone issues an instruction every ~5 cycles at best: aim at ~2 wavefronts per SIMD
-    // (2048 in all) with as few packets each as that allows; workgroups of 4 wavefronts, two per CU (LDS tables).
+    // Launch shape.  A batch's parse time has a floor -- one lane's serial decode of one packet, ~0.5 ms -- that no shape moves
+    // (tools/sweep_parse_shape.sh: 0.54-0.60 ms per 4096 packets for 1-2 packets per wavefront x 4-16 wavefronts per workgroup);
+    // what the shape decides is how many parses share the chip.  Workgroups of 16 wavefronts (one copy of the Huffman tables per
+    // CU instead of two to four) and up to 4096 wavefronts: a lone 4096-packet batch 0.55 ms (0.54 with the round-4 shape: 4
+    // wavefronts, 2048 in all), 32 768 packets 1.17 against 1.23 ms, the corpus pass (16 host threads, each parsing its own
+    // file's batches) 2.57 -> 2.01 s.
     const int lanes_env = nvh_toggles().parse_lanes, waves_env = nvh_toggles().parse_waves;
-    const int kParseWaves = (waves_env >= 1 && waves_env <= 16) ? waves_env : 4;
+    const int kParseWaves = (waves_env >= 1 && waves_env <= 16) ? waves_env : 16;
     int lanes = 1;
-    while (lanes < 64 && (nf + (size_t)lanes - 1) / (size_t)lanes > 2048) lanes *= 2;
+    while (lanes < 64 && (nf + (size_t)lanes - 1) / (size_t)lanes > 4096) lanes *= 2;
     if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
     const size_t per_wg = (size_t)kParseWaves * (size_t)lanes;
     const unsigned pblocks = (unsigned)((nf + per_wg - 1) / per_wg);
