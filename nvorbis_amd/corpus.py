@@ -37,7 +37,9 @@ def gather_pcm(local, nfiles, rank, world, dist=None, device="cpu", to_host=True
     Exchange: one all_gather of per-file sample counts, then one flat payload per rank (ascending file index) sent
     point-to-point to the root, all transfers posted as one group (xGMI is point-to-point: every peer has its own
     link to the root, so the root receives from all of them at once; a ring collective would be the wrong shape)."""
-    import_torch = dist is not None and world > 1
+    # (a process group of one rank still goes through the backend: the counts' all_gather and the barrier are then the whole
+    # exchange -- tests/test_multi_rank_gpu.py initialises RCCL that way on a one-GPU box)
+    import_torch = dist is not None
     if not import_torch:
         vals = [local.get(i) for i in range(nfiles)]
         if to_host:

@@ -55,3 +55,23 @@ def test_corpus_transcode_two_ranks_equals_one_rank():
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     assert one["pcm_floats"] == two["pcm_floats"] > 0
     assert one["pcm_sha256"] == two["pcm_sha256"]
+
+
+def test_corpus_transcode_one_rank_through_rccl():
+    """RCCL itself on the one GPU a test box has: a process group of one rank over backend "nccl" (two ranks cannot share a device
+    under RCCL), so that the library initialises under this code and the counts' all_gather and the barriers of the gather go
+    through it with device tensors.  The point-to-point payloads need a peer: they stay with the driver's 8-GPU run."""
+    def run(rccl):
+        env = dict(os.environ)
+        env.pop("NVH_BENCH_SHARE_GPU", None)
+        cmd = [sys.executable]
+        if rccl:
+            env["NVH_RCCL_WORLD1"] = "1"
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29733"]
+        cmd += [os.path.join(ROOT, "tools", "corpus_transcode.py"), "--files", "9", "--workers", "4"]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        return _last_json(r.stdout)
+    plain, rccl = run(False), run(True)
+    assert plain["backend"] is None and rccl["backend"] == "nccl" and rccl["n_gpus"] == 1
+    assert plain["pcm_sha256"] == rccl["pcm_sha256"] and plain["pcm_floats"] == rccl["pcm_floats"] > 0

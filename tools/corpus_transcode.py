@@ -32,7 +32,9 @@ if share_gpu:
     local = 0
 torch.cuda.set_device(local)
 dist = None
-if world > 1:
+# NVH_RCCL_WORLD1=1 (under torch.distributed.run --nproc-per-node 1): a one-rank RCCL process group, so that the library is
+# initialised and the counts' all_gather + barriers run through it on a one-GPU box
+if world > 1 or (os.environ.get("NVH_RCCL_WORLD1") and "RANK" in os.environ):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if share_gpu:
@@ -70,7 +72,7 @@ if rank == 0:
     hh = hashlib.sha256()
     for o in out:  # every file's PCM in file order, as gathered on rank 0
         hh.update(o.cpu().numpy().tobytes())
-    print(json.dumps({"pcm_sha256": hh.hexdigest(), "files": len(files), "n_gpus": world, "workers_per_gpu": a.workers, "decode_s": t1 - t0, "gather_s": t2 - t1,
+    print(json.dumps({"pcm_sha256": hh.hexdigest(), "files": len(files), "n_gpus": world, "backend": dist.get_backend() if dist is not None else None, "workers_per_gpu": a.workers, "decode_s": t1 - t0, "gather_s": t2 - t1,
                       "files_per_s": len(files) / (t2 - t0), "pcm_floats": int(samples),
                       "long_frame_equivalents_per_s": samples / 2 / 1024 / (t2 - t0)}), flush=True)
 if dist is not None:
