@@ -234,6 +234,8 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
     import os
     import time
     timing = bool(os.environ.get("NVH_CORPUS_TIMING"))
+    if os.environ.get("NVH_CORPUS_BATCH"):  # A/B aid: packets per parse / synthesis batch
+        batch_frames = int(os.environ["NVH_CORPUS_BATCH"])
     t_start = time.perf_counter()
     errors = _run_pool(n, workers, device, index_one)
     if errors:

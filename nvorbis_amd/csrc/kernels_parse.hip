@@ -562,8 +562,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     uint16_t* __restrict__ eout = entries + ent_base + nent;
                     // (one exit test: the table read is always in range, so it is not guarded)
                     uint32_t node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
-                    while ((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)((node >> 7) & 1u)) {
-                      const uint32_t len = node & 0x7Fu;
+                    auto consume = [&](const uint32_t len) {
                       p.buf >>= len;
                       p.avail -= len;
                       p.pos += len;
@@ -574,7 +573,36 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                         p.buf |= (uint64_t)word << p.avail;
                         p.avail += 32u;
                       }
-                      eout[done] = (uint16_t)(node >> 8);
+                    };
+                    for (;;) {
+                      while ((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)((node >> 7) & 1u)) {
+                        consume(node & 0x7Fu);
+                        eout[done] = (uint16_t)(node >> 8);
+                        ++done;
+                        node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                      }
+                      // A code longer than the prefix (Codebook.cs:307-318), still 32 bits left: its slot's group of overflow nodes
+                      // (decode_scalar's scan, same nodes in the same order) without leaving this loop -- the general loop below
+                      // costs some hundred exec-mask instructions per symbol, and packets that use the long codes often (the C5
+                      // writer's, which draws entries uniformly) spent most of their parse there.
+                      if (!((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)(book.has_overflow != 0))) break;
+                      const uint32_t data = (uint32_t)p.buf & (book.max_bits >= 32 ? 0xFFFFFFFFu : (1u << book.max_bits) - 1u);
+                      const NvhPOverflow* __restrict__ ov = T.overflow + book.ovf_off;
+                      uint32_t cnt = node & 0x7Fu;
+                      if (cnt == 0x7Fu) cnt = book.ovf_count;
+                      else ov += book.ovf_count + (node >> 8);
+                      uint32_t hit_len = 0, hit_val = 0;
+                      for (uint32_t k = 0; k < cnt; ++k) {
+                        const uint4 o = *reinterpret_cast<const uint4*>(ov + k);  // bits, mask, value, length
+                        if (o.x == (data & o.y)) {
+                          hit_val = o.z;
+                          hit_len = o.w;
+                          break;
+                        }
+                      }
+                      if (hit_len == 0u || hit_len > 32u) break;  // no match (or nothing this loop may skip): the general loop decides
+                      consume(hit_len);
+                      eout[done] = (uint16_t)hit_val;
                       ++done;
                       node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
                     }

@@ -9,6 +9,13 @@ if os.environ.get("NVH_TIME_PARSE_CHILD"):
     ctx = nv.Context(0)
     N = int(os.environ.get("FRAMES", "4096"))
     pk = [ll[(i + 1) % len(ll)] for i in range(N)]
+    if os.environ.get("CORPUS"):  # packets of a C5 corpus file (tests/vorbis_encode.corpus_file: full-depth writer packets) instead of 3test's own
+        from tests import vorbis_encode as ve
+        S = ve.setup_of(headers)
+        pool = ve.packet_pool(S, 5, per_kind=64)
+        cpk, _, _ = nv.demux_ogg(ve.corpus_file(S, list(headers), pool, 700, scale=1.0))
+        cpk = cpk[3:]
+        pk = [cpk[i % len(cpk)] for i in range(N)]
     offs = np.zeros(N + 1, np.int64); offs[1:] = np.cumsum([len(p) for p in pk])
     pa = nv.PacketArray(np.frombuffer(b"".join(pk), np.uint8), offs, np.full(N, -1, np.int64), np.zeros(N, np.uint8))
     st = nv.Stream(ctx, *headers)
@@ -25,6 +32,6 @@ r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, stdout=
 w = [float(x) for x in re.findall(r"wait for k_parse ([0-9.]+) ms", r.stdout)]
 if not w:
     print(r.stdout[-2000:])
-print("FRAMES %s LANES %s WAVES %s: wait for k_parse min %.3f ms median %.3f ms (%d uploads)" % (
-    os.environ.get("FRAMES", "4096"), os.environ.get("NVH_PARSE_LANES", "-"), os.environ.get("NVH_PARSE_WAVES", "-"),
+print("FRAMES %s%s LANES %s WAVES %s: wait for k_parse min %.3f ms median %.3f ms (%d uploads)" % (
+    os.environ.get("FRAMES", "4096"), " (corpus packets)" if os.environ.get("CORPUS") else "", os.environ.get("NVH_PARSE_LANES", "-"), os.environ.get("NVH_PARSE_WAVES", "-"),
     min(w[2:]) if len(w) > 2 else -1, sorted(w[2:])[len(w[2:]) // 2] if len(w) > 2 else -1, len(w)))
