@@ -95,6 +95,16 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern unsafe int nvh_stream_synth_begin(IntPtr stream, float* pcmHost, long capacity, out long expected);
         [DllImport(Lib)] public static extern int nvh_stream_synth_end(IntPtr stream, out long written);
 
+        /// <summary>The corpus gather (include/nvorbis_hip.h, "multi-GPU"): RCCL over xGMI through the library, one process per GPU (GpuCorpusGather.cs).</summary>
+        public const int NVH_COMM_ID_BYTES = 128;
+        public const int NVH_GATHER_SELF_P2P = 1;
+        [DllImport(Lib)] public static extern unsafe int nvh_comm_unique_id(byte* id);
+        [DllImport(Lib)] public static extern unsafe int nvh_comm_create(IntPtr ctx, byte* id, int rank, int world, out IntPtr comm);
+        [DllImport(Lib)] public static extern void nvh_comm_destroy(IntPtr comm);
+        [DllImport(Lib)] public static extern int nvh_comm_info(IntPtr comm, out int rank, out int world);
+        [DllImport(Lib)] public static extern unsafe int nvh_comm_allgather_i64(IntPtr comm, long* mine, int n, long* all);
+        [DllImport(Lib)] public static extern unsafe int nvh_comm_gather_pcm(IntPtr comm, IntPtr dSend, long sendCount, IntPtr dRecv, long* counts, int root, int flags);
+
         internal static void Check(int rc)
         {
             switch (rc)

@@ -339,6 +339,34 @@ int nvh_ogg_index_page(const nvh_ogg_index *ix, int page, int64_t *granule, int 
 int nvh_ogg_seek(const nvh_ogg_index *ix, const nvh_stream *s, int64_t granule_pos, int pre_roll, int64_t *packet_index,
                  int64_t *granule_out);
 
+/* ---- multi-GPU: the gather of the file-parallel corpus transcode (SURVEY 8 e) ----
+ * StreamDecoder holds per-stream state only (StreamDecoder.cs:35-39), so a corpus shards by file: every process decodes its
+ * files on its own GPU (one nvh_ctx per process) and the PCM is gathered on one of them -- the path's one collective, through
+ * RCCL over xGMI.  Python callers have nvorbis_amd.corpus (torch.distributed); these entry points are the same exchange for a
+ * host without it (the C# host: INTEGRATION.md, "Eight GPUs").  RCCL is loaded on first use (dlopen); NVH_ERR_UNSUPPORTED when
+ * it is not installed, NVH_ERR_DEVICE for an RCCL failure (nvh_last_hip_error() = 10000 + its ncclResult_t).
+ *   nvh_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other processes by whatever
+ *                        means the host has (a file, a socket, its job launcher);
+ *   nvh_comm_create      every rank, with the same id (ncclCommInitRank on the context's device; collective: returns when
+ *                        all `world` ranks have called it);
+ *   nvh_comm_allgather_i64  `n` 64-bit words per rank -- e.g. the number of floats of each file it decoded -- to every rank
+ *                        (host arrays: mine[n], all[world * n], rank-major);
+ *   nvh_comm_gather_pcm  rank r's `send_count` floats at d_send (HBM) arrive at d_recv + sum(counts[0..r-1]) on `root`
+ *                        (d_recv: HBM, sum(counts) floats, ignored elsewhere); counts[world] = every rank's total, the same on every rank.  One
+ *                        group of point-to-point transfers on the context's stream, waited for.  The root's own part is a
+ *                        device copy; NVH_GATHER_SELF_P2P sends it through RCCL as well (a one-rank check of the
+ *                        point-to-point path on a single GPU). */
+#define NVH_COMM_ID_BYTES 128
+#define NVH_GATHER_SELF_P2P 1
+typedef struct nvh_comm nvh_comm;
+int nvh_comm_unique_id(uint8_t *id);
+int nvh_comm_create(nvh_ctx *ctx, const uint8_t *id, int rank, int world, nvh_comm **out);
+void nvh_comm_destroy(nvh_comm *comm);
+int nvh_comm_info(const nvh_comm *comm, int *rank, int *world);
+int nvh_comm_allgather_i64(nvh_comm *comm, const int64_t *mine, int n, int64_t *all);
+int nvh_comm_gather_pcm(nvh_comm *comm, const float *d_send, int64_t send_count, float *d_recv, const int64_t *counts,
+                        int root, int flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,39 @@ def gather_pcm(local, nfiles, rank, world, dist=None, device="cpu", to_host=True
     return out
 
 
+def gather_pcm_native(local, nfiles, comm, root=0, flags=0):
+    """gather_pcm through the library's own RCCL entry points (include/nvorbis_hip.h: nvh_comm_*; nvorbis_amd.Comm) instead
+    of torch.distributed -- the exchange a host without Python performs ("Eight GPUs"), used here so that it
+    is tested: an all-gather of the per-file float counts, one flat payload per rank (ascending file index) point to point to
+    `root`.  `local`: {file index -> float32 torch tensor on this process's GPU}.  Returns, on the root, a list of nfiles
+    device tensors (views of the receive buffer, files that produced nothing: empty), None elsewhere."""
+    import torch
+    mine = [0] * nfiles
+    for i, a in local.items():
+        mine[i] = int(a.numel())
+    every = comm.allgather_i64(mine)  # [world][nfiles]
+    totals = [sum(row) for row in every]
+    idx = sorted(local.keys())
+    dev = local[idx[0]].device if idx else torch.device("cuda", torch.cuda.current_device())
+    flat = _flat_payload([local[i].reshape(-1) for i in idx], torch, dev)
+    recv = torch.empty(sum(totals) if comm.rank == root else 0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)  # the payload was written on torch's stream; the gather runs on the context's
+    comm.gather_pcm(flat.data_ptr() if flat.numel() else 0, int(flat.numel()), recv.data_ptr() if recv.numel() else 0, totals, root, flags)
+    if comm.rank != root:
+        return None
+    out = [None] * nfiles
+    off = 0
+    for r in range(comm.world):
+        for i in range(nfiles):
+            if every[r][i] > 0:
+                out[i] = recv[off:off + every[r][i]]
+                off += every[r][i]
+    for i in range(nfiles):
+        if out[i] is None:
+            out[i] = torch.zeros(0, dtype=torch.float32, device=dev)
+    return out
+
+
 def _to_numpy(v):
     if v is None:
         return np.zeros(0, np.float32)

@@ -85,6 +85,48 @@ def demux_ogg(data: bytes, forward_only=False):
     return [pa[i] for i in range(n)], pa.granules[:n].copy(), pa.flags[:n].copy()
 
 
+class Comm:
+    """nvh_comm: the corpus gather through RCCL's C API (include/nvorbis_hip.h, "multi-GPU"; nvh_comm.hip) -- what a host
+    without torch.distributed calls.  One per process, on the process's Context.  `id_bytes`: Comm.unique_id() of rank 0,
+    handed to the other ranks by the caller."""
+
+    SELF_P2P = 1  # NVH_GATHER_SELF_P2P
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib().nvh_comm_unique_id(buf), "nvh_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, ctx, id_bytes, rank, world):
+        if len(id_bytes) != 128:
+            raise ValueError("the id is the 128 bytes Comm.unique_id() returned")
+        self._h = C.c_void_p()
+        self.rank, self.world = int(rank), int(world)
+        self._ctx = ctx  # (the context must outlive the communicator)
+        buf = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
+        check(lib().nvh_comm_create(ctx._h, buf, int(rank), int(world), C.byref(self._h)), "nvh_comm_create")
+
+    def allgather_i64(self, mine):
+        """`mine`: a list of n ints; returns world lists of n ints (rank-major)."""
+        n = len(mine)
+        src = (C.c_int64 * n)(*[int(v) for v in mine])
+        out = (C.c_int64 * (self.world * n))()
+        check(lib().nvh_comm_allgather_i64(self._h, src, n, out), "nvh_comm_allgather_i64")
+        return [[int(out[r * n + k]) for k in range(n)] for r in range(self.world)]
+
+    def gather_pcm(self, d_send, send_count, d_recv, counts, root=0, flags=0):
+        """d_send / d_recv: device addresses (ints); counts[world]: every rank's total number of floats."""
+        arr = (C.c_int64 * self.world)(*[int(v) for v in counts])
+        check(lib().nvh_comm_gather_pcm(self._h, C.c_void_p(d_send), int(send_count), C.c_void_p(d_recv), arr, int(root), int(flags)),
+              "nvh_comm_gather_pcm")
+
+    def close(self):
+        if self._h:
+            lib().nvh_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 class Context:
     """nvh_ctx: one GPU + one HIP stream."""
 

@@ -329,7 +329,7 @@ def test_csharp_pinvoke_declarations_follow_the_header():
             if re.match(r"(const )?int [a-z_]+$", cp):
                 assert sp.startswith("int "), (name, cp, sp)
     # every native call in the C# sources is declared
-    for fn in ("GpuStreamDecoder.cs", "GpuFactory.cs"):
+    for fn in ("GpuStreamDecoder.cs", "GpuFactory.cs", "GpuCorpusGather.cs"):
         src = open(os.path.join(ROOT, "csharp", fn)).read()
         for called in set(re.findall(r"NativeMethods\.(nvh_[a-z0-9_]+)\(", src)):
             assert called in decls, (fn, called)

@@ -75,3 +75,40 @@ def test_corpus_transcode_one_rank_through_rccl():
     plain, rccl = run(False), run(True)
     assert plain["backend"] is None and rccl["backend"] == "nccl" and rccl["n_gpus"] == 1
     assert plain["pcm_sha256"] == rccl["pcm_sha256"] and plain["pcm_floats"] == rccl["pcm_floats"] > 0
+
+
+def test_native_rccl_gather_entry_points(tmp_path):
+    """include/nvorbis_hip.h's nvh_comm_* (the gather for a host without torch.distributed: RCCL's C API inside the library) on
+    the one GPU of a test box: a communicator of one rank, the counts' all-gather, and the payload through ncclSend / ncclRecv
+    (NVH_GATHER_SELF_P2P: the root's own part takes the point-to-point path too) -- byte-identical to the plain run, and to the
+    device-copy form."""
+    import numpy as np
+    import torch
+    import nvorbis_amd as nv
+    ctx = nv.Context(0)
+    comm = nv.Comm(ctx, nv.Comm.unique_id(), 0, 1)
+    try:
+        assert comm.allgather_i64([5, 0, 7]) == [[5, 0, 7]]
+        src = torch.arange(1 << 20, dtype=torch.float32, device="cuda:0") * 0.5
+        for flags in (0, nv.Comm.SELF_P2P):
+            dst = torch.full((src.numel(),), -1.0, dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            comm.gather_pcm(src.data_ptr(), src.numel(), dst.data_ptr(), [src.numel()], 0, flags)
+            assert torch.equal(src, dst)
+        with pytest.raises(nv.NvhError):  # counts must say what is sent
+            comm.gather_pcm(src.data_ptr(), src.numel(), src.data_ptr(), [src.numel() - 1], 0, 0)
+    finally:
+        comm.close()
+        ctx.close()
+
+    def run(extra):
+        env = dict(os.environ)
+        env.pop("NVH_BENCH_SHARE_GPU", None)
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "corpus_transcode.py"), "--files", "9", "--workers", "4"] + extra
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        return _last_json(r.stdout)
+    plain = run([])
+    native = run(["--native-gather", str(tmp_path / "comm_id"), "--self-p2p"])
+    assert native["backend"].startswith("rccl") and plain["backend"] is None
+    assert plain["pcm_sha256"] == native["pcm_sha256"] and plain["pcm_floats"] == native["pcm_floats"] > 0

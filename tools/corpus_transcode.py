@@ -22,6 +22,10 @@ ap.add_argument("--dir", type=str, default=None)
 ap.add_argument("--workers", type=int, default=16)
 ap.add_argument("--gpu-parse", action="store_true")
 ap.add_argument("--synthetic", action="store_true")
+ap.add_argument("--native-gather", type=str, default=None, metavar="ID_FILE",
+                help="gather through the library's own RCCL entry points (nvh_comm_*, what a host without torch.distributed calls) "
+                     "instead of torch.distributed; rank 0 writes the communicator id to ID_FILE, the other ranks read it there")
+ap.add_argument("--self-p2p", action="store_true", help="with --native-gather: the root's own part goes through ncclSend / ncclRecv too")
 ap.add_argument("--scale", type=float, default=0.05, help="length scale of the synthetic corpus (1.0 = 5-300 s per file)")
 a = ap.parse_args()
 rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -63,7 +67,26 @@ mine = shards[rank]
 arena, views = corpus.decode_files_to_device([files[i] for i in mine], device=local, workers=a.workers, gpu_parse=a.gpu_parse)
 t1 = time.perf_counter()
 local_map = {i: v for i, v in zip(mine, views)}
-out = corpus.gather_pcm(local_map, len(files), rank, world, dist, "cuda:%d" % local, to_host=False)  # stays in HBM
+if a.native_gather:
+    import nvorbis_amd as nv
+    nctx = nv.Context(local)
+    if rank == 0:
+        with open(a.native_gather + ".tmp", "wb") as f:
+            f.write(nv.Comm.unique_id())
+        os.replace(a.native_gather + ".tmp", a.native_gather)
+    else:
+        t_id = time.time()
+        while not os.path.exists(a.native_gather):
+            if time.time() - t_id > 120:
+                raise SystemExit("no communicator id at %s" % a.native_gather)
+            time.sleep(0.01)
+    comm = nv.Comm(nctx, open(a.native_gather, "rb").read(), rank, world)
+    t1 = time.perf_counter()  # (the communicator's set-up is not part of the gather)
+    out = corpus.gather_pcm_native(local_map, len(files), comm, 0, nv.Comm.SELF_P2P if a.self_p2p else 0)
+    backend_name = "rccl (nvh_comm_*)"
+else:
+    out = corpus.gather_pcm(local_map, len(files), rank, world, dist, "cuda:%d" % local, to_host=False)  # stays in HBM
+    backend_name = dist.get_backend() if dist is not None else None
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 if rank == 0:
@@ -72,9 +95,14 @@ if rank == 0:
     hh = hashlib.sha256()
     for o in out:  # every file's PCM in file order, as gathered on rank 0
         hh.update(o.cpu().numpy().tobytes())
-    print(json.dumps({"pcm_sha256": hh.hexdigest(), "files": len(files), "n_gpus": world, "backend": dist.get_backend() if dist is not None else None, "workers_per_gpu": a.workers, "decode_s": t1 - t0, "gather_s": t2 - t1,
+    print(json.dumps({"pcm_sha256": hh.hexdigest(), "files": len(files), "n_gpus": world, "backend": backend_name, "workers_per_gpu": a.workers, "decode_s": t1 - t0, "gather_s": t2 - t1,
                       "files_per_s": len(files) / (t2 - t0), "pcm_floats": int(samples),
                       "long_frame_equivalents_per_s": samples / 2 / 1024 / (t2 - t0)}), flush=True)
+if a.native_gather:
+    comm.close()
+    nctx.close()
+    if rank == 0 and os.path.exists(a.native_gather):
+        os.remove(a.native_gather)
 if dist is not None:
     dist.barrier()
     dist.destroy_process_group()
