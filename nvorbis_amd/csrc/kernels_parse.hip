@@ -360,8 +360,12 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   uint2* const recs = SLAB ? reinterpret_cast<uint2*>(slab + NVH_SLAB_HDR_VECS) : nullptr;
   uint32_t nrec_alloc = 0, nheads = 0;
   unsigned long long pcs = 0;  // post count of every channel, 7 bits each (at most eight channels)
-  int s_rtype = 0, s_rch = 1, s_psz = 0, s_rbegin = 0, s_npass = 0, s_parts = 0, s_chs = 1, s_b1 = 0;
-  int* const g_rows_base = scratch + (long long)f * 2 * T.cap_parts;
+  int s_rtype = 0, s_rch = 1, s_psz = 0, s_rbegin = 0, s_npass = 0, s_parts = 0, s_chs = 1, s_b1 = 0, s_res = 0;
+  // streams of the general bin walk (T.slab_general): one chain-start row per residue pass, two words in front of each -- the
+  // pass's residue and its partition count -- from which the tail below builds the heads and the group list
+  const bool gen_rows = SLAB && T.slab_general != 0;
+  const int row_stride = T.cap_parts + 2;
+  int* const g_rows_base = scratch + (long long)f * T.row_words;
   int* const l_rows_base = reinterpret_cast<int*>(s_meta + T.meta_words) + slot * scratch_words;
 
   if (fr.n != 0) {
@@ -436,7 +440,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         int* l_rows = l_rows_base;
         auto row_get = [&](int i) { return LDS ? l_rows[i] : g_rows[i]; };
         auto row_set = [&](int i, int v) { if (LDS) l_rows[i] = v; else g_rows[i] = v; };
-        const int last_base = T.cap_parts;  // last_op row behind the part_word row
+        const int last_base = gen_rows ? T.cap_parts + s_npass * row_stride + 2 : T.cap_parts;  // last_op row behind the part_word row
         const int pw_stride = partition_words > 0 ? partition_words : 1;
         for (int i = 0; i < r.channels * pw_stride; i++) row_set(i, -1);
         for (int i = 0; i < r.channels * (partition_count > 0 ? partition_count : 1); i++) row_set(last_base + i, -1);
@@ -709,8 +713,18 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         s_parts = err ? 0 : partition_count; s_chs = r.channels; s_b1 = r.alias_b1;
       }
       if (SLAB) {
-        s_npass = 1;
-        if (!ran) { s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin; s_b1 = r.alias_b1; }
+        if (!ran) { s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin; s_b1 = r.alias_b1; s_parts = 0; }
+        s_res = residue_idx;
+        if (gen_rows) {
+          if (s_npass >= T.cap_pass) {
+            err = kErrRuntime;
+          } else {
+            int* rows = LDS ? l_rows_base : g_rows_base;
+            rows[T.cap_parts + s_npass * row_stride] = residue_idx;
+            rows[T.cap_parts + s_npass * row_stride + 1] = (ran && !err) ? s_parts : 0;
+          }
+        }
+        s_npass += 1;
       }
       // stages not reached keep empty ranges
       if (!err) {
@@ -740,8 +754,8 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
     H.off_heads = H.off_rec = H.off_ent = NVH_SLAB_HDR_VECS; H.vecs = NVH_SLAB_HDR_VECS;
     H.lpc = 0; H.rgeom = 0; H.group = 2; H.lpc_magic = 0; H.frame = (uint32_t)f; H.coupling = 0;
     for (int c = 0; c < NVH_SLAB_MAX_CH; ++c) H.chan[c] = (uint32_t)NVH_SLAB_HDR_VECS << 16;
-    uint32_t off = NVH_SLAB_HDR_VECS, b1_bins = 0;
-    bool fault = false;
+    uint32_t off = NVH_SLAB_HDR_VECS, b1_bins = 0, gen_list = 0;
+    bool fault = false, gen_frame = false;
     const bool mine = active && fr.n != 0 && !err;  // this lane has a frame to finish
     if (mine) {
       H.n = (uint16_t)fr.n;
@@ -752,7 +766,10 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       const uint32_t off_heads = off_rec + ((nrec_alloc + 1) >> 1);
       if (nrec_alloc & 1u) recs[nrec_alloc] = make_uint2(0u, 0u);
       auto row_get = [&](int i) { return LDS ? l_rows_base[i] : g_rows_base[i]; };
-      {
+      const int row0 = gen_rows ? T.cap_parts + 2 : T.cap_parts;  // chain-start row of the (first) pass
+      // a frame of the general bin walk (host_slab.cpp: build_slabs): more than one pass, or a residue outside the pair path and B-1
+      gen_frame = gen_rows && (s_npass > 1 || (s_npass == 1 && residues[s_res].general != 0));
+      if (!gen_frame) {
         // the chain heads, from the rows of the walk: first record | the partition's first bin << 16, partition by partition
         uint32_t* hd = reinterpret_cast<uint32_t*>(slab + off_heads);
         const unsigned rchm = s_rch > 1 ? (unsigned)((0x100000000ull + (unsigned)s_rch - 1) / (unsigned)s_rch) : 0u;
@@ -760,16 +777,69 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
           const unsigned offset = (unsigned)s_rbegin + (unsigned)pi * (unsigned)s_psz;
           const unsigned xb0 = (s_rtype == 2 && s_rch > 1) ? __umulhi(offset, rchm) : offset;
           for (int c = 0; c < s_chs; ++c) {
-            const int start = row_get(T.cap_parts + pi * s_chs + c);
+            const int start = row_get(row0 + pi * s_chs + c);
             if (start >= 0) hd[nheads++] = (uint32_t)start | (xb0 << 16);
           }
           if (xb0 > 0xFFFFu) err = kErrUnsupported;
         }
         for (uint32_t i = nheads; i < ((nheads + 3) & ~3u); ++i) hd[i] = 0;
+      } else {
+        // every pass's chains, pass by pass (the group list below numbers them in this very order)
+        uint32_t* hd = reinterpret_cast<uint32_t*>(slab + off_heads);
+        for (int k = 0; k < s_npass; ++k) {
+          const int blk = T.cap_parts + k * row_stride;
+          const NvhPResidue& rk = residues[row_get(blk)];
+          const int np = row_get(blk + 1), chs = rk.channels;
+          const unsigned rch = rk.type == 2 ? (unsigned)rk.real_channels : 1u;
+          const unsigned rchm = rch > 1 ? (unsigned)((0x100000000ull + rch - 1) / rch) : 0u;
+          for (int pi = 0; pi < np; ++pi) {
+            const unsigned offset = (unsigned)rk.begin + (unsigned)pi * (unsigned)rk.partition_size;
+            const unsigned xb0 = rch > 1 ? __umulhi(offset, rchm) : offset;
+            for (int c = 0; c < chs; ++c) {
+              const int start = row_get(blk + 2 + pi * chs + c);
+              if (start >= 0) hd[nheads++] = (uint32_t)start | (xb0 << 16);
+            }
+            if (xb0 > 0xFFFFu) err = kErrUnsupported;
+          }
+        }
+        for (uint32_t i = nheads; i < ((nheads + 3) & ~3u); ++i) hd[i] = 0;
+        if (nheads > 0xFFFEu) err = kErrUnsupported;
       }
       const uint32_t off_ent = off_heads + ((nheads + 3) >> 2);
       off = off_ent + ((nent + 7) >> 3);
-      if (s_b1) {
+      if (gen_frame) {
+        // the group list (nvh_format.h: NvhSlabHdr::group == 1; host_slab.cpp: residue_general): count | per (pass, channel) of a
+        // per-channel residue, per pass of a Residue2: two units of geometry | uint16 pchain[]: the chain of every partition
+        uint32_t* w = reinterpret_cast<uint32_t*>(slab + off);
+        uint32_t ngroups = 0, npc = 0;
+        for (int k = 0; k < s_npass; ++k) ngroups += (uint32_t)residues[row_get(T.cap_parts + k * row_stride)].channels;
+        w[0] = ngroups; w[1] = w[2] = w[3] = 0;
+        uint16_t* pc = reinterpret_cast<uint16_t*>(w + 4 + 8 * ngroups);
+        uint32_t gi = 0, hk = 0;
+        for (int k = 0; k < s_npass; ++k) {
+          const int blk = T.cap_parts + k * row_stride;
+          const NvhPResidue& rk = residues[row_get(blk)];
+          const int np = row_get(blk + 1), chs = rk.channels;
+          const unsigned rch = rk.type == 2 ? (unsigned)rk.real_channels : 1u, psz = (unsigned)rk.partition_size;
+          for (int c = 0; c < chs; ++c) {
+            uint32_t* q = w + 4 + 8 * gi;
+            q[0] = (uint32_t)rk.begin; q[1] = psz; q[2] = (uint32_t)np; q[3] = (psz + rch - 1u) / rch;
+            q[4] = (uint32_t)rk.type | (rch << 4) | ((uint32_t)k << 8) | ((uint32_t)(rk.type == 2 ? 0 : c) << 12);
+            q[5] = (uint32_t)((0x100000000ull + psz - 1) / psz);
+            q[6] = npc + (uint32_t)(c * np);
+            q[7] = 0;
+            ++gi;
+          }
+          // chain numbers in the order the heads were written: partition by partition, channel by channel
+          for (int pi = 0; pi < np; ++pi)
+            for (int c = 0; c < chs; ++c) pc[npc + (uint32_t)(c * np + pi)] = row_get(blk + 2 + pi * chs + c) >= 0 ? (uint16_t)hk++ : (uint16_t)0xFFFFu;
+          npc += (uint32_t)(chs * np);
+        }
+        for (uint32_t i = npc; i < ((npc + 7u) & ~7u); ++i) pc[i] = 0xFFFFu;
+        if (npc > 0xFFFFFFu) err = kErrUnsupported;
+        gen_list = off;
+        off += 1u + 2u * ngroups + ((npc + 7u) >> 3);
+      } else if (s_b1) {
         // quirk B-1 (kernels_synth.hip: residue_walk_bins): the residue's geometry and the chain of every partition -- the heads
         // above are in partition order, one per partition that has a chain (Residue2: a single channel)
         uint32_t* prm = reinterpret_cast<uint32_t*>(slab + off);
@@ -777,7 +847,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         prm[3] = ((uint32_t)s_psz + (uint32_t)s_rch - 1u) / (uint32_t)s_rch;
         uint16_t* pchain = reinterpret_cast<uint16_t*>(prm + 4);
         uint32_t k = 0;
-        for (int pi = 0; pi < s_parts; ++pi) pchain[pi] = row_get(T.cap_parts + pi) >= 0 ? (uint16_t)k++ : (uint16_t)0xFFFFu;
+        for (int pi = 0; pi < s_parts; ++pi) pchain[pi] = row_get(row0 + pi) >= 0 ? (uint16_t)k++ : (uint16_t)0xFFFFu;
         for (int pi = s_parts; pi < ((s_parts + 7) & ~7); ++pi) pchain[pi] = 0xFFFFu;
         b1_bins = off;
         off += 1u + (uint32_t)((s_parts + 7) >> 3);
@@ -845,7 +915,11 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       const NvhPMapping& map = mappings[fr.mapping];
       if (fault) H.flags |= NVH_SLAB_FLOOR_FAULT;
       // residue geometry (Residue0.cs:157-170, Residue2.cs:23-47): components a lane of the synthesis kernel owns
-      if (s_npass == 1) {
+      if (gen_frame) {
+        H.group = 1;
+        H.lpc = (uint16_t)gen_list;
+        H.lpc_magic = 0;
+      } else if (s_npass == 1) {
         unsigned group = ((unsigned)s_psz & 7u) == 0 ? 8u : 2u;
         if (s_rtype == 2 && s_rch > 2) group = ((unsigned)s_psz % (2u * (unsigned)s_rch)) == 0 ? 2u * (unsigned)s_rch : 2u;  // (host: slab setups only)
         const unsigned lpc = (unsigned)s_psz / group;
@@ -858,9 +932,9 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
           H.lpc_magic = (uint32_t)((0x100000000ull + (unsigned)s_psz - 1) / (unsigned)s_psz);
         }
       }
-      H.rgeom = (uint8_t)(s_rtype | (s_rch << 4));
+      H.rgeom = gen_frame ? (uint8_t)(1 | (1 << 4)) : (uint8_t)(s_rtype | (s_rch << 4));
       // inverse coupling (Mapping.cs:137-182): in the chain walk when one lane holds both channels of a bin, else passes
-      if (nch == 2 && map.coupling_steps == 1 && s_npass == 1 && s_rtype == 2 && s_rch == 2) {
+      if (nch == 2 && map.coupling_steps == 1 && s_npass == 1 && s_rtype == 2 && s_rch == 2 && !gen_frame) {
         if ((exec_mask & 3u) != 0) {
           if (map.coupling_mag[0] == 1) H.flags |= NVH_SLAB_MG1;
           H.flags |= NVH_SLAB_SWEEP_COUPLES;
@@ -880,7 +954,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         }
       }
       if (nch <= 2 && !(H.flags & NVH_SLAB_COUPLE_PASS) &&
-          (s_npass == 0 || (H.group == 8 && ((unsigned)s_rbegin & ((s_rtype == 2 && s_rch == 2) ? 7u : 3u)) == 0)))
+          (s_npass == 0 || (!gen_frame && H.group == 8 && ((unsigned)s_rbegin & ((s_rtype == 2 && s_rch == 2) ? 7u : 3u)) == 0)))
         H.flags |= NVH_SLAB_FUSE_FLOOR;
       if (off > (uint32_t)T.slab_stride_vecs || off > 0xFFFFu) err = kErrRuntime;
       H.vecs = (uint16_t)off;

@@ -95,7 +95,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   const size_t o_en = al(o_lk + nf * ops_per_frame * sizeof(uint16_t));
   const size_t o_po = al(o_en + nf * (size_t)T.cap_ent * sizeof(uint16_t) + 64);
   const size_t o_sc = al(o_po + nf * (size_t)ch * NVH_MAX_POSTS * sizeof(uint16_t));
-  const size_t row_words = 2 * (size_t)T.cap_parts;  // the residue walk's rows
+  const size_t row_words = (size_t)T.row_words;  // the residue walk's rows
   const size_t o_rs = al(o_sc + nf * row_words * sizeof(int));
   const size_t total = al(o_rs + sizeof(NvhParseResult));
   if (slab_mode) {
@@ -178,7 +178,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     const size_t table_words = (size_t)(T.lds_words + T.meta_words);
     // (workgroups of eight and more wavefronts may take a CU's whole LDS: one workgroup per CU still is 2+ wavefronts per SIMD)
     const size_t lds_cap_words = (size_t)(kParseWaves >= 8 ? 156 : 80) * 1024 / 4;
-    int scratch_words = 2 * T.cap_parts, pkt_words = (int)max_pkt_words;
+    int scratch_words = T.row_words, pkt_words = (int)max_pkt_words;
     // LDS variant only when both the rows and the longest packet of the batch fit for every lane; else everything per-lane
     // stays in global memory (k_parse_g)
     // slab mode: + one floor scratch block and an error word per wavefront (kernels_parse.hip: floor_to_slab_wave)

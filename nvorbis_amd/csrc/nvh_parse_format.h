@@ -59,7 +59,8 @@ struct NvhPResidue {  // Residue0.cs:21-33
   int32_t alias_b1;         // quirk B-1 on its own (NvhDevResidue::alias_b1): the slab carries the partition table of the bin walk
   uint32_t decode_map_off;  // into the int pool: partvals * class_dims class numbers
   uint32_t rch_magic;       // ceil(2^32 / real_channels), 0 for one channel
-  uint32_t pad2[2];
+  uint32_t general;         // its frames take the general bin walk (neither the pair path nor B-1 on its own; host_slab.h: residue_general)
+  uint32_t pad2;
   uint8_t cascade[NVH_MAX_CLASSES];
   int16_t books[NVH_MAX_CLASSES][NVH_MAX_STAGES];
   uint8_t book_mask[NVH_MAX_CLASSES];  // per class: the cascade stages that have a book (a chain of the slab has one record per set bit)
@@ -88,7 +89,12 @@ struct NvhDevParse {
   // books, floors, residues and mappings are contiguous in the arena (in that order): `meta_words` words from `books`
   // are copied into LDS too, the three offsets locate the other arrays inside that copy
   int32_t meta_words;
-  int32_t meta_floors_off, meta_residues_off, meta_mappings_off, pad;  // byte offsets from `books`
+  int32_t meta_floors_off, meta_residues_off, meta_mappings_off;  // byte offsets from `books`
+  // slab mode for streams of the general bin walk (several residue passes per frame, Residue0, odd dimensions, ...): the frame's
+  // slab carries a group list (nvh_format.h: NvhSlabHdr::group == 1); the walk's scratch then keeps one chain-start row PER PASS
+  int32_t slab_general;
+  int32_t row_words;      // ints of per-packet scratch: the class-word row + the chain-start rows (kernels_parse.hip: parse_body)
+  int32_t pad;
   // slab mode (the parser writes the synthesis kernels' slabs itself): the synthesis setup's floor records and reciprocal table,
   // the slab stride (the setup's worst case, 16-byte units; 0: this setup's batches take the descriptor kernels)
   const NvhDevFloor* dfloors;

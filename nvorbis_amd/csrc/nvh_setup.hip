@@ -392,6 +392,8 @@ int upload_parse_tables(nvh_stream* s) {
     d.real_channels = r.real_channels; d.max_stages = r.max_stages; d.partvals = r.partvals;
     d.class_dims = S.books[(size_t)r.class_book].dimensions;
     d.alias_b1 = (i < sh.slab.residue_b1.size() && sh.slab.residue_b1[i]) ? 1 : 0;
+    d.general = (i < sh.slab.residue_general.size() && sh.slab.residue_general[i] && !d.alias_b1 &&
+                 !(i < sh.slab.residue_pair.size() && sh.slab.residue_pair[i])) ? 1u : 0u;
     d.rch_magic = r.real_channels > 1 ? (uint32_t)((0x100000000ull + (uint64_t)r.real_channels - 1) / (uint64_t)r.real_channels) : 0u;
     if ((uint64_t)S.block1 * (uint64_t)std::max(S.channels, 1) * (uint64_t)std::max(r.real_channels, 1) >= 0x100000000ull) return NVH_OK;
     d.decode_map_off = (uint32_t)ipool.size();
@@ -496,6 +498,8 @@ int upload_parse_tables(nvh_stream* s) {
   P.meta_residues_off = (int32_t)(o_rs - o_bk);
   P.meta_mappings_off = (int32_t)(o_mp - o_bk);
   P.pad = 0;
+  P.slab_general = 0;
+  P.row_words = 2 * cap_parts;
   // slab mode: setups inside the slab kernels' contract whose frames have one residue pass, lattice offsets and values a record
   // can hold (+ room for the partition table of a quirk-B-1 residue)
   P.dfloors = sh.dev.floors;
@@ -503,11 +507,19 @@ int upload_parse_tables(nvh_stream* s) {
   P.max_posts = sh.max_posts;
   P.slab_stride_vecs = 0;
   {
-    bool ok = sh.slab_setup_ok && !sh.slab_general && cap_pass <= 1 && S.channels <= NVH_SLAB_MAX_CH;
+    // (streams of the general bin walk -- several passes per frame, Residue0, odd dimensions, aliasing stereo Residue2: round 5 --
+    // carry a group list: the count, two units per (pass, channel), one chain index per (pass, channel, partition))
+    const bool general = sh.slab_general;
+    bool ok = sh.slab_setup_ok && (general ? (cap_pass <= 15 && !s->has_floor0) : cap_pass <= 1) && S.channels <= NVH_SLAB_MAX_CH;
     for (const NvhDevBook& db : sh.slab.books) ok = ok && db.lat_off <= NVH_SLAB_MAX_LAT_OFF && db.lat_values <= 0xFFu;
     const size_t Pn = (size_t)sh.max_posts + 2;
     size_t v = NVH_SLAB_HDR_VECS + (size_t)S.channels * (Pn + ((size_t)S.block1 / 8 + 15) / 16) + ((size_t)cap_ops + 3) / 4 + ((size_t)cap_ops + 1) / 2 +
                ((size_t)cap_ent + 7) / 8 + 1 + 1 + ((size_t)cap_parts + 7) / 8;
+    if (general) {
+      v += 1 + 2 * (size_t)cap_pass * (size_t)S.channels + ((size_t)cap_pass * (size_t)cap_parts + 7) / 8;
+      P.slab_general = 1;
+      P.row_words = cap_parts + cap_pass * (cap_parts + 2);
+    }
     if (v < (size_t)S.block1 / 64 + 8) v = (size_t)S.block1 / 64 + 8;
     v = (v + 3) & ~(size_t)3;
     if (ok && v <= 0xFFFFu && cap_ops <= 0xFFFF && cap_ent <= 0xFFFF) P.slab_stride_vecs = (int32_t)v;

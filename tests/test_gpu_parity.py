@@ -282,19 +282,23 @@ def test_general_bin_walk_bit_exact(oracle, gpu_ctx, name, consistent):
             got = _decode_gpu(nv, gpu_ctx, pk, gr, fl, clip, bf)
             assert got.size == ref.size, (name, clip, bf)
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, clip, bf, float(np.abs(got - ref).max()))
-    toggles = ("NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_NO_SLAB", "NVH_GPU_PARSE")
+    toggles = ("NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_NO_SLAB")
     if consistent and not any(os.environ.get(t) for t in toggles):
         torch = _torch()
-        st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
-        for p in pk[3:40]:
-            st.push_packet(p, -1, 0)
-        b = st.upload_batch()
-        pcm = torch.empty(max(b.samples * st.channels, 1), dtype=torch.float32, device="cuda")
-        b.synth(pcm.data_ptr(), pcm.numel())
-        names = [k for k in b.kernels() if k != "-"]
-        b.free(); st.close()
-        kn = "k_synth8_g" if name == "res0_3ch" else "k_synth_g"
-        assert names and names[0] == kn and all(k in (kn, "k_ola_compact") for k in names), names
+        # ... with the packets parsed on the host, and with the GPU packet parser writing the group lists itself (round 5)
+        for gpu_parse in (False, True):
+            st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+            if gpu_parse:
+                st.set_gpu_parse(True)
+            for p in pk[3:40]:
+                st.push_packet(p, -1, 0)
+            b = st.upload_batch()
+            pcm = torch.empty(max(b.samples * st.channels, 1), dtype=torch.float32, device="cuda")
+            b.synth(pcm.data_ptr(), pcm.numel())
+            names = [k for k in b.kernels() if k != "-"]
+            b.free(); st.close()
+            kn = "k_synth8_g" if name == "res0_3ch" else "k_synth_g"
+            assert names and kn in names and all(k in (kn, "k_ola_compact", "k_parse_slab", "k_parse_links") for k in names), (gpu_parse, names)
 
 
 @pytest.mark.parametrize("name", ["ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"])

@@ -24,6 +24,22 @@ def test_abi_exports_every_declared_symbol():
     assert b"gfx950" in nv.lib().nvh_version()
 
 
+def test_comm_entry_points_check_their_arguments():
+    """The native gather's entry points (nvh_comm_*) refuse bad arguments before they touch RCCL or a device."""
+    import nvorbis_amd as nv
+    from nvorbis_amd import native
+    L = nv.lib()
+    h = C.c_void_p()
+    ident = (C.c_uint8 * 128)()
+    assert L.nvh_comm_create(None, ident, 0, 1, C.byref(h)) == native.ERR_ARGUMENT and not h.value
+    assert L.nvh_comm_unique_id(None) == native.ERR_ARGUMENT
+    assert L.nvh_comm_info(None, None, None) == native.ERR_ARGUMENT
+    one = (C.c_int64 * 1)(0)
+    assert L.nvh_comm_allgather_i64(None, one, 1, one) == native.ERR_ARGUMENT
+    assert L.nvh_comm_gather_pcm(None, None, 0, None, one, 0, 0) == native.ERR_ARGUMENT
+    L.nvh_comm_destroy(None)  # a no-op
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a HIP device the compute entry points fail loudly (NVH_ERR_NO_GPU), they never fall back."""
     import nvorbis_amd as nv
