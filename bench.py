@@ -42,6 +42,7 @@ import argparse
 import datetime
 import json
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd/__init__.py says why)
 import sys
 import time
 

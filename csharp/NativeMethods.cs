@@ -22,6 +22,7 @@ namespace NVorbis.Hip
         [DllImport(Lib)] public static extern int nvh_ctx_create(int device, out IntPtr ctx);
         [DllImport(Lib)] public static extern void nvh_ctx_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern int nvh_ctx_synchronize(IntPtr ctx);
+        [DllImport(Lib)] public static extern int nvh_ctx_set_parse_lanes(IntPtr ctx, int lanes);
 
         [DllImport(Lib)] public static extern int nvh_mdct_reverse(IntPtr ctx, int n, int batch, IntPtr dBuf, long stride);
         [DllImport(Lib)] public static extern int nvh_calc_window(int prevBlock, int block, int nextBlock, [Out] float[] window);

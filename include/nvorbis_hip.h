@@ -59,6 +59,14 @@ void nvh_ctx_destroy(nvh_ctx *ctx);
 /* Launch on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
 int nvh_ctx_set_hip_stream(nvh_ctx *ctx, void *hip_stream);
 int nvh_ctx_synchronize(nvh_ctx *ctx);
+/* Launch shape of the GPU packet parser (nvh_stream_set_gpu_parse) for the streams of this context: packets per wavefront,
+ * a power of two 1..64, 0 = automatic (one packet per wavefront up to 4096 packets per batch: the lowest latency for a lone
+ * stream).  A host that keeps many contexts busy at once -- a corpus worker pool, one context per thread -- gives each
+ * of them 8: a parse then occupies an eighth of the wavefront slots for about four times as long, and the parses of all workers
+ * fit the chip side by side (the corpus of BASELINE configs[4], 16 workers: decode pass 0.82 -> 0.51 s; with the process
+ * started under GPU_MAX_HW_QUEUES=16, the HIP runtime's default of 4 hardware queues lets only four kernels run at once).
+ * No counterpart in the reference (its decoder is one thread per stream); results do not depend on it. */
+int nvh_ctx_set_parse_lanes(nvh_ctx *ctx, int lanes);
 
 /* ---- level 1: batched mirrors of the plug-in interface methods (device pointers) ----
  * nvh_inverse_couple, nvh_mdct_reverse, nvh_window_apply and nvh_overlap_buffers only enqueue their kernel on the

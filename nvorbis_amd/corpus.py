@@ -204,8 +204,25 @@ def _decode_file_packets(st, pa, batch_frames, sink):
             break
 
 
-def _run_pool(n_items, workers, device, fn):
-    """fn(index, ctx) for every index on a pool of host threads, one nvh_ctx (= one HIP stream) per thread."""
+_WORKER_CONTEXTS = {}  # device -> [Context]: worker contexts kept between jobs (keep_contexts=True)
+
+
+def close_worker_contexts():
+    """Release the worker contexts a keep_contexts=True job left behind (streams, block pools, setup caches)."""
+    for ctxs in _WORKER_CONTEXTS.values():
+        for c in ctxs:
+            c.close()
+    _WORKER_CONTEXTS.clear()
+
+
+PARSE_LANES_POOL = 8  # nvh_ctx_set_parse_lanes for the contexts of a worker pool of eight threads and more (see the header)
+
+
+def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, parse_lanes=0):
+    """fn(index, ctx) for every index on a pool of host threads, one nvh_ctx (= one HIP stream) per thread (ctx is None with
+    need_ctx=False: host-only work).  keep_contexts: the threads' contexts outlive the call and serve the next one -- a
+    context's pools of device / page-locked blocks and its setup cache are warm after its first file, and creating them
+    (hipMalloc / hipHostMalloc, serialised by the runtime) is most of a short job's decode pass."""
     import queue
     import threading
 
@@ -214,9 +231,19 @@ def _run_pool(n_items, workers, device, fn):
     q = queue.Queue()
     for i in range(n_items):
         q.put(i)
+    nthreads = max(1, min(workers, n_items))
+    kept = _WORKER_CONTEXTS.setdefault(device, []) if (need_ctx and keep_contexts) else None
 
-    def work():
-        ctx = Context(device)
+    def work(t):
+        ctx = None
+        if need_ctx:
+            if kept is not None and t < len(kept) and kept[t] is not None:
+                ctx = kept[t]
+            else:
+                ctx = Context(device)
+                if kept is not None:
+                    kept[t] = ctx
+            ctx.set_parse_lanes(parse_lanes)
         try:
             while True:
                 try:
@@ -228,9 +255,13 @@ def _run_pool(n_items, workers, device, fn):
                 except Exception as e:  # one bad file must not take the pool down; the caller sees it
                     errors.append((i, e))
         finally:
-            ctx.close()
+            if ctx is not None and kept is None:
+                ctx.close()
 
-    threads = [threading.Thread(target=work, daemon=True) for _ in range(max(1, min(workers, n_items)))]
+    if kept is not None:
+        while len(kept) < nthreads:
+            kept.append(None)
+    threads = [threading.Thread(target=work, args=(t,), daemon=True) for t in range(nthreads)]
     for t in threads:
         t.start()
     for t in threads:
@@ -238,7 +269,7 @@ def _run_pool(n_items, workers, device, fn):
     return errors
 
 
-def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False):
+def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False, keep_contexts=False):
     """Decode .ogg byte strings on ONE GPU into ONE device arena: returns (arena, views) with views[i] the interleaved
     float32 PCM of files[i] as a slice of `arena` (torch tensors on cuda:<device>), files back to back in list order.
 
@@ -270,7 +301,7 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
     if os.environ.get("NVH_CORPUS_BATCH"):  # A/B aid: packets per parse / synthesis batch
         batch_frames = int(os.environ["NVH_CORPUS_BATCH"])
     t_start = time.perf_counter()
-    errors = _run_pool(n, workers, device, index_one)
+    errors = _run_pool(n, workers, device, index_one, need_ctx=False)  # host-only: no GPU context per thread
     if errors:
         raise RuntimeError("index failed for files %s: %r" % ([i for i, _ in errors], errors[0][1]))
     t_index = time.perf_counter()
@@ -307,7 +338,8 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
             st.close()
 
     t_alloc = time.perf_counter()
-    errors = _run_pool(n, workers, device, decode_one)
+    errors = _run_pool(n, workers, device, decode_one, keep_contexts=keep_contexts or bool(os.environ.get("NVH_CORPUS_KEEP_CTX")),
+                       parse_lanes=PARSE_LANES_POOL if (gpu_parse and min(workers, n) >= 8) else 0)
     if errors:
         raise RuntimeError("decode failed for files %s: %r" % ([order[k] for k, _ in errors], errors[0][1]))
     if timing:
@@ -357,7 +389,8 @@ def decode_files_threaded(files, device=0, workers=16, batch_frames=4096, gpu_pa
         finally:
             st.close()
 
-    errors = _run_pool(len(files), workers, device, decode_one)
+    errors = _run_pool(len(files), workers, device, decode_one,
+                       parse_lanes=PARSE_LANES_POOL if (gpu_parse and min(workers, len(files)) >= 8) else 0)
     if errors:
         raise RuntimeError("decode failed for files %s: %r" % ([order[k] for k, _ in errors], errors[0][1]))
     return out

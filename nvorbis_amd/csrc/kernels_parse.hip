@@ -124,7 +124,10 @@ __device__ __attribute__((noinline)) uint32_t prefix_from_global(const uint32_t*
 }
 
 // Codebook.DecodeScalar (Codebook.cs:294-320).  -1 = no symbol; -2 = the reference would fault (null list)
-template <bool LDS>
+// UNI (parse_body): the compiler takes the result of any call (and of any FLAT load) for divergent, which would make the whole
+// parse divergent again; a volatile load from the global address space cannot be folded into the LDS read either, and is
+// uniform when its address is.  (Checked with opt -passes='print<uniformity>': only the slab's tail is divergent.)
+template <bool LDS, bool UNI = false>
 __device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const uint32_t* __restrict__ s_pkt,
                                              const NvhPBook bk, BitR& p) {
   // The common case first: at least 32 bits left in the packet, the prefix table in LDS, the code no longer than the prefix.
@@ -148,6 +151,7 @@ __device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_
   if (!bk.has_tree) return -2;
   uint32_t node;
   if (bk.lds_off != 0xFFFFFFFFu) node = s_prefix[bk.lds_off + data];  // ds_read
+  else if (UNI) node = *(const volatile __attribute__((address_space(1))) uint32_t*)(unsigned long long)(T.prefix + (bk.prefix_off + data));  // (global, said so: a FLAT load counts as divergent too)
   else node = prefix_from_global(T.prefix, bk.prefix_off + data);
   if (node & 0x80u) {
     br_skip<LDS>(p, (int)(node & 0x7Fu), s_pkt);
@@ -157,8 +161,19 @@ __device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_
   if (!bk.has_overflow) return -2;
   // the longer codes: the reference scans its whole overflow list for the first match; a code can only match a
   // peek whose low prefix_bits select its slot, so scanning that slot's group (same relative order) finds the same node
-  const NvhPOverflow* ov = T.overflow + bk.ovf_off;
   uint32_t cnt = node & 0x7Fu;
+  if (cnt != 0x7Fu && bk.ovf_lds != 0xFFFFFFFFu) {  // the slot's group lies in LDS (8-byte nodes: bits, value << 8 | length)
+    const uint32_t g = bk.ovf_lds + 2u * (node >> 8);
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const uint32_t bits = s_prefix[g + 2u * k], vl = s_prefix[g + 2u * k + 1u], len = vl & 0xFFu;
+      if (bits == (data & ((1u << len) - 1u))) {
+        br_skip<LDS>(p, (int)len, s_pkt);
+        return (int)(vl >> 8);
+      }
+    }
+    return -1;
+  }
+  const NvhPOverflow* ov = T.overflow + bk.ovf_off;
   if (cnt == 0x7Fu) {
     cnt = bk.ovf_count;
   } else {
@@ -175,7 +190,7 @@ __device__ __forceinline__ int decode_scalar(const NvhDevParse& T, const uint32_
 }
 
 // Floor1.Unpack (Floor1.cs:135-184).  Writes the raw posts of one channel; returns 0 or an error code.
-template <bool LDS>
+template <bool LDS, bool UNI = false>
 __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_t* __restrict__ s_prefix, const uint32_t* __restrict__ s_pkt,
                                              const NvhPBook* books,
                                              const NvhPFloor1& f, BitR& p, uint16_t* __restrict__ posts,
@@ -194,7 +209,7 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_
       const uint32_t csub = (1u << cbits) - 1u;
       uint32_t cval = 0;
       if (cbits > 0) {
-        const int r = decode_scalar<LDS>(T, s_prefix, s_pkt, books[f.class_master[cls]], p);
+        const int r = decode_scalar<LDS, UNI>(T, s_prefix, s_pkt, books[f.class_master[cls]], p);
         if (r == -2) return kErrRuntime;
         cval = (uint32_t)r;
         if (cval == 0xFFFFFFFFu) {
@@ -208,7 +223,7 @@ __device__ __forceinline__ int decode_floor1(const NvhDevParse& T, const uint32_
         cval >>= cbits;
         if (book >= 0) {
           if (post_count >= NVH_MAX_POSTS) return kErrRuntime;  // Posts = new int[64]
-          const int r = decode_scalar<LDS>(T, s_prefix, s_pkt, books[book], p);
+          const int r = decode_scalar<LDS, UNI>(T, s_prefix, s_pkt, books[book], p);
           if (r == -2) return kErrRuntime;
           if (r == -1) {
             post_count = 0;
@@ -292,11 +307,18 @@ __device__ __forceinline__ int floor_to_slab_wave(FloorScratch* Q, const NvhDevF
 // the wavefront together again -- the floors (floor_to_slab), the heads, the entries and the header follow.  `ops` then only
 // and `op_link` are not used.  Without SLAB: the
 // descriptors of rounds 1-3, for the stream shapes the descriptor kernels serve.
-template <bool LDS, bool SLAB>
+// UNI: one packet per wavefront (the launch shape of every batch of up to 4096 packets), and the compiler is told so: the
+// packet index comes through readfirstlane, every value of the parse derives from it, and so all 64 lanes run the packet's
+// decode side by side with the same values -- the loops' conditions are wave-uniform and compile to scalar branches, where the
+// one-lane-of-64 form pays for every level of its divergent loop nest in exec-mask arithmetic (half of the instructions of the
+// entry loop, more in the levels around it).  Stores of the parse are issued by all lanes with one address and one value;
+// behind the parse lane 0 is the packet's lane, as before.
+template <bool LDS, bool SLAB, bool UNI = false>
 __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
-        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs NVH_DBG_PARAMS) {
+        NvhParseResult* __restrict__ result, int lanes_arg, int scratch_words, int pkt_words, uint4* __restrict__ slabs NVH_DBG_PARAMS) {
+  const int lanes = UNI ? 1 : lanes_arg;
 #ifdef NVH_DEBUG
 #define PM(bit) (!(phase_mask & ((bit) << 8)))  // profiling builds: NVH_DEBUG_SPECTRUM_MASK = 15 + 256 * (pieces to leave out)
 #else
@@ -324,12 +346,16 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   // this code, so the lanes of a wavefront run mostly one after the other, and a lone wavefront issues an instruction
   // every ~5 cycles at best: the host picks few packets per wavefront and ~2 wavefronts per SIMD for small batches
   // (a 4096-packet batch at 64 per wavefront would sit on 64 of 1024 SIMDs) and fills wavefronts up for large ones.
-  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int wave = UNI ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  // UNI: the wavefront's packet (uniform)
+  const int f_u = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
+  const bool valid_u = f_u < nframes;
   // slab mode keeps the lanes without a packet alive: behind the parse the whole wavefront works on the floors of its packets
-  const bool active = lane < lanes && blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + wave * lanes + lane < nframes;
-  if (!SLAB && !active) return;
-  const int slot = wave * lanes + (active ? lane : 0);  // packet of this workgroup
-  const int f = active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0;
+  const bool active = UNI ? (lane == 0 && valid_u) : (lane < lanes && blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + wave * lanes + lane < nframes);
+  const bool parses = UNI ? valid_u : active;  // takes part in the parse of a packet
+  if (!SLAB && !parses) return;
+  const int slot = UNI ? wave : wave * lanes + (active ? lane : 0);  // packet of this workgroup
+  const int f = UNI ? (valid_u ? f_u : 0) : (active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0);
 #ifdef NVH_DEBUG
 #define PT_T(k) do { if (dbg && active) dbg[(long long)f * 24 + (k)] = clock64(); } while (0)
 #define PT_ACC_BEGIN() const long long pt_t0 = clock64()
@@ -342,7 +368,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
 #endif
   PT_T(0);
   NvhFrame fr;
-  if (active) {
+  if (parses) {
     fr = frames[f];
   } else {
     fr.n = 0; fr.mapping = 0; fr.mdct_slot = 0;
@@ -388,7 +414,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       const int fl = map.chan_floor[c];
       int pc = 0;
       uint16_t* my_posts = posts + ((long long)f * nch + c) * NVH_MAX_POSTS;
-      err = decode_floor1<LDS>(T, s_prefix, s_pkt, books, floors[fl], p, my_posts, &pc);
+      err = decode_floor1<LDS, UNI>(T, s_prefix, s_pkt, books, floors[fl], p, my_posts, &pc);
       NvhChan cn;
       cn.exec = 0;
       cn.floor = (uint8_t)fl;
@@ -454,7 +480,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
             if (stage == 0) {
               PT_ACC_BEGIN();
               for (int c = 0; c < r.channels; c++) {
-                const int idx = decode_scalar<LDS>(T, s_prefix, s_pkt, class_book, p);
+                const int idx = decode_scalar<LDS, UNI>(T, s_prefix, s_pkt, class_book, p);
                 if (idx == -2) {
                   err = kErrRuntime;
                   break;
@@ -521,7 +547,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     break;
                   }
                   for (int i = 0; i < steps; i++) {
-                    const int e = decode_scalar<LDS>(T, s_prefix, s_pkt, book, p);
+                    const int e = decode_scalar<LDS, UNI>(T, s_prefix, s_pkt, book, p);
                     if (e == -2) {
                       err = kErrRuntime;
                       break;
@@ -579,7 +605,8 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                       }
                     };
                     for (;;) {
-                      while ((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)((node >> 7) & 1u)) {
+                      while (UNI ? (done < slots && p.total - p.pos >= 32u && (node & 0x80u) != 0u)
+                                 : (bool)((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)((node >> 7) & 1u))) {
                         consume(node & 0x7Fu);
                         eout[done] = (uint16_t)(node >> 8);
                         ++done;
@@ -591,17 +618,30 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                       // writer's, which draws entries uniformly) spent most of their parse there.
                       if (!((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)(book.has_overflow != 0))) break;
                       const uint32_t data = (uint32_t)p.buf & (book.max_bits >= 32 ? 0xFFFFFFFFu : (1u << book.max_bits) - 1u);
-                      const NvhPOverflow* __restrict__ ov = T.overflow + book.ovf_off;
                       uint32_t cnt = node & 0x7Fu;
-                      if (cnt == 0x7Fu) cnt = book.ovf_count;
-                      else ov += book.ovf_count + (node >> 8);
                       uint32_t hit_len = 0, hit_val = 0;
-                      for (uint32_t k = 0; k < cnt; ++k) {
-                        const uint4 o = *reinterpret_cast<const uint4*>(ov + k);  // bits, mask, value, length
-                        if (o.x == (data & o.y)) {
-                          hit_val = o.z;
-                          hit_len = o.w;
-                          break;
+                      if (cnt != 0x7Fu && book.ovf_lds != 0xFFFFFFFFu) {
+                        // the group's nodes from LDS (nvh_setup.hip: 8 bytes each): a probe is an LDS round trip, not an L2 one
+                        const uint32_t g = book.ovf_lds + 2u * (node >> 8);
+                        for (uint32_t k = 0; k < cnt; ++k) {
+                          const uint32_t bits = s_prefix[g + 2u * k], vl = s_prefix[g + 2u * k + 1u], len = vl & 0xFFu;
+                          if (bits == (data & ((1u << len) - 1u))) {
+                            hit_val = vl >> 8;
+                            hit_len = len;
+                            break;
+                          }
+                        }
+                      } else {
+                        const NvhPOverflow* __restrict__ ov = T.overflow + book.ovf_off;
+                        if (cnt == 0x7Fu) cnt = book.ovf_count;
+                        else ov += book.ovf_count + (node >> 8);
+                        for (uint32_t k = 0; k < cnt; ++k) {
+                          const uint4 o = *reinterpret_cast<const uint4*>(ov + k);  // bits, mask, value, length
+                          if (o.x == (data & o.y)) {
+                            hit_val = o.z;
+                            hit_len = o.w;
+                            break;
+                          }
                         }
                       }
                       if (hit_len == 0u || hit_len > 32u) break;  // no match (or nothing this loop may skip): the general loop decides
@@ -613,7 +653,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     nent += (uint32_t)done;
                   }
                   for (int i = done * dims; i < r.partition_size; i += dims) {
-                    const int e = decode_scalar<LDS>(T, s_prefix, s_pkt, book, p);
+                    const int e = decode_scalar<LDS, UNI>(T, s_prefix, s_pkt, book, p);
                     if (e == -2) {
                       err = kErrRuntime;
                       break;
@@ -988,19 +1028,20 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   }
 }
 
-#define NVH_PARSE_KERNEL(NAME, LDSV, SLABV)                                                                                              \
+#define NVH_PARSE_KERNEL(NAME, LDSV, SLABV, UNIV)                                                                                        \
   extern "C" __global__ void __launch_bounds__(64 * NVH_PARSE_MAX_WAVES)                                                                  \
   NAME(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,                          \
        NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,          \
        uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,          \
        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs NVH_DBG_PARAMS) {     \
-    parse_body<LDSV, SLABV>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,      \
+    parse_body<LDSV, SLABV, UNIV>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,      \
                             scratch_words, pkt_words, slabs NVH_DBG_ARGS);                                                                \
   }
-NVH_PARSE_KERNEL(k_parse, true, false)       // descriptors out, packets and scratch rows in LDS
-NVH_PARSE_KERNEL(k_parse_g, false, false)    // ... in global memory (a packet too long for the LDS budget)
-NVH_PARSE_KERNEL(k_parse_slab, true, true)   // slabs out (the stream shapes the slab synthesis kernels take)
-NVH_PARSE_KERNEL(k_parse_slab_g, false, true)
+NVH_PARSE_KERNEL(k_parse, true, false, false)       // descriptors out, packets and scratch rows in LDS
+NVH_PARSE_KERNEL(k_parse_g, false, false, false)    // ... in global memory (a packet too long for the LDS budget)
+NVH_PARSE_KERNEL(k_parse_slab, true, true, false)   // slabs out (the stream shapes the slab synthesis kernels take)
+NVH_PARSE_KERNEL(k_parse_slab_g, false, true, false)
+NVH_PARSE_KERNEL(k_parse_slab_u, true, true, true)  // k_parse_slab for one packet per wavefront, wave-uniform (UNI above)
 
 // Second pass: what a frame needs from its neighbours (known only after every lane has parsed its packet): the overlap source's
 // execute flags (NvhChan::ov_exec / NvhFrame::ov_exec_mask) -- carry_exec_in: flags of the block carried in from the previous

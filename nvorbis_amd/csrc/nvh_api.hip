@@ -32,6 +32,7 @@ const NvhToggles& nvh_toggles() {
     x.ola_threads = num("NVH_OLA_THREADS");
     x.parse_lanes = num("NVH_PARSE_LANES");
     x.parse_waves = num("NVH_PARSE_WAVES");
+    x.no_parse_uni = on("NVH_NO_PARSE_UNI");
     x.ola_segs = num("NVH_OLA_SEGS");
     x.phase_mask = std::getenv("NVH_DEBUG_SPECTRUM_MASK") ? num("NVH_DEBUG_SPECTRUM_MASK") : 15;
     return x;
@@ -107,6 +108,14 @@ extern "C" void nvh_ctx_destroy(nvh_ctx* c) {
     c->hpool.clear();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+  });
+}
+
+extern "C" int nvh_ctx_set_parse_lanes(nvh_ctx* c, int lanes) {
+  return nvh_guard([&]() -> int {
+    if (!c || lanes < 0 || lanes > 64 || (lanes & (lanes - 1)) != 0) return NVH_ERR_ARGUMENT;
+    c->parse_lanes = lanes;
+    return NVH_OK;
   });
 }
 

@@ -52,6 +52,7 @@ NVH_PARSE_DECL(k_parse);         // descriptors out; packets and scratch rows in
 NVH_PARSE_DECL(k_parse_g);       // ... in global memory
 NVH_PARSE_DECL(k_parse_slab);    // slabs out (kernels_parse.hip: parse_body<.., SLAB>)
 NVH_PARSE_DECL(k_parse_slab_g);
+NVH_PARSE_DECL(k_parse_slab_u);  // k_parse_slab for one packet per wavefront, wave-uniform control flow (parse_body<.., UNI>)
 __global__ void k_parse_result_out(const NvhParseResult* dev, NvhParseResult* host);
 __global__ void k_parse_fetch(const uint4* stage_h, uint4* stage_d, long long stage_n16, const uint8_t* pool_h, uint8_t* pool_d,
                               long long pool_bytes, NvhParseResult* result);
@@ -131,6 +132,7 @@ struct NvhToggles {
   bool poison_planes;    // NVH_POISON_PLANES: work planes filled with NaN patterns at upload (finds reads of regions a batch never wrote)
   bool no_slab;   // NVH_NO_SLAB: the descriptor kernels (k_spectrum_imdct & co.) instead of the slab kernels (test / A-B aid)
   int lds_pad, ola_threads, parse_lanes, parse_waves;
+  bool no_parse_uni;  // NVH_NO_PARSE_UNI: one-packet-per-wavefront batches through k_parse_slab instead of k_parse_slab_u (A/B aid)
   int ola_segs;   // NVH_OLA_SEGS: workgroups per frame in k_ola_compact (default: by frame size)
   int phase_mask;  // debug build only (NVH_DEBUG_SPECTRUM_MASK)
 };
@@ -252,6 +254,7 @@ struct nvh_ctx {
   bool big_lds_attr_set = false;    // the general spectrum kernels' 152 KB dynamic-LDS opt-in was made on this context's device
   bool synth_lds_attr_set = false;  // k_synth8's 160 KB dynamic-LDS opt-in was made on this context's device
   bool parse_lds_attr_set = false;  // k_parse's 80 KB dynamic-LDS opt-in was made on this context's device
+  int parse_lanes = 0;              // nvh_ctx_set_parse_lanes: packets per wavefront of the GPU parser, 0 = automatic
 };
 
 struct nvh_batch {

@@ -168,6 +168,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     const int kParseWaves = (waves_env >= 1 && waves_env <= 16) ? waves_env : 16;
     int lanes = 1;
     while (lanes < 64 && (nf + (size_t)lanes - 1) / (size_t)lanes > 4096) lanes *= 2;
+    if (s->ctx->parse_lanes >= 1) lanes = std::max(lanes, s->ctx->parse_lanes);  // nvh_ctx_set_parse_lanes: a host with many parses in flight
     if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
     const size_t per_wg = (size_t)kParseWaves * (size_t)lanes;
     const unsigned pblocks = (unsigned)((nf + per_wg - 1) / per_wg);
@@ -191,9 +192,12 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_u, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       s->ctx->parse_lds_attr_set = true;
     }
-    hipLaunchKernelGGL(slab_mode ? (in_lds ? k_parse_slab : k_parse_slab_g) : (in_lds ? k_parse : k_parse_g), dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
+    // one packet per wavefront (every batch of up to 4096 packets): the wave-uniform form of the slab parser
+    const bool uni = slab_mode && in_lds && lanes == 1 && !nvh_toggles().no_parse_uni;
+    hipLaunchKernelGGL(uni ? k_parse_slab_u : slab_mode ? (in_lds ? k_parse_slab : k_parse_slab_g) : (in_lds ? k_parse : k_parse_g), dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
                        (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
                        (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),

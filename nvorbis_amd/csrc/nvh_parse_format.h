@@ -32,6 +32,8 @@ struct NvhPBook {
   uint32_t slab_lat;      // lattice pool offset | lat_values << 16
   uint32_t slab_dm16;     // ceil(2^16 / dims)
   uint32_t dim_magic;     // ceil(2^32 / dims), 0 for dims <= 1: partition_size / dims without a division (nvh_setup.hip checks the range)
+  uint32_t ovf_lds;       // word offset of the book's GROUPED overflow nodes inside the LDS image, two words each (bits, value << 8 |
+                          // length; the mask is (1 << length) - 1), 0xFFFFFFFF: scan them in global memory
 };
 
 struct NvhPOverflow {

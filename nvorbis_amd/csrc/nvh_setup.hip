@@ -361,6 +361,25 @@ int upload_parse_tables(nvh_stream* s) {
       books[(size_t)b].lds_off = (uint32_t)lds_image.size();
       lds_image.insert(lds_image.end(), prefix.begin() + books[(size_t)b].prefix_off, prefix.begin() + books[(size_t)b].prefix_off + n);
     }
+    // ... and behind them the grouped overflow nodes of those books, 8 bytes each: a code longer than the prefix costs a scan of
+    // its slot's group, a chain of dependent loads -- from LDS instead of from L2 (the C5 writer's packets, whose entries are
+    // drawn uniformly, take this path for 25-96 % of their symbols)
+    for (auto& d : books) d.ovf_lds = 0xFFFFFFFFu;
+    const size_t node_budget = lds_image.size() + 5 * 1024;  // words (20 KB)
+    for (int b : order) {
+      NvhPBook& d = books[(size_t)b];
+      const nvh::Codebook& cb = S.books[(size_t)b];
+      if (d.lds_off == 0xFFFFFFFFu || !cb.has_overflow || cb.overflow_grouped.empty()) continue;
+      bool ok = lds_image.size() + 2 * cb.overflow_grouped.size() <= node_budget;
+      for (const nvh::HuffNode& n : cb.overflow_grouped)
+        ok = ok && n.length >= 1 && n.length <= 31 && n.value >= 0 && n.value <= 0xFFFFFF && (uint32_t)n.mask == (1u << n.length) - 1u;
+      if (!ok) continue;
+      d.ovf_lds = (uint32_t)lds_image.size();
+      for (const nvh::HuffNode& n : cb.overflow_grouped) {
+        lds_image.push_back((uint32_t)n.bits);
+        lds_image.push_back(((uint32_t)n.value << 8) | (uint32_t)n.length);
+      }
+    }
     if (lds_image.empty()) lds_image.push_back(0u);
   }
   std::vector<NvhPFloor1> floors(S.floors.size());

@@ -42,6 +42,7 @@ SIGNATURES = {
     "nvh_ctx_destroy": (None, [_vp]),
     "nvh_ctx_set_hip_stream": (C.c_int, [_vp, _vp]),
     "nvh_ctx_synchronize": (C.c_int, [_vp]),
+    "nvh_ctx_set_parse_lanes": (C.c_int, [_vp, C.c_int]),
     "nvh_dev_alloc": (C.c_int, [_vp, C.c_size_t, _vpp]),
     "nvh_dev_free": (None, [_vp, _vp]),
     "nvh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

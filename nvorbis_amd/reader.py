@@ -67,7 +67,9 @@ def demux_ogg_array(data: bytes, stream_index=0, forward_only=False):
     n = C.c_int(0)
     total = C.c_int64(0)
     k = int(stream_index)
-    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    # the file's bytes where they lie (no copy under the GIL: a worker pool of demuxing threads would take turns at it)
+    src = np.frombuffer(data if data else b"\0", dtype=np.uint8)
+    buf = C.c_void_p(src.ctypes.data)
     check(fn(buf, len(data), k, None, 0, None, None, None, 0, C.byref(n), C.byref(total), None), "nvh_ogg_demux")
     pk = np.zeros(max(total.value, 1), dtype=np.uint8)
     offs = np.zeros(n.value + 1, dtype=np.int64)
@@ -142,6 +144,10 @@ class Context:
 
     def synchronize(self):
         check(lib().nvh_ctx_synchronize(self._h), "nvh_ctx_synchronize")
+
+    def set_parse_lanes(self, lanes):
+        """Packets per wavefront of the GPU packet parser for this context's streams (0 = automatic); see the header."""
+        check(lib().nvh_ctx_set_parse_lanes(self._h, int(lanes)), "nvh_ctx_set_parse_lanes")
 
     def mdct_reverse(self, n, batch, d_ptr, stride):
         """IMdct.Reverse on `batch` device buffers (Contracts/IMdct.cs:5)."""

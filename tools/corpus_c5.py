@@ -11,6 +11,7 @@ tests/c5_corpus.py (lengths log-uniform 5-300 s x scale, seed = file 
 import argparse
 import json
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd/__init__.py says why)
 import sys
 import time
 
