@@ -385,7 +385,8 @@ def c5_block(nv, torch, dist, rank, world, local_rank, scale, workers, share_gpu
     dev = "cuda:%d" % local_rank
     barrier()
     t0 = time.perf_counter()
-    arena, views = corpus.decode_files_to_device([files[i] for i in mine], device=local_rank, workers=workers, gpu_parse=True)
+    passes = {}
+    arena, views = corpus.decode_files_to_device([files[i] for i in mine], device=local_rank, workers=workers, gpu_parse=True, timings=passes)
     torch.cuda.synchronize()
     decode_s = max_over_ranks(time.perf_counter() - t0)
     local_map = {i: v for i, v in zip(mine, views)}
@@ -409,7 +410,7 @@ def c5_block(nv, torch, dist, rank, world, local_rank, scale, workers, share_gpu
         block = {"what": "C5: %d-file corpus at length scale %g, LPT shard over %d rank(s), GPU packet parser, one device arena per rank, "
                          "then the gather of all PCM to rank 0 (device to device)" % (len(files), scale, world),
                  "files": len(files), "scale": scale, "workers_per_rank": workers,
-                 "decode_s": decode_s, "gather_s": gather_s, "pcm_bytes": floats * 4, "gathered_bytes_over_links": remote * 4,
+                 "decode_s": decode_s, "decode_passes_rank0": passes, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "gather_s": gather_s, "pcm_bytes": floats * 4, "gathered_bytes_over_links": remote * 4,
                  "gather_GBps": (remote * 4 / gather_s / 1e9) if (world > 1 and gather_s > 0) else None,
                  "gather_bound": "each sender's one direct xGMI link to the root, ~153 GB/s; the root receives from all of them at once",
                  "long_frame_equivalents_per_s": floats / 2 / 1024 / (decode_s + gather_s),

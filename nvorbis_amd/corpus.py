@@ -218,7 +218,108 @@ def close_worker_contexts():
 PARSE_LANES_POOL = 8  # nvh_ctx_set_parse_lanes for the contexts of a worker pool of eight threads and more (see the header)
 
 
-def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, parse_lanes=0):
+def _warm_contexts(device, nthreads, sample, batch_frames, gpu_parse, parse_lanes, have):
+    """Worker contexts made ready while the host-only index pass runs: each opens a stream on `sample` (a file of the job),
+    parses and synthesises one look-ahead batch of it into a scratch buffer and closes the stream again -- which leaves behind
+    what a cold context spends its first file on: the device's copy of the setup (codebook / Huffman / MDCT tables) and the
+    pools of device and page-locked blocks, sized for a whole batch (hipMalloc / hipHostMalloc take milliseconds each and
+    the runtime serialises them across threads).  Returns (thread, list) -- the list is filled when the thread has ended;
+    entries stay None where something failed (the pool then makes that context itself).  `have`: contexts that exist already
+    (keep_contexts) are passed through untouched."""
+    import threading
+
+    import torch
+
+    from .reader import Context, Stream, demux_ogg_array
+    out = [have[t] if (have is not None and t < len(have)) else None for t in range(nthreads)]
+
+    def one(t, pa):
+        ctx = None
+        try:
+            ctx = Context(device)
+            ctx.set_parse_lanes(parse_lanes)
+            st = Stream(ctx, pa[0], pa[1], pa[2])
+            try:
+                if gpu_parse:
+                    try:
+                        st.set_gpu_parse(True)
+                    except Exception:
+                        pass
+                if len(pa) > 3:
+                    st.push_packets(pa, 3, batch_frames)
+                need = st.pending()[1] * st.channels
+                if st.pending()[0] and need:
+                    scratch = torch.empty(need, dtype=torch.float32, device="cuda:%d" % device)
+                    st.synth_device(scratch.data_ptr(), need)
+                    ctx.synchronize()
+                    del scratch
+            finally:
+                st.close()
+            out[t] = ctx
+        except Exception:
+            if ctx is not None:
+                ctx.close()
+
+    def run():
+        try:
+            pa = demux_ogg_array(sample)
+        except Exception:
+            return
+        ts = [threading.Thread(target=one, args=(t, pa), daemon=True) for t in range(nthreads) if out[t] is None]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    return th, out
+
+
+def _pcm_upper_bound(files):
+    """Floats the decode of `files` cannot exceed, from container fields alone: per file (granule position of its last page
+    + two maximal blocks) x the channel count of its identification header -- or None when a file does not look like that
+    (then the arena waits for the index pass).  Only used to start the arena's allocation early; the index pass decides."""
+    total = 0
+    for f in files:
+        j = f.rfind(b"OggS")
+        if j < 0 or j + 27 > len(f) or len(f) < 58 or f[:4] != b"OggS" or f[26] != 1 or f[28:35] != b"\x01vorbis":
+            return None
+        gran = int.from_bytes(f[j + 6:j + 14], "little", signed=True)
+        ch = f[39]
+        if gran < 0 or gran > (1 << 40) or ch == 0:
+            return None
+        total += (gran + 2 * 8192) * ch
+    return total
+
+
+def _early_arena(files, device):
+    """(thread, box): box[0] becomes a float32 device tensor of _pcm_upper_bound(files) elements, allocated while the index
+    pass runs (the runtime takes ~30 ms per GB of a fresh allocation: 0.6 s for the 21.6 GB of the corpus at its stated size) --
+    or stays None: no bound, or a bound beyond half of the free device memory."""
+    import threading
+
+    import torch
+    box = [None]
+
+    def run():
+        try:
+            bound = _pcm_upper_bound(files)
+            if not bound:
+                return
+            free, _ = torch.cuda.mem_get_info(device)
+            if bound * 4 > free // 2:
+                return
+            box[0] = torch.empty(bound, dtype=torch.float32, device="cuda:%d" % device)
+        except Exception:
+            box[0] = None
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    return th, box
+
+
+def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, parse_lanes=0, contexts=None):
     """fn(index, ctx) for every index on a pool of host threads, one nvh_ctx (= one HIP stream) per thread (ctx is None with
     need_ctx=False: host-only work).  keep_contexts: the threads' contexts outlive the call and serve the next one -- a
     context's pools of device / page-locked blocks and its setup cache are warm after its first file, and creating them
@@ -239,6 +340,10 @@ def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, 
         if need_ctx:
             if kept is not None and t < len(kept) and kept[t] is not None:
                 ctx = kept[t]
+            elif contexts is not None and t < len(contexts) and contexts[t] is not None:
+                ctx = contexts[t]  # made ready by _warm_contexts
+                if kept is not None:
+                    kept[t] = ctx
             else:
                 ctx = Context(device)
                 if kept is not None:
@@ -266,10 +371,14 @@ def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, 
         t.start()
     for t in threads:
         t.join()
+    if contexts is not None and kept is None:  # warmed contexts no thread took (fewer items than threads)
+        for t in range(nthreads, len(contexts)):
+            if contexts[t] is not None:
+                contexts[t].close()
     return errors
 
 
-def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False, keep_contexts=False):
+def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False, keep_contexts=False, timings=None):
     """Decode .ogg byte strings on ONE GPU into ONE device arena: returns (arena, views) with views[i] the interleaved
     float32 PCM of files[i] as a slice of `arena` (torch tensors on cuda:<device>), files back to back in list order.
 
@@ -301,20 +410,42 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
     if os.environ.get("NVH_CORPUS_BATCH"):  # A/B aid: packets per parse / synthesis batch
         batch_frames = int(os.environ["NVH_CORPUS_BATCH"])
     t_start = time.perf_counter()
+    keep = keep_contexts or bool(os.environ.get("NVH_CORPUS_KEEP_CTX"))
+    lanes = PARSE_LANES_POOL if (gpu_parse and min(workers, n) >= 8) else 0
+    warm_thread, warm = None, None
+    if n and not os.environ.get("NVH_CORPUS_NO_WARM"):  # the GPU side of the workers gets ready while the index pass keeps the CPUs busy
+        sample = max(range(n), key=lambda i: len(files[i]))
+        warm_thread, warm = _warm_contexts(device, max(1, min(workers, n)), files[sample], batch_frames, gpu_parse, lanes,
+                                           _WORKER_CONTEXTS.get(device) if keep else None)
+    arena_thread, arena_box = (None, [None]) if (not n or os.environ.get("NVH_CORPUS_NO_WARM")) else _early_arena(files, device)
     errors = _run_pool(n, workers, device, index_one, need_ctx=False)  # host-only: no GPU context per thread
+    if arena_thread is not None:
+        arena_thread.join()
     if errors:
+        if warm_thread is not None:
+            warm_thread.join()
+            for c in warm:
+                if c is not None and not (keep and c in _WORKER_CONTEXTS.get(device, [])):
+                    c.close()
         raise RuntimeError("index failed for files %s: %r" % ([i for i, _ in errors], errors[0][1]))
     t_index = time.perf_counter()
     offs = np.zeros(n + 1, np.int64)
     offs[1:] = np.cumsum(totals)
-    arena = torch.empty(max(int(offs[-1]), 1), dtype=torch.float32, device="cuda:%d" % device)
+    if arena_box[0] is not None and int(offs[-1]) >= 1 and int(arena_box[0].numel()) >= int(offs[-1]):
+        arena = arena_box[0][:int(offs[-1])]  # allocated during the index pass from an upper bound; the unused tail is < 1 %
+    else:
+        arena_box[0] = None
+        arena = torch.empty(max(int(offs[-1]), 1), dtype=torch.float32, device="cuda:%d" % device)
     torch.cuda.synchronize(device)
     base = arena.data_ptr()
     order = sorted(range(n), key=lambda i: (-len(files[i]), i))  # longest first: shorter tail
 
+    phase = {"open": 0.0, "synth": 0.0, "push": 0.0, "close": 0.0}  # NVH_CORPUS_TIMING: seconds summed over the workers
+
     def decode_one(k, ctx):
         i = order[k]
         pa = arrays[i]
+        t0 = time.perf_counter()
         st = Stream(ctx, pa[0], pa[1], pa[2])
         try:
             if gpu_parse:
@@ -323,29 +454,48 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
                 except Exception:
                     pass
             pos = [int(offs[i])]
+            t1 = time.perf_counter()
+            in_sink = [0.0]
 
             def sink(s):
+                ts = time.perf_counter()
                 room = int(offs[i + 1]) - pos[0]
                 need = s.pending()[1] * s.channels
                 if need > room:
                     raise RuntimeError("file %d produces more than the %d floats its index says" % (i, totals[i]))
                 pos[0] += s.synth_device(base + 4 * pos[0], room)
+                in_sink[0] += time.perf_counter() - ts
 
             _decode_file_packets(st, pa, batch_frames, sink)
             if pos[0] != int(offs[i + 1]):
                 raise RuntimeError("file %d produced %d floats, its index says %d" % (i, pos[0] - int(offs[i]), totals[i]))
         finally:
+            t2 = time.perf_counter()
             st.close()
+            if timing:
+                t3 = time.perf_counter()
+                phase["open"] += t1 - t0
+                phase["synth"] += in_sink[0]
+                phase["push"] += t2 - t1 - in_sink[0]
+                phase["close"] += t3 - t2
 
     t_alloc = time.perf_counter()
-    errors = _run_pool(n, workers, device, decode_one, keep_contexts=keep_contexts or bool(os.environ.get("NVH_CORPUS_KEEP_CTX")),
-                       parse_lanes=PARSE_LANES_POOL if (gpu_parse and min(workers, n) >= 8) else 0)
+    if warm_thread is not None:
+        warm_thread.join()
+    t_warm = time.perf_counter()
+    errors = _run_pool(n, workers, device, decode_one, keep_contexts=keep, parse_lanes=lanes, contexts=warm)
     if errors:
         raise RuntimeError("decode failed for files %s: %r" % ([order[k] for k, _ in errors], errors[0][1]))
+    if timings is not None:  # (a dict of the caller's: where the call's time went)
+        timings.update({"index_s": t_index - t_start, "arena_s": t_alloc - t_index, "wait_for_warm_contexts_s": t_warm - t_alloc,
+                        "decode_pass_s": time.perf_counter() - t_warm, "parse_lanes": lanes})
     if timing:
         import sys
         sys.stderr.write("decode_files_to_device: demux + index pass %.3f s, arena %.3f s, decode pass %.3f s (%d workers)\n" % (
             t_index - t_start, t_alloc - t_index, time.perf_counter() - t_alloc, workers))
+        sys.stderr.write("decode_files_to_device: waited %.3f s for the warmed contexts; summed over the workers: stream open %.3f s, "
+                         "push (+ upload and parse on the GPU in GPU-parse mode) %.3f s, synthesis %.3f s, close %.3f s\n" % (
+                             t_warm - t_alloc, phase["open"], phase["push"], phase["synth"], phase["close"]))
     views = [arena[int(offs[i]):int(offs[i + 1])] for i in range(n)]
     return arena, views
 

@@ -168,7 +168,14 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     const int kParseWaves = (waves_env >= 1 && waves_env <= 16) ? waves_env : 16;
     int lanes = 1;
     while (lanes < 64 && (nf + (size_t)lanes - 1) / (size_t)lanes > 4096) lanes *= 2;
-    if (s->ctx->parse_lanes >= 1) lanes = std::max(lanes, s->ctx->parse_lanes);  // nvh_ctx_set_parse_lanes: a host with many parses in flight
+    if (s->ctx->parse_lanes >= 1) {
+      // nvh_ctx_set_parse_lanes: a host with many parses in flight.  A small batch keeps at least 256 wavefronts -- a parse of
+      // 260 packets at eight per wavefront is 33 wavefronts that take four times as long (the corpus at a tenth of its length:
+      // decode pass 0.25 s with eight lanes throughout, 0.14 s with one)
+      int want = s->ctx->parse_lanes;
+      while (want > 1 && nf / (size_t)want < 256) want >>= 1;
+      lanes = std::max(lanes, want);
+    }
     if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
     const size_t per_wg = (size_t)kParseWaves * (size_t)lanes;
     const unsigned pblocks = (unsigned)((nf + per_wg - 1) / per_wg);

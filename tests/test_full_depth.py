@@ -150,15 +150,17 @@ def test_c5_corpus_world1_from_device_buffers(oracle, ogg_bytes):
         _assert_same(host[i], out[i].cpu().numpy(), ("C5 host", i))
 
 
-@pytest.mark.parametrize("scale", [0.1, 1.0])
-def test_c5_corpus_1004_files_digests(scale):
+@pytest.mark.parametrize("scale,gpu_parse", [(0.1, False), (0.1, True), (1.0, False)])
+def test_c5_corpus_1004_files_digests(scale, gpu_parse):
     """BASELINE C5 at world size 1, >= 1000 files: the SURVEY 8d corpus (tests/c5_corpus.py: 1000 writer files, lengths
     log-uniform 5-300 s x scale, seed = file index, + the 4 TestFiles) decoded file-parallel through the HIP path into one
     device arena (corpus.decode_files_to_device, what corpus.transcode(..., world=1, to_host=False) runs per rank); the
     SHA-256 of every file's PCM equals the oracle's committed digest (tests/golden/c5_digests_scale*.json, written by
     tools/corpus_c5.py --make-digests).  scale 0.1 (0.5-30 s per file, 270 k frames, 2.2 GB of PCM) runs always; the stated
     size, scale 1.0 (3.1 M frames, 21.6 GB of PCM in one device arena, about half a minute on the GPU box), runs too unless
-    NVH_C5_SKIP_FULL=1 (and not in the toggle replays of test_fallback_kernel_paths_bit_exact)."""
+    NVH_C5_SKIP_FULL=1 (and not in the toggle replays of test_fallback_kernel_paths_bit_exact).  gpu_parse: the way bench.py's
+    corpus block runs it -- the GPU packet parser with the worker pool's launch shape (nvh_ctx_set_parse_lanes(8)), twice over
+    worker contexts that are kept between the two jobs (keep_contexts)."""
     import os
 
     from nvorbis_amd import corpus
@@ -170,8 +172,11 @@ def test_c5_corpus_1004_files_digests(scale):
     files = c5_corpus.build_files(scale)
     assert len(files) == 1004
     assert [c5_corpus.file_digest(f) for f in files] == [r[0] for r in dig["digests"]]  # the very files the oracle decoded
-    arena, views = corpus.decode_files_to_device(files, device=0, workers=16)
-    assert int(arena.numel()) == dig["total_floats"]
-    bad = [i for i, v in enumerate(views)
-           if int(v.numel()) != dig["digests"][i][1] or c5_corpus.pcm_digest(v.cpu().numpy()) != dig["digests"][i][2]]
-    assert not bad, bad[:10]
+    for rep in range(2 if gpu_parse else 1):
+        arena, views = corpus.decode_files_to_device(files, device=0, workers=16, gpu_parse=gpu_parse, keep_contexts=gpu_parse)
+        assert int(arena.numel()) == dig["total_floats"]
+        bad = [i for i, v in enumerate(views)
+               if int(v.numel()) != dig["digests"][i][1] or c5_corpus.pcm_digest(v.cpu().numpy()) != dig["digests"][i][2]]
+        assert not bad, (rep, bad[:10])
+        del arena, views
+    corpus.close_worker_contexts()

@@ -187,3 +187,32 @@ def test_paired_emission_with_silent_channels(oracle, gpu_ctx, ogg_bytes, gpu_pa
     for bf in (512, 100):
         got = _decode(nv, gpu_ctx, pk, gr, fl, gpu_parse, bf)
         assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (gpu_parse, bf)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 8, 64])
+def test_parse_lanes_of_a_context_do_not_change_the_pcm(oracle, ogg_bytes, lanes):
+    """nvh_ctx_set_parse_lanes: the parser's launch shape a worker pool asks for (packets per wavefront; 1 = the wave-uniform
+    kernel k_parse_slab_u, more = k_parse_slab's divergent lanes) -- shipped files and a random-bit stream whose packets end
+    anywhere, both against the oracle; an argument that is not a power of two up to 64 is refused."""
+    import nvorbis_amd as nv
+    from nvorbis_amd import native
+    from tests import synth_stream as ss
+    ctx = nv.Context(0)
+    try:
+        for bad in (3, -1, 128):
+            with pytest.raises(native.NvhError):
+                ctx.set_parse_lanes(bad)
+        ctx.set_parse_lanes(lanes)
+        for name in ("3test", "issue6test"):
+            ref, _ = oracle.decode_ogg(ogg_bytes[name])
+            rd = nv.VorbisReader(ogg_bytes[name], ctx=ctx, batch_frames=300, gpu_parse=True)
+            got = rd.read_all()
+            rd.close()
+            assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, lanes)
+        pk, gr, fl = ss.filtered_stream(oracle, "stereo_res1_coupled", 160, 11, True)
+        ref, _ = oracle.decode_packets(pk, gr, fl, clip=True)
+        got = _decode(nv, ctx, pk, gr, fl, True, 64)
+        assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), lanes
+        ctx.set_parse_lanes(0)
+    finally:
+        ctx.close()
