@@ -317,7 +317,8 @@ template <bool LDS, bool SLAB, bool UNI = false>
 __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
-        NvhParseResult* __restrict__ result, int lanes_arg, int scratch_words, int pkt_words, uint4* __restrict__ slabs NVH_DBG_PARAMS) {
+        NvhParseResult* __restrict__ result, int lanes_arg, int scratch_words, int pkt_words, uint4* __restrict__ slabs,
+        const int* __restrict__ order NVH_DBG_PARAMS) {
   const int lanes = UNI ? 1 : lanes_arg;
 #ifdef NVH_DEBUG
 #define PM(bit) (!(phase_mask & ((bit) << 8)))  // profiling builds: NVH_DEBUG_SPECTRUM_MASK = 15 + 256 * (pieces to leave out)
@@ -355,7 +356,10 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   const bool parses = UNI ? valid_u : active;  // takes part in the parse of a packet
   if (!SLAB && !parses) return;
   const int slot = UNI ? wave : wave * lanes + (active ? lane : 0);  // packet of this workgroup
-  const int f = UNI ? (valid_u ? f_u : 0) : (active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0);
+  // Which frame that is: the host hands the frames over longest packet first (`order`), so that the packets of a wavefront are of
+  // a size -- its lanes run side by side only while all of them have symbols left -- and the launch ends on short ones.
+  const int f_idx = UNI ? (valid_u ? f_u : 0) : (active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0);
+  const int f = order ? order[f_idx] : f_idx;
 #ifdef NVH_DEBUG
 #define PT_T(k) do { if (dbg && active) dbg[(long long)f * 24 + (k)] = clock64(); } while (0)
 #define PT_ACC_BEGIN() const long long pt_t0 = clock64()
@@ -1033,9 +1037,10 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   NAME(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,                          \
        NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,          \
        uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,          \
-       NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs NVH_DBG_PARAMS) {     \
+       NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs,                     \
+       const int* __restrict__ order NVH_DBG_PARAMS) {                                                                                  \
     parse_body<LDSV, SLABV, UNIV>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,      \
-                            scratch_words, pkt_words, slabs NVH_DBG_ARGS);                                                                \
+                            scratch_words, pkt_words, slabs, order NVH_DBG_ARGS);                                                         \
   }
 NVH_PARSE_KERNEL(k_parse, true, false, false)       // descriptors out, packets and scratch rows in LDS
 NVH_PARSE_KERNEL(k_parse_g, false, false, false)    // ... in global memory (a packet too long for the LDS budget)

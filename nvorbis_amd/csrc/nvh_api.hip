@@ -33,6 +33,8 @@ const NvhToggles& nvh_toggles() {
     x.parse_lanes = num("NVH_PARSE_LANES");
     x.parse_waves = num("NVH_PARSE_WAVES");
     x.no_parse_uni = on("NVH_NO_PARSE_UNI");
+    x.no_sleep_wait = on("NVH_NO_SLEEP_WAIT");
+    x.no_parse_sort = on("NVH_NO_PARSE_SORT");
     x.ola_segs = num("NVH_OLA_SEGS");
     x.phase_mask = std::getenv("NVH_DEBUG_SPECTRUM_MASK") ? num("NVH_DEBUG_SPECTRUM_MASK") : 15;
     return x;
@@ -591,7 +593,7 @@ extern "C" int nvh_stream_synth(nvh_stream* s, float* pcm_host, float* d_pcm, in
     int* h_flags = (int*)((uint8_t*)s->h_pcm.p + bounce);
     if (pcm_bytes) HIP_TRY(hipMemcpyAsync(direct ? (void*)pcm_host : s->h_pcm.p, dst, pcm_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h_flags, s->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(nvh_wait_stream(s->ctx, st));
     if (bounce) std::memcpy(pcm_host, s->h_pcm.p, bounce);
     if (h_flags[0] || h_flags[1]) HIP_TRY(hipMemsetAsync(s->flags.p, 0, 2 * sizeof(int), st));
     if (h_flags[1]) s->has_clipped = 1;

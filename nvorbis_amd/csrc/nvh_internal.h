@@ -5,6 +5,7 @@
 //   nvh_ops.hip     level-1 operators: device-pointer mirrors of the reference's interface methods
 // Nothing here is part of the ABI (include/nvorbis_hip.h is).
 #pragma once
+#include <time.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -47,7 +48,7 @@ __global__ void k_mdct_reverse_wave(float* buf, int n, long long stride, const f
 #define NVH_PARSE_DECL(NAME)                                                                                                         \
   __global__ void NAME(NvhDevParse T, const uint8_t* pkt_pool, const NvhPacketRef* refs, int nframes, NvhFrame* frames, NvhChan* chans,   \
                        NvhResPass* passes, NvhResOp* ops, uint16_t* op_link, uint16_t* entries, uint16_t* posts, int* scratch,            \
-                       NvhParseResult* result, int lanes, int scratch_words, int pkt_words, uint4* slabs NVH_DBG_PARAMS)
+                       NvhParseResult* result, int lanes, int scratch_words, int pkt_words, uint4* slabs, const int* order NVH_DBG_PARAMS)
 NVH_PARSE_DECL(k_parse);         // descriptors out; packets and scratch rows in LDS
 NVH_PARSE_DECL(k_parse_g);       // ... in global memory
 NVH_PARSE_DECL(k_parse_slab);    // slabs out (kernels_parse.hip: parse_body<.., SLAB>)
@@ -132,6 +133,8 @@ struct NvhToggles {
   bool poison_planes;    // NVH_POISON_PLANES: work planes filled with NaN patterns at upload (finds reads of regions a batch never wrote)
   bool no_slab;   // NVH_NO_SLAB: the descriptor kernels (k_spectrum_imdct & co.) instead of the slab kernels (test / A-B aid)
   int lds_pad, ola_threads, parse_lanes, parse_waves;
+  bool no_sleep_wait;  // NVH_NO_SLEEP_WAIT: worker-pool contexts wait with hipStreamSynchronize like every other (A/B aid)
+  bool no_parse_sort;  // NVH_NO_PARSE_SORT: the GPU parser takes a batch's frames in stream order instead of longest packet first (A/B aid)
   bool no_parse_uni;  // NVH_NO_PARSE_UNI: one-packet-per-wavefront batches through k_parse_slab instead of k_parse_slab_u (A/B aid)
   int ola_segs;   // NVH_OLA_SEGS: workgroups per frame in k_ola_compact (default: by frame size)
   int phase_mask;  // debug build only (NVH_DEBUG_SPECTRUM_MASK)
@@ -256,6 +259,19 @@ struct nvh_ctx {
   bool parse_lds_attr_set = false;  // k_parse's 80 KB dynamic-LDS opt-in was made on this context's device
   int parse_lanes = 0;              // nvh_ctx_set_parse_lanes: packets per wavefront of the GPU parser, 0 = automatic
 };
+
+// Wait for the context's stream.  A context of a worker pool (nvh_ctx_set_parse_lanes > 0: one of many host threads, each waiting
+// milliseconds for its own parse) polls and sleeps instead of calling hipStreamSynchronize, which spins: a pool may then have
+// more threads than the host has cores for it (a container's CPU quota), and more parses in flight than cores.
+inline hipError_t nvh_wait_stream(const nvh_ctx* c, hipStream_t st) {
+  if (!c || c->parse_lanes <= 0 || nvh_toggles().no_sleep_wait) return hipStreamSynchronize(st);
+  for (;;) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    struct timespec ts = {0, 50 * 1000};
+    nanosleep(&ts, nullptr);
+  }
+}
 
 struct nvh_batch {
   nvh_stream* s = nullptr;
