@@ -23,7 +23,7 @@ def test_bench_two_ranks_share_one_gpu():
     env = dict(os.environ)
     env["NVH_BENCH_SHARE_GPU"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--min-timed-ms", "60",
-                        "--working-set-mib", "64", "--no-configs", "--no-cpu-baseline", "--no-unfused"], cwd=ROOT, env=env,
+                        "--working-set-mib", "64", "--no-configs", "--no-cpu-baseline", "--no-unfused", "--c5-scale", "0.1"], cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     d = _last_json(r.stdout)

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 NAME=${1:-r03}
 OUT=gpurun_out/prof_$NAME
 rm -rf $OUT; mkdir -p $OUT
-B="python bench.py --no-cpu-baseline --no-configs --no-unfused --steps 20 --warmup 5 --min-timed-ms 300 --streams 1 $3"
+B="python bench.py --no-cpu-baseline --no-configs --no-unfused --c5-scale 0 --steps 20 --warmup 5 --min-timed-ms 300 --streams 1 $3"
 BUILD=$(python -c "from nvorbis_amd import native; print(native.build_id())" 2>/dev/null | tail -1)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
