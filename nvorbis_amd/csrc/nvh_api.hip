@@ -167,11 +167,17 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
     }
     std::string key;
     std::shared_ptr<SharedSetup> sh;
+    key.assign((const char*)id_pkt, (size_t)id_len);
+    key.append((const char*)setup_pkt, (size_t)setup_len);
+    // host-only streams (the index pass of a corpus: one per file, on a pool of threads) share their setups per thread: parsing
+    // the codebooks costs ~1.2 ms, as much as demultiplexing and indexing a one-minute file
+    static thread_local std::map<std::string, std::shared_ptr<SharedSetup>> t_host_setups;
     if (c) {
-      key.assign((const char*)id_pkt, (size_t)id_len);
-      key.append((const char*)setup_pkt, (size_t)setup_len);
       auto it = c->setup_cache.find(key);
       if (it != c->setup_cache.end()) sh = it->second;
+    } else {
+      auto it = t_host_setups.find(key);
+      if (it != t_host_setups.end()) sh = it->second;
     }
     const bool cached = (bool)sh;
     if (!cached) {
@@ -205,6 +211,8 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
         }
         nvh::classify_residues(sh->setup, sh->slab, nvh_toggles().no_pair || lattice.size() > 0xFFFFu);
         sh->slab.lattice = lattice;
+        if (t_host_setups.size() >= 8) t_host_setups.clear();
+        t_host_setups.emplace(std::move(key), sh);
       }
       *out = s.release();
       return NVH_OK;
@@ -896,11 +904,14 @@ int demux_two_call(bool forward, Demux demux, const uint8_t* bytes, size_t len, 
   if (!bytes || !npackets || !total_bytes || stream_index < 0) return NVH_ERR_ARGUMENT;
   DemuxMemo& M = g_demux_memo;
   const bool sizing = !pkt_bytes && !offsets && !granules && !flags;
-  const uint64_t print = demux_fingerprint(bytes, len);
+  // (the fingerprint is a pass over the file: only where it decides something -- a sizing call, or a fill call that could be
+  // the second half of one; a one-call caller with buffers of its own pays for the demultiplex alone)
+  const bool memo_candidate = !sizing && M.bytes == bytes && M.len == len && M.stream == stream_index && M.forward == forward;
+  const uint64_t print = (sizing || memo_candidate) ? demux_fingerprint(bytes, len) : 0;
   nvh::OggPackets local;
   nvh::OggPackets* pk = &local;
   int ns = 0;
-  if (!sizing && M.bytes == bytes && M.len == len && M.stream == stream_index && M.forward == forward && M.print == print) {
+  if (memo_candidate && M.print == print) {
     pk = &M.pk;  // the sizing call's result
     ns = M.nstreams;
   } else {

@@ -70,6 +70,22 @@ def demux_ogg_array(data: bytes, stream_index=0, forward_only=False):
     # the file's bytes where they lie (no copy under the GIL: a worker pool of demuxing threads would take turns at it)
     src = np.frombuffer(data if data else b"\0", dtype=np.uint8)
     buf = C.c_void_p(src.ctypes.data)
+    # One call where a guess at the packet count holds (a packet every 48 bytes or fewer is not audio): the packets of a stream
+    # cannot be longer than its file, so the byte buffer is sized by the file.  The library then demultiplexes once and copies
+    # once; the sizing call + fill call below cost a fingerprint of the file each on top.
+    cap_n = len(data) // 48 + 64
+    if len(data) >= 4096:
+        pk = np.empty(len(data), dtype=np.uint8)
+        offs = np.empty(cap_n + 1, dtype=np.int64)
+        gran = np.empty(cap_n, dtype=np.int64)
+        flags = np.empty(cap_n, dtype=np.uint8)
+        rc = fn(buf, len(data), k, pk.ctypes.data, pk.size, offs.ctypes.data, gran.ctypes.data, flags.ctypes.data, cap_n,
+                C.byref(n), C.byref(total), None)
+        if rc == native.OK:
+            m = n.value
+            return PacketArray(pk[:max(total.value, 1)], offs[:m + 1].copy(), gran[:max(m, 1)].copy(), flags[:max(m, 1)].copy())
+        if rc != native.ERR_ARGUMENT:
+            check(rc, "nvh_ogg_demux")
     check(fn(buf, len(data), k, None, 0, None, None, None, 0, C.byref(n), C.byref(total), None), "nvh_ogg_demux")
     pk = np.zeros(max(total.value, 1), dtype=np.uint8)
     offs = np.zeros(n.value + 1, dtype=np.int64)

@@ -439,3 +439,47 @@ def test_codebook_tables_product_vs_oracle_vs_spec(oracle, ogg_bytes, source):
     finally:
         O.orc_close(d)
         st.close()
+
+
+def test_pcm_upper_bound_covers_what_the_decoder_emits(oracle, ogg_bytes):
+    """corpus._pcm_upper_bound (the early arena of decode_files_to_device): container fields alone bound the decoded length of
+    every shipped file -- issue6test emits more samples than its last granule position says -- and of corpus writer files; input
+    that is not an Ogg Vorbis file gives no bound (the arena then waits for the index pass)."""
+    from nvorbis_amd import corpus
+    from tests import c5_corpus
+    files = [ogg_bytes[k] for k in ("1test", "2test", "3test", "issue6test")]
+    ws = c5_corpus.writer_setup()
+    files += [c5_corpus.corpus_file(ws, i, 0.02) for i in (0, 1, 2)]
+    for data in files:
+        pcm, _ = oracle.decode_ogg(data)
+        bound = corpus._pcm_upper_bound([data])
+        assert bound is not None and pcm.size <= bound <= pcm.size + 2 * 2 * 8192 * 8 + 4096, (len(data), pcm.size, bound)
+    assert corpus._pcm_upper_bound(files) == sum(corpus._pcm_upper_bound([f]) for f in files)
+    assert corpus._pcm_upper_bound([b"junk" * 100]) is None
+    assert corpus._pcm_upper_bound([files[0], b""]) is None
+
+
+def test_demux_in_one_call_equals_the_sizing_and_fill_calls(ogg_bytes):
+    """reader.demux_ogg_array hands the library buffers sized from the file and gets the packets in one call; the two-call form
+    (sizing call, then fill call: what a caller without a bound uses, and the fallback) yields the same arrays."""
+    import ctypes as C
+
+    import numpy as np
+
+    from nvorbis_amd import native
+    from nvorbis_amd.reader import demux_ogg_array
+    L = native.lib()
+    for name in ("1test", "2test", "3test", "issue6test"):
+        data = ogg_bytes[name]
+        for fn, forward in ((L.nvh_ogg_demux_stream, False), (L.nvh_ogg_demux_forward, True)):
+            pa = demux_ogg_array(data, 0, forward)
+            src = np.frombuffer(data, dtype=np.uint8)
+            n, total = C.c_int(0), C.c_int64(0)
+            assert fn(C.c_void_p(src.ctypes.data), len(data), 0, None, 0, None, None, None, 0, C.byref(n), C.byref(total), None) == native.OK
+            pk = np.zeros(max(total.value, 1), np.uint8)
+            offs, gran, flags = np.zeros(n.value + 1, np.int64), np.zeros(max(n.value, 1), np.int64), np.zeros(max(n.value, 1), np.uint8)
+            assert fn(C.c_void_p(src.ctypes.data), len(data), 0, pk.ctypes.data, pk.size, offs.ctypes.data, gran.ctypes.data,
+                      flags.ctypes.data, n.value, C.byref(n), C.byref(total), None) == native.OK
+            assert len(pa) == n.value and pa.data.size == pk.size
+            assert np.array_equal(pa.data, pk) and np.array_equal(pa.offsets, offs)
+            assert np.array_equal(pa.granules[:n.value], gran[:n.value]) and np.array_equal(pa.flags[:n.value], flags[:n.value])

@@ -44,6 +44,8 @@ def child(scale, workers, gpu_parse, reps):
         best = dt if best is None else min(best, dt)
         print("REP_S %.4f" % dt, flush=True)
         del arena, views
+        if os.environ.get("NVH_SWEEP_EMPTY_CACHE"):  # every rep decodes into a freshly allocated arena
+            torch.cuda.empty_cache()
     print("DECODE_S %.4f" % best, flush=True)
 
 
