@@ -1,5 +1,5 @@
 """Stress: GPU packet parser vs host parser on many random synthetic streams (every shape inside the GPU parser's limits),
-random batch sizes; PCM must be identical bit for bit.  Not part of the test suite (minutes of runtime)."""
+random batch sizes and parser launch shapes (nvh_ctx_set_parse_lanes); PCM must be identical bit for bit.  Not part of the test suite (minutes of runtime)."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -19,7 +19,9 @@ for name in names:
         pk, gr, fl = ss.filtered_stream(orc, name, int(rng.integers(20, 120)), seed, consistent)
         bf = int(rng.choice([1, 2, 3, 7, 16, 50, 400]))
         a = _decode(nv, ctx, pk, gr, fl, False, bf)
+        ctx.set_parse_lanes(int(rng.choice([0, 0, 1, 2, 4, 8, 64])))  # the launch shape a worker pool asks for: same PCM
         b = _decode(nv, ctx, pk, gr, fl, True, bf)
+        ctx.set_parse_lanes(0)
         assert a.size == b.size and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, seed, bf)
         n += 1; frames += len(pk) - 3
 print("gpu-parse == host-parse on %d random streams (%d packets), %.0f s" % (n, frames, time.time() - t0))
