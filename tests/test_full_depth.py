@@ -124,6 +124,15 @@ def test_c3_markov_8192_frames_bit_exact(oracle, gpu_ctx, ogg_bytes):
     for bf in (1024, 4096):
         _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, True, bf), ref, ("C3", bf))
     _assert_same(_decode_gpu(nv, gpu_ctx, pk, gr, fl, True, 2048, gpu_parse=True), ref, ("C3", "gpu_parse"))
+    # the launch shapes a worker pool asks for (nvh_ctx_set_parse_lanes): several packets per wavefront, and -- block sizes mix --
+    # the batch's frames handed to the parser longest packet first; 4096 frames at 8 and 2 lanes, 2048 at 8 (256 wavefronts)
+    pool_ctx = nv.Context(0)
+    try:
+        for lanes, bf in ((8, 4096), (2, 4096), (8, 2048), (64, 8192)):
+            pool_ctx.set_parse_lanes(lanes)
+            _assert_same(_decode_gpu(nv, pool_ctx, pk, gr, fl, True, bf, gpu_parse=True), ref, ("C3", "gpu_parse lanes", lanes, bf))
+    finally:
+        pool_ctx.close()
 
 
 def test_c5_corpus_world1_from_device_buffers(oracle, ogg_bytes):
