@@ -8,6 +8,8 @@ point-to-point, each peer has one direct link to the root; a ring collective wou
 shape).  Works with backend "nccl" (= RCCL, device tensors) and "gloo" (CPU tensors, used by the CPU
 test suite).
 """
+import os
+
 import numpy as np
 
 
@@ -205,6 +207,13 @@ def _decode_file_packets(st, pa, batch_frames, sink):
 
 
 _WORKER_CONTEXTS = {}  # device -> [Context]: worker contexts kept between jobs (keep_contexts=True)
+_CLOSERS = []  # threads that are closing the contexts of finished jobs
+
+
+def wait_contexts_closed():
+    """Block until the worker contexts of finished jobs have been released (they are closed behind the job's return)."""
+    while _CLOSERS:
+        _CLOSERS.pop().join()
 
 
 def close_worker_contexts():
@@ -251,8 +260,7 @@ def _warm_contexts(device, nthreads, sample, batch_frames, gpu_parse, parse_lane
                 if st.pending()[0] and need:
                     scratch = torch.empty(need, dtype=torch.float32, device="cuda:%d" % device)
                     st.synth_device(scratch.data_ptr(), need)
-                    ctx.synchronize()
-                    del scratch
+                    del scratch  # (closing the stream waits for its work)
             finally:
                 st.close()
             out[t] = ctx
@@ -265,7 +273,15 @@ def _warm_contexts(device, nthreads, sample, batch_frames, gpu_parse, parse_lane
             pa = demux_ogg_array(sample)
         except Exception:
             return
-        ts = [threading.Thread(target=one, args=(t, pa), daemon=True) for t in range(nthreads) if out[t] is None]
+        # a few threads, several contexts each: the runtime serialises most of what they do, and the index pass wants the cores
+        todo = [t for t in range(nthreads) if out[t] is None]
+        lanes_n = max(1, min(int(os.environ.get("NVH_CORPUS_WARM_THREADS", "4")), len(todo)))
+
+        def some(k):
+            for t in todo[k::lanes_n]:
+                one(t, pa)
+
+        ts = [threading.Thread(target=some, args=(k,), daemon=True) for k in range(lanes_n)]
         for t in ts:
             t.start()
         for t in ts:
@@ -361,8 +377,9 @@ def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, 
                     errors.append((i, e))
         finally:
             if ctx is not None and kept is None:
-                ctx.close()
+                done_with.append(ctx)
 
+    done_with = []
     if kept is not None:
         while len(kept) < nthreads:
             kept.append(None)
@@ -374,7 +391,20 @@ def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, 
     if contexts is not None and kept is None:  # warmed contexts no thread took (fewer items than threads)
         for t in range(nthreads, len(contexts)):
             if contexts[t] is not None:
-                contexts[t].close()
+                done_with.append(contexts[t])
+    if done_with:
+        # The job's results are complete; giving the workers' pools back to the runtime (hipFree / hipHostFree of every block,
+        # serialised, ~0.2 s for 16 contexts) does not have to hold the caller up.
+        def close_all(ctxs):
+            for c in ctxs:
+                try:
+                    c.close()
+                except Exception:
+                    pass
+
+        th = threading.Thread(target=close_all, args=(done_with,), daemon=True)
+        th.start()
+        _CLOSERS.append(th)
     return errors
 
 
