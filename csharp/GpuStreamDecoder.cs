@@ -37,11 +37,16 @@ namespace NVorbis.Hip
         // exceptions the reference would throw from inside Read, queued at the ring position they belong to
         readonly Queue<KeyValuePair<Exception, int>> _pendingErrors = new Queue<KeyValuePair<Exception, int>>();
 
-        public GpuStreamDecoder(Contracts.IPacketProvider packetProvider, int device = 0, int batchPackets = 1024)
+        /// <param name="poolParseLanes">0 for a lone decoder.  A host that runs many decoders at once (one per worker thread: a
+        /// corpus transcoder) passes 8 -- nvh_ctx_set_parse_lanes: the GPU parser then puts up to eight packets on a wavefront,
+        /// so that the parses of all workers fit the chip side by side -- and starts its process with GPU_MAX_HW_QUEUES=16 in the
+        /// environment (INTEGRATION.md).  The PCM does not depend on it.</param>
+        public GpuStreamDecoder(Contracts.IPacketProvider packetProvider, int device = 0, int batchPackets = 1024, int poolParseLanes = 0)
         {
             _packetProvider = packetProvider ?? throw new ArgumentNullException(nameof(packetProvider));
             _batchPackets = batchPackets;
             NativeMethods.Check(NativeMethods.nvh_ctx_create(device, out _ctx));
+            if (poolParseLanes != 0) NativeMethods.Check(NativeMethods.nvh_ctx_set_parse_lanes(_ctx, poolParseLanes));
             // ProcessHeaderPackets (StreamDecoder.cs:107-127): id, comment, setup
             byte[] id = ReadAll(_packetProvider.GetNextPacket());
             byte[] comment = ReadAll(_packetProvider.GetNextPacket());
