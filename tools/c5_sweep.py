@@ -96,7 +96,7 @@ if __name__ == "__main__":
                   w, lanes or "-", waves or "-", batch or "-", "host-parse" if hostp else "gpu-parse ", m[-1] if m else "FAILED", " ".join(reps),
                   " ".join("/".join(x) for x in passes) if passes else "-", len(up), sums[0], sums[1], sums[2], sums[0] / n, sums[1] / n, sums[2] / n), flush=True)
         for ln in r.stdout.splitlines():
-            if "summed over the workers: stream open" in ln:
+            if "summed over the workers:" in ln and "decode_files_to_device: " in ln:
                 print("    " + ln.split("decode_files_to_device: ")[1], flush=True)
         if not m:
             print(r.stdout[-1500:], flush=True)
