@@ -621,7 +621,7 @@ def main():
         alg_bytes = FRAMES * ch * 4 * BLOCK
         # paired emission: k_synth runs twice per pass, each launch over half of the batch's frames (the library times the two
         # together); per LAUNCH, like rocprofv3's average and the PMC traffic: half the bytes, half the duration
-        launches = 2 if names[dom] == "k_synth+k_synth_emit" else 1
+        launches = 2 if names[dom] in ("k_synth+k_synth_emit", "k_synth_group2", "k_synth_group4") else 1
         dom_ms = km[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh);
@@ -635,9 +635,13 @@ def main():
                 if launches == 2:
                     # paired emission: the pass is one launch over the odd frames (k_synth_tail when the last block is odd,
                     # else k_synth) and one of k_synth_emit over the even frames; per launch = their mean
-                    odd = tk.get("k_synth_tail") or tk.get("k_synth")
-                    even = tk.get("k_synth_emit")
-                    traffic = (odd["hbm_bytes"] + even["hbm_bytes"]) / 2 if odd and even else None
+                    if names[dom].startswith("k_synth_group"):
+                        # frame groups: both launches are the same kernel (rocprofv3's row is the mean over the two)
+                        traffic = tk.get(names[dom], {}).get("hbm_bytes")
+                    else:
+                        odd = tk.get("k_synth_tail") or tk.get("k_synth")
+                        even = tk.get("k_synth_emit")
+                        traffic = (odd["hbm_bytes"] + even["hbm_bytes"]) / 2 if odd and even else None
                 else:
                     traffic = tk.get(names[dom], {}).get("hbm_bytes")
                 traffic_build = tj.get("build")

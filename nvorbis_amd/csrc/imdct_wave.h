@@ -39,6 +39,14 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// A workgroup barrier that orders LDS accesses only: global loads and LDS-DMA in flight (vmcnt) are not waited for, as
+// __syncthreads() would (callers that have staging DMA under way across the barrier: kernels_synth.hip, frame groups).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // LDS layout: complex point c (float2) lives at float2 slot c + 8*(c>>6): the pad keeps the stride-8 and
 // stride-64 set patterns of the radix passes off each other's banks.
 __device__ __forceinline__ int phys(int c) { return c + ((c >> 6) << 3); }
@@ -290,7 +298,8 @@ struct PassesPF {
 // passes exactly one __syncthreads; those without a transform of their own call it themselves).
 // PRESYNC (with INPLACE): the caller's workgroup barrier in front of the transform (the spectrum is other wavefronts' work too) is
 // taken HERE, after the step-0 twiddle loads have been issued, so that their L2 round trip overlaps the wait.
-template <int LD, bool WIN, typename Sink, bool INPLACE = false, bool WGSYNC = false, bool PRESYNC = false, bool PF = false>
+// LDSBAR (with WGSYNC): that barrier orders LDS accesses only (lds_barrier above).
+template <int LD, bool WIN, typename Sink, bool INPLACE = false, bool WGSYNC = false, bool PRESYNC = false, bool PF = false, bool LDSBAR = false>
 __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __restrict__ w, float* lds,
                                                 const float* __restrict__ A, const float* __restrict__ B,
                                                 const float* __restrict__ C, const float* __restrict__ TW, int lane,
@@ -334,7 +343,7 @@ __device__ __forceinline__ void imdct_wave_sink(const float* X, const float* __r
       const int j = lane + 64 * r;
       xin[r] = reinterpret_cast<const float4*>(X)[j < G::n8 ? j : G::n8 - 1];
     }
-    if constexpr (WGSYNC) __syncthreads(); else wave_sync();
+    if constexpr (WGSYNC && LDSBAR) lds_barrier(); else if constexpr (WGSYNC) __syncthreads(); else wave_sync();
 #pragma unroll
     for (int r = 0; r < J; ++r) {
       const int j = lane + 64 * r;

@@ -77,6 +77,7 @@ struct NvhSynthArgs {
   int lds_vecs;             // the LDS slab area (>= cap_vecs; paired emission stages the neighbours' quarters over constants + slab)
   int channels, block1;
   int f0, fstep;            // workgroup b synthesises frame f0 + b * fstep (paired emission: odd frames, then even frames)
+  int nframes;              // frames of the batch (frame groups: a group's frames beyond the batch's end are skipped)
   int xcd_map;              // frames in eight contiguous runs, one per XCD (kernels_synth.hip: synth_body)
   int prefetch_prev;        // paired emission, odd launch: workgroup b touches the slab of frame f - 1, which workgroup b of the even
                             // launch fetches next -- on the same XCD (workgroups go round the XCDs by index), so from that XCD's L2

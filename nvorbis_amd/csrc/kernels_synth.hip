@@ -537,8 +537,9 @@ __device__ __forceinline__ void synth_carry_out(const NvhSynthArgs& A, const flo
 // its registers.
 template <int NT>
 __device__ __forceinline__ void synth_self_carry(const NvhSynthArgs& A, const float* spec, int n, int nch, unsigned window_off,
-                                              unsigned out_pos, int tid) {
+                                              unsigned out_pos, int tid, int cstride = 0) {
   const int half = n >> 1;
+  if (cstride == 0) cstride = half;  // floats between the channels' first quarters
   const float* __restrict__ w = A.windows + window_off;
   float* out = A.pcm + (long long)out_pos * nch;
   int clipped = 0;
@@ -550,7 +551,7 @@ __device__ __forceinline__ void synth_self_carry(const NvhSynthArgs& A, const fl
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       if (c < nch) {
-        const float4 a = *reinterpret_cast<const float4*>(spec + c * half + i0);
+        const float4 a = *reinterpret_cast<const float4*>(spec + c * cstride + i0);
         const float* cp = A.carry + (long long)c * A.block1;
         const float4 tt = *reinterpret_cast<const float4*>(cp + half + i0);
         const float4 r = *reinterpret_cast<const float4*>(cp + (n - 4 - i0));
@@ -1021,92 +1022,18 @@ __device__ __forceinline__ void synth_emit8_direct(const NvhSynthArgs& A, float*
   if (A.clip) report_clipped(clipped, A.clipped_flag);
 }
 
-// ---- float side ------------------------------------------------------------------------------------------------------------
-// LDS map (dynamic, floats): [ inverse_dB_table 256 | lattice pool (const_vecs * 4 - 256) | slab image cap_vecs * 4 |
-//                              spectrum channels * block1 / 2 | block1 / 16 of IMDCT padding (k_synth) ]
-// NT = 256, MAXCH = 2 (k_synth): mono / stereo, blocks up to 2048, 8 workgroups per CU; the floor multiply inside the chain
-//   walk where the slab says so, the transform in place over the channel's own spectrum.
-// NT = 512, MAXCH = 8 (k_synth8): up to eight channels (one wavefront per channel in the transform), blocks up to 4096; coupling
-//   as passes of their own, the floor multiply as a pass over all channels, the transforms' slices laid over everything
-//   that is dead by then (imdct_wave<.., WGSYNC>).
-// MODE (k_synth only): 0 = synthesis alone, 1 = + the carried tail written by the last decoded block's workgroup, 2 = + paired
-// emission.  Three instantiations, so that the launches that never emit keep the registers of the kernel that cannot (62 instead
-// of 64 VGPRs at the 64-VGPR cap: 24.4 against 25.1 us for 4096 frames).
-template <int NT, int MAXCH, int MODE = 0, bool GENERAL = false>
-__device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-#ifdef NVH_ABL_EMPTY0
-  if (A.f0 >= 0) return;  // (ablation build: the launch alone)
-#endif
-  // Which frame this workgroup takes.  Workgroups go round the eight XCDs by index (workgroup b runs on XCD b % 8, each XCD
-  // with an L2 of its own), so with A.xcd_map the launch's frame list is cut into eight contiguous runs, one per XCD: frame
-  // 2k of the even launch and frames 2k - 1, 2k + 1 of the odd launch then ran on the same XCD (except at the seven cuts), and
-  // the quarters an emitting workgroup stages come out of that XCD's L2 instead of the memory side.
-  int slot = (int)blockIdx.x;
-  if (A.xcd_map) {
-    const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, x = slot & 7;
-    slot = x * q + (x < r ? x : r) + (slot >> 3);
-  }
-  const int f = A.f0 + slot * A.fstep;
+// The float side of one frame up to its spectra: residue adds (+ inverse coupling and the floor multiply inside the walk where the
+// slab says so), else coupling and floor curves as passes of their own.  slab / spec: the frame's slab image and spectra in LDS;
+// w0 .. w5, cpl_word: the slab header's words (scalar loads).  Every barrier in here is passed by the whole workgroup (the flags are
+// the frame's, hence uniform).  dbgf: profiling builds' stamp row of the frame (3 walk done, 6 / 7 around the coupling passes).
+template <int NT, int MAXCH, bool GENERAL>
+__device__ __forceinline__ void synth_frame_spectrum(const NvhSynthArgs& A, const float* s_db, const uint32_t* s_lat, float* slab,
+                                                     float* spec, unsigned w0, unsigned w1, unsigned w2, unsigned w3, unsigned w4,
+                                                     unsigned w5, unsigned cpl_word, int tid, long long* dbgf = nullptr) {
+#define SY_T(k) do { if (dbgf && threadIdx.x == 0) dbgf[(k)] = clock64(); } while (0)
   const int nch = A.channels;
-  float* s_db = smem;
-  const uint32_t* s_lat = reinterpret_cast<const uint32_t*>(smem + 256);
-  float* slab = smem + A.const_vecs * 4;
-  float* spec = slab + A.lds_vecs * 4;
-  const int half_max = A.block1 >> 1;
-#ifdef NVH_DEBUG
-#define SY_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)f * 24 + (k)] = clock64(); } while (0)
-#else
-#define SY_T(k) do { } while (0)
-#endif
-  SY_T(0);
-#ifdef NVH_DEBUG
-  if (dbg && threadIdx.x == 0) dbg[(long long)f * 24 + 22] = wall_clock64();
-#endif
-  // ---- one round trip: constants + the first NT * 16 bytes of the slab by LDS-DMA, the slab's header by a scalar load next to
-  // them (the slabs are constant for the life of the kernel: address space 4 makes the load an s_load), the spectrum cleared
-  // meanwhile; a slab beyond the speculative piece has its rest fetched as soon as the header is there -- in front of the ONE
-  // barrier, not behind a second round trip ----
-  const uint4* gslab = A.slabs + (long long)f * A.stride_vecs;
-  typedef const __attribute__((address_space(4))) uint32_t* const_words;
-  const_words gh = (const_words)(unsigned long long)gslab;
-  const unsigned w0 = gh[0], w1 = gh[1], w2 = gh[2], w3 = gh[3], w4 = gh[4], w5 = gh[5], frame = gh[6], cpl_word = gh[7];
-  constexpr unsigned kSpec = MAXCH > 2 ? 2 * NT : (NT < 256 ? 256 : NT);  // 16-byte units fetched before the header is known
-  {
-    const int v = tid;  // 16-byte unit handled by this lane: wavefront w moves units [64 w, 64 w + 64)
-    constexpr int kAux = (MAXCH <= 2 && MODE < 2) ? kSlabAuxOdd : kSlabAux;
-    if (v < A.cap_vecs) dma16<kAux>(gslab + v, slab + wv * 256);
-    if ((MAXCH > 2 || NT < 256) && NT + v < A.cap_vecs) dma16<kAux>(gslab + NT + v, slab + (NT / 64 + wv) * 256);  // big slabs: 16 KB up front (two-wavefront workgroups: the same 4 KB)
-    for (int c0 = wv * 64; c0 < A.const_vecs; c0 += NT)
-      if (c0 + lane < A.const_vecs) dma16(A.consts + c0 + lane, smem + c0 * 4);
-    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int i = tid; i < (nch * half_max) >> 2; i += NT) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
-  }
-  if constexpr (MAXCH <= 2 && MODE < 2) {
-    // the even launch's slab of the frame in front of this one: one dword per 128-byte line brings it into this XCD's L2 (the
-    // value is not used; the load is volatile so that it is issued)
-    if (A.prefetch_prev && wv == NT / 64 - 1 && f >= 1) {
-      const int lines = (A.cap_vecs < 256 ? A.cap_vecs : 256) >> 3;
-      if (lane < lines) {
-        const volatile unsigned* pp = reinterpret_cast<const volatile unsigned*>(A.slabs + (long long)(f - 1) * A.stride_vecs) + lane * 32;
-        (void)*pp;
-      }
-    }
-  }
-  const unsigned vecs = w3 >> 16;
-  if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
-  if (vecs > kSpec) {
-    for (unsigned c0 = kSpec + wv * 64; c0 < vecs; c0 += NT)
-      if (c0 + lane < vecs) dma16<kSlabAux>(gslab + c0 + lane, slab + c0 * 4);
-  }
-  __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
-  SY_T(1);
-#ifdef NVH_ABL_EMPTY1
-  if (A.f0 >= 0) return;  // (ablation build: launch + the one round trip)
-#endif
   const int n = (int)(w0 & 0xFFFFu);
-  if (n == 0) return;
-  const unsigned exec_mask = (w0 >> 16) & 0xFFu, flags = w0 >> 24;
+  const unsigned flags = w0 >> 24;
   const unsigned nheads = w1 & 0xFFFFu;
   const unsigned off_heads = w2 & 0xFFFFu, off_rec = w2 >> 16;
   const unsigned off_ent = w3 & 0xFFFFu;
@@ -1115,8 +1042,6 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
   const uint32_t* s_chan = reinterpret_cast<const uint32_t*>(slab) + 8;  // per channel: mode | nseg << 8 | off_seg << 16
   const int half = n >> 1;
   if ((flags & NVH_SLAB_FLOOR_FAULT) && tid == 0) atomicOr(A.err, NVH_DEVERR_FLOOR1_Y);
-  SY_T(2);
-
   // the floor curve of channel c as it lies in the slab
   auto floor_of = [&](unsigned cw, const uint4*& seg, const uint8_t*& tab) {
     const unsigned ns = (cw >> 8) & 0xFFu, oseg = cw >> 16;
@@ -1239,6 +1164,106 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
     // spectrum before the one barrier it has (WGSYNC), so the floor multiply ends with one of its own
     if (MAXCH > 2) __syncthreads();
   }
+#undef SY_T
+}
+
+// ---- float side ------------------------------------------------------------------------------------------------------------
+// LDS map (dynamic, floats): [ inverse_dB_table 256 | lattice pool (const_vecs * 4 - 256) | slab image cap_vecs * 4 |
+//                              spectrum channels * block1 / 2 | block1 / 16 of IMDCT padding (k_synth) ]
+// NT = 256, MAXCH = 2 (k_synth): mono / stereo, blocks up to 2048, 8 workgroups per CU; the floor multiply inside the chain
+//   walk where the slab says so, the transform in place over the channel's own spectrum.
+// NT = 512, MAXCH = 8 (k_synth8): up to eight channels (one wavefront per channel in the transform), blocks up to 4096; coupling
+//   as passes of their own, the floor multiply as a pass over all channels, the transforms' slices laid over everything
+//   that is dead by then (imdct_wave<.., WGSYNC>).
+// MODE (k_synth only): 0 = synthesis alone, 1 = + the carried tail written by the last decoded block's workgroup, 2 = + paired
+// emission.  Three instantiations, so that the launches that never emit keep the registers of the kernel that cannot (62 instead
+// of 64 VGPRs at the 64-VGPR cap: 24.4 against 25.1 us for 4096 frames).
+template <int NT, int MAXCH, int MODE = 0, bool GENERAL = false>
+__device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+#ifdef NVH_ABL_EMPTY0
+  if (A.f0 >= 0) return;  // (ablation build: the launch alone)
+#endif
+  // Which frame this workgroup takes.  Workgroups go round the eight XCDs by index (workgroup b runs on XCD b % 8, each XCD
+  // with an L2 of its own), so with A.xcd_map the launch's frame list is cut into eight contiguous runs, one per XCD: frame
+  // 2k of the even launch and frames 2k - 1, 2k + 1 of the odd launch then ran on the same XCD (except at the seven cuts), and
+  // the quarters an emitting workgroup stages come out of that XCD's L2 instead of the memory side.
+  int slot = (int)blockIdx.x;
+  if (A.xcd_map) {
+    const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, x = slot & 7;
+    slot = x * q + (x < r ? x : r) + (slot >> 3);
+  }
+  const int f = A.f0 + slot * A.fstep;
+  const int nch = A.channels;
+  float* s_db = smem;
+  const uint32_t* s_lat = reinterpret_cast<const uint32_t*>(smem + 256);
+  float* slab = smem + A.const_vecs * 4;
+  float* spec = slab + A.lds_vecs * 4;
+  const int half_max = A.block1 >> 1;
+#ifdef NVH_DEBUG
+#define SY_T(k) do { if (dbg && threadIdx.x == 0) dbg[(long long)f * 24 + (k)] = clock64(); } while (0)
+#else
+#define SY_T(k) do { } while (0)
+#endif
+  SY_T(0);
+#ifdef NVH_DEBUG
+  if (dbg && threadIdx.x == 0) dbg[(long long)f * 24 + 22] = wall_clock64();
+#endif
+  // ---- one round trip: constants + the first NT * 16 bytes of the slab by LDS-DMA, the slab's header by a scalar load next to
+  // them (the slabs are constant for the life of the kernel: address space 4 makes the load an s_load), the spectrum cleared
+  // meanwhile; a slab beyond the speculative piece has its rest fetched as soon as the header is there -- in front of the ONE
+  // barrier, not behind a second round trip ----
+  const uint4* gslab = A.slabs + (long long)f * A.stride_vecs;
+  typedef const __attribute__((address_space(4))) uint32_t* const_words;
+  const_words gh = (const_words)(unsigned long long)gslab;
+  const unsigned w0 = gh[0], w1 = gh[1], w2 = gh[2], w3 = gh[3], w4 = gh[4], w5 = gh[5], frame = gh[6], cpl_word = gh[7];
+  constexpr unsigned kSpec = MAXCH > 2 ? 2 * NT : (NT < 256 ? 256 : NT);  // 16-byte units fetched before the header is known
+  {
+    const int v = tid;  // 16-byte unit handled by this lane: wavefront w moves units [64 w, 64 w + 64)
+    constexpr int kAux = (MAXCH <= 2 && MODE < 2) ? kSlabAuxOdd : kSlabAux;
+    if (v < A.cap_vecs) dma16<kAux>(gslab + v, slab + wv * 256);
+    if ((MAXCH > 2 || NT < 256) && NT + v < A.cap_vecs) dma16<kAux>(gslab + NT + v, slab + (NT / 64 + wv) * 256);  // big slabs: 16 KB up front (two-wavefront workgroups: the same 4 KB)
+    for (int c0 = wv * 64; c0 < A.const_vecs; c0 += NT)
+      if (c0 + lane < A.const_vecs) dma16(A.consts + c0 + lane, smem + c0 * 4);
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = tid; i < (nch * half_max) >> 2; i += NT) reinterpret_cast<float4*>(spec)[i] = z;  // Mapping.cs:108
+  }
+  if constexpr (MAXCH <= 2 && MODE < 2) {
+    // the even launch's slab of the frame in front of this one: one dword per 128-byte line brings it into this XCD's L2 (the
+    // value is not used; the load is volatile so that it is issued)
+    if (A.prefetch_prev && wv == NT / 64 - 1 && f >= 1) {
+      const int lines = (A.cap_vecs < 256 ? A.cap_vecs : 256) >> 3;
+      if (lane < lines) {
+        const volatile unsigned* pp = reinterpret_cast<const volatile unsigned*>(A.slabs + (long long)(f - 1) * A.stride_vecs) + lane * 32;
+        (void)*pp;
+      }
+    }
+  }
+  const unsigned vecs = w3 >> 16;
+  if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab area is sized from the batch's largest slab
+  if (vecs > kSpec) {
+    for (unsigned c0 = kSpec + wv * 64; c0 < vecs; c0 += NT)
+      if (c0 + lane < vecs) dma16<kSlabAux>(gslab + c0 + lane, slab + c0 * 4);
+  }
+  __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
+  SY_T(1);
+#ifdef NVH_ABL_EMPTY1
+  if (A.f0 >= 0) return;  // (ablation build: launch + the one round trip)
+#endif
+  const int n = (int)(w0 & 0xFFFFu);
+  if (n == 0) return;
+  const unsigned exec_mask = (w0 >> 16) & 0xFFu, flags = w0 >> 24;
+  const uint32_t* s_chan = reinterpret_cast<const uint32_t*>(slab) + 8;  // per channel: mode | nseg << 8 | off_seg << 16
+  const int half = n >> 1;
+  SY_T(2);
+
+  synth_frame_spectrum<NT, MAXCH, GENERAL>(A, s_db, s_lat, slab, spec, w0, w1, w2, w3, w4, w5, cpl_word, tid,
+#ifdef NVH_DEBUG
+                                           dbg ? dbg + (long long)f * 24 : nullptr
+#else
+                                           nullptr
+#endif
+  );
   SY_T(4);
 
   // ---- inverse MDCT (Mdct.cs:65-313), one wavefront per channel ----
@@ -1394,6 +1419,312 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
 #undef SY_T
 }
 
+// ---- frame groups (round 6): FPW consecutive frames per workgroup, the overlaps between them on chip -----------------------------
+// Paired emission with one frame per workgroup sends every second frame through HBM: the odd frames' planes go out (two quarters
+// per channel) and come back in through the even frames' staging -- 16.8 MB out and 16.8 MB back per 4096-frame pass of C2, a
+// quarter of the pass's real traffic, on a pass that runs at 85 % of the box's copy rate under three streams.  Here a workgroup takes
+// FPW consecutive frames (one wavefront per (frame, channel) in the transform: all of them busy in the longest phase, where
+// k_synth has two of four idle), keeps every transform's two independent quarters in registers, puts them into the channel's dead
+// slice, and overlap-adds the FPW - 1 overlaps INSIDE the group from LDS (Mode.cs:160-166 windows, StreamDecoder.cs:532-541 adds,
+// :391-415 / Utils.cs:30-43 interleave + clip: synth_emit's arithmetic).  Only the overlaps between groups cross HBM, and they the
+// way they did: the groups with an odd index run first ("export": first quarter of their first frame and third quarter of their
+// last frame to the planes), the even groups second ("import": those quarters staged by LDS-DMA, both outer overlaps emitted).
+// Plane traffic per pass: 1 / FPW of the one-frame form's.
+// The emission flags keep their meaning (nvh_format.h): SELF = this frame's workgroup emits the frame's PCM (its first half over
+// frame f - 1's second half), NEXT = it emits frame f + 1's; the host sets them by position in the group (nvh_launch.hip), the
+// device withdraws them by the execute flags (k_parse_links) exactly as before.  A quarter goes to the plane unless the overlap it
+// belongs to is emitted by this workgroup -- k_ola_compact (frames outside the steady state) and the other launch find it there.
+// LDS map (floats), two phases over the same bytes (nvh_launch.hip: slab_lds_bytes sizes the larger + the table):
+//   walk:      [ constants | FPW slab images (A.lds_vecs * 4 each) | FPW x channels x block1/2 spectra ]
+//   transform: [ staged quarters, channels x block1/2: B(first - 1) at 0, A(last + 1) at channels * block1/4 | FPW x channels slices of
+//                block1/2 + block1/16 ] -- the slices overlay dead slabs AND live spectra: every wavefront takes its spectrum into
+//                registers in front of ONE LDS-only workgroup barrier (imdct_wave_sink<.., WGSYNC, .., LDSBAR>); the staging DMA,
+//                issued in front of it, lands below the spectra (the host sizes the slab areas for that) and is waited for behind the
+//                transforms
+//   behind both: 8 (FPW + 1) words, the overlaps' parameters.
+// Against private pads around every frame's spectra: 28.1 -> 26.7 KB for C2's shape = six workgroups per CU instead of five.
+// (Tried and removed, round 6: two frames per workgroup of EIGHT wavefronts, every 256 threads walking their own frame side by side --
+// k_synth's per-frame parallelism, 4 workgroups = 32 wavefronts per CU at 64 VGPRs: 171 M frames/s over three streams against 202 M for
+// this form, 124 M against 123 M on one.)
+template <int NT, int FPW>
+__device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* smem NVH_DBG_PARAMS) {
+  static_assert(NT / 64 >= 2 * FPW, "one wavefront per (frame, channel) in the transform");
+  // (the wavefront's index through readfirstlane: what depends on it alone -- which frame and channel it transforms, where its
+  // planes lie -- then lives in scalar registers)
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int nch = A.channels;
+  const int fa = A.f0 + (int)blockIdx.x * A.fstep;  // the group's first frame
+  const int half_max = A.block1 >> 1, pad_max = A.block1 >> 4;
+  float* s_db = smem;
+  const uint32_t* s_lat = reinterpret_cast<const uint32_t*>(smem + 256);
+  float* slab0 = smem + A.const_vecs * 4;
+  const int slab_words = A.lds_vecs * 4;
+  float* spec0 = slab0 + FPW * slab_words;
+  const int region = nch * half_max;                 // a frame's spectra
+  const int slice_words = half_max + pad_max;        // a transform's slice
+  float* slice0 = smem + nch * half_max;             // behind the staged quarters
+  const int walk_end = A.const_vecs * 4 + FPW * (slab_words + region), xform_end = nch * half_max + FPW * nch * slice_words;
+  uint32_t* otab = reinterpret_cast<uint32_t*>(smem + (walk_end > xform_end ? walk_end : xform_end));
+  typedef const __attribute__((address_space(4))) uint32_t* const_words;
+  // ---- one round trip: constants, the first NT * 16 bytes of every slab, the headers' size words by scalar loads; spectra
+  // cleared meanwhile ----
+  unsigned w0[FPW], w3[FPW];
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    w0[k] = 0u; w3[k] = 0u;
+    if (fa + k < A.nframes) {  // (uniform)
+      const uint4* gslab = A.slabs + (long long)(fa + k) * A.stride_vecs;
+      const_words gh = (const_words)(unsigned long long)gslab;
+      w0[k] = gh[0]; w3[k] = gh[3];
+      if (tid < A.cap_vecs) dma16<kSlabAux>(gslab + tid, slab0 + k * slab_words + wv * 256);
+    }
+  }
+  for (int c0 = wv * 64; c0 < A.const_vecs; c0 += NT)
+    if (c0 + lane < A.const_vecs) dma16(A.consts + c0 + lane, smem + c0 * 4);
+  {
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < FPW; ++k) {
+      float4* sp = reinterpret_cast<float4*>(spec0 + k * region);
+      for (int i = tid; i < (nch * half_max) >> 2; i += NT) sp[i] = z;  // Mapping.cs:108
+    }
+  }
+  int nn[FPW];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    nn[k] = (int)(w0[k] & 0xFFFFu);
+    any = any || nn[k] != 0;
+    const unsigned vecs = w3[k] >> 16;
+    if ((int)vecs > A.cap_vecs) __builtin_trap();  // host bug: the LDS slab areas are sized from the batch's largest slab
+    if (vecs > (unsigned)NT) {
+      const uint4* gslab = A.slabs + (long long)(fa + k) * A.stride_vecs;
+      for (unsigned c0 = NT + wv * 64; c0 < vecs; c0 += NT)
+        if (c0 + lane < vecs) dma16<kSlabAux>(gslab + c0 + lane, slab0 + k * slab_words + c0 * 4);
+    }
+  }
+  // (opt-in, NVH_GROUP_PREFETCH) the other launch's slabs of the group in front of this one, one dword per 128-byte line
+  if (A.prefetch_prev && wv == NT / 64 - 1 && fa >= FPW) {
+    const int lines = (A.cap_vecs < 256 ? A.cap_vecs : 256) >> 3;
+#pragma unroll
+    for (int k = 0; k < FPW; ++k)
+      if (lane < lines) {
+        const volatile unsigned* pp = reinterpret_cast<const volatile unsigned*>(A.slabs + (long long)(fa - FPW + k) * A.stride_vecs) + lane * 32;
+        (void)*pp;
+      }
+  }
+  __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
+  if (!any) return;
+
+  // a slab's header word i, from its LDS image (uniform)
+  auto hdr = [&](int k, int i) { return __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t*>(slab0 + k * slab_words)[i]); };
+  // ---- spectra, frame by frame (every barrier inside is the whole workgroup's) ----
+  {
+#pragma unroll
+    for (int k = 0; k < FPW; ++k)
+      if (nn[k] != 0)
+        synth_frame_spectrum<NT, 2, false>(A, s_db, s_lat, slab0 + k * slab_words, spec0 + k * region, w0[k], hdr(k, 1), hdr(k, 2),
+                                           w3[k], hdr(k, 4), hdr(k, 5), hdr(k, 7), tid);
+  }
+
+  // ---- what this workgroup emits: overlap j = the PCM of the group's frame j (j = FPW: of the frame behind the group) ----
+  const bool emit = A.pcm != nullptr;
+  bool self_k[FPW], next_k[FPW], cout_k[FPW];
+  bool self_carry = false;
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    const unsigned flags = w0[k] >> 24, xm = (w0[k] >> 16) & 0xFFu;
+    self_k[k] = emit && nn[k] != 0 && (flags & NVH_SLAB_EMIT_SELF);
+    next_k[k] = emit && nn[k] != 0 && (flags & NVH_SLAB_EMIT_NEXT);
+    cout_k[k] = A.carry_out != nullptr && nn[k] != 0 && (xm & NVH_SLABX_CARRY_OUT);
+    if (k == 0) self_carry = self_k[0] && (xm & NVH_SLABX_SELF_CARRY);
+  }
+  bool act[FPW + 1];
+  act[0] = self_k[0] && !self_carry;
+#pragma unroll
+  for (int j = 1; j < FPW; ++j) act[j] = next_k[j - 1] && self_k[j] && nn[j - 1] == nn[j];
+  act[FPW] = next_k[FPW - 1];
+  // The overlaps' parameters, out of the slabs before the staging overwrites them, into a table behind the spectra (one row of
+  // eight words per overlap, written by lane j of the first wavefront, read by every task of the overlap: a broadcast read instead of
+  // select chains over values that would stay live through the transforms): window, the earlier block's window, output position, block
+  // size, float offsets from smem and channel strides of the later block's first quarter and the earlier block's third quarter.
+  // Overlap 0 takes the first frame's SELF fields (chan[2], [3], [6]), overlap j >= 1 frame j - 1's NEXT fields (chan[4], [5], [7]).
+  const int S0 = (int)(slice0 - smem), SK = nch * slice_words;  // float offset of frame 0's slices from smem, slice words per frame
+  if (tid <= FPW) {
+    const int j = tid, kb = j == 0 ? 0 : j - 1;
+    const uint32_t* H = reinterpret_cast<const uint32_t*>(slab0 + kb * slab_words);
+    const int n = (int)(H[0] & 0xFFFFu);
+    uint4 r0, r1;
+    r0.x = H[j == 0 ? 10 : 12]; r0.y = H[j == 0 ? 11 : 13]; r0.z = H[j == 0 ? 14 : 15]; r0.w = (unsigned)n;
+    if (j == 0) { r1.x = (unsigned)S0; r1.y = (unsigned)slice_words; r1.z = 0u; r1.w = (unsigned)(n >> 2); }  // A(first) own, B(first - 1) staged
+    else {
+      r1.z = (unsigned)(S0 + kb * SK + (n >> 2)); r1.w = (unsigned)slice_words;
+      if (j < FPW) { r1.x = (unsigned)(S0 + j * SK); r1.y = (unsigned)slice_words; }
+      else { r1.x = (unsigned)(nch * (A.block1 >> 2)); r1.y = (unsigned)(n >> 2); }  // A(last + 1) staged
+    }
+    reinterpret_cast<uint4*>(otab)[2 * j] = r0;
+    reinterpret_cast<uint4*>(otab)[2 * j + 1] = r1;
+  }
+  unsigned cwin[FPW];  // a frame that writes the carried tail: its window (chan[2])
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) cwin[k] = cout_k[k] ? hdr(k, 10) : 0u;
+  __syncthreads();  // the walks are through everywhere: constants and slabs are dead, the spectra complete
+
+  // ---- stage the neighbours' quarters (import groups): B(first - 1), A(last + 1) ----
+  float* stageB = smem;
+  float* stageA = smem + nch * (A.block1 >> 2);
+  {
+    auto stage = [&](const float* plane0, int n, float* dst) __attribute__((always_inline)) {  // per channel n / 16 16-byte units at plane0 + c * block1
+      const int q16 = n >> 4, sh = 27 - __clz(n), units = nch * q16;  // q16 = 1 << sh
+      for (int u0 = wv * 64; u0 < units; u0 += NT) {
+        const int u = u0 + lane;
+        if (u < units) {
+          const int c = u >> sh, r = u & (q16 - 1);
+          dma16<kStageAux>(reinterpret_cast<const uint4*>(plane0 + (long long)c * A.block1 + 4 * r), dst + 4 * u0);
+        }
+      }
+    };
+    if (act[0]) stage(A.work + (long long)(fa - 1) * nch * A.block1 + (nn[0] >> 1), nn[0], stageB);
+    if (act[FPW]) stage(A.work + (long long)(fa + FPW) * nch * A.block1, nn[FPW - 1], stageA);
+  }
+
+  // ---- inverse MDCT (Mdct.cs:65-313): one wavefront per (frame, channel), the two independent quarters stay in registers; a
+  // quarter goes to the plane unless its overlap is emitted here ----
+  {
+    const int k = wv >> 1, c = wv & 1;
+    const bool tw = k < FPW;
+    int n = 0;
+    unsigned mw0 = 0u;
+    bool wrA = true, wrB = true, keep = false;
+#pragma unroll
+    for (int kk = 0; kk < FPW; ++kk)
+      if (kk == k) {
+        n = nn[kk]; mw0 = w0[kk];
+        const bool a_here = kk == 0 ? self_k[0] : act[kk], b_here = kk == FPW - 1 ? next_k[FPW - 1] : act[kk + 1];
+        wrA = !a_here || cout_k[kk];
+        wrB = !b_here || cout_k[kk];
+        keep = a_here || b_here;
+      }
+    const unsigned exec_mask = (mw0 >> 16) & 0xFFu, flags = mw0 >> 24;
+    const int half = n >> 1;
+    const int sl = (flags & NVH_SLAB_MDCT_SLOT) ? 1 : 0;
+    const float* X = spec0 + k * region + c * half;
+    float* slice = slice0 + (k * nch + c) * slice_words;
+    float* plane = A.work + ((long long)(fa + k) * nch + c) * A.block1;  // (a batch with paired emission has its slabs in frame order)
+    const bool mine = tw && c < nch && n != 0;
+    if (mine && !((exec_mask >> c) & 1u)) {
+      // Mapping.cs:192-196: the residue stays in [0, n/2) (k_ola_compact windows it); its tail quarter is zero
+      // (copied out in front of the barrier: behind it the slices overlay this spectrum)
+      for (int i = lane * 4; i < half; i += 256) *reinterpret_cast<float4*>(plane + i) = *reinterpret_cast<const float4*>(X + i);
+      for (int i = lane * 4; i < (half >> 1); i += 256) *reinterpret_cast<float4*>(plane + half + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (mine && ((exec_mask >> c) & 1u)) {
+      float4 ca[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, cb[2] = {ca[0], ca[0]};
+      auto sink = [&](int slot, int, float4 v) {  // slot = 4 h + q: q = 0 first quarter, q = 2 third quarter (1, 3: their mirrors)
+        if (slot == 0) ca[0] = v; else if (slot == 2) cb[0] = v; else if (slot == 4) ca[1] = v; else if (slot == 6) cb[1] = v;
+      };
+      const float* Aa = A.mdct_a[sl];
+      const float* Bb = A.mdct_b[sl];
+      const float* Cc = A.mdct_c[sl];
+      const float* TW = A.mdct_tw[sl];
+      switch (n) {
+        case 256: imdct_wave_sink<8, false, decltype(sink), true, true, false, kSynthPFEmit, true>(X, nullptr, slice, Aa, Bb, Cc, TW, lane, sink, nullptr, kAblSkip); break;
+        case 512: imdct_wave_sink<9, false, decltype(sink), true, true, false, kSynthPFEmit, true>(X, nullptr, slice, Aa, Bb, Cc, TW, lane, sink, nullptr, kAblSkip); break;
+        case 1024: imdct_wave_sink<10, false, decltype(sink), true, true, false, kSynthPFEmit, true>(X, nullptr, slice, Aa, Bb, Cc, TW, lane, sink, nullptr, kAblSkip); break;
+        case 2048: imdct_wave_sink<11, false, decltype(sink), true, true, false, kSynthPFEmit, true>(X, nullptr, slice, Aa, Bb, Cc, TW, lane, sink, nullptr, kAblSkip); break;
+        default: __builtin_trap();  // host launches this kernel for 256 <= block0, block1 <= 2048 only
+      }
+      if (lane < (n >> 5)) {  // lanes with output: four values of each quarter at 4 i8, i8 = lane and i8 = n/16 - 1 - lane
+        const int i8a = lane, i8b = (n >> 4) - 1 - lane;
+        if (wrA) {
+          *reinterpret_cast<float4*>(plane + 4 * i8a) = ca[0];
+          *reinterpret_cast<float4*>(plane + 4 * i8b) = ca[1];
+        }
+        if (wrB) {
+          *reinterpret_cast<float4*>(plane + half + 4 * i8a) = cb[0];
+          *reinterpret_cast<float4*>(plane + half + 4 * i8b) = cb[1];
+        }
+        if (keep) {  // the channel's own quarters, for the overlap-adds below: A in [0, n/4), B in [n/4, n/2) of its dead slice
+          float* own = slice;
+          *reinterpret_cast<float4*>(own + 4 * i8a) = ca[0];
+          *reinterpret_cast<float4*>(own + 4 * i8b) = ca[1];
+          *reinterpret_cast<float4*>(own + (half >> 1) + 4 * i8a) = cb[0];
+          *reinterpret_cast<float4*>(own + (half >> 1) + 4 * i8b) = cb[1];
+        }
+      }
+    } else {
+      lds_barrier();  // the one barrier every transforming wavefront passes inside imdct_wave_sink<.., WGSYNC, .., LDSBAR>
+    }
+  }
+  __syncthreads();  // drains the staging DMA; every own quarter is in LDS, every plane store of the workgroup is issued
+
+#pragma unroll
+  for (int k = 0; k < FPW; ++k)
+    if (cout_k[k])  // the block that becomes the next batch's carried tail (its whole plane was written above)
+      synth_carry_out<NT>(A, A.work + (long long)(fa + k) * nch * A.block1, nn[k], nch, (w0[k] >> 16) & 0xFFu, cwin[k], tid);
+  if (self_carry)  // the batch's first frame
+    synth_self_carry<NT>(A, slice0, nn[0], nch, __builtin_amdgcn_readfirstlane(otab[0]), __builtin_amdgcn_readfirstlane(otab[2]), tid, slice_words);
+
+  // ---- overlap-add + interleave + clip: lane task = (overlap j, group of four compact indices i0); it produces sample times
+  // i0 .. i0 + 3 and n/2 - 4 - i0 .. n/2 - 1 - i0 of every channel (kernels.hip: ola_sym) ----
+  int cnt[FPW + 2];
+  cnt[0] = 0;
+#pragma unroll
+  for (int j = 0; j <= FPW; ++j) cnt[j + 1] = cnt[j] + (act[j] ? (nn[j < FPW ? j : FPW - 1] >> 4) : 0);
+  int clipped = 0;
+  for (int t = tid; t < cnt[FPW + 1]; t += NT) {
+    int j = 0;
+#pragma unroll
+    for (int jj = 1; jj <= FPW; ++jj) j += (int)(t >= cnt[jj]);
+    int g = t;
+#pragma unroll
+    for (int jj = 1; jj <= FPW; ++jj) g = j == jj ? t - cnt[jj] : g;
+    const uint4 r0 = reinterpret_cast<const uint4*>(otab)[2 * j], r1 = reinterpret_cast<const uint4*>(otab)[2 * j + 1];
+    const int n = (int)r0.w, half = n >> 1, i0 = 4 * g;
+    const float* __restrict__ w = A.windows + r0.x;
+    const float* __restrict__ wp = A.windows + r0.y;
+    const float4 wf = *reinterpret_cast<const float4*>(w + i0);
+    const float4 wm = *reinterpret_cast<const float4*>(w + (half - 4 - i0));
+    const float4 pf = *reinterpret_cast<const float4*>(wp + (half + i0));
+    const float4 pm = *reinterpret_cast<const float4*>(wp + (n - 4 - i0));
+    float fwd[8], mir[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < nch) {
+        const float4 a = *reinterpret_cast<const float4*>(smem + r1.x + c * r1.y + i0);
+        const float4 b = *reinterpret_cast<const float4*>(smem + r1.z + c * r1.w + i0);
+        float4 v = make_float4(a.x * wf.x, a.y * wf.y, a.z * wf.z, a.w * wf.w);
+        const float4 tt = make_float4(b.x * pf.x, b.y * pf.y, b.z * pf.z, b.w * pf.w);
+        v.x = v.x + tt.x; v.y = v.y + tt.y; v.z = v.z + tt.z; v.w = v.w + tt.w;
+        float4 u = make_float4(-a.w * wm.x, -a.z * wm.y, -a.y * wm.z, -a.x * wm.w);
+        const float4 r = make_float4(b.w * pm.x, b.z * pm.y, b.y * pm.z, b.x * pm.w);
+        u.x = u.x + r.x; u.y = u.y + r.y; u.z = u.z + r.z; u.w = u.w + r.w;
+        if (A.clip) {
+          v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
+          v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
+          u.x = clip_value(u.x, &clipped); u.y = clip_value(u.y, &clipped);
+          u.z = clip_value(u.z, &clipped); u.w = clip_value(u.w, &clipped);
+        }
+        fwd[c] = v.x; fwd[2 + c] = v.y; fwd[4 + c] = v.z; fwd[6 + c] = v.w;
+        mir[c] = u.x; mir[2 + c] = u.y; mir[4 + c] = u.z; mir[6 + c] = u.w;
+      }
+    }
+    float* out = A.pcm + (long long)r0.z * nch;
+    if (nch == 2) {
+      float4* of = reinterpret_cast<float4*>(out) + 2 * (long long)g;
+      float4* om = reinterpret_cast<float4*>(out) + 2 * (long long)((n >> 3) - 1 - g);
+      pcm_store4(of, fwd[0], fwd[1], fwd[2], fwd[3]);
+      pcm_store4(of + 1, fwd[4], fwd[5], fwd[6], fwd[7]);
+      pcm_store4(om, mir[0], mir[1], mir[2], mir[3]);
+      pcm_store4(om + 1, mir[4], mir[5], mir[6], mir[7]);
+    } else {
+      pcm_store4(reinterpret_cast<float4*>(out) + g, fwd[0], fwd[2], fwd[4], fwd[6]);
+      pcm_store4(reinterpret_cast<float4*>(out) + ((n >> 3) - 1 - g), mir[0], mir[2], mir[4], mir[6]);
+    }
+  }
+  if (A.clip && emit) report_clipped(clipped, A.clipped_flag);
+}
+
 // 8 waves per SIMD = 8 resident workgroups per CU: the register budget (64 VGPRs) is part of the design
 #ifndef NVH_SYNTH_NT
 #define NVH_SYNTH_NT SP_THREADS
@@ -1445,4 +1776,18 @@ extern "C" __global__ void __launch_bounds__(512)
 k_synth8_emit(NvhSynthArgs A NVH_DBG_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   synth_body<512, NVH_SLAB_MAX_CH, 2>(A, smem NVH_DBG_ARGS);
+}
+
+// frame groups: two frames per workgroup (four wavefronts: one per (frame, channel)); LDS, not registers, decides the residency
+extern "C" __global__ void __launch_bounds__(256)
+k_synth_group2(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_group_body<256, 2>(A, smem NVH_DBG_ARGS);
+}
+
+// ... four frames per workgroup (eight wavefronts)
+extern "C" __global__ void __launch_bounds__(512)
+k_synth_group4(NvhSynthArgs A NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  synth_group_body<512, 4>(A, smem NVH_DBG_ARGS);
 }

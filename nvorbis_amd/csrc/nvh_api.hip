@@ -23,6 +23,8 @@ const NvhToggles& nvh_toggles() {
     x.emit8 = on("NVH_EMIT8");
     x.no_emit8 = on("NVH_NO_EMIT8");
     x.no_prefetch = on("NVH_NO_PREFETCH");
+    x.fpw = std::getenv("NVH_FPW") ? num("NVH_FPW") : 2;
+    if (x.fpw != 1 && x.fpw != 2 && x.fpw != 4) x.fpw = 2;
     x.copy_upload = on("NVH_COPY_UPLOAD");
     x.xcd_map = on("NVH_XCD_MAP");
     x.emit_always = on("NVH_EMIT_ALWAYS");

@@ -65,6 +65,8 @@ __global__ void k_synth(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_synth_g(NvhSynthArgs A NVH_DBG_PARAMS);     // + the general bin walk (Residue0, odd dimensions, several passes)
 __global__ void k_synth_tail(NvhSynthArgs A NVH_DBG_PARAMS);  // + the carried tail written in place (kernels_synth.hip: MODE 1)
 __global__ void k_synth_emit(NvhSynthArgs A NVH_DBG_PARAMS);  // + paired emission (MODE 2)
+__global__ void k_synth_group2(NvhSynthArgs A NVH_DBG_PARAMS);  // frame groups: two / four frames per workgroup, the overlaps between them on chip
+__global__ void k_synth_group4(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_synth8(NvhSynthArgs A NVH_DBG_PARAMS);
 __global__ void k_synth8_g(NvhSynthArgs A NVH_DBG_PARAMS);    // + the general bin walk
 __global__ void k_synth8_emit(NvhSynthArgs A NVH_DBG_PARAMS);  // wide frames + paired emission through LDS (synth_emit8)
@@ -127,6 +129,8 @@ struct NvhToggles {
                     // at least 7/8 steady state; the parity suite replays itself with this switch to cover the mixed cases)
   bool xcd_map;      // NVH_XCD_MAP: paired-emission launches take their frames in eight per-XCD runs instead of workgroup order (A/B aid)
   bool copy_upload;  // NVH_COPY_UPLOAD: a GPU-parse batch's input goes up by copy commands instead of k_parse_fetch (A/B aid)
+  int fpw;           // NVH_FPW: frames per workgroup of the mono / stereo synthesis with paired emission (kernels_synth.hip: frame groups):
+                     // 1 = k_synth + k_synth_emit (the round-3..5 form), 2 (default) = k_synth_group2, 4 = k_synth_group4
   bool no_prefetch;  // NVH_NO_PREFETCH: the odd launch of a paired-emission pass does not touch the even launch's slabs (A/B aid)
   bool uncached_planes;  // NVH_UNCACHED_PLANES: a batch's work planes in hipDeviceMallocUncached memory (the round-4 experiment whose
                          // wrong PCM with GPU-parsed batches was never explained: tools/repro_uncached.py)
@@ -255,6 +259,7 @@ struct nvh_ctx {
   BufPool hpool;  // pinned staging blocks
   std::map<std::string, std::shared_ptr<SharedSetup>> setup_cache;  // key: identification packet + setup packet bytes
   bool big_lds_attr_set = false;    // the general spectrum kernels' 152 KB dynamic-LDS opt-in was made on this context's device
+  bool group_lds_attr_set = false;  // ... k_synth_group2 / 4's
   bool synth_lds_attr_set = false;  // k_synth8's 160 KB dynamic-LDS opt-in was made on this context's device
   bool parse_lds_attr_set = false;  // k_parse's 80 KB dynamic-LDS opt-in was made on this context's device
   int parse_lanes = 0;              // nvh_ctx_set_parse_lanes: packets per wavefront of the GPU parser, 0 = automatic
@@ -305,6 +310,7 @@ struct nvh_batch {
   const uint4* d_slabs = nullptr;  // ... here
   // paired emission (nvh_format.h: NVH_EMIT_*): frames whose PCM k_synth writes itself, and the frames left to k_ola_compact
   int emit_frames = 0;           // frames with NVH_EMIT_DONE
+  int fpw = 1;                   // frames per workgroup the emission flags were laid out for (1: odd / even frames; 2, 4: frame groups)
   bool ola_all = false;          // GPU-parsed batch in which k_parse_links withdrew an emission candidate: k_ola_compact over every frame
   int ola_count = 0;             // entries of d_ola_list
   const int* d_ola_list = nullptr;  // inside the descriptor blob

@@ -6,6 +6,7 @@
 static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResult* d_res);
 static bool slab_shape_ok(const nvh_batch* b);
 static bool slab_size_ok(const nvh_batch* b);
+static void assign_emission(nvh_stream* s, nvh_batch* b, nvh::FrameBatch& P, int fpw, std::vector<int>& ola_list);
 
 void replay_note(nvh_stream* s, int kind, const uint8_t* data, int len, int64_t granule, int flags) {
   if (!s->gpu_parse) return;
@@ -294,40 +295,17 @@ static int collect_parse_result(nvh_stream* s, nvh_batch* b, const NvhParseResul
   return NVH_OK;
 }
 
-int batch_upload(nvh_stream* s, nvh_batch* b) {
-  nvh::FrameBatch& P = s->pending;
-  b->s = s;
-  b->nframes = (int)P.frames.size();
-  b->chan_frames = (int)P.chans.size();
-  b->pcm_samples = P.pcm_samples;
-  b->sequential_ola = P.sequential_ola;
-  b->last_decoded = -1;
-  b->max_ops = b->max_ent = b->max_pass = 0;
-  b->slabs_ready = false;
-  b->slab_host = false;
-  b->d_slabs = nullptr;
-  b->slab_stride_vecs = b->slab_cap_vecs = 0;
-  b->links_ok = P.links_ok && P.op_link.size() == P.ops.size();
-  for (const NvhFrame& fr : P.frames) {
-    if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
-    if ((int)fr.ent_count > b->max_ent) b->max_ent = (int)fr.ent_count;
-    if ((int)(fr.pass_end - fr.pass_begin) > b->max_pass) b->max_pass = (int)(fr.pass_end - fr.pass_begin);
-    // kernels index channel records by frame: every frame owns exactly `channels` of them (host_parse.cpp)
-    if (fr.chan_off != (uint32_t)((size_t)(&fr - P.frames.data()) * (size_t)s->setup.channels)) return NVH_ERR_RUNTIME;
-  }
-  for (int i = b->nframes - 1; i >= 0; --i)
-    if (P.frames[(size_t)i].n != 0) {
-      b->last_decoded = i;
-      break;
-    }
-
+// Paired emission: marks the steady-state overlaps the slab synthesis kernels emit themselves (NvhFrame::emit_flags) for workgroups
+// of `fpw` consecutive frames, and lists what is left for k_ola_compact.
+static void assign_emission(nvh_stream* s, nvh_batch* b, nvh::FrameBatch& P, int fpw, std::vector<int>& ola_list) {
   // ---- paired emission (nvh_format.h: NVH_EMIT_*): which steady-state overlaps the slab synthesis kernel emits itself ----
   // g "steady": its whole first half lies over the whole second half of frame g - 1, same size, every channel executing in
   // both, whole groups of four samples (k_ola_compact's read-once path has the same contract: kernels.hip, ola_sym).  Even
   // frames emit; an odd steady frame's PCM comes from the even frame in front of it.  Host-parsed batches of mono / stereo
   // streams with blocks 256..2048 only (the execute flags of a GPU-parsed batch are not known here).
-  std::vector<int> ola_list;
+  ola_list.clear();
   b->emit_frames = 0;
+  b->fpw = 1;
   {
     const int ch = s->setup.channels;
     // mono / stereo with blocks up to 2048 (k_synth_emit: from registers and LDS-staged quarters), or the wide kernel's shapes --
@@ -356,15 +334,23 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
              full(fr.ov_exec_mask) && full(pv.exec_mask) && ((fr.out_pos * ch) & 3) == 0 &&
              fr.out_pos >= 0 && fr.out_pos < 0x7FFFFFFFll && fr.window_off < 0x7FFFFFFFu;
     };
+    // Who emits an overlap.  Frames go to workgroups in groups of fpw consecutive frames (1: k_synth / k_synth_emit, the odd
+    // frames first; 2, 4: kernels_synth.hip, frame groups -- the groups with an odd index first); a steady overlap inside a group
+    // is emitted by that group from LDS, one between two groups by the group of the second launch (even index), which finds the
+    // other group's quarter in the planes.  SELF: the frame's own workgroup emits its PCM; NEXT: it emits frame g + 1's.
+    if (narrow && can && fpw > 1) b->fpw = fpw;
+    const int gw = b->fpw;
     for (int g = 0; g < nf; g++) {
       NvhFrame& fr = P.frames[(size_t)g];
       fr.emit_flags = 0;
+      const int k = g % gw;
+      const bool second_launch = ((g / gw) & 1) == 0;
       if (steady(g)) {
         fr.emit_flags |= NVH_EMIT_DONE;
-        if ((g & 1) == 0) fr.emit_flags |= NVH_EMIT_SELF;
+        if (k > 0 || second_launch) fr.emit_flags |= NVH_EMIT_SELF;
         b->emit_frames++;
       }
-      if ((g & 1) == 0 && steady(g + 1)) fr.emit_flags |= NVH_EMIT_NEXT;
+      if ((k < gw - 1 || second_launch) && steady(g + 1)) fr.emit_flags |= NVH_EMIT_NEXT;
     }
     // the batch's first frame over the carried tail of the batch before (same geometry, the tail stored fully windowed)
     if (can && nf > 0) {
@@ -386,6 +372,7 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       if (!nvh_toggles().emit_always && (long long)b->emit_frames * 8 < (long long)decoded * 7) {
         for (NvhFrame& fr : P.frames) fr.emit_flags = 0;
         b->emit_frames = 0;
+        b->fpw = 1;
       }
     }
     // what is left for k_ola_compact: every other frame that emits samples.  The block that becomes the carried tail is written
@@ -399,6 +386,37 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       if ((fr.emit_count > 0 && !(fr.emit_flags & NVH_EMIT_DONE)) || (g == last && !(fr.emit_flags & NVH_EMIT_CARRY_OUT))) ola_list.push_back(g);
     }
   }
+}
+
+int batch_upload(nvh_stream* s, nvh_batch* b) {
+  nvh::FrameBatch& P = s->pending;
+  b->s = s;
+  b->nframes = (int)P.frames.size();
+  b->chan_frames = (int)P.chans.size();
+  b->pcm_samples = P.pcm_samples;
+  b->sequential_ola = P.sequential_ola;
+  b->last_decoded = -1;
+  b->max_ops = b->max_ent = b->max_pass = 0;
+  b->slabs_ready = false;
+  b->slab_host = false;
+  b->d_slabs = nullptr;
+  b->slab_stride_vecs = b->slab_cap_vecs = 0;
+  b->links_ok = P.links_ok && P.op_link.size() == P.ops.size();
+  for (const NvhFrame& fr : P.frames) {
+    if ((int)fr.op_count > b->max_ops) b->max_ops = (int)fr.op_count;
+    if ((int)fr.ent_count > b->max_ent) b->max_ent = (int)fr.ent_count;
+    if ((int)(fr.pass_end - fr.pass_begin) > b->max_pass) b->max_pass = (int)(fr.pass_end - fr.pass_begin);
+    // kernels index channel records by frame: every frame owns exactly `channels` of them (host_parse.cpp)
+    if (fr.chan_off != (uint32_t)((size_t)(&fr - P.frames.data()) * (size_t)s->setup.channels)) return NVH_ERR_RUNTIME;
+  }
+  for (int i = b->nframes - 1; i >= 0; --i)
+    if (P.frames[(size_t)i].n != 0) {
+      b->last_decoded = i;
+      break;
+    }
+
+  std::vector<int> ola_list;
+  assign_emission(s, b, P, nvh_toggles().fpw, ola_list);
   b->ola_count = (int)ola_list.size();
   b->d_ola_list = nullptr;
   b->ola_all = false;
@@ -407,6 +425,11 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
   b->stats[3] = (int64_t)P.ops.size(); b->stats[4] = (int64_t)P.entries.size(); b->stats[5] = (int64_t)P.posts.size();
   b->stats[6] = (int64_t)P.coeffs.size();
   if (s->gpu_parse) {
+    if (b->fpw > 1) {  // a setup whose worst-case slabs do not leave room for a group's LDS: one frame per workgroup
+      b->slab_stride_vecs = b->slab_cap_vecs = s->shared->parse.slab_stride_vecs;
+      if (!slab_size_ok(b)) assign_emission(s, b, P, 1, ola_list);
+      b->ola_count = (int)ola_list.size();
+    }
     int rc = batch_upload_gpu(s, b, ola_list);
     if (rc != NVH_INTERNAL_REPLAY) {
       if (rc == NVH_OK) s->replay.clear();
@@ -431,6 +454,12 @@ int batch_upload(nvh_stream* s, nvh_batch* b) {
       stride = (stride + 3) & ~(size_t)3;
       b->slab_stride_vecs = b->slab_cap_vecs = (int)stride;
       b->slab_host = true;
+      if (!slab_size_ok(b) && b->fpw > 1) {  // no room for a group's LDS: one frame per workgroup, the slab headers written again
+        assign_emission(s, b, P, 1, ola_list);
+        b->ola_count = (int)ola_list.size();
+        rc = nvh::build_slabs(s->setup, s->shared->slab, P, SB);
+        if (rc != NVH_OK) return rc;
+      }
       if (!slab_size_ok(b)) b->slab_host = false;
     }
     if (b->slab_host) {
@@ -552,6 +581,9 @@ static bool slab_wide(const nvh_stream* s) { return s->setup.channels > 2 || s->
 // reported by k_parse for GPU-parsed batches (before its launch: the setup's worst case, for the size check).
 static size_t slab_bound_vecs(const nvh_batch* b) { return (size_t)b->slab_cap_vecs; }
 
+// A mono / stereo batch with paired emission whose frames go to workgroups in groups (k_synth_group2 / 4)
+static bool slab_groups(const nvh_batch* b) { return !slab_wide(b->s) && b->emit_frames > 0 && b->fpw > 1; }
+
 // The LDS slab area in 16-byte units: the batch's largest slab -- and, for a batch with paired emission (k_synth only), room
 // for the neighbours' quarters that are staged over constants + slab in front of the first transform slice's padding
 // (kernels_synth.hip: synth_emit).
@@ -560,8 +592,14 @@ static size_t slab_lds_vecs(const nvh_batch* b) {
   size_t v = slab_bound_vecs(b);
   if (!slab_wide(s) && b->emit_frames > 0) {
     const size_t ch = (size_t)s->setup.channels, b1 = (size_t)s->setup.block1;
-    const size_t need_words = ch * (b1 / 2) + b1 / 16, have = (size_t)s->shared->synth_const_vecs * 4;
-    if (need_words > have) v = std::max(v, (need_words - have + 3) / 4);
+    if (b->fpw > 1) {
+      // frame groups: the two staged quarters of every channel lie over the constants and the group's fpw slab areas together
+      const size_t need_words = ch * (b1 / 2), have = (size_t)s->shared->synth_const_vecs * 4, g = (size_t)b->fpw;
+      if (need_words > have) v = std::max(v, (need_words - have + 4 * g - 1) / (4 * g));
+    } else {
+      const size_t need_words = ch * (b1 / 2) + b1 / 16, have = (size_t)s->shared->synth_const_vecs * 4;
+      if (need_words > have) v = std::max(v, (need_words - have + 3) / 4);
+    }
   }
   return (v + 3) & ~(size_t)3;
 }
@@ -571,6 +609,14 @@ static size_t slab_lds_vecs(const nvh_batch* b) {
 static size_t slab_lds_bytes(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   const size_t ch = (size_t)s->setup.channels, b1 = (size_t)s->setup.block1;
+  if (slab_groups(b)) {
+    // kernels_synth.hip, frame groups: the larger of the walk's map (constants | fpw slab areas | fpw x spectra) and the transforms'
+    // (staged quarters | fpw x channels slices), + the overlaps' parameter table
+    const size_t g = (size_t)b->fpw;
+    const size_t walk = (size_t)s->shared->synth_const_vecs * 4 + g * (slab_lds_vecs(b) * 4 + ch * (b1 / 2));
+    const size_t xform = ch * (b1 / 2) + g * ch * (b1 / 2 + b1 / 16);
+    return (std::max(walk, xform) + 8 * (g + 1)) * sizeof(float);
+  }
   size_t words = (size_t)s->shared->synth_const_vecs * 4 + slab_lds_vecs(b) * 4 + ch * (b1 / 2) + b1 / 16;
   if (slab_wide(s)) words = std::max(words, ch * (b1 / 2 + b1 / 16));
   if (b1 > 4096) words += ch * (b1 / 2 + b1 / 16);  // n = 8192: the transforms' slices lie behind the spectra, not over them
@@ -593,7 +639,7 @@ static bool slab_shape_ok(const nvh_batch* b) {
 static bool slab_size_ok(const nvh_batch* b) {
   const nvh_stream* s = b->s;
   if (slab_bound_vecs(b) > 0xFFFFu) return false;
-  return slab_lds_bytes(b) + (size_t)nvh_toggles().lds_pad <= (slab_wide(s) ? (size_t)160 * 1024 - 1024 : (size_t)64 * 1024);
+  return slab_lds_bytes(b) + (size_t)nvh_toggles().lds_pad <= ((slab_wide(s) || slab_groups(b)) ? (size_t)160 * 1024 - 1024 : (size_t)64 * 1024);
 }
 
 static bool slab_path(const nvh_batch* b) { return slab_shape_ok(b) && slab_size_ok(b); }
@@ -651,6 +697,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     A.channels = ch;
     A.block1 = s->setup.block1;
     A.f0 = 0; A.fstep = 1;
+    A.nframes = b->nframes;
     A.prefetch_prev = 0;
     A.xcd_map = 0;
     const bool wide = slab_wide(s);
@@ -687,7 +734,35 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     else if (wide) hipLaunchKernelGGL(k_synth8, dim3((unsigned)b->nframes), dim3(512), synth_lds, st, A NVH_DBG_LAUNCH);
     else if (narrow_general) hipLaunchKernelGGL(k_synth_g, dim3((unsigned)b->nframes), dim3(256), synth_lds, st, A NVH_DBG_LAUNCH);
     else if (!emitted) hipLaunchKernelGGL(k_synth, dim3((unsigned)b->nframes), dim3(NVH_SYNTH_NT), synth_lds, st, A NVH_DBG_LAUNCH);
-    else {
+    else if (b->fpw > 1) {
+      // frame groups (kernels_synth.hip): fpw consecutive frames per workgroup, the overlaps inside a group on chip.  The groups
+      // with an odd index first (they leave their outer quarters in the planes), then the even ones, which emit the overlaps
+      // between groups as well.
+      const int gw = b->fpw, ngroups = (b->nframes + gw - 1) / gw;
+      if (synth_lds > 64 * 1024 && !s->ctx->group_lds_attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_synth_group2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_synth_group4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        s->ctx->group_lds_attr_set = true;
+      }
+      auto kern = gw == 2 ? k_synth_group2 : k_synth_group4;
+      const unsigned nt = gw == 2 ? 256u : 512u;
+      if (T.debug_occ) {
+        int nb = -1;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, (int)nt, synth_lds);
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, (const void*)kern);
+        fprintf(stderr, "frame groups of %d: %u threads, lds %zu B (constants %d, slab area %d, largest slab %d vecs), occupancy %d WG/CU (err %d), regs %d\n",
+                gw, nt, synth_lds, A.const_vecs, A.lds_vecs, A.cap_vecs, nb, (int)oe, fa.numRegs);
+      }
+      A.fstep = 2 * gw;
+      A.f0 = gw;
+      static const bool group_prefetch = std::getenv("NVH_GROUP_PREFETCH") != nullptr;  // (measured: 181.6 with, 184.5 M frames/s without)
+      A.prefetch_prev = group_prefetch ? 1 : 0;
+      if (ngroups / 2 > 0) hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups / 2)), dim3(nt), synth_lds, st, A NVH_DBG_LAUNCH);
+      A.f0 = 0;
+      A.prefetch_prev = 0;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((ngroups + 1) / 2)), dim3(nt), synth_lds, st, A NVH_DBG_LAUNCH);
+    } else {
       // odd frames first (their planes are what the even frames overlap-add with), then the even frames, which emit
       // (the odd frames never emit: the plain kernel, or the one that can write the carried tail when the last decoded block is odd)
       A.fstep = 2;
@@ -704,7 +779,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       A.prefetch_prev = 0;
       hipLaunchKernelGGL(k_synth_emit, dim3((unsigned)((b->nframes + 1) / 2)), dim3(NVH_SYNTH_NT), synth_lds, st, A NVH_DBG_LAUNCH);
     }
-    if (emitted) b->slot_name[1] = wide ? "k_synth8+k_synth8_emit" : "k_synth+k_synth_emit";  // odd frames, then the emitting even frames
+    if (emitted) b->slot_name[1] = wide ? "k_synth8+k_synth8_emit" : (b->fpw == 2 ? "k_synth_group2" : b->fpw == 4 ? "k_synth_group4" : "k_synth+k_synth_emit");  // odd frames, then the emitting even frames
     slab_done = true;
     fuse_gen8 = true;  // the inverse MDCT is inside: no transform kernel behind it
   }
