@@ -42,7 +42,8 @@ import argparse
 import datetime
 import json
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd/__init__.py says why)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd.configure_process says why)
+os.environ.setdefault("NVH_CORPUS_MALLOPT", "1")  # this process is a corpus job: the allocator settings of nvorbis_amd.corpus._tune_malloc (opt-in)
 import sys
 import time
 
@@ -361,60 +362,134 @@ def c5_block(nv, torch, dist, rank, world, local_rank, scale, workers, share_gpu
     """BASELINE.json configs[4] inside the bench line: the 1004-file corpus (tests/c5_corpus.py, length scale `scale`) sharded
     file-parallel over the ranks (LPT by compressed size, no data-path collective), decoded by every rank into one device arena
     with the GPU packet parser, then the north star's ONE collective: the gather of the PCM to rank 0, device to device
-    (nvorbis_amd.corpus.gather_pcm: all_gather of the counts + grouped point-to-point payloads over RCCL / xGMI).  Rank 0 checks
-    every file's PCM against the oracle's committed SHA-256 (tests/golden/c5_digests_scale*.json) outside the timed regions."""
+    (nvorbis_amd.corpus.gather_pcm: all_gather of the counts + grouped point-to-point payloads over RCCL / xGMI).
+
+    Outside the timed regions, and sized so that eight ranks on one host stay cheap: the shard plan comes from the compressed
+    sizes in the committed digest file (`ogg_bytes`), so a rank BUILDS ONLY ITS OWN SHARD (child interpreters, no GPU); every
+    rank checks its own files -- the .ogg bytes and the SHA-256 of the PCM against the oracle's committed digests
+    (tests/golden/c5_digests_scale*.json), hashed by a few threads out of page-locked staging buffers -- BEFORE the gather; and
+    the gather itself is checked on the device: two 64-bit word sums per file, taken by the owner before and by the root after
+    (a checksum of checksums: the root never copies 21.6 GB to the host to hash it on one core)."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     from nvorbis_amd import corpus
     from tests import c5_corpus
+    t_setup = time.perf_counter()
     dig = c5_corpus.load_digests(scale)
-    files = c5_corpus.build_files(scale)
-    shards = corpus.lpt_shards([len(f) for f in files], world)
-    mine = shards[rank]
+    nfiles = c5_corpus.n_files()
+    cpus = len(os.sched_getaffinity(0))
+    if dig is not None and "ogg_bytes" in dig:
+        sizes = [int(x) for x in dig["ogg_bytes"]]
+        shards = corpus.lpt_shards(sizes, world)
+        mine = shards[rank]
+        per_rank = max(1, cpus // (world if (world > 1 and cpus >= 2 * world) else 1))
+        built = c5_corpus.build_subset(mine, scale, procs=min(8, per_rank))
+    else:  # no committed sizes for this scale: every rank builds the list to learn them
+        every = c5_corpus.build_files(scale)
+        sizes = [len(f) for f in every]
+        shards = corpus.lpt_shards(sizes, world)
+        mine = shards[rank]
+        built = {i: every[i] for i in mine}
+        del every
+    my_files = [built[i] for i in mine]
+    input_ok = all(len(f) == sizes[i] for f, i in zip(my_files, mine))
+    setup_s = time.perf_counter() - t_setup
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def max_over_ranks(x):
+    def over_ranks(x, op):
         if dist is None:
             return x
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
         return float(t.item())
+
+    def word_sums(tensors):
+        """[n, 2] int64 on the device: the sum of a file's 32-bit words and of its even-indexed words (wrapping)."""
+        out = torch.zeros((len(tensors), 2), dtype=torch.int64, device=dev)
+        for k, v in enumerate(tensors):
+            if v.numel():
+                w = v.reshape(-1).view(torch.int32)
+                out[k, 0] = w.sum(dtype=torch.int64)
+                out[k, 1] = w[::2].sum(dtype=torch.int64)
+        return out
 
     dev = "cuda:%d" % local_rank
     barrier()
     t0 = time.perf_counter()
     passes = {}
-    arena, views = corpus.decode_files_to_device([files[i] for i in mine], device=local_rank, workers=workers, gpu_parse=True, timings=passes)
+    arena, views = corpus.decode_files_to_device(my_files, device=local_rank, workers=workers, gpu_parse=True, timings=passes)
     torch.cuda.synchronize()
-    decode_s = max_over_ranks(time.perf_counter() - t0)
+    decode_mine = time.perf_counter() - t0
+    decode_s, decode_min = over_ranks(decode_mine, "MAX"), over_ranks(decode_mine, "MIN")
+    index_max = over_ranks(float(passes.get("index_s", 0.0)), "MAX")
     local_map = {i: v for i, v in zip(mine, views)}
+
+    # ---- this rank's files against the oracle's digests (untimed) ----
+    t_chk = time.perf_counter()
+    ok_mine, checked_mine = 1.0, 0
+    if dig is not None:
+        rows = dig["digests"]
+        nthr = max(1, min(8, cpus))
+        longest = max([int(v.numel()) for v in views] + [1])
+        stage = [torch.empty(longest, dtype=torch.float32).pin_memory() for _ in range(nthr)]
+        free = list(range(nthr))
+
+        def check(k):
+            i, v = mine[k], views[k]
+            want = rows[i]
+            if c5_corpus.file_digest(my_files[k]) != want[0] or int(v.numel()) != want[1]:
+                return False
+            slot = free.pop()
+            try:
+                h = stage[slot][:v.numel()]
+                h.copy_(v)
+                return hashlib.sha256(h.numpy().view("uint8").data).hexdigest() == want[2]
+            finally:
+                free.append(slot)
+
+        with ThreadPoolExecutor(nthr) as ex:
+            res = list(ex.map(check, range(len(mine))))
+        ok_mine, checked_mine = float(all(res)), len(res)
+        del stage
+    sums_mine = word_sums(views)
+    check_s = time.perf_counter() - t_chk
+    sha_ok = over_ranks(ok_mine, "MIN") == 1.0 if dig is not None else None
+    checked = int(over_ranks(float(checked_mine), "SUM"))
+    inputs_ok = over_ranks(float(input_ok), "MIN") == 1.0
+    # every file's two sums as its owner saw them
+    table = torch.zeros((nfiles, 2), dtype=torch.int64, device=dev)
+    if mine:
+        table[torch.tensor(mine, device=dev)] = sums_mine
+    if dist is not None:
+        dist.all_reduce(table)
+
     barrier()
     t1 = time.perf_counter()
-    out = corpus.gather_pcm(local_map, len(files), rank, world, dist, dev, to_host=False)  # stays in HBM
+    out = corpus.gather_pcm(local_map, nfiles, rank, world, dist, dev, to_host=False)  # stays in HBM
     torch.cuda.synchronize()
-    gather_s = max_over_ranks(time.perf_counter() - t1)
+    gather_s = over_ranks(time.perf_counter() - t1, "MAX")
     block = None
     if rank == 0:
         floats = sum(int(o.numel()) for o in out)
         remote = floats - sum(int(v.numel()) for v in views)  # what crossed a link
-        ok, checked = None, 0
-        if dig is not None:
-            ok = True
-            for i, o in enumerate(out):
-                want = dig["digests"][i]
-                if c5_corpus.file_digest(files[i]) != want[0] or int(o.numel()) != want[1] or c5_corpus.pcm_digest(o.cpu().numpy()) != want[2]:
-                    ok = False
-                checked += 1
+        gathered_ok = bool(torch.equal(word_sums(out), table)) and (dig is None or [int(o.numel()) for o in out] == [r[1] for r in dig["digests"]])
         block = {"what": "C5: %d-file corpus at length scale %g, LPT shard over %d rank(s), GPU packet parser, one device arena per rank, "
-                         "then the gather of all PCM to rank 0 (device to device)" % (len(files), scale, world),
-                 "files": len(files), "scale": scale, "workers_per_rank": workers,
-                 "decode_s": decode_s, "decode_passes_rank0": passes, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "gather_s": gather_s, "pcm_bytes": floats * 4, "gathered_bytes_over_links": remote * 4,
+                         "then the gather of all PCM to rank 0 (device to device)" % (nfiles, scale, world),
+                 "files": nfiles, "scale": scale, "workers_per_rank": workers,
+                 "decode_s": decode_s, "decode_s_min_rank": decode_min, "index_s_max_rank": index_max, "decode_passes_rank0": passes,
+                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "gather_s": gather_s, "pcm_bytes": floats * 4, "gathered_bytes_over_links": remote * 4,
                  "gather_GBps": (remote * 4 / gather_s / 1e9) if (world > 1 and gather_s > 0) else None,
                  "gather_bound": "each sender's one direct xGMI link to the root, ~153 GB/s; the root receives from all of them at once",
                  "long_frame_equivalents_per_s": floats / 2 / 1024 / (decode_s + gather_s),
-                 "pcm_sha256_ok": ok, "files_checked": checked,
+                 "pcm_sha256_ok": (sha_ok and inputs_ok and gathered_ok) if dig is not None else None, "files_checked": checked,
+                 "check": {"per_rank_sha256_ok": sha_ok, "inputs_ok": inputs_ok, "gathered_word_sums_ok": gathered_ok,
+                           "how": "every rank: SHA-256 of its own files' PCM against the committed oracle digests before the gather; "
+                                  "root: two 64-bit word sums per gathered file against the owner's, on the device"},
+                 "untimed_rank0": {"setup_s": setup_s, "check_s": check_s, "files_built": len(mine)},
                  "digests": os.path.relpath(c5_corpus.digest_path(scale), ROOT) if dig is not None else None,
                  "note": ("NVH_BENCH_SHARE_GPU: every rank on ONE GPU over gloo -- a code-path check, not a transfer rate" if share_gpu else None)}
     del out, views, arena

@@ -316,6 +316,18 @@ int nvh_ogg_demux_stream(const uint8_t *bytes, size_t len, int stream_index, uin
                          int64_t *offsets, int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets,
                          int64_t *total_bytes, int *nstreams);
 
+/* The index form of nvh_ogg_demux_stream, for a pass that only asks what the stream decodes to (a corpus transcoder sizing its
+ * output before the first kernel runs): the same page walk and packet rules (Ogg/PageReaderBase.cs:227-292 header + lacing
+ * values, Ogg/PacketProvider.cs:324-438) WITHOUT the page checksums and without the packets' bodies.  The first three packets
+ * (the Vorbis headers) are delivered whole, every other packet as its first (up to) 8 bytes -- packet type, mode number and window
+ * flags, all nvh_stream_index_packets reads, are in the first two; *payload_bytes = the bytes the packets really have.  One call,
+ * caller's buffers (pkt_bytes_cap >= len and pkt_cap >= len / 27 + 8 always suffice); NVH_ERR_ARGUMENT when they are too small.
+ * A damaged page passes unnoticed here: the pass that decodes the file demultiplexes it with the checksums and compares the
+ * packet count and the payload size with this call's (a refused page changes both). */
+int nvh_ogg_index_packets(const uint8_t *bytes, size_t len, int stream_index, uint8_t *pkt_bytes, int64_t pkt_bytes_cap,
+                          int64_t *offsets, int64_t *granules, uint8_t *flags, int pkt_cap, int *npackets,
+                          int64_t *total_bytes, int64_t *payload_bytes, int *nstreams);
+
 /* The packet list of a source that cannot seek: ForwardOnlyPageReader + ForwardOnlyPacketProvider
  * (Ogg/ForwardOnlyPageReader.cs:21-52, Ogg/ForwardOnlyPacketProvider.cs:36-67, 119-290), same calling convention.  It differs from
  * the seekable reader's list in the resync marks (the first page always carries one, sequence numbers are checked without the

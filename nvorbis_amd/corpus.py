@@ -214,10 +214,15 @@ def _tune_malloc():
     buffers of the size of a file per file on every thread; with the allocator's defaults each of them is an mmap, a page fault
     per 4 KB and a munmap under the process's one address-space lock -- until the allocator has raised its own threshold, which
     takes a job: the first index pass of a process took twice (16 CPUs) to four times (8 CPUs) as long as the following ones.
-    NVH_CORPUS_NO_MALLOPT=1 leaves the allocator alone."""
+    PROCESS-WIDE state (freed heap is no longer returned to the operating system), therefore OPT-IN: decode_files_to_device(...,
+    tune_process=True) or NVH_CORPUS_MALLOPT=1 (bench.py and the corpus tools ask for it); it is logged once on stderr.
+    NVH_CORPUS_NO_MALLOPT=1 leaves the allocator alone whoever asks."""
     if _MALLOC_TUNED[0] or os.environ.get("NVH_CORPUS_NO_MALLOPT"):
         return
     _MALLOC_TUNED[0] = True
+    import sys
+    sys.stderr.write("nvorbis_amd.corpus: glibc allocator tuned for this process (mallopt: M_MMAP_THRESHOLD 1 GiB, M_TRIM_THRESHOLD 2 GiB, "
+                     "M_TOP_PAD 256 MiB) -- asked for by tune_process / NVH_CORPUS_MALLOPT=1\n")
     try:
         import ctypes
         libc = ctypes.CDLL("libc.so.6")
@@ -233,9 +238,15 @@ _CLOSERS = []  # threads that are closing the contexts of finished jobs
 
 
 def wait_contexts_closed():
-    """Block until the worker contexts of finished jobs have been released (they are closed behind the job's return)."""
+    """Block until the worker contexts of finished jobs have been released (they are closed behind the job's return).  Called at
+    the start of the next job (its early arena is sized from the device memory that is free) and at interpreter exit (a closer
+    still inside hipFree / hipHostFree must not race the runtime's teardown)."""
     while _CLOSERS:
         _CLOSERS.pop().join()
+
+
+import atexit as _atexit  # noqa: E402
+_atexit.register(wait_contexts_closed)
 
 
 def close_worker_contexts():
@@ -426,39 +437,57 @@ def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, 
 
         th = threading.Thread(target=close_all, args=(done_with,), daemon=True)
         th.start()
+        _CLOSERS[:] = [t for t in _CLOSERS if t.is_alive()]  # (finished closers do not pile up)
         _CLOSERS.append(th)
     return errors
 
 
-def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False, keep_contexts=False, timings=None):
+def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False, keep_contexts=False, timings=None, tune_process=False):
     """Decode .ogg byte strings on ONE GPU into ONE device arena: returns (arena, views) with views[i] the interleaved
     float32 PCM of files[i] as a slice of `arena` (torch tensors on cuda:<device>), files back to back in list order.
 
     Two passes over the worker pool: a geometry-only index of every stream (nvh_stream_index_packets: packet type, mode
     number, window flags -- how many samples the serial decoder emits), which sizes the arena; then the decode, whose
     overlap-add kernels write each batch's PCM at its final address (nvh_stream_synth with a device destination).  No
-    PCM crosses PCIe."""
+    PCM crosses PCIe.  tune_process: see _tune_malloc (process-wide, opt-in)."""
     import torch
 
-    from .reader import Stream, demux_ogg_array
+    from .reader import Context, Stream, demux_ogg_array, index_ogg_array
     n = len(files)
-    arrays = [None] * n
+    shape = [None] * n  # what the index saw of file i: (packets, payload bytes) -- the decode pass's full demultiplex must agree
     totals = [0] * n
     chans = [1] * n
+    full_index = bool(os.environ.get("NVH_CORPUS_FULL_INDEX"))  # A/B aid: the round-5 index (checksums + a copy of every packet)
 
     def index_one(i, ctx):
+        # Lacing-only index (reader.index_ogg_array / nvh_ogg_index_packets): page headers and lacing values give the packet list,
+        # one byte per packet its block size, the page granule positions the length -- no checksum, no copy of the packets (1 % of the
+        # file is read instead of all of it twice).  The checksums are the decode pass's, where the packets are needed anyway.
+        def measure(pa):
+            st = Stream(None, pa[0], pa[1], pa[2])
+            try:
+                totals[i] = int(st.index_packets(pa, 3)[3]) * st.channels
+                chans[i] = st.channels
+            finally:
+                st.close()
+
+        if not full_index:
+            try:
+                pa, payload = index_ogg_array(files[i])
+                measure(pa)
+                shape[i] = (len(pa), payload)
+                return
+            except Exception:
+                pass  # (a damaged header page, say: the checked demultiplex decides what the file is)
         pa = demux_ogg_array(files[i])
-        st = Stream(None, pa[0], pa[1], pa[2])
-        try:
-            totals[i] = int(st.index_packets(pa, 3)[3]) * st.channels
-            chans[i] = st.channels
-        finally:
-            st.close()
-        arrays[i] = pa
+        measure(pa)
+        shape[i] = (len(pa), int(pa.offsets[-1]))
 
     import os
     import time
-    _tune_malloc()
+    if tune_process or os.environ.get("NVH_CORPUS_MALLOPT"):  # process-wide allocator settings: opt-in (see _tune_malloc)
+        _tune_malloc()
+    wait_contexts_closed()  # the job before gives its workers' device / page-locked pools back first
     timing = bool(os.environ.get("NVH_CORPUS_TIMING"))
     if os.environ.get("NVH_CORPUS_BATCH"):  # A/B aid: packets per parse / synthesis batch
         batch_frames = int(os.environ["NVH_CORPUS_BATCH"])
@@ -484,20 +513,32 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
     t_index = time.perf_counter()
     offs = np.zeros(n + 1, np.int64)
     offs[1:] = np.cumsum(totals)
-    if arena_box[0] is not None and int(offs[-1]) >= 1 and int(arena_box[0].numel()) >= int(offs[-1]):
-        arena = arena_box[0][:int(offs[-1])]  # allocated during the index pass from an upper bound; the unused tail is < 1 %
+    total = int(offs[-1])
+    if arena_box[0] is not None and total >= 1 and total <= int(arena_box[0].numel()) <= total + max(total // 50, 1 << 20):
+        # allocated during the index pass from an upper bound (two maximal blocks per file beyond its last granule position): taken
+        # when at most 2 % (or 4 MB) of it stays unused -- the slice pins the whole block for the arena's lifetime
+        arena = arena_box[0][:total]
     else:
-        arena_box[0] = None
-        arena = torch.empty(max(int(offs[-1]), 1), dtype=torch.float32, device="cuda:%d" % device)
+        # short files (a 1-second stereo file's bound is ~37 % above its length), chained or damaged ones: the exact size, and the
+        # early block goes back to the device first so that both do not sit in torch's cache next to the library's own pools
+        if arena_box[0] is not None:
+            arena_box[0] = None
+            torch.cuda.empty_cache()
+        arena = torch.empty(max(total, 1), dtype=torch.float32, device="cuda:%d" % device)
     torch.cuda.synchronize(device)
     base = arena.data_ptr()
     order = sorted(range(n), key=lambda i: (-len(files[i]), i))  # longest first: shorter tail
 
     phase = {"open": 0.0, "synth": 0.0, "push": 0.0, "close": 0.0}  # NVH_CORPUS_TIMING: seconds summed over the workers
 
+    redo = []  # files whose checked demultiplex disagrees with the index (a damaged page): decoded again below, the slow way
+
     def decode_one(k, ctx):
         i = order[k]
-        pa = arrays[i]
+        pa = demux_ogg_array(files[i])  # with the page checksums
+        if shape[i] != (len(pa), int(pa.offsets[-1])):
+            redo.append(i)
+            return
         t0 = time.perf_counter()
         st = Stream(ctx, pa[0], pa[1], pa[2])
         try:
@@ -550,6 +591,44 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
                          "push (+ upload and parse on the GPU in GPU-parse mode) %.3f s, synthesis %.3f s, close %.3f s\n" % (
                              t_warm - t_alloc, phase["open"], phase["push"], phase["synth"], phase["close"]))
     views = [arena[int(offs[i]):int(offs[i + 1])] for i in range(n)]
+    if redo:
+        # A page the index took at its word failed its checksum: the reference's reader drops it and resynchronises, the file's
+        # packet list -- and with it its length -- is another.  Such a file gets a tensor of its own (views[i] is then not a slice
+        # of the arena; the gather copes), decoded from the checked packet list.
+        ctx = Context(device)
+        try:
+            for i in sorted(redo):
+                pa = demux_ogg_array(files[i])
+                st = Stream(None, pa[0], pa[1], pa[2])
+                try:
+                    tot = int(st.index_packets(pa, 3)[3]) * st.channels
+                finally:
+                    st.close()
+                own = torch.empty(max(tot, 1), dtype=torch.float32, device="cuda:%d" % device)
+                torch.cuda.synchronize(device)
+                st = Stream(ctx, pa[0], pa[1], pa[2])
+                try:
+                    if gpu_parse:
+                        try:
+                            st.set_gpu_parse(True)
+                        except Exception:
+                            pass
+                    pos = [0]
+
+                    def sink(s_):
+                        pos[0] += s_.synth_device(own.data_ptr() + 4 * pos[0], tot - pos[0])
+
+                    _decode_file_packets(st, pa, batch_frames, sink)
+                    if pos[0] != tot:
+                        raise RuntimeError("file %d produced %d floats, its checked index says %d" % (i, pos[0], tot))
+                finally:
+                    st.close()
+                ctx.synchronize()
+                views[i] = own[:tot]
+        finally:
+            ctx.close()
+        if timings is not None:
+            timings["files_reindexed"] = sorted(redo)
     return arena, views
 
 

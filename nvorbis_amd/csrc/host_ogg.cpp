@@ -79,7 +79,7 @@ bool page_crc_ok(const uint8_t* pg, size_t total) {
 }  // namespace
 
 
-int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index, int* nstreams, bool want_pages) {
+int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index, int* nstreams, bool want_pages, OggIndexMode* index_mode) {
   // Logical streams in the order their first page appears (Ogg/PageReader.cs:126-158): a page with a serial number that
   // has no reader opens a new stream (multiplexed streams interleave their pages, chained streams follow one another);
   // the end-of-stream page retires the serial, so a later page with the same number starts another stream; a page
@@ -117,7 +117,7 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
     size_t data_len = 0;
     for (int s = 0; s < seg_cnt; s++) data_len += h[27 + s];
     size_t total = 27 + (size_t)seg_cnt + data_len;
-    if (pos + total > len || !page_crc_ok(h, total)) {
+    if (pos + total > len || (!index_mode && !page_crc_ok(h, total))) {
       ++pos;
       resync = true;
       continue;
@@ -245,6 +245,17 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
   out.flags.clear();
   const int npages = (int)pages.size();
   int page_index = 0, packet_index = 0;
+  int64_t payload = 0;
+  // a fragment of the packet that is being assembled (index form: only up to head_bytes of it are kept, behind the headers)
+  size_t mark = 0;
+  auto append = [&](const uint8_t* p, size_t n) {
+    payload += (int64_t)n;
+    if (index_mode && (int)out.granule.size() >= index_mode->full_first) {
+      const size_t have = out.bytes.size() - mark, cap = (size_t)index_mode->head_bytes;
+      n = have >= cap ? 0 : (n < cap - have ? n : cap - have);
+    }
+    out.bytes.insert(out.bytes.end(), p, p + n);
+  };
   while (page_index < npages) {
     const Page& pg = pages[(size_t)page_index];
     int64_t granule_pos = pg.granule;
@@ -252,9 +263,9 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
     int packet_count = (int)pg.pk_off.size();
     bool is_last_packet;
     int final_page = page_index;
-    size_t mark = out.bytes.size();
-    out.bytes.insert(out.bytes.end(), bytes + pg.data_off + pg.pk_off[(size_t)packet_index],
-                     bytes + pg.data_off + pg.pk_off[(size_t)packet_index] + pg.pk_len[(size_t)packet_index]);
+    mark = out.bytes.size();
+    const int64_t payload_mark = payload;
+    append(bytes + pg.data_off + pg.pk_off[(size_t)packet_index], (size_t)pg.pk_len[(size_t)packet_index]);
     if (is_continued && packet_index == packet_count - 1) {
       int cont = page_index;
       bool truncated = false;
@@ -271,10 +282,11 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
         packet_count = (int)np.pk_off.size();
         if (!is_continuation || is_resync) break;
         if (is_continued && packet_count > 1) is_continued = false;
-        out.bytes.insert(out.bytes.end(), bytes + np.data_off + np.pk_off[0], bytes + np.data_off + np.pk_off[0] + np.pk_len[0]);
+        append(bytes + np.data_off + np.pk_off[0], (size_t)np.pk_len[0]);
       }
       if (truncated) {
         out.bytes.resize(mark);
+        payload = payload_mark;
         break;
       }
       is_last_packet = packet_count == 1;
@@ -305,6 +317,7 @@ int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_inde
     }
   }
   out.offs.push_back((int64_t)out.bytes.size());
+  if (index_mode) index_mode->payload_bytes = payload;
   return NVH_OK;
 }
 

@@ -31,8 +31,21 @@ struct OggPackets {
   int64_t max_granule = 0;        // StreamPageReader._maxGranulePos
 };
 
+// The index form of ogg_demux: the same page walk and packet rules without the page checksums and without the packets' bodies --
+// what a pass needs that only asks how many samples the stream decodes to (page headers + lacing values are ~1 % of a file).
+// The first `full_first` packets (the Vorbis headers) are delivered whole, every other packet as its first `head_bytes` bytes
+// (the packet type, mode number and window flags are in the first two); payload_bytes = the bytes the packets really have.
+// A damaged page passes unnoticed here: whoever decodes the file demultiplexes it with the checksums and compares the packet
+// count and payload_bytes (a refused page changes both).
+struct OggIndexMode {
+  int head_bytes = 8;
+  int full_first = 3;
+  int64_t payload_bytes = 0;  // out
+};
+
 // Packets of logical stream `stream_index` (0 = the first one whose page appears); *nstreams = how many there are.
-int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index = 0, int* nstreams = nullptr, bool want_pages = false);
+int ogg_demux(const uint8_t* bytes, size_t len, OggPackets& out, int stream_index = 0, int* nstreams = nullptr, bool want_pages = false,
+              OggIndexMode* index_mode = nullptr);
 
 // The same for a source that cannot seek: ForwardOnlyPageReader + ForwardOnlyPacketProvider (Ogg/ForwardOnlyPageReader.cs,
 // Ogg/ForwardOnlyPacketProvider.cs:36-67, 119-290); the differences are listed in host_ogg.cpp.  A granule position of -1 in

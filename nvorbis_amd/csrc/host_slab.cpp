@@ -209,6 +209,12 @@ void classify_residues(const Setup& S, SlabSetup& X, bool no_pair) {
       }
   }
   if (X.pool_words > (size_t)NVH_SLAB_MAX_LAT_OFF) X.digits_ok = false;  // a record addresses the pools with 12 bits of words
+  if (!X.digits_ok) {
+    // No slab of this setup takes the digit form: the value pool is not part of the kernels' constants block (it would be
+    // staged into LDS by every workgroup for nothing and count against the LDS limit of slab_size_ok).
+    X.val_pool.clear();
+    X.pool_words = X.lattice.size();
+  }
 }
 
 bool residue_general_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
@@ -650,12 +656,15 @@ int build_slabs(const Setup& S, const SlabSetup& X, const FrameBatch& P, SlabBat
       H.chan[2] = fr.window_off;
     }
     if (nch <= 2 && (fr.emit_flags & NVH_EMIT_SELF_CARRY)) H.exec_mask |= NVH_SLABX_SELF_CARRY;
-    if (nch <= 2 && (fr.emit_flags & (NVH_EMIT_SELF | NVH_EMIT_NEXT))) {
+    if (nch <= 2 && (fr.emit_flags & NVH_EMIT_DONE)) H.exec_mask |= NVH_SLABX_DONE;
+    if (nch <= 2 && (fr.emit_flags & (NVH_EMIT_SELF | NVH_EMIT_NEXT | NVH_EMIT_DONE))) {
       H.chan[2] = fr.window_off; H.chan[3] = fr.ov_window_off; H.chan[6] = (uint32_t)fr.out_pos;
+      const bool nxt = (fr.emit_flags & NVH_EMIT_NEXT) && f + 1 < nf;
+      H.chan[5] = NVH_SLAB_GEO(fr.ov_n, nxt ? P.frames[f + 1].n : 0, fr.start, fr.valid);
       if (fr.emit_flags & NVH_EMIT_SELF) H.flags |= NVH_SLAB_EMIT_SELF;
-      if ((fr.emit_flags & NVH_EMIT_NEXT) && f + 1 < nf) {
+      if (nxt) {
         const NvhFrame& nx = P.frames[f + 1];
-        H.chan[4] = nx.window_off; H.chan[5] = nx.ov_window_off; H.chan[7] = (uint32_t)nx.out_pos;
+        H.chan[4] = nx.window_off; H.chan[7] = (uint32_t)nx.out_pos;
         H.flags |= NVH_SLAB_EMIT_NEXT;
       }
     }

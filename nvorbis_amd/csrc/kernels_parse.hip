@@ -1089,7 +1089,7 @@ k_parse_links(int nframes, int channels, NvhFrame* __restrict__ frames, NvhChan*
   }
   // slab mode, mono / stereo: what k_synth_emit needs to know about the overlaps this frame emits goes into its slab's header
   // (k_parse left those fields clear; host_slab.cpp writes the same for host-parsed batches)
-  if (slabs && channels <= 2 && fr.n != 0 && (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT | NVH_EMIT_CARRY_OUT))) {
+  if (slabs && channels <= 2 && fr.n != 0 && (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT | NVH_EMIT_CARRY_OUT | NVH_EMIT_DONE))) {
     uint32_t* H = reinterpret_cast<uint32_t*>(slabs + (long long)f * stride_vecs);
     uint32_t w0 = H[0];
     if (ef & NVH_EMIT_CARRY_OUT) {
@@ -1097,12 +1097,15 @@ k_parse_links(int nframes, int channels, NvhFrame* __restrict__ frames, NvhChan*
       H[8 + 2] = fr.window_off;
     }
     if (ef & NVH_EMIT_SELF_CARRY) w0 |= (uint32_t)NVH_SLABX_SELF_CARRY << 16;
-    if (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT)) {
+    if (ef & NVH_EMIT_DONE) w0 |= (uint32_t)NVH_SLABX_DONE << 16;
+    if (ef & (NVH_EMIT_SELF | NVH_EMIT_NEXT | NVH_EMIT_DONE)) {
       H[8 + 2] = fr.window_off; H[8 + 3] = fr.ov_window_off; H[8 + 6] = (uint32_t)fr.out_pos;
+      const bool nxt = (ef & NVH_EMIT_NEXT) && f + 1 < nframes;
+      H[8 + 5] = NVH_SLAB_GEO(fr.ov_n, nxt ? frames[f + 1].n : 0, fr.start, fr.valid);
       if (ef & NVH_EMIT_SELF) w0 |= (uint32_t)NVH_SLAB_EMIT_SELF << 24;
-      if ((ef & NVH_EMIT_NEXT) && f + 1 < nframes) {
+      if (nxt) {
         const NvhFrame nx = frames[f + 1];
-        H[8 + 4] = nx.window_off; H[8 + 5] = nx.ov_window_off; H[8 + 7] = (uint32_t)nx.out_pos;
+        H[8 + 4] = nx.window_off; H[8 + 7] = (uint32_t)nx.out_pos;
         w0 |= (uint32_t)NVH_SLAB_EMIT_NEXT << 24;
       }
     }

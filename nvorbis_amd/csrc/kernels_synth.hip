@@ -611,7 +611,7 @@ __device__ __forceinline__ void synth_emit(const NvhSynthArgs& A, float* smem, f
 #define EM_T(k) do { if (stamps && tid == 0) stamps[k] = clock64(); } while (0)
   // parameters of the overlaps, out of the slab before the staging overwrites it
   const unsigned w_self = __builtin_amdgcn_readfirstlane(s_chan[2]), wp_self = __builtin_amdgcn_readfirstlane(s_chan[3]);
-  const unsigned w_next = __builtin_amdgcn_readfirstlane(s_chan[4]), wp_next = __builtin_amdgcn_readfirstlane(s_chan[5]);
+  const unsigned w_next = __builtin_amdgcn_readfirstlane(s_chan[4]), wp_next = w_self;  // (the next frame's overlap source is this frame)
   const unsigned out_self = __builtin_amdgcn_readfirstlane(s_chan[6]), out_next = __builtin_amdgcn_readfirstlane(s_chan[7]);
   __syncthreads();  // the chain walk is through everywhere: constants and slab are dead, the spectra complete (the transform
                     // below is in place over the wavefront's own channel and needs no workgroup barrier of its own)
@@ -1441,7 +1441,7 @@ __device__ __forceinline__ void synth_body(const NvhSynthArgs& A, float* smem NV
 //                registers in front of ONE LDS-only workgroup barrier (imdct_wave_sink<.., WGSYNC, .., LDSBAR>); the staging DMA,
 //                issued in front of it, lands below the spectra (the host sizes the slab areas for that) and is waited for behind the
 //                transforms
-//   behind both: 8 (FPW + 1) words, the overlaps' parameters.
+//   behind both: 8 (2 FPW + 1) words: the overlaps' parameters, and those of what each frame emits alone.
 // Against private pads around every frame's spectra: 28.1 -> 26.7 KB for C2's shape = six workgroups per CU instead of five.
 // (Tried and removed, round 6: two frames per workgroup of EIGHT wavefronts, every 256 threads walking their own frame side by side --
 // k_synth's per-frame parallelism, 4 workgroups = 32 wavefronts per CU at 64 VGPRs: 171 M frames/s over three streams against 202 M for
@@ -1529,21 +1529,42 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
 
   // ---- what this workgroup emits: overlap j = the PCM of the group's frame j (j = FPW: of the frame behind the group) ----
   const bool emit = A.pcm != nullptr;
-  bool self_k[FPW], next_k[FPW], cout_k[FPW];
+  bool self_k[FPW], next_k[FPW], cout_k[FPW], done_k[FPW];
   bool self_carry = false;
+  // geometry (NVH_SLAB_GEO): block sizes of the frame before and behind, this frame's start and valid
+  int gprev[FPW], gnext[FPW], gstart[FPW], gvalid[FPW];
 #pragma unroll
   for (int k = 0; k < FPW; ++k) {
     const unsigned flags = w0[k] >> 24, xm = (w0[k] >> 16) & 0xFFu;
     self_k[k] = emit && nn[k] != 0 && (flags & NVH_SLAB_EMIT_SELF);
     next_k[k] = emit && nn[k] != 0 && (flags & NVH_SLAB_EMIT_NEXT);
+    done_k[k] = emit && nn[k] != 0 && (xm & NVH_SLABX_DONE);
     cout_k[k] = A.carry_out != nullptr && nn[k] != 0 && (xm & NVH_SLABX_CARRY_OUT);
     if (k == 0) self_carry = self_k[0] && (xm & NVH_SLABX_SELF_CARRY);
+    const unsigned geo = (self_k[k] || next_k[k] || done_k[k]) ? hdr(k, 13) : 0u;
+    gprev[k] = (int)(geo & 0xFFu) << 6; gnext[k] = (int)((geo >> 8) & 0xFFu) << 6;
+    gstart[k] = (int)((geo >> 16) & 0xFFu) << 6; gvalid[k] = (int)(geo >> 24) << 6;
   }
   bool act[FPW + 1];
   act[0] = self_k[0] && !self_carry;
 #pragma unroll
-  for (int j = 1; j < FPW; ++j) act[j] = next_k[j - 1] && self_k[j] && nn[j - 1] == nn[j];
+  for (int j = 1; j < FPW; ++j) act[j] = next_k[j - 1] && self_k[j] && nn[j] == gnext[j - 1];
   act[FPW] = next_k[FPW - 1];
+  // overlap j spans mov[j] = min(block sizes) samples' worth of quarters: m / 4 values of each block (ola_sym on m)
+  int mov[FPW + 1];
+  mov[0] = nn[0] < gprev[0] ? nn[0] : gprev[0];
+#pragma unroll
+  for (int j = 1; j <= FPW; ++j) mov[j] = nn[j - 1] < gnext[j - 1] ? nn[j - 1] : gnext[j - 1];
+  // what a frame emits alone (the flat parts of a long window next to a short block): R1 = [start + m/2, n/2) out of its first
+  // quarter (mirrored, negated), R2 = [n/2, valid) out of its third quarter
+  int r1len[FPW], r2len[FPW];
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    const int mk = nn[k] < gprev[k] ? nn[k] : gprev[k];
+    r1len[k] = done_k[k] ? (nn[k] >> 1) - gstart[k] - (mk >> 1) : 0;
+    r2len[k] = done_k[k] ? gvalid[k] - (nn[k] >> 1) : 0;
+    if (r1len[k] < 0 || r2len[k] < 0 || r1len[k] > (nn[k] >> 2) || r2len[k] > (nn[k] >> 2)) __builtin_trap();  // host bug
+  }
   // The overlaps' parameters, out of the slabs before the staging overwrites them, into a table behind the spectra (one row of
   // eight words per overlap, written by lane j of the first wavefront, read by every task of the overlap: a broadcast read instead of
   // select chains over values that would stay live through the transforms): window, the earlier block's window, output position, block
@@ -1551,19 +1572,40 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
   // Overlap 0 takes the first frame's SELF fields (chan[2], [3], [6]), overlap j >= 1 frame j - 1's NEXT fields (chan[4], [5], [7]).
   const int S0 = (int)(slice0 - smem), SK = nch * slice_words;  // float offset of frame 0's slices from smem, slice words per frame
   if (tid <= FPW) {
+    // row j: window of the later block at its start, window of the earlier block at its valid, output position, m |
+    // float offset from smem and channel stride of the later block's quarter values (the last m/4 of its first quarter), of the
+    // earlier block's (the last m/4 of its third quarter)
     const int j = tid, kb = j == 0 ? 0 : j - 1;
     const uint32_t* H = reinterpret_cast<const uint32_t*>(slab0 + kb * slab_words);
     const int n = (int)(H[0] & 0xFFFFu);
+    const unsigned geo = H[13];
     uint4 r0, r1;
-    r0.x = H[j == 0 ? 10 : 12]; r0.y = H[j == 0 ? 11 : 13]; r0.z = H[j == 0 ? 14 : 15]; r0.w = (unsigned)n;
-    if (j == 0) { r1.x = (unsigned)S0; r1.y = (unsigned)slice_words; r1.z = 0u; r1.w = (unsigned)(n >> 2); }  // A(first) own, B(first - 1) staged
-    else {
-      r1.z = (unsigned)(S0 + kb * SK + (n >> 2)); r1.w = (unsigned)slice_words;
-      if (j < FPW) { r1.x = (unsigned)(S0 + j * SK); r1.y = (unsigned)slice_words; }
-      else { r1.x = (unsigned)(nch * (A.block1 >> 2)); r1.y = (unsigned)(n >> 2); }  // A(last + 1) staged
+    if (j == 0) {  // SELF of the first frame: A(first) own, B(first - 1) staged (m/4 values per channel)
+      const int pn = (int)(geo & 0xFFu) << 6, m = n < pn ? n : pn, start = (int)((geo >> 16) & 0xFFu) << 6;
+      r0.x = H[10] + (unsigned)start; r0.y = H[11] + (unsigned)(3 * (pn >> 2) - (m >> 2)); r0.z = H[14]; r0.w = (unsigned)m;
+      r1.x = (unsigned)(S0 + (n >> 2) - (m >> 2)); r1.y = (unsigned)slice_words; r1.z = 0u; r1.w = (unsigned)(m >> 2);
+    } else {       // NEXT of frame j - 1: B(j - 1) own; A(j) own, or A(last + 1) staged
+      const int cn = (int)((geo >> 8) & 0xFFu) << 6, m = n < cn ? n : cn;
+      r0.x = H[12] + (unsigned)((cn >> 2) - (m >> 2)); r0.y = H[10] + (unsigned)(3 * (n >> 2) - (m >> 2)); r0.z = H[15]; r0.w = (unsigned)m;
+      r1.z = (unsigned)(S0 + kb * SK + (n >> 1) - (m >> 2)); r1.w = (unsigned)slice_words;
+      if (j < FPW) { r1.x = (unsigned)(S0 + j * SK + (cn >> 2) - (m >> 2)); r1.y = (unsigned)slice_words; }
+      else { r1.x = (unsigned)(nch * (A.block1 >> 2)); r1.y = (unsigned)(m >> 2); }
     }
     reinterpret_cast<uint4*>(otab)[2 * j] = r0;
     reinterpret_cast<uint4*>(otab)[2 * j + 1] = r1;
+  } else if (tid <= 2 * FPW) {
+    // row FPW + 1 + k: what frame k emits alone -- window, output position, block size, float offset of its slices | first index of
+    // R1, samples of R1, of R2, the frame's start
+    const int k = tid - FPW - 1;
+    const uint32_t* H = reinterpret_cast<const uint32_t*>(slab0 + k * slab_words);
+    const int n = (int)(H[0] & 0xFFFFu);
+    const unsigned geo = H[13];
+    const int pn = (int)(geo & 0xFFu) << 6, m = n < pn ? n : pn, start = (int)((geo >> 16) & 0xFFu) << 6, valid = (int)(geo >> 24) << 6;
+    uint4 r0, r1;
+    r0.x = H[10]; r0.y = H[14]; r0.z = (unsigned)n; r0.w = (unsigned)(S0 + k * SK);
+    r1.x = (unsigned)(start + (m >> 1)); r1.y = (unsigned)((n >> 1) - start - (m >> 1)); r1.z = (unsigned)(valid - (n >> 1)); r1.w = (unsigned)start;
+    reinterpret_cast<uint4*>(otab)[2 * tid] = r0;
+    reinterpret_cast<uint4*>(otab)[2 * tid + 1] = r1;
   }
   unsigned cwin[FPW];  // a frame that writes the carried tail: its window (chan[2])
 #pragma unroll
@@ -1584,8 +1626,9 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
         }
       }
     };
-    if (act[0]) stage(A.work + (long long)(fa - 1) * nch * A.block1 + (nn[0] >> 1), nn[0], stageB);
-    if (act[FPW]) stage(A.work + (long long)(fa + FPW) * nch * A.block1, nn[FPW - 1], stageA);
+    // (the last m/4 values of B(first - 1), of A(last + 1): all an overlap of m/2 samples reads)
+    if (act[0]) stage(A.work + (long long)(fa - 1) * nch * A.block1 + 3 * (gprev[0] >> 2) - (mov[0] >> 2), mov[0], stageB);
+    if (act[FPW]) stage(A.work + (long long)(fa + FPW) * nch * A.block1 + (gnext[FPW - 1] >> 2) - (mov[FPW] >> 2), mov[FPW], stageA);
   }
 
   // ---- inverse MDCT (Mdct.cs:65-313): one wavefront per (frame, channel), the two independent quarters stay in registers; a
@@ -1601,9 +1644,10 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
       if (kk == k) {
         n = nn[kk]; mw0 = w0[kk];
         const bool a_here = kk == 0 ? self_k[0] : act[kk], b_here = kk == FPW - 1 ? next_k[FPW - 1] : act[kk + 1];
-        wrA = !a_here || cout_k[kk];
-        wrB = !b_here || cout_k[kk];
-        keep = a_here || b_here;
+        // (a frame k_ola_compact emits is read there quarter by quarter, whatever its neighbours do)
+        wrA = !a_here || cout_k[kk] || !done_k[kk];
+        wrB = !b_here || cout_k[kk] || !done_k[kk];
+        keep = a_here || b_here || done_k[kk];
       }
     const unsigned exec_mask = (mw0 >> 16) & 0xFFu, flags = mw0 >> 24;
     const int half = n >> 1;
@@ -1670,7 +1714,7 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
   int cnt[FPW + 2];
   cnt[0] = 0;
 #pragma unroll
-  for (int j = 0; j <= FPW; ++j) cnt[j + 1] = cnt[j] + (act[j] ? (nn[j < FPW ? j : FPW - 1] >> 4) : 0);
+  for (int j = 0; j <= FPW; ++j) cnt[j + 1] = cnt[j] + (act[j] ? (mov[j] >> 4) : 0);
   int clipped = 0;
   for (int t = tid; t < cnt[FPW + 1]; t += NT) {
     int j = 0;
@@ -1680,13 +1724,13 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
 #pragma unroll
     for (int jj = 1; jj <= FPW; ++jj) g = j == jj ? t - cnt[jj] : g;
     const uint4 r0 = reinterpret_cast<const uint4*>(otab)[2 * j], r1 = reinterpret_cast<const uint4*>(otab)[2 * j + 1];
-    const int n = (int)r0.w, half = n >> 1, i0 = 4 * g;
+    const int n = (int)r0.w, half = n >> 1, i0 = 4 * g;  // (n: the overlap's m)
     const float* __restrict__ w = A.windows + r0.x;
     const float* __restrict__ wp = A.windows + r0.y;
     const float4 wf = *reinterpret_cast<const float4*>(w + i0);
     const float4 wm = *reinterpret_cast<const float4*>(w + (half - 4 - i0));
-    const float4 pf = *reinterpret_cast<const float4*>(wp + (half + i0));
-    const float4 pm = *reinterpret_cast<const float4*>(wp + (n - 4 - i0));
+    const float4 pf = *reinterpret_cast<const float4*>(wp + i0);
+    const float4 pm = *reinterpret_cast<const float4*>(wp + (half - 4 - i0));
     float fwd[8], mir[8];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -1720,6 +1764,48 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
     } else {
       pcm_store4(reinterpret_cast<float4*>(out) + g, fwd[0], fwd[2], fwd[4], fwd[6]);
       pcm_store4(reinterpret_cast<float4*>(out) + ((n >> 3) - 1 - g), mir[0], mir[2], mir[4], mir[6]);
+    }
+  }
+  // ---- what a frame emits alone: lane task = four consecutive sample times of R1 or R2 of one frame (window multiply of
+  // Mode.cs:160-166 on the block's own values, nothing overlapped onto them; kernels.hip: compact_value) ----
+  int fcnt[FPW + 1];
+  fcnt[0] = 0;
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) fcnt[k + 1] = fcnt[k] + ((r1len[k] + r2len[k]) >> 2);
+  for (int t = tid; t < fcnt[FPW]; t += NT) {
+    int k = 0;
+#pragma unroll
+    for (int kk = 1; kk < FPW; ++kk) k += (int)(t >= fcnt[kk]);
+    int g = t;
+#pragma unroll
+    for (int kk = 1; kk < FPW; ++kk) g = k == kk ? t - fcnt[kk] : g;
+    const uint4 r0 = reinterpret_cast<const uint4*>(otab)[2 * (FPW + 1 + k)], r1 = reinterpret_cast<const uint4*>(otab)[2 * (FPW + 1 + k) + 1];
+    const int n = (int)r0.z, q1 = (int)(r1.y >> 2);
+    const bool second = g >= q1;
+    const int idx0 = second ? (n >> 1) + 4 * (g - q1) : (int)r1.x + 4 * g;
+    const float4 wv4 = *reinterpret_cast<const float4*>(A.windows + r0.x + idx0);
+    // first half: y[idx] = -A[n/2 - 1 - idx] (idx >= n/4); second half: y[idx] = B[idx - n/2] (idx < 3n/4); B lies behind A in the slice
+    const int src = second ? (n >> 2) + (idx0 - (n >> 1)) : (n >> 1) - 4 - idx0;
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < nch) {
+        const float4 x = *reinterpret_cast<const float4*>(smem + r0.w + c * slice_words + src);
+        float4 v = second ? make_float4(x.x * wv4.x, x.y * wv4.y, x.z * wv4.z, x.w * wv4.w)
+                          : make_float4(-x.w * wv4.x, -x.z * wv4.y, -x.y * wv4.z, -x.x * wv4.w);
+        if (A.clip) {
+          v.x = clip_value(v.x, &clipped); v.y = clip_value(v.y, &clipped);
+          v.z = clip_value(v.z, &clipped); v.w = clip_value(v.w, &clipped);
+        }
+        o[c] = v.x; o[2 + c] = v.y; o[4 + c] = v.z; o[6 + c] = v.w;
+      }
+    }
+    float* out = A.pcm + ((long long)r0.y + (idx0 - (int)r1.w)) * nch;
+    if (nch == 2) {
+      pcm_store4(reinterpret_cast<float4*>(out), o[0], o[1], o[2], o[3]);
+      pcm_store4(reinterpret_cast<float4*>(out) + 1, o[4], o[5], o[6], o[7]);
+    } else {
+      pcm_store4(reinterpret_cast<float4*>(out), o[0], o[2], o[4], o[6]);
     }
   }
   if (A.clip && emit) report_clipped(clipped, A.clipped_flag);

@@ -958,6 +958,33 @@ extern "C" int nvh_ogg_demux_stream(const uint8_t* bytes, size_t len, int stream
   });
 }
 
+// The index form (host_ogg.h: OggIndexMode): no checksums, packet heads only -- see include/nvorbis_hip.h
+extern "C" int nvh_ogg_index_packets(const uint8_t* bytes, size_t len, int stream_index, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
+                                     int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,
+                                     int64_t* total_bytes, int64_t* payload_bytes, int* nstreams) {
+  return nvh_guard([&]() -> int {
+    if (!bytes || !npackets || !total_bytes || stream_index < 0 || !pkt_bytes || !offsets || !granules || !flags) return NVH_ERR_ARGUMENT;
+    nvh::OggPackets pk;
+    nvh::OggIndexMode mode;
+    int ns = 0;
+    int rc = nvh::ogg_demux(bytes, len, pk, stream_index, &ns, false, &mode);
+    if (rc != NVH_OK) return rc;
+    const int n = (int)pk.granule.size();
+    *npackets = n;
+    *total_bytes = (int64_t)pk.bytes.size();
+    if (payload_bytes) *payload_bytes = mode.payload_bytes;
+    if (nstreams) *nstreams = ns;
+    if (pkt_cap < n || pkt_bytes_cap < (int64_t)pk.bytes.size()) return NVH_ERR_ARGUMENT;
+    if (!pk.bytes.empty()) std::memcpy(pkt_bytes, pk.bytes.data(), pk.bytes.size());
+    std::memcpy(offsets, pk.offs.data(), sizeof(int64_t) * (size_t)(n + 1));
+    if (n) {
+      std::memcpy(granules, pk.granule.data(), sizeof(int64_t) * (size_t)n);
+      std::memcpy(flags, pk.flags.data(), (size_t)n);
+    }
+    return NVH_OK;
+  });
+}
+
 // ForwardOnlyPageReader / ForwardOnlyPacketProvider (host_ogg.cpp): the packet list a non-seekable source yields
 extern "C" int nvh_ogg_demux_forward(const uint8_t* bytes, size_t len, int stream_index, uint8_t* pkt_bytes, int64_t pkt_bytes_cap,
                                      int64_t* offsets, int64_t* granules, uint8_t* flags, int pkt_cap, int* npackets,

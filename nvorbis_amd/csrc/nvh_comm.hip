@@ -11,7 +11,16 @@
 // the library itself has no link-time dependency on it, and a single-GPU caller never touches it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without RCCL's development headers still builds the library (the single-GPU path never touches RCCL): the
+// handful of types and constants of the NCCL ABI these entry points use, as rccl.h / nccl.h declare them.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt64 = 4, ncclFloat32 = 7 } ncclDataType_t;
+#endif
 
 #include <mutex>
 #include <vector>

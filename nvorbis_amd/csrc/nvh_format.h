@@ -194,6 +194,13 @@ struct NvhFrame {
 // mono / stereo slabs: bits 6 and 7 of NvhSlabHdr::exec_mask (two channels need two bits)
 #define NVH_SLABX_SELF_CARRY 0x40u // NVH_EMIT_SELF_CARRY (together with NVH_SLAB_EMIT_SELF)
 #define NVH_SLABX_CARRY_OUT 0x80u  // NVH_EMIT_CARRY_OUT (chan[2] = window_off)
+#define NVH_SLABX_DONE 0x20u       // NVH_EMIT_DONE: the frame's PCM comes out of the synthesis kernels -- its overlap with the frame before by
+                                   // whoever holds SELF / NEXT, the samples only this block contributes to (a long block next to a short one:
+                                   // the flat parts of its window, Mode.cs:102-117) by its own workgroup (kernels_synth.hip, frame groups)
+// chan[5] of a mono / stereo slab with NVH_SLAB_EMIT_* / NVH_SLABX_DONE: the geometry of the overlaps in units of 64 samples
+// (Mode.cs:102-151: every start / valid / block size of a stream with blocks >= 256 is a multiple of 64)
+#define NVH_SLAB_GEO(prev_n, next_n, start, valid) \
+  ((uint32_t)((prev_n) >> 6) | ((uint32_t)((next_n) >> 6) << 8) | ((uint32_t)((start) >> 6) << 16) | ((uint32_t)((valid) >> 6) << 24))
 #define NVH_SLAB_HDR_VECS 4
 #define NVH_SLAB_MAX_CH 8          // channels a slab describes (k_synth: 2, k_synth8: 8)
 #define NVH_SLAB_MAX_COUPLE 4      // coupling steps of a pass of its own (3 + 3 bits each in NvhSlabHdr::coupling)
@@ -214,6 +221,8 @@ struct NvhSlabHdr {      // 64 bytes
   uint32_t coupling;     // NVH_SLAB_COUPLE_PASS: step count | (magnitude | angle << 3) << (4 + 6 k) for step k (Mapping.cs:137-182)
   uint32_t chan[NVH_SLAB_MAX_CH];  // per channel: floor mode (0 none, 1 curve, 2 clear; Floor1.cs:218-221) | nseg << 8 | off_seg << 16
                                    // NVH_SLAB_EMIT_* (at most two channels): chan[2..7] = window_off, ov_window_off, the next
-                                   // frame's window_off and ov_window_off, out_pos, the next frame's out_pos
+                                   // frame's window_off, NVH_SLAB_GEO(block size of the frame before, of the frame behind, this
+                                   // frame's start and valid), out_pos, the next frame's out_pos (the next frame's ov_window_off
+                                   // is this frame's window_off)
 };
 

@@ -334,29 +334,51 @@ static void assign_emission(nvh_stream* s, nvh_batch* b, nvh::FrameBatch& P, int
              full(fr.ov_exec_mask) && full(pv.exec_mask) && ((fr.out_pos * ch) & 3) == 0 &&
              fr.out_pos >= 0 && fr.out_pos < 0x7FFFFFFFll && fr.window_off < 0x7FFFFFFFu;
     };
+    // Frame groups (fpw > 1) also emit through block-size switches (Mode.cs:102-151, StreamDecoder.cs:417-463): the overlap of
+    // two blocks of n and pn samples is ola_sym's read-once form on m = min(n, pn) -- sample times i and m/2 - 1 - i need the last
+    // m/4 values of the later block's first quarter and of the earlier block's third quarter --, and what a long block emits
+    // beside its overlaps (the flat parts of its window next to a short neighbour: [start + m/2, n/2) and [n/2, valid)) only that
+    // block contributes to: its own workgroup emits it.  "pairable": the geometry the window flags promise is the geometry the
+    // stream has (consistent flags, no end-of-stream trim), everything in whole groups of four samples.
+    auto pairable = [&](int g) {
+      if (!can || g < 1 || g >= nf) return false;
+      const NvhFrame& fr = P.frames[(size_t)g];
+      const NvhFrame& pv = P.frames[(size_t)g - 1];
+      if (fr.n < 256 || pv.n < 256) return false;
+      const int m = fr.n < pv.n ? fr.n : pv.n, half = fr.n >> 1;
+      return fr.ov_frame == g - 1 && fr.ov_n == pv.n && fr.ov_window_off == pv.window_off && fr.start == (fr.n >> 2) - (m >> 2) &&
+             fr.ov_len == (m >> 1) && fr.ov_src == 3 * (pv.n >> 2) - (m >> 2) && fr.emit_start == fr.start &&
+             fr.emit_count == fr.valid - fr.start && fr.valid >= half && fr.valid <= half + (fr.n >> 2) && (fr.valid & 63) == 0 &&
+             full(fr.exec_mask) && full(fr.ov_exec_mask) && full(pv.exec_mask) && ((fr.out_pos * ch) & 3) == 0 &&
+             fr.out_pos >= 0 && fr.out_pos < 0x7FFFFFFFll && fr.window_off < 0x7FFFFFFFu;
+    };
     // Who emits an overlap.  Frames go to workgroups in groups of fpw consecutive frames (1: k_synth / k_synth_emit, the odd
     // frames first; 2, 4: kernels_synth.hip, frame groups -- the groups with an odd index first); a steady overlap inside a group
     // is emitted by that group from LDS, one between two groups by the group of the second launch (even index), which finds the
     // other group's quarter in the planes.  SELF: the frame's own workgroup emits its PCM; NEXT: it emits frame g + 1's.
     if (narrow && can && fpw > 1) b->fpw = fpw;
     const int gw = b->fpw;
+    auto emits = [&](int g) { return gw > 1 ? pairable(g) : steady(g); };
     for (int g = 0; g < nf; g++) {
       NvhFrame& fr = P.frames[(size_t)g];
       fr.emit_flags = 0;
       const int k = g % gw;
       const bool second_launch = ((g / gw) & 1) == 0;
-      if (steady(g)) {
+      if (emits(g)) {
         fr.emit_flags |= NVH_EMIT_DONE;
         if (k > 0 || second_launch) fr.emit_flags |= NVH_EMIT_SELF;
         b->emit_frames++;
       }
-      if ((k < gw - 1 || second_launch) && steady(g + 1)) fr.emit_flags |= NVH_EMIT_NEXT;
+      if ((k < gw - 1 || second_launch) && emits(g + 1)) fr.emit_flags |= NVH_EMIT_NEXT;
     }
-    // the batch's first frame over the carried tail of the batch before (same geometry, the tail stored fully windowed)
+    // the batch's first frame over the carried tail of the batch before (same geometry, the tail stored fully windowed; frame
+    // groups: a long block in front of a short one emits the flat part behind its first half as well)
     if (can && nf > 0) {
       NvhFrame& fr = P.frames[0];
       const int half = fr.n >> 1;
-      if (fr.n >= 256 && fr.ov_frame == -2 && fr.ov_n == fr.n && fr.start == 0 && fr.emit_start == 0 && fr.emit_count == half &&
+      const bool tail_ok = gw > 1 ? (fr.emit_count == fr.valid - fr.start && fr.valid >= half && fr.valid <= half + (fr.n >> 2) && (fr.valid & 63) == 0)
+                                  : fr.emit_count == half;
+      if (fr.n >= 256 && fr.ov_frame == -2 && fr.ov_n == fr.n && fr.start == 0 && fr.emit_start == 0 && tail_ok &&
           fr.ov_src == half && fr.ov_len == half && full(fr.exec_mask) && ((fr.out_pos * ch) & 3) == 0 &&
           fr.out_pos >= 0 && fr.out_pos < 0x7FFFFFFFll) {
         fr.emit_flags |= NVH_EMIT_SELF | NVH_EMIT_SELF_CARRY | NVH_EMIT_DONE;
@@ -615,7 +637,7 @@ static size_t slab_lds_bytes(const nvh_batch* b) {
     const size_t g = (size_t)b->fpw;
     const size_t walk = (size_t)s->shared->synth_const_vecs * 4 + g * (slab_lds_vecs(b) * 4 + ch * (b1 / 2));
     const size_t xform = ch * (b1 / 2) + g * ch * (b1 / 2 + b1 / 16);
-    return (std::max(walk, xform) + 8 * (g + 1)) * sizeof(float);
+    return (std::max(walk, xform) + 8 * (2 * g + 1)) * sizeof(float);
   }
   size_t words = (size_t)s->shared->synth_const_vecs * 4 + slab_lds_vecs(b) * 4 + ch * (b1 / 2) + b1 / 16;
   if (slab_wide(s)) words = std::max(words, ch * (b1 / 2 + b1 / 16));

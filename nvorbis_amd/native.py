@@ -107,6 +107,7 @@ SIGNATURES = {
     "nvh_ogg_index_page": (C.c_int, [_vp, C.c_int, _i64p, _ip, _ip, _ip]),
     "nvh_ogg_seek": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _i64p, _i64p]),
     "nvh_ogg_demux_stream": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, C.c_int, _ip, _i64p, _ip]),
+    "nvh_ogg_index_packets": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, C.c_int, _ip, _i64p, _i64p, _ip]),
     # the corpus gather through RCCL's C API (nvh_comm.hip): what a host without torch.distributed binds to
     "nvh_comm_unique_id": (C.c_int, [_vp]),
     "nvh_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),

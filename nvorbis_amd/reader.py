@@ -96,6 +96,36 @@ def demux_ogg_array(data: bytes, stream_index=0, forward_only=False):
     return PacketArray(pk, offs[:n.value + 1], gran, flags)
 
 
+def index_ogg_array(data: bytes, stream_index=0):
+    """The index form of demux_ogg_array (nvh_ogg_index_packets): the stream's packet list without page checksums and packet
+    bodies -- the three headers whole, every audio packet as its first (up to) 8 bytes -- as (PacketArray, payload_bytes); what a
+    sizing pass hands to Stream.index_packets.  A later demux_ogg_array of the same bytes must find the same packet count and
+    the same payload size (PacketArray.data.size), else a page was damaged and the index does not hold."""
+    L = lib()
+    n = C.c_int(0)
+    total = C.c_int64(0)
+    payload = C.c_int64(0)
+    src = np.frombuffer(data if data else b"\0", dtype=np.uint8)
+    # heads + headers: 8 bytes per packet and the setup header; a page (>= 27 bytes of header) starts at most 255 packets, and only
+    # lacing values of 0..254 end one, so len / 27 + len / 64 is far beyond any audio stream -- the call says so if it is not
+    cap_n = len(data) // 48 + 64
+    cap_b = min(len(data), 8 * cap_n + (1 << 16)) + 64
+    for _ in range(2):
+        pk = np.empty(cap_b, dtype=np.uint8)
+        offs = np.empty(cap_n + 1, dtype=np.int64)
+        gran = np.empty(cap_n, dtype=np.int64)
+        flags = np.empty(cap_n, dtype=np.uint8)
+        rc = L.nvh_ogg_index_packets(C.c_void_p(src.ctypes.data), len(data), int(stream_index), pk.ctypes.data, pk.size, offs.ctypes.data,
+                                     gran.ctypes.data, flags.ctypes.data, cap_n, C.byref(n), C.byref(total), C.byref(payload), None)
+        if rc == native.ERR_ARGUMENT and (n.value > cap_n or total.value > cap_b):
+            cap_n, cap_b = n.value + 1, total.value + 64
+            continue
+        check(rc, "nvh_ogg_index_packets")
+        break
+    m = n.value
+    return PacketArray(pk[:max(total.value, 1)], offs[:m + 1].copy(), gran[:max(m, 1)].copy(), flags[:max(m, 1)].copy()), int(payload.value)
+
+
 def demux_ogg(data: bytes, forward_only=False):
     """First logical stream of an Ogg file -> (list of packet bytes, granules, flags)."""
     pa = demux_ogg_array(data, 0, forward_only)

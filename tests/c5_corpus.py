@@ -51,6 +51,43 @@ def build_files(scale, ws=None):
     return [corpus_file(ws, i, scale) for i in range(n_files())]
 
 
+def build_subset(indices, scale, procs=0):
+    """{index: bytes} of the corpus files `indices` -- what ONE rank of a sharded job needs.  procs > 1: written by that many
+    child interpreters (python -m tests.c5_corpus --emit ...; the writer is a Python loop per packet, ~30 ms per file) into a
+    scratch directory (tmpfs where there is one) and read back; children never import torch or touch the GPU."""
+    indices = list(indices)
+    if procs <= 1 or len(indices) < 4 * procs:
+        ws = writer_setup()
+        return {i: corpus_file(ws, i, scale) for i in indices}
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="nvh_c5_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
+    try:
+        # file lengths are log-uniform and independent of the index: strided lists balance
+        jobs = []
+        for k in range(procs):
+            part = indices[k::procs]
+            out = os.path.join(tmp, "part%d.bin" % k)
+            jobs.append((part, out, subprocess.Popen([sys.executable, "-m", "tests.c5_corpus", "--emit", out, "--scale", repr(float(scale)),
+                                                      "--indices", ",".join(map(str, part))], cwd=ROOT)))
+        files = {}
+        for part, out, pr in jobs:
+            if pr.wait() != 0:
+                raise RuntimeError("corpus writer child failed (%d)" % pr.returncode)
+            lens = json.load(open(out + ".idx"))
+            blob = open(out, "rb").read()
+            off = 0
+            for i, n in zip(part, lens):
+                files[i] = blob[off:off + n]
+                off += n
+            assert off == len(blob)
+        return files
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def file_digest(data):
     return hashlib.sha256(data).hexdigest()[:16]
 
@@ -67,3 +104,20 @@ def load_digests(scale):
     d = json.load(open(p))
     assert d["files"] == n_files() and abs(d["scale"] - scale) < 1e-12, (d["files"], d["scale"])
     return d
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--emit", required=True)
+    ap.add_argument("--scale", type=float, required=True)
+    ap.add_argument("--indices", required=True)
+    a = ap.parse_args()
+    ws_ = writer_setup()
+    lens_ = []
+    with open(a.emit, "wb") as fh:
+        for i_ in map(int, a.indices.split(",")):
+            d_ = corpus_file(ws_, i_, a.scale)
+            fh.write(d_)
+            lens_.append(len(d_))
+    json.dump(lens_, open(a.emit + ".idx", "w"))

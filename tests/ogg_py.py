@@ -66,6 +66,13 @@ class PageWriter:
     def add_packet(self, data, granule, flush=False, eos=False):
         n = len(data)
         lacing = [255] * (n // 255) + [n % 255]
+        if len(self._segs) + len(lacing) <= self.max_segments:  # the whole packet fits the open page: no flush inside it
+            self._segs += lacing
+            self._body += data
+            self._granule = granule
+            if flush or eos:
+                self._flush(eos=eos)
+            return
         pos = 0
         for k, seg in enumerate(lacing):
             if len(self._segs) == self.max_segments:

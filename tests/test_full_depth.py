@@ -189,3 +189,32 @@ def test_c5_corpus_1004_files_digests(scale, gpu_parse):
         assert not bad, (rep, bad[:10])
         del arena, views
     corpus.close_worker_contexts()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpu_parse", [False, True])
+def test_corpus_pass_reindexes_a_file_with_a_damaged_page(gpu_parse):
+    """The corpus pass sizes its arena from the lacing-only index (no page checksums); the decode pass demultiplexes with them.  A
+    file one of whose pages fails its checksum decodes to another packet list than the index promised (the reference's reader
+    drops the page and resynchronises, Ogg/PageReaderBase.cs:33-70): the pass finds out by count and payload, decodes that
+    file from the checked list into a tensor of its own -- bit-exact against the oracle's decode of the damaged bytes -- and
+    the other files' PCM is what it would have been."""
+    import numpy as np
+
+    from nvorbis_amd import corpus
+    from tests import c5_corpus, ogg_py, oracle_py
+    ws = c5_corpus.writer_setup()
+    files = [c5_corpus.corpus_file(ws, i, 0.05) for i in range(6)]
+    pages = ogg_py.read_pages(files[2])
+    bad = bytearray(files[2])
+    pg = pages[len(pages) // 2]
+    bad[pg["offset"] + pg["length"] - 3] ^= 0x11
+    files[2] = bytes(bad)
+    orc = oracle_py.load()
+    want = [orc.decode_ogg(f)[0] for f in files]
+    t = {}
+    arena, views = corpus.decode_files_to_device(files, device=0, workers=4, gpu_parse=gpu_parse, timings=t)
+    assert t.get("files_reindexed") == [2]
+    for i, (v, w) in enumerate(zip(views, want)):
+        got = v.cpu().numpy()
+        assert got.size == w.size and np.array_equal(got.view(np.uint32), w.view(np.uint32)), i

@@ -483,3 +483,47 @@ def test_demux_in_one_call_equals_the_sizing_and_fill_calls(ogg_bytes):
             assert len(pa) == n.value and pa.data.size == pk.size
             assert np.array_equal(pa.data, pk) and np.array_equal(pa.offsets, offs)
             assert np.array_equal(pa.granules[:n.value], gran[:n.value]) and np.array_equal(pa.flags[:n.value], flags[:n.value])
+
+
+def test_lacing_only_index_equals_the_checked_demultiplex(ogg_bytes):
+    """reader.index_ogg_array (nvh_ogg_index_packets; Ogg/PageReaderBase.cs:227-292 page header + lacing values,
+    Ogg/PacketProvider.cs:324-438 packet rules): without the page checksums and the packets' bodies it yields the packet list of
+    reader.demux_ogg_array -- same count, granule positions, end-of-stream / resync flags, the three headers whole, every other
+    packet's first 8 bytes, the true payload size -- and Stream.index_packets over it the same geometry; a page with a damaged
+    body passes the index and is found by the comparison the corpus pass makes (count, payload)."""
+    import numpy as np
+
+    from nvorbis_amd.reader import Stream, demux_ogg_array, index_ogg_array
+    from tests import c5_corpus, ogg_py
+    ws = c5_corpus.writer_setup()
+    files = [ogg_bytes[k] for k in ("1test", "2test", "3test", "issue6test")] + [c5_corpus.corpus_file(ws, i, 0.05) for i in (0, 7, 19)]
+    for data in files:
+        pa = demux_ogg_array(data)
+        qa, payload = index_ogg_array(data)
+        n = len(pa)
+        assert len(qa) == n and payload == int(pa.offsets[-1])
+        assert np.array_equal(pa.granules[:n], qa.granules[:n]) and np.array_equal(pa.flags[:n], qa.flags[:n])
+        assert all(pa[k] == qa[k] for k in range(3)) and all(pa[k][:8] == qa[k] for k in range(3, n))
+        st = Stream(None, pa[0], pa[1], pa[2])
+        try:
+            a, b = st.index_packets(pa, 3), st.index_packets(qa, 3)
+        finally:
+            st.close()
+        assert a[3] == b[3] and all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3]))
+        # a flipped body byte in the third-to-last page: the checksum refuses the page, the index cannot know
+        pages = ogg_py.read_pages(data)
+        if len(pages) >= 6:
+            pg = pages[-3]
+            bad = bytearray(data)
+            bad[pg["offset"] + pg["length"] - 1] ^= 0x40
+            bad = bytes(bad)
+            qb, payload_b = index_ogg_array(bad)
+            pb = demux_ogg_array(bad)
+            assert (len(qb), payload_b) == (n, payload)                      # the index takes the page at its word
+            assert (len(pb), int(pb.offsets[-1])) != (len(qb), payload_b)    # the checked list differs: the corpus pass re-indexes
+    # chained streams: the index form follows the same stream bookkeeping
+    two = files[0] + files[1]
+    for k in (0, 1):
+        pa = demux_ogg_array(two, k)
+        qa, payload = index_ogg_array(two, k)
+        assert len(pa) == len(qa) and payload == int(pa.offsets[-1])

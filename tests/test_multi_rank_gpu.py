@@ -39,6 +39,27 @@ def test_bench_two_ranks_share_one_gpu():
     assert abs(d["value"] - 2 * 4096 * d["config"]["passes_per_step"] * d["steps"] / d["config"]["timed_region_s"]) < 1e-6 * d["value"]
 
 
+def test_bench_eight_ranks_share_one_gpu():
+    """The driver's 8-GPU launch shape on the one GPU of a test box: eight ranks through bench.py's own launcher, 8 x 3 decoder
+    instances, eight worker pools, the eight-way LPT shard (every rank builds ONLY its shard from the committed sizes), the
+    per-rank SHA-256 checks, the gather into the root and its device-side word sums.  A dry run of the code path, not a rate."""
+    env = dict(os.environ)
+    env["NVH_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--min-timed-ms", "60",
+                        "--working-set-mib", "64", "--no-configs", "--no-cpu-baseline", "--no-unfused", "--c5-scale", "0.1", "--c5-workers", "4"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["pcm_digest_ok"] is True
+    assert d["collective"]["world"] == 8 and d["collective"]["backend"] == "gloo"
+    c5 = d["c5"]
+    assert c5["files"] == 1004 and c5["pcm_sha256_ok"] is True and c5["files_checked"] == 1004
+    assert c5["check"] == dict(c5["check"], per_rank_sha256_ok=True, inputs_ok=True, gathered_word_sums_ok=True)
+    assert 100 <= c5["untimed_rank0"]["files_built"] <= 140  # an eighth of the corpus, not all of it
+    assert 0 < c5["decode_s_min_rank"] <= c5["decode_s"] and c5["gather_s"] > 0
+    assert 0.8 * c5["pcm_bytes"] < c5["gathered_bytes_over_links"] < c5["pcm_bytes"]  # seven eighths crossed to the root
+
+
 def test_corpus_transcode_two_ranks_equals_one_rank():
     def run(world):
         env = dict(os.environ)

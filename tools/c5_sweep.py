@@ -7,7 +7,8 @@ Each case is a child process (the NVH_* switches are read once when the library 
 lines over all workers.  No digest check here (tools/corpus_c5.py and the suite do that)."""
 import argparse
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd/__init__.py says why)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd.configure_process says why)
+os.environ.setdefault("NVH_CORPUS_MALLOPT", "1")  # this process is a corpus job: the allocator settings of nvorbis_amd.corpus._tune_malloc (opt-in)
 import pickle
 import re
 import subprocess

@@ -11,7 +11,8 @@ tests/c5_corpus.py (lengths log-uniform 5-300 s x scale, seed = file 
 import argparse
 import json
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd/__init__.py says why)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd.configure_process says why)
+os.environ.setdefault("NVH_CORPUS_MALLOPT", "1")  # this process is a corpus job: the allocator settings of nvorbis_amd.corpus._tune_malloc (opt-in)
 import sys
 import time
 
@@ -83,9 +84,22 @@ def run(scale, workers, gpu_parse):
     return 0 if not mism and not bad_files else 1
 
 
+def add_sizes(scale):
+    """`ogg_bytes` of the digest file: the compressed size of every file, checked against the committed file digests."""
+    path = c5_corpus.digest_path(scale)
+    d = json.load(open(path))
+    files = c5_corpus.build_files(scale)
+    assert [c5_corpus.file_digest(f) for f in files] == [r[0] for r in d["digests"]]
+    d["ogg_bytes"] = [len(f) for f in files]
+    with open(path, "w") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("sizes entered:", path, sum(d["ogg_bytes"]), "bytes")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--make-digests", action="store_true")
+    ap.add_argument("--add-sizes", action="store_true", help="enter every file's compressed size into the committed digest file (what an LPT shard needs, so that a rank builds its own shard only)")
     ap.add_argument("--run", action="store_true")
     ap.add_argument("--scale", type=float, default=0.1)
     ap.add_argument("--workers", type=int, default=16)
@@ -94,5 +108,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.make_digests:
         make_digests(a.scale, a.procs)
+    if a.add_sizes or a.make_digests:
+        add_sizes(a.scale)
     if a.run:
         raise SystemExit(run(a.scale, a.workers, a.gpu_parse))

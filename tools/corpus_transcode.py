@@ -11,7 +11,8 @@ nvorbis_amd.corpus.gather_pcm).  Corpus: --dir DIR (*.ogg), or --synthetic (SURV
 tests/vorbis_encode.py from 3test.ogg's setup, lengths log-uniform 5-300 s x --scale, seed = file index), else the four
 shipped test files cycled to --files entries.  Rank 0 prints one JSON line."""
 import argparse, glob, json, os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd/__init__.py says why)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises (nvorbis_amd.configure_process says why)
+os.environ.setdefault("NVH_CORPUS_MALLOPT", "1")  # this process is a corpus job: the allocator settings of nvorbis_amd.corpus._tune_malloc (opt-in)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
