@@ -701,7 +701,7 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh);
         # null when the committed profile does not cover the kernel that ran
-        traffic, traffic_source, traffic_build = None, None, None
+        traffic, traffic_source, traffic_build, rocprof_us = None, None, None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
@@ -720,6 +720,9 @@ def main():
                 else:
                     traffic = tk.get(names[dom], {}).get("hbm_bytes")
                 traffic_build = tj.get("build")
+                # per-kernel average durations of the committed rocprofv3 --kernel-trace pass (the same three-stream loop)
+                rocprof_us = {k: round(v["avg_us"], 3) for k, v in tk.items() if k.startswith("k_synth") and "avg_us" in v}
+                rocprof_us["source"] = tj.get("source")
                 if traffic is not None:
                     traffic_source = "profiles/traffic.json: %s (committed rocprofv3 --pmc passes of this command, not measured in this run)" % tj.get("source", "?")
             except Exception:
@@ -772,9 +775,19 @@ def main():
                          "traffic_build_matches": (traffic_build == nv.native.build_id()) if traffic is not None else None,
                          "algorithmic_bytes_per_launch": alg_bytes // launches, "avg_launch_ms": dom_ms / launches,
                          "launches_per_pass": launches,
-                         "kernel_scope": ("k_synth+k_synth_emit = residue + floor + inverse MDCT + (paired emission) window / overlap-add / clip / interleave of the "
-                                          "steady-state frames, two launches per pass (odd frames, then the emitting even frames), timed together, one stream"
+                         "kernel_scope": (("k_synth_group2 = residue + floor + inverse MDCT + window / overlap-add / clip / interleave of two consecutive frames per "
+                                           "workgroup (the overlap inside a group on chip), two launches per pass (the groups with an odd index, then the even ones, "
+                                           "which also emit the overlaps between groups), timed together by hipEvents on ONE stream"
+                                           if names[dom].startswith("k_synth_group") else
+                                           "k_synth+k_synth_emit = residue + floor + inverse MDCT + (paired emission) window / overlap-add / clip / interleave of the "
+                                           "steady-state frames, two launches per pass (odd frames, then the emitting even frames), timed together, one stream")
                                           if fused else "k_synth = residue + floor + inverse MDCT; overlap-add in k_ola_compact"),
+                         # how to read the numbers: `frac` / `achieved` / `avg_launch_ms` are ONE decoder instance (what a ReadSamples caller's
+                         # kernels run at); `value` and `whole_pass_frac` are the timed loop over `streams` instances, whose launches overlap
+                         "one_stream": {"pass_us": dom_ms * 1e3, "frames_per_s": FRAMES / (dom_ms * 1e-3), "frac": achieved / HBM_PEAK_GBPS},
+                         "timed_loop": {"streams": nin, "pass_us": step_ms * 1e3, "frames_per_s": FRAMES / (step_ms * 1e-3),
+                                        "frac": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                         "rocprof_avg_us": rocprof_us,
                          "unfused": unfused,
                          "working_set_MiB": touched / (1 << 20), "regime": "HBM-resident: a batch is revisited after %.0f MiB went by (Infinity Cache: 256 MiB)" % (touched / (1 << 20)),
                          # the same bytes over one whole pass of the pipeline (all kernels, the batches of the streams overlapped)

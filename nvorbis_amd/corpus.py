@@ -483,7 +483,6 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
         measure(pa)
         shape[i] = (len(pa), int(pa.offsets[-1]))
 
-    import os
     import time
     if tune_process or os.environ.get("NVH_CORPUS_MALLOPT"):  # process-wide allocator settings: opt-in (see _tune_malloc)
         _tune_malloc()

@@ -108,6 +108,19 @@ __device__ __forceinline__ void br_skip(BitR& b, int count, const uint32_t* __re
   }
 }
 
+// The cursor moved q bits on in one step (the caller knows the bits are there): the buffer from the packet's words again,
+// three independent reads, in the state br_fill leaves (more than 32 bits while words remain, the next word fetched ahead).
+template <bool LDS>
+__device__ __forceinline__ void br_jump(BitR& b, const uint32_t* __restrict__ s_pkt, uint32_t q) {
+  const uint32_t np = b.pos + q, w = np >> 5, sh = np & 31u;
+  const uint32_t W0 = br_word<LDS>(b, s_pkt, w), W1 = br_word<LDS>(b, s_pkt, w + 1u), W2 = br_word<LDS>(b, s_pkt, w + 2u);
+  b.pos = np;
+  b.buf = (((uint64_t)W1 << 32) | W0) >> sh;
+  b.next = w + 2u < b.nwords ? w + 2u : b.nwords;
+  b.avail = 32u * b.next - np;
+  b.ahead = W2;
+}
+
 template <bool LDS>
 __device__ __forceinline__ uint32_t br_read(BitR& b, int count, const uint32_t* __restrict__ s_pkt) {
   if (count == 0) return 0;
@@ -446,51 +459,126 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       if (!any_execute) continue;
       const int residue_idx = map.submap_residue[sm];
       const NvhPResidue& r = residues[residue_idx];
+      // (the scalars of the record by value: `r` lies in LDS, which the walk also writes, so every use would be a reload)
+      const int r_type = r.type, r_begin = r.begin, r_psize = r.partition_size, r_chs = r.channels, r_rch = r.real_channels,
+                r_stages = r.max_stages, r_partvals = r.partvals;
+      const uint32_t r_rchm = r.rch_magic;
       const NvhPBook class_book = books[r.class_book];  // by value: registers, not an LDS reload per symbol
+      const uint32_t dm_lds = r.decode_map_lds;         // the class decode map's copy in LDS (nvh_setup.hip), if it has one
+      const uint32_t vis_lds = r.vis_lds;               // ... the visit descriptors'
+      // The entries of one vector, one packet per wavefront (UNI): the 64 lanes are idle copies of one another, and a symbol of the
+      // scalar loop is a chain of a dozen and more instructions on the one scalar unit 16 wavefronts share.  Here lane i looks up the
+      // code that WOULD start at bit i of a 96-bit window (buffer + the word fetched ahead) -- one alignbit, one table read, for up
+      // to 63 start positions at once -- and the scalar side only walks the chain of lengths: readlane, add, per symbol.  The lanes
+      // on the chain then store their entries side by side.  Same symbols, same order, same stop rules as the scalar loop (a start
+      // position needs 32 bits left in the packet, a code that resolves in the prefix table, a slot); whatever ends a window early
+      // -- its width, a long code -- is taken up by the next window or by the long-code scan.  Returns true when it cannot go on
+      // for a reason the caller's loops do not know (never, by the bit reader's invariants).
+      auto decode_windows = [&](const uint32_t toff, const uint32_t pmask, uint16_t* __restrict__ eout, const int slots, int& done) -> bool {
+        bool stuck = false;
+        for (;;) {
+          const uint32_t rem = p.total - p.pos;
+          if (done >= slots || rem < 32u) break;
+          const uint32_t av = p.avail;
+          uint64_t lo = p.buf;
+          uint32_t hi = p.ahead;
+          if (av < 64u) {
+            lo |= (uint64_t)p.ahead << av;
+            hi = av > 32u ? p.ahead >> (64u - av) : 0u;
+          }
+          const uint32_t wbits = av + (p.next < p.nwords ? 32u : 0u);
+          const uint32_t mbits = wbits < rem ? wbits : rem;
+          if (mbits < 32u) { stuck = true; break; }  // (cannot happen: the buffer holds the packet's last bits, or more than 32)
+          const uint32_t limit = mbits - 32u < 62u ? mbits - 32u : 62u;  // last start position of this window (lane 63 ends every chain)
+          const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+          const uint32_t fa = lane < 32 ? w0 : w1, fb = lane < 32 ? w1 : hi;
+          const uint32_t field = __builtin_amdgcn_alignbit(fb, fa, (uint32_t)lane & 31u);
+          const uint32_t nodev = s_prefix[toff + (field & pmask)];
+          const uint32_t lenv = ((nodev & 0x80u) != 0u && (uint32_t)lane <= limit) ? (nodev & 0x7Fu) : 0u;
+          // (lanes behind `limit` hold 0, lane 63 among them: a position past the window reads a 0 and ends the chain)
+          uint32_t q, cnt, t_lane, t_len;
+          unsigned long long chain;
+          const uint32_t want = (uint32_t)__builtin_amdgcn_readfirstlane(slots - done);  // >= 1 (uniform: said so for the asm's scalar operand)
+          // do { len = lenv[min(q, 63)]; if (!len) break; chain |= 1 << q; q += len; } while (++cnt < want);
+          // by hand: the compiler turns the two exits into a dozen condition-mask instructions per symbol, and this
+          // loop IS the parse's cost (nine scalar-side instructions per symbol; no software wait states are due: the
+          // lane select is written by the scalar unit, v_readlane's result is read by it)
+          asm volatile(
+              "s_mov_b32 %0, 0\n\t"
+              "s_mov_b32 %1, 0\n\t"
+              "s_mov_b64 %2, 0\n"
+              "1:\n\t"
+              "s_min_u32 %3, %0, 63\n\t"
+              "v_readlane_b32 %4, %5, %3\n\t"
+              "s_cmp_eq_u32 %4, 0\n\t"
+              "s_cbranch_scc1 2f\n\t"
+              "s_bitset1_b64 %2, %0\n\t"
+              "s_add_u32 %0, %0, %4\n\t"
+              "s_add_u32 %1, %1, 1\n\t"
+              "s_cmp_lt_u32 %1, %6\n\t"
+              "s_cbranch_scc1 1b\n"
+              "2:\n\t"
+              : "=&s"(q), "=&s"(cnt), "=&s"(chain), "=&s"(t_lane), "=&s"(t_len)
+              : "v"(lenv), "s"(want)
+              : "scc");
+          if (cnt == 0u) break;
+          if ((chain >> lane) & 1ull) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chain, 0u));
+            eout[(uint32_t)done + rank] = (uint16_t)(nodev >> 8);
+          }
+          done += (int)cnt;
+          br_jump<LDS>(p, s_pkt, q);
+        }
+        return stuck;
+      };
       NvhResPass pass;
       pass.residue = residue_idx;
       for (int s = 0; s <= NVH_MAX_STAGES; s++) pass.op_begin[s] = op_base + nops;
       int block_size = fr.n;
-      if (r.type == 2) block_size *= r.real_channels;  // Residue2.cs:16-21
+      if (r_type == 2) block_size *= r_rch;  // Residue2.cs:16-21
       const int end = r.end < block_size / 2 ? r.end : block_size / 2;
-      const int n = end - r.begin;
+      const int n = end - r_begin;
       bool ran = false;
       int stage = 0;
       if (n > 0) {
         ran = true;
-        const int partition_count = n / r.partition_size;
+        const int partition_count = n / r_psize;
         const int cdim = r.class_dims;
         if (cdim == 0) {
           err = kErrRuntime;
           break;
         }
-        const int partition_words = (partition_count + cdim - 1) / cdim;
-        // the two scratch rows of the walk: class word per [channel][word], last op per [partition][channel]
+        // the two scratch rows of the walk: class per [channel][partition] (a class word is expanded through the residue's decode map
+        // when it is decoded: a visit then is one lookup away from its class, not two), last op per [partition][channel]
         int* g_rows = g_rows_base;
         int* l_rows = l_rows_base;
         auto row_get = [&](int i) { return LDS ? l_rows[i] : g_rows[i]; };
         auto row_set = [&](int i, int v) { if (LDS) l_rows[i] = v; else g_rows[i] = v; };
         const int last_base = gen_rows ? T.cap_parts + s_npass * row_stride + 2 : T.cap_parts;  // last_op row behind the part_word row
-        const int pw_stride = partition_words > 0 ? partition_words : 1;
-        for (int i = 0; i < r.channels * pw_stride; i++) row_set(i, -1);
-        for (int i = 0; i < r.channels * (partition_count > 0 ? partition_count : 1); i++) row_set(last_base + i, -1);
+        const int pw_stride = partition_count > 0 ? partition_count : 1;
+        for (int i = 0; i < r_chs * pw_stride; i++) row_set(i, -1);
+        auto class_of = [&](int word, int d) {
+          if constexpr (UNI) return (int)s_prefix[dm_lds + (uint32_t)(word * cdim + d)];
+          else return dm_lds != 0xFFFFFFFFu ? (int)s_prefix[dm_lds + (uint32_t)(word * cdim + d)] : ipool_at(r.decode_map_off + (uint32_t)(word * cdim + d));
+        };
+        for (int i = 0; i < r_chs * (partition_count > 0 ? partition_count : 1); i++) row_set(last_base + i, -1);
         const int buflen = T.block1;  // float[ch][block1Size] (StreamDecoder.cs:498-505)
         bool stop = false;
         int stop_p = 0, stop_c = 0;  // slab mode: where the packet ran out (partition, channel), and whether that vector write was kept
         bool stop_pushed = false;
-        for (; stage < r.max_stages && !stop && !err; stage++) {
+        for (; stage < r_stages && !stop && !err; stage++) {
           pass.op_begin[stage] = op_base + nops;
           for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count && !stop && !err; entry_idx++) {
             if (stage == 0) {
               PT_ACC_BEGIN();
-              for (int c = 0; c < r.channels; c++) {
+              for (int c = 0; c < r_chs; c++) {
                 const int idx = decode_scalar<LDS, UNI>(T, s_prefix, s_pkt, class_book, p);
                 if (idx == -2) {
                   err = kErrRuntime;
                   break;
                 }
-                if (idx >= 0 && idx < r.partvals) {
-                  row_set(c * pw_stride + entry_idx, idx);
+                if (idx >= 0 && idx < r_partvals) {
+                  for (int d = 0; d < cdim && partition_idx + d < partition_count; d++) row_set(c * pw_stride + partition_idx + d, class_of(idx, d));
                 } else {
                   stop = true;
                   stop_p = partition_idx; stop_c = 0; stop_pushed = false;
@@ -502,25 +590,50 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
             }
             for (int dimension_idx = 0; partition_idx < partition_count && dimension_idx < cdim && !stop && !err;
                  dimension_idx++, partition_idx++) {
-              const int offset = r.begin + partition_idx * r.partition_size;
-              for (int c = 0; c < r.channels; c++) {
-                const int word = row_get(c * pw_stride + entry_idx);
-                if (word < 0) {
+              const int offset = r_begin + partition_idx * r_psize;
+              for (int c = 0; c < r_chs; c++) {
+                // (UNI: launched only for setups whose decode maps are all in LDS: no global load on this path)
+                const int cls = row_get(c * pw_stride + partition_idx);
+                if (cls < 0) {
                   err = kErrRuntime;  // NullReferenceException on partWordCache
                   break;
                 }
-                const int cls = ipool_at(r.decode_map_off + (uint32_t)(word * cdim + dimension_idx));
                 if (SLAB && stage == 0) {
                   // the chain of this partition / channel: one record per cascade stage that has a book, consecutive, allocated
                   // now that its class is known (stage 0 visits every partition in order)
                   // (only the allocation happens here, where the lanes of the wavefront run one after the other; the list of
                   // chain heads is written behind the parse, from these rows)
                   const unsigned cm = r.book_mask[cls];
-                  row_set(last_base + partition_idx * r.channels + c, cm ? (int)nrec_alloc : -1);
+                  row_set(last_base + partition_idx * r_chs + c, cm ? (int)nrec_alloc : -1);
                   nrec_alloc += (uint32_t)__popc(cm);
                   if (nrec_alloc > (uint32_t)T.cap_ops) {
                     err = kErrRuntime;
                     break;
+                  }
+                }
+                int fast_done = 0;
+                if constexpr (UNI && SLAB && LDS) {
+                  // The visit from its descriptor (nvh_parse_format.h: NVH_PVIS_*; the launch guarantees the table): one 16-byte read
+                  // instead of the cascade test, the book number, the book's record and the slot arithmetic.  A vector that decodes
+                  // completely in windows -- all of them, on real material -- is done here: its record, the counters, on to the next
+                  // visit.  Whatever is left of one that does not (a long code, the packet's last bits) the general code below
+                  // finishes, from the entries decoded so far.
+                  const uint4 V = *reinterpret_cast<const uint4*>(s_prefix + vis_lds + 4u * (uint32_t)(cls * NVH_MAX_STAGES + stage));
+                  if (V.x == NVH_PVIS_NONE) continue;
+                  const uint32_t vslots = V.y & 0xFFFFu;
+                  if (V.x != NVH_PVIS_SLOW && nent + vslots <= (uint32_t)T.cap_ent && nops < (uint32_t)T.cap_ops && partition_idx <= 0xFFFF) {
+                    PT_ACC_BEGIN();
+                    int wdone = 0;
+                    const bool stuck = decode_windows(V.x & 0xFFFFFFu, (1u << (V.x >> 24)) - 1u, entries + ent_base + nent, (int)vslots, wdone);
+                    PT_ACC_END(0);
+                    if (!stuck && wdone == (int)vslots) {
+                      const int start = row_get(last_base + partition_idx * r_chs + c);
+                      if (PM(1)) recs[(uint32_t)start + ((V.y >> 24) & 7u)] = make_uint2((V.z & 0xFFFF0000u) | nent, V.w | ((uint32_t)c << 25));
+                      nent += vslots;
+                      ++nops;
+                      continue;
+                    }
+                    fast_done = wdone;
                   }
                 }
                 if ((r.cascade[cls] & (1 << stage)) == 0) continue;
@@ -542,9 +655,9 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                 op.channel = (uint8_t)c;
                 op.book = (uint8_t)book_idx;
                 bool push = false, bad = false;
-                if (r.type == 0) {
+                if (r_type == 0) {
                   // Residue0.WriteVectors (:180-201): decode all entries first, add only if all decoded
-                  const int steps = r.partition_size / dims;
+                  const int steps = r_psize / dims;
                   const uint32_t mark = nent;
                   if (nent + (uint32_t)steps > (uint32_t)T.cap_ent) {
                     err = kErrRuntime;
@@ -578,12 +691,12 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   // Residue1.WriteVectors (Residue1.cs:8-26) / Residue2.WriteVectors (Residue2.cs:23-47):
                   // vectors are added as they are decoded; a failed decode keeps what was added so far
                   // (partition_size + dims - 1) / dims by the book's reciprocal (exact: nvh_setup.hip checked the range)
-                  const int slots = dims > 1 ? (int)__umulhi((uint32_t)(r.partition_size + dims - 1), book.dim_magic) : r.partition_size;
+                  const int slots = dims > 1 ? (int)__umulhi((uint32_t)(r_psize + dims - 1), book.dim_magic) : r_psize;
                   if (nent + (uint32_t)slots > (uint32_t)T.cap_ent) {
                     err = kErrRuntime;
                     break;
                   }
-                  int done = 0;
+                  int done = fast_done;  // (UNI: entries the visit's fast form above has decoded already)
                   PT_ACC_BEGIN();
                   // The vector's entries, fast form: while the packet has 32 bits left, the code resolves in the book's LDS prefix
                   // table and slots remain, a symbol is a masked ds_read, a 64-bit shift and a 16-bit store in a loop with one
@@ -595,7 +708,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     const uint32_t pmask = (1u << book.prefix_bits) - 1u, toff = book.lds_off;
                     uint16_t* __restrict__ eout = entries + ent_base + nent;
                     // (one exit test: the table read is always in range, so it is not guarded)
-                    uint32_t node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                    uint32_t node = (UNI && LDS) ? 0u : s_prefix[toff + ((uint32_t)p.buf & pmask)];  // (UNI: read where it is needed)
                     auto consume = [&](const uint32_t len) {
                       p.buf >>= len;
                       p.avail -= len;
@@ -609,12 +722,19 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                       }
                     };
                     for (;;) {
-                      while (UNI ? (done < slots && p.total - p.pos >= 32u && (node & 0x80u) != 0u)
-                                 : (bool)((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)((node >> 7) & 1u))) {
+                      if constexpr (UNI && LDS) {
+                        // (decode_windows above: the vector's entries by windows of up to 63 start positions)
+                        const bool stuck = decode_windows(toff, pmask, eout, slots, done);
+                        if (stuck || !((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)(book.has_overflow != 0))) break;
+                        node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                        if (node & 0x80u) continue;  // (cannot happen: a window ends in front of a code only if it does not resolve)
+                      } else {
+                      while ((bool)((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)((node >> 7) & 1u))) {
                         consume(node & 0x7Fu);
                         eout[done] = (uint16_t)(node >> 8);
                         ++done;
                         node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                      }
                       }
                       // A code longer than the prefix (Codebook.cs:307-318), still 32 bits left: its slot's group of overflow nodes
                       // (decode_scalar's scan, same nodes in the same order) without leaving this loop -- the general loop below
@@ -656,7 +776,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     }
                     nent += (uint32_t)done;
                   }
-                  for (int i = done * dims; i < r.partition_size; i += dims) {
+                  for (int i = done * dims; i < r_psize; i += dims) {
                     const int e = decode_scalar<LDS, UNI>(T, s_prefix, s_pkt, book, p);
                     if (e == -2) {
                       err = kErrRuntime;
@@ -673,12 +793,12 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   if (err) break;
                   if (done > 0) {  // bounds of the adds the reference performed
                     const int last = done * dims - 1;
-                    if (r.type == 1) {
+                    if (r_type == 1) {
                       if (offset + last >= buflen) err = kErrRuntime;
                     } else {
                       // offset / real_channels + last / real_channels (Residue2.cs:27, :30-45) by the residue's reciprocal
-                      const int ob = r.real_channels > 1 ? (int)__umulhi((uint32_t)offset, r.rch_magic) : offset;
-                      const int lb = r.real_channels > 1 ? (int)__umulhi((uint32_t)last, r.rch_magic) : last;
+                      const int ob = r_rch > 1 ? (int)__umulhi((uint32_t)offset, r_rchm) : offset;
+                      const int lb = r_rch > 1 ? (int)__umulhi((uint32_t)last, r_rchm) : last;
                       if (ob + lb >= buflen) err = kErrRuntime;
                     }
                     if (err) break;
@@ -693,7 +813,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   }
                   if constexpr (SLAB) {
                     const unsigned cm = r.book_mask[cls];
-                    const int start = row_get(last_base + partition_idx * r.channels + c);
+                    const int start = row_get(last_base + partition_idx * r_chs + c);
                     const unsigned rank = (unsigned)__popc(cm & ((1u << stage) - 1u));
                     const uint32_t rw[2] = {NVH_SLAB_REC(op.ent_off - ent_base, book.slab_dm16, book.slab_lat & 0xFFFFu, book.slab_lat >> 16, dims, c,
                                                          stage, (cm >> (stage + 1)) != 0)};
@@ -703,7 +823,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                     ops[op_base + rel] = op;
                     uint16_t lk = (uint16_t)NVH_LINK_NONE;
                     if (rel >= (uint32_t)NVH_LINK_NONE) links_ok = false;
-                    const int last_i = last_base + partition_idx * r.channels + c;
+                    const int last_i = last_base + partition_idx * r_chs + c;
                     const int last = row_get(last_i);
                     if (last >= 0 && rel < (uint32_t)NVH_LINK_NONE) {
                       op_link[op_base + (uint32_t)last] = (uint16_t)((op_link[op_base + (uint32_t)last] & 0x8000u) | (uint16_t)rel);
@@ -729,20 +849,19 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
           // synthesis kernel needs no notion of a truncated chain.  `stage` is one past the stage the packet ended in.
           const int stop_stage = stage - 1;
           for (int pi = 0; pi < partition_count && !err; ++pi)
-            for (int c = 0; c < r.channels && !err; ++c) {
-              const int start = row_get(last_base + pi * r.channels + c);
+            for (int c = 0; c < r_chs && !err; ++c) {
+              const int start = row_get(last_base + pi * r_chs + c);
               if (start < 0) continue;
-              const int word = row_get(c * pw_stride + pi / cdim);
-              const int cls = ipool_at(r.decode_map_off + (uint32_t)(word * cdim + pi % cdim));
+              const int cls = row_get(c * pw_stride + pi);
               const unsigned cm = r.book_mask[cls];
-              for (int st = 0; st < r.max_stages; ++st) {
+              for (int st = 0; st < r_stages; ++st) {
                 if (!((cm >> st) & 1u)) continue;
                 const bool written = st < stop_stage ||
                                      (st == stop_stage && (pi < stop_p || (pi == stop_p && (c < stop_c || (c == stop_c && stop_pushed)))));
                 if (written) continue;
                 const NvhPBook book = books[r.books[cls][st]];
                 const int dims = book.dims;
-                const int slots = r.type == 0 ? r.partition_size / dims : (r.partition_size + dims - 1) / dims;
+                const int slots = r_type == 0 ? r_psize / dims : (r_psize + dims - 1) / dims;
                 if (nent + (uint32_t)slots > (uint32_t)T.cap_ent) {
                   err = kErrRuntime;
                   break;
@@ -753,8 +872,8 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
               }
             }
         }
-        s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin;
-        s_parts = err ? 0 : partition_count; s_chs = r.channels; s_b1 = r.alias_b1;
+        s_rtype = r_type; s_rch = r_rch; s_psz = r_psize; s_rbegin = r_begin;
+        s_parts = err ? 0 : partition_count; s_chs = r_chs; s_b1 = r.alias_b1;
       }
       if (SLAB) {
         if (!ran) { s_rtype = r.type; s_rch = r.real_channels; s_psz = r.partition_size; s_rbegin = r.begin; s_b1 = r.alias_b1; s_parts = 0; }
@@ -787,6 +906,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   }
 
   PT_T(3);
+  if constexpr (UNI) __threadfence_block();  // the entries the window decode's lanes stored are read by the packet's lane below
 #ifdef NVH_DEBUG
   if (dbg && active) { dbg[(long long)f * 24 + 8] = pt_acc[0]; dbg[(long long)f * 24 + 9] = pt_acc[1]; }
 #endif

@@ -227,7 +227,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
       s->ctx->parse_lds_attr_set = true;
     }
     // one packet per wavefront (every batch of up to 4096 packets): the wave-uniform form of the slab parser
-    const bool uni = slab_mode && in_lds && lanes == 1 && !nvh_toggles().no_parse_uni;
+    const bool uni = slab_mode && in_lds && lanes == 1 && T.dm_in_lds && !nvh_toggles().no_parse_uni;
     hipLaunchKernelGGL(uni ? k_parse_slab_u : slab_mode ? (in_lds ? k_parse_slab : k_parse_slab_g) : (in_lds ? k_parse : k_parse_g), dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
                        (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),

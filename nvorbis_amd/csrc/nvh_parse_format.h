@@ -62,11 +62,25 @@ struct NvhPResidue {  // Residue0.cs:21-33
   uint32_t decode_map_off;  // into the int pool: partvals * class_dims class numbers
   uint32_t rch_magic;       // ceil(2^32 / real_channels), 0 for one channel
   uint32_t general;         // its frames take the general bin walk (neither the pair path nor B-1 on its own; host_slab.h: residue_general)
-  uint32_t pad2;
+  uint32_t decode_map_lds;  // word offset of the same class numbers inside the LDS image, 0xFFFFFFFF: read them from the int pool
+  uint32_t vis_lds;         // word offset of the visit descriptors inside the LDS image (NVH_PVIS_*), 0xFFFFFFFF: none
   uint8_t cascade[NVH_MAX_CLASSES];
   int16_t books[NVH_MAX_CLASSES][NVH_MAX_STAGES];
   uint8_t book_mask[NVH_MAX_CLASSES];  // per class: the cascade stages that have a book (a chain of the slab has one record per set bit)
 };
+
+// Visit descriptors of a residue (k_parse_slab_u): four words per (class, cascade stage) -- everything a visit of the walk
+// (Residue0.cs:157-170: one partition of one channel in one stage) needs to know once the partition's class is known, so that
+// it is one 16-byte LDS read away from decoding: no cascade test, no book number, no 44-byte book record, no divisions.
+//   x: NVH_PVIS_NONE (the class has no book in this stage: nothing to do), NVH_PVIS_SLOW (a book the fast form does not take: a
+//      Residue0, a table in global memory, ...: the general code decides), else the book's prefix table in the LDS image (word
+//      offset, 24 bits) | prefix_bits << 24
+//   y: entries per partition | dims << 16 | rank << 24 (records of the chain in front of this stage's: popcount of the lower stages
+//      that have a book)
+//   z: the record's x word without the entry offset (ceil(2^16 / dims) << 16) | the book's number
+//   w: the record's y word without the channel (nvh_format.h: NVH_SLAB_REC: pool offset, lat_values, dims, stage, more)
+#define NVH_PVIS_NONE 0xFFFFFFFFu
+#define NVH_PVIS_SLOW 0xFFFFFFFEu
 
 struct NvhPMapping {  // Mapping.cs:16-78
   int32_t submaps, coupling_steps;
@@ -96,7 +110,8 @@ struct NvhDevParse {
   // slab carries a group list (nvh_format.h: NvhSlabHdr::group == 1); the walk's scratch then keeps one chain-start row PER PASS
   int32_t slab_general;
   int32_t row_words;      // ints of per-packet scratch: the class-word row + the chain-start rows (kernels_parse.hip: parse_body)
-  int32_t pad;
+  int32_t dm_in_lds;      // every residue's class decode map and visit descriptors have their copy in the LDS image (k_parse_slab_u
+                          // reads nothing else)
   // slab mode (the parser writes the synthesis kernels' slabs itself): the synthesis setup's floor records and reciprocal table,
   // the slab stride (the setup's worst case, 16-byte units; 0: this setup's batches take the descriptor kernels)
   const NvhDevFloor* dfloors;

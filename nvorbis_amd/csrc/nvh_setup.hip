@@ -331,13 +331,36 @@ int upload_parse_tables(nvh_stream* s) {
     for (const nvh::HuffNode& n : b.overflow_grouped) put(n);
     d.ovf_count = (uint32_t)b.overflow.size();
   }
-  // LDS image: residue VQ books first (most symbols of a packet), then class books, then floor books, while they fit
-  std::vector<uint32_t> lds_image;
+  // LDS image: the decode maps and visit descriptors, the residue VQ books, then the class and floor books, while they fit
+  std::vector<uint32_t> lds_image, dm_lds, vis_lds;
   {
-    const size_t budget = 13 * 1024;  // words (52 KB; + <= 8 KB of book / floor / residue / mapping records).  The residue books of a
-                                      // libvorbis setup fill it; floor and class books then come through L2 -- measured with 20 k / 24 k / 28 k
-                                      // words (everything resident): 0.57 -> 0.56 ms per 4096 packets, nil
+    const size_t budget = 16 * 1024;  // words (64 KB; + <= 8 KB of book / floor / residue / mapping records).  The residue books first:
+                                      // they fill 13 k words for a libvorbis setup, and one of them out of LDS costs more than
+                                      // everything else in it saves (round 6, class and floor books in front with 17 k words: the
+                                      // entry loops of a packet 200 k -> 980 k cycles, a parse 0.43 -> 0.74 ms); what is left goes to
+                                      // the class and floor books, whose symbols come through L2 at ~1-2 k cycles each otherwise.
     for (auto& d : books) d.lds_off = 0xFFFFFFFFu;
+    // In front of the books: the residues' class decode maps (Residue0.cs:60-76: class word -> the classes of its partitions), a
+    // few hundred words.  Every (stage, partition, channel) visit of the walk looks its class up; from the int pool in global
+    // memory that lookup made the visit wait for its memory round trip AND for every store still in flight (one counter serves
+    // both): half of a packet's parse time in the wave-uniform form.
+    dm_lds.assign(S.residues.size(), 0xFFFFFFFFu);
+    vis_lds.assign(S.residues.size(), 0xFFFFFFFFu);
+    for (size_t i = 0; i < S.residues.size(); i++) {
+      const std::vector<int>& dm = S.residues[i].decode_map;
+      if (dm.empty() || lds_image.size() + dm.size() > 1024) continue;
+      dm_lds[i] = (uint32_t)lds_image.size();
+      for (int v : dm) lds_image.push_back((uint32_t)v);
+    }
+    // ... and room for the visit descriptors (nvh_parse_format.h: NVH_PVIS_*), 16-byte aligned; filled in below, when the books
+    // have their places
+    for (size_t i = 0; i < S.residues.size(); i++) {
+      const size_t nw = (size_t)std::min(S.residues[i].classifications, NVH_MAX_CLASSES) * NVH_MAX_STAGES * 4;
+      while (lds_image.size() & 3u) lds_image.push_back(0u);
+      if (nw == 0 || lds_image.size() + nw > 3 * 1024) continue;
+      vis_lds[i] = (uint32_t)lds_image.size();
+      lds_image.resize(lds_image.size() + nw, 0u);
+    }
     std::vector<int> order;
     std::vector<char> seen(S.books.size(), 0);
     auto want = [&](int b) {
@@ -381,6 +404,39 @@ int upload_parse_tables(nvh_stream* s) {
       }
     }
     if (lds_image.empty()) lds_image.push_back(0u);
+    // the visit descriptors, now that the books have their places
+    for (size_t i = 0; i < S.residues.size(); i++) {
+      if (vis_lds[i] == 0xFFFFFFFFu) continue;
+      const nvh::Residue& r = S.residues[i];
+      for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++) {
+        unsigned mask = 0;
+        for (int k = 0; k < NVH_MAX_STAGES; k++)
+          if (k < r.max_stages && (r.cascade[c] & (1 << k)) && r.books[c][k] >= 0) mask |= 1u << k;
+        for (int k = 0; k < NVH_MAX_STAGES; k++) {
+          uint32_t* V = &lds_image[vis_lds[i] + 4u * (uint32_t)(c * NVH_MAX_STAGES + k)];
+          V[0] = NVH_PVIS_NONE; V[1] = V[2] = V[3] = 0;
+          // (the walk tests the cascade bit and the book number, Residue0.cs:160-163; a stage beyond max_stages is never visited)
+          if (!(r.cascade[c] & (1 << k)) || r.books[c][k] < 0) continue;
+          V[0] = NVH_PVIS_SLOW;
+          const int b = r.books[c][k];
+          if (b >= (int)S.books.size() || k >= r.max_stages) continue;
+          const NvhPBook& d = books[(size_t)b];
+          const uint32_t dims = d.dims;
+          if (r.type == 0 || !d.has_tree || d.lds_off == 0xFFFFFFFFu || d.lds_off > 0xFFFFFFu || d.prefix_bits < 1 || d.prefix_bits > 24 ||
+              dims < 1 || dims > 31 || b > 0xFFFF || r.partition_size < 1)
+            continue;
+          const uint32_t slots = ((uint32_t)r.partition_size + dims - 1) / dims;
+          const uint32_t lat_off = d.slab_lat & 0xFFFFu, lat_values = d.slab_lat >> 16;
+          if (slots > 0xFFFFu || lat_off > NVH_SLAB_MAX_LAT_OFF || lat_values > 0xFFu || d.slab_dm16 > 0xFFFFu) continue;
+          const uint32_t rank = (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
+          const uint32_t rw[2] = {NVH_SLAB_REC(0u, d.slab_dm16, lat_off, lat_values, dims, 0u, (uint32_t)k, (mask >> (k + 1)) != 0)};
+          V[0] = d.lds_off | ((uint32_t)d.prefix_bits << 24);
+          V[1] = slots | (dims << 16) | (rank << 24);
+          V[2] = (rw[0] & 0xFFFF0000u) | (uint32_t)b;
+          V[3] = rw[1];
+        }
+      }
+    }
   }
   std::vector<NvhPFloor1> floors(S.floors.size());
   for (size_t i = 0; i < S.floors.size(); i++) {
@@ -416,6 +472,8 @@ int upload_parse_tables(nvh_stream* s) {
     d.rch_magic = r.real_channels > 1 ? (uint32_t)((0x100000000ull + (uint64_t)r.real_channels - 1) / (uint64_t)r.real_channels) : 0u;
     if ((uint64_t)S.block1 * (uint64_t)std::max(S.channels, 1) * (uint64_t)std::max(r.real_channels, 1) >= 0x100000000ull) return NVH_OK;
     d.decode_map_off = (uint32_t)ipool.size();
+    d.decode_map_lds = dm_lds[i];
+    d.vis_lds = vis_lds[i];
     ipool.insert(ipool.end(), r.decode_map.begin(), r.decode_map.end());
     int min_dims = 1 << 30;
     for (int c = 0; c < NVH_MAX_CLASSES; c++) {
@@ -516,7 +574,9 @@ int upload_parse_tables(nvh_stream* s) {
   P.meta_floors_off = (int32_t)(o_fl - o_bk);
   P.meta_residues_off = (int32_t)(o_rs - o_bk);
   P.meta_mappings_off = (int32_t)(o_mp - o_bk);
-  P.pad = 0;
+  P.dm_in_lds = 1;
+  for (uint32_t o : dm_lds) if (o == 0xFFFFFFFFu) P.dm_in_lds = 0;
+  for (uint32_t o : vis_lds) if (o == 0xFFFFFFFFu) P.dm_in_lds = 0;
   P.slab_general = 0;
   P.row_words = 2 * cap_parts;
   // slab mode: setups inside the slab kernels' contract whose frames have one residue pass, lattice offsets and values a record
