@@ -236,7 +236,10 @@ int nvh_stream_pending_geometry(const nvh_stream *s, int32_t *out, int cap_frame
 int nvh_stream_pending(const nvh_stream *s, int *frames, int64_t *pcm_samples_per_channel);
 /* The pending frames in the form the synthesis kernels fetch (per-frame slabs: the integer half of Floor1.Apply --
  * UnwrapPosts and the walk over the sorted posts, Floor1.cs:196-297 -- as line segments, the vector writes of
- * Residue0.cs:132-175 / Residue2.cs:23-47 as chain-major records), written by the host parser's thread.  Host only, for
+ * Residue0.cs:132-175 / Residue2.cs:23-47 as chain-major records; the entry section in DIGIT form for setups whose residue books
+ * have at most 63 lattice values (nvh_format.h: NVH_SLAB_RGEOM_DIGITS -- one byte per vector component, the byte offset of its
+ * float from the book's first word in the value pool; a record's x then counts 2-byte units of that section, its y holds the
+ * book's value-pool offset), else as uint16 entry numbers), written by the host parser's thread.  Host only, for
  * tests and tools: buf receives the slabs back to back, first_unit[f] the first 16-byte unit of frame f's slab
  * (first_unit[frames] = total units).  NVH_ERR_UNSUPPORTED: the stream shape is outside the slab kernels' contract.
  * *bytes is set even when cap is too small (NVH_ERR_ARGUMENT then). */
@@ -244,8 +247,10 @@ int nvh_stream_pending_slabs(const nvh_stream *s, uint8_t *buf, int64_t cap, int
                              int cap_frames);
 /* The setup's lattice pool as the synthesis kernels hold it: per lattice codebook (Codebook.cs:222-283, lookup type 1 without
  * sequence_p) its distinct component values as float bits, then the reciprocals ceil(2^32 / lat_values^i) for i < dimensions;
- * a slab record's lattice offset points at a book's first value.  Host only, for tests and tools.  *words is set even when
- * cap_words is too small (NVH_ERR_ARGUMENT then). */
+ * a slab record of the ENTRY form points at a book's first value there.  Behind it -- only for setups that take the digit form --
+ * the VALUE pool: per book its distinct values again, then +0.0f (where the bytes of a vector that was never added point); a slab
+ * record of the DIGIT form holds the offset of the book's first value-pool word, counted from the lattice pool's start.  Host only,
+ * for tests and tools.  *words is set even when cap_words is too small (NVH_ERR_ARGUMENT then). */
 int nvh_stream_lattice_pool(const nvh_stream *s, uint32_t *out, int64_t cap_words, int64_t *words);
 
 /* Synthesise the pending batch: H2D descriptors -> kernels -> interleaved PCM.  Exactly one of
