@@ -79,6 +79,7 @@ struct NvhSynthArgs {
   int f0, fstep;            // workgroup b synthesises frame f0 + b * fstep (paired emission: odd frames, then even frames)
   int nframes;              // frames of the batch (frame groups: a group's frames beyond the batch's end are skipped)
   int xcd_map;              // frames in eight contiguous runs, one per XCD (kernels_synth.hip: synth_body)
+  int walk_two;             // frame groups of two: the two frames' residue walks in one loop (kernels_synth.hip: residue_walk_two)
   int prefetch_prev;        // paired emission, odd launch: workgroup b touches the slab of frame f - 1, which workgroup b of the even
                             // launch fetches next -- on the same XCD (workgroups go round the XCDs by index), so from that XCD's L2
   // paired emission (nvh_format.h: NVH_EMIT_*); pcm == nullptr: off, every frame leaves its plane for k_ola_compact

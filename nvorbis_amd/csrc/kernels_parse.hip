@@ -568,7 +568,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         bool stop_pushed = false;
         for (; stage < r_stages && !stop && !err; stage++) {
           pass.op_begin[stage] = op_base + nops;
-          for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count && !stop && !err; entry_idx++) {
+          for (int partition_idx = 0; partition_idx < partition_count && !stop && !err;) {
             if (stage == 0) {
               PT_ACC_BEGIN();
               for (int c = 0; c < r_chs; c++) {

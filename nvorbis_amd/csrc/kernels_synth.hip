@@ -314,6 +314,114 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
 }
 
 
+// The same walk for the TWO frames of a frame group at once (digit form, eight components per lane, stereo Residue2 with the floor
+// multiply fused: the shape of every libvorbis stereo stream): a lane takes its chain group of frame 0 AND its chain group of frame 1
+// through the cascade stages in one loop, so that the two chains' LDS round trips -- record, digit bytes, eight values, per stage --
+// are in flight together instead of one chain after the other (a workgroup's two walks were 10 k of its 27-31 k cycles, each a
+// chain of dependent reads: profiles/r06_group_phases.txt).  Branch-free inside the loop: a chain that has ended (or a lane without
+// a group in that frame) re-reads its last record and adds +0.0f, the identity on these sums.  Same additions, same order per
+// element as residue_walk.
+struct WalkFrame {
+  const float* slab;
+  unsigned off_heads, off_rec, off_ent, nheads, lpc, lpc_magic, flags;
+  float* spec;
+  int half;
+  FloorRef F;
+};
+
+template <int NT>
+__device__ __forceinline__ void residue_walk_two(const WalkFrame (&W)[2], const uint32_t* __restrict__ s_lat, int tid) {
+  constexpr int G = 8;
+  const uint32_t* heads[2];
+  const uint2* recs[2];
+  const uint8_t* ent[2];
+  unsigned total[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    heads[f] = reinterpret_cast<const uint32_t*>(W[f].slab + W[f].off_heads * 4);
+    recs[f] = reinterpret_cast<const uint2*>(W[f].slab + W[f].off_rec * 4);
+    ent[f] = reinterpret_cast<const uint8_t*>(W[f].slab + W[f].off_ent * 4);
+    total[f] = W[f].nheads * W[f].lpc;  // >= 1 (the caller)
+  }
+  const unsigned tmax = total[0] > total[1] ? total[0] : total[1];
+  for (unsigned idx = tid; idx < tmax; idx += NT) {
+    bool act[2], more[2];
+    unsigned o[2], xbase[2], i0[2];
+    uint2 rec[2];
+    float a[2][G];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      act[f] = idx < total[f];
+      const unsigned ii = act[f] ? idx : 0u;  // (a lane without a group in this frame walks group 0 and stores nothing)
+      const unsigned oq = W[f].lpc > 1 ? __umulhi(ii, W[f].lpc_magic) : ii;
+      i0[f] = (ii - oq * W[f].lpc) * G;
+      const unsigned hd = heads[f][oq];
+      o[f] = hd & 0xFFFFu;
+      xbase[f] = hd >> 16;
+      rec[f] = recs[f][o[f]];
+      more[f] = act[f];
+#pragma unroll
+      for (int k = 0; k < G; ++k) a[f][k] = 0.0f;
+    }
+    while (more[0] | more[1]) {
+      float v[2][G];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const char* vb = reinterpret_cast<const char*>(s_lat) + ((rec[f].y & 0xFFFu) << 2);
+        const uint8_t* db = ent[f] + ((rec[f].x & 0xFFFFu) << 1) + i0[f];
+        const uint2 w = *reinterpret_cast<const uint2*>(db);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[f][k] = *reinterpret_cast<const float*>(vb + ((w.x >> (8 * k)) & 0xFFu));
+          v[f][4 + k] = *reinterpret_cast<const float*>(vb + ((w.y >> (8 * k)) & 0xFFu));
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        // (the +0.0f of a chain that has ended as a bit mask on the value, not as a select: the compiler turns a select into a
+        // branch around that frame's loads, and the two frames' reads then queue up behind one another again)
+        const uint32_t keep = more[f] ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int k = 0; k < G; ++k) a[f][k] = a[f][k] + __uint_as_float(__float_as_uint(v[f][k]) & keep);
+        more[f] = more[f] && (rec[f].y & 0x80000000u) != 0u;
+        o[f] += more[f] ? 1u : 0u;
+        rec[f] = recs[f][o[f]];
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      if (!act[f]) continue;
+      // a[2m] / a[2m + 1] = bin xb + m of channel 0 / 1 (residue_walk: interleaved, FUSE, G == 8)
+      const unsigned xb = xbase[f] + (i0[f] >> 1);
+      if (W[f].flags & NVH_SLAB_SWEEP_COUPLES) {  // Mapping.cs:137-182
+        if (!(W[f].flags & NVH_SLAB_MG1)) {
+#pragma unroll
+          for (int m = 0; m < G / 2; ++m) couple1(a[f][2 * m], a[f][2 * m + 1]);
+        } else {
+#pragma unroll
+          for (int m = 0; m < G / 2; ++m) couple1(a[f][2 * m + 1], a[f][2 * m]);
+        }
+      }
+      if (xb + 4 <= (unsigned)W[f].half) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (W[f].F.md[c] == 1) {
+            float m[4];
+            floor_walk_fx<4>(W[f].F.seg[c], W[f].F.tab[c], W[f].F.s_db, (int)xb, m);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[f][2 * q + c] = a[f][2 * q + c] * m[q];
+          } else if (W[f].F.md[c] == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[f][2 * q + c] = 0.0f;  // Floor1.cs:218-221
+          }
+        }
+        *reinterpret_cast<float4*>(W[f].spec + xb) = make_float4(a[f][0], a[f][2], a[f][4], a[f][6]);
+        *reinterpret_cast<float4*>(W[f].spec + (unsigned)W[f].half + xb) = make_float4(a[f][1], a[f][3], a[f][5], a[f][7]);
+      }
+    }
+  }
+}
+
 // Residue2 whose partitions share bins (quirk B-1: `offset /= channels` truncates and chPtr restarts at 0 for every partition,
 // Residue2.cs:25-27): component q of partition p lands in channel q % rch, bin (begin + p psz) / rch + q / rch, so
 // when psz is not a multiple of rch the last bin of a partition is the first bin of the next one, and an element receives the
@@ -1454,6 +1562,14 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int nch = A.channels;
   const int fa = A.f0 + (int)blockIdx.x * A.fstep;  // the group's first frame
+#ifdef NVH_DEBUG
+  // profiling build: shader-clock stamps of thread 0 in the row of the group's first frame (tools/dbg_phase_group.py): 0 entry,
+  // 1 slabs + constants arrived, 2 / 3 the frames' walks, 4 table + barrier, 5 transform of wavefront 0, 6 staging drained, 7 emitted
+#define GR_T(k) do { if (dbg && tid == 0 && fa < A.nframes) dbg[(long long)fa * 24 + (k)] = clock64(); } while (0)
+#else
+#define GR_T(k) do { } while (0)
+#endif
+  GR_T(0);
   const int half_max = A.block1 >> 1, pad_max = A.block1 >> 4;
   float* s_db = smem;
   const uint32_t* s_lat = reinterpret_cast<const uint32_t*>(smem + 256);
@@ -1515,16 +1631,49 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
   }
   __syncthreads();  // drains the DMA (vmcnt(0)) in front of the barrier
   if (!any) return;
+  GR_T(1);
 
   // a slab's header word i, from its LDS image (uniform)
   auto hdr = [&](int k, int i) { return __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t*>(slab0 + k * slab_words)[i]); };
   // ---- spectra, frame by frame (every barrier inside is the whole workgroup's) ----
   {
+    // (two frames of the common shape -- digit form, stereo Residue2, fused floor multiply -- walk together: residue_walk_two)
+    bool together = false;
+    if constexpr (FPW == 2) {
+      WalkFrame W[2];
+      together = A.walk_two != 0;
 #pragma unroll
-    for (int k = 0; k < FPW; ++k)
+      for (int k = 0; k < 2; ++k) {
+        const unsigned w1 = hdr(k, 1), w2 = hdr(k, 2), w4 = hdr(k, 4), flags = w0[k] >> 24, rgeom = (w4 >> 16) & 0xFFu;
+        W[k].slab = slab0 + k * slab_words;
+        W[k].nheads = w1 & 0xFFFFu; W[k].off_heads = w2 & 0xFFFFu; W[k].off_rec = w2 >> 16; W[k].off_ent = w3[k] & 0xFFFFu;
+        W[k].lpc = w4 & 0xFFFFu; W[k].lpc_magic = hdr(k, 5); W[k].flags = flags;
+        W[k].spec = spec0 + k * region; W[k].half = nn[k] >> 1;
+        together = together && nn[k] != 0 && (flags & NVH_SLAB_FUSE_FLOOR) && !(flags & NVH_SLAB_FLOOR_FAULT) &&
+                   rgeom == (2u | NVH_SLAB_RGEOM_DIGITS | (2u << 4)) && (w4 >> 24) == 8u && W[k].nheads * W[k].lpc != 0u;
+        const uint32_t* s_chan = reinterpret_cast<const uint32_t*>(W[k].slab) + 8;
+        const unsigned c0w = __builtin_amdgcn_readfirstlane(s_chan[0]), c1w = __builtin_amdgcn_readfirstlane(s_chan[1]);
+        const unsigned cw[2] = {c0w, c1w};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned ns = (cw[c] >> 8) & 0xFFu, oseg = cw[c] >> 16;
+          W[k].F.seg[c] = reinterpret_cast<const uint4*>(W[k].slab + oseg * 4);
+          W[k].F.tab[c] = reinterpret_cast<const uint8_t*>(W[k].slab + (oseg + ns) * 4);
+          W[k].F.md[c] = (int)(cw[c] & 0xFFu);
+        }
+        W[k].F.s_db = s_db;
+      }
+      if (together) residue_walk_two<NT>(W, s_lat, tid);
+      if (together) { GR_T(2); GR_T(3); }
+    }
+    if (!together)
+#pragma unroll
+    for (int k = 0; k < FPW; ++k) {
       if (nn[k] != 0)
         synth_frame_spectrum<NT, 2, false>(A, s_db, s_lat, slab0 + k * slab_words, spec0 + k * region, w0[k], hdr(k, 1), hdr(k, 2),
                                            w3[k], hdr(k, 4), hdr(k, 5), hdr(k, 7), tid);
+      if (k < 2) GR_T(2 + k);
+    }
   }
 
   // ---- what this workgroup emits: overlap j = the PCM of the group's frame j (j = FPW: of the frame behind the group) ----
@@ -1611,6 +1760,7 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
 #pragma unroll
   for (int k = 0; k < FPW; ++k) cwin[k] = cout_k[k] ? hdr(k, 10) : 0u;
   __syncthreads();  // the walks are through everywhere: constants and slabs are dead, the spectra complete
+  GR_T(4);
 
   // ---- stage the neighbours' quarters (import groups): B(first - 1), A(last + 1) ----
   float* stageB = smem;
@@ -1700,7 +1850,9 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
       lds_barrier();  // the one barrier every transforming wavefront passes inside imdct_wave_sink<.., WGSYNC, .., LDSBAR>
     }
   }
+  GR_T(5);
   __syncthreads();  // drains the staging DMA; every own quarter is in LDS, every plane store of the workgroup is issued
+  GR_T(6);
 
 #pragma unroll
   for (int k = 0; k < FPW; ++k)
@@ -1809,6 +1961,8 @@ __device__ __forceinline__ void synth_group_body(const NvhSynthArgs& A, float* s
     }
   }
   if (A.clip && emit) report_clipped(clipped, A.clipped_flag);
+  GR_T(7);
+#undef GR_T
 }
 
 // 8 waves per SIMD = 8 resident workgroups per CU: the register budget (64 VGPRs) is part of the design

@@ -23,6 +23,7 @@ const NvhToggles& nvh_toggles() {
     x.emit8 = on("NVH_EMIT8");
     x.no_emit8 = on("NVH_NO_EMIT8");
     x.no_prefetch = on("NVH_NO_PREFETCH");
+    x.no_walk_two = on("NVH_NO_WALK_TWO");
     x.fpw = std::getenv("NVH_FPW") ? num("NVH_FPW") : 2;
     if (x.fpw != 1 && x.fpw != 2 && x.fpw != 4) x.fpw = 2;
     x.copy_upload = on("NVH_COPY_UPLOAD");

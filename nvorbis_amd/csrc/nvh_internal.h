@@ -131,6 +131,7 @@ struct NvhToggles {
   bool copy_upload;  // NVH_COPY_UPLOAD: a GPU-parse batch's input goes up by copy commands instead of k_parse_fetch (A/B aid)
   int fpw;           // NVH_FPW: frames per workgroup of the mono / stereo synthesis with paired emission (kernels_synth.hip: frame groups):
                      // 1 = k_synth + k_synth_emit (the round-3..5 form), 2 (default) = k_synth_group2, 4 = k_synth_group4
+  bool no_walk_two;  // NVH_NO_WALK_TWO: a frame group's two residue walks one after the other (A/B aid)
   bool no_prefetch;  // NVH_NO_PREFETCH: the odd launch of a paired-emission pass does not touch the even launch's slabs (A/B aid)
   bool uncached_planes;  // NVH_UNCACHED_PLANES: a batch's work planes in hipDeviceMallocUncached memory (the round-4 experiment whose
                          // wrong PCM with GPU-parsed batches was never explained: tools/repro_uncached.py)

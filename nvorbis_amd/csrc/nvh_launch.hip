@@ -722,6 +722,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
     A.nframes = b->nframes;
     A.prefetch_prev = 0;
     A.xcd_map = 0;
+    A.walk_two = nvh_toggles().no_walk_two ? 0 : 1;
     const bool wide = slab_wide(s);
     // paired emission (nvh_format.h: NVH_EMIT_*): the host marked the frames at upload; it needs the PCM buffer and the slabs
     // in frame order
