@@ -363,6 +363,9 @@ __device__ __forceinline__ void residue_walk_two(const WalkFrame (&W)[2], const 
 #pragma unroll
       for (int k = 0; k < G; ++k) a[f][k] = 0.0f;
     }
+#ifdef NVH_ABL_NO_CHAIN2
+    more[0] = more[1] = false;  // (ablation build: the walk without its cascade stages)
+#endif
     while (more[0] | more[1]) {
       float v[2][G];
 #pragma unroll
@@ -403,9 +406,16 @@ __device__ __forceinline__ void residue_walk_two(const WalkFrame (&W)[2], const 
         }
       }
       if (xb + 4 <= (unsigned)W[f].half) {
+        // (the four curves of a lane -- two frames x two channels -- side by side, their table, segment and inverse_dB_table reads in
+        // flight together, the segment behind each fetched with it: built and measured, round 6 -- 80 instead of 69 VGPRs, 220 -> 210 M
+        // frames/s over three streams; these four chains one after the other stay)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+#ifdef NVH_ABL_NO_FLOOR2
+          if (false) {  // (ablation build: the walk without its floor multiply)
+#else
           if (W[f].F.md[c] == 1) {
+#endif
             float m[4];
             floor_walk_fx<4>(W[f].F.seg[c], W[f].F.tab[c], W[f].F.s_db, (int)xb, m);
 #pragma unroll
