@@ -252,6 +252,11 @@ int nvh_stream_pending_slabs(const nvh_stream *s, uint8_t *buf, int64_t cap, int
  * record of the DIGIT form holds the offset of the book's first value-pool word, counted from the lattice pool's start.  Host only,
  * for tests and tools.  *words is set even when cap_words is too small (NVH_ERR_ARGUMENT then). */
 int nvh_stream_lattice_pool(const nvh_stream *s, uint32_t *out, int64_t cap_words, int64_t *words);
+/* The setup's VQ table pool (Codebook.cs:222-283: every book's lookup table, entries x dimensions floats, book after book).  A
+ * slab record that names a book with an EXPLICIT table (lookup type 2, or type 1 with sequence_p: lat_values = 0 in the record)
+ * points at one word of the lattice pool, that book's offset in this pool; component d of entry e is float offset + e * dim + d.
+ * Host only, for tests and tools.  *floats is set even when cap_floats is too small (NVH_ERR_ARGUMENT then). */
+int nvh_stream_vq_pool(const nvh_stream *s, float *out, int64_t cap_floats, int64_t *floats);
 
 /* Synthesise the pending batch: H2D descriptors -> kernels -> interleaved PCM.  Exactly one of
  * pcm_host / d_pcm is non-NULL; capacity is in floats and must hold pending samples * channels.

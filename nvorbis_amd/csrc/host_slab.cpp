@@ -148,6 +148,10 @@ int floor1_segments(const Floor1& f, const uint16_t* posts, int post_count, int 
   return ns;
 }
 
+// A book the slab walks can take: a lattice book (digits or entry numbers) or one with an explicit table (entry numbers, the
+// component gathered from the VQ pool); a book without a lookup (map type 0) has no vectors to add.
+static inline bool book_has_vectors(const NvhDevBook& bk) { return bk.lat_values != 0 || bk.tab_off != 0xFFFFFFFFu; }
+
 bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r) {
   if (r.type != 2 || r.real_channels < 3 || r.real_channels > NVH_SLAB_MAX_CH) return false;
   if (r.begin % r.real_channels == 0 && r.partition_size % r.real_channels == 0) return false;  // no aliasing at all
@@ -158,7 +162,7 @@ bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r) {
       const int b = r.books[c][k];
       if (b < 0) continue;
       const NvhDevBook& bk = X.books[(size_t)b];
-      if (bk.lat_values == 0 || bk.dim == 0 || (bk.dim & 1u) || (uint32_t)r.partition_size % bk.dim != 0) return false;
+      if (!book_has_vectors(bk) || bk.dim == 0 || (bk.dim & 1u) || (uint32_t)r.partition_size % bk.dim != 0) return false;
       max_div = std::max<uint64_t>(max_div, bk.dim);
     }
   // the walk's reciprocal multiplies are exact while index * divisor < 2^32 (nvh_setup.hip: NvhDevResidue::fast -- the same
@@ -176,7 +180,7 @@ bool residue_pair_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
       const int b = r.books[c][k];
       if (b < 0) continue;
       const NvhDevBook& bk = X.books[(size_t)b];
-      if (bk.lat_values == 0 || bk.dim == 0 || (bk.dim & 1u) || (uint32_t)r.partition_size % bk.dim != 0) return false;
+      if (!book_has_vectors(bk) || bk.dim == 0 || (bk.dim & 1u) || (uint32_t)r.partition_size % bk.dim != 0) return false;
       max_div = std::max<uint64_t>(max_div, bk.dim);
     }
   // (the reciprocal multiplies of the walk are exact while index * divisor < 2^32: nvh_setup.hip, NvhDevResidue::fast)
@@ -229,7 +233,7 @@ bool residue_general_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
       const int b = r.books[c][k];
       if (b < 0) continue;
       const NvhDevBook& bk = X.books[(size_t)b];
-      if (bk.lat_values == 0 || bk.lat_values > 0xFFu || bk.dim == 0 || bk.dim > 16u || psz % bk.dim != 0) return false;
+      if (!book_has_vectors(bk) || bk.lat_values > 0xFFu || bk.dim == 0 || bk.dim > 16u || psz % bk.dim != 0) return false;
       // the walk's divisions: i / dim by the 16-bit reciprocal, and (Residue0) i dim / partition_size by the 32-bit one
       if (((psz * bk.dim_magic16) >> 16) != psz / bk.dim) return false;
       for (uint32_t i = 0; i < psz; i++) {
@@ -730,6 +734,13 @@ void build_book_directory(const Setup& S, SlabSetup& X, std::vector<float>& vq, 
     } else {
       books[i].tab_off = (uint32_t)vq.size();
       vq.insert(vq.end(), b.lookup.begin(), b.lookup.end());
+      if (books[i].lat_values == 0) {
+        // A book with an explicit table (Codebook.cs:262-281: lookup type 2, or type 1 with sequence_p): its place in the lattice
+        // pool is ONE word, the table's offset in the VQ pool -- a slab record then says lat_values = 0 and points at that word,
+        // and the walks of the synthesis kernels gather the component out of the table (kernels_synth.hip: table_value).
+        books[i].lat_off = (uint32_t)lattice.size();
+        lattice.push_back(books[i].tab_off);
+      }
     }
   }
   // the digit form (host_slab.h): value pool behind the lattice pool, digit bytes of every entry

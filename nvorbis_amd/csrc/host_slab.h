@@ -32,6 +32,9 @@ struct SlabSetup {
   // the lattice pool as the device holds it (build_book_directory), kept for nvh_stream_lattice_pool: what a record's lattice
   // offset points into
   std::vector<uint32_t> lattice;
+  // the VQ table pool (build_book_directory), kept for nvh_stream_vq_pool: what the one lattice-pool word of a book with an explicit
+  // table points into
+  std::vector<float> vq;
   // Digit form of a slab's vector entries (round 5; nvh_format.h: NVH_SLAB_RGEOM_DIGITS).  A lattice book's entry number is
   // its components' digits in base lat_values (Codebook.cs:242-260); peeling them is integer work, so the parser does it: the
   // slab carries one byte per vector component, digit * 4 = the byte offset of the component's value from the book's first word

@@ -72,6 +72,7 @@ struct NvhSynthArgs {
   const float* mdct_c[2];
   const float* mdct_tw[2];
   const int32_t* ipool;     // Floor0 Bark maps (NvhDevSetup::ipool)
+  const float* vq;          // the VQ pool (NvhDevSetup::vq): books with an explicit table are gathered from it (kernels_synth.hip: table_value)
   const NvhFrame* frames;   // the batch's frame records (k_synth8_emit reads the overlaps' windows and output positions from them)
   int const_vecs, stride_vecs, cap_vecs;  // cap_vecs: largest slab of the batch
   int lds_vecs;             // the LDS slab area (>= cap_vecs; paired emission stages the neighbours' quarters over constants + slab)

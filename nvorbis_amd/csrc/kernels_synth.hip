@@ -85,6 +85,16 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
   return v;
 }
 
+// Component `comp` of entry e of a book with an explicit table (Codebook.cs:262-281: lookup type 2, or type 1 with sequence_p -- the
+// host built the table the way the reference does, host_setup.cpp): a slab record names such a book by lat_values = 0 and points at
+// ONE word of the lattice pool, the table's offset in the VQ pool (host_slab.cpp: build_book_directory).  Entry form only (the digit
+// form is for setups whose residue books are all lattice books).  The component comes from global memory (L2): these are the
+// streams that took the descriptor kernels through round 5, which gather the same way.
+__device__ __forceinline__ float table_value(const float* __restrict__ vq, const uint32_t* lat, unsigned dims, unsigned e, unsigned comp) {
+  const unsigned es = e != NVH_ENTRY_SKIP ? e : 0u;  // ("no vector was added here": the caller adds +0.0f; the address stays inside the table)
+  return vq[lat[0] + es * dims + comp];
+}
+
 // Residue adds of one frame (Residue1.cs:8-26, Residue2.cs:23-47 WriteVectors for lattice books).  A lane owns G consecutive
 // vector components of one partition / channel (a "chain": the writes to it through the cascade stages are consecutive
 // records) and keeps their running sums in registers from the first stage to the last: the reference's additions, in the
@@ -141,7 +151,7 @@ template <int G, bool FUSE = false, int RCH = 0, int NT = SP_THREADS, bool DIG =
 __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
                                              const uint32_t* __restrict__ s_lat, float* spec, int half, unsigned nheads,
                                              unsigned lpc, unsigned lpc_magic, bool interleaved, unsigned flags, int tid,
-                                             const FloorRef* F = nullptr) {
+                                             const FloorRef* F = nullptr, const float* __restrict__ vq = nullptr) {
   static_assert(RCH == 0 || G == 2 * RCH, "two bins of every channel per lane");
   const uint32_t* heads = reinterpret_cast<const uint32_t*>(slab + off_heads * 4);
   const uint2* recs = reinterpret_cast<const uint2*>(slab + off_rec * 4);
@@ -189,6 +199,19 @@ __device__ __forceinline__ void residue_walk(const float* slab, unsigned off_hea
       const unsigned dims = (rec.y >> 20) & 31u, lv = (rec.y >> 12) & 0xFFu, dm16 = rec.x >> 16;
       const uint32_t* lat = s_lat + (rec.y & 0xFFFu);
       const uint16_t* eb = ent + (rec.x & 0xFFFFu);
+      if (lv == 0u) {  // a book with an explicit table: the components out of the VQ pool (table_value)
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          const unsigned i = i0 + k;
+          const unsigned j = (i * dm16) >> 16;  // i / dims
+          const unsigned e = eb[j];
+          const float v = table_value(vq, lat, dims, e, i - j * dims);
+          a[k] = a[k] + (e != NVH_ENTRY_SKIP ? v : 0.0f);
+        }
+        if (!(rec.y & 0x80000000u)) break;
+        rec = recs[++o];
+        continue;
+      }
       const unsigned lvm = lat[lv + 1];  // ceil(2^32 / lv): the second of the book's power magics (dims >= 2)
       // Branch-free on purpose: every entry of the group is fetched first, then the digits, then the lattice values, so
       // that the LDS round trips of the group overlap instead of queueing behind exec-mask regions.  A skipped entry
@@ -442,7 +465,7 @@ __device__ __forceinline__ void residue_walk_two(const WalkFrame (&W)[2], const 
 template <int NT, bool DIG = false>
 __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
                                                   unsigned off_bins, unsigned psz_magic, const uint32_t* __restrict__ s_lat,
-                                                  float* spec, int half, unsigned rch, int tid) {
+                                                  float* spec, int half, unsigned rch, int tid, const float* __restrict__ vq = nullptr) {
   const uint32_t* heads = reinterpret_cast<const uint32_t*>(slab + off_heads * 4);
   const uint2* recs = reinterpret_cast<const uint2*>(slab + off_rec * 4);
   const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
@@ -500,10 +523,15 @@ __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned of
           const unsigned qq = in ? q : 0u;
           const unsigned j = (qq * dm16) >> 16, comp = qq - j * dims;
           const unsigned e = eb[j];
-          const unsigned pw = lat[lv + comp];
-          const unsigned qv = comp ? __umulhi(e, pw) : e;
-          const unsigned dgt = qv - __umul24(__umulhi(qv, lvm), lv);
-          const float v = __uint_as_float(lat[dgt]);
+          float v;
+          if (lv == 0u) {
+            v = table_value(vq, lat, dims, e, comp);
+          } else {
+            const unsigned pw = lat[lv + comp];
+            const unsigned qv = comp ? __umulhi(e, pw) : e;
+            const unsigned dgt = qv - __umul24(__umulhi(qv, lvm), lv);
+            v = __uint_as_float(lat[dgt]);
+          }
           a[c] = a[c] + ((in && e != NVH_ENTRY_SKIP) ? v : 0.0f);  // +0.0f is the identity on these sums (they start at +0.0f)
         }
       }
@@ -534,7 +562,7 @@ __device__ __forceinline__ void residue_walk_bins(const float* slab, unsigned of
 template <int NT, int MAXC, bool DIG = false>
 __device__ __forceinline__ void residue_walk_general(const float* slab, unsigned off_heads, unsigned off_rec, unsigned off_ent,
                                                      unsigned off_gen, const uint32_t* __restrict__ s_lat, float* spec, int half,
-                                                     int tid) {
+                                                     int tid, const float* __restrict__ vq = nullptr) {
   const uint32_t* heads = reinterpret_cast<const uint32_t*>(slab + off_heads * 4);
   const uint2* recs = reinterpret_cast<const uint2*>(slab + off_rec * 4);
   const uint16_t* ent = reinterpret_cast<const uint16_t*>(slab + off_ent * 4);
@@ -606,10 +634,15 @@ __device__ __forceinline__ void residue_walk_general(const float* slab, unsigned
               a[c] = a[c] + (in ? v : 0.0f);
             } else {
             const unsigned e = eb[j];
-            const unsigned pw = lat[lv + comp];
-            const unsigned qv = comp ? __umulhi(e, pw) : e;
-            const unsigned dgt = qv - __umul24(__umulhi(qv, lvm), lv);
-            const float v = __uint_as_float(lat[dgt]);
+            float v;
+            if (lv == 0u) {
+              v = table_value(vq, lat, dims, e, comp);
+            } else {
+              const unsigned pw = lat[lv + comp];
+              const unsigned qv = comp ? __umulhi(e, pw) : e;
+              const unsigned dgt = qv - __umul24(__umulhi(qv, lvm), lv);
+              v = __uint_as_float(lat[dgt]);
+            }
             a[c] = a[c] + ((in && e != NVH_ENTRY_SKIP) ? v : 0.0f);
             }
           }
@@ -1176,7 +1209,7 @@ __device__ __forceinline__ void synth_frame_spectrum(const NvhSynthArgs& A, cons
 #define NVH_WALK(G, FUSE, RCH, FP)                                                                                                 \
   do {                                                                                                                             \
     if (dig) residue_walk<G, FUSE, RCH, NT, true>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP); \
-    else residue_walk<G, FUSE, RCH, NT, false>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP);    \
+    else residue_walk<G, FUSE, RCH, NT, false>(slab, off_heads, off_rec, off_ent, s_lat, spec, half, nheads, lpc, lpc_magic, interleaved, flags, tid, FP, A.vq); \
   } while (0)
 #ifdef NVH_ABL_NO_WALK
     if (true) {
@@ -1184,7 +1217,7 @@ __device__ __forceinline__ void synth_frame_spectrum(const NvhSynthArgs& A, cons
 #endif
     if (GENERAL && group == 1) {
       if (dig) residue_walk_general<NT, MAXCH, true>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid);
-      else residue_walk_general<NT, MAXCH, false>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid);
+      else residue_walk_general<NT, MAXCH, false>(slab, off_heads, off_rec, off_ent, lpc, s_lat, spec, half, tid, A.vq);
     } else if (MAXCH <= 2 && (flags & NVH_SLAB_FUSE_FLOOR)) {
       FloorRef F;
       const unsigned c0w = __builtin_amdgcn_readfirstlane(s_chan[0]), c1w = __builtin_amdgcn_readfirstlane(s_chan[1]);
@@ -1198,7 +1231,7 @@ __device__ __forceinline__ void synth_frame_spectrum(const NvhSynthArgs& A, cons
       else NVH_WALK(2, false, 0, nullptr);
     } else if (MAXCH > 2 && group == 0) {
       if (dig) residue_walk_bins<NT, true>(slab, off_heads, off_rec, off_ent, lpc, lpc_magic, s_lat, spec, half, rch, tid);  // quirk B-1
-      else residue_walk_bins<NT, false>(slab, off_heads, off_rec, off_ent, lpc, lpc_magic, s_lat, spec, half, rch, tid);
+      else residue_walk_bins<NT, false>(slab, off_heads, off_rec, off_ent, lpc, lpc_magic, s_lat, spec, half, rch, tid, A.vq);
     } else if (MAXCH > 2) {
       switch (rch) {  // group == 2 * rch (the slab writers)
         case 3: NVH_WALK(6, false, 3, nullptr); break;

@@ -214,6 +214,7 @@ extern "C" int nvh_stream_open(nvh_ctx* c, const uint8_t* id_pkt, int id_len, co
         }
         nvh::classify_residues(sh->setup, sh->slab, nvh_toggles().no_pair || lattice.size() > 0xFFFFu);
         sh->slab.lattice = lattice;
+        sh->slab.vq = vq;
         if (t_host_setups.size() >= 8) t_host_setups.clear();
         t_host_setups.emplace(std::move(key), sh);
       }
@@ -546,6 +547,17 @@ extern "C" int nvh_stream_lattice_pool(const nvh_stream* s, uint32_t* out, int64
     if (lw > L.size()) out[0] = 0u;
     if (!L.empty()) std::memcpy(out, L.data(), L.size() * sizeof(uint32_t));
     if (!V.empty()) std::memcpy(out + lw, V.data(), V.size() * sizeof(uint32_t));
+    return NVH_OK;
+  });
+}
+
+extern "C" int nvh_stream_vq_pool(const nvh_stream* s, float* out, int64_t cap_floats, int64_t* floats) {
+  return nvh_guard([&]() -> int {
+    if (!s || !floats || cap_floats < 0 || (cap_floats > 0 && !out)) return NVH_ERR_ARGUMENT;
+    const std::vector<float>& V = s->shared->slab.vq;
+    *floats = (int64_t)V.size();
+    if (*floats > cap_floats) return NVH_ERR_ARGUMENT;
+    if (!V.empty()) std::memcpy(out, V.data(), V.size() * sizeof(float));
     return NVH_OK;
   });
 }

@@ -712,6 +712,7 @@ int batch_launch(nvh_batch* b, const float* carry, float* carry_out, float* d_pc
       A.mdct_a[w] = s->dev.mdct_a[w]; A.mdct_b[w] = s->dev.mdct_b[w]; A.mdct_c[w] = s->dev.mdct_c[w]; A.mdct_tw[w] = s->dev.mdct_tw[w];
     }
     A.ipool = s->dev.ipool;
+    A.vq = s->dev.vq;
     A.const_vecs = s->shared->synth_const_vecs;
     A.stride_vecs = b->slab_stride_vecs;
     A.cap_vecs = b->slab_cap_vecs;

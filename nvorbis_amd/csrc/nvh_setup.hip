@@ -33,6 +33,7 @@ int upload_setup(nvh_stream* s) {
   nvh::build_book_directory(S, s->shared->slab, vq, lattice);
   nvh::classify_residues(S, s->shared->slab, nvh_toggles().no_pair || lattice.size() > 0xFFFFu);
   s->shared->slab.lattice = lattice;
+  s->shared->slab.vq = vq;
   const std::vector<NvhDevBook>& books = s->shared->slab.books;
 
   std::vector<int32_t> ipool;
@@ -130,7 +131,13 @@ int upload_setup(nvh_stream* s) {
       d.fast = (r.type != 0 && r.partition_size > 1 && max_index * max_div < 0x100000000ull) ? 1 : 0;
       // the pair path and the B-1 bin walk (host_slab.cpp: residue_pair_ok, residue_alias_b1; pair records pack LDS offsets /
       // bin indices into 16 bits and use a 16-bit reciprocal of the book dimension)
-      d.pair_path = (!nvh_toggles().no_pair && lattice.size() <= 0xFFFFu && nvh::residue_pair_ok(S, s->shared->slab, r)) ? 1 : 0;
+      // (the descriptor kernels' pair path peels lattice digits and nothing else: a residue with an explicit-table book, which the
+      // slab kernels take since round 6, keeps their general path)
+      bool all_lattice = true;
+      for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++)
+        for (int k = 0; k < NVH_MAX_STAGES; k++)
+          if (r.books[c][k] >= 0 && s->shared->slab.books[(size_t)r.books[c][k]].lat_values == 0) all_lattice = false;
+      d.pair_path = (!nvh_toggles().no_pair && all_lattice && lattice.size() <= 0xFFFFu && nvh::residue_pair_ok(S, s->shared->slab, r)) ? 1 : 0;
       d.alias_b1 = (seq && d.fast != 0 && s->shared->slab.residue_b1[i]) ? 1 : 0;
       s->shared->slab.residue_b1[i] = (uint8_t)d.alias_b1;
       d.hp_magic = r.partition_size / 2 > 1 ? (uint32_t)((0x100000000ull + (uint64_t)(r.partition_size / 2) - 1) / (uint64_t)(r.partition_size / 2)) : 0u;

@@ -87,6 +87,7 @@ SIGNATURES = {
     "nvh_stream_pending_geometry": (C.c_int, [_vp, _vp, C.c_int]),
     "nvh_stream_pending_slabs": (C.c_int, [_vp, _vp, C.c_int64, _i64p, _vp, C.c_int]),
     "nvh_stream_lattice_pool": (C.c_int, [_vp, _vp, C.c_int64, _i64p]),
+    "nvh_stream_vq_pool": (C.c_int, [_vp, _vp, C.c_int64, _i64p]),
     "nvh_stream_synth_begin": (C.c_int, [_vp, _vp, C.c_int64, _i64p]),
     "nvh_stream_synth_end": (C.c_int, [_vp, _i64p]),
     "nvh_stream_synth": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i64p]),

@@ -356,6 +356,14 @@ class Stream:
         check(lib().nvh_stream_lattice_pool(self._h, buf.ctypes.data, buf.size, C.byref(need)), "nvh_stream_lattice_pool")
         return buf[:int(need.value)]
 
+    def vq_pool(self):
+        """The setup's VQ table pool (float32): what the lattice-pool word of a book with an explicit table points into."""
+        need = C.c_int64(0)
+        lib().nvh_stream_vq_pool(self._h, None, 0, C.byref(need))
+        buf = np.zeros(max(int(need.value), 1), np.float32)
+        check(lib().nvh_stream_vq_pool(self._h, buf.ctypes.data, buf.size, C.byref(need)), "nvh_stream_vq_pool")
+        return buf[:int(need.value)]
+
     def position(self):
         pos, em, eos = C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(lib().nvh_stream_position(self._h, C.byref(pos), C.byref(em), C.byref(eos)), "nvh_stream_position")

@@ -437,6 +437,33 @@ def config(name):
                  mappings=[lambda w: write_mapping(w, nch, 2 if two else 1, [(0, 1)], [0, 1] if two else None, [(0, 0)] * (2 if two else 1)),
                            lambda w: write_mapping(w, nch, 2 if two else 1, [(nch - 1, 0)], [1, 0] if two else None, [(1, 1)] * (2 if two else 1))],
                  modes=[(0, 0), (1, 1)])
+    elif name in ("table_books_pair", "table_books_general", "table_books_b1"):
+        # books with an explicit table -- lookup type 2 (books 6, 9) and type 1 with sequence_p (book 7), Codebook.cs:262-281 -- in
+        # residues the slab kernels take (round 6: kernels_synth.hip: table_value): on the pair walk (even dimensions, a per-channel
+        # Residue1 and a stereo Residue2), on the general bin walk (dimensions 3 and 5 dividing 15 / 30), on the quirk-B-1 bin walk
+        # (three channels, partitions off the channel grid); every residue mixes them with lattice books
+        c["books"] = books + [
+            Book(6, dims=2, lookup=2, min_me=(-9, -5), delta_me=(1, -4), value_bits=5),                       # 11: type 2, dim 2
+            Book(7, dims=4, lookup=2, min_me=(-11, -6), delta_me=(1, -5), value_bits=5, sequence_p=1),       # 12: type 2 + sequence_p, dim 4
+        ]
+        if name == "table_books_pair":
+            nch, cpl = 2, [(0, 1)]
+            res = [lambda w: write_residue(w, 1, 0, 128, 16, 2, [1, 2, 7, 0], [7, 11, 3, 12, 7]),
+                   lambda w: write_residue(w, 2, 0, 1800, 32, 2, [3, 1, 4, 6], [11, 4, 7, 12, 5, 11])]
+        elif name == "table_books_general":
+            nch, cpl = 2, [(0, 1)]
+            res = [lambda w: write_residue(w, 1, 0, 120, 15, 2, [1, 2, 7, 0], [6, 9, 6, 9, 6]),
+                   lambda w: write_residue(w, 2, 6, 1986, 30, 2, [3, 1, 4, 6], [6, 7, 9, 3, 6, 9])]
+        else:
+            nch, cpl = 3, [(0, 1), (2, 1)]
+            res = [lambda w: write_residue(w, 2, 0, 360, 16, 2, [1, 3, 0, 2], [7, 11, 3, 12]),
+                   lambda w: write_residue(w, 2, 4, 1500, 32, 2, [1, 3, 5, 2], [11, 7, 12, 3, 4, 7])]
+        c.update(channels=nch, block0=256, block1=1024 if nch == 3 else 2048,
+                 floors=[_floor1_small(0, 1), _floor1_long(0, 1, 9 if nch == 3 else 10)],
+                 residues=res,
+                 mappings=[lambda w: write_mapping(w, nch, 1, cpl, None, [(0, 0)]),
+                           lambda w: write_mapping(w, nch, 1, cpl[::-1] if nch == 3 else [(1, 0)], None, [(1, 1)])],
+                 modes=[(0, 0), (1, 1)])
     elif name in ("ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"):   # the channel counts no other config has
         nch, rtype = int(name[2]), int(name[-1])
         couple = [(0, 1), (2, 3)] if nch == 4 else [(0, 2), (3, 4)] if nch == 5 else [(0, 1), (2, 3), (5, 6)] if nch == 7 else [(0, 7), (1, 6), (2, 5)]
@@ -455,7 +482,8 @@ def config(name):
 
 CONFIG_NAMES = ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
                 "floor0_stereo", "floor0_slab", "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192", "ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2", "mono_res1_2048",
-                "res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"]
+                "res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch",
+                "table_books_pair", "table_books_general", "table_books_b1"]
 
 
 def filtered_stream(oracle, name, npackets, seed, consistent_windows=True):

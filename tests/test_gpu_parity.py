@@ -301,6 +301,43 @@ def test_general_bin_walk_bit_exact(oracle, gpu_ctx, name, consistent):
             assert names and kn in names and all(k in (kn, "k_ola_compact", "k_parse_slab", "k_parse_links") for k in names), (gpu_parse, names)
 
 
+@pytest.mark.parametrize("name", ["table_books_pair", "table_books_general", "table_books_b1"])
+@pytest.mark.parametrize("consistent", [True, False])
+def test_table_books_take_the_slab_kernels(oracle, gpu_ctx, name, consistent):
+    """Books with an explicit table -- lookup type 2 and type 1 with sequence_p (Codebook.cs:262-281) -- in residues of the slab
+    kernels' shapes: a slab record names such a book by lat_values = 0 and the walks gather the component from the VQ pool
+    (kernels_synth.hip: table_value; round 6 -- through round 5 these streams took the descriptor kernels).  The pair walk, the
+    general bin walk and the quirk-B-1 bin walk, host-parsed and GPU-parsed: bit-exact against the oracle, and synthesised by
+    the slab kernels on the default path."""
+    import os
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    pk, gr, fl = ss.filtered_stream(oracle, name, 150, 41 + int(consistent), consistent_windows=consistent)
+    for clip in (True, False):
+        ref, info = oracle.decode_packets(pk, gr, fl, clip=clip)
+        for bf in (1024, 13):
+            got = _decode_gpu(nv, gpu_ctx, pk, gr, fl, clip, bf)
+            assert got.size == ref.size, (name, clip, bf)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, clip, bf, float(np.abs(got - ref).max()))
+    toggles = ("NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_NO_SLAB")
+    if consistent and not any(os.environ.get(t) for t in toggles):
+        torch = _torch()
+        for gpu_parse in (False, True):
+            st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+            if gpu_parse:
+                st.set_gpu_parse(True)
+            for p in pk[3:40]:
+                st.push_packet(p, -1, 0)
+            b = st.upload_batch()
+            pcm = torch.empty(max(b.samples * st.channels, 1), dtype=torch.float32, device="cuda")
+            b.synth(pcm.data_ptr(), pcm.numel())
+            names = [k for k in b.kernels() if k != "-"]
+            b.free(); st.close()
+            assert names and all(k.startswith("k_synth") or k in ("k_ola_compact", "k_parse_slab", "k_parse_links") for k in names), (gpu_parse, names)
+            if name == "table_books_general":
+                assert "k_synth_g" in names, (gpu_parse, names)
+
+
 @pytest.mark.parametrize("name", ["ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"])
 def test_channel_counts_4_5_7_8_bit_exact(oracle, gpu_ctx, name):
     """Every channel count has its own instantiation of the overlap-add kernels (ola_vec / ola_sym_lds<CH>) and of the

@@ -36,7 +36,8 @@ def test_files_gpu_parse_equals_oracle(oracle, gpu_ctx, ogg_bytes, name, batch_f
 
 @pytest.mark.parametrize("name", ["mono_res0_small_blocks", "stereo_res1_coupled", "three_ch_res2_misaligned", "six_ch_res2_4096",
                                   "two_submaps", "equal_blocks_overrun", "mono_8192", "stereo_8192",
-                                  "res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch"])
+                                  "res0_slab", "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch",
+                                  "table_books_pair", "table_books_general", "table_books_b1"])
 def test_synthetic_shapes_gpu_parse_equals_oracle(oracle, gpu_ctx, name):
     """Residue0/1/2, 1-6 channels, several submaps, vector overrun, 64..8192 blocks, random-bit packets (so packets end in
     the middle of floors, class words and vectors all the time)."""

@@ -290,7 +290,7 @@ def test_slab_general_group_list(oracle, name):
         s.close()
 
 
-def _slab_residue_sums(words, h, lat, nch, half):
+def _slab_residue_sums(words, h, lat, nch, half, vq=None):
     """The residue sums [nch][half] a slab's chains encode, added in the reference's order (cascade stage by stage, inside a
     stage the partitions in order; Residue0.cs:132-175), for every walk of the synthesis kernels: the pair walk (group 2 / 8 /
     2 * channels), the quirk-B-1 bin walk (group 0) and the general one (group 1, with its group list)."""
@@ -347,7 +347,10 @@ def _slab_residue_sums(words, h, lat, nch, half):
                 e = int(eb[j])
                 if e == 0xFFFF:
                     continue
-                v = lat[lat_off + (e // lv ** comp) % lv: lat_off + (e // lv ** comp) % lv + 1].view(np.float32)[0]
+                if lv == 0:  # a book with an explicit table: the lattice-pool word is its offset in the VQ pool
+                    v = vq[int(lat[lat_off]) + e * dims + comp]
+                else:
+                    v = lat[lat_off + (e // lv ** comp) % lv: lat_off + (e // lv ** comp) % lv + 1].view(np.float32)[0]
             c, b = (q % rch, x0 + q // rch) if (rtype == 2 and rch > 1) else (chan, x0 + q)
             if b < half:
                 spec[c, b] = np.float32(spec[c, b] + v)
@@ -355,7 +358,8 @@ def _slab_residue_sums(words, h, lat, nch, half):
 
 
 @pytest.mark.parametrize("name", ["3test", "2test", "stereo_res1_coupled", "six_ch_res2_4096", "three_ch_res2_misaligned", "res0_slab",
-                                  "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch", "floor0_slab"])
+                                  "odd_dims_slab", "res2_alias_stereo", "two_pass_slab", "res0_3ch", "floor0_slab",
+                                  "table_books_pair", "table_books_general", "table_books_b1"])
 def test_slab_residue_sums_match_oracle(oracle, ogg_bytes, name):
     """The residue half of the host-written slabs against the oracle's IResidue.Decode (oracle/orc_residue.c), without a GPU: the
     chains, records and entries of a frame, walked here in the reference's order of additions, must give the oracle's residue
@@ -374,6 +378,7 @@ def test_slab_residue_sums_match_oracle(oracle, ogg_bytes, name):
     s = nv.Stream(None, pk[0], pk[1], pk[2])
     try:
         lat = s.lattice_pool()
+        vq = s.vq_pool()
         nch, b1 = s.channels, s.block1
         scratch = np.zeros(nch * b1, np.float32)
         frames = vectors = 0
@@ -396,7 +401,7 @@ def test_slab_residue_sums_match_oracle(oracle, ogg_bytes, name):
                 bits = C.c_int()
                 assert oracle.L.orc_residue_decode_at(d, int(idx[k]), pk[i], len(pk[i]), int(pos[k]), anyx.value, n, ref.ctypes.data,
                                                       C.byref(bits)) == 0
-            got = _slab_residue_sums(words, h, lat, nch, n // 2)
+            got = _slab_residue_sums(words, h, lat, nch, n // 2, vq)
             want = ref.reshape(nch, b1)[:, :n // 2]
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, i, float(np.abs(got - want).max()))
             frames += 1
