@@ -221,6 +221,19 @@ void classify_residues(const Setup& S, SlabSetup& X, bool no_pair) {
   }
 }
 
+uint32_t residue_max_span(const Setup& S, const Residue& r) {
+  uint32_t span = (uint32_t)(r.partition_size > 0 ? r.partition_size : 0);
+  if (r.type == 0 || r.partition_size <= 0) return span;
+  for (int c = 0; c < r.classifications && c < NVH_MAX_CLASSES; c++)
+    for (int k = 0; k < NVH_MAX_STAGES; k++) {
+      const int b = r.books[c][k];
+      if (b < 0 || (size_t)b >= S.books.size()) continue;
+      const uint32_t dim = (uint32_t)S.books[(size_t)b].dimensions;
+      if (dim > 0) span = std::max(span, ((uint32_t)r.partition_size + dim - 1) / dim * dim);
+    }
+  return span;
+}
+
 bool residue_general_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
   (void)S;
   const int rch = r.type == 2 ? r.real_channels : 1;
@@ -233,10 +246,16 @@ bool residue_general_ok(const Setup& S, const SlabSetup& X, const Residue& r) {
       const int b = r.books[c][k];
       if (b < 0) continue;
       const NvhDevBook& bk = X.books[(size_t)b];
-      if (!book_has_vectors(bk) || bk.lat_values > 0xFFu || bk.dim == 0 || bk.dim > 16u || psz % bk.dim != 0) return false;
-      // the walk's divisions: i / dim by the 16-bit reciprocal, and (Residue0) i dim / partition_size by the 32-bit one
-      if (((psz * bk.dim_magic16) >> 16) != psz / bk.dim) return false;
-      for (uint32_t i = 0; i < psz; i++) {
+      if (!book_has_vectors(bk) || bk.lat_values > 0xFFu || bk.dim == 0 || bk.dim > 16u) return false;
+      // A dimension that does not divide the partition: a Residue0 adds partition_size / dim whole steps (Residue0.cs:180-201: the
+      // walk's geometry needs dim | size there); Residue1 / Residue2 add whole entries, the last one running over into the next
+      // partition's elements (vector overrun, round 6: the bin walk merges the two partitions that touch a bin anyway) -- by
+      // less than a partition, so that at most two partitions touch a bin.
+      const uint32_t span = (psz + bk.dim - 1) / bk.dim * bk.dim;
+      if (r.type == 0 ? psz % bk.dim != 0 : span - psz >= psz) return false;
+      // the walk's divisions: i / dim and ceil(size / dim) by the 16-bit reciprocal, and (Residue0) i dim / partition_size by the 32-bit one
+      if (((psz * bk.dim_magic16) >> 16) != psz / bk.dim || (((psz + bk.dim - 1) * bk.dim_magic16) >> 16) != (psz + bk.dim - 1) / bk.dim) return false;
+      for (uint32_t i = 0; i < span; i++) {
         if (((i * bk.dim_magic16) >> 16) != i / bk.dim) return false;
         if (r.type == 0 && (uint32_t)(((uint64_t)(i * bk.dim) * psz_magic) >> 32) != i * bk.dim / psz) return false;
       }
@@ -345,11 +364,13 @@ int residue_general(const Setup& S, const SlabSetup& X, const FrameBatch& P, con
         const NvhResOp& op = ops[q];
         const NvhDevBook& bk = X.books[op.book];
         uint32_t rel = op.ent_off - fr.ent_begin, pool_off = bk.lat_off;
-        if (dig) {  // the record's run of digit bytes: partition_size / dim entries (the general walk's contract: no vector overrun)
-          if (bk.dim == 0 || psz % bk.dim != 0 || rel + psz / bk.dim > fr.ent_count || (dg.size() & 1u)) return NVH_ERR_RUNTIME;
+        if (dig) {  // the record's run of digit bytes: its entries' components (Residue0: size / dim entries; else ceil(size / dim))
+          if (bk.dim == 0) return NVH_ERR_RUNTIME;
+          const uint32_t n_ent = R.type == 0 ? psz / bk.dim : (psz + bk.dim - 1) / bk.dim;
+          if ((R.type == 0 && psz % bk.dim != 0) || rel + n_ent > fr.ent_count || (dg.size() & 1u)) return NVH_ERR_RUNTIME;
           rel = (uint32_t)(dg.size() >> 1);
           pool_off = X.val_off[op.book];
-          append_digits(X, op.book, bk.dim, bk.lat_values, P.entries.data() + op.ent_off, psz / bk.dim, dg);
+          append_digits(X, op.book, bk.dim, bk.lat_values, P.entries.data() + op.ent_off, n_ent, dg);
           if (dg.size() & 1u) dg.push_back(0);  // (a partition of odd size: runs start on even bytes)
         }
         if (rel > 0xFFFFu || pool_off > NVH_SLAB_MAX_LAT_OFF || bk.lat_values > 0xFFu || bk.dim > 31u || op.channel > 7u ||
@@ -367,7 +388,7 @@ int residue_general(const Setup& S, const SlabSetup& X, const FrameBatch& P, con
     for (int c = 0; c < pass_ch; c++) {
       Group g;
       g.rbegin = rbegin; g.psz = psz; g.nparts = nparts;
-      g.cover = (psz + (uint32_t)rch - 1) / (uint32_t)rch;
+      g.cover = (residue_max_span(S, R) + (uint32_t)rch - 1) / (uint32_t)rch;  // bins a partition's longest vector write touches
       g.geom = (uint32_t)R.type | ((uint32_t)rch << 4) | ((uint32_t)pi << 8) | ((uint32_t)(R.type == 2 ? 0 : c) << 12);
       g.psz_magic = (uint32_t)((0x100000000ull + psz - 1) / psz);
       g.pchain_off = (uint32_t)(pc0 + (size_t)c * nparts);

@@ -63,6 +63,10 @@ bool floor0_section_values(const Floor0& f, int slot, int half, float amp, const
 // truncates and chPtr restarts at 0, Residue2.cs:25-27, so neighbouring partitions share a bin), every book a lattice book of
 // even dimension that divides the partition, at least two bins per partition (a bin then belongs to at most two partitions).
 bool residue_alias_b1(const Setup& S, const SlabSetup& X, const Residue& r);
+// Components the longest vector write of a partition of residue r covers: partition_size, or -- Residue1 / Residue2 with a book whose
+// dimension does not divide it (Residue1.cs:12-22: whole entries are added, the last one runs over into the next partition's
+// elements) -- ceil(partition_size / dim) * dim for the worst book.  The general bin walk's `cover` comes from it.
+uint32_t residue_max_span(const Setup& S, const Residue& r);
 
 // The general bin walk (kernels_synth.hip: residue_walk_general) takes a residue when every book it uses is a lattice book whose
 // dimension divides the partition size (no vector overrun; Residue0: partition_size / dimensions whole steps), partitions of 2

@@ -987,7 +987,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
           const unsigned rch = rk.type == 2 ? (unsigned)rk.real_channels : 1u, psz = (unsigned)rk.partition_size;
           for (int c = 0; c < chs; ++c) {
             uint32_t* q = w + 4 + 8 * gi;
-            q[0] = (uint32_t)rk.begin; q[1] = psz; q[2] = (uint32_t)np; q[3] = (psz + rch - 1u) / rch;
+            q[0] = (uint32_t)rk.begin; q[1] = psz; q[2] = (uint32_t)np; q[3] = (rk.span_max + rch - 1u) / rch;
             q[4] = (uint32_t)rk.type | (rch << 4) | ((uint32_t)k << 8) | ((uint32_t)(rk.type == 2 ? 0 : c) << 12);
             q[5] = (uint32_t)((0x100000000ull + psz - 1) / psz);
             q[6] = npc + (uint32_t)(c * np);

@@ -613,11 +613,14 @@ __device__ __forceinline__ void residue_walk_general(const float* slab, unsigned
         const unsigned lvm = (!DIG && dims > 1) ? lat[lv + 1] : 0u;  // (a book of dimension 1 has no second power: the entry is the digit)
         // partition_size / dims (host_slab.cpp checked the reciprocal; dimension 1: the record's 16-bit field cannot hold 2^16)
         const unsigned steps = dims > 1 ? (psz * dm16) >> 16 : psz;
+        // components this vector write covers: the partition, or -- Residue1 / Residue2, a dimension that does not divide it -- whole
+        // entries, the last one running over into the next partition's elements (Residue1.cs:12-22, Residue2.cs:27-45)
+        const unsigned span = (rtype == 0 || dims <= 1) ? psz : (((psz + dims - 1u) * dm16) >> 16) * dims;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
           if ((unsigned)c < rch) {  // uniform
             const unsigned q = q0 + (unsigned)c;
-            const bool in = q < psz;
+            const bool in = q < span;
             const unsigned qq = in ? q : 0u;
             unsigned j, comp;
             if (rtype == 0) {  // component comp of entry j lies at j + comp * steps

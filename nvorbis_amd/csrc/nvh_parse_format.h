@@ -64,6 +64,7 @@ struct NvhPResidue {  // Residue0.cs:21-33
   uint32_t general;         // its frames take the general bin walk (neither the pair path nor B-1 on its own; host_slab.h: residue_general)
   uint32_t decode_map_lds;  // word offset of the same class numbers inside the LDS image, 0xFFFFFFFF: read them from the int pool
   uint32_t vis_lds;         // word offset of the visit descriptors inside the LDS image (NVH_PVIS_*), 0xFFFFFFFF: none
+  uint32_t span_max;        // components a partition's longest vector write covers (host_slab.h: residue_max_span): the bin walk's `cover`
   uint8_t cascade[NVH_MAX_CLASSES];
   int16_t books[NVH_MAX_CLASSES][NVH_MAX_STAGES];
   uint8_t book_mask[NVH_MAX_CLASSES];  // per class: the cascade stages that have a book (a chain of the slab has one record per set bit)

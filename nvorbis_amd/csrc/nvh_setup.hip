@@ -481,6 +481,7 @@ int upload_parse_tables(nvh_stream* s) {
     d.decode_map_off = (uint32_t)ipool.size();
     d.decode_map_lds = dm_lds[i];
     d.vis_lds = vis_lds[i];
+    d.span_max = nvh::residue_max_span(S, r);
     ipool.insert(ipool.end(), r.decode_map.begin(), r.decode_map.end());
     int min_dims = 1 << 30;
     for (int c = 0; c < NVH_MAX_CLASSES; c++) {

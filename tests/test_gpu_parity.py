@@ -338,6 +338,38 @@ def test_table_books_take_the_slab_kernels(oracle, gpu_ctx, name, consistent):
                 assert "k_synth_g" in names, (gpu_parse, names)
 
 
+def test_vector_overrun_takes_the_general_walk(oracle, gpu_ctx):
+    """Book dimensions that do not divide the partition size (Residue1.cs:12-22, Residue2.cs:27-45: whole entries are added, the
+    last one runs over into the next partition's elements): the general bin walk merges the two partitions that touch a bin anyway
+    and takes the spill as part of the earlier partition's vector write (round 6; kernels_synth.hip: residue_walk_general, `span`;
+    through round 5: the descriptor kernels).  Bit-exact against the oracle (test_synthetic_configs_bit_exact has the long form);
+    here: the kernels that ran, for both parsers."""
+    import os
+    import nvorbis_amd as nv
+    from tests import synth_stream as ss
+    if any(os.environ.get(t) for t in ("NVH_UNFUSED", "NVH_NO_FUSED_IMDCT", "NVH_NO_COMPACT", "NVH_NO_SLAB")):
+        pytest.skip("a replay that forces the descriptor kernels")
+    torch = _torch()
+    pk, gr, fl = ss.filtered_stream(oracle, "equal_blocks_overrun", 120, 17)
+    ref, info = oracle.decode_packets(pk, gr, fl, clip=True)
+    for gpu_parse in (False, True):
+        st = nv.Stream(gpu_ctx, pk[0], pk[1], pk[2])
+        if gpu_parse:
+            st.set_gpu_parse(True)
+        for i in range(3, len(pk)):
+            st.push_packet(pk[i], int(gr[i]), int(fl[i]))
+        st.push_end()
+        b = st.upload_batch()
+        pcm = torch.empty(max(b.samples * st.channels, 1), dtype=torch.float32, device="cuda")
+        b.synth(pcm.data_ptr(), pcm.numel())
+        gpu_ctx.synchronize()
+        names = [k for k in b.kernels() if k != "-"]
+        got = pcm.cpu().numpy()[:b.samples * st.channels]
+        b.free(); st.close()
+        assert "k_synth_g" in names and all(k in ("k_synth_g", "k_ola_compact", "k_parse_slab", "k_parse_links") for k in names), (gpu_parse, names)
+        assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), gpu_parse
+
+
 @pytest.mark.parametrize("name", ["ch4_res1", "ch5_res2", "ch7_res1", "ch8_res2"])
 def test_channel_counts_4_5_7_8_bit_exact(oracle, gpu_ctx, name):
     """Every channel count has its own instantiation of the overlap-add kernels (ola_vec / ola_sym_lds<CH>) and of the
