@@ -16,6 +16,8 @@
 // every packet), the tables come through L2.  Output goes to fixed-capacity per-frame slabs.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels_common.h"
 #include "nvh_parse_format.h"
 #include "spectrum_dev.h"
@@ -326,13 +328,24 @@ __device__ __forceinline__ int floor_to_slab_wave(FloorScratch* Q, const NvhDevF
 // one-lane-of-64 form pays for every level of its divergent loop nest in exec-mask arithmetic (half of the instructions of the
 // entry loop, more in the levels around it).  Stores of the parse are issued by all lanes with one address and one value;
 // behind the parse lane 0 is the packet's lane, as before.
-template <bool LDS, bool SLAB, bool UNI = false>
+// CUR (slab mode, several packets per wavefront): the residue walk as one cursor per lane -- see the comment at the walk.
+// PHASE: 0 = the whole job in one kernel; 1 = the parse alone, several packets per wavefront, its per-packet results handed over
+// in `handover` (NVH_PHO_* words per frame); 2 = the rest of the slab (heads, entries, floors, header) from that hand-over, ONE
+// packet per wavefront: the floors are written by a whole wavefront per channel (lane = post), which in one kernel would happen
+// packet after packet for every lane of the parse's wavefront -- as long as the parse itself once its lanes run side by side.
+#define NVH_PHO_WORDS 16
+#define NVH_PSTG 32  // entries of one vector a lane of the cursor walk collects in LDS (a longer vector stores straight to memory)
+template <bool LDS, bool SLAB, bool UNI = false, bool CUR = false, int PHASE = 0>
 __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
         NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
         uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
         NvhParseResult* __restrict__ result, int lanes_arg, int scratch_words, int pkt_words, uint4* __restrict__ slabs,
-        const int* __restrict__ order NVH_DBG_PARAMS) {
-  const int lanes = UNI ? 1 : lanes_arg;
+        const int* __restrict__ order, uint32_t* __restrict__ handover NVH_DBG_PARAMS) {
+  static_assert(PHASE == 0 || (SLAB && !LDS && !UNI), "the split form: slab mode, rows and packets in global memory");
+  static_assert(!CUR || (SLAB && !UNI && !LDS), "the cursor walk: slab mode, several packets per wavefront, rows and packets in global memory");
+  constexpr bool WAVE1 = UNI || PHASE == 2;  // one packet per wavefront, the packet index uniform
+  const int lanes = WAVE1 ? 1 : lanes_arg;
+  const int tab_words = PHASE == 2 ? 0 : T.lds_words;  // (the tail reads no Huffman table)
 #ifdef NVH_DEBUG
 #define PM(bit) (!(phase_mask & ((bit) << 8)))  // profiling builds: NVH_DEBUG_SPECTRUM_MASK = 15 + 256 * (pieces to leave out)
 #else
@@ -340,8 +353,8 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
 #endif
   // hot Huffman tables into LDS (every lane of the wavefront helps, then lanes without a frame leave)
   extern __shared__ __attribute__((aligned(16))) uint32_t s_prefix[];
-  uint32_t* s_meta = s_prefix + T.lds_words;  // books | floors | residues | mappings, as in the arena
-  for (int i = threadIdx.x; i < T.lds_words; i += (int)blockDim.x) s_prefix[i] = T.lds_image[i];
+  uint32_t* s_meta = s_prefix + tab_words;  // books | floors | residues | mappings, as in the arena
+  for (int i = threadIdx.x; i < tab_words; i += (int)blockDim.x) s_prefix[i] = T.lds_image[i];
   {
     const uint32_t* gm = reinterpret_cast<const uint32_t*>(T.books);
     for (int i = threadIdx.x; i < T.meta_words; i += (int)blockDim.x) s_meta[i] = gm[i];
@@ -355,29 +368,32 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   // per-lane LDS (when the host found room): the residue walk's two scratch rows, and the packet itself -- the bit
   // reader and the class words are on every symbol's dependency chain, and a global round trip costs ~10x an LDS one
   int* s_lane = reinterpret_cast<int*>(s_meta + T.meta_words);          // [packets per workgroup][scratch_words]
+  // (CUR: no per-lane rows or packets in LDS; the area holds the entry staging of the cursor walk, NVH_PSTG entries per lane)
+  uint16_t* const s_stage16 = reinterpret_cast<uint16_t*>(s_meta + T.meta_words);
   uint32_t* s_pkt = reinterpret_cast<uint32_t*>(s_lane + (int)(blockDim.x >> 6) * lanes * scratch_words);  // [packets per workgroup][pkt_words]
   // `lanes` packets per wavefront, blockDim.x / 64 wavefronts per workgroup.  Packets follow different paths through
   // this code, so the lanes of a wavefront run mostly one after the other, and a lone wavefront issues an instruction
   // every ~5 cycles at best: the host picks few packets per wavefront and ~2 wavefronts per SIMD for small batches
   // (a 4096-packet batch at 64 per wavefront would sit on 64 of 1024 SIMDs) and fills wavefronts up for large ones.
-  const int wave = UNI ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int wave = WAVE1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   // UNI: the wavefront's packet (uniform)
   const int f_u = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
   const bool valid_u = f_u < nframes;
   // slab mode keeps the lanes without a packet alive: behind the parse the whole wavefront works on the floors of its packets
-  const bool active = UNI ? (lane == 0 && valid_u) : (lane < lanes && blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + wave * lanes + lane < nframes);
-  const bool parses = UNI ? valid_u : active;  // takes part in the parse of a packet
-  if (!SLAB && !parses) return;
-  const int slot = UNI ? wave : wave * lanes + (active ? lane : 0);  // packet of this workgroup
+  const bool active = WAVE1 ? (lane == 0 && valid_u) : (lane < lanes && blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + wave * lanes + lane < nframes);
+  const bool parses = WAVE1 ? valid_u : active;  // takes part in the parse of a packet
+  if ((!SLAB || PHASE == 1) && !parses) return;
+  const int slot = WAVE1 ? wave : wave * lanes + (active ? lane : 0);  // packet of this workgroup
   // Which frame that is: the host hands the frames over longest packet first (`order`), so that the packets of a wavefront are of
   // a size -- its lanes run side by side only while all of them have symbols left -- and the launch ends on short ones.
-  const int f_idx = UNI ? (valid_u ? f_u : 0) : (active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0);
-  const int f = order ? order[f_idx] : f_idx;
+  const int f_idx = WAVE1 ? (valid_u ? f_u : 0) : (active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0);
+  const int f = (order && PHASE != 2) ? order[f_idx] : f_idx;
 #ifdef NVH_DEBUG
-#define PT_T(k) do { if (dbg && active) dbg[(long long)f * 24 + (k)] = clock64(); } while (0)
+#define PT_T(k) do { if (dbg && active) dbg[(long long)f * 24 + (PHASE == 2 ? 12 : 0) + (k)] = clock64(); } while (0)
 #define PT_ACC_BEGIN() const long long pt_t0 = clock64()
 #define PT_ACC_END(k) pt_acc[k] += clock64() - pt_t0
-  long long pt_acc[3] = {0, 0, 0};  // cycles inside: the entry loops of the vectors, the class words, (spare)
+  long long pt_acc[3] = {0, 0, 0};  // cycles inside: the entry loops of the vectors, the class words, the cursor walk's steps between vectors
+  long long pt_rounds = 0;          // vectors decoded (cursor walk: rounds of its outer loop)
 #else
 #define PT_T(k) do { } while (0)
 #define PT_ACC_BEGIN() do { } while (0)
@@ -411,7 +427,22 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   int* const g_rows_base = scratch + (long long)f * T.row_words;
   int* const l_rows_base = reinterpret_cast<int*>(s_meta + T.meta_words) + slot * scratch_words;
 
-  if (fr.n != 0) {
+  // hand-over between the two kernels of the split form (PHASE 1 -> 2), NVH_PHO_WORDS words per frame:
+  //   0 err | 1 nrec_alloc | 2 nent | 3 nops | 4 npass | 5 exec_mask | 6, 7 pcs | 8 s_rtype | 9 s_rch | 10 s_psz | 11 s_rbegin |
+  //   12 s_npass | 13 s_parts | 14 s_chs | s_b1 << 8 | links_ok << 16 | 15 s_res
+  uint32_t* const ho = PHASE != 0 ? handover + (long long)f * NVH_PHO_WORDS : nullptr;
+  if constexpr (PHASE == 2) {
+    if (parses) {  // (uniform: every lane of the wavefront holds the packet's state, lane 0 is the packet's lane below)
+      const uint4 h0 = *reinterpret_cast<const uint4*>(ho), h1 = *reinterpret_cast<const uint4*>(ho + 4),
+                  h2 = *reinterpret_cast<const uint4*>(ho + 8), h3 = *reinterpret_cast<const uint4*>(ho + 12);
+      err = (int)h0.x; nrec_alloc = h0.y; nent = h0.z; nops = h0.w;
+      npass = h1.x; exec_mask = h1.y; pcs = ((unsigned long long)h1.w << 32) | h1.z;
+      s_rtype = (int)h2.x; s_rch = (int)h2.y; s_psz = (int)h2.z; s_rbegin = (int)h2.w;
+      s_npass = (int)h3.x; s_parts = (int)h3.y; s_chs = (int)(h3.z & 0xFFu); s_b1 = (int)((h3.z >> 8) & 0xFFu);
+      links_ok = ((h3.z >> 16) & 1u) != 0; s_res = (int)h3.w;
+    }
+  }
+  if (PHASE != 2 && fr.n != 0) {
     const NvhPacketRef ref = refs[f];
     BitR p;
     const uint32_t* pw = reinterpret_cast<const uint32_t*>(pkt_pool + ref.byte_off);
@@ -566,6 +597,289 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         bool stop = false;
         int stop_p = 0, stop_c = 0;  // slab mode: where the packet ran out (partition, channel), and whether that vector write was kept
         bool stop_pushed = false;
+        if constexpr (CUR) {
+          // ---- the walk as one cursor per lane (several packets per wavefront) ----
+          // The loop nest below visits (stage, partition, channel) in lockstep over the lanes of a wavefront: at a visit only the
+          // lanes whose partition class has a book in that stage decode -- on real material one in four to one in eight -- and the
+          // others wait; the entry loops of a wavefront's packets ran, in effect, one after the other (64 packets per wavefront:
+          // 18 times one packet's time).  Here a lane carries its own position (stage, partition_idx, c) through the same visit
+          // order: it steps over the visits that decode nothing, stops at the next one that does, and then ALL lanes run their
+          // entry loops together, each on its own vector.  Same reads, same order, same stop rules per packet (the code of a
+          // visit is the nest's, statement for statement); only which lanes keep each other company changes.
+          // What a step needs to know about a position -- its class, and where its chain of records starts -- comes from LDS and
+          // from a running count: the class of every (channel, partition) is kept as a byte per lane (lane-strided words behind the
+          // entry staging; the host checked the room), and since every stage walks the positions in the order stage 0 allocated
+          // their chains in, a chain's first record is the sum of the chain lengths in front of it.  The rows in global memory
+          // are still written (the tail kernel builds the heads from them, the end-of-packet fix-up below reads them), never read
+          // here: a step that waits for a global load behind its own stores cost 2-5 k cycles, 180 steps per packet.
+          uint8_t* const s_cls = reinterpret_cast<uint8_t*>(s_stage16) + (size_t)blockDim.x * (NVH_PSTG * 2);
+          auto cls_at = [&](const int i) -> uint8_t& { return s_cls[4 * ((i >> 2) * (int)blockDim.x + (int)threadIdx.x) + (i & 3)]; };
+          const uint32_t pass_rec0 = nrec_alloc;
+          uint32_t run = pass_rec0, start = 0;
+          int partition_idx = 0, c = 0, dimension_idx = 0;
+          bool running = r_stages > 0;
+          if (running) pass.op_begin[0] = op_base + nops;
+          while (running) {
+            int cls = 0, book_idx = -1;
+            bool have = false;
+#ifdef NVH_DEBUG
+            const long long pt_adv0 = clock64();
+            ++pt_rounds;
+#endif
+            while (!have) {
+              if (c >= r_chs) {
+                c = 0;
+                ++partition_idx;
+                if (++dimension_idx >= cdim) dimension_idx = 0;
+              }
+              if (partition_idx >= partition_count) {  // next cascade stage (Residue0.cs:132)
+                ++stage;
+                if (stage >= r_stages) break;
+                pass.op_begin[stage] = op_base + nops;
+                partition_idx = 0; c = 0; dimension_idx = 0;
+                run = pass_rec0;
+                continue;
+              }
+              if (stage == 0 && c == 0 && dimension_idx == 0) {  // the class words of this group of partitions (:137-150)
+                PT_ACC_BEGIN();
+                for (int cc = 0; cc < r_chs; cc++) {
+                  const int idx = decode_scalar<LDS, false>(T, s_prefix, s_pkt, class_book, p);
+                  if (idx == -2) {
+                    err = kErrRuntime;
+                    break;
+                  }
+                  if (idx >= 0 && idx < r_partvals) {
+                    for (int d = 0; d < cdim && partition_idx + d < partition_count; d++) {
+                      const int k = class_of(idx, d);
+                      row_set(cc * pw_stride + partition_idx + d, k);
+                      cls_at(cc * pw_stride + partition_idx + d) = (uint8_t)k;  // (class numbers are below NVH_MAX_CLASSES)
+                    }
+                  } else {
+                    stop = true;
+                    stop_p = partition_idx; stop_c = 0; stop_pushed = false;
+                    break;
+                  }
+                }
+                PT_ACC_END(1);
+                if (stop || err) break;
+              }
+              // (a position is reached only behind its group's class words: the nest's "class not set" fault cannot happen)
+              const int cl = (int)cls_at(c * pw_stride + partition_idx);
+              const unsigned cm = r.book_mask[cl];  // the stages in which this class has a book (nvh_setup.hip: cascade bit and book)
+              start = run;
+              run += (uint32_t)__popc(cm);
+              if (stage == 0) {  // the chain of this partition / channel (see the nest)
+                row_set(last_base + partition_idx * r_chs + c, cm ? (int)start : -1);
+                nrec_alloc = run;
+                if (nrec_alloc > (uint32_t)T.cap_ops) {
+                  err = kErrRuntime;
+                  break;
+                }
+              }
+              if (((cm >> stage) & 1u) == 0) {
+                ++c;
+                continue;
+              }
+              cls = cl;
+              book_idx = r.books[cl][stage];
+              have = true;
+            }
+#ifdef NVH_DEBUG
+            pt_acc[2] += clock64() - pt_adv0;
+#endif
+            if (!have) {  // the last stage is through, the packet ran out in a class word, or the reference would have thrown
+              running = false;
+              break;
+            }
+            // ---- one visit: the entries of a vector (Residue0.cs:157-170) ----
+            const int offset = r_begin + partition_idx * r_psize;
+            const NvhPBook book = books[book_idx];
+            const int dims = book.dims;
+            if (dims == 0) {
+              err = kErrRuntime;
+              break;
+            }
+            if (partition_idx > 0xFFFF) {
+              err = kErrUnsupported;
+              break;
+            }
+            const uint32_t ent_off = ent_base + nent;
+            bool push = false, bad = false;
+            if (r_type == 0) {
+              // Residue0.WriteVectors (:180-201): decode all entries first, add only if all decoded
+              const int steps = r_psize / dims;
+              const uint32_t mark = nent;
+              if (nent + (uint32_t)steps > (uint32_t)T.cap_ent) {
+                err = kErrRuntime;
+                break;
+              }
+              for (int i = 0; i < steps; i++) {
+                const int e = decode_scalar<LDS, false>(T, s_prefix, s_pkt, book, p);
+                if (e == -2) {
+                  err = kErrRuntime;
+                  break;
+                }
+                if (e == -1) {
+                  bad = true;
+                  break;
+                }
+                entries[ent_base + nent++] = (uint16_t)e;
+              }
+              if (err) break;
+              if (bad) {
+                nent = mark;
+                stop = true;
+                stop_p = partition_idx; stop_c = c; stop_pushed = false;
+                break;
+              }
+              if (offset + steps * dims > buflen) {
+                err = kErrRuntime;
+                break;
+              }
+              push = true;
+            } else {
+              // Residue1.WriteVectors (Residue1.cs:8-26) / Residue2.WriteVectors (Residue2.cs:23-47): vectors are added as they
+              // are decoded; a failed decode keeps what was added so far
+              const int slots = dims > 1 ? (int)__umulhi((uint32_t)(r_psize + dims - 1), book.dim_magic) : r_psize;
+              if (nent + (uint32_t)slots > (uint32_t)T.cap_ent) {
+                err = kErrRuntime;
+                break;
+              }
+              int done = 0;
+              PT_ACC_BEGIN();
+              // fast form (see the nest): a symbol is a masked ds_read and a 64-bit shift while the packet has 32 bits left, the code
+              // resolves in the book's LDS prefix table and slots remain; long codes from their slot's group.  The entries of the
+              // vector are collected in LDS (NVH_PSTG per lane, lane-strided words) and leave behind the loop: a store per symbol
+              // is a store in flight at every refill of the bit buffer, and the wait for the word fetched ahead is a wait for
+              // every memory operation before it -- a round trip to L2 per symbol where the loop's own chain is one LDS read.
+              if (book.has_tree && book.lds_off != 0xFFFFFFFFu) {
+                const uint32_t pmask = (1u << book.prefix_bits) - 1u, toff = book.lds_off;
+                uint16_t* __restrict__ eout = entries + ent_base + nent;
+                uint32_t node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                auto consume = [&](const uint32_t len) {
+                  p.buf >>= len;
+                  p.avail -= len;
+                  p.pos += len;
+                  if (p.avail <= 32u && p.next < p.nwords) {  // (one word restores br_fill's invariant: len <= 32)
+                    const uint32_t word = p.ahead;
+                    p.next++;
+                    p.ahead = br_word<LDS>(p, s_pkt, p.next);
+                    p.buf |= (uint64_t)word << p.avail;
+                    p.avail += 32u;
+                  }
+                };
+                auto run = [&](auto staged) {
+                  constexpr bool STG = decltype(staged)::value;
+                  auto put = [&](const int i, const uint32_t v) {
+                    if constexpr (STG) s_stage16[2 * ((i >> 1) * (int)blockDim.x + (int)threadIdx.x) + (i & 1)] = (uint16_t)v;
+                    else eout[i] = (uint16_t)v;
+                  };
+                  for (;;) {
+                    while ((bool)((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)((node >> 7) & 1u))) {
+                      consume(node & 0x7Fu);
+                      put(done, node >> 8);
+                      ++done;
+                      node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                    }
+                    if (!((int)(done < slots) & (int)(p.total - p.pos >= 32u) & (int)(book.has_overflow != 0))) break;
+                    const uint32_t data = (uint32_t)p.buf & (book.max_bits >= 32 ? 0xFFFFFFFFu : (1u << book.max_bits) - 1u);
+                    uint32_t cnt = node & 0x7Fu;
+                    uint32_t hit_len = 0, hit_val = 0;
+                    if (cnt != 0x7Fu && book.ovf_lds != 0xFFFFFFFFu) {
+                      const uint32_t g = book.ovf_lds + 2u * (node >> 8);
+                      for (uint32_t k = 0; k < cnt; ++k) {
+                        const uint32_t bits = s_prefix[g + 2u * k], vl = s_prefix[g + 2u * k + 1u], len = vl & 0xFFu;
+                        if (bits == (data & ((1u << len) - 1u))) {
+                          hit_val = vl >> 8;
+                          hit_len = len;
+                          break;
+                        }
+                      }
+                    } else {
+                      const NvhPOverflow* __restrict__ ov = T.overflow + book.ovf_off;
+                      if (cnt == 0x7Fu) cnt = book.ovf_count;
+                      else ov += book.ovf_count + (node >> 8);
+                      for (uint32_t k = 0; k < cnt; ++k) {
+                        const uint4 o = *reinterpret_cast<const uint4*>(ov + k);  // bits, mask, value, length
+                        if (o.x == (data & o.y)) {
+                          hit_val = o.z;
+                          hit_len = o.w;
+                          break;
+                        }
+                      }
+                    }
+                    if (hit_len == 0u || hit_len > 32u) break;  // no match (or nothing this loop may skip): the general loop decides
+                    consume(hit_len);
+                    put(done, hit_val);
+                    ++done;
+                    node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                  }
+                  if constexpr (STG) {
+                    // the collected entries to their place: a lone leading one where the vector starts on an odd entry, then pairs
+                    auto get = [&](const int i) { return (uint32_t)s_stage16[2 * ((i >> 1) * (int)blockDim.x + (int)threadIdx.x) + (i & 1)]; };
+                    int k = 0;
+                    if ((nent & 1u) && done > 0) {
+                      eout[0] = (uint16_t)get(0);
+                      k = 1;
+                    }
+                    for (; k + 1 < done; k += 2) *reinterpret_cast<uint32_t*>(eout + k) = get(k) | (get(k + 1) << 16);
+                    if (k < done) eout[k] = (uint16_t)get(k);
+                  }
+                };
+                if (slots <= NVH_PSTG) run(std::true_type{});
+                else run(std::false_type{});
+                nent += (uint32_t)done;
+              }
+              for (int i = done * dims; i < r_psize; i += dims) {
+                const int e = decode_scalar<LDS, false>(T, s_prefix, s_pkt, book, p);
+                if (e == -2) {
+                  err = kErrRuntime;
+                  break;
+                }
+                if (e == -1) {
+                  bad = true;
+                  break;
+                }
+                entries[ent_base + nent++] = (uint16_t)e;
+                ++done;
+              }
+              PT_ACC_END(0);
+              if (err) break;
+              if (done > 0) {  // bounds of the adds the reference performed
+                const int last = done * dims - 1;
+                if (r_type == 1) {
+                  if (offset + last >= buflen) err = kErrRuntime;
+                } else {
+                  const int ob = r_rch > 1 ? (int)__umulhi((uint32_t)offset, r_rchm) : offset;
+                  const int lb = r_rch > 1 ? (int)__umulhi((uint32_t)last, r_rchm) : last;
+                  if (ob + lb >= buflen) err = kErrRuntime;
+                }
+                if (err) break;
+              }
+              for (int i = done; i < slots; i++) entries[ent_base + nent++] = (uint16_t)NVH_ENTRY_SKIP;
+              push = true;
+            }
+            if (push) {
+              if (nops >= (uint32_t)T.cap_ops) {
+                err = kErrRuntime;
+                break;
+              }
+              const unsigned cm = r.book_mask[cls];
+              const unsigned rank = (unsigned)__popc(cm & ((1u << stage) - 1u));
+              const uint32_t rw[2] = {NVH_SLAB_REC(ent_off - ent_base, book.slab_dm16, book.slab_lat & 0xFFFFu, book.slab_lat >> 16, dims, c,
+                                                   stage, (cm >> (stage + 1)) != 0)};
+              if (PM(1)) recs[start + rank] = make_uint2(rw[0], rw[1]);
+              ++nops;
+            }
+            if (bad) {
+              stop = true;
+              stop_p = partition_idx; stop_c = c; stop_pushed = true;
+              break;
+            }
+            ++c;
+          }
+          if (stop || err) ++stage;  // (the nest leaves `stage` one past the stage the packet ended in)
+        } else {
         for (; stage < r_stages && !stop && !err; stage++) {
           pass.op_begin[stage] = op_base + nops;
           for (int partition_idx = 0; partition_idx < partition_count && !stop && !err;) {
@@ -843,6 +1157,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
             }
           }
         }
+        }  // (the nest)
         if (SLAB && stop && !err) {
           // The packet ran out (Residue0.cs:160-168): the vector writes behind that point never happened, but their records are
           // part of chains that were allocated by class -- they get entries that say "no vector" (quirks B-14 / B-16), so that the
@@ -906,10 +1221,19 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   }
 
   PT_T(3);
-  if constexpr (UNI) __threadfence_block();  // the entries the window decode's lanes stored are read by the packet's lane below
 #ifdef NVH_DEBUG
-  if (dbg && active) { dbg[(long long)f * 24 + 8] = pt_acc[0]; dbg[(long long)f * 24 + 9] = pt_acc[1]; }
+  if (PHASE != 2 && dbg && active) { dbg[(long long)f * 24 + 8] = pt_acc[0]; dbg[(long long)f * 24 + 9] = pt_acc[1]; dbg[(long long)f * 24 + 10] = pt_acc[2]; dbg[(long long)f * 24 + 11] = pt_rounds; }
 #endif
+  if constexpr (PHASE == 1) {
+    // (every store of the parse -- posts, rows, records, entries, channel records -- is in global memory: the tail kernel's)
+    uint4* const hv = reinterpret_cast<uint4*>(ho);
+    hv[0] = make_uint4((uint32_t)err, nrec_alloc, nent, nops);
+    hv[1] = make_uint4(npass, exec_mask, (uint32_t)pcs, (uint32_t)(pcs >> 32));
+    hv[2] = make_uint4((uint32_t)s_rtype, (uint32_t)s_rch, (uint32_t)s_psz, (uint32_t)s_rbegin);
+    hv[3] = make_uint4((uint32_t)s_npass, (uint32_t)s_parts, (uint32_t)s_chs | ((uint32_t)s_b1 << 8) | ((links_ok ? 1u : 0u) << 16), (uint32_t)s_res);
+    return;
+  }
+  if constexpr (UNI) __threadfence_block();  // the entries the window decode's lanes stored are read by the packet's lane below
   uint32_t slab_vecs = 0;
   if constexpr (SLAB) {
     // ---- behind the parse, the lanes of the wavefront side by side: the rest of the slab ----
@@ -1022,7 +1346,9 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
         const uint4* src = reinterpret_cast<const uint4*>(entries + ent_base);
         uint4* dst = slab + off_ent;
         const uint32_t full = PM(4) ? nent >> 3 : 0;
-        for (uint32_t i = 0; i < full; ++i) dst[i] = src[i];
+        if constexpr (PHASE != 2) {
+          for (uint32_t i = 0; i < full; ++i) dst[i] = src[i];
+        }  // (PHASE 2: by the whole wavefront, below)
         if (nent & 7u) {
           uint16_t* d16 = reinterpret_cast<uint16_t*>(dst + full);
           const uint16_t* s16 = entries + ent_base + 8 * full;
@@ -1035,12 +1361,22 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
       H.off_heads = (uint16_t)off_heads;
       H.off_ent = (uint16_t)off_ent;
     }
+    if constexpr (PHASE == 2) {
+      // the frame's entries, 16 bytes per lane (the packet's lane has done the last partial vector)
+      const uint32_t oe = (uint32_t)__shfl(mine ? (int)H.off_ent : 0, 0);
+      if (__shfl((int)mine, 0)) {
+        const uint4* src = reinterpret_cast<const uint4*>(entries + ent_base);
+        uint4* dst = slab + oe;
+        const uint32_t full = nent >> 3;
+        for (uint32_t i = (uint32_t)lane; i < full; i += 64u) dst[i] = src[i];
+      }
+    }
     PT_T(4);
     // ---- floors, the wavefront together: the packets of its lanes one after the other, lane = post (floor_to_slab_wave) ----
     {
       // one floor scratch block per wavefront behind the per-lane areas (16-byte aligned), then one error word each
       const int nwaves = (int)(blockDim.x >> 6);
-      const int fs_word = (T.lds_words + T.meta_words + nwaves * lanes * (scratch_words + pkt_words) + 3) & ~3;
+      const int fs_word = (tab_words + T.meta_words + nwaves * lanes * (scratch_words + pkt_words) + 3) & ~3;
       FloorScratch* Q = reinterpret_cast<FloorScratch*>(s_prefix + fs_word) + wave;
       int* s_err = reinterpret_cast<int*>(s_prefix + fs_word + nwaves * NVH_SP_FLOOR_SCRATCH_WORDS) + wave;
       for (int j = 0; j < (PM(8) ? lanes : 0); ++j) {
@@ -1152,21 +1488,25 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   }
 }
 
-#define NVH_PARSE_KERNEL(NAME, LDSV, SLABV, UNIV)                                                                                        \
+#define NVH_PARSE_KERNEL(NAME, LDSV, SLABV, UNIV, CURV, PHASEV)                                                                          \
   extern "C" __global__ void __launch_bounds__(64 * NVH_PARSE_MAX_WAVES)                                                                  \
   NAME(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,                          \
        NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,          \
        uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,          \
        NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs,                     \
-       const int* __restrict__ order NVH_DBG_PARAMS) {                                                                                  \
-    parse_body<LDSV, SLABV, UNIV>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, result, lanes,      \
-                            scratch_words, pkt_words, slabs, order NVH_DBG_ARGS);                                                         \
+       const int* __restrict__ order, uint32_t* __restrict__ handover NVH_DBG_PARAMS) {                                                 \
+    parse_body<LDSV, SLABV, UNIV, CURV, PHASEV>(T, pkt_pool, refs, nframes, frames, chans, passes, ops, op_link, entries, posts, scratch, \
+                                                result, lanes, scratch_words, pkt_words, slabs, order, handover NVH_DBG_ARGS);           \
   }
-NVH_PARSE_KERNEL(k_parse, true, false, false)       // descriptors out, packets and scratch rows in LDS
-NVH_PARSE_KERNEL(k_parse_g, false, false, false)    // ... in global memory (a packet too long for the LDS budget)
-NVH_PARSE_KERNEL(k_parse_slab, true, true, false)   // slabs out (the stream shapes the slab synthesis kernels take)
-NVH_PARSE_KERNEL(k_parse_slab_g, false, true, false)
-NVH_PARSE_KERNEL(k_parse_slab_u, true, true, true)  // k_parse_slab for one packet per wavefront, wave-uniform (UNI above)
+NVH_PARSE_KERNEL(k_parse, true, false, false, false, 0)       // descriptors out, packets and scratch rows in LDS
+NVH_PARSE_KERNEL(k_parse_g, false, false, false, false, 0)    // ... in global memory (a packet too long for the LDS budget)
+NVH_PARSE_KERNEL(k_parse_slab, true, true, false, false, 0)   // slabs out (the stream shapes the slab synthesis kernels take)
+NVH_PARSE_KERNEL(k_parse_slab_g, false, true, false, false, 0)
+NVH_PARSE_KERNEL(k_parse_slab_u, true, true, true, false, 0)  // k_parse_slab for one packet per wavefront, wave-uniform (UNI above)
+// several packets per wavefront, every lane with its own cursor through the residue walk (CUR above), in two kernels (PHASE above):
+// the parse with up to 64 packets per wavefront, then the rest of the slab with one wavefront per packet
+NVH_PARSE_KERNEL(k_parse_slab_c, false, true, false, true, 1)
+NVH_PARSE_KERNEL(k_parse_slab_t, false, true, false, false, 2)
 
 // Second pass: what a frame needs from its neighbours (known only after every lane has parsed its packet): the overlap source's
 // execute flags (NvhChan::ov_exec / NvhFrame::ov_exec_mask) -- carry_exec_in: flags of the block carried in from the previous

@@ -99,7 +99,8 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
   const size_t o_sc = al(o_po + nf * (size_t)ch * NVH_MAX_POSTS * sizeof(uint16_t));
   const size_t row_words = (size_t)T.row_words;  // the residue walk's rows
   const size_t o_rs = al(o_sc + nf * row_words * sizeof(int));
-  const size_t total = al(o_rs + sizeof(NvhParseResult));
+  const size_t o_ho = al(o_rs + sizeof(NvhParseResult));  // hand-over of the split parser (kernels_parse.hip: NVH_PHO_WORDS words per frame)
+  const size_t total = al(o_ho + (slab_mode ? std::max<size_t>(nf, 1) * 16 * sizeof(uint32_t) : 0));
   if (slab_mode) {
     int rcs = b->slab3.reserve(((size_t)std::max<size_t>(nf, 1) * (size_t)T.slab_stride_vecs * 16 + 4096 + 255) & ~(size_t)255);
     if (rcs != NVH_OK) return rcs;
@@ -189,7 +190,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     // wavefronts, 2048 in all), 32 768 packets 1.17 against 1.23 ms, the corpus pass (16 host threads, each parsing its own
     // file's batches) 2.57 -> 2.01 s.
     const int lanes_env = nvh_toggles().parse_lanes, waves_env = nvh_toggles().parse_waves;
-    const int kParseWaves = (waves_env >= 1 && waves_env <= 16) ? waves_env : 16;
+    int kParseWaves = (waves_env >= 1 && waves_env <= 16) ? waves_env : 16;
     int lanes = 1;
     while (lanes < 64 && (nf + (size_t)lanes - 1) / (size_t)lanes > 4096) lanes *= 2;
     if (s->ctx->parse_lanes >= 1) {
@@ -201,6 +202,19 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
       lanes = std::max(lanes, want);
     }
     if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
+    // Several packets per wavefront, slab mode: the cursor form (kernels_parse.hip: CUR) in two kernels -- the parse, then the rest
+    // of the slab with one wavefront per packet (NVH_PARSE_CUR=0: the lockstep nest, k_parse_slab / _g, the form of rounds 3-5).
+    // The walk keeps a byte per (channel, partition) and NVH_PSTG = 32 entries of staging per lane in LDS next to the tables;
+    // workgroups of four wavefronts where that fits (a file's parse is a few dozen wavefronts: they should not sit on three CUs),
+    // else two, else one -- else the lockstep nest.
+    bool cur = slab_mode && lanes > 1 && nvh_toggles().parse_cur > 0;
+    const size_t cls_words = ((size_t)T.cap_parts + 3) / 4;
+    if (cur) {
+      int w = (waves_env >= 1 && waves_env <= 16) ? waves_env : 4;
+      while (w > 1 && (size_t)(T.lds_words + T.meta_words) + (size_t)w * 64 * (16 + cls_words) > (size_t)156 * 1024 / 4) w >>= 1;
+      if ((size_t)(T.lds_words + T.meta_words) + (size_t)w * 64 * (16 + cls_words) > (size_t)156 * 1024 / 4) cur = false;
+      else kParseWaves = w;
+    }
     const size_t per_wg = (size_t)kParseWaves * (size_t)lanes;
     const unsigned pblocks = (unsigned)((nf + per_wg - 1) / per_wg);
     // per-lane LDS next to the tables, while two workgroups still fit a CU (2 x 80 KB): the residue scratch rows first,
@@ -215,25 +229,40 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     // stays in global memory (k_parse_g)
     // slab mode: + one floor scratch block and an error word per wavefront (kernels_parse.hip: floor_to_slab_wave)
     const size_t floor_words = slab_mode ? (size_t)kParseWaves * (NVH_SP_FLOOR_SCRATCH_WORDS + 1) + 8 : 0;
-    const bool in_lds = table_words + per_wg * (size_t)(scratch_words + pkt_words) + floor_words <= lds_cap_words;
+    const bool in_lds = !cur && table_words + per_wg * (size_t)(scratch_words + pkt_words) + floor_words <= lds_cap_words;
     if (!in_lds) scratch_words = pkt_words = 0;
-    const size_t parse_lds = (table_words + per_wg * (size_t)(scratch_words + pkt_words) + floor_words) * sizeof(uint32_t);
+    const size_t stage_words = cur ? (size_t)kParseWaves * 64 * (16 + cls_words) : 0;
+    const size_t parse_lds = (table_words + std::max(per_wg * (size_t)(scratch_words + pkt_words), stage_words) + floor_words) * sizeof(uint32_t);
     if (!s->ctx->parse_lds_attr_set) {  // the opt-in is per device: once per context (contexts are single-threaded)
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_u, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_t, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       s->ctx->parse_lds_attr_set = true;
     }
     // one packet per wavefront (every batch of up to 4096 packets): the wave-uniform form of the slab parser
     const bool uni = slab_mode && in_lds && lanes == 1 && T.dm_in_lds && !nvh_toggles().no_parse_uni;
-    hipLaunchKernelGGL(uni ? k_parse_slab_u : slab_mode ? (in_lds ? k_parse_slab : k_parse_slab_g) : (in_lds ? k_parse : k_parse_g), dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
+    hipLaunchKernelGGL(cur ? k_parse_slab_c : uni ? k_parse_slab_u : slab_mode ? (in_lds ? k_parse_slab : k_parse_slab_g) : (in_lds ? k_parse : k_parse_g),
+                       dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
                        (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
                        (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
                        (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
                        (NvhParseResult*)(base + o_rs), lanes, scratch_words, pkt_words, slab_mode ? (uint4*)b->slab3.p : (uint4*)nullptr,
-                       sorted_parse ? (const int*)(base + o_od) : (const int*)nullptr NVH_DBG_LAUNCH);
+                       sorted_parse ? (const int*)(base + o_od) : (const int*)nullptr, (uint32_t*)(base + o_ho) NVH_DBG_LAUNCH);
+    if (cur) {
+      // the rest of the slab: one wavefront per packet, four per workgroup; LDS = the setup records + a floor scratch block and
+      // an error word per wavefront
+      constexpr int kTailWaves = 4;
+      const size_t tail_lds = ((size_t)T.meta_words + 3 + (size_t)kTailWaves * (NVH_SP_FLOOR_SCRATCH_WORDS + 1) + 8) * sizeof(uint32_t);
+      hipLaunchKernelGGL(k_parse_slab_t, dim3((unsigned)((nf + kTailWaves - 1) / kTailWaves)), dim3(64 * kTailWaves), tail_lds, st, T,
+                         (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
+                         (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
+                         (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
+                         (NvhParseResult*)(base + o_rs), 1, 0, 0, (uint4*)b->slab3.p, (const int*)nullptr, (uint32_t*)(base + o_ho) NVH_DBG_LAUNCH);
+    }
     // the carried block's execute flags ping-pong together with the carried block (nvh_stream_synth flips carry_cur)
     uint32_t* ce = (uint32_t*)s->carry_exec.p;
     hipLaunchKernelGGL(k_parse_links, dim3(blocks), dim3(64), 0, st, (int)nf, ch, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch),

@@ -28,8 +28,11 @@ names = ["frame record + packet into LDS + bit reader", "floors (Floor1.Unpack x
 for k in range(5):
     dt = d[:, k + 1] - d[:, k]
     print("%-48s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (names[k], dt.mean(), np.median(dt), np.percentile(dt, 90)))
-for nm, k in (("  inside residue: entry loops of the vectors", 8), ("  inside residue: class words", 9)):
+for nm, k in (("  inside residue: entry loops of the vectors", 8), ("  inside residue: class words", 9),
+              ("  inside residue: cursor steps between vectors (incl. class words)", 10), ("  vectors (rounds of the cursor walk)", 11)):
     print("%-48s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (nm, d[:, k].mean(), np.median(d[:, k]), np.percentile(d[:, k], 90)))
+if os.environ.get("NVH_PARSE_CUR", "2") == "2" and int(os.environ.get("NVH_PARSE_LANES", "1")) > 1:
+    d[:, 5] = d[:, 3]  # the split form: the parse kernel's stamps end with the residue
 life = d[:, 5] - d[:, 0]
 print("lane lifetime mean %.0f p50 %.0f p90 %.0f cycles" % (life.mean(), np.median(life), np.percentile(life, 90)))
 b.free(); st.close()
