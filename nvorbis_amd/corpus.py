@@ -257,7 +257,8 @@ def close_worker_contexts():
     _WORKER_CONTEXTS.clear()
 
 
-PARSE_LANES_POOL = 8  # nvh_ctx_set_parse_lanes for the contexts of a worker pool of eight threads and more (see the header)
+PARSE_LANES_POOL = 32  # nvh_ctx_set_parse_lanes for the contexts of a worker pool of eight threads and more (see the header; round 6:
+                       # 8 -> 32 with the lean walk of the multi-packet parser, whose wavefronts cost the same at 8 or 64 packets)
 
 
 def _warm_contexts(device, nthreads, sample, batch_frames, gpu_parse, parse_lanes, have):

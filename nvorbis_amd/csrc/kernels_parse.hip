@@ -44,9 +44,13 @@ struct BitR {
 
 template <bool LDS>
 __device__ __forceinline__ uint32_t br_word(const BitR& b, const uint32_t* __restrict__ s_pkt, uint32_t i) {
-  if (i >= b.nwords) return 0u;
-  if (LDS) return s_pkt[b.lds_word + (int)i];  // compile-time choice: never a generic pointer
-  return b.w[i];
+  if (LDS) return i >= b.nwords ? 0u : s_pkt[b.lds_word + (int)i];  // compile-time choice: never a generic pointer
+  // Global memory: the word is fetched whether or not the packet has it.  Index nwords -- the one word past the packet a reader
+  // ever asks for -- is the next packet's first word or the pool's zero tail (nvh_launch.hip: eight zero bytes behind the pool), and
+  // every use of a fetched word is behind `next < nwords`.  With the bounds test in front of the load the fetched value reaches
+  // its register through a copy, and the copy waits for the load then and there: "fetched ahead" was a round trip to L2 in every
+  // refill, ~700 cycles per symbol with several packets per wavefront (profiles/r06_cursor.txt).
+  return b.w[i < b.nwords ? i : b.nwords];
 }
 
 template <bool LDS>
@@ -334,6 +338,7 @@ __device__ __forceinline__ int floor_to_slab_wave(FloorScratch* Q, const NvhDevF
 // packet per wavefront: the floors are written by a whole wavefront per channel (lane = post), which in one kernel would happen
 // packet after packet for every lane of the parse's wavefront -- as long as the parse itself once its lanes run side by side.
 #define NVH_PHO_WORDS 16
+#define NVH_PHO_BAIL 0x7FFFFFF0u  // word 0 of a frame's hand-over: k_parse_slab_f left this packet to the general body (see there)
 #define NVH_PSTG 32  // entries of one vector a lane of the cursor walk collects in LDS (a longer vector stores straight to memory)
 template <bool LDS, bool SLAB, bool UNI = false, bool CUR = false, int PHASE = 0>
 __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
@@ -346,6 +351,26 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   constexpr bool WAVE1 = UNI || PHASE == 2;  // one packet per wavefront, the packet index uniform
   const int lanes = WAVE1 ? 1 : lanes_arg;
   const int tab_words = PHASE == 2 ? 0 : T.lds_words;  // (the tail reads no Huffman table)
+  // PHASE 1 behind k_parse_slab_f (pkt_words < 0): only the frames that kernel marked; a workgroup without one leaves at once
+  const bool redo_only = PHASE == 1 && pkt_words < 0;
+  if constexpr (PHASE == 1) {
+    if (redo_only) {
+      const int w0 = (int)threadIdx.x >> 6, l0 = (int)threadIdx.x & 63;
+      const int fi = (int)blockIdx.x * ((int)(blockDim.x >> 6) * lanes_arg) + w0 * lanes_arg + l0;
+      bool marked = l0 < lanes_arg && fi < nframes;
+      if (marked) marked = handover[(long long)(order ? order[fi] : fi) * NVH_PHO_WORDS] == NVH_PHO_BAIL;
+      // (a vote through the first word of the dynamic LDS: __syncthreads_or would bring a static block along, and the kernel's
+      // opt-in to a CU's whole LDS is sized for the dynamic one alone)
+      extern __shared__ __attribute__((aligned(16))) uint32_t s_vote[];
+      if (threadIdx.x == 0) s_vote[0] = 0u;
+      __syncthreads();
+      if (marked) s_vote[0] = 1u;
+      __syncthreads();
+      const bool any = s_vote[0] != 0u;
+      __syncthreads();  // (the table image goes over this word next)
+      if (!any) return;
+    }
+  }
 #ifdef NVH_DEBUG
 #define PM(bit) (!(phase_mask & ((bit) << 8)))  // profiling builds: NVH_DEBUG_SPECTRUM_MASK = 15 + 256 * (pieces to leave out)
 #else
@@ -388,6 +413,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   // a size -- its lanes run side by side only while all of them have symbols left -- and the launch ends on short ones.
   const int f_idx = WAVE1 ? (valid_u ? f_u : 0) : (active ? blockIdx.x * ((int)(blockDim.x >> 6) * lanes) + slot : 0);
   const int f = (order && PHASE != 2) ? order[f_idx] : f_idx;
+  if (redo_only && handover[(long long)f * NVH_PHO_WORDS] != NVH_PHO_BAIL) return;  // (no barrier below in this form)
 #ifdef NVH_DEBUG
 #define PT_T(k) do { if (dbg && active) dbg[(long long)f * 24 + (PHASE == 2 ? 12 : 0) + (k)] = clock64(); } while (0)
 #define PT_ACC_BEGIN() const long long pt_t0 = clock64()
@@ -1507,6 +1533,341 @@ NVH_PARSE_KERNEL(k_parse_slab_u, true, true, true, false, 0)  // k_parse_slab fo
 // the parse with up to 64 packets per wavefront, then the rest of the slab with one wavefront per packet
 NVH_PARSE_KERNEL(k_parse_slab_c, false, true, false, true, 1)
 NVH_PARSE_KERNEL(k_parse_slab_t, false, true, false, false, 2)
+
+// ---- the lean form of the multi-packet parse (k_parse_slab_f) ----
+// What k_parse_slab_c's measurements said (profiles/r06_cursor.txt): with the lanes' vectors decoded side by side the walk was
+// no faster on real packets, and neither its rows in global memory nor its stores per symbol were why -- moving both into LDS
+// changed nothing.  The general body compiles to ~13 k instructions with its condition masks spilled from SGPRs into VGPR lanes:
+// a step of the cursor costs ~1.7 k cycles of exec-mask bookkeeping.  This kernel is the same walk with nothing in it that the
+// ordinary packet does not need: one residue pass, Residue1 / Residue2, every vector of a visit in windows of the book's LDS
+// prefix table (long codes from their slot's group in LDS), whole packets.  Whatever else turns up -- a packet that ends inside
+// the residue, a book outside the LDS image, a Residue0, several submaps, a fault the reference would throw on -- is not decided
+// here: the lane marks its frame (NVH_PHO_BAIL) and k_parse_slab_c, launched behind this kernel over the marked frames only,
+// parses that packet from its first bit.  Same reads in the same order, same records, entries and rows as the general body for
+// every packet this kernel completes; the tail kernel (k_parse_slab_t) does not know which of the two wrote them.
+extern "C" __global__ void __launch_bounds__(256)
+k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
+               NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
+               uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
+               NvhParseResult* __restrict__ result, int lanes, int scratch_words, int pkt_words, uint4* __restrict__ slabs,
+               const int* __restrict__ order, uint32_t* __restrict__ handover NVH_DBG_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_prefix[];
+  uint32_t* s_meta = s_prefix + T.lds_words;
+  for (int i = threadIdx.x; i < T.lds_words; i += (int)blockDim.x) s_prefix[i] = T.lds_image[i];
+  {
+    const uint32_t* gm = reinterpret_cast<const uint32_t*>(T.books);
+    for (int i = threadIdx.x; i < T.meta_words; i += (int)blockDim.x) s_meta[i] = gm[i];
+  }
+  // (scratch_words: the words of the second-level image the host found room for -- all of it or none)
+  uint32_t* const s_sub = s_meta + T.meta_words;
+  const int sub_words = scratch_words;
+  for (int i = threadIdx.x; i < sub_words; i += (int)blockDim.x) s_sub[i] = T.sub_image[i];
+  __syncthreads();
+  const NvhPBook* books = reinterpret_cast<const NvhPBook*>(s_meta);
+  const NvhPFloor1* floors = reinterpret_cast<const NvhPFloor1*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_floors_off);
+  const NvhPResidue* residues = reinterpret_cast<const NvhPResidue*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_residues_off);
+  const NvhPMapping* mappings = reinterpret_cast<const NvhPMapping*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_mappings_off);
+  uint16_t* const s_stage16 = reinterpret_cast<uint16_t*>(s_sub + sub_words);                          // NVH_PSTG entries per lane
+  uint8_t* const s_cls = reinterpret_cast<uint8_t*>(s_stage16) + (size_t)blockDim.x * (NVH_PSTG * 2);  // a byte per (channel, partition)
+  const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int f_idx = (int)blockIdx.x * ((nt >> 6) * lanes) + wave * lanes + lane;
+  if (lane >= lanes || f_idx >= nframes) return;
+  const int f = order ? order[f_idx] : f_idx;
+  const NvhFrame fr = frames[f];
+  const int nch = T.channels;
+  NvhChan* ch_out = chans + (long long)f * nch;
+  const uint32_t ent_base = (uint32_t)f * (uint32_t)T.cap_ent;
+  uint2* const recs = reinterpret_cast<uint2*>(slabs + (long long)f * T.slab_stride_vecs + NVH_SLAB_HDR_VECS);
+  int* const g_rows = scratch + (long long)f * T.row_words;
+  bool bail = false;
+#ifdef NVH_DEBUG
+  long long ft[4] = {clock64(), 0, 0, 0}, facc[3] = {0, 0, 0}, frounds = 0;  // stamps: start, floors done, residue done; cycles in: steps, entries, flush + record
+  int why = 0;  // profiling builds: which test left the packet to the general body (tools/dbg_phase_parse.py prints the histogram)
+#define NVH_WHY(k) why = (k)
+#else
+#define NVH_WHY(k) do { } while (0)
+#endif
+  uint32_t nrec_alloc = 0, nent = 0, nops = 0, npass = 0, exec_mask = 0;
+  unsigned long long pcs = 0;
+  int s_rtype = 0, s_rch = 1, s_psz = 0, s_rbegin = 0, s_npass = 0, s_parts = 0, s_chs = 1, s_b1 = 0, s_res = 0;
+  if (fr.n != 0) {
+    const NvhPacketRef ref = refs[f];
+    BitR p;
+    br_init<false>(p, reinterpret_cast<const uint32_t*>(pkt_pool + ref.byte_off), -1, nullptr, ref.bit_len, ref.bit_pos);
+    const NvhPMapping& map = mappings[fr.mapping];
+    // ---- floors (Mapping.cs:95-111), as in parse_body ----
+    uint32_t energy = 0;
+    int err = 0;
+    for (int c = 0; c < nch && !err; c++) {
+      const int fl = map.chan_floor[c];
+      int pc = 0;
+      uint16_t* my_posts = posts + ((long long)f * nch + c) * NVH_MAX_POSTS;
+      err = decode_floor1<false, false>(T, s_prefix, nullptr, books, floors[fl], p, my_posts, &pc);
+      NvhChan cn;
+      cn.exec = 0;
+      cn.floor = (uint8_t)fl;
+      cn.post_count = (uint8_t)pc;
+      cn.ov_exec = 0;
+      cn.data_off = (uint32_t)(((long long)f * nch + c) * NVH_MAX_POSTS);
+      cn.amp = 0.0f;
+      ch_out[c] = cn;
+      if (pc > 0) energy |= 1u << c;
+      pcs |= (unsigned long long)(pc & 0x7F) << (7 * c);
+    }
+#ifdef NVH_DEBUG
+    ft[1] = clock64();
+#endif
+    if (err || map.submaps != 1) {
+      bail = true;
+      NVH_WHY(1);
+    }
+    const bool any_execute = energy != 0;  // computed before ForceEnergy (quirk B-5)
+    uint32_t force_e = 0, force_no = 0;
+    for (int i = 0; i < map.coupling_steps; i++) {  // Mapping.cs:112-119
+      const uint32_t a = 1u << map.coupling_ang[i], m = 1u << map.coupling_mag[i];
+      if (((force_e | energy) & ~force_no) & (a | m)) force_e |= a | m;
+    }
+    for (int j = 0; j < nch; j++)
+      if (map.submap_floor[0] != map.chan_floor[j] || map.submap_residue[0] != map.chan_residue[j]) force_no |= 1u << j;
+    // ---- the residue pass (Mapping.cs:122-134; Residue0.Decode :119-178) ----
+    if (any_execute && !bail) {
+      const int residue_idx = map.submap_residue[0];
+      const NvhPResidue& r = residues[residue_idx];
+      const int r_type = r.type, r_begin = r.begin, r_psize = r.partition_size, r_chs = r.channels, r_rch = r.real_channels,
+                r_stages = r.max_stages, r_partvals = r.partvals, cdim = r.class_dims;
+      const uint32_t dm_lds = r.decode_map_lds, vis_lds = r.vis_lds;
+      int block_size = fr.n;
+      if (r_type == 2) block_size *= r_rch;  // Residue2.cs:16-21
+      const int end = r.end < block_size / 2 ? r.end : block_size / 2;
+      const int n = end - r_begin;
+      int partition_count = 0;
+      if (n > 0) {
+        partition_count = n / r_psize;
+        // what the general body tests visit by visit, once: the last partition's longest vector stays inside the buffers
+        // (Residue1.cs:12-22, Residue2.cs:27-45), every partition index fits a record, the class rows fit their LDS bytes
+        const int last_off = r_begin + (partition_count > 0 ? partition_count - 1 : 0) * r_psize, span = (int)r.span_max;
+        const bool inside = r_type == 1 ? last_off + span - 1 < T.block1
+                                        : (r_rch > 1 ? (int)__umulhi((uint32_t)last_off, r.rch_magic) + (int)__umulhi((uint32_t)(span - 1), r.rch_magic)
+                                                     : last_off + span - 1) < T.block1;
+        if (cdim == 0 || r_stages == 0 || (r_type != 1 && r_type != 2) || dm_lds == 0xFFFFFFFFu || vis_lds == 0xFFFFFFFFu || !inside ||
+            partition_count > 0xFFFF || r_chs * partition_count > T.cap_parts || span < 1)
+          bail = true;
+ NVH_WHY(2);
+        if (!bail && partition_count > 0) {
+          const NvhPBook class_book = books[r.class_book];
+          const int last_base = T.cap_parts;
+          auto cls_at = [&](const int i) -> uint8_t& { return s_cls[4 * ((i >> 2) * nt + tid) + (i & 3)]; };
+          auto stage_at = [&](const int i) -> uint16_t& { return s_stage16[2 * ((i >> 1) * nt + tid) + (i & 1)]; };
+          auto consume = [&](const uint32_t len) {
+            p.buf >>= len;
+            p.avail -= len;
+            p.pos += len;
+            if (p.avail <= 32u && p.next < p.nwords) {  // (one word restores br_fill's invariant: len <= 32)
+              const uint32_t word = p.ahead;
+              p.next++;
+              p.ahead = p.w[p.next];  // (index nwords at most: see br_word)
+              p.buf |= (uint64_t)word << p.avail;
+              p.avail += 32u;
+            }
+          };
+          // Positions -- (partition, channel) in the order the walk visits them: index partition * channels + channel -- have two
+          // bytes in LDS each, written when their group's class word is decoded: the class, and the stages in which that class
+          // has a book (= how many records its chain has).  A step reads FOUR positions' stage bytes in one word: the first one
+          // with a book in this stage is the next visit, the bits in front of it are the records of the chains in front of it.
+          // (One position per step, class byte -> book mask -> test, cost 0.6 M of a packet's 1.4 M cycles: 180 steps of two
+          // dependent LDS reads, taken by every lane of the wavefront whenever one lane had to.)
+          const int npos = partition_count * r_chs, group_pos = cdim * r_chs;
+          uint32_t* const s_bmw = reinterpret_cast<uint32_t*>(s_cls) + (size_t)nt * (((size_t)T.cap_parts + 3) / 4);
+          auto bm_at = [&](const int i) -> uint8_t& { return reinterpret_cast<uint8_t*>(s_bmw)[4 * ((i >> 2) * nt + tid) + (i & 3)]; };
+          s_bmw[((npos - 1) >> 2) * nt + tid] = 0u;  // (the last word's bytes behind the last position)
+          uint32_t run = 0, start = 0, run0 = 0;
+          int stage = 0, pos = 0, known_end = 0;
+          bool going = true;
+          while (going) {
+            // ---- to the next visit that has a vector to decode ----
+#ifdef NVH_DEBUG
+            const long long fa0 = clock64();
+            ++frounds;
+#endif
+            unsigned cm = 0;
+            for (;;) {
+              if (pos >= known_end) {
+                if (pos >= npos) {  // next cascade stage (Residue0.cs:132)
+                  if (++stage >= r_stages) {
+                    going = false;
+                    break;
+                  }
+                  pos = 0; run = 0;
+                  continue;
+                }
+                // stage 0, the class words of the group of partitions that starts here (:137-150), then the chains of its
+                // positions in walk order (the tail kernel builds the heads from these rows)
+                const int p0 = known_end == 0 ? 0 : (r_chs == 1 ? pos : pos / r_chs);
+                for (int cc = 0; cc < r_chs; cc++) {
+                  const int idx = decode_scalar<false, false>(T, s_prefix, nullptr, class_book, p);
+                  if (idx < 0 || idx >= r_partvals) {  // the packet ends here, or the reference would fault: not this kernel's
+                    bail = true;
+                    NVH_WHY(3);
+                    break;
+                  }
+                  for (int d = 0; d < cdim && p0 + d < partition_count; d++) {
+                    const uint32_t k = s_prefix[dm_lds + (uint32_t)(idx * cdim + d)];
+                    cls_at((p0 + d) * r_chs + cc) = (uint8_t)k;
+                    bm_at((p0 + d) * r_chs + cc) = r.book_mask[k];
+                  }
+                }
+                if (bail) {
+                  going = false;
+                  break;
+                }
+                known_end = pos + group_pos < npos ? pos + group_pos : npos;
+                for (int i = pos; i < known_end; ++i) {
+                  const unsigned m = bm_at(i);
+                  g_rows[last_base + i] = m ? (int)run0 : -1;
+                  run0 += (uint32_t)__popc(m);
+                }
+              }
+              const int k4 = pos & ~3, o = pos & 3, lim = known_end - k4;
+              uint32_t w = s_bmw[(pos >> 2) * nt + tid];
+              w &= (0xFFFFFFFFu << (8 * o)) & (lim >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * lim)));
+              const uint32_t t = w & (0x01010101u << stage);
+              if (t == 0u) {
+                run += (uint32_t)__popc(w);
+                pos = lim >= 4 ? k4 + 4 : known_end;
+                continue;
+              }
+              const int kk = (__ffs((int)t) - 1) >> 3;
+              run += (uint32_t)__popc(w & ~(0xFFFFFFFFu << (8 * kk)));
+              start = run;
+              cm = (w >> (8 * kk)) & 0xFFu;
+              run += (uint32_t)__popc(cm);
+              pos = k4 + kk;
+              break;
+            }
+#ifdef NVH_DEBUG
+            const long long fa1 = clock64();
+            facc[0] += fa1 - fa0;
+#endif
+            if (!going) break;
+            if (run0 > (uint32_t)T.cap_ops) {
+              bail = true;
+ NVH_WHY(4);
+              break;
+            }
+            // ---- one visit: the entries of a vector (Residue0.cs:157-170) from its descriptor ----
+            const int cl = (int)cls_at(pos), c = r_chs == 1 ? 0 : pos % r_chs;
+            const uint4 V = *reinterpret_cast<const uint4*>(s_prefix + vis_lds + 4u * (uint32_t)(cl * NVH_MAX_STAGES + stage));
+            const int slots = (int)(V.y & 0xFFFFu);
+            if (V.x >= NVH_PVIS_SLOW || slots > NVH_PSTG || nent + (uint32_t)slots > (uint32_t)T.cap_ent) {
+              bail = true;
+ NVH_WHY(5);
+              break;
+            }
+            const uint32_t toff = V.x & 0xFFFFFFu, pmask = (1u << (V.x >> 24)) - 1u;
+            int done = 0;
+            uint32_t node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+            for (;;) {
+              const uint32_t rem = p.total - p.pos, len = node & 0x7Fu;
+              if ((node & 0x80u) != 0u && len <= rem) {
+                consume(len);
+                stage_at(done) = (uint16_t)(node >> 8);
+                if (++done >= slots) break;
+                node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+                continue;
+              }
+              // a code longer than the prefix (Codebook.cs:307-318): its slot's group of overflow nodes, in LDS
+              const NvhPBook& bk = books[V.z & 0xFFFFu];
+              const uint32_t cnt = node & 0x7Fu, ovf = bk.ovf_lds, sdir = sub_words > 1 ? bk.sub_dir : 0xFFFFFFFFu;
+              uint32_t hit_len = 0, hit_val = 0;
+              if ((node & 0x80u) == 0u && cnt != 0u && cnt != 0x7Fu && sdir != 0xFFFFFFFFu) {
+                // the group's second-level table (nvh_setup.hip): the bits behind the prefix index it
+                const uint32_t dw = s_sub[sdir + (node >> 8)];
+                if (dw != 0u) {
+                  const uint32_t e = s_sub[(dw & 0xFFFFFFu) + ((uint32_t)(p.buf >> (V.x >> 24)) & ((1u << (dw >> 24)) - 1u))];
+                  if (e & 0x80u) {
+                    hit_val = e >> 8;
+                    hit_len = e & 0x7Fu;
+                  }
+                }
+              } else if ((node & 0x80u) == 0u && bk.has_overflow && cnt != 0x7Fu && ovf != 0xFFFFFFFFu) {
+                const uint32_t mb = bk.max_bits;
+                const uint32_t data = (uint32_t)p.buf & (mb >= 32u ? 0xFFFFFFFFu : (1u << mb) - 1u);
+                const uint32_t g = ovf + 2u * (node >> 8);
+                for (uint32_t k = 0; k < cnt; ++k) {
+                  const uint32_t bits = s_prefix[g + 2u * k], vl = s_prefix[g + 2u * k + 1u], ln = vl & 0xFFu;
+                  if (bits == (data & ((1u << ln) - 1u))) {
+                    hit_val = vl >> 8;
+                    hit_len = ln;
+                    break;
+                  }
+                }
+              }
+              // (the buffer is the packet zero-extended, which is what the reference peeks at: Codebook.cs:307-318, DataPacket.cs:168-205)
+              if (hit_len == 0u || hit_len > 32u || hit_len > rem) {  // past the packet's end, a group outside LDS, no such code
+                bail = true;
+ NVH_WHY(6);
+                break;
+              }
+              consume(hit_len);
+              stage_at(done) = (uint16_t)hit_val;
+              if (++done >= slots) break;
+              node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
+            }
+#ifdef NVH_DEBUG
+            const long long fa2 = clock64();
+            facc[1] += fa2 - fa1;
+#endif
+            if (bail) break;
+            {
+              // the vector's entries to their place: a lone leading one where it starts on an odd entry, then pairs
+              uint16_t* __restrict__ eout = entries + ent_base + nent;
+              int k = 0;
+              if (nent & 1u) {
+                eout[0] = stage_at(0);
+                k = 1;
+              }
+              for (; k + 1 < slots; k += 2) *reinterpret_cast<uint32_t*>(eout + k) = (uint32_t)stage_at(k) | ((uint32_t)stage_at(k + 1) << 16);
+              if (k < slots) eout[k] = stage_at(k);
+            }
+            recs[start + ((V.y >> 24) & 7u)] = make_uint2((V.z & 0xFFFF0000u) | nent, V.w | ((uint32_t)c << 25));
+            nent += (uint32_t)slots;
+            ++nops;
+            ++pos;
+#ifdef NVH_DEBUG
+            facc[2] += clock64() - fa2;
+#endif
+          }
+          nrec_alloc = run0;
+          if (run0 > (uint32_t)T.cap_ops) {
+            bail = true;
+            NVH_WHY(7);
+          }
+        }
+      }
+      s_rtype = r_type; s_rch = r_rch; s_psz = r_psize; s_rbegin = r_begin;
+      s_parts = partition_count; s_chs = r_chs; s_b1 = r.alias_b1; s_res = residue_idx;
+      s_npass = 1;
+      npass = 1;
+    }
+    exec_mask = (force_e | energy) & ~force_no;
+    for (int c = 0; c < nch; c++) ch_out[c].exec = (exec_mask >> c) & 1u;
+  }
+#ifdef NVH_DEBUG
+  if (dbg) {
+    long long* D = dbg + (long long)f * 24;
+    D[20] = bail ? why : 0;
+    D[0] = ft[0]; D[1] = ft[0]; D[2] = ft[1]; D[3] = clock64();
+    D[8] = facc[1]; D[9] = 0; D[10] = facc[0]; D[11] = frounds; D[21] = facc[2];
+  }
+#endif
+  uint4* const hv = reinterpret_cast<uint4*>(handover + (long long)f * NVH_PHO_WORDS);
+  hv[0] = make_uint4(bail ? NVH_PHO_BAIL : 0u, nrec_alloc, nent, nops);
+  hv[1] = make_uint4(npass, exec_mask, (uint32_t)pcs, (uint32_t)(pcs >> 32));
+  hv[2] = make_uint4((uint32_t)s_rtype, (uint32_t)s_rch, (uint32_t)s_psz, (uint32_t)s_rbegin);
+  hv[3] = make_uint4((uint32_t)s_npass, (uint32_t)s_parts, (uint32_t)s_chs | ((uint32_t)s_b1 << 8) | (1u << 16), (uint32_t)s_res);
+}
+
 
 // Second pass: what a frame needs from its neighbours (known only after every lane has parsed its packet): the overlap source's
 // execute flags (NvhChan::ov_exec / NvhFrame::ov_exec_mask) -- carry_exec_in: flags of the block carried in from the previous

@@ -36,6 +36,7 @@ const NvhToggles& nvh_toggles() {
     x.parse_lanes = num("NVH_PARSE_LANES");
     x.parse_waves = num("NVH_PARSE_WAVES");
     x.no_parse_uni = on("NVH_NO_PARSE_UNI");
+    x.no_parse_sub = on("NVH_NO_PARSE_SUB");
     x.parse_cur = std::getenv("NVH_PARSE_CUR") ? num("NVH_PARSE_CUR") : -1;
     if (x.parse_cur > 2) x.parse_cur = 2;
     x.no_sleep_wait = on("NVH_NO_SLEEP_WAIT");

@@ -56,6 +56,7 @@ NVH_PARSE_DECL(k_parse_slab);    // slabs out (kernels_parse.hip: parse_body<..,
 NVH_PARSE_DECL(k_parse_slab_g);
 NVH_PARSE_DECL(k_parse_slab_u);  // k_parse_slab for one packet per wavefront, wave-uniform control flow (parse_body<.., UNI>)
 NVH_PARSE_DECL(k_parse_slab_c);  // several packets per wavefront, one cursor per lane through the residue walk: the parse alone ...
+NVH_PARSE_DECL(k_parse_slab_f);  // the lean form of k_parse_slab_c for ordinary packets; the others it leaves to k_parse_slab_c
 NVH_PARSE_DECL(k_parse_slab_t);  // ... and the rest of the slab, one packet per wavefront (parse_body<.., CUR, PHASE>)
 __global__ void k_parse_result_out(const NvhParseResult* dev, NvhParseResult* host);
 __global__ void k_parse_fetch(const uint4* stage_h, uint4* stage_d, long long stage_n16, const uint8_t* pool_h, uint8_t* pool_d,
@@ -143,8 +144,10 @@ struct NvhToggles {
   int lds_pad, ola_threads, parse_lanes, parse_waves;
   bool no_sleep_wait;  // NVH_NO_SLEEP_WAIT: worker-pool contexts wait with hipStreamSynchronize like every other (A/B aid)
   bool no_parse_sort;  // NVH_NO_PARSE_SORT: the GPU parser takes a batch's frames in stream order instead of longest packet first (A/B aid)
-  int parse_cur;      // NVH_PARSE_CUR: several packets per wavefront in slab mode: 0 = the lockstep nest (k_parse_slab / _g), else (default)
-                      // the cursor walk + tail kernel (k_parse_slab_c / _t); -1 = not set
+  int parse_cur;      // NVH_PARSE_CUR: several packets per wavefront in slab mode: 0 = the lockstep nest (k_parse_slab / _g), 1 = the cursor
+                      // walk + tail kernel (k_parse_slab_c / _t), 2 = the lean walk in front of it (k_parse_slab_f; the default where
+                      // the setup allows it); -1 = not set
+  bool no_parse_sub;  // NVH_NO_PARSE_SUB: k_parse_slab_f finds long codes by scanning their groups instead of through the second-level tables (A/B aid)
   bool no_parse_uni;  // NVH_NO_PARSE_UNI: one-packet-per-wavefront batches through k_parse_slab instead of k_parse_slab_u (A/B aid)
   int ola_segs;   // NVH_OLA_SEGS: workgroups per frame in k_ola_compact (default: by frame size)
   int phase_mask;  // debug build only (NVH_DEBUG_SPECTRUM_MASK)

@@ -197,23 +197,39 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
       // nvh_ctx_set_parse_lanes: a host with many parses in flight.  A small batch keeps at least 256 wavefronts -- a parse of
       // 260 packets at eight per wavefront is 33 wavefronts that take four times as long (the corpus at a tenth of its length:
       // decode pass 0.25 s with eight lanes throughout, 0.14 s with one)
+      // (that bound is the lockstep nest's, whose wavefronts take longer the more packets they hold; the lean walk's do not --
+      // k_parse_slab_f: 0.66 ms per wavefront at 8 or 64 packets -- so a batch of a thousand packets and more takes the pool's
+      // figure as it is: the fewer wavefronts a parse is, the more parses run side by side)
       int want = s->ctx->parse_lanes;
-      while (want > 1 && nf / (size_t)want < 256) want >>= 1;
+      const bool lean_batch = T.slab_stride_vecs > 0 && T.dm_in_lds && !T.slab_general && nvh_toggles().parse_cur != 0 &&
+                              nvh_toggles().parse_cur != 1 && nf >= 1024;
+      if (!lean_batch) while (want > 1 && nf / (size_t)want < 256) want >>= 1;
       lanes = std::max(lanes, want);
     }
+    // the lean walk (below) runs one workgroup of four wavefronts per CU (its tables and per-lane rows take most of a CU's LDS): a
+    // batch that is several packets per wavefront anyway gets enough of them for its workgroups to run in one round
+    if (lanes > 1 && T.slab_stride_vecs > 0 && T.dm_in_lds && !T.slab_general && nvh_toggles().parse_cur != 0 && nvh_toggles().parse_cur != 1)
+      while (lanes < 64 && (nf + (size_t)lanes * 4 - 1) / ((size_t)lanes * 4) > 256) lanes *= 2;
     if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
     // Several packets per wavefront, slab mode: the cursor form (kernels_parse.hip: CUR) in two kernels -- the parse, then the rest
     // of the slab with one wavefront per packet (NVH_PARSE_CUR=0: the lockstep nest, k_parse_slab / _g, the form of rounds 3-5).
     // The walk keeps a byte per (channel, partition) and NVH_PSTG = 32 entries of staging per lane in LDS next to the tables;
     // workgroups of four wavefronts where that fits (a file's parse is a few dozen wavefronts: they should not sit on three CUs),
     // else two, else one -- else the lockstep nest.
-    bool cur = slab_mode && lanes > 1 && nvh_toggles().parse_cur > 0;
-    const size_t cls_words = ((size_t)T.cap_parts + 3) / 4;
+    const int cur_env = nvh_toggles().parse_cur;
+    const bool lean_ok = T.dm_in_lds && !T.slab_general;  // (k_parse_slab_f: one residue pass per frame, visit descriptors in LDS)
+    bool cur = slab_mode && lanes > 1 && (cur_env > 0 || (cur_env < 0 && lean_ok));
+    const bool lean = cur && lean_ok && cur_env != 1;
+    const size_t cls_words = 2 * (((size_t)T.cap_parts + 3) / 4);  // class bytes + stage-mask bytes
+    size_t sub_words = 0;  // k_parse_slab_f: the second-level tables of the long codes, if they fit behind the records
     if (cur) {
       int w = (waves_env >= 1 && waves_env <= 16) ? waves_env : 4;
       while (w > 1 && (size_t)(T.lds_words + T.meta_words) + (size_t)w * 64 * (16 + cls_words) > (size_t)156 * 1024 / 4) w >>= 1;
       if ((size_t)(T.lds_words + T.meta_words) + (size_t)w * 64 * (16 + cls_words) > (size_t)156 * 1024 / 4) cur = false;
       else kParseWaves = w;
+      if (cur && T.sub_words > 1 && !nvh_toggles().no_parse_sub &&
+          (size_t)(T.lds_words + T.meta_words) + (size_t)T.sub_words + (size_t)w * 64 * (16 + cls_words) <= (size_t)156 * 1024 / 4)
+        sub_words = (size_t)T.sub_words;
     }
     const size_t per_wg = (size_t)kParseWaves * (size_t)lanes;
     const unsigned pblocks = (unsigned)((nf + per_wg - 1) / per_wg);
@@ -231,7 +247,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     const size_t floor_words = slab_mode ? (size_t)kParseWaves * (NVH_SP_FLOOR_SCRATCH_WORDS + 1) + 8 : 0;
     const bool in_lds = !cur && table_words + per_wg * (size_t)(scratch_words + pkt_words) + floor_words <= lds_cap_words;
     if (!in_lds) scratch_words = pkt_words = 0;
-    const size_t stage_words = cur ? (size_t)kParseWaves * 64 * (16 + cls_words) : 0;
+    const size_t stage_words = cur ? (size_t)kParseWaves * 64 * (16 + cls_words) + sub_words : 0;
     const size_t parse_lds = (table_words + std::max(per_wg * (size_t)(scratch_words + pkt_words), stage_words) + floor_words) * sizeof(uint32_t);
     if (!s->ctx->parse_lds_attr_set) {  // the opt-in is per device: once per context (contexts are single-threaded)
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -240,11 +256,21 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_u, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse_slab_t, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       s->ctx->parse_lds_attr_set = true;
     }
     // one packet per wavefront (every batch of up to 4096 packets): the wave-uniform form of the slab parser
     const bool uni = slab_mode && in_lds && lanes == 1 && T.dm_in_lds && !nvh_toggles().no_parse_uni;
+    if (lean) {
+      hipLaunchKernelGGL(k_parse_slab_f, dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
+                         (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
+                         (int)nf, (NvhFrame*)(base + o_fr), (NvhChan*)(base + o_ch), (NvhResPass*)(base + o_ps), (NvhResOp*)(base + o_op),
+                         (uint16_t*)(base + o_lk), (uint16_t*)(base + o_en), (uint16_t*)(base + o_po), (int*)(base + o_sc),
+                         (NvhParseResult*)(base + o_rs), lanes, (int)sub_words, 0, (uint4*)b->slab3.p,
+                         sorted_parse ? (const int*)(base + o_od) : (const int*)nullptr, (uint32_t*)(base + o_ho) NVH_DBG_LAUNCH);
+      pkt_words = -1;  // k_parse_slab_c below: the frames k_parse_slab_f marked, nothing else
+    }
     hipLaunchKernelGGL(cur ? k_parse_slab_c : uni ? k_parse_slab_u : slab_mode ? (in_lds ? k_parse_slab : k_parse_slab_g) : (in_lds ? k_parse : k_parse_g),
                        dim3(pblocks), dim3(64 * kParseWaves), parse_lds, st, T,
                        (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),
@@ -255,7 +281,7 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     if (cur) {
       // the rest of the slab: one wavefront per packet, four per workgroup; LDS = the setup records + a floor scratch block and
       // an error word per wavefront
-      constexpr int kTailWaves = 4;
+      constexpr int kTailWaves = 4;  // (sixteen per workgroup: 207 -> 250 us per 32 768 packets)
       const size_t tail_lds = ((size_t)T.meta_words + 3 + (size_t)kTailWaves * (NVH_SP_FLOOR_SCRATCH_WORDS + 1) + 8) * sizeof(uint32_t);
       hipLaunchKernelGGL(k_parse_slab_t, dim3((unsigned)((nf + kTailWaves - 1) / kTailWaves)), dim3(64 * kTailWaves), tail_lds, st, T,
                          (const uint8_t*)(base + o_pk), (const NvhPacketRef*)(base + o_rf),

@@ -34,6 +34,8 @@ struct NvhPBook {
   uint32_t dim_magic;     // ceil(2^32 / dims), 0 for dims <= 1: partition_size / dims without a division (nvh_setup.hip checks the range)
   uint32_t ovf_lds;       // word offset of the book's GROUPED overflow nodes inside the LDS image, two words each (bits, value << 8 |
                           // length; the mask is (1 << length) - 1), 0xFFFFFFFF: scan them in global memory
+  uint32_t sub_dir;       // word offset of the book's directory inside the second-level image (NvhDevParse::sub_image; nvh_setup.hip),
+                          // 0xFFFFFFFF: none -- a long code is found by scanning its group
 };
 
 struct NvhPOverflow {
@@ -118,6 +120,9 @@ struct NvhDevParse {
   const NvhDevFloor* dfloors;
   const uint32_t* recip;
   int32_t slab_stride_vecs, max_posts;
+  // second-level tables of the long codes (k_parse_slab_f): directories + tables, NvhPBook::sub_dir locates a book's directory
+  const uint32_t* sub_image;
+  int32_t sub_words, pad_sub;
 };
 
 // One packet's location for k_parse (its frame record carries the geometry).

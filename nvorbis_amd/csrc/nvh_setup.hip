@@ -339,7 +339,7 @@ int upload_parse_tables(nvh_stream* s) {
     d.ovf_count = (uint32_t)b.overflow.size();
   }
   // LDS image: the decode maps and visit descriptors, the residue VQ books, then the class and floor books, while they fit
-  std::vector<uint32_t> lds_image, dm_lds, vis_lds;
+  std::vector<uint32_t> lds_image, dm_lds, vis_lds, sub_image;
   {
     const size_t budget = 16 * 1024;  // words (64 KB; + <= 8 KB of book / floor / residue / mapping records).  The residue books first:
                                       // they fill 13 k words for a libvorbis setup, and one of them out of LDS costs more than
@@ -411,6 +411,52 @@ int upload_parse_tables(nvh_stream* s) {
       }
     }
     if (lds_image.empty()) lds_image.push_back(0u);
+    // Second-level tables for those books (k_parse_slab_f only, its own LDS block behind the records): per book a directory with one
+    // word per grouped node -- the word at a group's first node says where the group's table lies and how many bits index it -- and
+    // per group a table over the bits behind the prefix, as wide as the group's longest code: entry = (value << 8) | 0x80 | the code's
+    // whole length, 0 = no code.  A long code then is two LDS reads instead of a scan of its group (books of a libvorbis setup:
+    // up to 27 nodes per group, 3.5 k table entries in all).  Filled in the list's order, an entry keeps its first code: the node
+    // the reference's scan would stop at (Codebook.cs:307-318) for every bit pattern.
+    for (auto& d : books) d.sub_dir = 0xFFFFFFFFu;
+    for (int b : order) {
+      NvhPBook& d = books[(size_t)b];
+      const nvh::Codebook& cb = S.books[(size_t)b];
+      if (d.ovf_lds == 0xFFFFFFFFu || cb.slot_group.size() != cb.prefix.size()) continue;
+      const uint32_t pb = d.prefix_bits;
+      const size_t dir_off = sub_image.size();
+      sub_image.resize(dir_off + cb.overflow_grouped.size(), 0u);
+      bool ok = pb >= 1 && pb <= 24;
+      for (size_t k = 0; ok && k < cb.prefix.size(); k++) {
+        if (cb.prefix[k].present) continue;
+        const uint32_t g = cb.slot_group[k], cnt = g & 0xFFu, beg = g >> 8;
+        if (cnt == 0) continue;
+        if (cnt >= 0x7Fu || beg + cnt > cb.overflow_grouped.size()) { ok = false; break; }
+        uint32_t gmax = 0;
+        for (uint32_t j = 0; j < cnt; j++) gmax = std::max<uint32_t>(gmax, (uint32_t)cb.overflow_grouped[beg + j].length);
+        if (gmax <= pb || gmax - pb > 12 || gmax > 32) { ok = false; break; }
+        const uint32_t sbits = gmax - pb;
+        const size_t sub_off = sub_image.size();
+        if (sub_off + ((size_t)1 << sbits) > 6 * 1024 || sub_off > 0xFFFFFFu) { ok = false; break; }
+        sub_image.resize(sub_off + ((size_t)1 << sbits), 0u);
+        for (uint32_t j = 0; j < cnt; j++) {
+          const nvh::HuffNode& n = cb.overflow_grouped[beg + j];
+          const uint32_t len = (uint32_t)n.length, rl = len - pb;
+          if (len <= pb || ((uint32_t)n.bits & ((1u << pb) - 1u)) != (uint32_t)k || n.value < 0 || n.value > 0xFFFFFF) { ok = false; break; }
+          const uint32_t rest = (len >= 32 ? (uint32_t)n.bits : ((uint32_t)n.bits & ((1u << len) - 1u))) >> pb;
+          for (uint32_t hi = 0; hi < (1u << (sbits - rl)); hi++) {
+            uint32_t& e = sub_image[sub_off + ((hi << rl) | rest)];
+            if (e == 0u) e = ((uint32_t)n.value << 8) | 0x80u | len;
+          }
+        }
+        sub_image[dir_off + beg] = (uint32_t)sub_off | (sbits << 24);
+      }
+      if (!ok) {
+        sub_image.resize(dir_off);
+        continue;
+      }
+      d.sub_dir = (uint32_t)dir_off;
+    }
+    if (sub_image.empty()) sub_image.push_back(0u);
     // the visit descriptors, now that the books have their places
     for (size_t i = 0; i < S.residues.size(); i++) {
       if (vis_lds[i] == 0xFFFFFFFFu) continue;
@@ -556,6 +602,7 @@ int upload_parse_tables(nvh_stream* s) {
   size_t o_ov = ab.add(overflow.empty() ? &none : overflow.data(), (overflow.empty() ? 1 : overflow.size()) * sizeof(NvhPOverflow));
   size_t o_ip = ab.add(ipool.data(), ipool.size() * sizeof(int32_t));
   size_t o_li = ab.add(lds_image.data(), lds_image.size() * sizeof(uint32_t));
+  size_t o_si = ab.add(sub_image.data(), sub_image.size() * sizeof(uint32_t));
   if (meta_end - o_bk > 8 * 1024) return NVH_OK;  // unusually large setup: keep the host parser
   sh.parse_arena.pool = &s->ctx->pool;
   int rc = sh.parse_arena.reserve(ab.bytes.size());
@@ -578,6 +625,8 @@ int upload_parse_tables(nvh_stream* s) {
   P.ipool = (const int32_t*)(base + o_ip);
   P.lds_image = (const uint32_t*)(base + o_li);
   P.lds_words = (int32_t)lds_image.size();
+  P.sub_image = (const uint32_t*)(base + o_si);
+  P.sub_words = (int32_t)sub_image.size();
   P.meta_words = (int32_t)((meta_end - o_bk) / 4);
   P.meta_floors_off = (int32_t)(o_fl - o_bk);
   P.meta_residues_off = (int32_t)(o_rs - o_bk);
