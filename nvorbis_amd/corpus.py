@@ -261,6 +261,19 @@ PARSE_LANES_POOL = 32  # nvh_ctx_set_parse_lanes for the contexts of a worker po
                        # 8 -> 32 with the lean walk of the multi-packet parser, whose wavefronts cost the same at 8 or 64 packets)
 
 
+def _cpu_budget():
+    """CPUs this process may really use: the cgroup's quota where there is one (a GPU box's container says 256 CPUs and has 16),
+    else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def _warm_contexts(device, nthreads, sample, batch_frames, gpu_parse, parse_lanes, have):
     """Worker contexts made ready while the host-only index pass runs: each opens a stream on `sample` (a file of the job),
     parses and synthesises one look-ahead batch of it into a scratch buffer and closes the stream again -- which leaves behind
@@ -497,10 +510,17 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
     warm_thread, warm = None, None
     if n and not os.environ.get("NVH_CORPUS_NO_WARM"):  # the GPU side of the workers gets ready while the index pass keeps the CPUs busy
         sample = max(range(n), key=lambda i: len(files[i]))
-        warm_thread, warm = _warm_contexts(device, max(1, min(workers, n)), files[sample], batch_frames, gpu_parse, lanes,
+        # (a pool of GPU-parse workers may be twice the CPUs -- its threads wait for the GPU most of the time --; the index pass
+        # is host work: as many threads as CPUs, and as many contexts warmed beside it -- 32 of each on a 16-CPU box made a
+        # fresh process's index pass 0.14 -> 0.49 s.  The pool's other threads make their contexts themselves.)
+        budget = _cpu_budget()
+        nwarm = max(1, min(workers, n))
+        if not keep:
+            nwarm = min(nwarm, max(8, budget))
+        warm_thread, warm = _warm_contexts(device, nwarm, files[sample], batch_frames, gpu_parse, lanes,
                                            _WORKER_CONTEXTS.get(device) if keep else None)
     arena_thread, arena_box = (None, [None]) if (not n or os.environ.get("NVH_CORPUS_NO_WARM")) else _early_arena(files, device)
-    errors = _run_pool(n, workers, device, index_one, need_ctx=False)  # host-only: no GPU context per thread
+    errors = _run_pool(n, min(workers, max(8, _cpu_budget())), device, index_one, need_ctx=False)  # host-only: no GPU context per thread
     if arena_thread is not None:
         arena_thread.join()
     if errors:
