@@ -178,7 +178,9 @@ def end_to_end(nv, ctx, headers, ll, frames=32768, rounds=16):
         dt = (time.perf_counter() - t0) / rounds
         best = dt if best is None or dt < best else best
     out["gpu_parser_pipelined_frames_per_s"] = frames / best
-    out["gpu_parser_kernels"] = ["k_parse_slab", "k_parse_links"] + [k for k in st.kernels() if k != "-"]
+    # (a 32 768-packet batch of this setup: 32 packets per wavefront through the lean walk, the general body over the frames it
+    # leaves -- none here --, the rest of the slab one wavefront per packet; nvh_launch.hip: batch_upload_gpu)
+    out["gpu_parser_kernels"] = ["k_parse_fetch", "k_parse_slab_f", "k_parse_slab_c", "k_parse_slab_t", "k_parse_links"] + [k for k in st.kernels() if k != "-"]
     out["gpu_parser_pcm_GBps_over_pcie"] = frames * (BLOCK // 2) * 2 * 4 / best / 1e9
     st.close()
     return out

@@ -401,6 +401,9 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
   // every ~5 cycles at best: the host picks few packets per wavefront and ~2 wavefronts per SIMD for small batches
   // (a 4096-packet batch at 64 per wavefront would sit on 64 of 1024 SIMDs) and fills wavefronts up for large ones.
   const int wave = WAVE1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  // (CUR: the per-lane LDS rows of the cursor walk are indexed by packet of the workgroup, not by thread: with 32 packets per
+  // wavefront twice as many wavefronts share a copy of the tables)
+  const int nl = (int)(blockDim.x >> 6) * lanes, li = wave * lanes + lane;
   // UNI: the wavefront's packet (uniform)
   const int f_u = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
   const bool valid_u = f_u < nframes;
@@ -638,8 +641,8 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
           // their chains in, a chain's first record is the sum of the chain lengths in front of it.  The rows in global memory
           // are still written (the tail kernel builds the heads from them, the end-of-packet fix-up below reads them), never read
           // here: a step that waits for a global load behind its own stores cost 2-5 k cycles, 180 steps per packet.
-          uint8_t* const s_cls = reinterpret_cast<uint8_t*>(s_stage16) + (size_t)blockDim.x * (NVH_PSTG * 2);
-          auto cls_at = [&](const int i) -> uint8_t& { return s_cls[4 * ((i >> 2) * (int)blockDim.x + (int)threadIdx.x) + (i & 3)]; };
+          uint8_t* const s_cls = reinterpret_cast<uint8_t*>(s_stage16) + (size_t)nl * (NVH_PSTG * 2);
+          auto cls_at = [&](const int i) -> uint8_t& { return s_cls[4 * ((i >> 2) * nl + li) + (i & 3)]; };
           const uint32_t pass_rec0 = nrec_alloc;
           uint32_t run = pass_rec0, start = 0;
           int partition_idx = 0, c = 0, dimension_idx = 0;
@@ -797,7 +800,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                 auto run = [&](auto staged) {
                   constexpr bool STG = decltype(staged)::value;
                   auto put = [&](const int i, const uint32_t v) {
-                    if constexpr (STG) s_stage16[2 * ((i >> 1) * (int)blockDim.x + (int)threadIdx.x) + (i & 1)] = (uint16_t)v;
+                    if constexpr (STG) s_stage16[2 * ((i >> 1) * nl + li) + (i & 1)] = (uint16_t)v;
                     else eout[i] = (uint16_t)v;
                   };
                   for (;;) {
@@ -842,7 +845,7 @@ __device__ __forceinline__ void parse_body(const NvhDevParse& T, const uint8_t* 
                   }
                   if constexpr (STG) {
                     // the collected entries to their place: a lone leading one where the vector starts on an odd entry, then pairs
-                    auto get = [&](const int i) { return (uint32_t)s_stage16[2 * ((i >> 1) * (int)blockDim.x + (int)threadIdx.x) + (i & 1)]; };
+                    auto get = [&](const int i) { return (uint32_t)s_stage16[2 * ((i >> 1) * nl + li) + (i & 1)]; };
                     int k = 0;
                     if ((nent & 1u) && done > 0) {
                       eout[0] = (uint16_t)get(0);
@@ -1545,7 +1548,7 @@ NVH_PARSE_KERNEL(k_parse_slab_t, false, true, false, false, 2)
 // here: the lane marks its frame (NVH_PHO_BAIL) and k_parse_slab_c, launched behind this kernel over the marked frames only,
 // parses that packet from its first bit.  Same reads in the same order, same records, entries and rows as the general body for
 // every packet this kernel completes; the tail kernel (k_parse_slab_t) does not know which of the two wrote them.
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(512)
 k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPacketRef* __restrict__ refs, int nframes,
                NvhFrame* __restrict__ frames, NvhChan* __restrict__ chans, NvhResPass* __restrict__ passes, NvhResOp* __restrict__ ops,
                uint16_t* __restrict__ op_link, uint16_t* __restrict__ entries, uint16_t* __restrict__ posts, int* __restrict__ scratch,
@@ -1568,10 +1571,11 @@ k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPac
   const NvhPResidue* residues = reinterpret_cast<const NvhPResidue*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_residues_off);
   const NvhPMapping* mappings = reinterpret_cast<const NvhPMapping*>(reinterpret_cast<const uint8_t*>(s_meta) + T.meta_mappings_off);
   uint16_t* const s_stage16 = reinterpret_cast<uint16_t*>(s_sub + sub_words);                          // NVH_PSTG entries per lane
-  uint8_t* const s_cls = reinterpret_cast<uint8_t*>(s_stage16) + (size_t)blockDim.x * (NVH_PSTG * 2);  // a byte per (channel, partition)
-  const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int f_idx = (int)blockIdx.x * ((nt >> 6) * lanes) + wave * lanes + lane;
+  // (the per-lane rows are indexed by packet of the workgroup -- nt of them, this lane's is tid --, not by thread: see parse_body)
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int nt = (int)(blockDim.x >> 6) * lanes, tid = wave * lanes + lane;
+  uint8_t* const s_cls = reinterpret_cast<uint8_t*>(s_stage16) + (size_t)nt * (NVH_PSTG * 2);  // a byte per (channel, partition)
+  const int f_idx = (int)blockIdx.x * nt + tid;
   if (lane >= lanes || f_idx >= nframes) return;
   const int f = order ? order[f_idx] : f_idx;
   const NvhFrame fr = frames[f];

@@ -206,31 +206,31 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
       if (!lean_batch) while (want > 1 && nf / (size_t)want < 256) want >>= 1;
       lanes = std::max(lanes, want);
     }
-    // the lean walk (below) runs one workgroup of four wavefronts per CU (its tables and per-lane rows take most of a CU's LDS): a
-    // batch that is several packets per wavefront anyway gets enough of them for its workgroups to run in one round
+    // the lean walk (below) runs one workgroup of up to eight wavefronts per CU (its tables and per-packet rows take most of a CU's
+    // LDS): a batch that is several packets per wavefront anyway gets enough of them for its workgroups to run in one round
     if (lanes > 1 && T.slab_stride_vecs > 0 && T.dm_in_lds && !T.slab_general && nvh_toggles().parse_cur != 0 && nvh_toggles().parse_cur != 1)
-      while (lanes < 64 && (nf + (size_t)lanes * 4 - 1) / ((size_t)lanes * 4) > 256) lanes *= 2;
+      while (lanes < 32 && (nf + (size_t)lanes * 8 - 1) / ((size_t)lanes * 8) > 256) lanes *= 2;
     if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
     // Several packets per wavefront, slab mode: the cursor form (kernels_parse.hip: CUR) in two kernels -- the parse, then the rest
     // of the slab with one wavefront per packet (NVH_PARSE_CUR=0: the lockstep nest, k_parse_slab / _g, the form of rounds 3-5).
-    // The walk keeps a byte per (channel, partition) and NVH_PSTG = 32 entries of staging per lane in LDS next to the tables;
-    // workgroups of four wavefronts where that fits (a file's parse is a few dozen wavefronts: they should not sit on three CUs),
-    // else two, else one -- else the lockstep nest.
+    // The walk keeps two bytes per (channel, partition) and NVH_PSTG = 32 entries of staging per packet in LDS next to the tables;
+    // workgroups of eight wavefronts where that fits, else four, two, one -- else the lockstep nest.
     const int cur_env = nvh_toggles().parse_cur;
     const bool lean_ok = T.dm_in_lds && !T.slab_general;  // (k_parse_slab_f: one residue pass per frame, visit descriptors in LDS)
     bool cur = slab_mode && lanes > 1 && (cur_env > 0 || (cur_env < 0 && lean_ok));
-    const bool lean = cur && lean_ok && cur_env != 1;
     const size_t cls_words = 2 * (((size_t)T.cap_parts + 3) / 4);  // class bytes + stage-mask bytes
     size_t sub_words = 0;  // k_parse_slab_f: the second-level tables of the long codes, if they fit behind the records
     if (cur) {
-      int w = (waves_env >= 1 && waves_env <= 16) ? waves_env : 4;
-      while (w > 1 && (size_t)(T.lds_words + T.meta_words) + (size_t)w * 64 * (16 + cls_words) > (size_t)156 * 1024 / 4) w >>= 1;
-      if ((size_t)(T.lds_words + T.meta_words) + (size_t)w * 64 * (16 + cls_words) > (size_t)156 * 1024 / 4) cur = false;
-      else kParseWaves = w;
-      if (cur && T.sub_words > 1 && !nvh_toggles().no_parse_sub &&
-          (size_t)(T.lds_words + T.meta_words) + (size_t)T.sub_words + (size_t)w * 64 * (16 + cls_words) <= (size_t)156 * 1024 / 4)
-        sub_words = (size_t)T.sub_words;
+      // (rows per packet of the workgroup: up to eight wavefronts -- two per SIMD -- where they hold 32 packets or fewer each)
+      const size_t lds_cap = (size_t)156 * 1024 / 4, tabw = (size_t)(T.lds_words + T.meta_words);
+      const size_t subw = (T.sub_words > 1 && !nvh_toggles().no_parse_sub) ? (size_t)T.sub_words : 0;
+      int w = (waves_env >= 1 && waves_env <= 8) ? waves_env : 8;
+      while (w > 1 && ((size_t)w * (size_t)lanes > 256 || tabw + subw + (size_t)w * (size_t)lanes * (16 + cls_words) > lds_cap)) w >>= 1;
+      if (tabw + subw + (size_t)w * (size_t)lanes * (16 + cls_words) <= lds_cap) sub_words = subw;
+      else if (tabw + (size_t)w * (size_t)lanes * (16 + cls_words) > lds_cap) cur = false;
+      if (cur) kParseWaves = w;
     }
+    const bool lean = cur && lean_ok && cur_env != 1;
     const size_t per_wg = (size_t)kParseWaves * (size_t)lanes;
     const unsigned pblocks = (unsigned)((nf + per_wg - 1) / per_wg);
     // per-lane LDS next to the tables, while two workgroups still fit a CU (2 x 80 KB): the residue scratch rows first,
@@ -244,10 +244,10 @@ static int batch_upload_gpu(nvh_stream* s, nvh_batch* b, const std::vector<int>&
     // LDS variant only when both the rows and the longest packet of the batch fit for every lane; else everything per-lane
     // stays in global memory (k_parse_g)
     // slab mode: + one floor scratch block and an error word per wavefront (kernels_parse.hip: floor_to_slab_wave)
-    const size_t floor_words = slab_mode ? (size_t)kParseWaves * (NVH_SP_FLOOR_SCRATCH_WORDS + 1) + 8 : 0;
+    const size_t floor_words = (slab_mode && !cur) ? (size_t)kParseWaves * (NVH_SP_FLOOR_SCRATCH_WORDS + 1) + 8 : 0;  // (cur: the tail kernel's)
     const bool in_lds = !cur && table_words + per_wg * (size_t)(scratch_words + pkt_words) + floor_words <= lds_cap_words;
     if (!in_lds) scratch_words = pkt_words = 0;
-    const size_t stage_words = cur ? (size_t)kParseWaves * 64 * (16 + cls_words) + sub_words : 0;
+    const size_t stage_words = cur ? (size_t)kParseWaves * (size_t)lanes * (16 + cls_words) + sub_words : 0;
     const size_t parse_lds = (table_words + std::max(per_wg * (size_t)(scratch_words + pkt_words), stage_words) + floor_words) * sizeof(uint32_t);
     if (!s->ctx->parse_lds_attr_set) {  // the opt-in is per device: once per context (contexts are single-threaded)
       HIP_TRY(hipFuncSetAttribute((const void*)k_parse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

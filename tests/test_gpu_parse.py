@@ -217,3 +217,35 @@ def test_parse_lanes_of_a_context_do_not_change_the_pcm(oracle, ogg_bytes, lanes
         ctx.set_parse_lanes(0)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["NVH_PARSE_LANES=8", "NVH_PARSE_LANES=32", "NVH_PARSE_LANES=16+NVH_NO_PARSE_SUB=1",
+                                  "NVH_PARSE_LANES=8+NVH_PARSE_CUR=1", "NVH_PARSE_LANES=8+NVH_PARSE_CUR=0"])
+def test_multi_packet_parser_forms_bit_exact(form):
+    """Several packets per wavefront (kernels_parse.hip): by default the lean walk k_parse_slab_f (one cursor per lane, four
+    positions per step, long codes through second-level tables; NVH_NO_PARSE_SUB: by scanning their groups), behind it the general
+    body k_parse_slab_c over the frames the lean walk left -- packets that end inside the residue, faults, setups of the general bin
+    walk -- and the tail kernel k_parse_slab_t; NVH_PARSE_CUR=1: the general body's cursor walk for every frame; NVH_PARSE_CUR=0:
+    the lockstep nest of rounds 3-5 (k_parse_slab / _g).  NVH_PARSE_LANES forces the shape on every batch, whatever its size:
+    this file (shipped files, truncated and random packets, faults) and the parity suite + the full-depth configs, GPU-parsed,
+    are replayed in a child process under each form."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NVH_TEST_CHILD"):
+        pytest.skip("already inside a replay")
+    env = dict(os.environ)
+    for t in form.split("+"):
+        k, v = t.split("=")
+        env[k] = v
+    env["NVH_TEST_CHILD"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"]
+    r = subprocess.run(base + [os.path.join(root, "tests", "test_gpu_parse.py")], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    env["NVH_GPU_PARSE"] = "1"
+    r = subprocess.run(base + [os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_full_depth.py")],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
