@@ -38,8 +38,8 @@ namespace NVorbis.Hip
         readonly Queue<KeyValuePair<Exception, int>> _pendingErrors = new Queue<KeyValuePair<Exception, int>>();
 
         /// <param name="poolParseLanes">0 for a lone decoder.  A host that runs many decoders at once (one per worker thread: a
-        /// corpus transcoder) passes 8 -- nvh_ctx_set_parse_lanes: the GPU parser then puts up to eight packets on a wavefront,
-        /// so that the parses of all workers fit the chip side by side -- and starts its process with GPU_MAX_HW_QUEUES=16 in the
+        /// corpus transcoder) passes 32 -- nvh_ctx_set_parse_lanes: the GPU parser then puts up to 32 packets on a wavefront, every
+        /// lane walking its own, so that the parses of all workers fit the chip side by side -- and starts its process with GPU_MAX_HW_QUEUES=16 in the
         /// environment (INTEGRATION.md).  The PCM does not depend on it.</param>
         public GpuStreamDecoder(Contracts.IPacketProvider packetProvider, int device = 0, int batchPackets = 1024, int poolParseLanes = 0)
         {

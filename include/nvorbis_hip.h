@@ -62,10 +62,12 @@ int nvh_ctx_synchronize(nvh_ctx *ctx);
 /* Launch shape of the GPU packet parser (nvh_stream_set_gpu_parse) for the streams of this context: packets per wavefront,
  * a power of two 1..64, 0 = automatic (one packet per wavefront up to 4096 packets per batch: the lowest latency for a lone
  * stream).  A host that keeps many contexts busy at once -- a corpus worker pool, one context per thread -- gives each
- * of them 8 (an upper limit: a batch keeps at least 256 wavefronts, so short files parse one packet per wavefront all the
- * same): a parse then occupies an eighth of the wavefront slots for about four times as long, and the parses of all workers
- * fit the chip side by side (the corpus of BASELINE configs[4], 16 workers: decode pass 0.82 -> 0.51 s; with the process
- * started under GPU_MAX_HW_QUEUES=16, the HIP runtime's default of 4 hardware queues lets only four kernels run at once).
+ * of them 32 (an upper limit for batches below a thousand packets, which keep at least 256 wavefronts: short files parse
+ * one packet per wavefront all the same): where packets share wavefronts every lane walks its own packet (k_parse_slab_f;
+ * a wavefront costs the same at 8 or 64 packets), a parse is a few dozen wavefronts, and the parses of all workers fit the
+ * chip side by side (the corpus of BASELINE configs[4]: decode pass 0.82 -> 0.51 s with 8 packets per wavefront and 16
+ * workers in round 5, 0.35 s with 32 and 32; with the process started under GPU_MAX_HW_QUEUES=16, the HIP runtime's
+ * default of 4 hardware queues lets only four kernels run at once).
  * No counterpart in the reference (its decoder is one thread per stream); results do not depend on it. */
 int nvh_ctx_set_parse_lanes(nvh_ctx *ctx, int lanes);
 
