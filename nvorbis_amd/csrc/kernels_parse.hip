@@ -1663,18 +1663,6 @@ k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPac
           const int last_base = T.cap_parts;
           auto cls_at = [&](const int i) -> uint8_t& { return s_cls[4 * ((i >> 2) * nt + tid) + (i & 3)]; };
           auto stage_at = [&](const int i) -> uint16_t& { return s_stage16[2 * ((i >> 1) * nt + tid) + (i & 1)]; };
-          auto consume = [&](const uint32_t len) {
-            p.buf >>= len;
-            p.avail -= len;
-            p.pos += len;
-            if (p.avail <= 32u && p.next < p.nwords) {  // (one word restores br_fill's invariant: len <= 32)
-              const uint32_t word = p.ahead;
-              p.next++;
-              p.ahead = p.w[p.next];  // (index nwords at most: see br_word)
-              p.buf |= (uint64_t)word << p.avail;
-              p.avail += 32u;
-            }
-          };
           // Positions -- (partition, channel) in the order the walk visits them: index partition * channels + channel -- have two
           // bytes in LDS each, written when their group's class word is decoded: the class, and the stages in which that class
           // has a book (= how many records its chain has).  A step reads FOUR positions' stage bytes in one word: the first one
@@ -1769,55 +1757,68 @@ k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPac
               break;
             }
             const uint32_t toff = V.x & 0xFFFFFFu, pmask = (1u << (V.x >> 24)) - 1u;
+            // The symbol loop: ONE copy of the consume / store / next-lookup sequence -- a long code only replaces (value, length) in
+            // front of it --, the bits left in the packet counted down instead of the position up, the staging address stepped instead
+            // of computed: a lone wavefront pays for every instruction and every branch of this loop with its latency.
             int done = 0;
+            uint32_t rem = p.total - p.pos;
+            uint8_t* sp = reinterpret_cast<uint8_t*>(s_stage16) + 4 * tid;  // entry i: 4 * ((i >> 1) * nt + tid) + 2 * (i & 1) bytes
+            const int sp_odd = 4 * nt - 2;
             uint32_t node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
             for (;;) {
-              const uint32_t rem = p.total - p.pos, len = node & 0x7Fu;
-              if ((node & 0x80u) != 0u && len <= rem) {
-                consume(len);
-                stage_at(done) = (uint16_t)(node >> 8);
-                if (++done >= slots) break;
-                node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
-                continue;
-              }
-              // a code longer than the prefix (Codebook.cs:307-318): its slot's group of overflow nodes, in LDS
-              const NvhPBook& bk = books[V.z & 0xFFFFu];
-              const uint32_t cnt = node & 0x7Fu, ovf = bk.ovf_lds, sdir = sub_words > 1 ? bk.sub_dir : 0xFFFFFFFFu;
-              uint32_t hit_len = 0, hit_val = 0;
-              if ((node & 0x80u) == 0u && cnt != 0u && cnt != 0x7Fu && sdir != 0xFFFFFFFFu) {
-                // the group's second-level table (nvh_setup.hip): the bits behind the prefix index it
-                const uint32_t dw = s_sub[sdir + (node >> 8)];
-                if (dw != 0u) {
-                  const uint32_t e = s_sub[(dw & 0xFFFFFFu) + ((uint32_t)(p.buf >> (V.x >> 24)) & ((1u << (dw >> 24)) - 1u))];
-                  if (e & 0x80u) {
-                    hit_val = e >> 8;
-                    hit_len = e & 0x7Fu;
+              uint32_t val = node >> 8, len = node & 0x7Fu;
+              if (!((node & 0x80u) != 0u && len <= rem)) {
+                // a code longer than the prefix (Codebook.cs:307-318): its slot's second-level table, else its group of overflow nodes
+                // (the buffer is the packet zero-extended, which is what the reference peeks at: DataPacket.cs:168-205)
+                const NvhPBook& bk = books[V.z & 0xFFFFu];
+                const uint32_t cnt = node & 0x7Fu, ovf = bk.ovf_lds, sdir = sub_words > 1 ? bk.sub_dir : 0xFFFFFFFFu;
+                uint32_t hit_len = 0, hit_val = 0;
+                if ((node & 0x80u) == 0u && cnt != 0u && cnt != 0x7Fu && sdir != 0xFFFFFFFFu) {
+                  const uint32_t dw = s_sub[sdir + (node >> 8)];
+                  if (dw != 0u) {
+                    const uint32_t e = s_sub[(dw & 0xFFFFFFu) + ((uint32_t)(p.buf >> (V.x >> 24)) & ((1u << (dw >> 24)) - 1u))];
+                    if (e & 0x80u) {
+                      hit_val = e >> 8;
+                      hit_len = e & 0x7Fu;
+                    }
+                  }
+                } else if ((node & 0x80u) == 0u && bk.has_overflow && cnt != 0x7Fu && ovf != 0xFFFFFFFFu) {
+                  const uint32_t mb = bk.max_bits;
+                  const uint32_t data = (uint32_t)p.buf & (mb >= 32u ? 0xFFFFFFFFu : (1u << mb) - 1u);
+                  const uint32_t g = ovf + 2u * (node >> 8);
+                  for (uint32_t k = 0; k < cnt; ++k) {
+                    const uint32_t bits = s_prefix[g + 2u * k], vl = s_prefix[g + 2u * k + 1u], ln = vl & 0xFFu;
+                    if (bits == (data & ((1u << ln) - 1u))) {
+                      hit_val = vl >> 8;
+                      hit_len = ln;
+                      break;
+                    }
                   }
                 }
-              } else if ((node & 0x80u) == 0u && bk.has_overflow && cnt != 0x7Fu && ovf != 0xFFFFFFFFu) {
-                const uint32_t mb = bk.max_bits;
-                const uint32_t data = (uint32_t)p.buf & (mb >= 32u ? 0xFFFFFFFFu : (1u << mb) - 1u);
-                const uint32_t g = ovf + 2u * (node >> 8);
-                for (uint32_t k = 0; k < cnt; ++k) {
-                  const uint32_t bits = s_prefix[g + 2u * k], vl = s_prefix[g + 2u * k + 1u], ln = vl & 0xFFu;
-                  if (bits == (data & ((1u << ln) - 1u))) {
-                    hit_val = vl >> 8;
-                    hit_len = ln;
-                    break;
-                  }
+                if (hit_len == 0u || hit_len > 32u || hit_len > rem) {  // past the packet's end, a group outside LDS, no such code
+                  bail = true;
+                  NVH_WHY(6);
+                  break;
                 }
+                val = hit_val;
+                len = hit_len;
               }
-              // (the buffer is the packet zero-extended, which is what the reference peeks at: Codebook.cs:307-318, DataPacket.cs:168-205)
-              if (hit_len == 0u || hit_len > 32u || hit_len > rem) {  // past the packet's end, a group outside LDS, no such code
-                bail = true;
- NVH_WHY(6);
-                break;
+              p.buf >>= len;
+              p.avail -= len;
+              rem -= len;
+              if (p.avail <= 32u && p.next < p.nwords) {  // (one word restores br_fill's invariant: len <= 32)
+                const uint32_t word = p.ahead;
+                p.next++;
+                p.ahead = p.w[p.next];  // (index nwords at most: see br_word)
+                p.buf |= (uint64_t)word << p.avail;
+                p.avail += 32u;
               }
-              consume(hit_len);
-              stage_at(done) = (uint16_t)hit_val;
+              *reinterpret_cast<uint16_t*>(sp) = (uint16_t)val;
+              sp += (done & 1) ? sp_odd : 2;
               if (++done >= slots) break;
               node = s_prefix[toff + ((uint32_t)p.buf & pmask)];
             }
+            p.pos = p.total - rem;
 #ifdef NVH_DEBUG
             const long long fa2 = clock64();
             facc[1] += fa2 - fa1;
