@@ -1660,6 +1660,8 @@ k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPac
  NVH_WHY(2);
         if (!bail && partition_count > 0) {
           const NvhPBook class_book = books[r.class_book];
+          const bool class_lean = class_book.has_tree && class_book.lds_off != 0xFFFFFFFFu && class_book.prefix_bits >= 1 && class_book.prefix_bits <= 24;
+          const uint32_t class_pmask = (1u << (class_book.prefix_bits & 31)) - 1u, class_sdir = sub_words > 1 ? class_book.sub_dir : 0xFFFFFFFFu;
           const int last_base = T.cap_parts;
           auto cls_at = [&](const int i) -> uint8_t& { return s_cls[4 * ((i >> 2) * nt + tid) + (i & 3)]; };
           auto stage_at = [&](const int i) -> uint16_t& { return s_stage16[2 * ((i >> 1) * nt + tid) + (i & 1)]; };
@@ -1697,7 +1699,38 @@ k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPac
                 // positions in walk order (the tail kernel builds the heads from these rows)
                 const int p0 = known_end == 0 ? 0 : (r_chs == 1 ? pos : pos / r_chs);
                 for (int cc = 0; cc < r_chs; cc++) {
-                  const int idx = decode_scalar<false, false>(T, s_prefix, nullptr, class_book, p);
+                  // (the class word the way the entries are decoded -- prefix table, second-level table, whole code inside the
+                  // packet --, else the general decode: lanes reach their group boundaries in different steps of a wavefront, so a
+                  // class word's cost is paid up to once per lane and group, and the general decode's is ~2 k cycles)
+                  int idx = -1;
+                  if (class_lean) {
+                    const uint32_t node = s_prefix[class_book.lds_off + ((uint32_t)p.buf & class_pmask)], rem = p.total - p.pos;
+                    uint32_t val = node >> 8, len = node & 0x7Fu;
+                    bool ok = (node & 0x80u) != 0u && len <= rem;
+                    if (!ok && (node & 0x80u) == 0u && (node & 0x7Fu) != 0u && (node & 0x7Fu) != 0x7Fu && class_sdir != 0xFFFFFFFFu) {
+                      const uint32_t dw = s_sub[class_sdir + (node >> 8)];
+                      if (dw != 0u) {
+                        const uint32_t e = s_sub[(dw & 0xFFFFFFu) + ((uint32_t)(p.buf >> class_book.prefix_bits) & ((1u << (dw >> 24)) - 1u))];
+                        val = e >> 8;
+                        len = e & 0x7Fu;
+                        ok = (e & 0x80u) != 0u && len <= rem && len <= 32u;
+                      }
+                    }
+                    if (ok) {
+                      p.buf >>= len;
+                      p.avail -= len;
+                      p.pos += len;
+                      if (p.avail <= 32u && p.next < p.nwords) {
+                        const uint32_t word = p.ahead;
+                        p.next++;
+                        p.ahead = p.w[p.next];  // (index nwords at most: see br_word)
+                        p.buf |= (uint64_t)word << p.avail;
+                        p.avail += 32u;
+                      }
+                      idx = (int)val;
+                    }
+                  }
+                  if (idx < 0) idx = decode_scalar<false, false>(T, s_prefix, nullptr, class_book, p);
                   if (idx < 0 || idx >= r_partvals) {  // the packet ends here, or the reference would fault: not this kernel's
                     bail = true;
                     NVH_WHY(3);
