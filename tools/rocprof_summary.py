@@ -18,8 +18,8 @@ def kernels_from_trace(path):
     # only the full-size launches of each kernel (bench.py also runs a one-frame priming batch)
     rows = cur.execute("select name, count(*), avg(duration), min(duration), max(duration), max(vgpr_count), "
                        "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) "
-                       "from kernels k where grid_x = (select max(grid_x) from kernels k2 where k2.name = k.name) "
-                       "group by name order by sum(duration) desc").fetchall()
+                       "from kernels k join (select name n, max(grid_x) g from kernels group by name) m on k.name = m.n and k.grid_x = m.g "
+                       "group by name order by sum(duration) desc").fetchall()  # (a join, not a correlated subquery: minutes -> seconds)
     out = {}
     for r in rows:
         out[r[0]] = dict(calls=r[1], avg_us=r[2] / 1e3, min_us=r[3] / 1e3, max_us=r[4] / 1e3, vgpr=r[5], agpr=r[6], sgpr=r[7],
@@ -29,9 +29,9 @@ def kernels_from_trace(path):
 
 def counter_avg(path, counter):
     cur = sqlite3.connect(path).cursor()
-    rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection c where counter_name=? and "
-                       "grid_size_x = (select max(grid_size_x) from counters_collection c2 where c2.kernel_name = c.kernel_name) "
-                       "group by kernel_name", (counter,)).fetchall()
+    rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection c join "
+                       "(select kernel_name n, max(grid_size_x) g from counters_collection group by kernel_name) m "
+                       "on c.kernel_name = m.n and c.grid_size_x = m.g where counter_name=? group by kernel_name", (counter,)).fetchall()
     return {r[0]: (r[1], r[2]) for r in rows}
 
 
