@@ -527,3 +527,21 @@ def test_lacing_only_index_equals_the_checked_demultiplex(ogg_bytes):
         pa = demux_ogg_array(two, k)
         qa, payload = index_ogg_array(two, k)
         assert len(pa) == len(qa) and payload == int(pa.offsets[-1])
+
+
+def test_clmul_page_checksum_equals_the_table(tmp_path):
+    """Ogg/Crc.cs:5-40 (polynomial 0x04c11db7, most significant bit first): the library checks pages by carry-less multiplication
+    where the CPU has it (host_ogg.cpp: crc_clmul -- the corpus pass checks 3.3 GB of pages inside its timed region) and by the
+    eight-byte table otherwise; tools/crc_check.cpp includes the source and compares the two on random buffers (lengths around
+    the 16- and 64-byte block sizes, up to a maximal page, random initial values)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    if "pclmul" not in open("/proc/cpuinfo").read():
+        pytest.skip("no pclmul on this CPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "crc_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "nvorbis_amd", "csrc"), os.path.join(root, "tools", "crc_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("0 of "), out.stdout
