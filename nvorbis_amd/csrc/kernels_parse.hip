@@ -11,9 +11,15 @@
 // What stays on the host in this mode is the per-stream integer state machine (Mode.GetPacketInfo, overlap
 // geometry, sample positions): it needs the packet type, the mode number and the two window flags only.
 //
-// Huffman decoding is sequential inside a packet, so the parallelism is across packets (64 per wavefront, all
-// divergent).  Per-lane state is a 64-bit bit buffer refilled by aligned word loads (the host aligns and zero-pads
-// every packet), the tables come through L2.  Output goes to fixed-capacity per-frame slabs.
+// Huffman decoding is sequential inside a packet, so the parallelism is across packets.  Per-lane state is a 64-bit bit
+// buffer refilled by aligned word loads (the host aligns and zero-pads every packet); the hot tables lie in LDS.  Output
+// goes to fixed-capacity per-frame slabs.  The forms (nvh_launch.hip: batch_upload_gpu picks one per batch):
+//   k_parse_slab_u       one packet per wavefront, wave-uniform control flow (batches of up to 4096 packets)
+//   k_parse_slab_f       several packets per wavefront, one cursor per lane through the residue walk, ordinary packets only;
+//   + k_parse_slab_c       the general body over the frames _f left (packets that end inside the residue, faults, other shapes)
+//   + k_parse_slab_t       the rest of the slab (heads, entries, floors, header), one wavefront per packet
+//   k_parse_slab / _g    several packets per wavefront in lockstep through the reference's loop nest (rounds 3-5; NVH_PARSE_CUR=0)
+//   k_parse / _g         descriptors instead of slabs, for the stream shapes outside the slab kernels' contract
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -1655,9 +1661,10 @@ k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPac
                                         : (r_rch > 1 ? (int)__umulhi((uint32_t)last_off, r.rch_magic) + (int)__umulhi((uint32_t)(span - 1), r.rch_magic)
                                                      : last_off + span - 1) < T.block1;
         if (cdim == 0 || r_stages == 0 || (r_type != 1 && r_type != 2) || dm_lds == 0xFFFFFFFFu || vis_lds == 0xFFFFFFFFu || !inside ||
-            partition_count > 0xFFFF || r_chs * partition_count > T.cap_parts || span < 1)
+            partition_count > 0xFFFF || r_chs * partition_count > T.cap_parts || span < 1) {
           bail = true;
- NVH_WHY(2);
+          NVH_WHY(2);
+        }
         if (!bail && partition_count > 0) {
           const NvhPBook class_book = books[r.class_book];
           const bool class_lean = class_book.has_tree && class_book.lds_off != 0xFFFFFFFFu && class_book.prefix_bits >= 1 && class_book.prefix_bits <= 24;
@@ -1777,7 +1784,7 @@ k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPac
             if (!going) break;
             if (run0 > (uint32_t)T.cap_ops) {
               bail = true;
- NVH_WHY(4);
+              NVH_WHY(4);
               break;
             }
             // ---- one visit: the entries of a vector (Residue0.cs:157-170) from its descriptor ----
@@ -1786,7 +1793,7 @@ k_parse_slab_f(NvhDevParse T, const uint8_t* __restrict__ pkt_pool, const NvhPac
             const int slots = (int)(V.y & 0xFFFFu);
             if (V.x >= NVH_PVIS_SLOW || slots > NVH_PSTG || nent + (uint32_t)slots > (uint32_t)T.cap_ent) {
               bail = true;
- NVH_WHY(5);
+              NVH_WHY(5);
               break;
             }
             const uint32_t toff = V.x & 0xFFFFFFu, pmask = (1u << (V.x >> 24)) - 1u;
