@@ -439,13 +439,11 @@ def test_fallback_kernel_paths_bit_exact(toggle):
     for t in toggle.split("+"):  # "A+B": both switches (slab kernels fed by the GPU packet parser)
         env[t] = "1"
     env["NVH_TEST_CHILD"] = "1"
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = [os.path.join(root, "tests", "test_gpu_parity.py")]
+    from tests.replay import run_children
+    children = [(["test_gpu_parity.py"], env, [])]
     if toggle in ("NVH_EMIT_ALWAYS", "NVH_NO_EMIT", "NVH_NO_EMIT8", "NVH_NO_SLAB"):
-        files.append(os.path.join(root, "tests", "test_full_depth.py"))
-    r = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
+        children.append((["test_full_depth.py"], env, []))  # (a second child beside the first)
+    run_children(children, timeout=900)
 
 
 def _level1_in_mapping_order(oracle, gpu_ctx, pk, pick):

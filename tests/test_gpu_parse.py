@@ -240,12 +240,8 @@ def test_multi_packet_parser_forms_bit_exact(form):
         k, v = t.split("=")
         env[k] = v
     env["NVH_TEST_CHILD"] = "1"
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    base = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"]
-    r = subprocess.run(base + [os.path.join(root, "tests", "test_gpu_parse.py")], cwd=root, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
-    env["NVH_GPU_PARSE"] = "1"
-    r = subprocess.run(base + [os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_full_depth.py")],
-                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
-    assert r.returncode == 0, r.stdout[-3000:]
+    from tests.replay import run_children
+    env_gp = dict(env)
+    env_gp["NVH_GPU_PARSE"] = "1"
+    # (three children side by side: this file, the parity suite GPU-parsed, the full-depth configs GPU-parsed)
+    run_children([(["test_gpu_parse.py"], env, []), (["test_gpu_parity.py"], env_gp, []), (["test_full_depth.py"], env_gp, [])])
