@@ -545,3 +545,30 @@ def test_clmul_page_checksum_equals_the_table(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "nvorbis_amd", "csrc"), os.path.join(root, "tools", "crc_check.cpp"), "-o", exe])
     out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("0 of "), out.stdout
+
+
+def test_committed_profiles_belong_to_the_committed_sources():
+    """profiles/traffic.json (the PMC passes behind bench.py's `roofline.traffic`) and the committed bench lines of the closing build
+    carry the source hash of the library they were taken with (nvorbis_amd/build.py: every file under csrc/, the public header, the
+    flags).  It must be the hash of the sources in the tree: numbers of another build are not this build's numbers.  (A change under
+    csrc/ or include/ makes this fail until tools/round6_profiles.sh has run on the GPU box again -- that is the point.)"""
+    import json
+    from nvorbis_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = "nvh-src-hash=" + build.source_hash()
+    traffic = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert traffic["build"].endswith(want), (traffic["build"], want)
+    assert "k_synth_group2" in traffic["kernels"]
+    for name in ("r06_bench.json", "r06_bench_b.json"):
+        line = json.loads(open(os.path.join(root, "profiles", name)).read().strip().splitlines()[-1])
+        assert line["build"].endswith(want), (name, line["build"], want)
+        assert line["roofline"]["traffic_build_matches"] is True and line["pcm_digest_ok"] is True
+        # the line's own arithmetic: value = frames of the timed region / its duration; frac = algorithmic bytes / duration / peak
+        c = line["config"]
+        frames = c["frames_per_gpu"] * c["passes_per_step"] * line["steps"]
+        assert abs(line["value"] - frames / c["timed_region_s"]) < 1e-6 * line["value"]
+        r = line["roofline"]
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 8000.0
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        assert r["algorithmic_bytes_per_launch"] == 2048 * 2 * (1024 * 4 + 1024 * 4)  # SURVEY 8(d): n/2 floats in, n/2 out per channel-frame
+        assert 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.10  # PMC bytes per launch: no wasted re-reads
