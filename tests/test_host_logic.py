@@ -559,7 +559,7 @@ def test_committed_profiles_belong_to_the_committed_sources():
     traffic = json.load(open(os.path.join(root, "profiles", "traffic.json")))
     assert traffic["build"].endswith(want), (traffic["build"], want)
     assert "k_synth_group2" in traffic["kernels"]
-    for name in ("r06_bench.json", "r06_bench_b.json"):
+    for name in ("r06_bench.json", "r06_bench_b.json", "r06_bench_driver.json"):
         line = json.loads(open(os.path.join(root, "profiles", name)).read().strip().splitlines()[-1])
         assert line["build"].endswith(want), (name, line["build"], want)
         assert line["roofline"]["traffic_build_matches"] is True and line["pcm_digest_ok"] is True
