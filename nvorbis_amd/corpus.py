@@ -456,34 +456,48 @@ def _run_pool(n_items, workers, device, fn, need_ctx=True, keep_contexts=False, 
     return errors
 
 
-def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False, keep_contexts=False, timings=None, tune_process=False):
-    """Decode .ogg byte strings on ONE GPU into ONE device arena: returns (arena, views) with views[i] the interleaved
-    float32 PCM of files[i] as a slice of `arena` (torch tensors on cuda:<device>), files back to back in list order.
-
-    Two passes over the worker pool: a geometry-only index of every stream (nvh_stream_index_packets: packet type, mode
-    number, window flags -- how many samples the serial decoder emits), which sizes the arena; then the decode, whose
-    overlap-add kernels write each batch's PCM at its final address (nvh_stream_synth with a device destination).  No
-    PCM crosses PCIe.  tune_process: see _tune_malloc (process-wide, opt-in)."""
-    import torch
-
-    from .reader import Context, Stream, demux_ogg_array, index_ogg_array
+def _index_pass(files, workers, full_index=False):
+    """The host-only sizing pass of decode_files_to_device over a pool of threads: (shape, totals, chans, errors) -- per file what
+    the index saw of it (packets, payload bytes), the floats its decode emits, its channels; errors as _run_pool returns them."""
+    from .reader import Stream, demux_ogg_array, index_ogg_array
     n = len(files)
     shape = [None] * n  # what the index saw of file i: (packets, payload bytes) -- the decode pass's full demultiplex must agree
     totals = [0] * n
     chans = [1] * n
-    full_index = bool(os.environ.get("NVH_CORPUS_FULL_INDEX"))  # A/B aid: the round-5 index (checksums + a copy of every packet)
+
+    # Host-only streams of the index pass, per thread and per distinct header triple: nvh_stream_index_packets does not touch the
+    # stream's state, and the files of a corpus mostly share their encoder's headers -- one open per thread instead of one per file
+    # (five library calls per file become two: the pass is a pool of Python threads, and what bounds it is how often they hand
+    # the interpreter lock to each other, not the calls' work: C5's 1004 files on the build box, 4 / 8 threads: 0.33 / 0.55 -> 0.22 / 0.33 s;
+    # on a GPU box's 16 CPUs the pass is flat from six threads on -- tools/index_sweep.py: 0.35 s on one thread, 0.081 on six, 0.098 on sixteen).
+    import threading
+    tl = threading.local()
+    opened, opened_lock = [], threading.Lock()
 
     def index_one(i, ctx):
         # Lacing-only index (reader.index_ogg_array / nvh_ogg_index_packets): page headers and lacing values give the packet list,
         # one byte per packet its block size, the page granule positions the length -- no checksum, no copy of the packets (1 % of the
         # file is read instead of all of it twice).  The checksums are the decode pass's, where the packets are needed anyway.
         def measure(pa):
-            st = Stream(None, pa[0], pa[1], pa[2])
+            key = (pa[0], pa[1], pa[2])
+            cache = getattr(tl, "streams", None)
+            if cache is None:
+                cache = tl.streams = {}
+            st = cache.get(key)
+            own = st is None
+            if own:
+                st = Stream(None, key[0], key[1], key[2])
+                if len(cache) < 8:
+                    cache[key] = st
+                    own = False
+                    with opened_lock:
+                        opened.append(st)
             try:
-                totals[i] = int(st.index_packets(pa, 3)[3]) * st.channels
+                totals[i] = int(st.index_total(pa, 3)) * st.channels
                 chans[i] = st.channels
             finally:
-                st.close()
+                if own:
+                    st.close()
 
         if not full_index:
             try:
@@ -496,6 +510,34 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
         pa = demux_ogg_array(files[i])
         measure(pa)
         shape[i] = (len(pa), int(pa.offsets[-1]))
+
+    def close_index_streams():
+        with opened_lock:
+            sts, opened[:] = list(opened), []
+        for st in sts:
+            try:
+                st.close()
+            except Exception:
+                pass
+
+    errors = _run_pool(n, workers, 0, index_one, need_ctx=False)  # host-only: no GPU context per thread
+    close_index_streams()
+    return shape, totals, chans, errors
+
+
+def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_parse=False, keep_contexts=False, timings=None, tune_process=False):
+    """Decode .ogg byte strings on ONE GPU into ONE device arena: returns (arena, views) with views[i] the interleaved
+    float32 PCM of files[i] as a slice of `arena` (torch tensors on cuda:<device>), files back to back in list order.
+
+    Two passes over the worker pool: a geometry-only index of every stream (nvh_stream_index_packets: packet type, mode
+    number, window flags -- how many samples the serial decoder emits), which sizes the arena; then the decode, whose
+    overlap-add kernels write each batch's PCM at its final address (nvh_stream_synth with a device destination).  No
+    PCM crosses PCIe.  tune_process: see _tune_malloc (process-wide, opt-in)."""
+    import torch
+
+    from .reader import Context, Stream, demux_ogg_array, index_ogg_array
+    n = len(files)
+    full_index = bool(os.environ.get("NVH_CORPUS_FULL_INDEX"))  # A/B aid: the round-5 index (checksums + a copy of every packet)
 
     import time
     if tune_process or os.environ.get("NVH_CORPUS_MALLOPT"):  # process-wide allocator settings: opt-in (see _tune_malloc)
@@ -511,8 +553,8 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
     if n and not os.environ.get("NVH_CORPUS_NO_WARM"):  # the GPU side of the workers gets ready while the index pass keeps the CPUs busy
         sample = max(range(n), key=lambda i: len(files[i]))
         # (a pool of GPU-parse workers may be twice the CPUs -- its threads wait for the GPU most of the time --; the index pass
-        # is host work: as many threads as CPUs, and as many contexts warmed beside it -- 32 of each on a 16-CPU box made a
-        # fresh process's index pass 0.14 -> 0.49 s.  The pool's other threads make their contexts themselves.)
+        # is host work on a few threads (below), with as many contexts as CPUs warmed beside it -- 32 index threads and 32 contexts on a
+        # 16-CPU box made a fresh process's index pass 0.14 -> 0.49 s.  The pool's other threads make their contexts themselves.)
         budget = _cpu_budget()
         nwarm = max(1, min(workers, n))
         if not keep:
@@ -520,7 +562,9 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
         warm_thread, warm = _warm_contexts(device, nwarm, files[sample], batch_frames, gpu_parse, lanes,
                                            _WORKER_CONTEXTS.get(device) if keep else None)
     arena_thread, arena_box = (None, [None]) if (not n or os.environ.get("NVH_CORPUS_NO_WARM")) else _early_arena(files, device)
-    errors = _run_pool(n, min(workers, max(8, _cpu_budget())), device, index_one, need_ctx=False)  # host-only: no GPU context per thread
+    # (host-only, no GPU context per thread; three eighths of the CPUs: beyond that its threads only wait for the interpreter lock,
+    # and the context warm-up and the arena allocation beside it want cores too)
+    shape, totals, chans, errors = _index_pass(files, min(workers, max(4, (3 * _cpu_budget()) // 8)), full_index)
     if arena_thread is not None:
         arena_thread.join()
     if errors:
@@ -621,7 +665,7 @@ def decode_files_to_device(files, device=0, workers=16, batch_frames=4096, gpu_p
                 pa = demux_ogg_array(files[i])
                 st = Stream(None, pa[0], pa[1], pa[2])
                 try:
-                    tot = int(st.index_packets(pa, 3)[3]) * st.channels
+                    tot = int(st.index_total(pa, 3)) * st.channels
                 finally:
                     st.close()
                 own = torch.empty(max(tot, 1), dtype=torch.float32, device="cuda:%d" % device)

@@ -7,6 +7,7 @@ parsed a batch ahead on the host and synthesised on the GPU one batch per launch
 is drained by the reads.  Python stands in for the C# shim of INTEGRATION.md (no .NET in this image).
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -96,6 +97,9 @@ def demux_ogg_array(data: bytes, stream_index=0, forward_only=False):
     return PacketArray(pk, offs[:n.value + 1], gran, flags)
 
 
+_index_scratch = threading.local()  # index_ogg_array: the calling thread's output arrays
+
+
 def index_ogg_array(data: bytes, stream_index=0):
     """The index form of demux_ogg_array (nvh_ogg_index_packets): the stream's packet list without page checksums and packet
     bodies -- the three headers whole, every audio packet as its first (up to) 8 bytes -- as (PacketArray, payload_bytes); what a
@@ -110,20 +114,27 @@ def index_ogg_array(data: bytes, stream_index=0):
     # lacing values of 0..254 end one, so len / 27 + len / 64 is far beyond any audio stream -- the call says so if it is not
     cap_n = len(data) // 48 + 64
     cap_b = min(len(data), 8 * cap_n + (1 << 16)) + 64
+    # The call writes into scratch arrays of the calling thread, kept from file to file (a pool of index threads would otherwise
+    # allocate and release four arrays of up to a megabyte per file side by side: the pass then does not scale with its threads --
+    # 502 corpus files: 0.22 s on one thread, 0.22 s on eight; with the scratch 0.04 s on eight); what the call filled is copied out.
+    sc = getattr(_index_scratch, "arrays", None)
     for _ in range(2):
-        pk = np.empty(cap_b, dtype=np.uint8)
-        offs = np.empty(cap_n + 1, dtype=np.int64)
-        gran = np.empty(cap_n, dtype=np.int64)
-        flags = np.empty(cap_n, dtype=np.uint8)
+        if sc is None or sc[0].size < cap_b or sc[2].size < cap_n:
+            grow_n = max(cap_n, 2 * sc[2].size if sc is not None else 0)
+            grow_b = max(cap_b, 2 * sc[0].size if sc is not None else 0)
+            sc = (np.empty(grow_b, dtype=np.uint8), np.empty(grow_n + 1, dtype=np.int64), np.empty(grow_n, dtype=np.int64),
+                  np.empty(grow_n, dtype=np.uint8))
+            _index_scratch.arrays = sc
+        pk, offs, gran, flags = sc
         rc = L.nvh_ogg_index_packets(C.c_void_p(src.ctypes.data), len(data), int(stream_index), pk.ctypes.data, pk.size, offs.ctypes.data,
-                                     gran.ctypes.data, flags.ctypes.data, cap_n, C.byref(n), C.byref(total), C.byref(payload), None)
-        if rc == native.ERR_ARGUMENT and (n.value > cap_n or total.value > cap_b):
+                                     gran.ctypes.data, flags.ctypes.data, gran.size, C.byref(n), C.byref(total), C.byref(payload), None)
+        if rc == native.ERR_ARGUMENT and (n.value > gran.size or total.value > pk.size):
             cap_n, cap_b = n.value + 1, total.value + 64
             continue
         check(rc, "nvh_ogg_index_packets")
         break
     m = n.value
-    return PacketArray(pk[:max(total.value, 1)], offs[:m + 1].copy(), gran[:max(m, 1)].copy(), flags[:max(m, 1)].copy()), int(payload.value)
+    return PacketArray(pk[:max(total.value, 1)].copy(), offs[:m + 1].copy(), gran[:max(m, 1)].copy(), flags[:max(m, 1)].copy()), int(payload.value)
 
 
 def demux_ogg(data: bytes, forward_only=False):
@@ -389,6 +400,16 @@ class Stream:
                                              pa.granules[first:].ctypes.data if n else None, pa.flags[first:].ctypes.data if n else None,
                                              n, pos.ctypes.data, em.ctypes.data, st.ctypes.data, C.byref(total)), "nvh_stream_index_packets")
         return pos[:n], em[:n], st[:n], total.value
+
+    def index_total(self, pa, first=3):
+        """total_emitted of index_packets alone (the per-packet outputs of nvh_stream_index_packets may be NULL): what a sizing pass
+        asks, without three arrays per file."""
+        n = max(0, len(pa) - first)
+        total = C.c_int64(0)
+        check(lib().nvh_stream_index_packets(self._h, pa.data.ctypes.data, pa.offsets[first:].ctypes.data if n else pa.offsets.ctypes.data,
+                                             pa.granules[first:].ctypes.data if n else None, pa.flags[first:].ctypes.data if n else None,
+                                             n, None, None, None, C.byref(total)), "nvh_stream_index_packets")
+        return total.value
 
     def packet_sample_count(self, packet, is_resync=False):
         """StreamDecoder.GetPacketGranules (StreamDecoder.cs:630-647)."""

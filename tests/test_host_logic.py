@@ -459,6 +459,34 @@ def test_pcm_upper_bound_covers_what_the_decoder_emits(oracle, ogg_bytes):
     assert corpus._pcm_upper_bound([files[0], b""]) is None
 
 
+def test_index_pass_totals_equal_the_oracle_lengths(oracle, ogg_bytes):
+    """corpus._index_pass (the sizing pass of decode_files_to_device: lacing-only page walk, packet geometry through host-only streams
+    that a thread keeps per distinct header triple): every file's float count equals the length of the oracle's decode, its channel
+    count the identification header's, its (packets, payload bytes) what the checked demultiplex finds -- on one thread and on four
+    (streams reused across files and threads), files in any order, and with a file whose first page is damaged in between (the
+    index then takes the checked demultiplex's word, ogg page CRC and all)."""
+    from nvorbis_amd import corpus
+    from nvorbis_amd.reader import demux_ogg_array
+    from tests import c5_corpus
+    ws = c5_corpus.writer_setup()
+    good = [ogg_bytes[k] for k in ("1test", "2test", "3test", "issue6test")] + [c5_corpus.corpus_file(ws, i, 0.02) for i in range(6)]
+    files = good + good[::-1] + good[4:]  # the writer files share their headers: the per-thread stream cache is hit
+    want = []
+    for data in files:
+        pcm, info = oracle.decode_ogg(data)
+        pa = demux_ogg_array(data)
+        want.append((pcm.size, info["channels"], (len(pa), int(pa.offsets[-1]))))
+    for workers in (1, 4):
+        shape, totals, chans, errors = corpus._index_pass(files, workers)
+        assert not errors
+        assert [(t, c, sh) for t, c, sh in zip(totals, chans, shape)] == want, workers
+    shape_f, totals_f, chans_f, errors = corpus._index_pass(files, 3, full_index=True)  # the round-5 index: checksums + packet copies
+    assert not errors and (shape_f, totals_f, chans_f) == (shape, totals, chans)
+    # not an Ogg file: an error for that file, the others unaffected
+    shape, totals, chans, errors = corpus._index_pass([good[0], b"junk" * 64, good[5]], 2)
+    assert [i for i, _ in errors] == [1] and totals[0] == want[0][0] and totals[2] == want[5][0]
+
+
 def test_demux_in_one_call_equals_the_sizing_and_fill_calls(ogg_bytes):
     """reader.demux_ogg_array hands the library buffers sized from the file and gets the packets in one call; the two-call form
     (sizing call, then fill call: what a caller without a bound uses, and the fallback) yields the same arrays."""
